@@ -1,0 +1,392 @@
+"""CPU oracle for the DeepLip audio-visual embedding hot path.   *** TEST INFRASTRUCTURE ***
+
+This file is the checker, never the product: only ``tests/``, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing under ``deeplip_amd/`` does.
+
+It is a plain functional restatement (torch-CPU / numpy, eval mode, fp32) of the reference
+algorithm, written from the reference's source text; each function cites the file:line it
+follows (paths relative to the reference repo root).  The arithmetic primitives the reference
+itself delegates to third-party code (PyTorch ATen conv / batch-norm / linear / std;
+scikit-learn ``roc_curve``; SciPy ``brentq`` / ``interp1d``; versions unpinned upstream, see
+SURVEY.md §8c) are called from the versions installed in this image (torch 2.10.0, numpy 2.2,
+scipy 1.15, scikit-learn 1.7).
+
+Pinning: the reference holds no tests, golden vectors or fixtures for this path,
+so the oracle is pinned against outputs of the reference's own model classes run in the build
+container: ``tests/golden/capture_golden.py`` imports them from /root/reference, fills them with
+the name-keyed deterministic weights of ``deeplip_amd.weightgen`` and commits the outputs as
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every function below against
+those vectors.  Pieces whose reference module cannot be imported anywhere (``LowFER`` ctor needs
+a CUDA device; ``models/fusion_models/utils.py`` needs kaldiio) follow the source text and are
+marked "parity unpinned (source-text only)".
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Mapping[str, Tensor]
+
+BN_EPS = 1e-5  # torch.nn.BatchNorm{1,2,3}d default, used everywhere in the reference
+
+
+def to_torch_sd(sd: Mapping[str, np.ndarray]) -> Dict[str, Tensor]:
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+def _bn(x: Tensor, sd: SD, p: str) -> Tensor:
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
+                        sd[p + ".bias"], training=False, eps=BN_EPS)
+
+
+def _act(x: Tensor, sd: SD, p: str, relu_type: str) -> Tensor:
+    # nn.PReLU(num_parameters=C) or nn.ReLU  (resnet.py:41-46, model.py:79)
+    return F.prelu(x, sd[p + ".weight"]) if relu_type == "prelu" else F.relu(x)
+
+
+# ----------------------------------------------------------------------------------------
+# Video encoder: models/video_models/model.py:61-105, resnet.py:28-127
+# ----------------------------------------------------------------------------------------
+def frontend3d(sd: SD, x: Tensor, relu_type: str = "prelu", taps: Optional[dict] = None) -> Tensor:
+    """model.py:80-85: Conv3d(1,64,(5,7,7),s(1,2,2),p(2,3,3),no bias) -> BN3d -> PReLU(64)|ReLU
+    -> MaxPool3d((1,3,3), s(1,2,2), p(0,1,1)).  x [B,1,T,88,88] -> [B,64,T,22,22]."""
+    y = F.conv3d(x, sd["frontend3D.0.weight"], None, stride=(1, 2, 2), padding=(2, 3, 3))
+    y = _bn(y, sd, "frontend3D.1")
+    y = _act(y, sd, "frontend3D.2", relu_type)
+    if taps is not None:
+        taps["stem_act"] = y
+    y = F.max_pool3d(y, kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+    return y
+
+
+def basic_block(sd: SD, p: str, x: Tensor, stride: int, relu_type: str) -> Tensor:
+    """resnet.py:55-69: conv3x3(stride)-bn1-relu1-conv3x3-bn2, += residual (1x1 stride conv + BN
+    when a downsample exists, resnet.py:13-17), relu2."""
+    out = F.conv2d(x, sd[p + ".conv1.weight"], None, stride=stride, padding=1)
+    out = _bn(out, sd, p + ".bn1")
+    out = _act(out, sd, p + ".relu1", relu_type)
+    out = F.conv2d(out, sd[p + ".conv2.weight"], None, stride=1, padding=1)
+    out = _bn(out, sd, p + ".bn2")
+    if (p + ".downsample.0.weight") in sd:
+        res = F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride=stride, padding=0)
+        res = _bn(res, sd, p + ".downsample.1")
+    else:
+        res = x
+    out = out + res
+    return _act(out, sd, p + ".relu2", relu_type)
+
+
+def resnet18_trunk(sd: SD, x: Tensor, relu_type: str = "prelu", taps: Optional[dict] = None,
+                   prefix: str = "trunk") -> Tensor:
+    """resnet.py:119-127 with layers [2,2,2,2], planes 64/128/256/512, strides 1/2/2/2
+    (resnet.py:79-82,100-115); AdaptiveAvgPool2d(1); flatten.  [N,64,22,22] -> [N,512]."""
+    for li, stride in ((1, 1), (2, 2), (3, 2), (4, 2)):
+        for bi in range(2):
+            x = basic_block(sd, f"{prefix}.layer{li}.{bi}", x, stride if bi == 0 else 1, relu_type)
+        if taps is not None:
+            taps[f"layer{li}"] = x
+    x = F.adaptive_avg_pool2d(x, 1)
+    return x.reshape(x.size(0), -1)
+
+
+def lipreading_features(sd: SD, x: Tensor, relu_type: str = "prelu", taps: Optional[dict] = None) -> Tensor:
+    """Lipreading.forward with extract_feats=True (model.py:96-105): stem -> threeD_to_2D_tensor
+    (model.py:9-13) -> trunk -> view(B, T, 512)."""
+    B, C, T, H, W = x.shape
+    y = frontend3d(sd, x, relu_type, taps)
+    if taps is not None:
+        taps["stem"] = y
+    Tn = y.shape[2]
+    y = y.transpose(1, 2).reshape(B * Tn, y.shape[1], y.shape[3], y.shape[4])
+    y = resnet18_trunk(sd, y, relu_type, taps)
+    return y.view(B, Tn, y.size(1))
+
+
+def _cbcr(sd: SD, p: str, x: Tensor, k: int, dilation: int, relu_type: str) -> Tensor:
+    """ConvBatchChompRelu (tcn.py:28-59, dwpw=False): Conv1d(pad=(k-1)*d, dilation d, bias) ->
+    BN1d -> symmetric Chomp1d(pad) (tcn.py:12-25) -> PReLU|ReLU."""
+    pad = (k - 1) * dilation
+    out = F.conv1d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], stride=1, padding=pad, dilation=dilation)
+    out = _bn(out, sd, p + ".batchnorm")
+    if pad > 0:
+        out = out[:, :, pad // 2: -pad // 2].contiguous()
+    return _act(out, sd, p + ".non_lin", relu_type)
+
+
+def ms_tcn_head(sd: SD, feats: Tensor, lengths: Sequence[int], kernel_sizes: Sequence[int] = (3, 5, 7),
+                num_layers: int = 4, relu_type: str = "prelu", prefix: str = "tcn") -> Tensor:
+    """MultiscaleMultibranchTCN.forward (model.py:31-37) in eval mode (dropout = identity):
+    4 x MultibranchTemporalBlock (tcn.py:64-116; dilation 2**i, tcn.py:126-134) ->
+    _average_batch masked mean over [0:length] (model.py:16-17) -> Linear (model.py:27).
+    feats [B,T,512] -> logits [B,num_classes]."""
+    x = feats.transpose(1, 2)
+    nk = len(kernel_sizes)
+    for i in range(num_layers):
+        p = f"{prefix}.mb_ms_tcn.network.{i}"
+        d = 2 ** i
+        out0 = torch.cat([_cbcr(sd, f"{p}.cbcr0_{j}", x, k, d, relu_type) for j, k in enumerate(kernel_sizes)], 1)
+        out1 = torch.cat([_cbcr(sd, f"{p}.cbcr1_{j}", out0, k, d, relu_type) for j, k in enumerate(kernel_sizes)], 1)
+        if (p + ".downsample.weight") in sd:  # tcn.py:87: always true for the shipped config
+            res = F.conv1d(x, sd[p + ".downsample.weight"], sd[p + ".downsample.bias"])
+        else:
+            res = x
+        x = _act(out1 + res, sd, p + ".relu_final", relu_type)
+    pooled = torch.stack([torch.mean(x[b][:, 0:int(l)], 1) for b, l in enumerate(lengths)], 0)
+    return F.linear(pooled, sd[prefix + ".tcn_output.weight"], sd[prefix + ".tcn_output.bias"])
+
+
+def lipreading_logits(sd: SD, x: Tensor, lengths: Sequence[int], relu_type: str = "prelu",
+                      kernel_sizes: Sequence[int] = (3, 5, 7), num_layers: int = 4) -> Tensor:
+    """Lipreading.forward with extract_feats=False (model.py:105)."""
+    return ms_tcn_head(sd, lipreading_features(sd, x, relu_type), lengths, kernel_sizes, num_layers, relu_type)
+
+
+def video_time_mean(feats: Tensor) -> Tensor:
+    """train_fusion.py:274,348: torch.mean(model_video(v)[1,T,512].squeeze(-3), dim=0), batched."""
+    return feats.mean(dim=1)
+
+
+def video_group_mean(clip_means: Tensor, group_ptr: Sequence[int]) -> Tensor:
+    """train_fusion.py:272-275,346-349: em = sum over the utterance's clip files / len(group).
+    ``group_ptr`` is CSR offsets into clip_means [G,512] -> [U,512]."""
+    out = []
+    for u in range(len(group_ptr) - 1):
+        seg = clip_means[group_ptr[u]:group_ptr[u + 1]]
+        em = 0
+        for row in seg:
+            em = em + row
+        out.append(em / len(seg))
+    return torch.stack(out)
+
+
+# ----------------------------------------------------------------------------------------
+# Audio encoder: models/audio_models/tdnn.py:7-111, pooling.py:7-26,73-107
+# ----------------------------------------------------------------------------------------
+def tdnn_dilation(context: Sequence[int]) -> Tuple[int, int]:
+    """tdnn.py:18-22: kernel = len(context); dilation = (last-first)//(k-1) or 1."""
+    k = len(context)
+    d = (context[-1] - context[0]) // (k - 1) if k > 1 else 1
+    return k, d
+
+
+def tdnn_block(sd: SD, p: str, x: Tensor, context: Sequence[int], bn_first: bool = True) -> Tensor:
+    """TDNN_Block.forward (tdnn.py:35-43): Conv1d(no padding, bias) then BN->LeakyReLU(0.2)
+    or LeakyReLU->BN."""
+    _, d = tdnn_dilation(context)
+    x = F.conv1d(x, sd[p + ".context_layer.weight"], sd[p + ".context_layer.bias"], dilation=d)
+    if bn_first:
+        return F.leaky_relu(_bn(x, sd, p + ".bn"), 0.2)
+    return _bn(F.leaky_relu(x, 0.2), sd, p + ".bn")
+
+
+def mean_std_pooling(x: Tensor) -> Tensor:
+    """MeanStdPooling.forward (pooling.py:24-26): cat(mean(x,2), std(x,2)); torch.std is the
+    unbiased (N-1) estimator."""
+    return torch.cat([torch.mean(x, dim=2), torch.std(x, dim=2)], dim=1)
+
+
+def attentive_stat_pooling(sd: SD, p: str, x: Tensor) -> Tensor:
+    """AttentiveStatPooling.forward (pooling.py:87-107)."""
+    W, b, v, k = sd[p + ".W"], sd[p + ".b"], sd[p + ".v"], sd[p + ".k"]
+    hidden = W.matmul(x).transpose(1, 2) + b
+    e = F.relu(hidden).matmul(v) + k
+    alpha = F.softmax(e, dim=1)
+    mean = torch.matmul(x, alpha).squeeze(-1)
+    std = torch.sqrt(torch.matmul(x * x, alpha).squeeze(-1) - mean * mean)
+    return torch.cat([mean, std], dim=1)
+
+
+def speaker_tdnn_stack(sd: SD, x: Tensor, context: Sequence[Sequence[int]], bn_first: bool = True) -> Tensor:
+    for i, ctx in enumerate(context):
+        x = tdnn_block(sd, f"tdnn.{i}", x, ctx, bn_first)
+    return x
+
+
+def speaker_extract_embedding(sd: SD, x: Tensor, context: Sequence[Sequence[int]], bn_first: bool = True,
+                              pooling: str = "statistic", taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+    """SpeakerEmbNet.extract_embedding (tdnn.py:89-101): tdnn stack -> pooling -> squeeze_(1)
+    -> fc1 (= x_a) -> BN/LReLU -> fc2 (= xv)."""
+    h = speaker_tdnn_stack(sd, x, context, bn_first)
+    if taps is not None:
+        taps["tdnn_out"] = h
+    if pooling == "statistic":
+        h = mean_std_pooling(h)
+    elif pooling == "average":
+        h = F.adaptive_avg_pool1d(h, 1)
+    elif pooling == "attentive_statistic":
+        h = attentive_stat_pooling(sd, "pooling", h)
+    else:
+        raise NotImplementedError("Other pooling method has not implemented.")
+    if taps is not None:
+        taps["pooled"] = h
+    if h.dim() == 3 and h.size(1) == 1:
+        h = h.squeeze(1)
+    if h.dim() == 3:
+        h = h.squeeze(-1)
+    x_a = F.linear(h, sd["fc1.weight"], sd["fc1.bias"])
+    if bn_first:
+        h = F.leaky_relu(_bn(x_a, sd, "bn1"), 0.2)
+    else:
+        h = _bn(F.leaky_relu(x_a, 0.2), sd, "bn1")
+    xv = F.linear(h, sd["fc2.weight"], sd["fc2.bias"])
+    return xv, x_a
+
+
+def speaker_forward(sd: SD, x: Tensor, context, bn_first: bool = True, pooling: str = "statistic") -> Tensor:
+    """SpeakerEmbNet.forward (tdnn.py:103-111): extract_embedding()[0] -> bn2/LReLU."""
+    xv, _ = speaker_extract_embedding(sd, x, context, bn_first, pooling)
+    if bn_first:
+        return F.leaky_relu(_bn(xv, sd, "bn2"), 0.2)
+    return _bn(F.leaky_relu(xv, 0.2), sd, "bn2")
+
+
+# ----------------------------------------------------------------------------------------
+# Criteria: models/audio_models/loss.py:6-51
+# ----------------------------------------------------------------------------------------
+def lmcl(emb: Tensor, labels: Tensor, weights: Tensor, s: float, margin: float) -> Tuple[Tensor, Tensor]:
+    """LMCL.forward (loss.py:43-51): cosine logits; margin only at the label column;
+    CE(s*(cos - m*onehot) + 1e-8) + 1e-5*||W||_1; returns the UN-margined cosine logits."""
+    logits = F.linear(F.normalize(emb), F.normalize(weights))
+    m = torch.zeros_like(logits)
+    m.scatter_(1, labels.view(-1, 1), margin)
+    m_logits = s * (logits - m)
+    loss = F.cross_entropy(m_logits + 1e-8, labels)
+    loss = loss + 0.00001 * torch.norm(weights, 1)
+    return loss, logits
+
+
+def cross_entropy_head(emb: Tensor, labels: Tensor, W: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
+    """CrossEntropy.forward (loss.py:13-16): Linear then CE(logits + 1e-8)."""
+    logits = F.linear(emb, W, b)
+    return F.cross_entropy(logits + 1e-8, labels), logits
+
+
+def argmax_first(logits: Tensor) -> Tensor:
+    """torch.max(logits, dim=1)[1] (train_fusion.py:296, train_audio.py:197, train_video.py:145):
+    int64 index of the first maximum."""
+    return torch.max(logits, dim=1)[1]
+
+
+# ----------------------------------------------------------------------------------------
+# Fusion heads: models/fusion_models/model_fusion.py:10-27, LBP.py:28-54
+# ----------------------------------------------------------------------------------------
+def linearfusion(sd: SD, x: Tensor, extract_feats: bool) -> Tensor:
+    """Linearfusion.forward (model_fusion.py:19-24), eval-mode BN."""
+    x1 = F.linear(x, sd["fc1.weight"], sd["fc1.bias"])
+    x1 = F.leaky_relu(_bn(x1, sd, "bn1"), 0.2)
+    out = F.linear(x1, sd["fc2.weight"], sd["fc2.bias"])
+    return x1 if extract_feats else out
+
+
+def lowfer(e1: Tensor, e2: Tensor) -> Tensor:
+    """LowFER.forward (LBP.py:28-54).  The MFB product (LBP.py:38-42) is computed and then
+    overwritten (LBP.py:48-50), so the returned value is cat[e1, sigmoid(e2), sigmoid(e2)*e1].
+    parity unpinned (source-text only): the ctor hard-codes device='cuda' (LBP.py:12-15)."""
+    s = torch.sigmoid(e2)
+    return torch.cat([e1, s, s * e1], dim=1)
+
+
+# ----------------------------------------------------------------------------------------
+# Test-time fusion and trial scoring: train_fusion.py:233-238,353-358;
+# models/fusion_models/utils.py:234-283,331-527
+# ----------------------------------------------------------------------------------------
+def feature_normalize_torch(data: Tensor) -> Tensor:
+    """Trainer.feature_normalize (train_fusion.py:233-238): per-row (x - mean) / std with
+    torch.std's UNBIASED estimator over dim 1."""
+    mu = torch.mean(data, dim=1)
+    std = torch.std(data, dim=1)
+    return ((data.transpose(0, 1) - mu) / std).transpose(0, 1)
+
+
+def feature_normalize_np(data: np.ndarray) -> np.ndarray:
+    """feature_normalize (models/fusion_models/utils.py:524-527): numpy BIASED std, axis 0 of
+    a 1-D vector.  parity unpinned (source-text only): the module needs kaldiio to import."""
+    mu = np.mean(data, axis=0)
+    std = np.std(data, axis=0)
+    return (data - mu) / std
+
+
+def fuse_av(xv_audio: Tensor, em_video: Tensor) -> Tensor:
+    """train_fusion.py:353-358: em = cat([znorm(xv_audio), znorm(em_video)], dim=1) -> [U,1024]."""
+    return torch.cat([feature_normalize_torch(xv_audio), feature_normalize_torch(em_video)], dim=1)
+
+
+def sklearn_cosine_rowwise(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """sklearn.metrics.pairwise.cosine_similarity(a.reshape(1,-1), b.reshape(1,-1)) per trial
+    (utils.py:244,262): X/||X|| . Y/||Y|| in the input dtype (float32 stays float32)."""
+    an = a / np.sqrt(np.einsum("ij,ij->i", a, a))[:, None]
+    bn = b / np.sqrt(np.einsum("ij,ij->i", b, b))[:, None]
+    return np.einsum("ij,ij->i", an, bn).astype(a.dtype)
+
+
+def cosine_trial_scores(emb: np.ndarray, idx_a: np.ndarray, idx_b: np.ndarray) -> np.ndarray:
+    """eer_cos_* inner loop (utils.py:254-262) with the .npy tree replaced by an [N,D] table."""
+    return sklearn_cosine_rowwise(emb[idx_a], emb[idx_b])
+
+
+def torch_cosine_rowwise(a: np.ndarray, b: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """F.cosine_similarity(x1, x2, dim=0, eps=1e-8) per trial (utils.py:372)."""
+    return F.cosine_similarity(torch.from_numpy(a), torch.from_numpy(b), dim=1, eps=eps).numpy()
+
+
+def score_fusion(audio_emb: np.ndarray, video_emb: np.ndarray, idx_a: np.ndarray, idx_b: np.ndarray) -> np.ndarray:
+    """eer_cos_*_scorefusion (utils.py:331-381): 0.5*sklearn-cos(audio) + 0.5*torch-cos(video)."""
+    return (0.5 * cosine_trial_scores(audio_emb, idx_a, idx_b)
+            + 0.5 * torch_cosine_rowwise(video_emb[idx_a], video_emb[idx_b]))
+
+
+def feature_fusion_scores(audio_emb: np.ndarray, video_emb: np.ndarray, idx_a, idx_b) -> np.ndarray:
+    """eer_cos_*_featurefusion (utils.py:465-473): hstack(znorm_np(video), znorm_np(audio)) then
+    sklearn cosine."""
+    def fuse(i):
+        v = np.stack([feature_normalize_np(video_emb[j]) for j in i])
+        a = np.stack([feature_normalize_np(audio_emb[j]) for j in i])
+        return np.hstack((v, a))
+    return sklearn_cosine_rowwise(fuse(idx_a), fuse(idx_b))
+
+
+def eer(y_true: Sequence[int], y_pred: Sequence[float]) -> Tuple[float, float]:
+    """utils.py:263-266: roc_curve(y_true, y_pred, pos_label=1); eer = brentq(1-x-interp1d(fpr,tpr)(x),
+    0, 1); threshold = interp1d(fpr, thresholds)(eer).  Third-party calls kept verbatim."""
+    from scipy.interpolate import interp1d
+    from scipy.optimize import brentq
+    from sklearn.metrics import roc_curve
+    fpr, tpr, threshold = roc_curve(list(y_true), list(y_pred), pos_label=1)
+    e = brentq(lambda x: 1. - x - interp1d(fpr, tpr)(x), 0., 1.)
+    thr = interp1d(fpr, threshold)(e)
+    return float(e), float(thr)
+
+
+# ----------------------------------------------------------------------------------------
+# Build-owned ingest (no reference counterpart on the live path; RgbToGray exists but is unused:
+# models/video_models/preprocess.py:32-46; constants dataloaders.py:11-22)
+# ----------------------------------------------------------------------------------------
+def ingest_rgb_u8(frames_u8: np.ndarray) -> np.ndarray:
+    """[B,T,3,H,W] uint8 RGB -> [B,1,T,H,W] float32: gray = 0.299 R + 0.587 G + 0.114 B (the
+    BT.601 weights of cv2.COLOR_RGB2GRAY, preprocess.py:44; kept in float, no uint8 rounding),
+    /255 then (x - 0.421)/0.165 (dataloaders.py:12,21-22).  Build-owned: parity unpinned."""
+    x = frames_u8.astype(np.float32)
+    g = np.float32(0.299) * x[:, :, 0] + np.float32(0.587) * x[:, :, 1] + np.float32(0.114) * x[:, :, 2]
+    g = g / np.float32(255.0)
+    g = (g - np.float32(0.421)) / np.float32(0.165)
+    return g[:, None].astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------
+# End-to-end helpers used by smoke() and bench.py's cpu_baseline leg
+# ----------------------------------------------------------------------------------------
+ETDNN_CONTEXT = [[-2, -1, 0, 1, 2], [0], [-2, 0, 2], [0], [-3, 0, 3], [0], [-4, 0, 4], [0], [0], [0]]
+TDNN_CONTEXT = [[-2, -1, 0, 1, 2], [-2, 0, 2], [-3, 0, 3], [0], [0]]
+
+
+def fused_av_embedding(video_sd: SD, audio_sd: SD, video: Tensor, audio: Tensor,
+                       context=ETDNN_CONTEXT) -> Tensor:
+    """One clip per utterance: train_fusion.py:338-358 collapsed to a batch."""
+    with torch.no_grad():
+        em_video = video_time_mean(lipreading_features(video_sd, video))
+        xv, _ = speaker_extract_embedding(audio_sd, audio, context)
+        return fuse_av(xv, em_video)
