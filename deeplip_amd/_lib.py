@@ -1,0 +1,100 @@
+"""ctypes binding of libdeeplip_hip.so (C ABI: include/deeplip_hip.h).
+
+There is no CPU fallback anywhere in this package: if the library is missing or fails to load,
+``lib()`` raises and every op that needs it fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch  # must be imported first: the library binds to the HIP runtime torch already loaded
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libdeeplip_hip.so")
+ABI_VERSION = 1
+
+_lock = threading.Lock()
+_lib = None
+
+c_f = C.c_void_p      # device float* (passed as integer address)
+c_i32 = C.c_int32
+c_i64 = C.c_int64
+c_stream = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """struct dlip_conv_desc"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "H", "W", "C", "K", "R", "S", "stride_h", "stride_w", "pad_h", "pad_w", "dil_h", "dil_w",
+        "Ho", "Wo", "ldx", "ldy", "ldr")]
+
+
+# name -> argtypes (restype is int for all but dlip_error_string); mirrors include/deeplip_hip.h
+SIGNATURES = {
+    "dlip_abi_version": [],
+    "dlip_conv_nhwc_f32": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_stream],
+    "dlip_stem3d_bn_act_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_maxpool3x3s2_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_avgpool_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
+    "dlip_time_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_group_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
+    "dlip_meanstd_pool_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
+    "dlip_nct_to_ntc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_ntc_to_nct_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
+    "dlip_ingest_rgb_u8": [c_f, c_f, c_i64, c_i32, c_i32, c_stream],
+    "dlip_znorm_cat_f32": [c_f, c_i32, c_f, c_i32, c_f, c_i32, c_i32, c_stream],
+    "dlip_l2_normalize_f32": [c_f, c_f, c_i32, c_i32, C.c_float, c_stream],
+    "dlip_pair_cosine_f32": [c_f, c_i32, c_i32, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_i32, c_stream],
+    "dlip_logits_argmax_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_margin_ce_loss_f32": [c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_stream],
+    "dlip_lowfer_cat_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
+}
+
+
+class DeepLipHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; raises if it is missing -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DeepLipHipError(
+                f"{LIB_PATH} not found: build it with `python -m deeplip_amd.build` "
+                "(or __graft_entry__.build()). deeplip_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
+            fn.argtypes = args
+            fn.restype = C.c_int
+        l.dlip_error_string.argtypes = [C.c_int]
+        l.dlip_error_string.restype = C.c_char_p
+        v = l.dlip_abi_version()
+        if v != ABI_VERSION:
+            raise DeepLipHipError(f"libdeeplip_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().dlip_error_string(code).decode()
+        raise DeepLipHipError(f"{what} failed: {msg} (code {code})")
+
+
+def ptr(t) -> int | None:
+    """Device address of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_handle() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,68 @@
+// Layout adapters at the drop-in boundary: the reference's modules speak channel-first
+// ([B,F,T] acoustic features, tdnn.py:89), the kernels speak channels-last.
+#include "dlip_common.h"
+
+namespace {
+
+// x [B,R,Cc] -> y [B,Cc,Rp] (zero-padded columns R..Rp-1); 32x32 LDS tile, +1 pad.
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int R, int Cc, int Rp) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* xb = x + (long long)b * R * Cc;
+  float* yb = y + (long long)b * Cc * Rp;
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int r = r0 + ty + j, c = c0 + tx;
+    tile[ty + j][tx] = (r < R && c < Cc) ? xb[(long long)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int c = c0 + ty + j, r = r0 + tx;
+    if (c < Cc && r < Rp) yb[(long long)c * Rp + r] = tile[tx][ty + j];
+  }
+}
+
+__global__ __launch_bounds__(256) void ingest_rgb_kernel(const uint8_t* __restrict__ x, float* __restrict__ y,
+                                                         long long n_frames, int HW) {
+  const long long total = n_frames * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long f = i / HW;
+    const int p = (int)(i - f * HW);
+    const uint8_t* px = x + f * 3 * HW + p;
+    const float g = 0.299f * (float)px[0] + 0.587f * (float)px[HW] + 0.114f * (float)px[2 * HW];
+    y[i] = (g / 255.0f - 0.421f) / 0.165f;
+  }
+}
+
+}  // namespace
+
+extern "C" int dlip_nct_to_ntc_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t Cp,
+                                   dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0 && Cp >= C && B <= 65535);
+  // rows = C, cols = T  ->  y [B, T, Cp]
+  dim3 grid((T + 31) / 32, (Cp + 31) / 32, B);
+  hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, C, T, Cp);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_ntc_to_nct_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
+                                   dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0 && B <= 65535);
+  dim3 grid((C + 31) / 32, (T + 31) / 32, B);
+  hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C, T);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_ingest_rgb_u8(const uint8_t* x, float* y, int64_t n_frames, int32_t H, int32_t W,
+                                  dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && n_frames > 0 && H > 0 && W > 0);
+  long long g = (n_frames * H * W + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(ingest_rgb_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), x, y,
+                     (long long)n_frames, H * W);
+  return dlip_launch_status();
+}

@@ -1,0 +1,149 @@
+// HBM-bound reductions on channels-last activations: max-pool, global average pool, (masked)
+// temporal mean, clip-group mean, mean + unbiased-std statistics pooling.  One thread owns one
+// channel (or a float4 of channels) so every wave access is a contiguous 256 B - 1 KiB segment;
+// statistics accumulate in fp64 (torch's CPU reductions accumulate float inputs in double).
+#include "dlip_common.h"
+
+namespace {
+
+// MaxPool3d((1,3,3), s(1,2,2), p(0,1,1)) == per-frame MaxPool2d(3, 2, 1); padding never wins.
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
+                                                           int N, int H, int W, int C4, int Ho, int Wo) {
+  const long long total = (long long)N * Ho * Wo * C4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    long long p = i / C4;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const float ninf = -__builtin_inff();
+    f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = 2 * ho - 1 + r;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wi = 2 * wo - 1 + s;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const f32x4 v = x[((long long)(n * H + hi) * W + wi) * C4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    y[i] = m;
+  }
+}
+
+// y[n,c] = mean over hw of x[n,hw,c]   (sequential fp32 sum, then one divide: AdaptiveAvgPool2d(1))
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      int N, int HW, int C) {
+  const long long total = (long long)N * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long n = i / C;
+    const float* p = x + n * HW * C + c;
+    float s = 0.f;
+    for (int h = 0; h < HW; ++h) s += p[(long long)h * C];
+    y[i] = s / (float)HW;
+  }
+}
+
+__global__ __launch_bounds__(256) void time_mean_kernel(const float* __restrict__ x, const int32_t* __restrict__ len,
+                                                        float* __restrict__ y, int B, int T, int C, int ldx) {
+  const long long total = (long long)B * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int b = (int)(i / C);
+    int L = len ? len[b] : T;
+    L = L < 0 ? 0 : (L > T ? T : L);
+    const float* p = x + (long long)b * T * ldx + c;
+    double s = 0.0;
+    for (int t = 0; t < L; ++t) s += (double)p[(long long)t * ldx];
+    y[i] = (float)(s / (double)L);
+  }
+}
+
+__global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict__ x, const int32_t* __restrict__ ptr,
+                                                         float* __restrict__ y, int U, int C) {
+  const long long total = (long long)U * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int u = (int)(i / C);
+    const int g0 = ptr[u], g1 = ptr[u + 1];
+    float s = 0.f;  // the reference accumulates the clip means in fp32 (`em += ...`, train_fusion.py:274)
+    for (int g = g0; g < g1; ++g) s += x[(long long)g * C + c];
+    y[i] = s / (float)(g1 - g0);
+  }
+}
+
+// y[b, c] = mean_t x[b,t,c];  y[b, C + c] = sqrt( sum_t (x - mean)^2 / (T - 1) )
+__global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      int B, int T, int C) {
+  const long long total = (long long)B * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long b = i / C;
+    const float* p = x + b * T * C + c;
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s += (double)p[(long long)t * C];
+    const double mean = s / (double)T;
+    double q = 0.0;
+    for (int t = 0; t < T; ++t) {
+      const double d = (double)p[(long long)t * C] - mean;
+      q += d * d;
+    }
+    y[b * 2 * C + c] = (float)mean;
+    y[b * 2 * C + C + c] = (float)sqrt(q / (double)(T - 1));  // T == 1 -> NaN, as torch.std
+  }
+}
+
+inline unsigned grid_for(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 8) g = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int dlip_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C,
+                                          dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_avgpool_nhwc_f32(const float* x, float* y, int32_t N, int32_t HW, int32_t C,
+                                     dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && N > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, y, N, HW, C);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_time_mean_f32(const float* x, const int32_t* len, float* y, int32_t B, int32_t T, int32_t C,
+                                  int32_t ldx, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0 && ldx >= C);
+  hipLaunchKernelGGL(time_mean_kernel, dim3(grid_for((long long)B * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, len, y, B, T, C, ldx);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_group_mean_f32(const float* x, const int32_t* group_ptr, float* y, int32_t U, int32_t C,
+                                   dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && group_ptr && y && U > 0 && C > 0);
+  hipLaunchKernelGGL(group_mean_kernel, dim3(grid_for((long long)U * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, group_ptr, y, U, C);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
+                                     dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0);
+  hipLaunchKernelGGL(meanstd_kernel, dim3(grid_for((long long)B * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, y, B, T, C);
+  return dlip_launch_status();
+}

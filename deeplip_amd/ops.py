@@ -1,0 +1,237 @@
+"""Thin tensor-level wrappers over the C ABI (include/deeplip_hip.h).
+
+PyTorch is plumbing here: it owns the device memory (``torch.empty``) and the stream; every
+arithmetic op is one ``dlip_*`` call on ``torch.cuda.current_stream()``.  Inputs must be fp32
+CUDA tensors; nothing in this module computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, lib, ptr, stream_handle
+
+Tensor = torch.Tensor
+
+
+def _req(t: Optional[Tensor], name: str, dtype=torch.float32) -> None:
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.DeepLipHipError(f"{name}: expected a CUDA (ROCm) tensor; deeplip_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+
+
+def conv_out_size(n: int, k: int, stride: int, pad: int, dil: int) -> int:
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, stride=(1, 1), pad=(0, 0),
+              dil=(1, 1), residual: Optional[Tensor] = None, slope: Optional[Tensor] = None,
+              post_scale: Optional[Tensor] = None, post_shift: Optional[Tensor] = None,
+              out: Optional[Tensor] = None, out_channel_offset: int = 0,
+              in_channels: Optional[int] = None, in_channel_offset: int = 0) -> Tensor:
+    """x [N,H,W,Cx] (NHWC), w [K,R,S,C] -> y [N,Ho,Wo,Ky].
+
+    ``out`` / ``out_channel_offset`` write the K result channels into a slice of a wider tensor
+    (concat-free multibranch blocks); ``in_channels`` / ``in_channel_offset`` read a slice."""
+    for t, n in ((x, "x"), (w_krsc, "w"), (bias, "bias"), (residual, "residual"), (slope, "slope"),
+                 (post_scale, "post_scale"), (post_shift, "post_shift"), (out, "out")):
+        _req(t, n)
+    N, H, W, Cx = x.shape
+    K, R, S, Cw = w_krsc.shape
+    Cin = Cw if in_channels is None else in_channels
+    if Cin != Cw or in_channel_offset + Cin > Cx:
+        raise ValueError(f"conv_nhwc: weight C={Cw} does not match input slice [{in_channel_offset}:+{Cin}] of {Cx}")
+    Ho = conv_out_size(H, R, stride[0], pad[0], dil[0])
+    Wo = conv_out_size(W, S, stride[1], pad[1], dil[1])
+    if out is None:
+        out = torch.empty((N, Ho, Wo, K), device=x.device, dtype=torch.float32)
+        out_channel_offset = 0
+    if tuple(out.shape[:3]) != (N, Ho, Wo) or out_channel_offset + K > out.shape[3]:
+        raise ValueError(f"conv_nhwc: bad output tensor {tuple(out.shape)} for result {(N, Ho, Wo, K)}")
+    if residual is not None and (tuple(residual.shape[:3]) != (N, Ho, Wo) or residual.shape[3] < K):
+        raise ValueError(f"conv_nhwc: residual {tuple(residual.shape)} does not match output {(N, Ho, Wo, K)}")
+    for v, n in ((bias, "bias"), (slope, "slope"), (post_scale, "post_scale"), (post_shift, "post_shift")):
+        if v is not None and v.numel() != K:
+            raise ValueError(f"conv_nhwc: {n} has {v.numel()} elements, expected K={K}")
+    d = ConvDesc(N, H, W, Cin, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], Ho, Wo,
+                 Cx, out.shape[3], residual.shape[3] if residual is not None else 0)
+    xp = x.data_ptr() + 4 * in_channel_offset
+    yp = out.data_ptr() + 4 * out_channel_offset
+    check(lib().dlip_conv_nhwc_f32(C.byref(d), xp, ptr(w_krsc), ptr(bias), ptr(residual), ptr(slope),
+                                   ptr(post_scale), ptr(post_shift), yp, stream_handle()), "dlip_conv_nhwc_f32")
+    return out
+
+
+def linear(x: Tensor, w_kc: Tensor, bias: Optional[Tensor] = None, **kw) -> Tensor:
+    """x [M,C] @ w [K,C]^T (+ epilogue) -> [M,K], through the same implicit-GEMM kernel."""
+    M, Cx = x.shape
+    K, Cw = w_kc.shape
+    y = conv_nhwc(x.view(1, 1, M, Cx), w_kc.view(K, 1, 1, Cw), bias, **kw)
+    return y.view(M, K)
+
+
+def conv1d_ntc(x: Tensor, w_ksc: Tensor, bias: Optional[Tensor] = None, *, dilation: int = 1, pad: int = 0,
+               **kw) -> Tensor:
+    """x [B,T,C] (time-major, channels-last), w [K,S,C] -> [B,T',K]."""
+    B, T, Cx = x.shape
+    K, S, Cw = w_ksc.shape
+    res = kw.pop("residual", None)
+    out = kw.pop("out", None)
+    if res is not None:
+        res = res.view(B, 1, res.shape[1], res.shape[2])
+    if out is not None:
+        out = out.view(B, 1, out.shape[1], out.shape[2])
+    y = conv_nhwc(x.view(B, 1, T, Cx), w_ksc.view(K, 1, S, Cw), bias, dil=(1, dilation), pad=(0, pad),
+                  residual=res, out=out, **kw)
+    return y.view(B, y.shape[2], y.shape[3])
+
+
+def stem3d(x_bthw: Tensor, w_248xk: Tensor, bias: Tensor, slope: Optional[Tensor]) -> Tensor:
+    """x [B,T,H,W] -> [(B*T), H/2, W/2, 64] (Conv3d 5x7x7 + folded BN + PReLU/ReLU)."""
+    for t, n in ((x_bthw, "x"), (w_248xk, "w"), (bias, "bias"), (slope, "slope")):
+        _req(t, n)
+    B, T, H, W = x_bthw.shape
+    K = w_248xk.shape[1]
+    if w_248xk.shape[0] != 248:
+        raise ValueError("stem3d: weights must be packed [248, K]")
+    y = torch.empty((B * T, H // 2, W // 2, K), device=x_bthw.device, dtype=torch.float32)
+    check(lib().dlip_stem3d_bn_act_f32(ptr(x_bthw), ptr(w_248xk), ptr(bias), ptr(slope), ptr(y), B, T, H, W, K,
+                                       stream_handle()), "dlip_stem3d_bn_act_f32")
+    return y
+
+
+def maxpool3x3s2(x: Tensor) -> Tensor:
+    _req(x, "x")
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=torch.float32)
+    check(lib().dlip_maxpool3x3s2_nhwc_f32(ptr(x), ptr(y), N, H, W, Cc, stream_handle()), "dlip_maxpool3x3s2_nhwc_f32")
+    return y
+
+
+def avgpool(x: Tensor) -> Tensor:
+    _req(x, "x")
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, Cc), device=x.device, dtype=torch.float32)
+    check(lib().dlip_avgpool_nhwc_f32(ptr(x), ptr(y), N, H * W, Cc, stream_handle()), "dlip_avgpool_nhwc_f32")
+    return y
+
+
+def time_mean(x: Tensor, lengths: Optional[Tensor] = None) -> Tensor:
+    """x [B,T,C] -> [B,C]; ``lengths`` int32 [B] masks the mean to t < len (model.py:16-17)."""
+    _req(x, "x")
+    _req(lengths, "lengths", torch.int32)
+    B, T, Cc = x.shape
+    y = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    check(lib().dlip_time_mean_f32(ptr(x), ptr(lengths), ptr(y), B, T, Cc, Cc, stream_handle()), "dlip_time_mean_f32")
+    return y
+
+
+def group_mean(x: Tensor, group_ptr: Tensor) -> Tensor:
+    _req(x, "x")
+    _req(group_ptr, "group_ptr", torch.int32)
+    U = group_ptr.numel() - 1
+    y = torch.empty((U, x.shape[1]), device=x.device, dtype=torch.float32)
+    check(lib().dlip_group_mean_f32(ptr(x), ptr(group_ptr), ptr(y), U, x.shape[1], stream_handle()), "dlip_group_mean_f32")
+    return y
+
+
+def meanstd_pool(x: Tensor) -> Tensor:
+    """x [B,T,C] -> [B,2C] = cat(mean_t, unbiased std_t)  (pooling.py:24-26)."""
+    _req(x, "x")
+    B, T, Cc = x.shape
+    y = torch.empty((B, 2 * Cc), device=x.device, dtype=torch.float32)
+    check(lib().dlip_meanstd_pool_f32(ptr(x), ptr(y), B, T, Cc, stream_handle()), "dlip_meanstd_pool_f32")
+    return y
+
+
+def nct_to_ntc(x: Tensor, pad_to: Optional[int] = None) -> Tensor:
+    _req(x, "x")
+    B, Cc, T = x.shape
+    Cp = Cc if pad_to is None else pad_to
+    y = torch.empty((B, T, Cp), device=x.device, dtype=torch.float32)
+    check(lib().dlip_nct_to_ntc_f32(ptr(x), ptr(y), B, Cc, T, Cp, stream_handle()), "dlip_nct_to_ntc_f32")
+    return y
+
+
+def ntc_to_nct(x: Tensor) -> Tensor:
+    _req(x, "x")
+    B, T, Cc = x.shape
+    y = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+    check(lib().dlip_ntc_to_nct_f32(ptr(x), ptr(y), B, T, Cc, stream_handle()), "dlip_ntc_to_nct_f32")
+    return y
+
+
+def ingest_rgb_u8(frames: Tensor) -> Tensor:
+    """[B,T,3,H,W] uint8 -> [B,1,T,H,W] float32 normalised gray."""
+    _req(frames, "frames", torch.uint8)
+    B, T, three, H, W = frames.shape
+    if three != 3:
+        raise ValueError("ingest_rgb_u8: expected [B,T,3,H,W]")
+    y = torch.empty((B, 1, T, H, W), device=frames.device, dtype=torch.float32)
+    check(lib().dlip_ingest_rgb_u8(ptr(frames), ptr(y), B * T, H, W, stream_handle()), "dlip_ingest_rgb_u8")
+    return y
+
+
+def znorm_cat(a: Optional[Tensor], v: Optional[Tensor], biased: bool = False) -> Tensor:
+    _req(a, "a"); _req(v, "v")
+    U = (a if a is not None else v).shape[0]
+    Da = a.shape[1] if a is not None else 0
+    Dv = v.shape[1] if v is not None else 0
+    y = torch.empty((U, Da + Dv), device=(a if a is not None else v).device, dtype=torch.float32)
+    check(lib().dlip_znorm_cat_f32(ptr(a), Da, ptr(v), Dv, ptr(y), U, int(biased), stream_handle()), "dlip_znorm_cat_f32")
+    return y
+
+
+def l2_normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
+    _req(x, "x")
+    y = torch.empty_like(x)
+    check(lib().dlip_l2_normalize_f32(ptr(x), ptr(y), x.shape[0], x.shape[1], eps, stream_handle()), "dlip_l2_normalize_f32")
+    return y
+
+
+def pair_cosine(emb: Tensor, idx_a: Tensor, idx_b: Tensor, mode: int = 0, eps: float = 1e-8,
+                weight: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    _req(emb, "emb"); _req(idx_a, "idx_a", torch.int32); _req(idx_b, "idx_b", torch.int32)
+    n = idx_a.numel()
+    acc = out is not None
+    if out is None:
+        out = torch.empty((n,), device=emb.device, dtype=torch.float32)
+    _req(out, "out")
+    check(lib().dlip_pair_cosine_f32(ptr(emb), emb.shape[0], emb.shape[1], ptr(idx_a), ptr(idx_b), ptr(out), n, mode,
+                                     eps, weight, int(acc), stream_handle()), "dlip_pair_cosine_f32")
+    return out
+
+
+def logits_argmax(e: Tensor, W: Tensor, bias: Optional[Tensor] = None, cosine: bool = False) -> Tuple[Tensor, Tensor]:
+    _req(e, "e"); _req(W, "W"); _req(bias, "bias")
+    B, D = e.shape
+    K = W.shape[0]
+    logits = torch.empty((B, K), device=e.device, dtype=torch.float32)
+    amax = torch.empty((B,), device=e.device, dtype=torch.int64)
+    check(lib().dlip_logits_argmax_f32(ptr(e), ptr(W), ptr(bias), ptr(logits), ptr(amax), B, D, K, int(cosine),
+                                       stream_handle()), "dlip_logits_argmax_f32")
+    return logits, amax
+
+
+def margin_ce_loss(logits: Tensor, labels: Tensor, scale: float = 1.0, margin: float = 0.0) -> Tensor:
+    _req(logits, "logits"); _req(labels, "labels", torch.int64)
+    loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
+    check(lib().dlip_margin_ce_loss_f32(ptr(logits), ptr(labels), ptr(loss), logits.shape[0], logits.shape[1], scale,
+                                        margin, stream_handle()), "dlip_margin_ce_loss_f32")
+    return loss[0]
+
+
+def lowfer_cat(e1: Tensor, e2: Tensor) -> Tensor:
+    _req(e1, "e1"); _req(e2, "e2")
+    B, D = e1.shape
+    y = torch.empty((B, 3 * D), device=e1.device, dtype=torch.float32)
+    check(lib().dlip_lowfer_cat_f32(ptr(e1), ptr(e2), ptr(y), B, D, stream_handle()), "dlip_lowfer_cat_f32")
+    return y

@@ -1,0 +1,164 @@
+/*
+ * deeplip_hip.h -- C ABI of libdeeplip_hip.so: the MI355X (gfx950 / CDNA4) kernels under the
+ * DeepLip audio-visual embedding hot path.
+ *
+ * The reference (DanielMengLiu/DeepLip) has no FFI / operator / plugin layer: its boundary is the
+ * Python module API + state-dict schema and all arithmetic is delegated to
+ * stock torch.nn layers.  Each entry point below therefore names the reference call site(s) whose
+ * torch.nn arithmetic it replaces (paths relative to the reference repo root).  The Python host
+ * (the deeplip_amd package, re-exported as the models package) binds these with ctypes; INTEGRATION.md shows the
+ * stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (kernels never allocate, free or synchronise);
+ *   - activations are channels-last (NHWC / N-T-C), fp32; weights are pre-packed by the
+ *     caller to [K][R][S][C] ("KRSC", BN already folded in fp64 on the host);
+ *   - every call is asynchronous on `stream` (a hipStream_t; NULL = the null stream);
+ *   - return value: 0 on success, a positive hipError_t value if the launch failed, or a
+ *     negative DLIP_E* code for argument errors detected on the host.  No exceptions, no
+ *     global mutable state: every function is re-entrant.
+ */
+#ifndef DEEPLIP_HIP_H
+#define DEEPLIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLIP_ABI_VERSION 1
+
+#define DLIP_OK 0
+#define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
+#define DLIP_ERANGE (-2)  /* a tensor exceeds the 2 GiB addressing window of one launch */
+
+typedef void* dlip_stream_t; /* hipStream_t */
+
+int dlip_abi_version(void);
+/* Human-readable text for a code returned by any dlip_* call. */
+const char* dlip_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic implicit-GEMM convolution, NHWC fp32, on v_mfma_f32_32x32x2_f32.
+ *   y[n,ho,wo,k] = epilogue( sum_{r,s,c} x[n, ho*sh-ph+r*dh, wo*sw-pw+s*dw, c] * w[k,r,s,c] )
+ *   epilogue(v)  = v + bias[k]; v += residual[m*ldr + k]; v = v>=0 ? v : v*slope[k];
+ *                  v = v*post_scale[k] + post_shift[k]            (each step skipped when NULL)
+ * Replaces, with BN folded into (w, bias):
+ *   Conv2d 3x3 / 1x1 + BatchNorm2d + PReLU|ReLU + residual add   models/video_models/resnet.py:9-17,55-69
+ *   Conv1d(dilated) + BatchNorm1d + LeakyReLU(0.2) (TDNN_Block)   models/audio_models/tdnn.py:23-43
+ *   Conv1d + BatchNorm1d + Chomp1d + PReLU, 1x1 residual Conv1d   models/video_models/tcn.py:46-59,87,113-116
+ *   nn.Linear (+BatchNorm1d +LeakyReLU)                           models/audio_models/tdnn.py:85-101,
+ *                                                                 models/fusion_models/model_fusion.py:19-24,
+ *                                                                 models/audio_models/loss.py:14,
+ *                                                                 models/video_models/model.py:27
+ * Conv1d is H=1; Linear is H=W=R=S=1.  C % 4 == 0 required (pad on pack); ldx/ldy/ldr are pixel
+ * strides in floats (>= C / K), so a call may read or write a channel slice of a wider tensor.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dlip_conv_desc {
+  int32_t N, H, W, C;          /* input  [N,H,W,C]                 */
+  int32_t K;                   /* output channels                  */
+  int32_t R, S;                /* filter taps (height, width)      */
+  int32_t stride_h, stride_w;
+  int32_t pad_h, pad_w;
+  int32_t dil_h, dil_w;
+  int32_t Ho, Wo;              /* output spatial size (validated)  */
+  int32_t ldx, ldy, ldr;       /* pixel strides in floats          */
+} dlip_conv_desc;
+
+int dlip_conv_nhwc_f32(const dlip_conv_desc* d, const float* x, const float* w_krsc,
+                       const float* bias, const float* residual, const float* slope,
+                       const float* post_scale, const float* post_shift, float* y,
+                       dlip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Video stem: Conv3d(1->K, 5x7x7, stride (1,2,2), pad (2,3,3), no bias) + BatchNorm3d + PReLU|ReLU
+ * (BN folded into w/bias; slope[k] = PReLU weight or 0 for ReLU), output NDHWC = [(B*T),Ho,Wo,K].
+ * Replaces models/video_models/model.py:81-84 (frontend3D.0-.2) and makes threeD_to_2D_tensor
+ * (model.py:9-13) a no-op.  x is [B,T,H,W] (the reference's [B,1,T,H,W]); w is [K][5][7][7] padded
+ * to [K][248]; H, W even.
+ * ------------------------------------------------------------------------------------------ */
+int dlip_stem3d_bn_act_f32(const float* x, const float* w_k248, const float* bias, const float* slope,
+                           float* y, int32_t B, int32_t T, int32_t H, int32_t W, int32_t K,
+                           dlip_stream_t stream);
+
+/* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) on NHWC: [N,H,W,C] -> [N,Ho,Wo,C],
+ * Ho = (H+2-3)/2+1.  Replaces models/video_models/model.py:85.  C % 4 == 0. */
+int dlip_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C,
+                               dlip_stream_t stream);
+
+/* AdaptiveAvgPool2d(1) + flatten on NHWC: [N,HW,C] -> [N,C].  Replaces resnet.py:83,125-126. */
+int dlip_avgpool_nhwc_f32(const float* x, float* y, int32_t N, int32_t HW, int32_t C,
+                          dlip_stream_t stream);
+
+/* Masked temporal mean: y[b,c] = mean_{t < len[b]} x[b,t,c]; len == NULL means T for every b.
+ * Replaces torch.mean(..., dim=0) over frames (train_fusion.py:274,348) and _average_batch
+ * (models/video_models/model.py:16-17).  x [B,T,C] with row stride ldx floats. */
+int dlip_time_mean_f32(const float* x, const int32_t* len, float* y, int32_t B, int32_t T, int32_t C,
+                       int32_t ldx, dlip_stream_t stream);
+
+/* Segmented mean over clip groups (CSR offsets, G+1 entries): y[u] = sum(x[ptr[u]:ptr[u+1]]) / count.
+ * Replaces the per-utterance clip-file average (train_fusion.py:272-275,346-349). */
+int dlip_group_mean_f32(const float* x, const int32_t* group_ptr, float* y, int32_t U, int32_t C,
+                        dlip_stream_t stream);
+
+/* MeanStdPooling on N-T-C: y[b, 0:C] = mean_t, y[b, C:2C] = unbiased std_t (N-1), two-pass.
+ * Replaces models/audio_models/pooling.py:24-26. */
+int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
+                          dlip_stream_t stream);
+
+/* Layout adapters at the API boundary.
+ *   dlip_nct_to_ntc_f32: x [B,C,T] (reference layout, tdnn.py:89) -> y [B,T,Cp] zero-padded to Cp>=C.
+ *   dlip_ntc_to_nct_f32: y [B,C,T] <- x [B,T,C].
+ *   dlip_ingest_rgb_u8 : [B,T,3,H,W] uint8 RGB -> [B,T,H,W] float = ((0.299R+0.587G+0.114B)/255-0.421)/0.165
+ *                        (constants: models/video_models/dataloaders.py:12,21-22; build-owned adapter). */
+int dlip_nct_to_ntc_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t Cp,
+                        dlip_stream_t stream);
+int dlip_ntc_to_nct_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
+                        dlip_stream_t stream);
+int dlip_ingest_rgb_u8(const uint8_t* x, float* y, int64_t n_frames, int32_t H, int32_t W,
+                       dlip_stream_t stream);
+
+/* Per-row z-normalisation with the UNBIASED std (train_fusion.py:233-238) of a [U,Da] and a [U,Dv]
+ * table, concatenated into y [U, Da+Dv] (train_fusion.py:353-358).  Either input may be NULL
+ * (D = 0) to z-normalise a single table.  biased != 0 selects numpy's biased std
+ * (models/fusion_models/utils.py:524-527, feature-fusion scoring). */
+int dlip_znorm_cat_f32(const float* a, int32_t Da, const float* v, int32_t Dv, float* y, int32_t U,
+                       int32_t biased, dlip_stream_t stream);
+
+/* y[u,:] = x[u,:] / max(||x[u,:]||_2, eps)   (F.normalize; loss.py:44, train_audio.py:355). */
+int dlip_l2_normalize_f32(const float* x, float* y, int32_t U, int32_t D, float eps,
+                          dlip_stream_t stream);
+
+/* Trial scoring over an [N,D] embedding table: score[i] = cos(emb[idx_a[i]], emb[idx_b[i]]).
+ * mode 0: sklearn cosine_similarity semantics (normalise each row, then dot; utils.py:244,262)
+ * mode 1: F.cosine_similarity(eps) semantics  (dot / max(||a||*||b||, eps); utils.py:372).
+ * score_io: if accumulate != 0, score[i] = score[i] + weight*cos, else score[i] = weight*cos
+ * (score-level fusion 0.5/0.5, utils.py:343-377). */
+int dlip_pair_cosine_f32(const float* emb, int32_t N, int32_t D, const int32_t* idx_a,
+                         const int32_t* idx_b, float* score, int32_t n_trials, int32_t mode,
+                         float eps, float weight, int32_t accumulate, dlip_stream_t stream);
+
+/* logits[b,k] = <normalize(e[b]), normalize(W[k])> (cosine logits, loss.py:44) when cosine != 0,
+ * else <e[b], W[k]> + bias[k] (loss.py:14); argmax[b] = first index of the row maximum
+ * (torch.max(logits,1)[1]; train_fusion.py:296), int64.  K <= 1024. */
+int dlip_logits_argmax_f32(const float* e, const float* W, const float* bias, float* logits,
+                           int64_t* argmax, int32_t B, int32_t D, int32_t K, int32_t cosine,
+                           dlip_stream_t stream);
+
+/* Softmax cross-entropy over margin-adjusted logits (forward value only):
+ *   z[b,k] = scale * (logits[b,k] - margin*[k==label[b]]) + 1e-8;  loss = mean_b( lse(z[b]) - z[b,label] )
+ * LMCL: scale=s, margin=m (loss.py:45-48); CrossEntropy: scale=1, margin=0 (loss.py:15).
+ * loss is one float on the device. */
+int dlip_margin_ce_loss_f32(const float* logits, const int64_t* labels, float* loss, int32_t B,
+                            int32_t K, float scale, float margin, dlip_stream_t stream);
+
+/* LowFER.forward as shipped (LBP.py:46-50): y = cat[e1, sigmoid(e2), sigmoid(e2)*e1], [B,3D]. */
+int dlip_lowfer_cat_f32(const float* e1, const float* e2, float* y, int32_t B, int32_t D,
+                        dlip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPLIP_HIP_H */

@@ -1,0 +1,45 @@
+"""CPU-side checks of the drop-in boundary: the in-tree library loads, exports every symbol
+that include/deeplip_hip.h declares, and the ctypes binding covers exactly that set.
+No compute call is made (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "deeplip_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dlip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deeplip_amd import build
+    path = build.build(verbose=False)
+    lib = ctypes.CDLL(path)
+    syms = header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in deeplip_hip.h but not exported"
+
+
+def test_binding_matches_header():
+    from deeplip_amd import _lib
+    assert sorted(list(_lib.SIGNATURES) + ["dlip_error_string"]) == header_symbols()
+    l = _lib.lib()
+    assert l.dlip_abi_version() == _lib.ABI_VERSION
+    assert l.dlip_error_string(0) == b"ok"
+    assert b"invalid argument" in l.dlip_error_string(-1)
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from deeplip_amd import ops
+    from deeplip_amd._lib import DeepLipHipError
+    with pytest.raises(DeepLipHipError):
+        ops.meanstd_pool(torch.zeros(1, 4, 8))
+    with pytest.raises(DeepLipHipError):
+        ops.conv_nhwc(torch.zeros(1, 2, 2, 4), torch.zeros(4, 1, 1, 4))

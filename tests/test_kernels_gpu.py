@@ -1,0 +1,254 @@
+"""Kernel-level parity (-m gpu): every C-ABI entry point against a plain torch-CPU fp32 (or fp64)
+statement of the same op on seeded inputs.  Tolerance: 2e-5 relative-to-max for the MFMA
+contractions (exact fp32 fma chains, only the summation order differs from ATen's), 1e-6 for the
+reductions, bit-exact for integer outputs.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    from deeplip_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, C, K, R, S, stride, pad, dil, residual, slope
+    (3, 22, 22, 64, 64, 3, 3, 1, 1, 1, True, True),      # layer1 shape
+    (3, 22, 22, 64, 128, 3, 3, 2, 1, 1, False, True),    # layer2.0.conv1
+    (3, 22, 22, 64, 128, 1, 1, 2, 0, 1, False, False),   # layer2.0.downsample
+    (5, 11, 11, 128, 128, 3, 3, 1, 1, 1, True, True),
+    (7, 6, 6, 256, 256, 3, 3, 1, 1, 1, True, True),
+    (9, 3, 3, 512, 512, 3, 3, 1, 1, 1, True, True),      # layer4: M = 81 (ragged M tile)
+    (40, 3, 3, 256, 512, 3, 3, 2, 1, 1, False, True),
+    (2, 1, 50, 24, 512, 1, 5, 1, 0, 1, False, True),     # tdnn.0 (C=24 < BK, conv1d as H=1)
+    (2, 1, 60, 512, 512, 1, 3, 1, 0, 3, False, True),    # dilated tdnn
+    (2, 1, 40, 512, 1500, 1, 1, 1, 0, 1, False, True),   # tdnn.9 (K tail 1500)
+    (1, 1, 37, 3000, 512, 1, 1, 1, 0, 1, False, False),  # fc1 as GEMM (C % 32 != 0)
+    (2, 1, 29, 512, 256, 1, 7, 1, 12, 4, False, True),   # TCN branch k=7, dil 4, same padding
+    (260, 22, 22, 64, 64, 3, 3, 1, 1, 1, True, True),    # enough tiles for the 128x64 path
+    (300, 6, 6, 256, 256, 3, 3, 1, 1, 1, True, True),    # 128x128 path (M=10800, K=256 -> 170 tiles? no: 64x64)
+    (1900, 6, 6, 256, 256, 3, 3, 1, 1, 1, False, True),  # 128x128 path (535 x 2 tiles)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:10]))
+def test_conv_nhwc(ops, case):
+    N, H, W, C, K, R, S, stride, pad, dil, use_res, use_slope = case
+    x = rnd(N, C, H, W, seed=1)
+    w = rnd(K, C, R, S, seed=2, scale=1.0 / np.sqrt(C * R * S))
+    b = rnd(K, seed=3, scale=0.1)
+    sh, sw = (1, stride) if H == 1 else (stride, stride)
+    ph, pw = (0, pad) if H == 1 else (pad, pad)
+    dh, dw = (1, dil) if H == 1 else (dil, dil)
+    ref = F.conv2d(x, w, b, stride=(sh, sw), padding=(ph, pw), dilation=(dh, dw))
+    res = rnd(*ref.shape, seed=4) if use_res else None
+    slope = torch.rand(K, generator=torch.Generator().manual_seed(5)) * 0.3 if use_slope else None
+    if res is not None:
+        ref = ref + res
+    if slope is not None:
+        ref = F.prelu(ref, slope)
+    dev = "cuda"
+    y = ops.conv_nhwc(nhwc(x).to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), b.to(dev),
+                      stride=(sh, sw), pad=(ph, pw), dil=(dh, dw),
+                      residual=nhwc(res).to(dev) if res is not None else None,
+                      slope=slope.to(dev) if slope is not None else None)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+
+
+def test_conv_post_affine_and_channel_slices(ops):
+    # act-first TDNN epilogue (LeakyReLU then BN affine) and concat-free output slices
+    x = rnd(2, 1, 40, 64, seed=7)
+    w = rnd(96, 1, 3, 64, seed=8, scale=0.1)
+    b = rnd(96, seed=9, scale=0.1)
+    sc = torch.rand(96) + 0.5
+    sf = rnd(96, seed=10, scale=0.1)
+    ref = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b), 0.2) * sc[None, :, None, None] + sf[None, :, None, None]
+    out = torch.zeros(2, 1, 38, 200, device="cuda")
+    slope = torch.full((96,), 0.2, device="cuda")
+    ops.conv_nhwc(x.cuda(), w.cuda(), b.cuda(), slope=slope, post_scale=sc.cuda(), post_shift=sf.cuda(), out=out,
+                  out_channel_offset=100)
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert rel_err(o[..., 100:196].permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    assert float(o[..., :100].abs().max()) == 0.0 and float(o[..., 196:].abs().max()) == 0.0
+    # input channel slice
+    y = ops.conv_nhwc(out, w.cuda()[:, :, :, :32].contiguous(), None, in_channels=32, in_channel_offset=100)
+    ref2 = F.conv2d(o[..., 100:132].permute(0, 3, 1, 2), w[:, :, :, :32].permute(0, 3, 1, 2))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().permute(0, 3, 1, 2).numpy(), ref2.numpy()) < TOL
+
+
+def test_conv_rejects_bad_args(ops):
+    from deeplip_amd._lib import DeepLipHipError
+    x = torch.zeros(1, 4, 4, 6, device="cuda")      # C % 4 != 0
+    w = torch.zeros(8, 1, 1, 6, device="cuda")
+    with pytest.raises(DeepLipHipError):
+        ops.conv_nhwc(x, w)
+    with pytest.raises(DeepLipHipError):
+        ops.conv_nhwc(torch.zeros(1, 4, 4, 8), torch.zeros(8, 1, 1, 8))  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("B,T,HW", [(2, 7, 88), (1, 3, 24), (1, 2, 96)])
+def test_stem3d(ops, B, T, HW):
+    x = rnd(B, 1, T, HW, HW, seed=11)
+    w = rnd(64, 1, 5, 7, 7, seed=12, scale=1.0 / np.sqrt(245))
+    b = rnd(64, seed=13, scale=0.1)
+    slope = torch.rand(64, generator=torch.Generator().manual_seed(14)) * 0.3
+    ref = F.prelu(F.conv3d(x, w, b, stride=(1, 2, 2), padding=(2, 3, 3)), slope)     # [B,64,T,Ho,Wo]
+    wp = torch.zeros(248, 64)
+    wp[:245] = w.reshape(64, 245).t()
+    y = ops.stem3d(x[:, 0].contiguous().cuda(), wp.cuda(), b.cuda(), slope.cuda())
+    torch.cuda.synchronize()
+    got = y.cpu().view(B, T, HW // 2, HW // 2, 64).permute(0, 4, 1, 2, 3)
+    assert rel_err(got.numpy(), ref.numpy()) < TOL
+
+
+def test_maxpool_avgpool(ops):
+    x = rnd(3, 64, 44, 44, seed=15)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    y = ops.maxpool3x3s2(nhwc(x).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy())
+    x = rnd(5, 512, 3, 3, seed=16)
+    y = ops.avgpool(nhwc(x).cuda())
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), F.adaptive_avg_pool2d(x, 1).flatten(1).numpy()) < 1e-6
+    x = rnd(2, 8, 5, 7, seed=17)      # odd sizes
+    y = ops.maxpool3x3s2(nhwc(x).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().permute(0, 3, 1, 2).numpy(), F.max_pool2d(x, 3, 2, 1).numpy())
+
+
+def test_time_and_group_mean(ops):
+    x = rnd(4, 29, 512, seed=18)
+    y = ops.time_mean(x.cuda())
+    lens = torch.tensor([29, 20, 11, 1], dtype=torch.int32)
+    ym = ops.time_mean(x.cuda(), lens.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), x.mean(1).numpy()) < 1e-6
+    ref = torch.stack([x[b, :int(l)].mean(0) for b, l in enumerate(lens)])
+    assert rel_err(ym.cpu().numpy(), ref.numpy()) < 1e-6
+    g = rnd(7, 512, seed=19)
+    ptr = torch.tensor([0, 1, 4, 7], dtype=torch.int32)
+    yg = ops.group_mean(g.cuda(), ptr.cuda())
+    torch.cuda.synchronize()
+    ref = torch.stack([g[0:1].mean(0), g[1:4].mean(0), g[4:7].mean(0)])
+    assert rel_err(yg.cpu().numpy(), ref.numpy()) < 1e-6
+
+
+def test_meanstd_pool(ops):
+    x = rnd(3, 1500, 278, seed=20) * 0.3 + 2.0     # large mean: catastrophic for one-pass sum/sumsq
+    ref = torch.cat([x.mean(2), x.std(2)], 1)
+    y = ops.meanstd_pool(x.permute(0, 2, 1).contiguous().cuda())
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 1e-6
+    assert np.abs(y.cpu().numpy()[:, 1500:] - ref.numpy()[:, 1500:]).max() < 1e-6 * 0.3 * 10
+
+
+def test_layout_adapters(ops):
+    x = rnd(3, 24, 301, seed=21)
+    y = ops.nct_to_ntc(x.cuda())
+    yp = ops.nct_to_ntc(x.cuda(), pad_to=32)
+    back = ops.ntc_to_nct(y)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), x.permute(0, 2, 1).numpy())
+    assert np.array_equal(yp.cpu().numpy()[..., :24], x.permute(0, 2, 1).numpy())
+    assert float(yp.cpu()[..., 24:].abs().max()) == 0.0
+    assert np.array_equal(back.cpu().numpy(), x.numpy())
+
+
+def test_ingest_rgb(ops):
+    from oracle import deeplip_oracle as O
+    u8 = torch.randint(0, 256, (2, 3, 3, 16, 20), dtype=torch.uint8, generator=torch.Generator().manual_seed(22))
+    y = ops.ingest_rgb_u8(u8.cuda())
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - O.ingest_rgb_u8(u8.numpy())).max() < 1e-5
+
+
+def test_znorm_l2_cosine(ops):
+    from oracle import deeplip_oracle as O
+    a = rnd(6, 512, seed=23) * 0.2 + 0.1
+    v = rnd(6, 512, seed=24) * 3.0 - 1.0
+    y = ops.znorm_cat(a.cuda(), v.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), O.fuse_av(a, v).numpy()) < 1e-6
+    yb = ops.znorm_cat(a.cuda(), None, biased=True)
+    torch.cuda.synchronize()
+    refb = np.stack([O.feature_normalize_np(r) for r in a.numpy()])
+    assert rel_err(yb.cpu().numpy(), refb) < 1e-6
+    n = ops.l2_normalize(a.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(n.cpu().numpy(), F.normalize(a).numpy()) < 1e-6
+    table = rnd(40, 1024, seed=25)
+    r = np.random.Generator(np.random.PCG64(3))
+    ia = torch.from_numpy(r.integers(0, 40, 500).astype(np.int32))
+    ib = torch.from_numpy(r.integers(0, 40, 500).astype(np.int32))
+    s0 = ops.pair_cosine(table.cuda(), ia.cuda(), ib.cuda(), mode=0)
+    s1 = ops.pair_cosine(table.cuda(), ia.cuda(), ib.cuda(), mode=1)
+    torch.cuda.synchronize()
+    assert np.abs(s0.cpu().numpy() - O.cosine_trial_scores(table.numpy(), ia.numpy(), ib.numpy())).max() < 1e-6
+    assert np.abs(s1.cpu().numpy() - O.torch_cosine_rowwise(table.numpy()[ia], table.numpy()[ib])).max() < 1e-6
+    # score fusion 0.5/0.5 through the accumulate path
+    ta, tv = rnd(40, 512, seed=26), rnd(40, 512, seed=27)
+    sf = ops.pair_cosine(ta.cuda(), ia.cuda(), ib.cuda(), mode=0, weight=0.5)
+    sf = ops.pair_cosine(tv.cuda(), ia.cuda(), ib.cuda(), mode=1, weight=0.5, out=sf)
+    torch.cuda.synchronize()
+    assert np.abs(sf.cpu().numpy() - O.score_fusion(ta.numpy(), tv.numpy(), ia.numpy(), ib.numpy())).max() < 1e-6
+
+
+def test_logits_argmax_and_losses(ops):
+    from oracle import deeplip_oracle as O
+    e = rnd(32, 512, seed=28)
+    W = rnd(57, 512, seed=29)
+    lab = torch.arange(32) % 57
+    loss_ref, logits_ref = O.lmcl(e, lab, W, 30.0, 0.2)
+    logits, amax = ops.logits_argmax(e.cuda(), W.cuda(), cosine=True)
+    loss = ops.margin_ce_loss(logits, lab.cuda(), 30.0, 0.2)
+    torch.cuda.synchronize()
+    assert rel_err(logits.cpu().numpy(), logits_ref.numpy()) < 1e-5
+    assert np.array_equal(amax.cpu().numpy(), O.argmax_first(logits_ref).numpy())
+    l1 = float(loss_ref) - 1e-5 * float(W.abs().sum())
+    assert abs(float(loss.cpu()) - l1) < 1e-4 * abs(l1)
+    b = rnd(57, seed=30)
+    loss_ref, logits_ref = O.cross_entropy_head(e, lab, W, b)
+    logits, amax = ops.logits_argmax(e.cuda(), W.cuda(), b.cuda(), cosine=False)
+    loss = ops.margin_ce_loss(logits, lab.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(logits.cpu().numpy(), logits_ref.numpy()) < 1e-5
+    assert np.array_equal(amax.cpu().numpy(), O.argmax_first(logits_ref).numpy())
+    assert abs(float(loss.cpu()) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    # first-max tie rule
+    e2 = torch.zeros(3, 8); W2 = torch.zeros(5, 8)
+    e2[:, 0] = 1.0; W2[1, 0] = 2.0; W2[3, 0] = 2.0
+    _, am = ops.logits_argmax(e2.cuda(), W2.cuda(), cosine=False)
+    torch.cuda.synchronize()
+    assert am.cpu().tolist() == [1, 1, 1]
+
+
+def test_lowfer_cat(ops):
+    from oracle import deeplip_oracle as O
+    e1, e2 = rnd(4, 512, seed=31), rnd(4, 512, seed=32)
+    y = ops.lowfer_cat(e1.cuda(), e2.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), O.lowfer(e1, e2).numpy()) < 1e-6
