@@ -44,6 +44,7 @@ SIGNATURES = {
     "dlip_nct_to_ntc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_ntc_to_nct_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_ingest_rgb_u8": [c_f, c_f, c_i64, c_i32, c_i32, c_stream],
+    "dlip_affine_act_f32": [c_f, c_f, c_f, c_f, c_i64, c_i32, C.c_float, c_i32, c_stream],
     "dlip_znorm_cat_f32": [c_f, c_i32, c_f, c_i32, c_f, c_i32, c_i32, c_stream],
     "dlip_l2_normalize_f32": [c_f, c_f, c_i32, c_i32, C.c_float, c_stream],
     "dlip_pair_cosine_f32": [c_f, c_i32, c_i32, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_i32, c_stream],

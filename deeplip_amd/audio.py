@@ -1,0 +1,175 @@
+"""Speech encoder (TDNN / E-TDNN x-vector) on the HIP engine.  Host-side mirror of the
+reference's ``models/audio_models/{tdnn,pooling}.py``: same class names, ``opts`` schema,
+state-dict keys and return tuples.
+
+Engine layout is time-major channels-last [B,T,C]: each TDNN_Block (dilated Conv1d + BN +
+LeakyReLU, tdnn.py:35-43) is one implicit-GEMM launch (k=1 layers are plain GEMMs over B*T rows),
+statistics pooling is a two-pass fp64 reduction, fc1/fc2 reuse the GEMM kernel.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from .holders import BatchNormParams, ConvParams, LinearParams, Marker
+from .video import _cached_pack, _require_eval
+
+Tensor = torch.Tensor
+LRELU = 0.2
+
+
+class MeanStdPooling(nn.Module):
+    """pooling.py:7-26: [B,C,T] -> [B,2C] = cat(mean, unbiased std) over T."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        return ops.meanstd_pool(ops.nct_to_ntc(x.contiguous()))
+
+    def run_ntc(self, x_ntc: Tensor) -> Tensor:
+        return ops.meanstd_pool(x_ntc)
+
+
+class AttentiveStatPooling(nn.Module):
+    """pooling.py:73-107.  Parameters kept for state-dict compatibility; the attention pooling
+    kernels are SURVEY.md section 8(f) rank 4 (both shipped configs use `pooling: statistic`)."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.hidden_size, self.input_size = hidden_size, input_size
+        self.W = nn.Parameter(torch.Tensor(hidden_size, input_size))
+        self.b = nn.Parameter(torch.Tensor(1, hidden_size))
+        self.v = nn.Parameter(torch.Tensor(hidden_size, 1))
+        self.k = nn.Parameter(torch.Tensor(1, 1))
+        for p in self.parameters():
+            nn.init.xavier_normal_(p)
+
+    def forward(self, x):
+        raise NotImplementedError("attentive_statistic pooling has no HIP kernel yet (SURVEY.md section 8f rank 4)")
+
+
+class TDNN_Block(nn.Module):
+    """tdnn.py:7-43.  ``dilation`` is the context list, e.g. [-2,0,2] -> kernel 3, dilation 2."""
+
+    def __init__(self, input_dim, output_dim, dilation, padding=0, stride=1, bn_first=True):
+        super().__init__()
+        kernel_size = len(dilation)
+        if len(dilation) > 1:
+            dilation = (dilation[-1] - dilation[0]) // (len(dilation) - 1)
+        else:
+            dilation = 1
+        if stride != 1:
+            raise NotImplementedError("TDNN_Block stride != 1 is never used (tdnn.py:62)")
+        self.kernel_size, self.dilation, self.padding = kernel_size, dilation, padding
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.context_layer = ConvParams(input_dim, output_dim, (kernel_size,), bias=True)
+        self.bn = BatchNormParams(output_dim)
+        self.activation = Marker("LeakyReLU(0.2)")
+        self.bn_first = bn_first
+
+    def pack(self, device) -> packing.Packed:
+        cp = packing.pad_channels(self.input_dim)
+        slope = packing.const_slope(self.output_dim, LRELU, device)
+        if self.bn_first:   # conv -> BN -> LReLU: BN folds into the conv
+            return packing.pack_conv1d(self.context_layer.weight, self.context_layer.bias, self.bn, device, slope, cp)
+        p = packing.pack_conv1d(self.context_layer.weight, self.context_layer.bias, None, device, slope, cp)
+        sc, sh = packing.bn_scale_shift(self.bn)  # conv -> LReLU -> BN: BN is the post-affine of the epilogue
+        p.post_scale, p.post_shift = sc.float().to(device), sh.float().to(device)
+        return p
+
+    def run_ntc(self, x: Tensor, p: packing.Packed) -> Tensor:
+        return ops.conv1d_ntc(x, p.w, p.b, dilation=self.dilation, pad=self.padding, slope=p.slope,
+                              post_scale=p.post_scale, post_shift=p.post_shift)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """[B,C,T] -> [B,K,T'] (reference layout, standalone use)."""
+        _require_eval(self)
+        p = _cached_pack(self, x.device, self.pack)
+        h = ops.nct_to_ntc(x.contiguous(), pad_to=packing.pad_channels(self.input_dim))
+        return ops.ntc_to_nct(self.run_ntc(h, p))
+
+
+class SpeakerEmbNet(nn.Module):
+    """tdnn.py:45-111.  ``opts`` = model options with sub-dict ``opts[opts['arch']]``."""
+
+    def __init__(self, opts):
+        super().__init__()
+        opts = opts[opts["arch"]]
+        context = opts["context"]
+        input_dim = opts["input_dim"]
+        hidden_dim = opts["hidden_dim"]
+        layers_num = opts["tdnn_layers"]
+        embedding_dim = opts["embedding_dim"]
+        attention_hidden_size = opts["attention_hidden_size"]
+        self.bn_first = opts["bn_first"]
+        self.input_dim = input_dim
+        self.embedding_dim = embedding_dim
+        self.activation = Marker("LeakyReLU(0.2)")
+        layers = []
+        for i in range(layers_num):
+            layers.append(TDNN_Block(input_dim, hidden_dim[i], dilation=context[i], stride=1, bn_first=self.bn_first))
+            input_dim = hidden_dim[i]
+        self.tdnn = nn.Sequential(*layers)
+        self.pooling_type = opts["pooling"]
+        if opts["pooling"] == "statistic":
+            self.pooling = MeanStdPooling()
+        elif opts["pooling"] == "average":
+            self.pooling = Marker("AdaptiveAvgPool1d(1)")
+        elif opts["pooling"] == "attentive_statistic":
+            self.pooling = AttentiveStatPooling(hidden_dim[-1], attention_hidden_size)
+        else:
+            raise NotImplementedError("Other pooling method has not implemented.")
+        if opts["pooling"] in ("statistic", "attentive_statistic"):
+            self.fc1 = LinearParams(hidden_dim[-1] * 2, embedding_dim)
+        elif opts["pooling"] == "average":
+            self.fc1 = LinearParams(hidden_dim[-1], embedding_dim)
+        else:
+            raise ValueError("pooling method is wrong!")
+        self.bn1 = BatchNormParams(embedding_dim)
+        self.fc2 = LinearParams(embedding_dim, embedding_dim)
+        self.bn2 = BatchNormParams(embedding_dim)
+
+    def _pack(self, device):
+        def ss(bn):
+            sc, sh = packing.bn_scale_shift(bn)
+            return sc.float().to(device), sh.float().to(device)
+        return {"tdnn": [b.pack(device) for b in self.tdnn],
+                "fc1": packing.pack_linear(self.fc1.weight, self.fc1.bias, None, device),
+                "fc2": packing.pack_linear(self.fc2.weight, self.fc2.bias, None, device),
+                "bn1": ss(self.bn1), "bn2": ss(self.bn2)}
+
+    def _to_ntc(self, x: Tensor) -> Tensor:
+        if x.dim() == 4:            # [B,1,F,T] (the north-star / train_audio.py:183-184 resnet layout)
+            x = x.squeeze(1)
+        if x.dim() != 3 or x.shape[1] != self.input_dim:
+            raise ValueError(f"SpeakerEmbNet expects [B,{self.input_dim},T] features, got {tuple(x.shape)}")
+        return ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim))
+
+    def extract_embedding(self, x: Tensor, taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+        """[B,F,T] -> (xv [B,E] = fc2 output, x_a [B,E] = fc1 output)   (tdnn.py:89-101)."""
+        _require_eval(self)
+        p = _cached_pack(self, x.device, self._pack)
+        h = self._to_ntc(x)
+        for blk, bp in zip(self.tdnn, p["tdnn"]):
+            h = blk.run_ntc(h, bp)
+        if taps is not None:
+            taps["tdnn_out"] = h
+        if self.pooling_type == "statistic":
+            h = ops.meanstd_pool(h)
+        elif self.pooling_type == "average":
+            h = ops.time_mean(h)
+        else:
+            h = self.pooling(h)
+        if taps is not None:
+            taps["pooled"] = h
+        x_a = ops.linear(h, p["fc1"].w, p["fc1"].b)
+        h = ops.affine_act(x_a, p["bn1"][0], p["bn1"][1], LRELU, act_first=not self.bn_first)
+        xv = ops.linear(h, p["fc2"].w, p["fc2"].b)
+        return xv, x_a
+
+    def forward(self, x: Tensor) -> Tensor:
+        """tdnn.py:103-111: extract_embedding()[0] -> bn2 / LeakyReLU."""
+        xv, _ = self.extract_embedding(x)
+        p = _cached_pack(self, x.device, self._pack)
+        return ops.affine_act(xv, p["bn2"][0], p["bn2"][1], LRELU, act_first=not self.bn_first)

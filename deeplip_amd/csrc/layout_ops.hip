@@ -66,3 +66,33 @@ extern "C" int dlip_ingest_rgb_u8(const uint8_t* x, float* y, int64_t n_frames, 
                      (long long)n_frames, H * W);
   return dlip_launch_status();
 }
+
+namespace {
+// y = act(x*scale + shift) (order 0: BN -> LeakyReLU) or act(x)*scale + shift (order 1), per channel.
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y,
+                                                         long long total, int C, float slope, int order) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    float v = x[i];
+    if (order == 0) {
+      v = v * scale[c] + shift[c];
+      v = v >= 0.f ? v : v * slope;
+    } else {
+      v = v >= 0.f ? v : v * slope;
+      v = v * scale[c] + shift[c];
+    }
+    y[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int dlip_affine_act_f32(const float* x, const float* scale, const float* shift, float* y, int64_t M,
+                                   int32_t C, float slope, int32_t order, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && scale && shift && y && M > 0 && C > 0 && (order == 0 || order == 1));
+  long long g = (M * C + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), x, scale,
+                     shift, y, (long long)M * C, C, slope, order);
+  return dlip_launch_status();
+}

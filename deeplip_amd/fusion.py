@@ -1,0 +1,75 @@
+"""Fusion heads on the HIP engine: mirror of ``models/fusion_models/model_fusion.py`` (Linearfusion)
+and ``models/fusion_models/LBP.py`` (LowFER), plus the test-time fusion the reference actually
+uses for scoring: per-modality z-norm + concat (train_fusion.py:233-238,353-358)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from .holders import BatchNormParams, LinearParams, Marker
+from .video import _cached_pack, _require_eval
+
+
+class Linearfusion(nn.Module):
+    """model_fusion.py:10-24: fc1 - bn1 - LeakyReLU(0.2) - fc2; returns x1 if extract_feats."""
+
+    def __init__(self, input_size, hidden_size, num_classes, extract_feats):
+        super().__init__()
+        self.extract_feats = extract_feats
+        self.hidden_size = hidden_size
+        self.fc1 = LinearParams(input_size, hidden_size)
+        self.bn1 = BatchNormParams(hidden_size)
+        self.fc2 = LinearParams(hidden_size, hidden_size)
+        self.activation = Marker("LeakyReLU(0.2)")
+
+    def _pack(self, device):
+        return {"fc1": packing.pack_linear(self.fc1.weight, self.fc1.bias, self.bn1, device,
+                                           packing.const_slope(self.hidden_size, 0.2, device)),
+                "fc2": packing.pack_linear(self.fc2.weight, self.fc2.bias, None, device)}
+
+    def forward(self, x):
+        _require_eval(self)
+        p = _cached_pack(self, x.device, self._pack)
+        x1 = ops.linear(x.contiguous(), p["fc1"].w, p["fc1"].b, slope=p["fc1"].slope)  # fc1+bn1+lrelu fused
+        if self.extract_feats:
+            return x1
+        return ops.linear(x1, p["fc2"].w, p["fc2"].b)
+
+
+def model_fusion(input_size, hidden_size, num_classes, extract_feats):
+    """model_fusion.py:26-27."""
+    return Linearfusion(input_size, hidden_size, num_classes, extract_feats)
+
+
+class LowFER(nn.Module):
+    """LBP.py:8-54.  Parameters U, V, bn0, bn1 are kept for state-dict compatibility (created on the
+    CPU: the reference hard-codes device='cuda', LBP.py:12-15).  forward returns what the shipped
+    code returns -- cat[e1, sigmoid(e2), sigmoid(e2)*e1] -- because the MFB product (LBP.py:38-42) is
+    overwritten before use (LBP.py:48-50)."""
+
+    def __init__(self, d1, d2, o):
+        super().__init__()
+        k = 30
+        self.U = nn.Parameter(torch.tensor(np.random.uniform(-1, 1, (d1, k * o)), dtype=torch.float))
+        self.V = nn.Parameter(torch.tensor(np.random.uniform(-1, 1, (d2, k * o)), dtype=torch.float))
+        self.input_dropout = Marker("Dropout(0.3)")
+        self.hidden_dropout1 = Marker("Dropout(0.4)")
+        self.hidden_dropout2 = Marker("Dropout(0.5)")
+        self.bn0 = BatchNormParams(d1)
+        self.bn1 = BatchNormParams(d1)
+        self.k, self.o = k, o
+
+    def forward(self, e1, e2):
+        return ops.lowfer_cat(e1.contiguous(), e2.contiguous())
+
+
+def feature_normalize(data: torch.Tensor) -> torch.Tensor:
+    """Trainer.feature_normalize (train_fusion.py:233-238): per-row z-norm, unbiased std."""
+    return ops.znorm_cat(data.contiguous(), None)
+
+
+def fuse_av(xv_audio: torch.Tensor, em_video: torch.Tensor) -> torch.Tensor:
+    """train_fusion.py:353-358: cat([znorm(audio), znorm(video)], 1) in one launch -> [U, Da+Dv]."""
+    return ops.znorm_cat(xv_audio.contiguous(), em_video.contiguous())

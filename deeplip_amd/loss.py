@@ -1,0 +1,79 @@
+"""Speaker-classification criteria on the HIP engine: mirror of the reference's
+``models/audio_models/loss.py`` (LMCL = CosFace / AM-softmax, CrossEntropy).
+
+``forward(embeddings, labels) -> (loss, logits)`` exactly as the reference; both values come from
+``dlip_logits_argmax_f32`` + ``dlip_margin_ce_loss_f32``.  ``predict`` adds the first-max argmax
+(torch.max(logits, 1)[1], train_fusion.py:296) from the same launch.  Forward values only: the
+trainable-head backward is SURVEY.md section 8(f) (config C5), not built this round.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .holders import LinearParams
+
+
+class LMCL(nn.Module):
+    """loss.py:33-51.  ``margin`` is a plain attribute the trainers mutate (train_fusion.py:137-141)."""
+
+    def __init__(self, embedding_size, num_classes, s, margin):
+        super().__init__()
+        self.embedding_size, self.num_classes = embedding_size, num_classes
+        self.s, self.margin = s, margin
+        self.weights = nn.Parameter(torch.Tensor(num_classes, embedding_size))
+        nn.init.kaiming_normal_(self.weights)
+
+    def predict(self, embeddings, labels=None):
+        w = self.weights.detach().contiguous()
+        logits, amax = ops.logits_argmax(embeddings.contiguous(), w, cosine=True)
+        loss = None
+        if labels is not None:
+            loss = ops.margin_ce_loss(logits, labels.contiguous(), float(self.s), float(self.margin))
+            # L1 regulariser 1e-5*||W||_1 (loss.py:49-50): a 29k-element reduction, done with the
+            # z-norm kernel's sibling would be overkill -- torch glue, not on the hot path.
+            loss = loss + 0.00001 * w.abs().sum()
+        return loss, logits, amax
+
+    def forward(self, embeddings, labels):
+        loss, logits, _ = self.predict(embeddings, labels)
+        return loss, logits
+
+
+class CrossEntropy(nn.Module):
+    """loss.py:6-16: Linear + CE(logits + 1e-8)."""
+
+    def __init__(self, embedding_size, num_classes):
+        super().__init__()
+        self.embedding_size, self.num_classes = embedding_size, num_classes
+        self.fc = LinearParams(embedding_size, num_classes)
+
+    def predict(self, embeddings, labels=None):
+        logits, amax = ops.logits_argmax(embeddings.contiguous(), self.fc.weight.detach().contiguous(),
+                                         self.fc.bias.detach().contiguous(), cosine=False)
+        loss = ops.margin_ce_loss(logits, labels.contiguous(), 1.0, 0.0) if labels is not None else None
+        return loss, logits, amax
+
+    def forward(self, embeddings, labels):
+        loss, logits, _ = self.predict(embeddings, labels)
+        return loss, logits
+
+
+class _Stub(nn.Module):
+    """ASoftmax / AAMSoftmax / Contrastive are empty TODO stubs upstream (loss.py:53-75)."""
+
+    def forward(self, x):
+        pass
+
+
+class ASoftmax(_Stub):
+    pass
+
+
+class AAMSoftmax(_Stub):
+    pass
+
+
+class Contrastive(_Stub):
+    pass

@@ -180,6 +180,15 @@ def ingest_rgb_u8(frames: Tensor) -> Tensor:
     return y
 
 
+def affine_act(x: Tensor, scale: Tensor, shift: Tensor, slope: float = 0.2, act_first: bool = False) -> Tensor:
+    """[M,C]: lrelu(x*scale+shift) or lrelu(x)*scale+shift (eval BatchNorm1d + LeakyReLU)."""
+    _req(x, "x"); _req(scale, "scale"); _req(shift, "shift")
+    y = torch.empty_like(x)
+    check(lib().dlip_affine_act_f32(ptr(x), ptr(scale), ptr(shift), ptr(y), x.numel() // x.shape[-1], x.shape[-1],
+                                    slope, int(act_first), stream_handle()), "dlip_affine_act_f32")
+    return y
+
+
 def znorm_cat(a: Optional[Tensor], v: Optional[Tensor], biased: bool = False) -> Tensor:
     _req(a, "a"); _req(v, "v")
     U = (a if a is not None else v).shape[0]

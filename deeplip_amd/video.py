@@ -1,0 +1,368 @@
+"""Video lip-clip encoder on the HIP engine.  Host-side mirror of the reference's
+``models/video_models/{model,resnet,tcn}.py``: same class names, constructor signatures,
+attribute (= state-dict key) names and forward signatures, so ``from models.video_models.model
+import Lipreading`` keeps working and the authors' ``video_model.pth`` loads unchanged.
+
+Data layout inside the engine is channels-last: the Conv3d stem writes [(B*T),H,W,C] directly, so
+``threeD_to_2D_tensor`` (model.py:9-13) costs nothing, every BasicBlock conv is one implicit-GEMM
+launch with BN / PReLU / residual fused, and the trunk output [(B*T),512] *is* [B,T,512].
+Encoders run in eval mode only (running-stat BN), as in the reference's fusion pipeline where they
+are frozen (train_fusion.py:198-201,245-252).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from .holders import BatchNormParams, ConvParams, LinearParams, Marker, PReLUParams
+
+Tensor = torch.Tensor
+
+
+def _require_eval(m: nn.Module):
+    if m.training:
+        raise RuntimeError(
+            f"{type(m).__name__}: the HIP engine implements eval-mode (running-statistics) BatchNorm; call .eval() "
+            "first. Train-mode encoder BN / backward is SURVEY.md section 8(f) rank 2 (not built yet).")
+
+
+def _act_holder(relu_type: str, channels: int):
+    return PReLUParams(channels) if relu_type == "prelu" else Marker("ReLU")
+
+
+def _slope(act, channels: int, device) -> Tensor:
+    if isinstance(act, PReLUParams):
+        w = act.weight.detach().float()
+        if w.numel() == 1:
+            w = w.expand(channels)
+        return w.contiguous().to(device)
+    return packing.const_slope(channels, 0.0, device)  # ReLU
+
+
+# ------------------------------------------------------------------------------------------
+# resnet.py
+# ------------------------------------------------------------------------------------------
+def conv3x3(in_planes, out_planes, stride=1):
+    """resnet.py:7-9 (parameter holder; stride/padding live in the engine call)."""
+    c = ConvParams(in_planes, out_planes, (3, 3), bias=False)
+    c.stride = stride
+    return c
+
+
+def downsample_basic_block(inplanes, outplanes, stride):
+    """resnet.py:12-16: 1x1 strided conv + BN; keys downsample.0.weight / downsample.1.*"""
+    c = ConvParams(inplanes, outplanes, (1, 1), bias=False)
+    c.stride = stride
+    return nn.Sequential(c, BatchNormParams(outplanes))
+
+
+class BasicBlock(nn.Module):
+    """resnet.py:28-69."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, relu_type="relu"):
+        super().__init__()
+        assert relu_type in ["relu", "prelu"]
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = BatchNormParams(planes)
+        self.relu1 = _act_holder(relu_type, planes)
+        self.relu2 = _act_holder(relu_type, planes)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = BatchNormParams(planes)
+        self.downsample = downsample
+        self.stride = stride
+        self.planes = planes
+
+    def pack(self, device) -> Dict[str, packing.Packed]:
+        p = {
+            "conv1": packing.pack_conv2d(self.conv1.weight, None, self.bn1, device, _slope(self.relu1, self.planes, device)),
+            "conv2": packing.pack_conv2d(self.conv2.weight, None, self.bn2, device, _slope(self.relu2, self.planes, device)),
+        }
+        if self.downsample is not None:
+            p["down"] = packing.pack_conv2d(self.downsample[0].weight, None, self.downsample[1], device)
+        return p
+
+    def run(self, x: Tensor, p: Dict[str, packing.Packed]) -> Tensor:
+        """x NHWC.  conv1+bn1+relu1 | (1x1 s2 conv + bn) | conv2+bn2 + residual + relu2."""
+        s = (self.stride, self.stride)
+        h = ops.conv_nhwc(x, p["conv1"].w, p["conv1"].b, stride=s, pad=(1, 1), slope=p["conv1"].slope)
+        res = ops.conv_nhwc(x, p["down"].w, p["down"].b, stride=s) if "down" in p else x
+        return ops.conv_nhwc(h, p["conv2"].w, p["conv2"].b, pad=(1, 1), residual=res, slope=p["conv2"].slope)
+
+
+class ResNet(nn.Module):
+    """resnet.py:72-127 (BasicBlock, [2,2,2,2]); init as resnet.py:86-99."""
+
+    def __init__(self, block, layers, num_classes=1000, relu_type="relu", gamma_zero=False,
+                 avg_pool_downsample=False):
+        super().__init__()
+        if avg_pool_downsample:
+            raise NotImplementedError("downsample_basic_block_v2 is not used by any shipped config")
+        self.inplanes = 64
+        self.relu_type = relu_type
+        self.gamma_zero = gamma_zero
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = Marker("AdaptiveAvgPool2d(1)")
+        for m in self.modules():
+            if isinstance(m, ConvParams):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+        if self.gamma_zero:
+            for m in self.modules():
+                if isinstance(m, BasicBlock):
+                    m.bn2.weight.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = downsample_basic_block(self.inplanes, planes * block.expansion, stride)
+        layers = [block(self.inplanes, planes, stride, downsample, relu_type=self.relu_type)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, relu_type=self.relu_type))
+        return nn.Sequential(*layers)
+
+    def blocks(self) -> List[BasicBlock]:
+        return [b for l in (self.layer1, self.layer2, self.layer3, self.layer4) for b in l]
+
+    def pack(self, device):
+        return [b.pack(device) for b in self.blocks()]
+
+    def run(self, x: Tensor, packed, taps: Optional[dict] = None) -> Tensor:
+        """x [N,H,W,64] NHWC -> [N,512]."""
+        for i, (b, p) in enumerate(zip(self.blocks(), packed)):
+            x = b.run(x, p)
+            if taps is not None and i % 2 == 1:
+                taps[f"layer{i // 2 + 1}"] = x
+        return ops.avgpool(x)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """x [N,64,H,W] (reference layout) -> [N,512].  Standalone use; Lipreading calls run()."""
+        _require_eval(self)
+        pk = _cached_pack(self, x.device, self.pack)
+        return self.run(x.permute(0, 2, 3, 1).contiguous(), pk)
+
+
+# ------------------------------------------------------------------------------------------
+# tcn.py (multibranch MS-TCN head; the single-branch TCN is on no shipped config)
+# ------------------------------------------------------------------------------------------
+class Chomp1d(Marker):
+    """tcn.py:12-25.  Symmetric chomp of a (k-1)d-padded conv == 'same' padding (k-1)d/2, which is
+    how the engine runs it; the module is kept for state-dict/API symmetry."""
+
+    def __init__(self, chomp_size, symm_chomp):
+        super().__init__(f"Chomp1d({chomp_size}, symm={symm_chomp})")
+        self.chomp_size, self.symm_chomp = chomp_size, symm_chomp
+        if symm_chomp:
+            assert chomp_size % 2 == 0, "If symmetric chomp, chomp size needs to be even"
+
+
+class ConvBatchChompRelu(nn.Module):
+    """tcn.py:28-59 (dwpw=False)."""
+
+    def __init__(self, n_inputs, n_outputs, kernel_size, stride, dilation, padding, relu_type, dwpw=False):
+        super().__init__()
+        if dwpw:
+            raise NotImplementedError("depthwise-separable TCN (tcn_dwpw) is off in every shipped config")
+        assert stride == 1
+        self.kernel_size, self.dilation, self.padding = kernel_size, dilation, padding
+        self.n_outputs = n_outputs
+        self.conv = ConvParams(n_inputs, n_outputs, (kernel_size,), bias=True)
+        self.batchnorm = BatchNormParams(n_outputs)
+        self.chomp = Chomp1d(padding, True)
+        self.non_lin = _act_holder(relu_type, n_outputs)
+
+    def pack(self, device):
+        return packing.pack_conv1d(self.conv.weight, self.conv.bias, self.batchnorm, device,
+                                   _slope(self.non_lin, self.n_outputs, device))
+
+
+class MultibranchTemporalBlock(nn.Module):
+    """tcn.py:64-116."""
+
+    def __init__(self, n_inputs, n_outputs, kernel_sizes, stride, dilation, padding, dropout=0.2,
+                 relu_type="relu", dwpw=False):
+        super().__init__()
+        self.kernel_sizes = kernel_sizes
+        self.num_kernels = len(kernel_sizes)
+        self.n_outputs_branch = n_outputs // self.num_kernels
+        self.n_outputs = n_outputs
+        self.dilation = dilation
+        assert n_outputs % self.num_kernels == 0, "Number of output channels needs to be divisible by number of kernels"
+        for k_idx, k in enumerate(kernel_sizes):
+            setattr(self, f"cbcr0_{k_idx}", ConvBatchChompRelu(n_inputs, self.n_outputs_branch, k, stride, dilation,
+                                                                padding[k_idx], relu_type, dwpw=dwpw))
+        self.dropout0 = Marker(f"Dropout({dropout})")
+        for k_idx, k in enumerate(kernel_sizes):
+            setattr(self, f"cbcr1_{k_idx}", ConvBatchChompRelu(n_outputs, self.n_outputs_branch, k, stride, dilation,
+                                                                padding[k_idx], relu_type, dwpw=dwpw))
+        self.dropout1 = Marker(f"Dropout({dropout})")
+        # tcn.py:87 -- the test compares n_inputs//num_kernels with n_outputs, so it is always true for
+        # the shipped config and every block owns a 1x1 projection.
+        self.downsample = ConvParams(n_inputs, n_outputs, (1,), bias=True) if (n_inputs // self.num_kernels) != n_outputs else None
+        self.relu_final = _act_holder(relu_type, n_outputs)
+
+    def pack(self, device):
+        p = {f"cbcr{s}_{j}": getattr(self, f"cbcr{s}_{j}").pack(device) for s in (0, 1) for j in range(self.num_kernels)}
+        if self.downsample is not None:
+            p["down"] = packing.pack_conv1d(self.downsample.weight, self.downsample.bias, None, device)
+        p["final_slope"] = _slope(self.relu_final, self.n_outputs, device)
+        return p
+
+    def run(self, x: Tensor, p) -> Tensor:
+        """x [B,T,Cin] -> [B,T,n_outputs]; branches write channel slices of one buffer (no concat)."""
+        B, T, _ = x.shape
+        nb = self.n_outputs_branch
+        cur = x
+        for s in (0, 1):
+            out = torch.empty((B, T, self.n_outputs), device=x.device, dtype=torch.float32)
+            for j, k in enumerate(self.kernel_sizes):
+                pk = p[f"cbcr{s}_{j}"]
+                ops.conv1d_ntc(cur, pk.w, pk.b, dilation=self.dilation, pad=(k - 1) * self.dilation // 2,
+                               slope=pk.slope, out=out, out_channel_offset=j * nb)
+            cur = out  # dropout: identity in eval
+        if self.downsample is not None:
+            return ops.conv1d_ntc(x, p["down"].w, p["down"].b, residual=cur, slope=p["final_slope"])
+        raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
+
+
+class MultibranchTemporalConvNet(nn.Module):
+    """tcn.py:118-140."""
+
+    def __init__(self, num_inputs, num_channels, tcn_options, dropout=0.2, relu_type="relu", dwpw=False):
+        super().__init__()
+        self.ksizes = tcn_options["kernel_size"]
+        layers = []
+        for i in range(len(num_channels)):
+            d = 2 ** i
+            cin = num_inputs if i == 0 else num_channels[i - 1]
+            padding = [(s - 1) * d for s in self.ksizes]
+            layers.append(MultibranchTemporalBlock(cin, num_channels[i], self.ksizes, stride=1, dilation=d,
+                                                   padding=padding, dropout=dropout, relu_type=relu_type, dwpw=dwpw))
+        self.network = nn.Sequential(*layers)
+
+
+class MultiscaleMultibranchTCN(nn.Module):
+    """model.py:20-37."""
+
+    def __init__(self, input_size, num_channels, num_classes, tcn_options, dropout, relu_type, dwpw=False):
+        super().__init__()
+        self.kernel_sizes = tcn_options["kernel_size"]
+        self.num_kernels = len(self.kernel_sizes)
+        self.mb_ms_tcn = MultibranchTemporalConvNet(input_size, num_channels, tcn_options, dropout=dropout,
+                                                    relu_type=relu_type, dwpw=dwpw)
+        self.tcn_output = LinearParams(num_channels[-1], num_classes)
+
+    def pack(self, device):
+        return {"blocks": [b.pack(device) for b in self.mb_ms_tcn.network],
+                "out": packing.pack_linear(self.tcn_output.weight, self.tcn_output.bias, None, device)}
+
+    def run(self, x: Tensor, lengths, p) -> Tensor:
+        """x [B,T,512] (already time-major channels-last: the reference's transpose(1,2) is a no-op here)."""
+        for b, bp in zip(self.mb_ms_tcn.network, p["blocks"]):
+            x = b.run(x, bp)
+        ln = torch.as_tensor([int(l) for l in lengths], dtype=torch.int32).to(x.device)
+        pooled = ops.time_mean(x, ln)                       # _average_batch, model.py:16-17
+        return ops.linear(pooled, p["out"].w, p["out"].b)   # tcn_output, model.py:27,37
+
+    def forward(self, x, lengths, B):
+        _require_eval(self)
+        return self.run(x.contiguous(), lengths, _cached_pack(self, x.device, self.pack))
+
+
+class TCN(nn.Module):
+    """model.py:40-58 single-branch head: selected only when len(kernel_size) == 1, which no
+    shipped config does (conf/video_config.json:6-10, conf/fusion_config.yaml:80)."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("single-branch TCN head is out of scope (no shipped config selects it)")
+
+
+# ------------------------------------------------------------------------------------------
+# model.py
+# ------------------------------------------------------------------------------------------
+def _cached_pack(module: nn.Module, device, builder):
+    ver = packing.state_version(module, device)
+    cache = module.__dict__.get("_dlip_pack")
+    if cache is None or cache[0] != ver:
+        cache = (ver, builder(device))
+        module.__dict__["_dlip_pack"] = cache
+    return cache[1]
+
+
+class Lipreading(nn.Module):
+    """model.py:61-105.  forward(x [B,1,T,H,W], lengths) -> [B,T,512] (extract_feats) or logits."""
+
+    def __init__(self, hidden_dim=256, backbone_type="resnet", num_classes=500, relu_type="prelu",
+                 tcn_options={}, width_mult=1.0, extract_feats=False):
+        super().__init__()
+        self.extract_feats = extract_feats
+        self.backbone_type = backbone_type
+        self.relu_type = relu_type
+        if backbone_type == "resnet":
+            self.frontend_nout = 64
+            self.backend_out = 512
+            self.trunk = ResNet(BasicBlock, [2, 2, 2, 2], relu_type=relu_type)
+        elif backbone_type == "shufflenet":
+            assert width_mult in [0.5, 1.0, 1.5, 2.0], "Width multiplier not correct"
+            raise NotImplementedError("shufflenet backbone is out of scope: both shipped configs select resnet "
+                                      "(conf/video_config.json:2, conf/fusion_config.yaml:75)")
+        else:
+            raise NotImplementedError(backbone_type)
+        frontend_relu = PReLUParams(self.frontend_nout) if relu_type == "prelu" else Marker("ReLU")
+        stem = ConvParams(1, self.frontend_nout, (5, 7, 7), bias=False)
+        self.frontend3D = nn.Sequential(stem, BatchNormParams(self.frontend_nout), frontend_relu,
+                                        Marker("MaxPool3d((1,3,3),(1,2,2),(0,1,1))"))
+        tcn_class = TCN if len(tcn_options["kernel_size"]) == 1 else MultiscaleMultibranchTCN
+        self.tcn = tcn_class(input_size=self.backend_out,
+                             num_channels=[hidden_dim * len(tcn_options["kernel_size"]) * tcn_options["width_mult"]] * tcn_options["num_layers"],
+                             num_classes=num_classes, tcn_options=tcn_options, dropout=tcn_options["dropout"],
+                             relu_type=relu_type, dwpw=tcn_options["dwpw"])
+
+    def _pack(self, device):
+        return {
+            "stem": packing.pack_stem3d(self.frontend3D[0].weight, self.frontend3D[1], device,
+                                        _slope(self.frontend3D[2], self.frontend_nout, device)),
+            "trunk": self.trunk.pack(device),
+            "tcn": self.tcn.pack(device),
+        }
+
+    def forward(self, x: Tensor, lengths, taps: Optional[dict] = None):
+        _require_eval(self)
+        B, C, T, H, W = x.size()
+        if C != 1:
+            raise ValueError("Lipreading expects grayscale clips [B,1,T,H,W] (model.py:82); use "
+                             "deeplip_amd.ops.ingest_rgb_u8 for [B,T,3,H,W] uint8 RGB")
+        p = _cached_pack(self, x.device, self._pack)
+        x = x.contiguous().float()
+        y = ops.stem3d(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope)   # [(B*T),H/2,W/2,64]
+        if taps is not None:
+            taps["stem_act"] = y
+        y = ops.maxpool3x3s2(y)
+        if taps is not None:
+            taps["stem"] = y
+        y = self.trunk.run(y, p["trunk"], taps).view(B, T, self.backend_out)
+        return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
+
+    def embed(self, x: Tensor) -> Tensor:
+        """[B,1,T,H,W] -> [B,512]: per-clip temporal mean of the features, the quantity the fusion
+        pipeline consumes (train_fusion.py:274,348)."""
+        ef, self.extract_feats = self.extract_feats, True
+        try:
+            return ops.time_mean(self.forward(x, lengths=None))
+        finally:
+            self.extract_feats = ef
+
+
+def threeD_to_2D_tensor(x):
+    """model.py:9-13: kept for API completeness; a pure index permutation (no arithmetic)."""
+    n_batch, n_channels, s_time, sx, sy = x.shape
+    return x.transpose(1, 2).reshape(n_batch * s_time, n_channels, sx, sy)

@@ -120,6 +120,12 @@ int dlip_ntc_to_nct_f32(const float* x, float* y, int32_t B, int32_t T, int32_t 
 int dlip_ingest_rgb_u8(const uint8_t* x, float* y, int64_t n_frames, int32_t H, int32_t W,
                        dlip_stream_t stream);
 
+/* Eval-mode BatchNorm1d (as per-channel scale/shift) and LeakyReLU(slope) on [M,C]:
+ * order 0: y = lrelu(x*scale + shift)  (bn_first, tdnn.py:92-94,105-107; model_fusion.py:21-22)
+ * order 1: y = lrelu(x)*scale + shift  (tdnn.py:96-97,109-110). */
+int dlip_affine_act_f32(const float* x, const float* scale, const float* shift, float* y, int64_t M,
+                        int32_t C, float slope, int32_t order, dlip_stream_t stream);
+
 /* Per-row z-normalisation with the UNBIASED std (train_fusion.py:233-238) of a [U,Da] and a [U,Dv]
  * table, concatenated into y [U, Da+Dv] (train_fusion.py:353-358).  Either input may be NULL
  * (D = 0) to z-normalise a single table.  biased != 0 selects numpy's biased std

@@ -1,0 +1,102 @@
+"""CPU tests of the host logic: state-dict schema of the drop-in modules equals the reference's
+(manifest captured from the reference classes), BN folding identity, EER implementation vs the
+golden (sklearn + scipy) value, module guards."""
+import numpy as np
+import pytest
+import torch
+
+from deeplip_amd import packing, scoring, weightgen as wg
+
+TCN_OPTS = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
+
+
+def shapes(m):
+    return {k: list(v.shape) for k, v in m.state_dict().items()}
+
+
+def test_video_state_dict_schema(manifest):
+    from models.video_models.model import Lipreading
+    net = Lipreading(hidden_dim=256, backbone_type="resnet", num_classes=54, relu_type="prelu",
+                     tcn_options=TCN_OPTS, width_mult=1.0, extract_feats=True)
+    assert shapes(net) == manifest["video_prelu_54"]
+    assert len(net.state_dict()) == 343
+    net = Lipreading(hidden_dim=256, num_classes=57, relu_type="relu", tcn_options=TCN_OPTS)
+    assert shapes(net) == manifest["video_relu_57"]
+
+
+def test_audio_and_heads_state_dict_schema(manifest):
+    from models.audio_models.tdnn import SpeakerEmbNet
+    from models.audio_models.loss import LMCL, CrossEntropy
+    from models.fusion_models.model_fusion import model_fusion
+    from oracle.deeplip_oracle import ETDNN_CONTEXT, TDNN_CONTEXT
+    et = {"input_dim": 24, "hidden_dim": [512] * 9 + [1500], "context": ETDNN_CONTEXT, "tdnn_layers": 10,
+          "embedding_dim": 512, "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+    td = {"input_dim": 24, "hidden_dim": [512] * 4 + [1500], "context": TDNN_CONTEXT, "tdnn_layers": 5,
+          "embedding_dim": 512, "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+    assert shapes(SpeakerEmbNet({"arch": "etdnn", "etdnn": et})) == manifest["audio_etdnn_24"]
+    assert len(SpeakerEmbNet({"arch": "etdnn", "etdnn": et}).state_dict()) == 84
+    assert shapes(SpeakerEmbNet({"arch": "tdnn", "tdnn": td})) == manifest["audio_tdnn_24"]
+    at = dict(td, pooling="attentive_statistic")
+    assert shapes(SpeakerEmbNet({"arch": "tdnn", "tdnn": at})) == manifest["audio_tdnn_24_attentive"]
+    assert shapes(LMCL(512, 57, 30, 0.2)) == manifest["lmcl_512_57"]
+    assert shapes(CrossEntropy(1024, 57)) == manifest["ce_1024_57"]
+    assert shapes(model_fusion(1024, 512, 57, False)) == manifest["linearfusion_1024_512"]
+    with pytest.raises(NotImplementedError):
+        SpeakerEmbNet({"arch": "tdnn", "tdnn": dict(td, pooling="mono_head_attention")})
+
+
+def test_bn_fold_identity():
+    from deeplip_amd.holders import BatchNormParams
+    torch.manual_seed(0)
+    bn = BatchNormParams(8)
+    sd = wg.fill_state_dict({f"bn.{k}": tuple(v.shape) for k, v in bn.state_dict().items()})
+    bn.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in sd.items()})
+    w = torch.randn(8, 4, 3, 3); b = torch.randn(8); x = torch.randn(2, 4, 5, 5)
+    ref = torch.nn.functional.batch_norm(torch.nn.functional.conv2d(x, w, b), bn.running_mean, bn.running_var,
+                                         bn.weight, bn.bias, False, 0.0, bn.eps)
+    wf, bf = packing.fold(w, b, bn)
+    got = torch.nn.functional.conv2d(x.double(), wf, bf)
+    assert float((got - ref.double()).abs().max()) < 1e-5
+
+
+def test_holders_refuse_to_compute():
+    from deeplip_amd.holders import ConvParams
+    with pytest.raises(RuntimeError):
+        ConvParams(4, 4, (3, 3))(torch.zeros(1, 4, 8, 8))
+
+
+def test_models_refuse_train_mode_and_cpu():
+    from models.fusion_models.model_fusion import model_fusion
+    from deeplip_amd._lib import DeepLipHipError
+    m = model_fusion(16, 8, 3, False)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 16))           # train mode
+    m.eval()
+    with pytest.raises(DeepLipHipError):
+        m(torch.zeros(2, 16))           # CPU tensor: no fallback
+
+
+def test_eer_matches_golden(golden):
+    g = golden["heads"]
+    e, thr = scoring.eer_from_scores(g["eer_y_true"].astype(int), g["eer_scores"])
+    assert abs(e - float(g["eer"])) < 1e-9
+    assert abs(thr - float(g["eer_threshold"])) < 1e-7
+
+
+def test_roc_curve_matches_sklearn():
+    from sklearn.metrics import roc_curve as sk_roc
+    r = np.random.Generator(np.random.PCG64(5))
+    for n in (10, 257, 5000):
+        y = r.integers(0, 2, n)
+        s = np.round(r.standard_normal(n), 1).astype(np.float32)   # many ties
+        a = scoring.roc_curve(y, s)
+        b = sk_roc(y, s, pos_label=1)
+        for u, v in zip(a, b):
+            assert np.array_equal(np.asarray(u, dtype=np.float64), np.asarray(v, dtype=np.float64))
+
+
+def test_trial_list_reader(tmp_path):
+    p = tmp_path / "t.txt"
+    p.write_text("1 a.wav b.wav\n0 a.wav c.wav\n")
+    y, pairs = scoring.read_trial_list(str(p))
+    assert y.tolist() == [1, 0] and pairs == [("a.wav", "b.wav"), ("a.wav", "c.wav")]

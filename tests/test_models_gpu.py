@@ -1,0 +1,239 @@
+"""Model-level parity (-m gpu): the drop-in ``models.*`` modules running on the HIP engine against
+(a) the committed golden vectors captured from the reference classes and (b) the CPU oracle on the
+same seeded inputs, up to the BASELINE.json parity sizes ([32,1,29,88,88] clips, [32,80,300] mels).
+
+Tolerances (BASELINE.json north_star): embeddings / features / trial scores within 1e-4 relative
+(measured as max|a-b| / max|b| per tensor; scores: absolute, they live in [-1,1]); speaker-label
+argmax bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from deeplip_amd import weightgen as wg
+from oracle import deeplip_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+TCN_OPTS = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
+DEV = "cuda"
+
+
+def load(module, prefix):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = wg.fill_state_dict(shapes, prefix=prefix)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return module.eval().to(DEV), O.to_torch_sd(sd)
+
+
+def etdnn_opts(input_dim=24, **kw):
+    o = {"input_dim": input_dim, "hidden_dim": [512] * 9 + [1500], "context": O.ETDNN_CONTEXT, "tdnn_layers": 10,
+         "embedding_dim": 512, "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+    o.update(kw)
+    return {"arch": "etdnn", "etdnn": o}
+
+
+def tdnn_opts(**kw):
+    o = {"input_dim": 24, "hidden_dim": [512] * 4 + [1500], "context": O.TDNN_CONTEXT, "tdnn_layers": 5,
+         "embedding_dim": 512, "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+    o.update(kw)
+    return {"arch": "tdnn", "tdnn": o}
+
+
+@pytest.fixture(scope="module")
+def video_net():
+    from models.video_models.model import Lipreading
+    net = Lipreading(hidden_dim=256, backbone_type="resnet", num_classes=54, relu_type="prelu",
+                     tcn_options=TCN_OPTS, width_mult=1.0, extract_feats=True)
+    return load(net, "video.")
+
+
+def test_video_golden_features_and_taps(golden, video_net):
+    net, _ = video_net
+    g = golden["video"]
+    x = torch.from_numpy(wg.video_input(4)).to(DEV)
+    taps = {}
+    net.extract_feats = True
+    feats = net(x, lengths=[29] * 4, taps=taps)
+    torch.cuda.synchronize()
+    assert feats.shape == (4, 29, 512)
+    assert rel_err(feats[:2].cpu().numpy(), g["feats_b2"]) < TOL
+    assert rel_err(feats.mean(1).cpu().numpy(), g["feats_time_mean"]) < TOL
+    assert rel_err(net.embed(x).cpu().numpy(), g["feats_time_mean"]) < TOL
+    b, t = [int(v) for v in g["tap_frame"]]
+    f = b * 29 + t
+    assert rel_err(taps["stem_act"][f, :, :, :8].permute(2, 0, 1).cpu().numpy(), g["tap_stem_act_c8"]) < TOL
+    assert rel_err(taps["stem"][f].permute(2, 0, 1).cpu().numpy(), g["tap_stem"]) < TOL
+    for li in range(1, 5):
+        assert rel_err(taps[f"layer{li}"][f].permute(2, 0, 1).cpu().numpy(), g[f"tap_layer{li}"]) < TOL
+
+
+def test_video_golden_tcn_logits(golden, video_net):
+    net, _ = video_net
+    g = golden["video"]
+    x = torch.from_numpy(wg.video_input(4))
+    lengths = [int(v) for v in g["tcn_lengths"]]
+    xp = x.clone()
+    for i, l in enumerate(lengths):
+        xp[i, :, l:] = 0.0
+    net.extract_feats = False
+    try:
+        logits = net(xp.to(DEV), lengths=lengths)
+        full = net(x.to(DEV), lengths=[29] * 4)
+        torch.cuda.synchronize()
+    finally:
+        net.extract_feats = True
+    assert rel_err(logits.cpu().numpy(), g["tcn_logits"]) < TOL
+    assert rel_err(full.cpu().numpy(), g["tcn_logits_full"]) < TOL
+    assert np.array_equal(torch.max(logits, 1)[1].cpu().numpy(), g["tcn_argmax"])
+
+
+def test_video_relu_variant(golden):
+    from models.video_models.model import Lipreading
+    net, _ = load(Lipreading(hidden_dim=256, num_classes=57, relu_type="relu", tcn_options=TCN_OPTS,
+                             extract_feats=True), "video_relu.")
+    x = torch.from_numpy(wg.video_input(1, frames=5, key="input.video.short")).to(DEV)
+    f = net(x, lengths=[5])
+    torch.cuda.synchronize()
+    assert rel_err(f.cpu().numpy(), golden["video"]["relu_feats_t5"]) < TOL
+
+
+def test_video_parity_size_b32_vs_oracle_and_batch_invariance(video_net):
+    """BASELINE parity size [32,1,29,88,88]: HIP vs oracle, and bit-exact batch invariance (each
+    output element is one fixed-order fp32 fma chain, so tiling / batch size cannot change it)."""
+    net, sd = video_net
+    x = torch.from_numpy(wg.video_input(32, speakers=np.arange(32) % 8))
+    em = net.embed(x.to(DEV))
+    em4 = net.embed(x[8:12].to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(em[8:12], em4)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.video_time_mean(O.lipreading_features(sd, x[:8]))   # 8 clips keep the CPU leg in seconds
+    assert rel_err(em[:8].cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.fixture(scope="module")
+def audio_net():
+    from models.audio_models.tdnn import SpeakerEmbNet
+    return load(SpeakerEmbNet(etdnn_opts()), "audio.")
+
+
+def test_audio_golden_etdnn(golden, audio_net):
+    net, _ = audio_net
+    g = golden["audio"]
+    x = torch.from_numpy(wg.audio_input(4, 24, 300)).to(DEV)
+    taps = {}
+    xv, xa = net.extract_embedding(x, taps=taps)
+    fwd = net(x)
+    torch.cuda.synchronize()
+    assert rel_err(xv.cpu().numpy(), g["etdnn_xv"]) < TOL
+    assert rel_err(xa.cpu().numpy(), g["etdnn_xa"]) < TOL
+    assert rel_err(fwd.cpu().numpy(), g["etdnn_forward"]) < TOL
+    assert rel_err(taps["pooled"].cpu().numpy(), g["etdnn_pooled"]) < TOL
+    assert rel_err(taps["tdnn_out"][:, :, :16].permute(0, 2, 1).cpu().numpy(), g["etdnn_tdnn_out_c16"]) < TOL
+    x200 = torch.from_numpy(wg.audio_input(2, 24, 200, key="input.audio.t200")).to(DEV)
+    assert rel_err(net.extract_embedding(x200)[0].cpu().numpy(), g["etdnn_xv_t200"]) < TOL
+    # [B,1,F,T] north-star layout is accepted and squeezed
+    assert torch.equal(net.extract_embedding(x.unsqueeze(1))[0], xv)
+
+
+def test_audio_golden_variants(golden):
+    from models.audio_models.tdnn import SpeakerEmbNet
+    g = golden["audio"]
+    x = torch.from_numpy(wg.audio_input(4, 24, 300)).to(DEV)
+    net, _ = load(SpeakerEmbNet(tdnn_opts()), "audio5.")
+    assert rel_err(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_xv"]) < TOL
+    net, _ = load(SpeakerEmbNet(etdnn_opts(80)), "audio80.")
+    x80 = torch.from_numpy(wg.audio_input(2, 80, 300, key="input.audio.f80")).to(DEV)
+    assert rel_err(net.extract_embedding(x80)[0].cpu().numpy(), g["etdnn80_xv"]) < TOL
+    net, _ = load(SpeakerEmbNet(tdnn_opts(bn_first=False)), "audio_nb.")
+    assert rel_err(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_actfirst_xv"]) < TOL
+    assert rel_err(net(x).cpu().numpy(), g["tdnn_actfirst_forward"]) < TOL
+
+
+def test_audio_parity_size_b32_f80_vs_oracle():
+    """BASELINE parity size: [32,1,80,300] mel tensors through E-TDNN(input_dim=80)."""
+    from models.audio_models.tdnn import SpeakerEmbNet
+    net, sd = load(SpeakerEmbNet(etdnn_opts(80)), "audio80.")
+    x = torch.from_numpy(wg.audio_input(32, 80, 300, speakers=np.arange(32) % 8))
+    xv, _ = net.extract_embedding(x.unsqueeze(1).to(DEV))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref, _ = O.speaker_extract_embedding(sd, x, O.ETDNN_CONTEXT)
+    assert rel_err(xv.cpu().numpy(), ref.numpy()) < TOL
+
+
+def test_pooling_module(golden):
+    from models.audio_models.pooling import MeanStdPooling
+    xp = torch.from_numpy(wg.gen("input.pool", (3, 40, 50))).to(DEV)
+    assert rel_err(MeanStdPooling()(xp).cpu().numpy(), golden["audio"]["meanstd_pool"]) < 1e-6
+
+
+def test_heads_golden(golden):
+    from models.audio_models.loss import LMCL, CrossEntropy
+    from models.fusion_models.model_fusion import model_fusion
+    g = golden["heads"]
+    emb = torch.from_numpy(wg.gen("input.emb", (32, 512))).to(DEV)
+    lab = torch.from_numpy(wg.labels(32, 57)).to(DEV)
+    crit, _ = load(LMCL(512, 57, 30, 0.2), "lmcl.")
+    loss, logits = crit(emb, lab)
+    _, _, amax = crit.predict(emb)
+    assert rel_err(logits.cpu().numpy(), g["lmcl_logits"]) < TOL
+    assert abs(float(loss) - float(g["lmcl_loss"])) < TOL * float(g["lmcl_loss"])
+    assert np.array_equal(amax.cpu().numpy(), g["lmcl_argmax"])          # int64, bit-exact
+    assert amax.dtype == torch.int64
+    emb2 = torch.from_numpy(wg.gen("input.emb1024", (32, 1024))).to(DEV)
+    ce, _ = load(CrossEntropy(1024, 57), "ce.")
+    loss, logits = ce(emb2, lab)
+    assert rel_err(logits.cpu().numpy(), g["ce_logits"]) < TOL
+    assert abs(float(loss) - float(g["ce_loss"])) < TOL * float(g["ce_loss"])
+    assert np.array_equal(ce.predict(emb2)[2].cpu().numpy(), g["ce_argmax"])
+    for ef in (False, True):
+        lf, _ = load(model_fusion(1024, 512, 57, ef), "lf.")
+        assert rel_err(lf(emb2).cpu().numpy(), g[f"linearfusion_extract{int(ef)}"]) < TOL
+
+
+def test_fusion_and_scoring_golden(golden):
+    from deeplip_amd import fusion, scoring
+    g = golden["heads"]
+    xa = torch.from_numpy(wg.gen("input.xv_audio", (4, 512))).to(DEV)
+    ev = torch.from_numpy(wg.gen("input.em_video", (4, 512))).to(DEV)
+    assert rel_err(fusion.fuse_av(xa, ev).cpu().numpy(), g["fused_av"]) < 1e-6
+    table = torch.from_numpy(wg.gen("input.table", (40, 1024))).to(DEV)
+    ia = torch.from_numpy(g["trial_idx_a"].astype(np.int32)).to(DEV)
+    ib = torch.from_numpy(g["trial_idx_b"].astype(np.int32)).to(DEV)
+    assert np.abs(scoring.cosine_scores(table, ia, ib).cpu().numpy() - g["trial_cos"]).max() < 1e-6
+    ta = torch.from_numpy(wg.gen("input.table_a", (40, 512))).to(DEV)
+    tv = torch.from_numpy(wg.gen("input.table_v", (40, 512))).to(DEV)
+    assert np.abs(scoring.score_fusion(ta, tv, ia, ib).cpu().numpy() - g["trial_scorefusion"]).max() < 1e-6
+    ff = scoring.feature_fusion_scores(ta, tv, ia, ib).cpu().numpy()
+    ref = O.feature_fusion_scores(ta.cpu().numpy(), tv.cpu().numpy(), g["trial_idx_a"], g["trial_idx_b"])
+    assert np.abs(ff - ref).max() < 1e-6
+
+
+def test_end_to_end_fused_av_trials_vs_oracle(video_net, audio_net):
+    """Config C4 in miniature: 16 utterances (4 speakers x 4), one clip each -> fused [16,1024]
+    -> all 120 pairs scored; HIP vs oracle: scores within 1e-4, EER equal to 1e-9 given equal
+    score ordering."""
+    from deeplip_amd import fusion, scoring
+    vnet, vsd = video_net
+    anet, asd = audio_net
+    spk = np.arange(16) // 4
+    xv_in = torch.from_numpy(wg.video_input(16, speakers=spk, key="input.video.c4"))
+    xa_in = torch.from_numpy(wg.audio_input(16, 24, 300, speakers=spk, key="input.audio.c4"))
+    fused = fusion.fuse_av(anet.extract_embedding(xa_in.to(DEV))[0], vnet.embed(xv_in.to(DEV)))
+    ia, ib = np.triu_indices(16, 1)
+    s = scoring.cosine_scores(fused, torch.from_numpy(ia.astype(np.int32)).to(DEV),
+                              torch.from_numpy(ib.astype(np.int32)).to(DEV))
+    torch.cuda.synchronize()
+    ref_fused = O.fused_av_embedding(vsd, asd, xv_in, xa_in)
+    ref_s = O.cosine_trial_scores(ref_fused.numpy(), ia, ib)
+    assert rel_err(fused.cpu().numpy(), ref_fused.numpy()) < TOL
+    assert np.abs(s.cpu().numpy() - ref_s).max() < TOL
+    y = (spk[ia] == spk[ib]).astype(int)
+    e_hip, _ = scoring.eer_from_scores(y, s.cpu().numpy())
+    e_ref, _ = O.eer(y, [np.array([v]) for v in ref_s])
+    assert abs(e_hip - e_ref) < 1e-3
