@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- fused audio-visual lip-biometric embedding throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic A+V pairs PER RANK
+(BASELINE.json configs[1] clip batch, one utterance per clip -- SURVEY.md section 8d C2/C3/C4):
+    video  [B,1,29,88,88] -> Lipreading(extract_feats) -> temporal mean -> [B,512]
+    audio  [B,1,80,300]   -> E-TDNN extract_embedding             -> [B,512]
+    fuse   z-norm + concat (train_fusion.py:353-358)               -> [B,1024]
+    (N>1)  all-gather of the [B,1024] rows over RCCL: the enrol/verify exchange step
+Inputs and weights are synthetic (name-keyed generator, seed 1), already resident in HBM when the
+timed region starts.  Rank 0 prints ONE JSON line.  metric = lip-clips/sec (whole job).
+
+roofline: the path is an fp32 dense contraction (exact fp32 MFMA, peak 157.3 TFLOP/s per
+MI355X, MI355X_MICROARCH.md).  `achieved` is for the dominant kernel (the implicit-GEMM conv
+instance that carries most FLOPs): algorithmic FLOPs of its launches in a step / the sum of their
+durations, both measured with HIP events around every launch inside the timed region, on the
+stream the kernels run on.  `step_achieved` applies BASELINE.md's whole-step formula
+(clips/s x 20.90 GFLOP).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GFLOP_PER_FUSED_CLIP = 20.90      # BASELINE.md section 2 (18.337 video + 2.563 audio)
+TCN_OPTS = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
+ETDNN_CONTEXT = [[-2, -1, 0, 1, 2], [0], [-2, 0, 2], [0], [-3, 0, 3], [0], [-4, 0, 4], [0], [0], [0]]
+
+
+class EventHook:
+    """Brackets every MFMA-kernel launch with HIP events on the current stream."""
+
+    def __init__(self):
+        self.records = []   # (name, flops, ev0, ev1)
+        self.enabled = False
+
+    def begin(self, name, flops):
+        if not self.enabled:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, flops, e0, e1)
+
+    def end(self, tok):
+        if tok is not None:
+            tok[3].record()
+            self.records.append(tok)
+
+    def summary(self):
+        agg = {}
+        for name, flops, e0, e1 in self.records:
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+        return agg
+
+
+def build_models(device, audio_dim):
+    from deeplip_amd import weightgen as wg
+    from models.audio_models.tdnn import SpeakerEmbNet
+    from models.video_models.model import Lipreading
+    video = Lipreading(hidden_dim=256, backbone_type="resnet", num_classes=57, relu_type="prelu",
+                       tcn_options=TCN_OPTS, width_mult=1.0, extract_feats=True)
+    et = {"input_dim": audio_dim, "hidden_dim": [512] * 9 + [1500], "context": ETDNN_CONTEXT, "tdnn_layers": 10,
+          "embedding_dim": 512, "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+    audio = SpeakerEmbNet({"arch": "etdnn", "etdnn": et})
+    sds = []
+    for m, pre in ((video, "video."), (audio, "audio80.")):
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        sd = wg.fill_state_dict(shapes, prefix=pre)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m.eval().to(device)
+        sds.append(sd)
+    return video, audio, sds
+
+
+def step(video, audio, xv, xa, world):
+    from deeplip_amd import fusion
+    em_video = video.embed(xv)
+    xv_audio, _ = audio.extract_embedding(xa)
+    fused = fusion.fuse_av(xv_audio, em_video)
+    if world > 1:
+        out = torch.empty((world * fused.shape[0], fused.shape[1]), device=fused.device, dtype=fused.dtype)
+        dist.all_gather_into_tensor(out, fused)
+        return out
+    return fused
+
+
+def cpu_baseline(sds, audio_dim, budget_s=12.0, sample=8):
+    """The CPU oracle (port of the reference path) timed on this box's host cores."""
+    from deeplip_amd import weightgen as wg
+    from oracle import deeplip_oracle as O
+    vsd, asd = O.to_torch_sd(sds[0]), O.to_torch_sd(sds[1])
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    xv = torch.from_numpy(wg.video_input(sample, key="bench.video"))
+    xa = torch.from_numpy(wg.audio_input(sample, audio_dim, 300, key="bench.audio"))
+    ref = O.fused_av_embedding(vsd, asd, xv, xa)   # warm-up + parity reference
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        O.fused_av_embedding(vsd, asd, xv, xa)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or iters >= 50:
+            break
+    return {"value": round(sample * iters / el, 3), "unit": "lip-clips/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{iters} passes of the oracle fused A+V embed on {sample} clips [{sample},1,29,88,88] + "
+                      f"[{sample},{audio_dim},300] (torch-CPU fp32, {el:.1f}s)"}, ref, xv, xa
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="A+V pairs per rank per step (configs[1]: 64)")
+    ap.add_argument("--audio-dim", type=int, default=80, help="mel bins F of the [B,1,F,300] audio input")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a ROCm GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from deeplip_amd import ops, weightgen as wg
+    video, audio, sds = build_models(device, args.audio_dim)
+    B = args.batch
+    # per-rank shard of the synthetic utterance list (weak scaling: B pairs per rank)
+    spk = (np.arange(B) + rank * B) % 33
+    xv = torch.from_numpy(wg.video_input(B, speakers=spk, key=f"bench.video.r{rank}")).to(device)
+    xa = torch.from_numpy(wg.audio_input(B, args.audio_dim, 300, speakers=spk, key=f"bench.audio.r{rank}")).unsqueeze(1).to(device)
+
+    hook = EventHook()
+    ops.LAUNCH_HOOK = None if args.no_kernel_events else hook
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step(video, audio, xv, xa, world)
+    sync_all()
+    hook.enabled = True
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        out = step(video, audio, xv, xa, world)
+    ev1.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    hook.enabled = False
+    gpu_ms = ev0.elapsed_time(ev1)
+
+    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        clips = world * B * args.steps
+        value = clips / elapsed
+        res = {
+            "metric": "lip-clips/sec (fused A+V embed)", "value": round(value, 2), "unit": "lip-clips/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"fused A+V embed: video [{B},1,29,88,88] 3D-stem+ResNet-18 + audio [{B},1,{args.audio_dim},300] "
+                                   f"E-TDNN -> z-norm concat [{B},1024] per rank per step (BASELINE configs[1] clip batch)",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random-init (name-keyed, seed 1)",
+                       "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4)},
+        }
+        step_tf = value / world * GFLOP_PER_FUSED_CLIP / 1e3
+        roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                "traffic": None, "step_achieved": round(step_tf, 2),
+                "step_frac": round(step_tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        if not args.no_kernel_events:
+            agg = hook.summary()
+            dom = max(agg.items(), key=lambda kv: kv[1]["flops"])
+            name, a = dom
+            tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            roof.update({"achieved": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "kernel": name,
+                         "launches_per_step": a["launches"] // args.steps,
+                         "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
+                         "gflop_per_launch": round(a["flops"] / a["launches"] / 1e9, 3),
+                         "kernels": {k: {"launches_per_step": v["launches"] // args.steps,
+                                         "ms_per_step": round(v["ms"] / args.steps, 4),
+                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                     for k, v in sorted(agg.items())}})
+        res["roofline"] = roof
+        if not args.no_cpu_baseline:
+            ops.LAUNCH_HOOK = None
+            cb, ref, cxv, cxa = cpu_baseline(sds, args.audio_dim)
+            from deeplip_amd import fusion
+            got = fusion.fuse_av(audio.extract_embedding(cxa.unsqueeze(1).to(device))[0], video.embed(cxv.to(device)))
+            torch.cuda.synchronize()
+            err = float((got.cpu() - ref).abs().max() / ref.abs().max())
+            gn = torch.nn.functional.normalize(got.cpu().double()); rn = torch.nn.functional.normalize(ref.double())
+            sc_err = float(((gn @ gn.t()) - (rn @ rn.t())).abs().max())
+            res["cpu_baseline"] = cb
+            res["parity"] = {"fused_emb_rel_err_vs_cpu": float(f"{err:.3e}"), "cos_score_abs_err_vs_cpu": float(f"{sc_err:.3e}"),
+                             "tolerance": 1e-4}
+        print(json.dumps(res), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

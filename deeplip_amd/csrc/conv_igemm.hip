@@ -214,6 +214,16 @@ int launch(const ConvArgs& a, hipStream_t st) {
   return dlip_launch_status();
 }
 
+// Tile choice: 128x128 when there are enough output channels and rows to fill the chip with it,
+// 128x64 for the 64-channel stage, 64x64 for short-M GEMMs (linear layers, tiny batches).
+int pick_tile(long long M, int K) {
+  const long long t128 = ((M + 127) / 128) * ((K + 127) / 128);
+  if (K > 64 && t128 >= 512) return 0;
+  const long long t12864 = ((M + 127) / 128) * ((K + 63) / 64);
+  if (t12864 >= 512) return 1;
+  return 2;
+}
+
 }  // namespace
 
 extern "C" int dlip_conv_nhwc_f32(const dlip_conv_desc* d, const float* x, const float* w_krsc,
@@ -252,11 +262,18 @@ extern "C" int dlip_conv_nhwc_f32(const dlip_conv_desc* d, const float* x, const
   a.x_bytes = (uint32_t)x_bytes; a.w_bytes = (uint32_t)w_bytes;
 
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // Tile choice: 128x128 when there are enough output channels and rows to fill the chip with
-  // it, 128x64 for the 64-channel stage, 64x64 for short-M GEMMs (linear layers, tiny batches).
-  const long long t128 = ((M + 127) / 128) * ((d->K + 127) / 128);
-  if (d->K > 64 && t128 >= 512) return launch<128, 128, 2, 2>(a, st);
-  const long long t12864 = ((M + 127) / 128) * ((d->K + 63) / 64);
-  if (t12864 >= 512) return launch<128, 64, 2, 2>(a, st);
-  return launch<64, 64, 2, 2>(a, st);
+  switch (pick_tile(M, d->K)) {
+    case 0: return launch<128, 128, 2, 2>(a, st);
+    case 1: return launch<128, 64, 2, 2>(a, st);
+    default: return launch<64, 64, 2, 2>(a, st);
+  }
+}
+
+extern "C" int dlip_conv_plan(const dlip_conv_desc* d, int32_t* bm, int32_t* bn) {
+  DLIP_CHECK_ARG(d && bm && bn && d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0);
+  static const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  const int t = pick_tile((long long)d->N * d->Ho * d->Wo, d->K);
+  *bm = tiles[t][0];
+  *bn = tiles[t][1];
+  return DLIP_OK;
 }

@@ -16,6 +16,10 @@ from ._lib import ConvDesc, check, lib, ptr, stream_handle
 
 Tensor = torch.Tensor
 
+# Optional measurement hook (bench.py): an object with begin(kernel_name, flops) -> token and
+# end(token), called around every MFMA kernel launch on the current stream.  None = no overhead.
+LAUNCH_HOOK = None
+
 
 def _req(t: Optional[Tensor], name: str, dtype=torch.float32) -> None:
     if t is None:
@@ -65,8 +69,15 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
                  Cx, out.shape[3], residual.shape[3] if residual is not None else 0)
     xp = x.data_ptr() + 4 * in_channel_offset
     yp = out.data_ptr() + 4 * out_channel_offset
+    hook = LAUNCH_HOOK
+    if hook is not None:
+        bm, bn = C.c_int32(), C.c_int32()
+        check(lib().dlip_conv_plan(C.byref(d), C.byref(bm), C.byref(bn)), "dlip_conv_plan")
+        tok = hook.begin(f"conv_igemm_f32_kernel<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
     check(lib().dlip_conv_nhwc_f32(C.byref(d), xp, ptr(w_krsc), ptr(bias), ptr(residual), ptr(slope),
                                    ptr(post_scale), ptr(post_shift), yp, stream_handle()), "dlip_conv_nhwc_f32")
+    if hook is not None:
+        hook.end(tok)
     return out
 
 
@@ -103,8 +114,13 @@ def stem3d(x_bthw: Tensor, w_248xk: Tensor, bias: Tensor, slope: Optional[Tensor
     if w_248xk.shape[0] != 248:
         raise ValueError("stem3d: weights must be packed [248, K]")
     y = torch.empty((B * T, H // 2, W // 2, K), device=x_bthw.device, dtype=torch.float32)
+    hook = LAUNCH_HOOK
+    if hook is not None:
+        tok = hook.begin("stem3d_f32_kernel", 2.0 * B * T * (H // 2) * (W // 2) * K * 245)
     check(lib().dlip_stem3d_bn_act_f32(ptr(x_bthw), ptr(w_248xk), ptr(bias), ptr(slope), ptr(y), B, T, H, W, K,
                                        stream_handle()), "dlip_stem3d_bn_act_f32")
+    if hook is not None:
+        hook.end(tok)
     return y
 
 
