@@ -7,16 +7,18 @@
 // slices of one filter tap at a time:
 //   global (buffer_load_dwordx4, halo / tails -> 0 via the buffer range check)
 //     -> registers (prefetch of slice t+1 is in flight while slice t is multiplied)
-//     -> LDS [row][36]  (32 floats + 4 pad: conflict-free ds_read_b128 / ds_write_b128)
+//     -> LDS [2 stages][row][36]  (32 floats + 4 pad: conflict-free ds_read_b128 / ds_write_b128)
 //     -> one ds_read_b128 per operand row feeds FOUR mfma 32x32x2 steps: lanes 0-31 hold
 //        k = 8q..8q+3, lanes 32-63 hold k = 8q+4..8q+7 of the same row, so step j multiplies
 //        k = 8q+j (lower half-wave) and k = 8q+4+j (upper half) -- a permutation of the
 //        reduction index that A and W share, hence exact.
-// Epilogue (fused, per output element): + bias[k] (folded BN), + residual, PReLU/LeakyReLU/ReLU
-// by per-channel slope, optional post affine; stores are 2 x 128-B segments per wave instruction.
+// Fusion: the accumulators are initialised with bias[k] (folded BN) + residual[m,k]; the epilogue
+// applies the per-channel PReLU/LeakyReLU/ReLU slope and the optional post affine and stores
+// 2 x 128-B segments per wave instruction, branch-free (tails dropped by the buffer range check).
 //
 // Replaces the torch.nn layers listed against dlip_conv_nhwc_f32 in include/deeplip_hip.h.
 #include "dlip_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -38,27 +40,32 @@ struct ConvArgs {
   int cchunks;  // ceil(C / 32)
   int nk;       // R * S * cchunks
   int rsc;      // R * S * C  (weight row length)
-  uint32_t x_bytes, w_bytes;
+  uint32_t x_bytes, w_bytes, r_bytes, y_bytes;
 };
 
 constexpr int BK = 32;
-constexpr int LDK = BK + 4;
+constexpr int LDK = BK;  // unpadded 128-B rows; bank conflicts are removed by an XOR swizzle of the 16-B chunks
 
+// ------------------------------------------------------------------------------------------
+// Software pipeline: two LDS stages, ONE barrier per 32-channel slice, and every
+// non-MFMA instruction of the slice (fragment ds_reads of the next k8 step, the global loads of
+// the next slice, their ds_writes, the barrier) placed in program order BETWEEN small groups of
+// MFMAs, so that an in-order wave issues them in the 64-cycle shadow of an executing MFMA instead
+// of in front of the matrix pipe.  Slice t, k8 step q (MI*NI MFMAs per j):
+//   q=0: [j0] read frags(q=1) [j1] load A rows of slice t+1 [j2] load A rows [j3] load W rows
+//   q=1: [j0] read frags(q=2) [j1..j3]
+//   q=2: [j0] read frags(q=3) [j1] ds_write A(t+1) -> other stage [j2] ds_write W(t+1) [j3]
+//   q=3: [j0] barrier; read frags(q=0 of slice t+1) [j1..j3]
+// ------------------------------------------------------------------------------------------
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int A_PER = BM / 32, B_PER = BN / 32;
-  static_assert(MI >= 1 && NI >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+  constexpr int STAGE = (BM + BN) * LDK;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
-  float* As = smem;
-  float* Bs = smem + BM * LDK;
-
-  // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so give each
-  // XCD a contiguous run of tiles (bijective for any grid size); tile_n is innermost so the
-  // tiles that re-read the same activation rows and the same filter slices meet in one L2.
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -66,122 +73,181 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
   const int tile_m = swz / a.tiles_n;
 
   const int tid = threadIdx.x;
-  const int cc = (tid & 7) * 4;   // channel offset of this thread's float4 inside a BK slice
-  const int rbase = tid >> 3;     // 0..31
-
+  const int cc = (tid & 7) * 4;
+  const int rbase = tid >> 3;
   const __amdgpu_buffer_rsrc_t xr = dlip_make_rsrc(a.x, a.x_bytes);
   const __amdgpu_buffer_rsrc_t wr = dlip_make_rsrc(a.w, a.w_bytes);
 
-  // Per-thread im2col row descriptors.
-  int a_pix[A_PER], a_hi0[A_PER], a_wi0[A_PER];
+  int a_off[A_PER];
+  uint32_t a_mask[A_PER];
 #pragma unroll
   for (int j = 0; j < A_PER; ++j) {
     const int m = tile_m * BM + rbase + 32 * j;
+    a_off[j] = 0;
+    a_mask[j] = 0u;
     if (m < a.M) {
       const int n = m / a.HoWo;
       const int rem = m - n * a.HoWo;
       const int ho = rem / a.Wo;
       const int wo = rem - ho * a.Wo;
-      a_pix[j] = n * a.H * a.W;
-      a_hi0[j] = ho * a.sh - a.ph;
-      a_wi0[j] = wo * a.sw - a.pw;
-    } else {
-      a_pix[j] = 0;
-      a_hi0[j] = -0x40000000;  // fails every bounds check -> zeros
-      a_wi0[j] = 0;
+      const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+      a_off[j] = (((n * a.H + hi0) * a.W + wi0) * a.ldx + cc) * 4;
+      uint32_t mk = 0u;
+      for (int r = 0; r < a.R; ++r)
+        for (int s = 0; s < a.S; ++s)
+          if ((unsigned)(hi0 + r * a.dh) < (unsigned)a.H && (unsigned)(wi0 + s * a.dw) < (unsigned)a.W)
+            mk |= 1u << (r * a.S + s);
+      a_mask[j] = mk;
     }
   }
-  int b_row[B_PER];
+  int b_off[B_PER];
 #pragma unroll
   for (int j = 0; j < B_PER; ++j) {
     const int n = tile_n * BN + rbase + 32 * j;
-    b_row[j] = n < a.K ? n * a.rsc : -1;
+    b_off[j] = n < a.K ? (n * a.rsc + cc) * 4 : -1;
   }
 
   f32x4 ra[A_PER], rb[B_PER];
-  auto load_slice = [&](int r, int s, int c0) {
+  int tap = 0, x_tap = 0, w_tap = 0, c0 = 0;   // wave-uniform position of the slice being LOADED
+  auto load_a = [&](int j0, int j1) {
     const bool cok = (c0 + cc) < a.C;
-    const int dh = r * a.dh, dw = s * a.dw;
 #pragma unroll
-    for (int j = 0; j < A_PER; ++j) {
-      const int hi = a_hi0[j] + dh, wi = a_wi0[j] + dw;
-      const bool ok = cok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      const uint32_t off = ok ? (uint32_t)(((a_pix[j] + hi * a.W + wi) * a.ldx + c0 + cc) * 4) : DLIP_OOB_OFFSET;
-      ra[j] = dlip_buffer_load_f4(xr, off);
-    }
-    const int kw = (r * a.S + s) * a.C + c0 + cc;
-#pragma unroll
-    for (int j = 0; j < B_PER; ++j) {
-      const bool ok = cok && b_row[j] >= 0;
-      const uint32_t off = ok ? (uint32_t)((b_row[j] + kw) * 4) : DLIP_OOB_OFFSET;
-      rb[j] = dlip_buffer_load_f4(wr, off);
+    for (int j = j0; j < j1; ++j) {
+      const bool ok = cok && ((a_mask[j] >> tap) & 1u);
+      ra[j] = dlip_buffer_load_f4(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET);
     }
   };
-  auto store_slice = [&]() {
+  auto load_b = [&]() {
+    const bool cok = (c0 + cc) < a.C;
 #pragma unroll
-    for (int j = 0; j < A_PER; ++j) *reinterpret_cast<f32x4*>(&As[(rbase + 32 * j) * LDK + cc]) = ra[j];
+    for (int j = 0; j < B_PER; ++j) {
+      const bool ok = cok && b_off[j] >= 0;
+      rb[j] = dlip_buffer_load_f4(wr, ok ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET);
+    }
+  };
+  // LDS image: row-major [row][32 floats], the eight 16-B chunks of a row permuted by
+  // chunk ^ ((row >> 1) & 7).  Rows r and r+1 sit in opposite halves of the 64 banks, and the key
+  // walks all 8 chunk positions over 16 consecutive rows, so both the ds_write_b128 (8 lanes = one
+  // row) and the ds_read_b128 (16 lanes = 16 rows, one logical chunk) are conflict-free.
+  const int st_off = rbase * LDK + ((((tid & 7) ^ ((rbase >> 1) & 7))) << 2);
+  auto store_a = [&](int stage) {
+    float* As = smem + stage * STAGE + st_off;
 #pragma unroll
-    for (int j = 0; j < B_PER; ++j) *reinterpret_cast<f32x4*>(&Bs[(rbase + 32 * j) * LDK + cc]) = rb[j];
+    for (int j = 0; j < A_PER; ++j) *reinterpret_cast<f32x4*>(&As[32 * j * LDK]) = ra[j];
+  };
+  auto store_b = [&](int stage) {
+    float* Bs = smem + stage * STAGE + BM * LDK + st_off;
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) *reinterpret_cast<f32x4*>(&Bs[32 * j * LDK]) = rb[j];
   };
 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int lrow = lane & 31, khalf = (lane >> 5) * 4;
-  const float* Aw = As + (wm * WM + lrow) * LDK + khalf;
-  const float* Bw = Bs + (wn * WN + lrow) * LDK + khalf;
-
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-  int r = 0, s = 0, c0 = 0;
-  load_slice(r, s, c0);
-  store_slice();
-  __syncthreads();
-
-  for (int kt = 0; kt < a.nk; ++kt) {
-    const bool more = (kt + 1) < a.nk;
-    if (more) {
-      c0 += BK;
-      if (c0 >= a.C) {
-        c0 = 0;
-        if (++s == a.S) { s = 0; ++r; }
-      }
-      load_slice(r, s, c0);  // in flight during the MFMAs below
-    }
-#pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      f32x4 af[MI], bf[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(Aw + mi * 32 * LDK + q * 8);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(Bw + ni * 32 * LDK + q * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
-    }
-    __syncthreads();
-    if (more) {
-      store_slice();
-      __syncthreads();
-    }
-  }
-
-  // Epilogue.  C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
+  const int lrow = lane & 31;
+  const int a_frag = (wm * WM + lrow) * LDK;
+  const int b_frag = BM * LDK + (wn * WN + lrow) * LDK;
   const int rquad = (lane >> 5) * 4;
+  int kq[BK / 8];  // swizzled float offset of this lane's 16-B chunk for k8 step q
+#pragma unroll
+  for (int q = 0; q < BK / 8; ++q) kq[q] = (((2 * q + (lane >> 5)) ^ ((lrow >> 1) & 7))) << 2;
+
+  // accumulators = bias (+ residual)
+  const __amdgpu_buffer_rsrc_t rr = dlip_make_rsrc(a.res, a.res ? a.r_bytes : 0u);
+  f32x16 acc[MI][NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int k = tile_n * BN + wn * WN + ni * 32 + lrow;
     const bool kok = k < a.K;
     const float bias = (kok && a.bias) ? a.bias[k] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m0 = tile_m * BM + wm * WM + mi * 32 + rquad;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (e & 3) + 8 * (e >> 2);
+        const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldr + k) * 4) : DLIP_OOB_OFFSET;
+        // rr has zero records when there is no residual: the load returns 0 without a branch
+        acc[mi][ni][e] = bias + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)off, 0, 0));
+      }
+    }
+  }
+
+  // slice-walk bookkeeping (scalar)
+  int s_pos = 0, x_row = 0;
+  const int x_dr = a.dh * a.W * a.ldx * 4, x_ds = a.dw * a.ldx * 4;
+  auto advance = [&]() {
+    c0 += BK;
+    if (c0 >= a.C) {
+      c0 = 0;
+      ++tap;
+      if (++s_pos == a.S) { s_pos = 0; x_row += x_dr; }
+    }
+    x_tap = x_row + s_pos * x_ds + c0 * 4;
+    w_tap = (tap * a.C + c0) * 4;
+  };
+
+  f32x4 fa[2][MI], fb[2][NI];
+  auto read_frags = [&](int set, int stage, int q) {
+    const float* Aw = smem + stage * STAGE + a_frag + kq[q];
+    const float* Bw = smem + stage * STAGE + b_frag + kq[q];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) fa[set][mi] = *reinterpret_cast<const f32x4*>(Aw + mi * 32 * LDK);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) fb[set][ni] = *reinterpret_cast<const f32x4*>(Bw + ni * 32 * LDK);
+  };
+  auto mfma_j = [&](int set, int j) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][mi][j], fb[set][ni][j], acc[mi][ni], 0, 0, 0);
+  };
+#define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+  load_a(0, A_PER);
+  load_b();
+  store_a(0);
+  store_b(0);
+  __syncthreads();
+  read_frags(0, 0, 0);
+
+  for (int kt = 0; kt < a.nk; ++kt) {
+    const bool more = (kt + 1) < a.nk;
+    const int cur = kt & 1;
+    // ---- q = 0 ----
+    mfma_j(0, 0); DLIP_FENCE();
+    read_frags(1, cur, 1); DLIP_FENCE();
+    mfma_j(0, 1); DLIP_FENCE();
+    if (more) { advance(); load_a(0, A_PER / 2); } DLIP_FENCE();
+    mfma_j(0, 2); DLIP_FENCE();
+    if (more) load_a(A_PER / 2, A_PER); DLIP_FENCE();
+    mfma_j(0, 3); DLIP_FENCE();
+    if (more) load_b(); DLIP_FENCE();
+    // ---- q = 1 ----
+    mfma_j(1, 0); DLIP_FENCE();
+    read_frags(0, cur, 2); DLIP_FENCE();
+    mfma_j(1, 1); mfma_j(1, 2); mfma_j(1, 3); DLIP_FENCE();
+    // ---- q = 2 ----
+    mfma_j(0, 0); DLIP_FENCE();
+    read_frags(1, cur, 3); DLIP_FENCE();
+    mfma_j(0, 1); DLIP_FENCE();
+    if (more) store_a(cur ^ 1); DLIP_FENCE();
+    mfma_j(0, 2); DLIP_FENCE();
+    if (more) store_b(cur ^ 1); DLIP_FENCE();
+    mfma_j(0, 3); DLIP_FENCE();
+    // ---- q = 3 ----
+    mfma_j(1, 0); DLIP_FENCE();
+    __syncthreads();
+    if (more) read_frags(0, cur ^ 1, 0); DLIP_FENCE();
+    mfma_j(1, 1); mfma_j(1, 2); mfma_j(1, 3); DLIP_FENCE();
+  }
+#undef DLIP_FENCE
+
+  const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int k = tile_n * BN + wn * WN + ni * 32 + lrow;
+    const bool kok = k < a.K;
     const float slope = (kok && a.slope) ? a.slope[k] : 1.f;
     const float psc = (kok && a.pscale) ? a.pscale[k] : 1.f;
     const float psh = (kok && a.pshift) ? a.pshift[k] : 0.f;
@@ -191,13 +257,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + (e & 3) + 8 * (e >> 2);
-        if (kok && m < a.M) {
-          float v = acc[mi][ni][e] + bias;
-          if (a.res) v += a.res[(size_t)m * a.ldr + k];
-          if (a.slope) v = v >= 0.f ? v : v * slope;
-          if (a.pscale) v = v * psc + psh;
-          a.y[(size_t)m * a.ldy + k] = v;
-        }
+        float v = acc[mi][ni][e];
+        v = v >= 0.f ? v : v * slope;
+        v = v * psc + psh;
+        const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + k) * 4) : DLIP_OOB_OFFSET;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)off, 0, 0);
       }
     }
   }
@@ -210,18 +274,52 @@ int launch(const ConvArgs& a, hipStream_t st) {
   b.tiles_n = (a.K + BN - 1) / BN;
   const long long grid = (long long)tiles_m * b.tiles_n;
   if (grid <= 0 || grid > 0x7FFFFFFFll) return DLIP_EINVAL;
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N>), dim3((unsigned)grid), dim3(256), 0, st, b);
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * LDK * sizeof(float);
+  auto kern = conv_igemm_f32_kernel<BM, BN, WAVES_M, WAVES_N>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b);
   return dlip_launch_status();
 }
 
-// Tile choice: 128x128 when there are enough output channels and rows to fill the chip with it,
-// 128x64 for the 64-channel stage, 64x64 for short-M GEMMs (linear layers, tiny batches).
+// Tile menu.  {BM, BN, WAVES_M, WAVES_N}: the 2x2 wave layouts give each wave a (BM/2)x(BN/2)
+// block; the 1x4 layouts give each wave all BM rows of a 32-channel column, which makes BM any
+// multiple of 32 -- used to fight tile quantisation: a launch takes ceil(tiles / 256 CUs) "rounds"
+// of one tile per CU, so for the short-M layers (layer3/4, TDNN) BM is chosen so the tile count
+// lands just under a multiple of 256.
+struct TileCfg { int bm, bn; float eff; };
+constexpr int NUM_CFG = 5;
+// eff = measured relative MFMA efficiency of a busy CU running this tile (tools/bench_layers.py,
+// MI355X, B=64): the 48-KiB-LDS tiles fit 3 workgroups per CU and win; 128x128 fits 2.
+const TileCfg kCfg[NUM_CFG] = {{128, 128, 0.90f}, {128, 64, 0.97f}, {64, 64, 0.93f}, {64, 128, 1.00f}, {96, 128, 0.97f}};
+
 int pick_tile(long long M, int K) {
-  const long long t128 = ((M + 127) / 128) * ((K + 127) / 128);
-  if (K > 64 && t128 >= 512) return 0;
-  const long long t12864 = ((M + 127) / 128) * ((K + 63) / 64);
-  if (t12864 >= 512) return 1;
-  return 2;
+  if (const char* e = getenv("DLIP_CONV_TILE")) {  // development override (A/B runs)
+    const int v = atoi(e);
+    if (v >= 0 && v < NUM_CFG) return v;
+  }
+  int best = 0;
+  double best_cost = 1e300;
+  for (int i = 0; i < NUM_CFG; ++i) {
+    const TileCfg& c = kCfg[i];
+    const long long tiles = ((M + c.bm - 1) / c.bm) * ((K + c.bn - 1) / c.bn);
+    const long long rounds = (tiles + 255) / 256;  // one tile per CU per round
+    const double cost = (double)rounds * c.bm * c.bn / c.eff;
+    if (cost < best_cost * 0.999) { best_cost = cost; best = i; }
+  }
+  return best;
+}
+
+int launch_cfg(int cfg, const ConvArgs& a, hipStream_t st) {
+  switch (cfg) {
+    case 0: return launch<128, 128, 2, 2>(a, st);
+    case 1: return launch<128, 64, 2, 2>(a, st);
+    case 2: return launch<64, 64, 2, 2>(a, st);
+    case 3: return launch<64, 128, 1, 4>(a, st);
+    default: return launch<96, 128, 1, 4>(a, st);
+  }
 }
 
 }  // namespace
@@ -240,12 +338,17 @@ extern "C" int dlip_conv_nhwc_f32(const dlip_conv_desc* d, const float* x, const
   const int Ho = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
   const int Wo = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
   DLIP_CHECK_ARG(Ho == d->Ho && Wo == d->Wo && Ho > 0 && Wo > 0);
+  DLIP_CHECK_ARG(d->R * d->S <= 32);  // per-row tap-validity mask is 32 bits
 
   const long long in_pix = (long long)d->N * d->H * d->W;
   const long long x_bytes = ((in_pix - 1) * d->ldx + d->C) * 4;
   const long long w_bytes = (long long)d->K * d->R * d->S * d->C * 4;
   const long long M = (long long)d->N * Ho * Wo;
-  if (x_bytes > DLIP_MAX_BUFFER_BYTES || w_bytes > DLIP_MAX_BUFFER_BYTES || M > 0x7FFFFFFFll) return DLIP_ERANGE;
+  const long long y_bytes = ((M - 1) * d->ldy + d->K) * 4;
+  const long long r_bytes = residual ? ((M - 1) * d->ldr + d->K) * 4 : 0;
+  if (x_bytes > DLIP_MAX_BUFFER_BYTES || w_bytes > DLIP_MAX_BUFFER_BYTES || y_bytes > DLIP_MAX_BUFFER_BYTES ||
+      r_bytes > DLIP_MAX_BUFFER_BYTES || M > 0x7FFFFFFFll)
+    return DLIP_ERANGE;
 
   ConvArgs a;
   a.x = x; a.w = w_krsc; a.bias = bias; a.res = residual; a.slope = slope;
@@ -260,20 +363,16 @@ extern "C" int dlip_conv_nhwc_f32(const dlip_conv_desc* d, const float* x, const
   a.nk = d->R * d->S * a.cchunks;
   a.rsc = d->R * d->S * d->C;
   a.x_bytes = (uint32_t)x_bytes; a.w_bytes = (uint32_t)w_bytes;
+  a.r_bytes = (uint32_t)r_bytes; a.y_bytes = (uint32_t)y_bytes;
 
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (pick_tile(M, d->K)) {
-    case 0: return launch<128, 128, 2, 2>(a, st);
-    case 1: return launch<128, 64, 2, 2>(a, st);
-    default: return launch<64, 64, 2, 2>(a, st);
-  }
+  return launch_cfg(pick_tile(M, d->K), a, st);
 }
 
 extern "C" int dlip_conv_plan(const dlip_conv_desc* d, int32_t* bm, int32_t* bn) {
   DLIP_CHECK_ARG(d && bm && bn && d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0);
-  static const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   const int t = pick_tile((long long)d->N * d->Ho * d->Wo, d->K);
-  *bm = tiles[t][0];
-  *bn = tiles[t][1];
+  *bm = kCfg[t].bm;
+  *bn = kCfg[t].bn;
   return DLIP_OK;
 }
