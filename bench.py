@@ -103,15 +103,41 @@ def step(video, audio, xv, xa, world):
     return fused
 
 
+def _host_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(sds, audio_dim, budget_s=12.0, sample=8):
-    """The CPU oracle (port of the reference path) timed on this box's host cores."""
+    """The CPU oracle (port of the reference path) timed on this box's host cores.  torch's intra-op
+    pool collapses when oversubscribed, so the thread count is calibrated first (a few short passes
+    at 8..cores threads) and the best one is used and reported."""
     from deeplip_amd import weightgen as wg
     from oracle import deeplip_oracle as O
     vsd, asd = O.to_torch_sd(sds[0]), O.to_torch_sd(sds[1])
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = _host_cores()
     xv = torch.from_numpy(wg.video_input(sample, key="bench.video"))
     xa = torch.from_numpy(wg.audio_input(sample, audio_dim, 300, key="bench.audio"))
+    cands = sorted({c for c in (8, 16, 32, 64, 128, cores) if c <= cores}) or [cores]
+    best_t, best_n = 1e30, cands[0]
+    for n in cands:
+        torch.set_num_threads(n)
+        O.fused_av_embedding(vsd, asd, xv[:2], xa[:2])
+        t0 = time.perf_counter()
+        O.fused_av_embedding(vsd, asd, xv[:2], xa[:2])
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best_t, best_n = dt, n
+        if dt > 4 * best_t:
+            break
+    torch.set_num_threads(best_n)
     ref = O.fused_av_embedding(vsd, asd, xv, xa)   # warm-up + parity reference
     iters, t0 = 0, time.perf_counter()
     while True:
@@ -120,10 +146,10 @@ def cpu_baseline(sds, audio_dim, budget_s=12.0, sample=8):
         el = time.perf_counter() - t0
         if el >= budget_s or iters >= 50:
             break
-    return {"value": round(sample * iters / el, 3), "unit": "lip-clips/sec", "cores": torch.get_num_threads(),
+    return {"value": round(sample * iters / el, 3), "unit": "lip-clips/sec", "cores": best_n,
             "kind": "port",
             "sample": f"{iters} passes of the oracle fused A+V embed on {sample} clips [{sample},1,29,88,88] + "
-                      f"[{sample},{audio_dim},300] (torch-CPU fp32, {el:.1f}s)"}, ref, xv, xa
+                      f"[{sample},{audio_dim},300] (torch-CPU fp32, {best_n} of {cores} usable cores, {el:.1f}s)"}, ref, xv, xa
 
 
 def main():

@@ -1,0 +1,62 @@
+"""world_size-2 gloo tests of the N>1 path: utterance sharding, ragged gather of embedding rows,
+trial-range sharded scoring (the scorer is a stand-in here: the HIP scorer needs a GPU and is
+covered by -m gpu tests; what is tested is the exchange logic)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from deeplip_amd import dist as ddist
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_utt, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        table = torch.arange(n_utt * 4, dtype=torch.float32).view(n_utt, 4)
+        lo, hi = ddist.shard_range(n_utt)
+        full = ddist.gather_rows(table[lo:hi].clone(), n_utt)
+        ia = torch.arange(0, 11, dtype=torch.int32) % n_utt
+        ib = (torch.arange(0, 11, dtype=torch.int32) * 3) % n_utt
+        scores = ddist.score_trials_sharded(lambda a, b: (full[a.long()] * full[b.long()]).sum(1), ia, ib)
+        m = ddist.allreduce_metrics([1.0, float(rank)], "cpu")
+        q.put((rank, (lo, hi), full.numpy(), scores.numpy(), m))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_utt", [7, 8])
+def test_shard_gather_score_world2(n_utt):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_utt, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(60) for p in procs]
+    table = np.arange(n_utt * 4, dtype=np.float32).reshape(n_utt, 4)
+    ia = np.arange(11) % n_utt; ib = (np.arange(11) * 3) % n_utt
+    ref = (table[ia] * table[ib]).sum(1)
+    ranges = sorted(r[1] for r in res)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n_utt and ranges[0][1] == ranges[1][0]
+    for rank, _, full, scores, m in res:
+        assert np.array_equal(full, table)
+        assert np.array_equal(scores, ref)
+        assert m == [2.0, 1.0]
+
+
+def test_shard_range_partition():
+    for n in (0, 1, 7, 64, 25834):
+        for w in (1, 2, 3, 8):
+            r = [ddist.shard_range(n, i, w) for i in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
