@@ -243,6 +243,14 @@ def main():
                                          "ms_per_step": round(v["ms"] / args.steps, 4),
                                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                      for k, v in sorted(agg.items())}})
+        try:  # HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            key = roof.get("kernel", "")
+            if key in tr and "hbm_read_bytes_per_launch" in tr[key]:
+                roof["traffic"] = round(tr[key]["hbm_read_bytes_per_launch"] + tr[key]["hbm_write_bytes_per_launch"])
+                roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per launch, FETCH x2 gfx950 correction)"
+        except Exception:
+            pass
         res["roofline"] = roof
         if not args.no_cpu_baseline:
             ops.LAUNCH_HOOK = None

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): bench + rocprofv3 kernel stats + PMC passes -> gpurun_out/prof_<tag>/
+# usage: tools/collect_profiles.sh <tag>
+set -u
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+tail -c 2500 $O/bench.json
+STEPS=5
+ARGS="$R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ARGS > $O/stats.log 2>&1
+for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  N=$(echo $P | cut -d" " -f1)
+  rocprofv3 --pmc $P --output-format csv -d $O/pmc_$N -- python3 $ARGS --no-kernel-events > $O/pmc_$N.log 2>&1
+done
+python3 $R/tools/pmc_summary.py $O/pmc_summary.json $((STEPS + 2)) $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_TCC_HIT_sum > /dev/null
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+rm -rf $O/stats/*/*kernel_trace.csv   # large; the stats csv is what gets committed
+ls $O
