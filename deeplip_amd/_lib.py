@@ -12,7 +12,7 @@ import threading
 import torch  # must be imported first: the library binds to the HIP runtime torch already loaded
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libdeeplip_hip.so")
+LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
 ABI_VERSION = 1
 
 _lock = threading.Lock()

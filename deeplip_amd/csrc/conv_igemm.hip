@@ -19,6 +19,7 @@
 // Replaces the torch.nn layers listed against dlip_conv_nhwc_f32 in include/deeplip_hip.h.
 #include "dlip_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -52,9 +53,11 @@ constexpr int LDK = BK;  // unpadded 128-B rows; bank conflicts are removed by a
 // the next slice, their ds_writes, the barrier) placed in program order BETWEEN small groups of
 // MFMAs, so that an in-order wave issues them in the 64-cycle shadow of an executing MFMA instead
 // of in front of the matrix pipe.  Slice t, k8 step q (MI*NI MFMAs per j):
-//   q=0: [j0] read frags(q=1) [j1] load A rows of slice t+1 [j2] load A rows [j3] load W rows
+//   q=0: [j0] read frags(q=1) [j1] load A rows of slice t+2 [j2] load A rows [j3] load W rows
 //   q=1: [j0] read frags(q=2) [j1..j3]
 //   q=2: [j0] read frags(q=3) [j1] ds_write A(t+1) -> other stage [j2] ds_write W(t+1) [j3]
+// (global loads run TWO slices ahead through two staging register sets: >= 1.5 slices of MFMA
+//  time to land, instead of 0.5)
 //   q=3: [j0] barrier; read frags(q=0 of slice t+1) [j1..j3]
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -107,22 +110,24 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
     b_off[j] = n < a.K ? (n * a.rsc + cc) * 4 : -1;
   }
 
-  f32x4 ra[A_PER], rb[B_PER];
+  f32x4 ra[2][A_PER], rb[2][B_PER];  // two staging sets: slice t+2 is in flight while slice t+1 waits for its ds_write
   int tap = 0, x_tap = 0, w_tap = 0, c0 = 0;   // wave-uniform position of the slice being LOADED
-  auto load_a = [&](int j0, int j1) {
+  auto load_a = [&](auto SETC, int j0, int j1) {
+    constexpr int SET = decltype(SETC)::value;
     const bool cok = (c0 + cc) < a.C;
 #pragma unroll
     for (int j = j0; j < j1; ++j) {
       const bool ok = cok && ((a_mask[j] >> tap) & 1u);
-      ra[j] = dlip_buffer_load_f4(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET);
+      ra[SET][j] = dlip_buffer_load_f4(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET);
     }
   };
-  auto load_b = [&]() {
+  auto load_b = [&](auto SETC) {
+    constexpr int SET = decltype(SETC)::value;
     const bool cok = (c0 + cc) < a.C;
 #pragma unroll
     for (int j = 0; j < B_PER; ++j) {
       const bool ok = cok && b_off[j] >= 0;
-      rb[j] = dlip_buffer_load_f4(wr, ok ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET);
+      rb[SET][j] = dlip_buffer_load_f4(wr, ok ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET);
     }
   };
   // LDS image: row-major [row][32 floats], the eight 16-B chunks of a row permuted by
@@ -130,15 +135,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
   // walks all 8 chunk positions over 16 consecutive rows, so both the ds_write_b128 (8 lanes = one
   // row) and the ds_read_b128 (16 lanes = 16 rows, one logical chunk) are conflict-free.
   const int st_off = rbase * LDK + ((((tid & 7) ^ ((rbase >> 1) & 7))) << 2);
-  auto store_a = [&](int stage) {
+  auto store_a = [&](auto SETC, int stage) {
+    constexpr int SET = decltype(SETC)::value;
     float* As = smem + stage * STAGE + st_off;
 #pragma unroll
-    for (int j = 0; j < A_PER; ++j) *reinterpret_cast<f32x4*>(&As[32 * j * LDK]) = ra[j];
+    for (int j = 0; j < A_PER; ++j) *reinterpret_cast<f32x4*>(&As[32 * j * LDK]) = ra[SET][j];
   };
-  auto store_b = [&](int stage) {
+  auto store_b = [&](auto SETC, int stage) {
+    constexpr int SET = decltype(SETC)::value;
     float* Bs = smem + stage * STAGE + BM * LDK + st_off;
 #pragma unroll
-    for (int j = 0; j < B_PER; ++j) *reinterpret_cast<f32x4*>(&Bs[32 * j * LDK]) = rb[j];
+    for (int j = 0; j < B_PER; ++j) *reinterpret_cast<f32x4*>(&Bs[32 * j * LDK]) = rb[SET][j];
   };
 
   const int lane = tid & 63, wave = tid >> 6;
@@ -204,25 +211,35 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
   };
 #define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-  load_a(0, A_PER);
-  load_b();
-  store_a(0);
-  store_b(0);
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  // Prologue: slice 0 -> set 0 -> LDS stage 0; slice 1 -> set 1 (stays in flight).
+  load_a(Set0{}, 0, A_PER);
+  load_b(Set0{});
+  if (a.nk > 1) {
+    advance();
+    load_a(Set1{}, 0, A_PER);
+    load_b(Set1{});
+  }
+  store_a(Set0{}, 0);
+  store_b(Set0{}, 0);
   __syncthreads();
   read_frags(0, 0, 0);
 
-  for (int kt = 0; kt < a.nk; ++kt) {
-    const bool more = (kt + 1) < a.nk;
+  // One slice.  LD = staging set that receives slice kt+2 (free: it held slice kt, already in LDS);
+  // ST = the other set, holding slice kt+1, written to LDS stage (kt+1)&1 during q=2.
+  auto slice = [&](auto LD, auto ST, int kt) {
+    const bool more1 = (kt + 1) < a.nk, more2 = (kt + 2) < a.nk;
     const int cur = kt & 1;
     // ---- q = 0 ----
     mfma_j(0, 0); DLIP_FENCE();
     read_frags(1, cur, 1); DLIP_FENCE();
     mfma_j(0, 1); DLIP_FENCE();
-    if (more) { advance(); load_a(0, A_PER / 2); } DLIP_FENCE();
+    if (more2) { advance(); load_a(LD, 0, A_PER / 2); } DLIP_FENCE();
     mfma_j(0, 2); DLIP_FENCE();
-    if (more) load_a(A_PER / 2, A_PER); DLIP_FENCE();
+    if (more2) load_a(LD, A_PER / 2, A_PER); DLIP_FENCE();
     mfma_j(0, 3); DLIP_FENCE();
-    if (more) load_b(); DLIP_FENCE();
+    if (more2) load_b(LD); DLIP_FENCE();
     // ---- q = 1 ----
     mfma_j(1, 0); DLIP_FENCE();
     read_frags(0, cur, 2); DLIP_FENCE();
@@ -231,15 +248,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
     mfma_j(0, 0); DLIP_FENCE();
     read_frags(1, cur, 3); DLIP_FENCE();
     mfma_j(0, 1); DLIP_FENCE();
-    if (more) store_a(cur ^ 1); DLIP_FENCE();
+    if (more1) store_a(ST, cur ^ 1); DLIP_FENCE();
     mfma_j(0, 2); DLIP_FENCE();
-    if (more) store_b(cur ^ 1); DLIP_FENCE();
+    if (more1) store_b(ST, cur ^ 1); DLIP_FENCE();
     mfma_j(0, 3); DLIP_FENCE();
     // ---- q = 3 ----
     mfma_j(1, 0); DLIP_FENCE();
     __syncthreads();
-    if (more) read_frags(0, cur ^ 1, 0); DLIP_FENCE();
+    if (more1) read_frags(0, cur ^ 1, 0); DLIP_FENCE();
     mfma_j(1, 1); mfma_j(1, 2); mfma_j(1, 3); DLIP_FENCE();
+  };
+  for (int kt = 0; kt < a.nk; kt += 2) {
+    slice(Set0{}, Set1{}, kt);
+    if (kt + 1 < a.nk) slice(Set1{}, Set0{}, kt + 1);
   }
 #undef DLIP_FENCE
 
