@@ -8,8 +8,8 @@
 //     LDS (24 KB) with coalesced row reads;
 //   * each of the 4 waves owns 16 output channels and keeps its 248 x 16 filter slice in 62
 //     VGPRs for the whole tile (weights packed k-major [248][64]: 64-B coalesced reads);
-//   * A fragments are gathered straight from the LDS window with ds_read_b32 (tap offset from a
-//     248-entry LDS table + a per-lane pixel offset; stride-2 pixels x 4 tap quarters = conflict
+//   * A fragments are gathered straight from the LDS window with ds_read_b32 (tap offset walked in
+//     registers + a per-lane pixel offset; stride-2 pixels x 4 tap quarters = mostly conflict
 //     free), v_mfma_f32_16x16x4_f32 accumulates exact fp32, 11 independent accumulators per wave.
 #include "dlip_common.h"
 
@@ -36,7 +36,6 @@ __global__ __launch_bounds__(256) void stem3d_f32_kernel(const StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int plane = PR * a.pwp;
   float* patch = smem;                                         // [5][13][pwp]
-  int* koff = reinterpret_cast<int*>(smem + KT * plane);       // [248]
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
@@ -47,29 +46,31 @@ __global__ __launch_bounds__(256) void stem3d_f32_kernel(const StemArgs a) {
   const int ho0 = rt * ROWS;
 
   const int tid = threadIdx.x;
-  for (int k = tid; k < KPAD; k += 256) {
-    const int kt = k / (KH * KW), rem = k - kt * (KH * KW), kh = rem / KW, kw = rem - kh * KW;
-    koff[k] = k < KTAPS ? kt * plane + kh * a.pwp + kw : 0;
-  }
-  {
-    const int hi0 = 2 * ho0 - 3;
-    const float* xf = a.x + (size_t)(f - t) * a.H * a.W;  // clip base
-    const int total = KT * plane;
-    for (int idx = tid; idx < total; idx += 256) {
-      const int ft = idx / plane, rem = idx - ft * plane;
-      const int pr = rem / a.pwp, pc = rem - pr * a.pwp;
-      const int tt = t + ft - 2, hi = hi0 + pr, wi = pc - 3;
-      float v = 0.f;
-      if ((unsigned)tt < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
-        v = xf[((size_t)tt * a.H + hi) * a.W + wi];
-      patch[idx] = v;
-    }
-  }
-
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int n = wave * 16 + li;
 
+  {
+    // Stage the 5 x 13 x (W+6) window: each wave takes whole window rows (wave-uniform row decode,
+    // lanes stride the columns -> coalesced 4-B reads, zero halo written explicitly).
+    const int hi0 = 2 * ho0 - 3;
+    const float* xf = a.x + (size_t)(f - t) * a.H * a.W;  // clip base
+    const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+    for (int row = w_id; row < KT * PR; row += 4) {
+      const int ft = row / PR, pr = row - ft * PR;
+      const int tt = t + ft - 2, hi = hi0 + pr;
+      const bool rok = (unsigned)tt < (unsigned)a.T && (unsigned)hi < (unsigned)a.H;
+      const float* src = xf + ((size_t)(rok ? tt : 0) * a.H + (rok ? hi : 0)) * a.W;
+      float* dst = patch + row * a.pwp;
+      for (int pc = ln; pc < a.pwp; pc += 64) {
+        const int wi = pc - 3;
+        dst[pc] = (rok && (unsigned)wi < (unsigned)a.W) ? src[wi] : 0.f;
+      }
+    }
+  }
+
+  // The wave's 248 x 16 filter slice lives in VGPRs (hoisting all 62 loads above the staging with
+  // a scheduling fence costs a wave of occupancy and measured 11 % slower: left to the compiler).
   float breg[KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) breg[ks] = a.w[(4 * ks + kq) * 64 + n];
@@ -90,13 +91,22 @@ __global__ __launch_bounds__(256) void stem3d_f32_kernel(const StemArgs a) {
 
   __syncthreads();
 
+  // Tap walk kept in registers: lane quarter kq owns taps k = 4*ks + kq; (kt,kh,kw) advance by 4
+  // taps per step with carry, so the LDS offset of the tap needs no table (and no lgkmcnt drain).
+  int kw = kq, kh = 0;              // kq < 7
+  int ko = kw;                       // ktp*plane + kh*pwp + kw
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    const int ko = koff[4 * ks + kq];
+    const int kk = (4 * ks + kq) < KTAPS ? ko : 0;   // padded taps read offset 0 (their weights are 0)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const float av = patch[ko + pixoff[mt]];
+      const float av = patch[kk + pixoff[mt]];
       acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, breg[ks], acc[mt], 0, 0, 0);
+    }
+    kw += 4; ko += 4;
+    if (kw >= KW) {
+      kw -= KW; ko += a.pwp - KW;
+      if (++kh == KH) { kh = 0; ko += plane - KH * a.pwp; }
     }
   }
 
@@ -133,7 +143,7 @@ extern "C" int dlip_stem3d_bn_act_f32(const float* x, const float* w_248xk, cons
   a.pwp = W + 6;
   const long long grid = (long long)B * T * a.row_tiles;
   if (grid > 0x7FFFFFFFll) return DLIP_ERANGE;
-  const size_t lds = (size_t)(KT * PR * a.pwp + KPAD) * 4;
+  const size_t lds = (size_t)(KT * PR * a.pwp) * 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int mt = (ROWS * a.Wo + 15) / 16;
   if (mt <= 11) {

@@ -67,7 +67,7 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res in L:
             torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) * 1e3 / a.iters)
     print(f"{name:12s} " + "  ".join(f"v{v}: {best[v]:8.1f}us {fl / best[v] / 1e6:6.1f}TF" for v in variants) + f"  {fl / 1e9:8.2f} GF")
-if not a.only and False:
+if not a.only or a.only == 'stem':
     x = torch.randn(B, 29, 88, 88, device=dev)
     wp = torch.randn(248, 64, device=dev) * 0.05
     b = torch.randn(64, device=dev); sl = torch.rand(64, device=dev)
