@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import ops, packing
 from .holders import BatchNormParams, LinearParams, Marker
-from .video import _cached_pack, _require_eval
+from .video import _cached_pack
 
 
 class Linearfusion(nn.Module):
@@ -30,7 +30,11 @@ class Linearfusion(nn.Module):
                 "fc2": packing.pack_linear(self.fc2.weight, self.fc2.bias, None, device)}
 
     def forward(self, x):
-        _require_eval(self)
+        if self.training:
+            # train mode (config C5): batch-statistics BN through the autograd-wrapped HIP kernels
+            from . import autograd as ag
+            x1 = ag.bn_act_train(ag.linear(x, self.fc1.weight, self.fc1.bias), self.bn1, 0.2)
+            return x1 if self.extract_feats else ag.linear(x1, self.fc2.weight, self.fc2.bias)
         p = _cached_pack(self, x.device, self._pack)
         x1 = ops.linear(x.contiguous(), p["fc1"].w, p["fc1"].b, slope=p["fc1"].slope)  # fc1+bn1+lrelu fused
         if self.extract_feats:

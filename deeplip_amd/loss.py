@@ -3,8 +3,9 @@
 
 ``forward(embeddings, labels) -> (loss, logits)`` exactly as the reference; both values come from
 ``dlip_logits_argmax_f32`` + ``dlip_margin_ce_loss_f32``.  ``predict`` adds the first-max argmax
-(torch.max(logits, 1)[1], train_fusion.py:296) from the same launch.  Forward values only: the
-trainable-head backward is SURVEY.md section 8(f) (config C5), not built this round.
+(torch.max(logits, 1)[1], train_fusion.py:296) from the same launch.  With grad enabled, forward
+goes through deeplip_amd/autograd.py (HIP forward + backward kernels) so the criterion trains
+(config C5).
 """
 from __future__ import annotations
 
@@ -37,6 +38,12 @@ class LMCL(nn.Module):
         return loss, logits, amax
 
     def forward(self, embeddings, labels):
+        if torch.is_grad_enabled() and (self.weights.requires_grad or embeddings.requires_grad):
+            from . import autograd as ag       # differentiable path (training)
+            logits = ag.linear(ag.l2_normalize(embeddings), ag.l2_normalize(self.weights))
+            loss = ag.margin_ce_loss(logits, labels, self.s, self.margin)
+            loss = loss + 0.00001 * torch.norm(self.weights, 1)   # L1 term: torch glue (loss.py:49-50)
+            return loss, logits
         loss, logits, _ = self.predict(embeddings, labels)
         return loss, logits
 
@@ -56,6 +63,10 @@ class CrossEntropy(nn.Module):
         return loss, logits, amax
 
     def forward(self, embeddings, labels):
+        if torch.is_grad_enabled() and (self.fc.weight.requires_grad or embeddings.requires_grad):
+            from . import autograd as ag
+            logits = ag.linear(embeddings, self.fc.weight, self.fc.bias)
+            return ag.margin_ce_loss(logits, labels, 1.0, 0.0), logits
         loss, logits, _ = self.predict(embeddings, labels)
         return loss, logits
 

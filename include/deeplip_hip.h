@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 1
+#define DLIP_ABI_VERSION 2
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -167,6 +167,38 @@ int dlip_margin_ce_loss_f32(const float* logits, const int64_t* labels, float* l
 /* LowFER.forward as shipped (LBP.py:46-50): y = cat[e1, sigmoid(e2), sigmoid(e2)*e1], [B,3D]. */
 int dlip_lowfer_cat_f32(const float* e1, const float* e2, float* y, int32_t B, int32_t D,
                         dlip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Train-mode / backward kernels for the trainable fusion head and criterion (config C5; the
+ * encoders stay frozen, train_fusion.py:198-201).  Replace the autograd of
+ *   nn.Linear / nn.BatchNorm1d(train) / nn.LeakyReLU   models/fusion_models/model_fusion.py:19-24
+ *   F.cross_entropy, F.normalize, F.linear              models/audio_models/loss.py:13-16,43-51
+ * ------------------------------------------------------------------------------------------ */
+/* y = lrelu_slope(BN_train(x)) on [M,C]: batch mean / biased variance, saves mean and 1/std for the
+ * backward, updates running stats (unbiased variance, `momentum`) when the pointers are non-NULL.
+ * slope = 1 gives plain BatchNorm1d. */
+int dlip_bn1d_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                            float* save_mean, float* save_invstd, float* running_mean,
+                            float* running_var, int32_t M, int32_t C, float momentum, float eps,
+                            float slope, dlip_stream_t stream);
+int dlip_bn1d_train_bwd_f32(const float* dy, const float* x, const float* save_mean,
+                            const float* save_invstd, const float* gamma, float* dx, float* dgamma,
+                            float* dbeta, int32_t M, int32_t C, dlip_stream_t stream);
+/* dx = dy * (y >= 0 ? 1 : slope)  (LeakyReLU backward from the OUTPUT; slope > 0). */
+int dlip_lrelu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, float slope,
+                       dlip_stream_t stream);
+/* y[c] = sum_m x[m,c]  (bias gradients). */
+int dlip_colsum_f32(const float* x, float* y, int32_t M, int32_t C, dlip_stream_t stream);
+/* dlogits = grad_scale * d/dlogits mean_b CE(scale*(logits - margin*onehot) + 1e-8, labels). */
+int dlip_margin_ce_bwd_f32(const float* logits, const int64_t* labels, float* dlogits, int32_t B,
+                           int32_t K, float scale, float margin, float grad_scale,
+                           dlip_stream_t stream);
+/* Backward of dlip_l2_normalize_f32. */
+int dlip_l2_normalize_bwd_f32(const float* x, const float* dy, float* dx, int32_t U, int32_t D,
+                              float eps, dlip_stream_t stream);
+/* C[M,N] = op(A)[M,K] * op(B)[K,N], row-major, any sizes (head gradients: dX = dY W, dW = dY^T X). */
+int dlip_gemm_small_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K,
+                        int32_t trans_a, int32_t trans_b, dlip_stream_t stream);
 
 #ifdef __cplusplus
 }

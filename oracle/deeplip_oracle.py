@@ -390,3 +390,29 @@ def fused_av_embedding(video_sd: SD, audio_sd: SD, video: Tensor, audio: Tensor,
         em_video = video_time_mean(lipreading_features(video_sd, video))
         xv, _ = speaker_extract_embedding(audio_sd, audio, context)
         return fuse_av(xv, em_video)
+
+
+# ----------------------------------------------------------------------------------------
+# Trainable tail (config C5): train_fusion.py:286-299 with the encoders frozen
+# ----------------------------------------------------------------------------------------
+def linearfusion_train(p: Dict[str, Tensor], x: Tensor, extract_feats: bool = False,
+                       momentum: float = 0.1) -> Tensor:
+    """Linearfusion.forward in TRAIN mode (model_fusion.py:19-24): BatchNorm1d uses batch statistics
+    and updates running_mean / running_var in place (torch default momentum 0.1)."""
+    x1 = F.linear(x, p["fc1.weight"], p["fc1.bias"])
+    x1 = F.batch_norm(x1, p["bn1.running_mean"], p["bn1.running_var"], p["bn1.weight"], p["bn1.bias"],
+                      training=True, momentum=momentum, eps=BN_EPS)
+    x1 = F.leaky_relu(x1, 0.2)
+    return x1 if extract_feats else F.linear(x1, p["fc2.weight"], p["fc2.bias"])
+
+
+def sgd_momentum_step(params: Sequence[Tensor], bufs: List[Optional[Tensor]], lr: float, momentum: float,
+                      weight_decay: float) -> None:
+    """torch.optim.SGD update (train_fusion.py:120-124; conf/fusion_config.yaml:96-99):
+    g += wd*p; buf = g (first step) or momentum*buf + g; p -= lr*buf."""
+    with torch.no_grad():
+        for i, p in enumerate(params):
+            g = p.grad + weight_decay * p
+            bufs[i] = g.clone() if bufs[i] is None else bufs[i].mul_(momentum).add_(g)
+            p.add_(bufs[i], alpha=-lr)
+            p.grad = None

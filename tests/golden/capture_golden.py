@@ -26,6 +26,9 @@ import torch  # noqa: E402
 from deeplip_amd import weightgen as wg  # noqa: E402
 
 # import the reference package under its own name, without letting our drop-in `models/` shadow it
+# (the reference's models/ is a namespace package: any regular package named `models` on sys.path
+# would win, so this repo's root and the cwd are taken off the path first)
+sys.path = [p for p in sys.path if os.path.realpath(p or os.getcwd()) != os.path.realpath(ROOT)]
 sys.path.insert(0, REF)
 for m in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
     del sys.modules[m]
@@ -242,8 +245,50 @@ def heads():
     print("heads:", {k: np.shape(v) for k, v in out.items()})
 
 
+def train():
+    """One optimisation step of the trainable tail exactly as train_fusion.py:286-299 composes it
+    (frozen-encoder outputs are synthetic [60,512] embeddings; bs 60, SGD lr 0.5 / momentum 0.9 /
+    wd 1e-5: conf/fusion_config.yaml:91-99), for CrossEntropy and for LMCL (audio_config: s=30, m=0.2)."""
+    out = {}
+    B = 60
+    xa = torch.from_numpy(wg.gen("train.xv_audio", (B, 512)))
+    ev = torch.from_numpy(wg.gen("train.em_video", (B, 512)))
+    lab = torch.from_numpy(wg.labels(B, 57))
+    for tag, make in (("ce", lambda: CrossEntropy(512, 57)), ("lmcl", lambda: LMCL(512, 57, 30, 0.2))):
+        fus = model_fusion(1024, 512, 57, False)
+        crit = make()
+        fill(fus, "train.lf."); fill(crit, f"train.{tag}.")
+        fus.train(); crit.train()
+        params = [{"params": fus.parameters()}, {"params": crit.parameters()}]
+        opt = torch.optim.SGD(params, lr=0.5, weight_decay=1e-5, momentum=0.9)
+        for step in range(2):      # two steps so the momentum buffer matters
+            opt.zero_grad()
+            output = fus(torch.cat([xa, ev], dim=1))
+            loss, logits = crit(output, lab)
+            _, pred = torch.max(logits, dim=1)
+            loss.backward()
+            if step == 0:
+                out[f"{tag}_loss0"] = loss.detach().numpy(); out[f"{tag}_logits0"] = logits.detach().numpy()
+                out[f"{tag}_argmax0"] = pred.numpy()
+                out[f"{tag}_grad_fc2_w_rows8"] = fus.fc2.weight.grad[:8].numpy().copy()
+                out[f"{tag}_grad_fc1_b"] = fus.fc1.bias.grad.numpy().copy()
+                out[f"{tag}_grad_bn1_w"] = fus.bn1.weight.grad.numpy().copy()
+                cw = crit.fc.weight if tag == "ce" else crit.weights
+                out[f"{tag}_grad_crit_w"] = cw.grad.numpy().copy()
+            opt.step()
+        out[f"{tag}_loss1"] = loss.detach().numpy()
+        sd = {**{"fus." + k: v for k, v in fus.state_dict().items()}, **{"crit." + k: v for k, v in crit.state_dict().items()}}
+        for k, v in sd.items():
+            v = v.detach().double()
+            out[f"{tag}_after2_{k}_sum"] = np.array([float(v.sum()), float(v.abs().sum())])
+        out[f"{tag}_after2_fc2_w_rows8"] = fus.fc2.weight.detach()[:8].numpy().copy()
+        out[f"{tag}_after2_bn1_running_var"] = fus.bn1.running_var.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "train_golden.npz"), **out)
+    print("train:", {k: np.shape(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["video", "audio", "heads"]
+    which = sys.argv[1:] or ["video", "audio", "heads", "train"]
     mpath = os.path.join(HERE, "manifest.json")
     if os.path.exists(mpath):
         manifest.update(json.load(open(mpath)))

@@ -158,3 +158,39 @@ def test_ingest_rgb_shape():
     # a gray image (R=G=B=v) maps to (v/255 - 0.421)/0.165
     v = np.full((1, 1, 3, 2, 2), 128, np.uint8)
     assert np.allclose(O.ingest_rgb_u8(v), (128 / 255 - 0.421) / 0.165, atol=1e-5)
+
+
+def test_train_step_oracle(golden, manifest):
+    """Two SGD steps of fusion head + criterion (config C5) -- oracle vs the reference classes."""
+    g = golden["train"]
+    B = 60
+    xa = torch.from_numpy(wg.gen("train.xv_audio", (B, 512)))
+    ev = torch.from_numpy(wg.gen("train.em_video", (B, 512)))
+    lab = torch.from_numpy(wg.labels(B, 57))
+    for tag, cname in (("ce", "ce_512_57"), ("lmcl", "lmcl_512_57")):
+        lf = sd_from(manifest, "linearfusion_1024_512", "train.lf.")
+        if tag == "ce":
+            cs = O.to_torch_sd(wg.fill_state_dict({"fc.weight": (57, 512), "fc.bias": (57,)}, prefix="train.ce."))
+        else:
+            cs = sd_from(manifest, "lmcl_512_57", "train.lmcl.")
+        train_keys = [k for k in lf if "running" not in k and "num_batches" not in k]
+        params = [lf[k].requires_grad_() for k in train_keys] + [v.requires_grad_() for v in cs.values()]
+        bufs = [None] * len(params)
+        for step in range(2):
+            out = O.linearfusion_train(lf, torch.cat([xa, ev], 1))
+            if tag == "ce":
+                loss, logits = O.cross_entropy_head(out, lab, cs["fc.weight"], cs["fc.bias"])
+            else:
+                loss, logits = O.lmcl(out, lab, cs["weights"], 30, 0.2)
+            loss.backward()
+            if step == 0:
+                assert abs(float(loss) - float(g[f"{tag}_loss0"])) < 1e-5
+                assert rel_err(logits.detach().numpy(), g[f"{tag}_logits0"]) < 1e-5
+                assert np.array_equal(O.argmax_first(logits).numpy(), g[f"{tag}_argmax0"])
+                assert rel_err(lf["fc2.weight"].grad[:8].numpy(), g[f"{tag}_grad_fc2_w_rows8"]) < 1e-4
+                cw = cs["fc.weight"] if tag == "ce" else cs["weights"]
+                assert rel_err(cw.grad.numpy(), g[f"{tag}_grad_crit_w"]) < 1e-4
+            O.sgd_momentum_step(params, bufs, 0.5, 0.9, 1e-5)
+        assert abs(float(loss) - float(g[f"{tag}_loss1"])) < 1e-3 * max(1.0, float(g[f"{tag}_loss1"]))
+        assert rel_err(lf["fc2.weight"].detach()[:8].numpy(), g[f"{tag}_after2_fc2_w_rows8"]) < 1e-4
+        assert rel_err(lf["bn1.running_var"].numpy(), g[f"{tag}_after2_bn1_running_var"]) < 1e-5
