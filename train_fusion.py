@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""train_fusion.py -- audio-visual fusion trainer / tester on the MI355X engine.
+
+Entry point of the reference (train_fusion.py) re-created runnable: same config schema
+(conf/fusion_config.yaml: data / model / train / test), same ``Trainer`` method names
+(``__call__/_train/_train_epoch/feature_normalize/extract_test_xv_lomgrid/extract_test_xv_grid/
+save/load/load_finetune``) and the same flow -- frozen audio + video encoders, trainable fusion
+head + criterion (train_fusion.py:120,198-201), test-time fusion = z-norm + concat
+(:353-358), cosine EER over a trial list -- with the upstream breakages fixed and
+three structural changes:
+  * batched: the reference's per-utterance / per-clip Python loops (:267-281,:346-349) become one
+    encoder launch set per batch + a segmented clip-group mean on the device;
+  * embeddings stay in HBM (``EmbeddingTable``) instead of one .npy per utterance (:361-364);
+  * data parallel = one process per GPU over RCCL (gradient all-reduce of the trainable tail, one
+    all-gather of test embeddings), replacing nn.DataParallel (:91-93).
+
+    python train_fusion.py --mode train            # single GPU
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_fusion.py --mode train
+    python train_fusion.py --mode av_test | av_fusion
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import yaml
+from torch import optim
+from torch.optim import lr_scheduler
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from deeplip_amd import dist as ddist, fusion, ops, scoring  # noqa: E402
+from deeplip_amd.synthetic import SyntheticAVSet, synthetic_trials  # noqa: E402
+from models.audio_models import tdnn  # noqa: E402
+from models.audio_models.loss import LMCL, CrossEntropy  # noqa: E402
+from models.fusion_models import LBP, model_fusion  # noqa: E402
+from models.video_models.model import Lipreading  # noqa: E402
+
+
+class Trainer(object):
+    def __init__(self, mode, config="conf/fusion_config.yaml", overrides=None):
+        with open(os.path.join(ROOT, config) if not os.path.isabs(config) else config) as f:
+            opts = yaml.safe_load(f)
+        for k, v in (overrides or {}).items():      # e.g. {"train.bs": 8}
+            d = opts
+            *path, leaf = k.split(".")
+            for p in path:
+                d = d[p]
+            d[leaf] = v
+        self.train_opts, self.model_opts = opts["train"], opts["model"]
+        self.data_opts, self.test_opts = opts["data"], opts["test"]
+        self.mode = mode
+
+        self.rank, self.world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        if not torch.cuda.is_available():
+            raise RuntimeError("train_fusion.py needs a ROCm GPU: the deeplip_amd engine has no CPU path")
+        torch.cuda.set_device(local)
+        self.device = torch.device("cuda", local)
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=self.device)
+
+        d = self.data_opts
+        acfg = self.model_opts["audio_config"]
+        feat_dim = acfg[acfg["arch"]]["input_dim"]
+        self.trainset = SyntheticAVSet(d["n_spk"], d["utt_per_spk"], d["clips_per_utt"], d["video_frames"], feat_dim,
+                                       d["audio_frames"], key="train")
+        self.lomgridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], d["clips_per_utt"],
+                                             d["video_frames"], feat_dim, d["audio_frames"], key="lomgrid")
+        self.gridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], d["clips_per_utt"],
+                                          d["video_frames"], feat_dim, d["audio_frames"], key="grid")
+        n_spk = self.trainset.n_spk
+
+        if acfg["arch"] in ("tdnn", "etdnn"):
+            self.model_audio = tdnn.SpeakerEmbNet(acfg)
+        else:
+            raise NotImplementedError("Other models are not implemented!")
+        vcfg = self.model_opts["video_config"]
+        if vcfg["arch"] == "tcn":
+            t = vcfg["tcn"]
+            tcn_options = {"num_layers": t["tcn_num_layers"], "kernel_size": t["tcn_kernel_size"],
+                           "dropout": t["tcn_dropout"], "dwpw": t["tcn_dwpw"], "width_mult": t["tcn_width_mult"]}
+            self.model_video = Lipreading(num_classes=n_spk, tcn_options=tcn_options, backbone_type=t["backbone_type"],
+                                          relu_type=t["relu_type"], width_mult=t["width_mult"],
+                                          extract_feats=t["extract_feats"])
+        else:
+            raise NotImplementedError("Other models are not implemented!")
+
+        self.embedding_dim = acfg[acfg["arch"]]["embedding_dim"]
+        kind = self.model_opts.get("fusion", "linear")
+        if kind == "linear":      # the commented-out upstream choice (train_fusion.py:82)
+            self.model_fusion = model_fusion.model_fusion(self.embedding_dim * 2, 512, n_spk, extract_feats=False)
+            fused_dim = 512
+        elif kind == "lowfer":    # LBP.LowFER as shipped: cat[e1, sigmoid(e2), sigmoid(e2)*e1]
+            self.model_fusion = LBP.LowFER(self.embedding_dim, self.embedding_dim, 512)
+            fused_dim = 3 * self.embedding_dim
+        elif kind == "concat":
+            self.model_fusion = torch.nn.Identity()
+            fused_dim = 2 * self.embedding_dim
+        else:
+            raise NotImplementedError(kind)
+        self.fusion_kind = kind
+        for m in (self.model_audio, self.model_video, self.model_fusion):
+            m.to(self.device)
+
+        if self.train_opts["loss"] == "CrossEntropy":
+            self.criterion = CrossEntropy(fused_dim, n_spk).to(self.device)
+        elif self.train_opts["loss"] == "LMCL":
+            self.init_margin, self.end_margin = self.train_opts["audio_config"]["margin"]
+            self.criterion = LMCL(fused_dim, n_spk, self.train_opts["audio_config"]["scale"], self.init_margin).to(self.device)
+        else:
+            raise NotImplementedError("Other loss function has not been implemented yet!")
+
+        param_groups = [{"params": list(self.model_fusion.parameters())}, {"params": self.criterion.parameters()}]
+        if self.train_opts["optimizer"] == "sgd":
+            o = self.train_opts["sgd"]
+            self.optim = optim.SGD(param_groups, o["init_lr"], momentum=o["momentum"], weight_decay=o["weight_decay"])
+        else:
+            raise NotImplementedError(self.train_opts["optimizer"])
+        self.epoch = self.train_opts["epoch"]
+        self.resume_audio = self.train_opts["audio_config"]["resume"]
+        self.resume_video = self.train_opts["video_config"]["resume"]
+        self.resume_fusion = self.train_opts["resume"]
+        self.log_time = time.asctime(time.localtime(time.time())).replace(" ", "_")[4:]
+        self.lr_scheduler = lr_scheduler.MultiStepLR(self.optim, milestones=self.train_opts["lr_decay_step"], gamma=0.1)
+        self.current_epoch = 0
+        self.load_finetune()
+        # replicas start identical (DataParallel broadcast equivalent)
+        if self.world > 1:
+            for p in list(self.model_fusion.parameters()) + list(self.criterion.parameters()):
+                dist.broadcast(p.data, 0)
+
+    # ------------------------------------------------------------------ training
+    def _adjust_margin(self):
+        if isinstance(self.criterion, LMCL):
+            self.criterion.margin = self.init_margin if self.current_epoch <= 5 else self.end_margin
+
+    def _train(self):
+        for epoch in range(self.current_epoch + 1, self.epoch + 1):
+            self.current_epoch = epoch
+            self._adjust_margin()
+            self._train_epoch()
+            self.lr_scheduler.step()
+            if self.rank == 0:
+                self.save()
+
+    def __call__(self):
+        if self.rank == 0:
+            os.makedirs("exp/{}".format(self.log_time), exist_ok=True)
+        self._train()
+
+    def feature_normalize(self, data):
+        """train_fusion.py:233-238 (per-row z-norm, unbiased std) -- one HIP launch."""
+        return fusion.feature_normalize(data)
+
+    def _embed_batch(self, dataset, idx):
+        """Frozen encoders on a batch of utterances -> (xv_audio [B,512], em_video [B,512])."""
+        with torch.no_grad():
+            audio = torch.from_numpy(dataset.audio(idx)).to(self.device)
+            xv_audio, _ = self.model_audio.extract_embedding(audio)      # train_fusion.py:262,338
+            clips, ptr = dataset.video(idx)
+            clip_means = self.model_video.embed(torch.from_numpy(clips).to(self.device))   # mean over T (:274,:348)
+            em_video = ops.group_mean(clip_means, torch.from_numpy(ptr).to(self.device))   # mean over clip files (:275,:349)
+        return xv_audio, em_video
+
+    def _fuse(self, xv_audio, em_video):
+        if self.fusion_kind == "lowfer":
+            return self.model_fusion(xv_audio, em_video)
+        return self.model_fusion(torch.cat([xv_audio, em_video], dim=1).contiguous())
+
+    def _allreduce_grads(self):
+        if self.world == 1:
+            return
+        params = [p for g in self.optim.param_groups for p in g["params"] if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in params])          # one bucket (3.4 MB): latency-bound
+        dist.all_reduce(flat)
+        flat /= self.world
+        o = 0
+        for p in params:
+            n = p.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p))
+            o += n
+
+    def _train_epoch(self):
+        self.model_fusion.train()
+        self.model_audio.eval()
+        self.model_video.eval()
+        bs = self.train_opts["bs"]
+        steps = self.train_opts.get("steps_per_epoch", max(1, len(self.trainset) // (bs * self.world)))
+        rng = np.random.Generator(np.random.PCG64([self.current_epoch, 17]))
+        sum_loss = sum_samples = correct = 0.0
+        t0 = time.perf_counter()
+        for it in range(steps):
+            # speaker-balanced sampling as the reference's sampler (datasets.py:161-164): idx % n_spk
+            glob = rng.integers(0, len(self.trainset), bs * self.world)
+            idx = glob[self.rank * bs:(self.rank + 1) * bs]
+            labels = torch.from_numpy(self.trainset.labels(idx)).to(self.device)
+            self.optim.zero_grad()
+            xv_audio, em_video = self._embed_batch(self.trainset, idx)
+            output = self._fuse(xv_audio, em_video)
+            loss, logits = self.criterion(output, labels)
+            _, prediction = torch.max(logits, dim=1)
+            loss.backward()
+            self._allreduce_grads()
+            self.optim.step()
+            n = float(len(idx))
+            sum_loss += float(loss.detach()) * n
+            sum_samples += n
+            correct += float((prediction == labels).sum())
+        tot = ddist.allreduce_metrics([sum_loss, correct, sum_samples], self.device)
+        dt = time.perf_counter() - t0
+        if self.rank == 0:
+            print("Epoch {} loss {:.4f} acc {:.2f}% | {:.1f} A+V pairs/s on {} GPU(s)".format(
+                self.current_epoch, tot[0] / tot[2], 100.0 * tot[1] / tot[2], tot[2] / dt, self.world), flush=True)
+        return tot[0] / tot[2], tot[1] / tot[2]
+
+    # ------------------------------------------------------------------ checkpoints
+    def save(self, filename=None):
+        path = "exp/{}/{}".format(self.log_time, filename or "net_{}.pth".format(self.current_epoch))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save({"epoch": self.current_epoch, "state_dict": self.model_fusion.state_dict(),
+                    "criterion": self.criterion.state_dict(), "optimizer": self.optim.state_dict()}, path)
+        return path
+
+    def load(self, resume):
+        ckpt = torch.load(resume, map_location="cpu")
+        self.model_fusion.load_state_dict(ckpt["state_dict"])
+        self.criterion.load_state_dict(ckpt["criterion"])
+        self.current_epoch = ckpt["epoch"]
+
+    def load_finetune(self):
+        """train_fusion.py:191-215: load pretrained audio (keys carry DataParallel's 'module.' prefix) and
+        video checkpoints if they exist, then freeze both encoders.  Without files the encoders keep
+        the deterministic synthetic initialisation (there are no checkpoints in this environment)."""
+        from deeplip_amd import weightgen as wg
+        if os.path.exists(self.resume_audio):
+            ck = torch.load(self.resume_audio, map_location="cpu")
+            self.model_audio.load_state_dict({k.replace("module.", ""): v for k, v in ck["state_dict"].items()})
+        else:
+            sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in self.model_audio.state_dict().items()}, prefix="audio.")
+            self.model_audio.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        if os.path.exists(self.resume_video):
+            self.model_video.load_state_dict(torch.load(self.resume_video, map_location="cpu"))
+        else:
+            sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in self.model_video.state_dict().items()}, prefix="video.")
+            self.model_video.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        for m in (self.model_audio, self.model_video):
+            for p in m.parameters():
+                p.requires_grad = False
+            m.eval()
+
+    # ------------------------------------------------------------------ test-time extraction + scoring
+    def _extract(self, dataset, batch=32):
+        """Sharded over ranks; returns (EmbeddingTable of fused [N,1024], audio-only table, video-only table)."""
+        lo, hi = ddist.shard_range(len(dataset))
+        fa, fv = [], []
+        for b0 in range(lo, hi, batch):
+            idx = list(range(b0, min(hi, b0 + batch)))
+            xv_audio, em_video = self._embed_batch(dataset, idx)
+            fa.append(xv_audio); fv.append(em_video)
+        D = self.embedding_dim
+        xa = torch.cat(fa) if fa else torch.empty((0, D), device=self.device)
+        xv = torch.cat(fv) if fv else torch.empty((0, D), device=self.device)
+        em = fusion.fuse_av(xa, xv) if xa.shape[0] else torch.empty((0, 2 * D), device=self.device)  # :353-358
+        n = len(dataset)
+        em, xa, xv = (ddist.gather_rows(t, n) for t in (em, xa, xv))
+        return (scoring.EmbeddingTable(dataset.utt_ids, em), scoring.EmbeddingTable(dataset.utt_ids, xa),
+                scoring.EmbeddingTable(dataset.utt_ids, xv))
+
+    def extract_test_xv_lomgrid(self):
+        self.lomgrid_tables = self._extract(self.lomgridtestset)
+        return self.lomgrid_tables[0]
+
+    def extract_test_xv_grid(self):
+        self.grid_tables = self._extract(self.gridtestset)
+        return self.grid_tables[0]
+
+    def eer_cos(self, dataset, tables, mode="cos"):
+        y, pairs = synthetic_trials(dataset, self.data_opts["trials"], self.data_opts["trial_targets"])
+        ia, ib = tables[0].trial_indices(pairs)
+        if mode == "cos":              # utils.eer_cos_* (utils.py:251-283)
+            s = scoring.cosine_scores(tables[0].emb, ia, ib)
+        elif mode == "scorefusion":    # utils.eer_cos_*_scorefusion (:331-381)
+            s = scoring.score_fusion(tables[1].emb, tables[2].emb, ia, ib)
+        else:                          # utils.eer_cos_*_featurefusion (:433-521)
+            s = scoring.feature_fusion_scores(tables[1].emb, tables[2].emb, ia, ib)
+        return scoring.eer_from_scores(y, s.cpu().numpy())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="av_test", choices=["train", "av_test", "av_fusion"])   # reference: hard-coded at :424
+    ap.add_argument("--config", default="conf/fusion_config.yaml")
+    ap.add_argument("--set", nargs="*", default=[], help="overrides, e.g. train.bs=8 data.trials=2000")
+    args = ap.parse_args()
+    ov = {}
+    for kv in args.set:
+        k, v = kv.split("=", 1)
+        ov[k] = yaml.safe_load(v)
+    trainer = Trainer(args.mode, args.config, ov)
+    rank0 = trainer.rank == 0
+    if args.mode == "train":
+        trainer()
+        trainer.extract_test_xv_lomgrid()
+        eer, thr = trainer.eer_cos(trainer.lomgridtestset, trainer.lomgrid_tables, "featurefusion")
+        if rank0:
+            print("EER: {:.6f}%".format(eer * 100))
+    else:
+        kind = "cos" if args.mode == "av_test" else "scorefusion"
+        if trainer.test_opts["eval_lomgrid"]:
+            trainer.extract_test_xv_lomgrid()
+            if trainer.test_opts["use_cos"]:
+                eer, thr = trainer.eer_cos(trainer.lomgridtestset, trainer.lomgrid_tables, kind)
+                if rank0:
+                    print("EER: {:.6f}%".format(eer * 100))
+        if trainer.test_opts["eval_grid"]:
+            trainer.extract_test_xv_grid()
+            if trainer.test_opts["use_cos"]:
+                eer, thr = trainer.eer_cos(trainer.gridtestset, trainer.grid_tables, kind)
+                if rank0:
+                    print("EER: {:.6f}%".format(eer * 100))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
