@@ -264,13 +264,16 @@ class MultiscaleMultibranchTCN(nn.Module):
         return {"blocks": [b.pack(device) for b in self.mb_ms_tcn.network],
                 "out": packing.pack_linear(self.tcn_output.weight, self.tcn_output.bias, None, device)}
 
-    def run(self, x: Tensor, lengths, p) -> Tensor:
-        """x [B,T,512] (already time-major channels-last: the reference's transpose(1,2) is a no-op here)."""
+    def pooled(self, x: Tensor, lengths, p) -> Tensor:
+        """x [B,T,512] (already time-major channels-last: the reference's transpose(1,2) is a no-op
+        here) -> consensus features [B, 768] = _average_batch(mb_ms_tcn(x)) (model.py:16-17,34-36)."""
         for b, bp in zip(self.mb_ms_tcn.network, p["blocks"]):
             x = b.run(x, bp)
         ln = torch.as_tensor([int(l) for l in lengths], dtype=torch.int32).to(x.device)
-        pooled = ops.time_mean(x, ln)                       # _average_batch, model.py:16-17
-        return ops.linear(pooled, p["out"].w, p["out"].b)   # tcn_output, model.py:27,37
+        return ops.time_mean(x, ln)
+
+    def run(self, x: Tensor, lengths, p) -> Tensor:
+        return ops.linear(self.pooled(x, lengths, p), p["out"].w, p["out"].b)   # tcn_output, model.py:27,37
 
     def forward(self, x, lengths, B):
         _require_eval(self)
@@ -351,6 +354,16 @@ class Lipreading(nn.Module):
             taps["stem"] = y
         y = self.trunk.run(y, p["trunk"], taps).view(B, T, self.backend_out)
         return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
+
+    def classifier_features(self, x: Tensor, lengths) -> Tensor:
+        """[B,1,T,H,W] -> [B,768]: everything of forward() except the final tcn_output Linear (the
+        input of the trainable classifier layer in train_video.py)."""
+        ef, self.extract_feats = self.extract_feats, True
+        try:
+            feats = self.forward(x, lengths)
+        finally:
+            self.extract_feats = ef
+        return self.tcn.pooled(feats, lengths, _cached_pack(self, x.device, self._pack)["tcn"])
 
     def embed(self, x: Tensor) -> Tensor:
         """[B,1,T,H,W] -> [B,512]: per-clip temporal mean of the features, the quantity the fusion

@@ -1,0 +1,47 @@
+"""Entry points: train_video.py plumbing on CPU (BASELINE config C1: no GPU), and its GPU run."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_train_video_cpu_plumbing(tmp_path):
+    """C1: CPU-only plumbing -- config, model with 54 classes, pad_packed_collate batches
+    [B=4, T<=29, 88, 88] + lengths, Adam + per-iteration cosine LR, checkpoint round trip."""
+    import train_video
+    args = train_video.load_args(["--device", "cpu", "--save-path", str(tmp_path / "ck"), "--steps", "2"])
+    model = train_video.get_model(args)
+    assert len(model.state_dict()) == 343 and model.tcn.tcn_output.weight.shape == (54, 768)
+    data, lengths, labels = train_video.synthetic_batch(args, 0)
+    assert data.shape == (4, 29, 88, 88) and lengths == sorted(lengths, reverse=True) and lengths[0] == 29
+    assert float(data[-1, lengths[-1]:].abs().max()) == 0.0 if lengths[-1] < 29 else True
+    rgb, _, _ = train_video.synthetic_batch(args, 0, rgb=True)
+    assert rgb.shape == (4, 29, 3, 88, 88) and rgb.dtype == torch.uint8
+    res = train_video.main(["--device", "cpu", "--save-path", str(tmp_path / "ck"), "--steps", "2"])
+    assert res is None and os.path.exists(tmp_path / "ck" / "1.pt")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rgb", [False, True])
+def test_train_video_gpu_two_steps(tmp_path, rgb):
+    import train_video
+    argv = ["--save-path", str(tmp_path / "ck"), "--steps", "2", "--frames", "9"] + (["--rgb"] if rgb else [])
+    loss, shape = train_video.main(argv)
+    assert np.isfinite(loss) and shape == (4, 54)
+
+
+@pytest.mark.gpu
+def test_train_audio_test_mode(tmp_path, monkeypatch):
+    import train_audio
+    monkeypatch.chdir(tmp_path)
+    tr = train_audio.Trainer(overrides={"data.test_speakers": 4, "data.test_utt_per_spk": 3, "data.trials": 200,
+                                        "data.trial_targets": 40, "data.audio_frames": 120, "data.n_spk": 6,
+                                        "data.utt_per_spk": 3, "train.bs": 8, "train.epoch": 2})
+    tr._train()
+    assert tr.model_average(2) == 2
+    table = tr.extract_test_xv()
+    assert table.emb.shape == (12, 512)
+    assert np.abs(table.emb.norm(dim=1).cpu().numpy() - 1).max() < 1e-5
+    eer, _ = tr.eer()
+    assert 0 <= eer <= 1

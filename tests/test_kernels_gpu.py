@@ -252,3 +252,30 @@ def test_lowfer_cat(ops):
     y = ops.lowfer_cat(e1.cuda(), e2.cuda())
     torch.cuda.synchronize()
     assert rel_err(y.cpu().numpy(), O.lowfer(e1, e2).numpy()) < 1e-6
+
+
+def test_trial_scoring_full_size_properties(ops):
+    """BASELINE config C4 size: 20 000 trials over a 25 834-utterance table of 1024-d rows
+    (database/trial_grid_v1.txt shape).  Size-independent properties + an oracle spot check."""
+    from oracle import deeplip_oracle as O
+    N, D, T = 25834, 1024, 20000
+    g = torch.Generator().manual_seed(41)
+    table = torch.randn(N, D, generator=g)
+    ia = torch.randint(0, N, (T,), generator=g, dtype=torch.int32)
+    ib = torch.randint(0, N, (T,), generator=g, dtype=torch.int32)
+    ia[:100] = ib[:100]                                   # self trials
+    dev = table.cuda()
+    s_ab = ops.pair_cosine(dev, ia.cuda(), ib.cuda(), mode=0)
+    s_ba = ops.pair_cosine(dev, ib.cuda(), ia.cuda(), mode=0)
+    s_scaled = ops.pair_cosine(dev * 3.5, ia.cuda(), ib.cuda(), mode=0)
+    torch.cuda.synchronize()
+    s = s_ab.cpu().numpy()
+    assert np.array_equal(s, s_ba.cpu().numpy())                       # symmetry, bit-exact
+    assert np.abs(s[:100] - 1.0).max() < 1e-6                          # cos(x, x) = 1
+    assert np.abs(s - s_scaled.cpu().numpy()).max() < 1e-6             # scale invariance
+    assert np.abs(s).max() <= 1.0 + 1e-6
+    sel = np.arange(0, T, 97)
+    ref = O.cosine_trial_scores(table.numpy(), ia.numpy()[sel], ib.numpy()[sel])
+    assert np.abs(s[sel] - ref).max() < 1e-6
+    bad = ops.pair_cosine(dev, torch.tensor([N], dtype=torch.int32).cuda(), torch.tensor([0], dtype=torch.int32).cuda())
+    assert np.isnan(float(bad.cpu()[0]))                               # out-of-table index -> NaN, not a fault

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""train_audio.py -- x-vector (TDNN / E-TDNN) entry point on the MI355X engine.
+
+Re-creation of the reference's train_audio.py surface that the A+V hot path uses: config schema
+(conf/audio_config.yaml: data / model / train / test), ``Trainer`` with ``extract_test_xv`` (x-vector
+extraction + F.normalize, train_audio.py:343-373), ``model_average`` (checkpoint averaging,
+:216-232), ``_adjust_margin`` (:141-145), ``save`` / ``load``; modes ``test`` (extract + cosine EER)
+and ``train``.  Full-encoder training (TDNN dgrad/wgrad, train-mode BN) is SURVEY.md section 8(f)
+rank 2 and not built yet: ``_train_epoch`` trains the LMCL criterion on frozen encoder embeddings
+(the HIP backward kernels of config C5) and says so.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from deeplip_amd import ops, scoring, weightgen as wg  # noqa: E402
+from deeplip_amd.synthetic import SyntheticAVSet, synthetic_trials  # noqa: E402
+from models.audio_models import tdnn  # noqa: E402
+from models.audio_models.loss import LMCL, CrossEntropy  # noqa: E402
+
+
+class Trainer(object):
+    def __init__(self, config="conf/audio_config.yaml", overrides=None):
+        with open(os.path.join(ROOT, config)) as f:
+            opts = yaml.safe_load(f)
+        for k, v in (overrides or {}).items():
+            d = opts
+            *path, leaf = k.split(".")
+            for p in path:
+                d = d[p]
+            d[leaf] = v
+        self.train_opts, self.model_opts = opts["train"], opts["model"]
+        self.data_opts, self.test_opts = opts["data"], opts["test"]
+        if not torch.cuda.is_available():
+            raise RuntimeError("train_audio.py needs a ROCm GPU: the deeplip_amd engine has no CPU path")
+        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+        arch = self.model_opts["arch"]
+        if arch not in ("tdnn", "etdnn"):
+            raise NotImplementedError("Other models are not implemented!")   # train_audio.py:67-68
+        self.model = tdnn.SpeakerEmbNet(self.model_opts)
+        d = self.data_opts
+        F_ = self.model_opts[arch]["input_dim"]
+        self.trainset = SyntheticAVSet(d["n_spk"], d["utt_per_spk"], 0, 1, F_, d["audio_frames"], key="atrain")
+        self.voxtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="atest")
+        sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in self.model.state_dict().items()}, prefix="audio.")
+        self.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        self.model.eval().to(self.device)
+        E = self.model_opts[arch]["embedding_dim"]
+        if self.train_opts["loss"] == "LMCL":
+            self.init_margin, self.end_margin = self.train_opts["margin"]
+            self.criterion = LMCL(E, d["n_spk"], self.train_opts["scale"], self.init_margin).to(self.device)
+        else:
+            self.criterion = CrossEntropy(E, d["n_spk"]).to(self.device)
+        o = self.train_opts["sgd"]
+        self.optim = torch.optim.SGD(self.criterion.parameters(), o["init_lr"], momentum=o["momentum"],
+                                     weight_decay=o["weight_decay"])
+        self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optim, milestones=self.train_opts["lr_decay_step"], gamma=0.1)
+        self.epoch, self.current_epoch = self.train_opts["epoch"], 0
+        self.log_time = time.asctime(time.localtime(time.time())).replace(" ", "_")[4:]
+
+    def _adjust_margin(self):
+        if isinstance(self.criterion, LMCL):
+            self.criterion.margin = self.init_margin if self.current_epoch <= 5 else self.end_margin
+
+    def _train_epoch(self):
+        """Criterion-only step on frozen-encoder x-vectors (see module docstring)."""
+        bs = self.train_opts["bs"]
+        rng = np.random.Generator(np.random.PCG64([self.current_epoch, 5]))
+        tot = n = 0.0
+        for _ in range(self.train_opts.get("steps_per_epoch", 2)):
+            idx = rng.integers(0, len(self.trainset), bs)
+            x = torch.from_numpy(self.trainset.audio(idx)).to(self.device)
+            lab = torch.from_numpy(self.trainset.labels(idx)).to(self.device)
+            with torch.no_grad():
+                emb = self.model(x)                       # SpeakerEmbNet.forward (train_audio.py:187)
+            self.optim.zero_grad()
+            loss, logits = self.criterion(emb, lab)
+            loss.backward()
+            self.optim.step()
+            tot += float(loss.detach()) * len(idx); n += len(idx)
+        return tot / n
+
+    def _train(self):
+        for epoch in range(self.current_epoch + 1, self.epoch + 1):
+            self.current_epoch = epoch
+            self._adjust_margin()
+            print("Epoch {} loss {:.4f}".format(epoch, self._train_epoch()), flush=True)
+            self.lr_scheduler.step()
+            self.save()
+
+    def save(self, filename=None):
+        path = "exp/{}/{}".format(self.log_time, filename or "net_{}.pth".format(self.current_epoch))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        # keys carry the DataParallel 'module.' prefix like the reference's checkpoints (train_audio.py:262)
+        torch.save({"epoch": self.current_epoch, "state_dict": {"module." + k: v for k, v in self.model.state_dict().items()},
+                    "criterion": self.criterion.state_dict(), "optimizer": self.optim.state_dict()}, path)
+        return path
+
+    def load(self, resume):
+        ck = torch.load(resume, map_location="cpu")
+        self.model.load_state_dict({k.replace("module.", ""): v for k, v in ck["state_dict"].items()})
+        self.criterion.load_state_dict(ck["criterion"])
+        self.current_epoch = ck["epoch"]
+
+    def model_average(self, avg_num=4):
+        """train_audio.py:216-232: average the state dicts of the last ``avg_num`` epoch checkpoints."""
+        paths = ["exp/{}/net_{}.pth".format(self.log_time, e) for e in range(self.current_epoch - avg_num + 1, self.current_epoch + 1)]
+        paths = [p for p in paths if os.path.exists(p)]
+        avg = None
+        for p in paths:
+            sd = torch.load(p, map_location="cpu")["state_dict"]
+            avg = {k: v.clone().double() for k, v in sd.items()} if avg is None else {k: avg[k] + v.double() for k, v in sd.items()}
+        avg = {k.replace("module.", ""): (v / len(paths)).to(self.model.state_dict()[k.replace("module.", "")].dtype) for k, v in avg.items()}
+        self.model.load_state_dict(avg)
+        return len(paths)
+
+    def extract_test_xv(self, batch=64):
+        """x-vectors of the test set, L2-normalised (train_audio.py:343-373) -> EmbeddingTable."""
+        rows = []
+        with torch.no_grad():
+            for b0 in range(0, len(self.voxtestset), batch):
+                idx = list(range(b0, min(len(self.voxtestset), b0 + batch)))
+                xv, _ = self.model.extract_embedding(torch.from_numpy(self.voxtestset.audio(idx)).to(self.device))
+                rows.append(ops.l2_normalize(xv))
+        self.table = scoring.EmbeddingTable(self.voxtestset.utt_ids, torch.cat(rows))
+        return self.table
+
+    def eer(self):
+        y, pairs = synthetic_trials(self.voxtestset, self.data_opts["trials"], self.data_opts["trial_targets"])
+        ia, ib = self.table.trial_indices(pairs)
+        return scoring.eer_from_scores(y, scoring.cosine_scores(self.table.emb, ia, ib).cpu().numpy())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="test", choices=["train", "test"])    # reference: hard-coded at :485
+    ap.add_argument("--config", default="conf/audio_config.yaml")
+    ap.add_argument("--set", nargs="*", default=[])
+    a = ap.parse_args()
+    tr = Trainer(a.config, {k: yaml.safe_load(v) for k, v in (kv.split("=", 1) for kv in a.set)})
+    if a.mode == "train":
+        tr._train()
+        tr.model_average(min(4, tr.epoch))
+    tr.extract_test_xv()
+    eer, thr = tr.eer()
+    print("EER: {:.6f}%".format(eer * 100))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""train_video.py -- lip-clip encoder entry point (ResNet-18 + MS-TCN) on the MI355X engine.
+
+Re-creation of the reference's train_video.py surface: the same argparse flags (:31-68), JSON model
+config (conf/video_config.json), ``get_model`` (:173-190), ``extract_feats`` (:99-106), ``train``
+(:108-169: Adam 3e-4 / wd 1e-4, CosineAnnealingLR(T_max=5) stepped PER ITERATION, CrossEntropy,
+per-epoch ``<save_path>/<epoch+1>.pt`` state-dict checkpoints), ``main``.  Data are synthetic clips
+produced with ``pad_packed_collate`` semantics (zero-pad to the longest clip + lengths list,
+models/video_models/dataset.py:123-139); ``--rgb`` feeds uint8 [B,T,3,88,88] frames through the
+GPU ingest kernel (gray + (x/255-0.421)/0.165).
+
+What trains: the classifier layer ``tcn.tcn_output`` on frozen stem + trunk + TCN features (HIP
+Linear / cross-entropy forward+backward kernels).  Training the encoder itself needs conv
+dgrad/wgrad + train-mode BN kernels: SURVEY.md section 8(f) rank 2, not built yet.
+``--device cpu`` runs the plumbing only (config -> model -> batches -> optimiser/scheduler ->
+checkpoint round trip) because the engine has no CPU arithmetic by design.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from deeplip_amd import weightgen as wg  # noqa: E402
+from models.video_models.model import Lipreading  # noqa: E402
+
+SEED = 1
+
+
+def load_args(argv=None):
+    p = argparse.ArgumentParser(description="Lipreading on the deeplip_amd engine")
+    p.add_argument("--dataset", default="lomgrid", help="dataset selection")
+    p.add_argument("--num-classes", type=int, default=54, help="Number of classes (database/lomgrid_54SpeakerLabel.txt)")
+    p.add_argument("--label-path", type=str, default=None, help="Path to txt file with labels")
+    p.add_argument("--backbone-type", type=str, default="resnet", choices=["resnet", "shufflenet"])
+    p.add_argument("--relu-type", type=str, default="prelu", choices=["relu", "prelu"])
+    p.add_argument("--width-mult", type=float, default=1.0)
+    p.add_argument("--lr", type=float, default=0.0003)
+    p.add_argument("--maxepoch", type=int, default=1)
+    p.add_argument("--tcn-kernel-size", type=int, nargs="+")
+    p.add_argument("--tcn-num-layers", type=int, default=4)
+    p.add_argument("--tcn-dropout", type=float, default=0.2)
+    p.add_argument("--tcn-dwpw", default=False, action="store_true")
+    p.add_argument("--tcn-width-mult", type=int, default=1)
+    p.add_argument("--batch-size", type=int, default=4)
+    p.add_argument("--model-path", type=str, default=None, help="Pretrained model pathname (bare state_dict)")
+    p.add_argument("--extract-feats", default=False, action="store_true")
+    p.add_argument("--mouth-patch-path", type=str, default=None)
+    p.add_argument("--mouth-embedding-out-path", type=str, default=None)
+    p.add_argument("--config-path", type=str, default=os.path.join(ROOT, "conf/video_config.json"))
+    p.add_argument("--display", type=int, default=1)
+    p.add_argument("--save-path", type=str, default="exp/video/epoch")
+    # build-owned
+    p.add_argument("--device", default="gpu", choices=["gpu", "cpu"])
+    p.add_argument("--steps", type=int, default=2, help="synthetic iterations per epoch")
+    p.add_argument("--frames", type=int, default=29)
+    p.add_argument("--rgb", action="store_true", help="feed uint8 RGB [B,T,3,88,88] through the ingest kernel")
+    return p.parse_args(argv)
+
+
+def load_json(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def get_model(args):
+    """train_video.py:173-190."""
+    j = load_json(args.config_path)
+    args.backbone_type, args.width_mult, args.relu_type = j["backbone_type"], j["width_mult"], j["relu_type"]
+    tcn_options = {"num_layers": j["tcn_num_layers"], "kernel_size": j["tcn_kernel_size"], "dropout": j["tcn_dropout"],
+                   "dwpw": j["tcn_dwpw"], "width_mult": j["tcn_width_mult"]}
+    return Lipreading(num_classes=args.num_classes, tcn_options=tcn_options, backbone_type=args.backbone_type,
+                      relu_type=args.relu_type, width_mult=args.width_mult, extract_feats=args.extract_feats)
+
+
+def pad_packed_collate(batch):
+    """dataset.py:123-139 semantics: sort by length (desc), zero-pad to the longest, lengths list."""
+    batch = sorted(batch, key=lambda x: x[0].shape[0], reverse=True)
+    lengths = [a.shape[0] for a, _ in batch]
+    data = np.zeros((len(batch), lengths[0]) + batch[0][0].shape[1:], dtype=batch[0][0].dtype)
+    for i, (a, _) in enumerate(batch):
+        data[i, :a.shape[0]] = a
+    return torch.from_numpy(data), lengths, torch.LongTensor([b for _, b in batch])
+
+
+def synthetic_batch(args, it, rgb=False):
+    r = np.random.Generator(np.random.PCG64([SEED, it]))
+    items = []
+    for i in range(args.batch_size):
+        spk = int(r.integers(args.num_classes))
+        T = args.frames if i == 0 else int(r.integers(max(2, args.frames // 3), args.frames + 1))
+        clip = wg.video_input(1, T, 88, key=f"tv.{it}.{i}", speakers=[spk])[0, 0]            # [T,88,88] normalised gray
+        if rgb:
+            g = np.clip((clip * 0.165 + 0.421) * 255.0, 0, 255).astype(np.uint8)
+            clip = np.repeat(g[:, None], 3, axis=1)                                            # [T,3,88,88] uint8
+        items.append((clip, spk))
+    return pad_packed_collate(items)
+
+
+def extract_feats(model, clip_thw, device):
+    """:99-106: model(FloatTensor(data)[None,None], lengths=[T]) with extract_feats=True."""
+    model.eval()
+    x = torch.as_tensor(clip_thw, dtype=torch.float32)[None, None].to(device)
+    return model(x, lengths=[x.shape[2]])
+
+
+def train(model, args, device):
+    from deeplip_amd import ops
+    for p in model.parameters():
+        p.requires_grad = False
+    head = model.tcn.tcn_output
+    for p in head.parameters():
+        p.requires_grad = True
+    optimizer = torch.optim.Adam(head.parameters(), lr=args.lr, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=5, eta_min=4e-08)
+    model.eval()                    # frozen encoder: running-stat BN (see module docstring)
+    last = None
+    for epoch in range(int(args.maxepoch)):
+        run_loss = run_ok = run_n = 0.0
+        for it in range(args.steps):
+            inputs, lengths, labels = synthetic_batch(args, epoch * args.steps + it, args.rgb)
+            if device.type == "cpu":
+                print(f"[plumbing] batch {tuple(inputs.shape)} lengths {lengths} labels {labels.tolist()} lr {sched.get_last_lr()}")
+                optimizer.step(); sched.step()
+                continue
+            labels = labels.to(device)
+            x = ops.ingest_rgb_u8(inputs.to(device)) if args.rgb else inputs.unsqueeze(1).to(device)   # :125
+            from deeplip_amd import autograd as ag
+            with torch.no_grad():
+                pooled = model.classifier_features(x, lengths)             # frozen stem + trunk + MS-TCN
+            optimizer.zero_grad()
+            logits = ag.linear(pooled, head.weight, head.bias)              # tcn_output (model.py:27)
+            loss = ag.margin_ce_loss(logits, labels, 1.0, 0.0)              # nn.CrossEntropyLoss (:112,138)
+            loss.backward()
+            optimizer.step()
+            sched.step()                                                    # per-iteration (:143)
+            _, pred = torch.max(torch.softmax(logits.detach(), 1), 1)       # (:145)
+            run_loss += float(loss.detach()) * len(labels); run_ok += float((pred == labels).sum()); run_n += len(labels)
+            last = (float(loss.detach()), tuple(logits.shape))
+            if it % args.display == 0:
+                print(f"epoch {epoch} it {it} loss {run_loss / run_n:.4f} acc {run_ok / run_n:.3f} lr {sched.get_last_lr()[0]:.2e}", flush=True)
+        os.makedirs(args.save_path, exist_ok=True)
+        torch.save(model.state_dict(), os.path.join(args.save_path, f"{epoch + 1}.pt"))      # (:169)
+    return last
+
+
+def main(argv=None):
+    args = load_args(argv)
+    torch.manual_seed(SEED); np.random.seed(SEED)
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))) if args.device == "gpu" else torch.device("cpu")
+    if args.device == "gpu" and not torch.cuda.is_available():
+        raise RuntimeError("no ROCm GPU visible: use --device cpu for the plumbing-only run")
+    model = get_model(args)
+    if args.model_path and os.path.exists(args.model_path):
+        model.load_state_dict(torch.load(args.model_path, map_location="cpu"))
+    else:
+        sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, prefix="video.")
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.to(device)
+    if args.extract_feats and args.mouth_patch_path:
+        out = extract_feats(model, np.load(args.mouth_patch_path)["data"], device)
+        if args.mouth_embedding_out_path:
+            np.savez(args.mouth_embedding_out_path, data=out.cpu().numpy())
+        return out
+    res = train(model, args, device)
+    # checkpoint round trip (bare state_dict, as the reference saves it)
+    ck = os.path.join(args.save_path, f"{int(args.maxepoch)}.pt")
+    model.load_state_dict(torch.load(ck, map_location="cpu"))
+    print("done:", res, "checkpoint", ck)
+    return res
+
+
+if __name__ == "__main__":
+    main()
