@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="A+V pairs per rank per step (configs[1]: 64)")
     ap.add_argument("--audio-dim", type=int, default=80, help="mel bins F of the [B,1,F,300] audio input")
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
+                    help="implicit-GEMM arithmetic: exact fp32 MFMA, or split fp16 pairs (3 f16 MFMAs per product)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     args = ap.parse_args()
@@ -177,7 +179,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    from deeplip_amd import ops, weightgen as wg
+    from deeplip_amd import ops, packing, weightgen as wg
+    packing.set_precision(args.precision)
     video, audio, sds = build_models(device, args.audio_dim)
     B = args.batch
     # per-rank shard of the synthetic utterance list (weak scaling: B pairs per rank)

@@ -80,7 +80,7 @@ class TDNN_Block(nn.Module):
 
     def run_ntc(self, x: Tensor, p: packing.Packed) -> Tensor:
         return ops.conv1d_ntc(x, p.w, p.b, dilation=self.dilation, pad=self.padding, slope=p.slope,
-                              post_scale=p.post_scale, post_shift=p.post_shift)
+                              post_scale=p.post_scale, post_shift=p.post_shift, w_scale=p.wscale)
 
     def forward(self, x: Tensor) -> Tensor:
         """[B,C,T] -> [B,K,T'] (reference layout, standalone use)."""
@@ -163,9 +163,9 @@ class SpeakerEmbNet(nn.Module):
             h = self.pooling(h)
         if taps is not None:
             taps["pooled"] = h
-        x_a = ops.linear(h, p["fc1"].w, p["fc1"].b)
+        x_a = ops.linear(h, p["fc1"].w, p["fc1"].b, w_scale=p["fc1"].wscale)
         h = ops.affine_act(x_a, p["bn1"][0], p["bn1"][1], LRELU, act_first=not self.bn_first)
-        xv = ops.linear(h, p["fc2"].w, p["fc2"].b)
+        xv = ops.linear(h, p["fc2"].w, p["fc2"].b, w_scale=p["fc2"].wscale)
         return xv, x_a
 
     def forward(self, x: Tensor) -> Tensor:

@@ -1,0 +1,103 @@
+// Shared between the fp32 and the split-fp16 implicit-GEMM convolution kernels (internal).
+#pragma once
+#include "dlip_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr int BK = 32;  // reduction slice: 32 channels of one filter tap
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* res;
+  const float* slope;
+  const float* pscale;
+  const float* pshift;
+  float* y;
+  int H, W, C, K, R, S;
+  int sh, sw, ph, pw, dh, dw;
+  int Wo, HoWo;
+  int ldx, ldy, ldr;
+  int M;
+  int tiles_n;
+  int cchunks;  // ceil(C / 32)
+  int nk;       // R * S * cchunks
+  int rsc;      // R * S * C  (weight row length)
+  uint32_t x_bytes, w_bytes, r_bytes, y_bytes;
+  const float* wscale;  // split-fp16 path: per-output-channel power-of-two weight scale (NULL otherwise)
+  int Cw;               // channels per tap in the PACKED weights (C, or C rounded up to 32)
+};
+
+
+// Validates a dlip_conv_desc and fills the kernel argument block.  `Cw` = channels per filter tap in
+// the packed weight tensor (== d->C for the fp32 layout).
+inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const float* w, const float* bias,
+                               const float* residual, const float* slope, const float* post_scale,
+                               const float* post_shift, float* y, int Cw, ConvArgs* out) {
+  DLIP_CHECK_ARG(d && x && w && y);
+  DLIP_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0);
+  DLIP_CHECK_ARG(d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0 && d->pad_h >= 0 && d->pad_w >= 0);
+  DLIP_CHECK_ARG((d->C & 3) == 0 && (d->ldx & 3) == 0 && d->ldx >= d->C && d->ldy >= d->K && Cw >= d->C);
+  DLIP_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0);
+  DLIP_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr));
+  DLIP_CHECK_ARG(residual == nullptr || d->ldr >= d->K);
+  const int Ho = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
+  const int Wo = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
+  DLIP_CHECK_ARG(Ho == d->Ho && Wo == d->Wo && Ho > 0 && Wo > 0);
+  DLIP_CHECK_ARG(d->R * d->S <= 32);  // per-row tap-validity mask is 32 bits
+
+  const long long in_pix = (long long)d->N * d->H * d->W;
+  const long long x_bytes = ((in_pix - 1) * d->ldx + d->C) * 4;
+  const long long w_bytes = (long long)d->K * d->R * d->S * Cw * 4;
+  const long long M = (long long)d->N * Ho * Wo;
+  const long long y_bytes = ((M - 1) * d->ldy + d->K) * 4;
+  const long long r_bytes = residual ? ((M - 1) * d->ldr + d->K) * 4 : 0;
+  if (x_bytes > DLIP_MAX_BUFFER_BYTES || w_bytes > DLIP_MAX_BUFFER_BYTES || y_bytes > DLIP_MAX_BUFFER_BYTES ||
+      r_bytes > DLIP_MAX_BUFFER_BYTES || M > 0x7FFFFFFFll)
+    return DLIP_ERANGE;
+
+  ConvArgs& a = *out;
+  a.x = x; a.w = w; a.bias = bias; a.res = residual; a.slope = slope;
+  a.pscale = post_scale; a.pshift = post_shift; a.y = y;
+  a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S;
+  a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+  a.Wo = Wo; a.HoWo = Ho * Wo;
+  a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr;
+  a.M = (int)M;
+  a.tiles_n = 0;
+  a.cchunks = (d->C + BK - 1) / BK;
+  a.nk = d->R * d->S * a.cchunks;
+  a.rsc = d->R * d->S * Cw;
+  a.x_bytes = (uint32_t)x_bytes; a.w_bytes = (uint32_t)w_bytes;
+  a.r_bytes = (uint32_t)r_bytes; a.y_bytes = (uint32_t)y_bytes;
+  a.wscale = nullptr;
+  a.Cw = Cw;
+  return DLIP_OK;
+}
+
+// Tile menu / picker shared by both kernels (see conv_igemm.hip for the rationale).
+struct TileCfg { int bm, bn; float eff; };
+constexpr int NUM_CFG = 5;
+const TileCfg kCfg[NUM_CFG] = {{128, 128, 0.90f}, {128, 64, 0.97f}, {64, 64, 0.93f}, {64, 128, 1.00f}, {96, 128, 0.97f}};
+
+inline int pick_tile(long long M, int K) {
+  if (const char* e = getenv("DLIP_CONV_TILE")) {  // development override (A/B runs)
+    const int v = atoi(e);
+    if (v >= 0 && v < NUM_CFG) return v;
+  }
+  int best = 0;
+  double best_cost = 1e300;
+  for (int i = 0; i < NUM_CFG; ++i) {
+    const TileCfg& c = kCfg[i];
+    const long long tiles = ((M + c.bm - 1) / c.bm) * ((K + c.bn - 1) / c.bn);
+    const long long rounds = (tiles + 255) / 256;  // one tile per CU per round
+    const double cost = (double)rounds * c.bm * c.bn / c.eff;
+    if (cost < best_cost * 0.999) { best_cost = cost; best = i; }
+  }
+  return best;
+}
+
+}  // namespace

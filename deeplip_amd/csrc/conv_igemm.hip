@@ -17,34 +17,10 @@
 // 2 x 128-B segments per wave instruction, branch-free (tails dropped by the buffer range check).
 //
 // Replaces the torch.nn layers listed against dlip_conv_nhwc_f32 in include/deeplip_hip.h.
-#include "dlip_common.h"
-#include <cstdlib>
-#include <type_traits>
+#include "conv_common.h"
 
 namespace {
 
-struct ConvArgs {
-  const float* x;
-  const float* w;
-  const float* bias;
-  const float* res;
-  const float* slope;
-  const float* pscale;
-  const float* pshift;
-  float* y;
-  int H, W, C, K, R, S;
-  int sh, sw, ph, pw, dh, dw;
-  int Wo, HoWo;
-  int ldx, ldy, ldr;
-  int M;
-  int tiles_n;
-  int cchunks;  // ceil(C / 32)
-  int nk;       // R * S * cchunks
-  int rsc;      // R * S * C  (weight row length)
-  uint32_t x_bytes, w_bytes, r_bytes, y_bytes;
-};
-
-constexpr int BK = 32;
 constexpr int LDK = BK;  // unpadded 128-B rows; bank conflicts are removed by an XOR swizzle of the 16-B chunks
 
 // ------------------------------------------------------------------------------------------
@@ -310,29 +286,6 @@ int launch(const ConvArgs& a, hipStream_t st) {
 // multiple of 32 -- used to fight tile quantisation: a launch takes ceil(tiles / 256 CUs) "rounds"
 // of one tile per CU, so for the short-M layers (layer3/4, TDNN) BM is chosen so the tile count
 // lands just under a multiple of 256.
-struct TileCfg { int bm, bn; float eff; };
-constexpr int NUM_CFG = 5;
-// eff = measured relative MFMA efficiency of a busy CU running this tile (tools/bench_layers.py,
-// MI355X, B=64): the 48-KiB-LDS tiles fit 3 workgroups per CU and win; 128x128 fits 2.
-const TileCfg kCfg[NUM_CFG] = {{128, 128, 0.90f}, {128, 64, 0.97f}, {64, 64, 0.93f}, {64, 128, 1.00f}, {96, 128, 0.97f}};
-
-int pick_tile(long long M, int K) {
-  if (const char* e = getenv("DLIP_CONV_TILE")) {  // development override (A/B runs)
-    const int v = atoi(e);
-    if (v >= 0 && v < NUM_CFG) return v;
-  }
-  int best = 0;
-  double best_cost = 1e300;
-  for (int i = 0; i < NUM_CFG; ++i) {
-    const TileCfg& c = kCfg[i];
-    const long long tiles = ((M + c.bm - 1) / c.bm) * ((K + c.bn - 1) / c.bn);
-    const long long rounds = (tiles + 255) / 256;  // one tile per CU per round
-    const double cost = (double)rounds * c.bm * c.bn / c.eff;
-    if (cost < best_cost * 0.999) { best_cost = cost; best = i; }
-  }
-  return best;
-}
-
 int launch_cfg(int cfg, const ConvArgs& a, hipStream_t st) {
   switch (cfg) {
     case 0: return launch<128, 128, 2, 2>(a, st);
@@ -349,43 +302,10 @@ extern "C" int dlip_conv_nhwc_f32(const dlip_conv_desc* d, const float* x, const
                                   const float* bias, const float* residual, const float* slope,
                                   const float* post_scale, const float* post_shift, float* y,
                                   dlip_stream_t stream) {
-  DLIP_CHECK_ARG(d && x && w_krsc && y);
-  DLIP_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0);
-  DLIP_CHECK_ARG(d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0 && d->pad_h >= 0 && d->pad_w >= 0);
-  DLIP_CHECK_ARG((d->C & 3) == 0 && (d->ldx & 3) == 0 && d->ldx >= d->C && d->ldy >= d->K);
-  DLIP_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_krsc) & 15) == 0);
-  DLIP_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr));
-  DLIP_CHECK_ARG(residual == nullptr || d->ldr >= d->K);
-  const int Ho = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
-  const int Wo = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
-  DLIP_CHECK_ARG(Ho == d->Ho && Wo == d->Wo && Ho > 0 && Wo > 0);
-  DLIP_CHECK_ARG(d->R * d->S <= 32);  // per-row tap-validity mask is 32 bits
-
-  const long long in_pix = (long long)d->N * d->H * d->W;
-  const long long x_bytes = ((in_pix - 1) * d->ldx + d->C) * 4;
-  const long long w_bytes = (long long)d->K * d->R * d->S * d->C * 4;
-  const long long M = (long long)d->N * Ho * Wo;
-  const long long y_bytes = ((M - 1) * d->ldy + d->K) * 4;
-  const long long r_bytes = residual ? ((M - 1) * d->ldr + d->K) * 4 : 0;
-  if (x_bytes > DLIP_MAX_BUFFER_BYTES || w_bytes > DLIP_MAX_BUFFER_BYTES || y_bytes > DLIP_MAX_BUFFER_BYTES ||
-      r_bytes > DLIP_MAX_BUFFER_BYTES || M > 0x7FFFFFFFll)
-    return DLIP_ERANGE;
-
   ConvArgs a;
-  a.x = x; a.w = w_krsc; a.bias = bias; a.res = residual; a.slope = slope;
-  a.pscale = post_scale; a.pshift = post_shift; a.y = y;
-  a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K; a.R = d->R; a.S = d->S;
-  a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
-  a.Wo = Wo; a.HoWo = Ho * Wo;
-  a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr;
-  a.M = (int)M;
-  a.tiles_n = 0;
-  a.cchunks = (d->C + BK - 1) / BK;
-  a.nk = d->R * d->S * a.cchunks;
-  a.rsc = d->R * d->S * d->C;
-  a.x_bytes = (uint32_t)x_bytes; a.w_bytes = (uint32_t)w_bytes;
-  a.r_bytes = (uint32_t)r_bytes; a.y_bytes = (uint32_t)y_bytes;
-
+  const int rc = dlip_fill_conv_args(d, x, w_krsc, bias, residual, slope, post_scale, post_shift, y, d ? d->C : 0, &a);
+  if (rc != DLIP_OK) return rc;
+  const long long M = a.M;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return launch_cfg(pick_tile(M, d->K), a, st);
 }

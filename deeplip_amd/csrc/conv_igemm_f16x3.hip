@@ -1,0 +1,310 @@
+// Split-precision implicit-GEMM convolution: fp32 operands carried as (hi, lo) fp16 pairs and
+// multiplied on the 16x faster f16 matrix core with THREE v_mfma_f32_32x32x16_f16 per product
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate).  hi has 11 significant bits and lo the next 11, so
+// x ~ hi + lo to ~2^-22, each fp16 x fp16 product is exact in the fp32 accumulator, and only the
+// lo*lo term (~2^-22 relative) is dropped: fp32-grade results (measured parity in tests /
+// bench) at up to 5.3x the fp32-MFMA rate.  Same GEMM view, tiling, swizzled two-stage LDS,
+// two-slice register prefetch and MFMA-shadow program order as conv_igemm.hip; differences:
+//   * weights are pre-split on the host (deeplip_amd/packing.py): per 32-channel slice of a tap the
+//     packed row holds [hi k0..31 | lo k0..31] fp16 (= 128 B, same bytes as fp32), scaled per output
+//     channel by a power of two so lo stays a NORMAL fp16 (the scale is undone exactly in the
+//     epilogue);
+//   * activations stay fp32 in HBM; each thread splits its float4 of a slice row in registers
+//     (cvt / sub / cvt, packed) and writes hi and lo with two ds_write_b64 into the same
+//     XOR-swizzled 128-B LDS row: chunks 0-3 = hi(k 0-7, 8-15, 16-23, 24-31), chunks 4-7 = lo;
+//   * a k16 step reads 4 fragments (a_hi, a_lo, b_hi, b_lo; lanes 0-31 take k 0-7, lanes 32-63 take
+//     k 8-15 of the step) and issues 3 MFMAs per 32x32 tile.
+// Replaces the same reference layers as dlip_conv_nhwc_f32 (include/deeplip_hip.h).
+#include "conv_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int LDK = BK;  // 32 dwords = 128 B per LDS row: 64 B of hi + 64 B of lo
+
+// float4 -> 4 hi halves, 4 lo halves
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 h = (_Float16)v[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(v[i] - (float)h);
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_f16x3_kernel(const ConvArgs a) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int A_PER = BM / 32, B_PER = BN / 32;
+  constexpr int STAGE = (BM + BN) * LDK;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_n = swz % a.tiles_n;
+  const int tile_m = swz / a.tiles_n;
+
+  const int tid = threadIdx.x;
+  const int cq = tid & 7;          // which float4 (4 channels) of the 32-channel slice row
+  const int cc = cq * 4;
+  const int rbase = tid >> 3;
+  const __amdgpu_buffer_rsrc_t xr = dlip_make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = dlip_make_rsrc(a.w, a.w_bytes);
+
+  int a_off[A_PER];
+  uint32_t a_mask[A_PER];
+#pragma unroll
+  for (int j = 0; j < A_PER; ++j) {
+    const int m = tile_m * BM + rbase + 32 * j;
+    a_off[j] = 0;
+    a_mask[j] = 0u;
+    if (m < a.M) {
+      const int n = m / a.HoWo;
+      const int rem = m - n * a.HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+      a_off[j] = (((n * a.H + hi0) * a.W + wi0) * a.ldx + cc) * 4;
+      uint32_t mk = 0u;
+      for (int r = 0; r < a.R; ++r)
+        for (int s = 0; s < a.S; ++s)
+          if ((unsigned)(hi0 + r * a.dh) < (unsigned)a.H && (unsigned)(wi0 + s * a.dw) < (unsigned)a.W)
+            mk |= 1u << (r * a.S + s);
+      a_mask[j] = mk;
+    }
+  }
+  int b_off[B_PER];
+#pragma unroll
+  for (int j = 0; j < B_PER; ++j) {
+    const int n = tile_n * BN + rbase + 32 * j;
+    b_off[j] = n < a.K ? (n * a.rsc + cc) * 4 : -1;   // packed weight rows: 16-B chunk cq of the slice
+  }
+
+  f32x4 ra[2][A_PER], rb[2][B_PER];
+  int tap = 0, x_tap = 0, w_tap = 0, c0 = 0;
+  auto load_a = [&](auto SETC, int j0, int j1) {
+    constexpr int SET = decltype(SETC)::value;
+    const bool cok = (c0 + cc) < a.C;
+#pragma unroll
+    for (int j = j0; j < j1; ++j) {
+      const bool ok = cok && ((a_mask[j] >> tap) & 1u);
+      ra[SET][j] = dlip_buffer_load_f4(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET);
+    }
+  };
+  auto load_b = [&](auto SETC) {
+    constexpr int SET = decltype(SETC)::value;
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j)
+      rb[SET][j] = dlip_buffer_load_f4(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET);
+  };
+
+  // LDS row = 8 chunks of 16 B, chunk p stored at p ^ ((row >> 1) & 7) (conv_igemm.hip).
+  const int key_st = (rbase >> 1) & 7;
+  // A: this thread's 4 channels go to hi chunk cq/2 and lo chunk 4 + cq/2, 8-B half cq & 1.
+  const int a_hi_off = rbase * LDK + ((((cq >> 1)) ^ key_st) << 2) + ((cq & 1) << 1);
+  const int a_lo_off = rbase * LDK + ((((cq >> 1) + 4) ^ key_st) << 2) + ((cq & 1) << 1);
+  const int b_st_off = rbase * LDK + ((cq ^ key_st) << 2);   // B rows arrive already in chunk order
+  auto store_a = [&](auto SETC, int stage) {
+    constexpr int SET = decltype(SETC)::value;
+    float* As = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+      f16x4 hi, lo;
+      split4(ra[SET][j], hi, lo);
+      *reinterpret_cast<f16x4*>(&As[a_hi_off + 32 * j * LDK]) = hi;
+      *reinterpret_cast<f16x4*>(&As[a_lo_off + 32 * j * LDK]) = lo;
+    }
+  };
+  auto store_b = [&](auto SETC, int stage) {
+    constexpr int SET = decltype(SETC)::value;
+    float* Bs = smem + stage * STAGE + BM * LDK + b_st_off;
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) *reinterpret_cast<f32x4*>(&Bs[32 * j * LDK]) = rb[SET][j];
+  };
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lrow = lane & 31, half = lane >> 5;
+  const int a_frag = (wm * WM + lrow) * LDK;
+  const int b_frag = BM * LDK + (wn * WN + lrow) * LDK;
+  const int rquad = half * 4;
+  const int key_rd = (lrow >> 1) & 7;
+  int khi[2], klo[2];   // swizzled dword offsets of this lane's hi / lo chunk for k16 step s
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    khi[s] = ((2 * s + half) ^ key_rd) << 2;
+    klo[s] = ((4 + 2 * s + half) ^ key_rd) << 2;
+  }
+
+  // accumulators = (bias + residual) * wscale[k]   (the weight scale is undone in the epilogue)
+  const __amdgpu_buffer_rsrc_t rr = dlip_make_rsrc(a.res, a.res ? a.r_bytes : 0u);
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int k = tile_n * BN + wn * WN + ni * 32 + lrow;
+    const bool kok = k < a.K;
+    const float bias = (kok && a.bias) ? a.bias[k] : 0.f;
+    const float ws = kok ? a.wscale[k] : 1.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m0 = tile_m * BM + wm * WM + mi * 32 + rquad;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (e & 3) + 8 * (e >> 2);
+        const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldr + k) * 4) : DLIP_OOB_OFFSET;
+        acc[mi][ni][e] = (bias + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)off, 0, 0))) * ws;
+      }
+    }
+  }
+
+  int s_pos = 0, x_row = 0;
+  const int x_dr = a.dh * a.W * a.ldx * 4, x_ds = a.dw * a.ldx * 4;
+  auto advance = [&]() {
+    c0 += BK;
+    if (c0 >= a.C) {
+      c0 = 0;
+      ++tap;
+      if (++s_pos == a.S) { s_pos = 0; x_row += x_dr; }
+    }
+    x_tap = x_row + s_pos * x_ds + c0 * 4;
+    w_tap = (tap * a.Cw + c0) * 4;
+  };
+
+  f16x8 fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];
+  auto read_frags = [&](int set, int stage, int s) {
+    const float* Aw = smem + stage * STAGE + a_frag;
+    const float* Bw = smem + stage * STAGE + b_frag;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      fah[set][mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 32 * LDK + khi[s]);
+      fal[set][mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 32 * LDK + klo[s]);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      fbh[set][ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 32 * LDK + khi[s]);
+      fbl[set][ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 32 * LDK + klo[s]);
+    }
+  };
+  // g = 0: lo*hi, 1: hi*lo, 2: hi*hi  (small terms first)
+  auto mfma_g = [&](int set, int g) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const f16x8 av = g == 0 ? fal[set][mi] : fah[set][mi];
+        const f16x8 bv = g == 1 ? fbl[set][ni] : fbh[set][ni];
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[mi][ni], 0, 0, 0);
+      }
+  };
+#define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  load_a(Set0{}, 0, A_PER);
+  load_b(Set0{});
+  if (a.nk > 1) {
+    advance();
+    load_a(Set1{}, 0, A_PER);
+    load_b(Set1{});
+  }
+  store_a(Set0{}, 0);
+  store_b(Set0{}, 0);
+  __syncthreads();
+  read_frags(0, 0, 0);
+
+  // One 32-channel slice = two k16 steps x three MFMA groups.  Non-MFMA work sits between groups.
+  auto slice = [&](auto LD, auto ST, int kt) {
+    const bool more1 = (kt + 1) < a.nk, more2 = (kt + 2) < a.nk;
+    const int cur = kt & 1;
+    // ---- k16 step 0 (fragment set 0) ----
+    mfma_g(0, 0); DLIP_FENCE();
+    read_frags(1, cur, 1); DLIP_FENCE();
+    mfma_g(0, 1); DLIP_FENCE();
+    if (more2) { advance(); load_a(LD, 0, A_PER); } DLIP_FENCE();
+    mfma_g(0, 2); DLIP_FENCE();
+    if (more2) load_b(LD); DLIP_FENCE();
+    // ---- k16 step 1 (fragment set 1) ----
+    mfma_g(1, 0); DLIP_FENCE();
+    if (more1) store_a(ST, cur ^ 1); DLIP_FENCE();
+    mfma_g(1, 1); DLIP_FENCE();
+    if (more1) store_b(ST, cur ^ 1);
+    __syncthreads();
+    if (more1) read_frags(0, cur ^ 1, 0); DLIP_FENCE();
+    mfma_g(1, 2); DLIP_FENCE();
+  };
+  for (int kt = 0; kt < a.nk; kt += 2) {
+    slice(Set0{}, Set1{}, kt);
+    if (kt + 1 < a.nk) slice(Set1{}, Set0{}, kt + 1);
+  }
+#undef DLIP_FENCE
+
+  const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int k = tile_n * BN + wn * WN + ni * 32 + lrow;
+    const bool kok = k < a.K;
+    const float inv = kok ? 1.f / a.wscale[k] : 1.f;   // power of two: exact
+    const float slope = (kok && a.slope) ? a.slope[k] : 1.f;
+    const float psc = (kok && a.pscale) ? a.pscale[k] : 1.f;
+    const float psh = (kok && a.pshift) ? a.pshift[k] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m0 = tile_m * BM + wm * WM + mi * 32 + rquad;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (e & 3) + 8 * (e >> 2);
+        float v = acc[mi][ni][e] * inv;
+        v = v >= 0.f ? v : v * slope;
+        v = v * psc + psh;
+        const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + k) * 4) : DLIP_OOB_OFFSET;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)off, 0, 0);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(const ConvArgs& a, hipStream_t st) {
+  ConvArgs b = a;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  b.tiles_n = (a.K + BN - 1) / BN;
+  const long long grid = (long long)tiles_m * b.tiles_n;
+  if (grid <= 0 || grid > 0x7FFFFFFFll) return DLIP_EINVAL;
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * LDK * sizeof(float);
+  auto kern = conv_igemm_f16x3_kernel<BM, BN, WAVES_M, WAVES_N>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b);
+  return dlip_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split,
+                                    const float* w_scale, const float* bias, const float* residual,
+                                    const float* slope, const float* post_scale, const float* post_shift,
+                                    float* y, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(d && w_scale);
+  const int Cw = (d->C + 31) / 32 * 32;
+  ConvArgs a;
+  const int rc = dlip_fill_conv_args(d, x, static_cast<const float*>(w_split), bias, residual, slope, post_scale,
+                                     post_shift, y, Cw, &a);
+  if (rc != DLIP_OK) return rc;
+  a.wscale = w_scale;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (pick_tile(a.M, d->K)) {
+    case 0: return launch<128, 128, 2, 2>(a, st);
+    case 1: return launch<128, 64, 2, 2>(a, st);
+    case 2: return launch<64, 64, 2, 2>(a, st);
+    case 3: return launch<64, 128, 1, 4>(a, st);
+    default: return launch<96, 128, 1, 4>(a, st);
+  }
+}

@@ -36,10 +36,10 @@ class Linearfusion(nn.Module):
             x1 = ag.bn_act_train(ag.linear(x, self.fc1.weight, self.fc1.bias), self.bn1, 0.2)
             return x1 if self.extract_feats else ag.linear(x1, self.fc2.weight, self.fc2.bias)
         p = _cached_pack(self, x.device, self._pack)
-        x1 = ops.linear(x.contiguous(), p["fc1"].w, p["fc1"].b, slope=p["fc1"].slope)  # fc1+bn1+lrelu fused
+        x1 = ops.linear(x.contiguous(), p["fc1"].w, p["fc1"].b, slope=p["fc1"].slope, w_scale=p["fc1"].wscale)  # fc1+bn1+lrelu fused
         if self.extract_feats:
             return x1
-        return ops.linear(x1, p["fc2"].w, p["fc2"].b)
+        return ops.linear(x1, p["fc2"].w, p["fc2"].b, w_scale=p["fc2"].wscale)
 
 
 def model_fusion(input_size, hidden_size, num_classes, extract_feats):

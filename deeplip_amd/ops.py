@@ -40,16 +40,26 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
               dil=(1, 1), residual: Optional[Tensor] = None, slope: Optional[Tensor] = None,
               post_scale: Optional[Tensor] = None, post_shift: Optional[Tensor] = None,
               out: Optional[Tensor] = None, out_channel_offset: int = 0,
-              in_channels: Optional[int] = None, in_channel_offset: int = 0) -> Tensor:
+              in_channels: Optional[int] = None, in_channel_offset: int = 0,
+              w_scale: Optional[Tensor] = None) -> Tensor:
     """x [N,H,W,Cx] (NHWC), w [K,R,S,C] -> y [N,Ho,Wo,Ky].
 
     ``out`` / ``out_channel_offset`` write the K result channels into a slice of a wider tensor
-    (concat-free multibranch blocks); ``in_channels`` / ``in_channel_offset`` read a slice."""
+    (concat-free multibranch blocks); ``in_channels`` / ``in_channel_offset`` read a slice.
+    With ``w_scale`` given, ``w_krsc`` is the split (hi, lo) fp16 packing of packing.split_weights
+    ([K,R,S,C32] float32 view) and the launch goes to the 3 x f16-MFMA kernel."""
     for t, n in ((x, "x"), (w_krsc, "w"), (bias, "bias"), (residual, "residual"), (slope, "slope"),
                  (post_scale, "post_scale"), (post_shift, "post_shift"), (out, "out")):
         _req(t, n)
+    _req(w_scale, "w_scale")
     N, H, W, Cx = x.shape
     K, R, S, Cw = w_krsc.shape
+    if w_scale is not None:        # split weights are channel-padded to a multiple of 32
+        if in_channels is None:
+            in_channels = min(Cx - in_channel_offset, Cw)
+        if (in_channels + 31) // 32 * 32 != Cw:
+            raise ValueError(f"conv_nhwc: split weights have C32={Cw}, input slice has {in_channels} channels")
+        Cw = in_channels
     Cin = Cw if in_channels is None else in_channels
     if Cin != Cw or in_channel_offset + Cin > Cx:
         raise ValueError(f"conv_nhwc: weight C={Cw} does not match input slice [{in_channel_offset}:+{Cin}] of {Cx}")
@@ -73,9 +83,15 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
     if hook is not None:
         bm, bn = C.c_int32(), C.c_int32()
         check(lib().dlip_conv_plan(C.byref(d), C.byref(bm), C.byref(bn)), "dlip_conv_plan")
-        tok = hook.begin(f"conv_igemm_f32_kernel<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
-    check(lib().dlip_conv_nhwc_f32(C.byref(d), xp, ptr(w_krsc), ptr(bias), ptr(residual), ptr(slope),
-                                   ptr(post_scale), ptr(post_shift), yp, stream_handle()), "dlip_conv_nhwc_f32")
+        kname = "conv_igemm_f16x3_kernel" if w_scale is not None else "conv_igemm_f32_kernel"
+        tok = hook.begin(f"{kname}<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
+    if w_scale is not None:
+        check(lib().dlip_conv_nhwc_f16x3(C.byref(d), xp, ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(residual),
+                                         ptr(slope), ptr(post_scale), ptr(post_shift), yp, stream_handle()),
+              "dlip_conv_nhwc_f16x3")
+    else:
+        check(lib().dlip_conv_nhwc_f32(C.byref(d), xp, ptr(w_krsc), ptr(bias), ptr(residual), ptr(slope),
+                                       ptr(post_scale), ptr(post_shift), yp, stream_handle()), "dlip_conv_nhwc_f32")
     if hook is not None:
         hook.end(tok)
     return out

@@ -13,13 +13,27 @@ from .holders import BatchNormParams
 Tensor = torch.Tensor
 
 
+# Arithmetic mode of the implicit-GEMM kernels for weights packed from now on:
+#   "f32"   exact fp32 MFMA (default; bit-reproducible fma chains)
+#   "f16x3" split (hi, lo) fp16 operands, 3 f16 MFMAs per product, fp32 accumulate (~2^-22 relative)
+PRECISION = "f32"
+
+
+def set_precision(mode: str) -> None:
+    global PRECISION
+    if mode not in ("f32", "f16x3"):
+        raise ValueError(mode)
+    PRECISION = mode
+
+
 @dataclass
 class Packed:
-    w: Tensor                      # kernel-layout weights (device, fp32)
+    w: Tensor                      # kernel-layout weights (device): fp32 KRSC, or split fp16 pairs
     b: Optional[Tensor] = None     # folded bias
     slope: Optional[Tensor] = None  # per-channel negative slope (PReLU weight / 0.2 / 0)
     post_scale: Optional[Tensor] = None
     post_shift: Optional[Tensor] = None
+    wscale: Optional[Tensor] = None  # f16x3 only: per-output-channel power-of-two weight scale
 
 
 def bn_scale_shift(bn: BatchNormParams):
@@ -47,6 +61,38 @@ def _dev(t: Tensor, device) -> Tensor:
     return t.to(dtype=torch.float32).contiguous().to(device)
 
 
+def split_weights(w: Tensor):
+    """fp64 [K, ..., C] (channels last) -> (float32 view [K, ..., C32] of (hi, lo) fp16 pairs, scale [K]).
+
+    Per output channel k the weights are multiplied by 2^e_k so that max|w_k| lands in [512, 1024):
+    hi = fp16(w) keeps 11 bits and lo = fp16(w - hi) stays a NORMAL fp16 for every weight down to
+    ~1e-4 of the channel maximum (unscaled, lo of a 0.03 weight would be subnormal and lose bits).
+    Layout per 32-channel block: 32 hi halves then 32 lo halves (128 B, as one fp32 block)."""
+    K, C = w.shape[0], w.shape[-1]
+    C32 = (C + 31) // 32 * 32
+    flat = w.reshape(K, -1)
+    amax = flat.abs().amax(dim=1).clamp_min(1e-30)
+    scale = torch.pow(2.0, torch.floor(torch.log2(1023.0 / amax))).to(torch.float64)
+    ws = w * scale.view(K, *([1] * (w.dim() - 1)))
+    if C32 != C:
+        pad = torch.zeros(*w.shape[:-1], C32 - C, dtype=torch.float64)
+        ws = torch.cat([ws, pad], dim=-1)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.to(torch.float64)).to(torch.float16)
+    lead = ws.shape[:-1]
+    blk = torch.stack([hi.reshape(*lead, C32 // 32, 32), lo.reshape(*lead, C32 // 32, 32)], dim=-2)  # [..., nb, 2, 32]
+    packed = blk.contiguous().view(torch.float32).reshape(*lead, C32)       # 64 halves = 32 dwords per block
+    return packed, scale.to(torch.float32)
+
+
+def _finish(w64: Tensor, b64: Tensor, device, slope) -> "Packed":
+    """w64: fp64 weights already in kernel layout [K, (R, S,) C]."""
+    if PRECISION == "f16x3":
+        ws, sc = split_weights(w64)
+        return Packed(ws.contiguous().to(device), _dev(b64, device), slope, wscale=sc.to(device))
+    return Packed(_dev(w64, device), _dev(b64, device), slope)
+
+
 def pad_channels(c: int, mult: int = 4) -> int:
     return (c + mult - 1) // mult * mult
 
@@ -54,7 +100,7 @@ def pad_channels(c: int, mult: int = 4) -> int:
 def pack_conv2d(weight, bias, bn, device, slope=None) -> Packed:
     """[K,C,R,S] -> KRSC."""
     w, b = fold(weight, bias, bn)
-    return Packed(_dev(w.permute(0, 2, 3, 1), device), _dev(b, device), slope)
+    return _finish(w.permute(0, 2, 3, 1).contiguous(), b, device, slope)
 
 
 def pack_conv1d(weight, bias, bn, device, slope=None, cin_pad: Optional[int] = None) -> Packed:
@@ -65,12 +111,12 @@ def pack_conv1d(weight, bias, bn, device, slope=None, cin_pad: Optional[int] = N
         wp = torch.zeros(w.shape[0], w.shape[1], cin_pad, dtype=torch.float64)
         wp[:, :, :w.shape[2]] = w
         w = wp
-    return Packed(_dev(w, device), _dev(b, device), slope)
+    return _finish(w.contiguous(), b, device, slope)
 
 
 def pack_linear(weight, bias, bn, device, slope=None) -> Packed:
     w, b = fold(weight, bias, bn)
-    return Packed(_dev(w, device), _dev(b, device), slope)
+    return _finish(w.contiguous(), b, device, slope)
 
 
 def pack_stem3d(weight, bn, device, slope=None) -> Packed:
@@ -88,7 +134,7 @@ def const_slope(k: int, value: float, device) -> Tensor:
 
 def state_version(module: torch.nn.Module, device) -> tuple:
     """Cheap fingerprint that changes on load_state_dict / in-place updates / device moves."""
-    v = [str(device)]
+    v = [str(device), PRECISION]
     for t in list(module.parameters()) + list(module.buffers()):
         v.append((t._version, t.data_ptr()))
     return tuple(v)

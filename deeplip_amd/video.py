@@ -89,9 +89,9 @@ class BasicBlock(nn.Module):
     def run(self, x: Tensor, p: Dict[str, packing.Packed]) -> Tensor:
         """x NHWC.  conv1+bn1+relu1 | (1x1 s2 conv + bn) | conv2+bn2 + residual + relu2."""
         s = (self.stride, self.stride)
-        h = ops.conv_nhwc(x, p["conv1"].w, p["conv1"].b, stride=s, pad=(1, 1), slope=p["conv1"].slope)
-        res = ops.conv_nhwc(x, p["down"].w, p["down"].b, stride=s) if "down" in p else x
-        return ops.conv_nhwc(h, p["conv2"].w, p["conv2"].b, pad=(1, 1), residual=res, slope=p["conv2"].slope)
+        h = ops.conv_nhwc(x, p["conv1"].w, p["conv1"].b, stride=s, pad=(1, 1), slope=p["conv1"].slope, w_scale=p["conv1"].wscale)
+        res = ops.conv_nhwc(x, p["down"].w, p["down"].b, stride=s, w_scale=p["down"].wscale) if "down" in p else x
+        return ops.conv_nhwc(h, p["conv2"].w, p["conv2"].b, pad=(1, 1), residual=res, slope=p["conv2"].slope, w_scale=p["conv2"].wscale)
 
 
 class ResNet(nn.Module):
@@ -226,10 +226,10 @@ class MultibranchTemporalBlock(nn.Module):
             for j, k in enumerate(self.kernel_sizes):
                 pk = p[f"cbcr{s}_{j}"]
                 ops.conv1d_ntc(cur, pk.w, pk.b, dilation=self.dilation, pad=(k - 1) * self.dilation // 2,
-                               slope=pk.slope, out=out, out_channel_offset=j * nb)
+                               slope=pk.slope, out=out, out_channel_offset=j * nb, w_scale=pk.wscale)
             cur = out  # dropout: identity in eval
         if self.downsample is not None:
-            return ops.conv1d_ntc(x, p["down"].w, p["down"].b, residual=cur, slope=p["final_slope"])
+            return ops.conv1d_ntc(x, p["down"].w, p["down"].b, residual=cur, slope=p["final_slope"], w_scale=p["down"].wscale)
         raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
 
 
@@ -273,7 +273,7 @@ class MultiscaleMultibranchTCN(nn.Module):
         return ops.time_mean(x, ln)
 
     def run(self, x: Tensor, lengths, p) -> Tensor:
-        return ops.linear(self.pooled(x, lengths, p), p["out"].w, p["out"].b)   # tcn_output, model.py:27,37
+        return ops.linear(self.pooled(x, lengths, p), p["out"].w, p["out"].b, w_scale=p["out"].wscale)   # tcn_output, model.py:27,37
 
     def forward(self, x, lengths, B):
         _require_eval(self)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 2
+#define DLIP_ABI_VERSION 3
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -71,6 +71,17 @@ int dlip_conv_nhwc_f32(const dlip_conv_desc* d, const float* x, const float* w_k
                        const float* bias, const float* residual, const float* slope,
                        const float* post_scale, const float* post_shift, float* y,
                        dlip_stream_t stream);
+
+/* Split-precision variant of dlip_conv_nhwc_f32: same operation, fp32 in / fp32 out, but every
+ * product is evaluated as hi*hi + hi*lo + lo*hi on the f16 matrix core (3 x v_mfma_f32_32x32x16_f16,
+ * fp32 accumulate; ~2^-22 relative, see conv_igemm_f16x3.hip).  `w_split` = weights pre-split by the
+ * host into (hi, lo) fp16: [K][R][S][C32/32][2][32] halves with C32 = C rounded up to 32 (zero
+ * filled), each output channel k pre-multiplied by the power of two `w_scale[k]` (undone exactly in
+ * the epilogue).  x, bias, residual, y are plain fp32 as in dlip_conv_nhwc_f32. */
+int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split,
+                         const float* w_scale, const float* bias, const float* residual,
+                         const float* slope, const float* post_scale, const float* post_shift,
+                         float* y, dlip_stream_t stream);
 
 /* Reports the workgroup tile (BM x BN) dlip_conv_nhwc_f32 will use for `d` -- i.e. which
  * conv_igemm_f32_kernel<BM,BN,..> instance a profiler will show.  Host-only, no launch. */

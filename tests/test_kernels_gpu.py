@@ -279,3 +279,44 @@ def test_trial_scoring_full_size_properties(ops):
     assert np.abs(s[sel] - ref).max() < 1e-6
     bad = ops.pair_cosine(dev, torch.tensor([N], dtype=torch.int32).cuda(), torch.tensor([0], dtype=torch.int32).cuda())
     assert np.isnan(float(bad.cpu()[0]))                               # out-of-table index -> NaN, not a fault
+
+
+F16X3_CASES = [c for c in CONV_CASES if c[0] <= 300]
+
+
+@pytest.mark.parametrize("case", F16X3_CASES, ids=lambda c: "x".join(str(v) for v in c[:10]))
+def test_conv_nhwc_f16x3(ops, case):
+    """Split-fp16 (3 x f16 MFMA) implicit GEMM: same op, same fp32 I/O; tolerance 2e-5 like the fp32 kernel
+    (error budget: dropped lo*lo terms ~2^-22 + fp32 accumulation)."""
+    from deeplip_amd import packing
+    N, H, W, C, K, R, S, stride, pad, dil, use_res, use_slope = case
+    x = rnd(N, C, H, W, seed=1) * 3.0          # activations up to ~12
+    w = rnd(K, C, R, S, seed=2, scale=1.0 / np.sqrt(C * R * S))
+    b = rnd(K, seed=3, scale=0.1)
+    sh, sw = (1, stride) if H == 1 else (stride, stride)
+    ph, pw = (0, pad) if H == 1 else (pad, pad)
+    dh, dw = (1, dil) if H == 1 else (dil, dil)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=(sh, sw), padding=(ph, pw), dilation=(dh, dw))
+    res = rnd(*ref.shape, seed=4) if use_res else None
+    slope = torch.rand(K, generator=torch.Generator().manual_seed(5)) * 0.3 if use_slope else None
+    if res is not None:
+        ref = ref + res.double()
+    if slope is not None:
+        ref = F.prelu(ref, slope.double())
+    ws, sc = packing.split_weights(w.permute(0, 2, 3, 1).contiguous().double())
+    y = ops.conv_nhwc(nhwc(x).cuda(), ws.cuda(), b.cuda(), stride=(sh, sw), pad=(ph, pw), dil=(dh, dw),
+                      residual=nhwc(res).cuda() if res is not None else None,
+                      slope=slope.cuda() if slope is not None else None, w_scale=sc.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+
+
+def test_split_weights_roundtrip():
+    from deeplip_amd import packing
+    w = torch.randn(7, 3, 3, 40, dtype=torch.float64) * torch.logspace(-4, 0, 7, dtype=torch.float64).view(7, 1, 1, 1)
+    ws, sc = packing.split_weights(w)
+    assert ws.shape == (7, 3, 3, 64) and ws.dtype == torch.float32
+    h = ws.view(torch.float16).reshape(7, 3, 3, 2, 2, 32).double()       # [.., block, hi/lo, 32]
+    rec = (h[..., 0, :] + h[..., 1, :]).reshape(7, 3, 3, 64)[..., :40] / sc.double().view(7, 1, 1, 1)
+    assert float(((rec - w).abs() / w.abs().clamp_min(1e-30)).max()) < 2.0 ** -20
+    assert float(((rec - w).abs().amax(dim=(1, 2, 3)) / w.abs().amax(dim=(1, 2, 3))).max()) < 2.0 ** -21

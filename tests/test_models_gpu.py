@@ -179,7 +179,8 @@ def test_heads_golden(golden):
     emb = torch.from_numpy(wg.gen("input.emb", (32, 512))).to(DEV)
     lab = torch.from_numpy(wg.labels(32, 57)).to(DEV)
     crit, _ = load(LMCL(512, 57, 30, 0.2), "lmcl.")
-    loss, logits = crit(emb, lab)
+    with torch.no_grad():                      # inference path (grad-enabled forward is covered by test_train_gpu)
+        loss, logits = crit(emb, lab)
     _, _, amax = crit.predict(emb)
     assert rel_err(logits.cpu().numpy(), g["lmcl_logits"]) < TOL
     assert abs(float(loss) - float(g["lmcl_loss"])) < TOL * float(g["lmcl_loss"])
@@ -187,7 +188,8 @@ def test_heads_golden(golden):
     assert amax.dtype == torch.int64
     emb2 = torch.from_numpy(wg.gen("input.emb1024", (32, 1024))).to(DEV)
     ce, _ = load(CrossEntropy(1024, 57), "ce.")
-    loss, logits = ce(emb2, lab)
+    with torch.no_grad():
+        loss, logits = ce(emb2, lab)
     assert rel_err(logits.cpu().numpy(), g["ce_logits"]) < TOL
     assert abs(float(loss) - float(g["ce_loss"])) < TOL * float(g["ce_loss"])
     assert np.array_equal(ce.predict(emb2)[2].cpu().numpy(), g["ce_argmax"])

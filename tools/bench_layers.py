@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--split", action="store_true", help="also time the split-fp16 (f16x3) kernel")
 ap.add_argument("--variants", default="-1", help="comma list of DLIP_CONV_TILE ids (-1 = built-in choice)")
 a = ap.parse_args()
 B = a.batch
@@ -66,7 +67,26 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res in L:
             e1.record()
             torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) * 1e3 / a.iters)
-    print(f"{name:12s} " + "  ".join(f"v{v}: {best[v]:8.1f}us {fl / best[v] / 1e6:6.1f}TF" for v in variants) + f"  {fl / 1e9:8.2f} GF")
+    line = f"{name:12s} " + "  ".join(f"v{v}: {best[v]:8.1f}us {fl / best[v] / 1e6:6.1f}TF" for v in variants)
+    if a.split:
+        from deeplip_amd import packing
+        wsp, wsc = packing.split_weights(wt.double().cpu())
+        wsp, wsc = wsp.cuda(), wsc.cuda()
+        bs = {v: 1e30 for v in variants}
+        y2 = torch.empty_like(y)
+        for rnd in range(4):
+            for v in variants:
+                os.environ["DLIP_CONV_TILE"] = v
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    ops.conv_nhwc(x, wsp, b, stride=sh, pad=pp, dil=dd, slope=sl, residual=rs, out=y2, w_scale=wsc)
+                e1.record()
+                torch.cuda.synchronize()
+                bs[v] = min(bs[v], e0.elapsed_time(e1) * 1e3 / a.iters)
+        err = float((y2 - y).abs().max() / y.abs().max())
+        line += "  | f16x3 " + "  ".join(f"v{v}: {bs[v]:8.1f}us {fl / bs[v] / 1e6:6.1f}TF" for v in variants) + f"  relerr {err:.1e}"
+    print(line + f"  {fl / 1e9:8.2f} GF")
 if not a.only or a.only == 'stem':
     x = torch.randn(B, 29, 88, 88, device=dev)
     wp = torch.randn(248, 64, device=dev) * 0.05
