@@ -14,12 +14,17 @@ One "step" = one pass of the hot path over one batch of synthetic A+V pairs PER 
 Inputs and weights are synthetic (name-keyed generator, seed 1), already resident in HBM when the
 timed region starts.  Rank 0 prints ONE JSON line.  metric = lip-clips/sec (whole job).
 
-roofline: the path is an fp32 dense contraction (exact fp32 MFMA, peak 157.3 TFLOP/s per
-MI355X, MI355X_MICROARCH.md).  `achieved` is for the dominant kernel (the implicit-GEMM conv
-instance that carries most FLOPs): algorithmic FLOPs of its launches in a step / the sum of their
-durations, both measured with HIP events around every launch inside the timed region, on the
-stream the kernels run on.  `step_achieved` applies BASELINE.md's whole-step formula
-(clips/s x 20.90 GFLOP).
+Arithmetic modes (--precision): "f16x3" (default) evaluates every conv/linear product of fp32
+values as hi*hi + hi*lo + lo*hi on the f16 matrix core with fp32 accumulation (fp32-grade: measured
+~1e-6 vs the CPU reference, bar 1e-4); "f32" is the exact fp32-MFMA path.  Both are timed in one
+run; the other one is reported under "alt_mode".
+
+roofline: the path is a dense contraction (MFMA-bound).  `achieved` is for the dominant kernel (the
+implicit-GEMM conv instance that carries most FLOPs): ALGORITHMIC FLOPs (2*M*N*K) of its launches
+in a step / the sum of their durations, measured with HIP events around every launch inside the
+timed region, on the stream the kernels run on.  `peak`: 157.3 TFLOP/s (fp32 MFMA) for "f32";
+2500/3 = 833.3 TFLOP/s for "f16x3" (dense f16 MFMA peak over the 3 MFMAs each product costs).
+`step_achieved` applies BASELINE.md's whole-step formula (clips/s x 20.90 GFLOP).
 """
 from __future__ import annotations
 
@@ -37,6 +42,8 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec)
+DTYPE_NAME = {"f32": "f32", "f16x3": "f16x3 (fp32 values as hi+lo fp16 pairs, 3 f16 MFMAs per product, fp32 accumulate)"}
 GFLOP_PER_FUSED_CLIP = 20.90      # BASELINE.md section 2 (18.337 video + 2.563 audio)
 TCN_OPTS = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
 ETDNN_CONTEXT = [[-2, -1, 0, 1, 2], [0], [-2, 0, 2], [0], [-3, 0, 3], [0], [-4, 0, 4], [0], [0], [0]]
@@ -161,6 +168,7 @@ def main():
     ap.add_argument("--audio-dim", type=int, default=80, help="mel bins F of the [B,1,F,300] audio input")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="implicit-GEMM arithmetic: exact fp32 MFMA, or split fp16 pairs (3 f16 MFMAs per product)")
+    ap.add_argument("--single-mode", action="store_true", help="do not also time the other arithmetic mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     args = ap.parse_args()
@@ -179,66 +187,58 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    from deeplip_amd import ops, packing, weightgen as wg
-    packing.set_precision(args.precision)
-    video, audio, sds = build_models(device, args.audio_dim)
+    from deeplip_amd import fusion, ops, packing, weightgen as wg
     B = args.batch
     # per-rank shard of the synthetic utterance list (weak scaling: B pairs per rank)
     spk = (np.arange(B) + rank * B) % 33
     xv = torch.from_numpy(wg.video_input(B, speakers=spk, key=f"bench.video.r{rank}")).to(device)
     xa = torch.from_numpy(wg.audio_input(B, args.audio_dim, 300, speakers=spk, key=f"bench.audio.r{rank}")).unsqueeze(1).to(device)
 
-    hook = EventHook()
-    ops.LAUNCH_HOOK = None if args.no_kernel_events else hook
-
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step(video, audio, xv, xa, world)
-    sync_all()
-    hook.enabled = True
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        out = step(video, audio, xv, xa, world)
-    ev1.record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    hook.enabled = False
-    gpu_ms = ev0.elapsed_time(ev1)
-
-    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-
-    if rank == 0:
-        clips = world * B * args.steps
-        value = clips / elapsed
-        res = {
-            "metric": "lip-clips/sec (fused A+V embed)", "value": round(value, 2), "unit": "lip-clips/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"fused A+V embed: video [{B},1,29,88,88] 3D-stem+ResNet-18 + audio [{B},1,{args.audio_dim},300] "
-                                   f"E-TDNN -> z-norm concat [{B},1024] per rank per step (BASELINE configs[1] clip batch)",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random-init (name-keyed, seed 1)",
-                       "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4)},
-        }
+    def measure(precision):
+        """W warm-up + K timed steps in one arithmetic mode -> (result fields, models, state dicts)."""
+        packing.set_precision(precision)
+        video, audio, sds = build_models(device, args.audio_dim)
+        hook = EventHook()
+        ops.LAUNCH_HOOK = None if args.no_kernel_events else hook
+        for _ in range(args.warmup):
+            step(video, audio, xv, xa, world)
+        sync_all()
+        hook.enabled = True
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            step(video, audio, xv, xa, world)
+        ev1.record()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        hook.enabled = False
+        ops.LAUNCH_HOOK = None
+        gpu_ms = ev0.elapsed_time(ev1)
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        value = world * B * args.steps / elapsed
+        # roofline of the mode: exact fp32 MFMA peak, or the f16 dense peak / 3 (three f16 MFMAs
+        # per fp32-grade product: the ceiling of the split algorithm in ALGORITHMIC FLOP/s)
+        peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
         step_tf = value / world * GFLOP_PER_FUSED_CLIP / 1e3
-        roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                "traffic": None, "step_achieved": round(step_tf, 2),
-                "step_frac": round(step_tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        roof = {"bound": "mfma", "achieved": None, "peak": round(peak, 1), "unit": "TFLOP/s", "frac": None,
+                "traffic": None, "step_achieved": round(step_tf, 2), "step_frac": round(step_tf / peak, 4)}
+        if precision != "f32":
+            roof["peak_note"] = ("algorithmic (2*M*N*K) FLOP/s ceiling of the split-fp16 scheme = 2500 TFLOP/s dense f16 MFMA / 3 "
+                                 "MFMAs per product; the stem kernel stays exact fp32")
         if not args.no_kernel_events:
             agg = hook.summary()
-            dom = max(agg.items(), key=lambda kv: kv[1]["flops"])
-            name, a = dom
+            name, a = max(agg.items(), key=lambda kv: kv[1]["flops"])
             tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
-            roof.update({"achieved": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "kernel": name,
+            roof.update({"achieved": round(tf, 2), "frac": round(tf / peak, 4), "kernel": name,
                          "launches_per_step": a["launches"] // args.steps,
                          "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
                          "gflop_per_launch": round(a["flops"] / a["launches"] / 1e9, 3),
@@ -254,19 +254,49 @@ def main():
                 roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per launch, FETCH x2 gfx950 correction)"
         except Exception:
             pass
-        res["roofline"] = roof
+        fields = {"value": round(value, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                  "dtype": DTYPE_NAME[precision], "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),
+                  "roofline": roof}
+        return fields, video, audio, sds
+
+    def parity(precision, video, audio, ref, cxv, cxa):
+        packing.set_precision(precision)      # the pack cache is keyed by the arithmetic mode
+        got = fusion.fuse_av(audio.extract_embedding(cxa.unsqueeze(1).to(device))[0], video.embed(cxv.to(device)))
+        torch.cuda.synchronize()
+        err = float((got.cpu() - ref).abs().max() / ref.abs().max())
+        gn = torch.nn.functional.normalize(got.cpu().double()); rn = torch.nn.functional.normalize(ref.double())
+        sc_err = float(((gn @ gn.t()) - (rn @ rn.t())).abs().max())
+        return {"fused_emb_rel_err_vs_cpu": float(f"{err:.3e}"), "cos_score_abs_err_vs_cpu": float(f"{sc_err:.3e}"),
+                "tolerance": 1e-4}
+
+    main_fields, video, audio, sds = measure(args.precision)
+    alt = None
+    if not args.single_mode:
+        alt_prec = "f32" if args.precision != "f32" else "f16x3"
+        alt_fields, avideo, aaudio, _ = measure(alt_prec)
+        alt = (alt_prec, alt_fields, avideo, aaudio)
+    packing.set_precision("f32")
+
+    if rank == 0:
+        res = {
+            "metric": "lip-clips/sec (fused A+V embed)", "value": main_fields["value"], "unit": "lip-clips/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_fields["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": main_fields["dtype"], "data": "synthetic",
+            "config": {"workload": f"fused A+V embed: video [{B},1,29,88,88] 3D-stem+ResNet-18 + audio [{B},1,{args.audio_dim},300] "
+                                   f"E-TDNN -> z-norm concat [{B},1024] per rank per step (BASELINE configs[1] clip batch)",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random-init (name-keyed, seed 1)",
+                       "gpu_ms_per_step_hip_events": main_fields["gpu_ms_per_step_hip_events"]},
+            "roofline": main_fields["roofline"],
+        }
+        if alt is not None:
+            res["alt_mode"] = {k: alt[1][k] for k in ("dtype", "value", "ms_per_step", "roofline")}
         if not args.no_cpu_baseline:
-            ops.LAUNCH_HOOK = None
             cb, ref, cxv, cxa = cpu_baseline(sds, args.audio_dim)
-            from deeplip_amd import fusion
-            got = fusion.fuse_av(audio.extract_embedding(cxa.unsqueeze(1).to(device))[0], video.embed(cxv.to(device)))
-            torch.cuda.synchronize()
-            err = float((got.cpu() - ref).abs().max() / ref.abs().max())
-            gn = torch.nn.functional.normalize(got.cpu().double()); rn = torch.nn.functional.normalize(ref.double())
-            sc_err = float(((gn @ gn.t()) - (rn @ rn.t())).abs().max())
             res["cpu_baseline"] = cb
-            res["parity"] = {"fused_emb_rel_err_vs_cpu": float(f"{err:.3e}"), "cos_score_abs_err_vs_cpu": float(f"{sc_err:.3e}"),
-                             "tolerance": 1e-4}
+            res["parity"] = parity(args.precision, video, audio, ref, cxv, cxa)
+            if alt is not None:
+                res["alt_mode"]["parity"] = parity(alt[0], alt[2], alt[3], ref, cxv, cxa)
         print(json.dumps(res), flush=True)
 
     if world > 1:

@@ -36,7 +36,7 @@ SIGNATURES = {
     "dlip_abi_version": [],
     "dlip_conv_nhwc_f32": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_stream],
     "dlip_conv_nhwc_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_stream],
-    "dlip_conv_plan": [C.POINTER(ConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "dlip_conv_plan": [C.POINTER(ConvDesc), c_i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "dlip_stem3d_bn_act_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_maxpool3x3s2_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_avgpool_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],

@@ -79,11 +79,14 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
 }
 
 // Tile menu / picker shared by both kernels (see conv_igemm.hip for the rationale).
-struct TileCfg { int bm, bn; float eff; };
+struct TileCfg { int bm, bn; };
 constexpr int NUM_CFG = 5;
-const TileCfg kCfg[NUM_CFG] = {{128, 128, 0.90f}, {128, 64, 0.97f}, {64, 64, 0.93f}, {64, 128, 1.00f}, {96, 128, 0.97f}};
+const TileCfg kCfg[NUM_CFG] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {96, 128}};
+// Measured relative efficiency of a busy CU per tile (tools/bench_layers.py, MI355X, B = 64).
+const float kEffF32[NUM_CFG] = {0.90f, 0.97f, 0.93f, 1.00f, 0.97f};
+const float kEffF16x3[NUM_CFG] = {0.95f, 0.93f, 0.80f, 1.00f, 0.90f};
 
-inline int pick_tile(long long M, int K) {
+inline int pick_tile(long long M, int K, const float* eff = kEffF32) {
   if (const char* e = getenv("DLIP_CONV_TILE")) {  // development override (A/B runs)
     const int v = atoi(e);
     if (v >= 0 && v < NUM_CFG) return v;
@@ -94,7 +97,7 @@ inline int pick_tile(long long M, int K) {
     const TileCfg& c = kCfg[i];
     const long long tiles = ((M + c.bm - 1) / c.bm) * ((K + c.bn - 1) / c.bn);
     const long long rounds = (tiles + 255) / 256;  // one tile per CU per round
-    const double cost = (double)rounds * c.bm * c.bn / c.eff;
+    const double cost = (double)rounds * c.bm * c.bn / eff[i];
     if (cost < best_cost * 0.999) { best_cost = cost; best = i; }
   }
   return best;

@@ -310,9 +310,9 @@ extern "C" int dlip_conv_nhwc_f32(const dlip_conv_desc* d, const float* x, const
   return launch_cfg(pick_tile(M, d->K), a, st);
 }
 
-extern "C" int dlip_conv_plan(const dlip_conv_desc* d, int32_t* bm, int32_t* bn) {
+extern "C" int dlip_conv_plan(const dlip_conv_desc* d, int32_t split_f16, int32_t* bm, int32_t* bn) {
   DLIP_CHECK_ARG(d && bm && bn && d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0);
-  const int t = pick_tile((long long)d->N * d->Ho * d->Wo, d->K);
+  const int t = pick_tile((long long)d->N * d->Ho * d->Wo, d->K, split_f16 ? kEffF16x3 : kEffF32);
   *bm = kCfg[t].bm;
   *bn = kCfg[t].bn;
   return DLIP_OK;

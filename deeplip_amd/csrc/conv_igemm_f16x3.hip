@@ -36,7 +36,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_f16x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(const ConvArgs a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 32, NI = WN / 32;
@@ -300,7 +300,7 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   if (rc != DLIP_OK) return rc;
   a.wscale = w_scale;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (pick_tile(a.M, d->K)) {
+  switch (pick_tile(a.M, d->K, kEffF16x3)) {
     case 0: return launch<128, 128, 2, 2>(a, st);
     case 1: return launch<128, 64, 2, 2>(a, st);
     case 2: return launch<64, 64, 2, 2>(a, st);

@@ -82,7 +82,7 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
     hook = LAUNCH_HOOK
     if hook is not None:
         bm, bn = C.c_int32(), C.c_int32()
-        check(lib().dlip_conv_plan(C.byref(d), C.byref(bm), C.byref(bn)), "dlip_conv_plan")
+        check(lib().dlip_conv_plan(C.byref(d), int(w_scale is not None), C.byref(bm), C.byref(bn)), "dlip_conv_plan")
         kname = "conv_igemm_f16x3_kernel" if w_scale is not None else "conv_igemm_f32_kernel"
         tok = hook.begin(f"{kname}<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
     if w_scale is not None:

@@ -83,9 +83,10 @@ int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_
                          const float* slope, const float* post_scale, const float* post_shift,
                          float* y, dlip_stream_t stream);
 
-/* Reports the workgroup tile (BM x BN) dlip_conv_nhwc_f32 will use for `d` -- i.e. which
- * conv_igemm_f32_kernel<BM,BN,..> instance a profiler will show.  Host-only, no launch. */
-int dlip_conv_plan(const dlip_conv_desc* d, int32_t* bm, int32_t* bn);
+/* Reports the workgroup tile (BM x BN) dlip_conv_nhwc_f32 (split_f16 = 0) or dlip_conv_nhwc_f16x3
+ * (split_f16 = 1) will use for `d` -- i.e. which conv_igemm_*_kernel<BM,BN,..> instance a profiler
+ * will show.  Host-only, no launch. */
+int dlip_conv_plan(const dlip_conv_desc* d, int32_t split_f16, int32_t* bm, int32_t* bn);
 
 /* ------------------------------------------------------------------------------------------
  * Video stem: Conv3d(1->K, 5x7x7, stride (1,2,2), pad (2,3,3), no bias) + BatchNorm3d + PReLU|ReLU
