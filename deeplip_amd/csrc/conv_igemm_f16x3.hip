@@ -165,13 +165,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(const ConvArgs
 
   int s_pos = 0, x_row = 0;
   const int x_dr = a.dh * a.W * a.ldx * 4, x_ds = a.dw * a.ldx * 4;
+  // Reduction walk: 32-channel slice OUTER, filter tap INNER.  Consecutive slices then read the same
+  // channel slice of neighbouring pixels (tap shifts the window by one pixel / one image row), so the
+  // activation rows of a tile are re-served from the 32 KiB L1 instead of L2; the weight stream is
+  // the same bytes in a different order.
+  const int ntaps = a.R * a.S;
   auto advance = [&]() {
-    c0 += BK;
-    if (c0 >= a.C) {
-      c0 = 0;
-      ++tap;
-      if (++s_pos == a.S) { s_pos = 0; x_row += x_dr; }
-    }
+    ++tap;
+    if (++s_pos == a.S) { s_pos = 0; x_row += x_dr; }
+    if (tap == ntaps) { tap = 0; s_pos = 0; x_row = 0; c0 += BK; }
     x_tap = x_row + s_pos * x_ds + c0 * 4;
     w_tap = (tap * a.Cw + c0) * 4;
   };

@@ -59,7 +59,7 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res in L:
     best = {v: 1e30 for v in variants}
     for rnd in range(4):          # interleaved rounds, report the min per variant
         for v in variants:
-            os.environ["DLIP_CONV_TILE"] = v
+            os.environ["DLIP_CONV_TILE"] = v.split(":")[0]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
@@ -76,7 +76,7 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res in L:
         y2 = torch.empty_like(y)
         for rnd in range(4):
             for v in variants:
-                os.environ["DLIP_CONV_TILE"] = v
+                os.environ["DLIP_CONV_TILE"] = v.split(":")[0]; pass
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.iters):
