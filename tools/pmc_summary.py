@@ -15,7 +15,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(conv_igemm_f32_kernel<\d+, \d+)", name)
+    m = re.search(r"(conv_igemm_\w+?_kernel<\d+, \d+)", name)
     if m:
         return m.group(1).replace(" ", "") + ">"
     m = re.search(r"(\w+_kernel)", name)
