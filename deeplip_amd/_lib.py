@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lock = threading.Lock()
 _lib = None
@@ -53,6 +53,11 @@ SIGNATURES = {
     "dlip_logits_argmax_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_margin_ce_loss_f32": [c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_stream],
     "dlip_lowfer_cat_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
+    "dlip_frame_preemph_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, C.c_float, c_stream],
+    "dlip_powspec_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_log_floor_f32": [c_f, c_f, c_i64, c_stream],
+    "dlip_cmvn_nct_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_crop_normalize_u8": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_bn1d_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_stream],
     "dlip_bn1d_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_lrelu_bwd_f32": [c_f, c_f, c_f, c_i64, C.c_float, c_stream],

@@ -1,0 +1,154 @@
+// GPU-side preprocessing at the entrance of the hot path.
+//
+// Audio: the reference extracts MFCC / (log-)fbank features per utterance on CPU workers with the
+// third-party python_speech_features package (models/audio_models/datasets.py:65-83: mfcc(winlen 0.025,
+// winstep 0.01, numcep 24) with that package's defaults nfilt 26, nfft 512, preemph 0.97,
+// ceplifter 22, appendEnergy, rectangular window; then per-utterance mean/variance normalisation,
+// datasets.py:52-53).  Here the chain is: framing + pre-emphasis (this file) -> 512-point real DFT as
+// ONE fp32 MFMA GEMM against a [514 x 512] cos/sin matrix -> power spectrum + frame energy (this
+// file) -> mel filterbank GEMM -> log -> DCT-II(+lifter) GEMM -> c0 := log energy -> CMVN (this file).
+// The GEMMs reuse dlip_conv_nhwc_f32 (host side: deeplip_amd/frontend.py).
+//
+// Video: uint8 gray or RGB frames -> centre crop -> /255 -> (x - 0.421)/0.165
+// (models/video_models/dataloaders.py:11-22: Normalize(0,255), CenterCrop(88), Normalize(0.421,0.165)).
+#include "dlip_common.h"
+
+namespace {
+
+// frames[b*NF + f][j] = (j < L ? pre(b, f*step + j) : 0), pre(n) = x[n] - coef*x[n-1] (x[-1] -> x[0] alone,
+// samples beyond the signal are zero padding as python_speech_features.sigproc.framesig does).
+__global__ __launch_bounds__(256) void frame_preemph_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int S, int NF, int L, int step, int nfft, float coef,
+                                                            long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int j = (int)(i % nfft);
+    const long long r = i / nfft;
+    const int f = (int)(r % NF);
+    const long long b = r / NF;
+    float v = 0.f;
+    const int n = f * step + j;
+    if (j < L && n < S) {
+      const float* xb = x + b * S;
+      v = n == 0 ? xb[0] : xb[n] - coef * xb[n - 1];
+    }
+    y[i] = v;
+  }
+}
+
+// spec [R, 2*NB] = (re_0..re_{NB-1}, im_0..im_{NB-1}) -> pow [R, NBp] = (re^2 + im^2)/nfft (zero padded to NBp),
+// energy[r] = sum_k pow (0 -> eps), as python_speech_features.sigproc.powspec / base.fbank.
+__global__ __launch_bounds__(256) void powspec_kernel(const float* __restrict__ spec, float* __restrict__ pw,
+                                                      float* __restrict__ energy, int R, int NB, int NBp, float inv_nfft) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* s = spec + (long long)r * 2 * NB;
+  double e = 0.0;
+  for (int k = lane; k < NBp; k += 64) {
+    float p = 0.f;
+    if (k < NB) {
+      p = (s[k] * s[k] + s[NB + k] * s[NB + k]) * inv_nfft;
+      e += (double)p;
+    }
+    pw[(long long)r * NBp + k] = p;
+  }
+  e = dlip_wave_sum_f64(e);
+  if (lane == 0) energy[r] = e == 0.0 ? 2.220446049250313e-16f : (float)e;
+}
+
+// y = log(x == 0 ? eps : x) elementwise (base.logfbank / base.mfcc)
+__global__ __launch_bounds__(256) void log_floor_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = x[i];
+    y[i] = logf(v == 0.f ? 2.220446049250313e-16f : v);
+  }
+}
+
+// feat [B, NF, C] (c0 optionally replaced by log(energy)) -> CMVN over the NF frames of each utterance:
+// (x - mean)/(std_biased + 2e-12) (datasets.py:52-53), written channel-first [B, C, NF] like the
+// reference loaders (datasets.py:135).  One thread per (b, c), fp64 statistics.
+__global__ __launch_bounds__(256) void cmvn_kernel(const float* __restrict__ feat, const float* __restrict__ energy,
+                                                   float* __restrict__ y, int B, int NF, int C, int ldf, int normalize) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * C) return;
+  const int c = (int)(i % C);
+  const long long b = i / C;
+  const float* p = feat + b * NF * ldf + c;
+  const float* en = (energy && c == 0) ? energy + b * NF : nullptr;
+  double s = 0.0;
+  for (int f = 0; f < NF; ++f) s += (double)(en ? logf(en[f]) : p[(long long)f * ldf]);
+  const double mean = s / NF;
+  double q = 0.0;
+  for (int f = 0; f < NF; ++f) {
+    const double d = (double)(en ? logf(en[f]) : p[(long long)f * ldf]) - mean;
+    q += d * d;
+  }
+  const float mu = normalize ? (float)mean : 0.f;
+  const float den = normalize ? (float)sqrt(q / NF) + 2e-12f : 1.f;
+  float* o = y + (b * C + c) * NF;
+  for (int f = 0; f < NF; ++f) o[f] = ((en ? logf(en[f]) : p[(long long)f * ldf]) - mu) / den;
+}
+
+// uint8 frames [N, CH, H, W] (CH = 1 gray or 3 RGB) -> centre crop [N, CS, CS] float, normalised.
+__global__ __launch_bounds__(256) void crop_norm_kernel(const uint8_t* __restrict__ x, float* __restrict__ y,
+                                                        long long N, int CH, int H, int W, int CS) {
+  const long long total = N * CS * CS;
+  const int oy = (H - CS) / 2, ox = (W - CS) / 2;     // CenterCrop: int(round((h - th)/2.)) for even margins
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cx = (int)(i % CS);
+    const int cy = (int)((i / CS) % CS);
+    const long long n = i / ((long long)CS * CS);
+    const uint8_t* p = x + (n * CH * H + (oy + cy)) * W + ox + cx;
+    float g;
+    if (CH == 3) g = 0.299f * (float)p[0] + 0.587f * (float)p[(long long)H * W] + 0.114f * (float)p[2LL * H * W];
+    else g = (float)p[0];
+    y[i] = (g / 255.0f - 0.421f) / 0.165f;
+  }
+}
+
+inline unsigned grid_for(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int dlip_frame_preemph_f32(const float* x, float* frames, int32_t B, int32_t S, int32_t NF, int32_t frame_len,
+                                      int32_t frame_step, int32_t nfft, float preemph, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && frames && B > 0 && S > 0 && NF > 0 && frame_len > 0 && frame_step > 0 && nfft >= frame_len);
+  const long long total = (long long)B * NF * nfft;
+  hipLaunchKernelGGL(frame_preemph_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     frames, S, NF, frame_len, frame_step, nfft, preemph, total);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_powspec_f32(const float* spec, float* pw, float* energy, int32_t R, int32_t NB, int32_t NBp,
+                                int32_t nfft, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(spec && pw && energy && R > 0 && NB > 0 && NBp >= NB && nfft > 0);
+  hipLaunchKernelGGL(powspec_kernel, dim3((R + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), spec, pw, energy,
+                     R, NB, NBp, 1.0f / (float)nfft);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_log_floor_f32(const float* x, float* y, int64_t n, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && n > 0);
+  hipLaunchKernelGGL(log_floor_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, (long long)n);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_cmvn_nct_f32(const float* feat, const float* energy, float* y, int32_t B, int32_t NF, int32_t C,
+                                 int32_t ldf, int32_t normalize, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(feat && y && B > 0 && NF > 0 && C > 0 && ldf >= C);
+  hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)(((long long)B * C + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), feat, energy, y, B, NF, C, ldf, normalize);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_crop_normalize_u8(const uint8_t* x, float* y, int64_t n_frames, int32_t channels, int32_t H,
+                                      int32_t W, int32_t crop, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && n_frames > 0 && (channels == 1 || channels == 3) && crop > 0 && H >= crop && W >= crop);
+  hipLaunchKernelGGL(crop_norm_kernel, dim3(grid_for(n_frames * crop * crop)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, y, (long long)n_frames, channels, H, W, crop);
+  return dlip_launch_status();
+}

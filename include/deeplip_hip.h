@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 3
+#define DLIP_ABI_VERSION 4
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -179,6 +179,29 @@ int dlip_margin_ce_loss_f32(const float* logits, const int64_t* labels, float* l
 /* LowFER.forward as shipped (LBP.py:46-50): y = cat[e1, sigmoid(e2), sigmoid(e2)*e1], [B,3D]. */
 int dlip_lowfer_cat_f32(const float* e1, const float* e2, float* y, int32_t B, int32_t D,
                         dlip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GPU-side preprocessing in front of the hot path.  Audio features as
+ * the reference computes them with python_speech_features (models/audio_models/datasets.py:65-83,52-53);
+ * the DFT / mel / DCT matrix products go through dlip_conv_nhwc_f32 (deeplip_amd/frontend.py).
+ * ------------------------------------------------------------------------------------------ */
+/* x [B,S] waveform -> frames [B*NF, nfft]: frame f = pre-emphasised samples [f*step, f*step+len), zero
+ * padded to nfft and past the end of the signal (sigproc.preemphasis + framesig, rectangular window). */
+int dlip_frame_preemph_f32(const float* x, float* frames, int32_t B, int32_t S, int32_t NF, int32_t frame_len,
+                           int32_t frame_step, int32_t nfft, float preemph, dlip_stream_t stream);
+/* spec [R, 2*NB] (re | im) -> pw [R, NBp] = |.|^2 / nfft (zero padded), energy [R] = row sum (0 -> eps). */
+int dlip_powspec_f32(const float* spec, float* pw, float* energy, int32_t R, int32_t NB, int32_t NBp,
+                     int32_t nfft, dlip_stream_t stream);
+/* y = log(x == 0 ? eps : x). */
+int dlip_log_floor_f32(const float* x, float* y, int64_t n, dlip_stream_t stream);
+/* feat [B,NF,C] (row stride ldf; channel 0 := log(energy) when energy != NULL) -> per-utterance
+ * (x - mean)/(std + 2e-12) when normalize != 0 -> y [B,C,NF] (the reference loaders' layout). */
+int dlip_cmvn_nct_f32(const float* feat, const float* energy, float* y, int32_t B, int32_t NF, int32_t C,
+                      int32_t ldf, int32_t normalize, dlip_stream_t stream);
+/* uint8 frames [n, channels(1|3), H, W] -> centre crop [n, crop, crop] float = ((gray)/255 - 0.421)/0.165
+ * (models/video_models/dataloaders.py:11-22; RGB -> gray with the BT.601 weights). */
+int dlip_crop_normalize_u8(const uint8_t* x, float* y, int64_t n_frames, int32_t channels, int32_t H,
+                           int32_t W, int32_t crop, dlip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Train-mode / backward kernels for the trainable fusion head and criterion (config C5; the

@@ -416,3 +416,76 @@ def sgd_momentum_step(params: Sequence[Tensor], bufs: List[Optional[Tensor]], lr
             bufs[i] = g.clone() if bufs[i] is None else bufs[i].mul_(momentum).add_(g)
             p.add_(bufs[i], alpha=-lr)
             p.grad = None
+
+
+# ----------------------------------------------------------------------------------------
+# Preprocessing in front of the path.
+# The arithmetic lives in the third-party package python_speech_features (pinned nowhere upstream;
+# v0.6 is the only release; NOT installed in this image), called at
+# models/audio_models/datasets.py:65-83.  Below is a numpy restatement of its published algorithm
+# (base.mfcc / base.fbank / base.logfbank / sigproc.*).  parity unpinned (no reference output can be
+# generated here); the product's GEMM-based front-end is checked against THIS restatement.
+# ----------------------------------------------------------------------------------------
+def _psf_frames(signal: np.ndarray, frame_len: int, frame_step: int, preemph: float = 0.97) -> np.ndarray:
+    sig = np.append(signal[0], signal[1:] - preemph * signal[:-1])            # sigproc.preemphasis
+    slen = len(sig)
+    nf = 1 if slen <= frame_len else 1 + int(np.ceil((1.0 * slen - frame_len) / frame_step))
+    padlen = int((nf - 1) * frame_step + frame_len)
+    pad = np.concatenate((sig, np.zeros((padlen - slen,))))
+    idx = np.tile(np.arange(0, frame_len), (nf, 1)) + np.tile(np.arange(0, nf * frame_step, frame_step), (frame_len, 1)).T
+    return pad[idx.astype(np.int32)]                                          # rectangular window (winfunc = ones)
+
+
+def psf_fbank(signal, rate=16000, winlen=0.025, winstep=0.01, nfilt=26, nfft=512, preemph=0.97):
+    """base.fbank -> (feat [NF, nfilt], energy [NF])."""
+    from deeplip_amd.frontend import mel_filterbank   # constant construction only (same published formula)
+    frames = _psf_frames(np.asarray(signal, dtype=np.float64), int(round(winlen * rate)), int(round(winstep * rate)), preemph)
+    pspec = 1.0 / nfft * np.square(np.absolute(np.fft.rfft(frames, nfft)))    # sigproc.powspec
+    energy = np.sum(pspec, 1)
+    energy = np.where(energy == 0, np.finfo(float).eps, energy)
+    fb = mel_filterbank(nfilt, nfft, rate)
+    feat = np.dot(pspec, fb.T)
+    feat = np.where(feat == 0, np.finfo(float).eps, feat)
+    return feat, energy
+
+
+def psf_mfcc(signal, rate=16000, winlen=0.025, winstep=0.01, numcep=24, nfilt=26, nfft=512, preemph=0.97,
+             ceplifter=22, append_energy=True):
+    """base.mfcc (datasets.py:67 passes winlen, winstep, numcep; the rest are package defaults)."""
+    from scipy.fftpack import dct
+    feat, energy = psf_fbank(signal, rate, winlen, winstep, nfilt, nfft, preemph)
+    feat = np.log(feat)
+    feat = dct(feat, type=2, axis=1, norm="ortho")[:, :numcep]
+    if ceplifter > 0:
+        n = np.arange(numcep)
+        feat = (1 + (ceplifter / 2.0) * np.sin(np.pi * n / ceplifter)) * feat
+    if append_energy:
+        feat[:, 0] = np.log(energy)
+    return feat
+
+
+def audio_features(signal, feat_type="mfcc", normalize=True, **kw) -> np.ndarray:
+    """SpkTrainDataset._extract_feature + _normalize (datasets.py:52-53,65-83) -> [F, NF] float32."""
+    if feat_type == "mfcc":
+        feat = psf_mfcc(signal, **kw)
+    elif feat_type == "fbank":
+        feat = psf_fbank(signal, **kw)[0]
+    elif feat_type == "logfbank":
+        feat = np.log(psf_fbank(signal, **kw)[0])
+    else:
+        raise NotImplementedError("Other features are not implemented!")
+    if normalize:
+        feat = (feat - feat.mean(axis=0)) / (feat.std(axis=0) + 2e-12)
+    return feat.T.astype(np.float32)
+
+
+def video_preprocess_u8(frames_u8: np.ndarray, crop: int = 88) -> np.ndarray:
+    """dataloaders.py:17-24 'val' pipeline: Normalize(0,255) -> CenterCrop(crop) -> Normalize(0.421,0.165)
+    on [T,H,W] gray (or [T,3,H,W] RGB through the BT.601 gray of preprocess.py:44, kept in float)."""
+    x = frames_u8.astype(np.float32)
+    if x.ndim == 4:
+        x = np.float32(0.299) * x[:, 0] + np.float32(0.587) * x[:, 1] + np.float32(0.114) * x[:, 2]
+    h, w = x.shape[-2:]
+    dh, dw = int(round((h - crop) / 2.0)), int(round((w - crop) / 2.0))       # preprocess.py CenterCrop
+    x = x[:, dh:dh + crop, dw:dw + crop] / np.float32(255.0)
+    return ((x - np.float32(0.421)) / np.float32(0.165)).astype(np.float32)

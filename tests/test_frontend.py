@@ -1,0 +1,85 @@
+"""Preprocessing front-end: GEMM-based MFCC / fbank / logfbank and the
+video crop+normalise, against the oracle's numpy restatement of python_speech_features / the
+reference's 'val' transform chain.  Tolerance 1e-4 relative-to-max on normalised features."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from deeplip_amd import weightgen as wg
+from oracle import deeplip_oracle as O
+
+
+def test_filterbank_and_oracle_self_consistency():
+    from deeplip_amd.frontend import mel_filterbank, num_frames
+    fb = mel_filterbank(26, 512, 16000)
+    assert fb.shape == (26, 257) and fb.min() >= 0 and abs(fb.max() - 1.0) < 1e-12
+    assert num_frames(16000, 400, 160) == 99 and num_frames(300, 400, 160) == 1
+    sig = wg.gen("fe.sig", (16000,)) * 0.1
+    f = O.audio_features(sig, "mfcc")
+    assert f.shape == (24, 99)
+    assert np.abs(f.mean(1)).max() < 1e-5 and np.abs(f.std(1) - 1).max() < 1e-4    # CMVN
+
+
+@pytest.mark.gpu
+# 80 bands at nfft=512: 19 one-bin filters sit next to DC where pre-emphasis leaves ~1e-9 of the spectrum, i.e.
+# at the fp32 noise floor of a 512-point DFT (the reference's numpy FFT runs in fp64); the shipped configs use
+# 26 / 24 / 60 bands (conf/fusion_config.yaml:12-40), which hold 1e-4.
+@pytest.mark.parametrize("feat_type,num_bin,tol", [("mfcc", 26, 1e-4), ("logfbank", 60, 1e-4), ("fbank", 24, 1e-4),
+                                                   ("logfbank", 80, 5e-3)])
+def test_audio_frontend_vs_oracle(feat_type, num_bin, tol):
+    from deeplip_amd.frontend import AudioFrontend
+    B, S = 3, 16000 * 2 + 123
+    t = np.arange(S) / 16000.0
+    sig = np.stack([0.3 * np.sin(2 * np.pi * (200 + 150 * b) * t) + 0.05 * wg.gen(f"fe.n{b}", (S,)) for b in range(B)]).astype(np.float32)
+    fe = AudioFrontend(feat_type, num_bin=num_bin)
+    y = fe(torch.from_numpy(sig).cuda())
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = O.audio_features(sig[b].astype(np.float64), feat_type, nfilt=num_bin)
+        assert y[b].shape == ref.shape
+        # at nfft=512 / 16 kHz the lowest mel filters of an 80-band bank are EMPTY (floor() collapses their
+        # bin edges): constant log(eps) rows whose "CMVN" is rounding noise / 2e-12 in the reference -- skip them
+        raw = O.audio_features(sig[b].astype(np.float64), feat_type, nfilt=num_bin, normalize=False)
+        live = raw.std(axis=1) > 1e-6
+        assert live.sum() >= num_bin - 8
+        assert rel_err(y[b].cpu().numpy()[live], ref[live]) < tol, (feat_type, b)
+
+
+@pytest.mark.gpu
+def test_mfcc_feeds_the_encoder():
+    """waveform -> MFCC-24 -> E-TDNN embedding, GPU end to end vs oracle end to end."""
+    from deeplip_amd.frontend import AudioFrontend
+    from models.audio_models.tdnn import SpeakerEmbNet
+    et = {"input_dim": 24, "hidden_dim": [512] * 9 + [1500], "context": O.ETDNN_CONTEXT, "tdnn_layers": 10,
+          "embedding_dim": 512, "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+    net = SpeakerEmbNet({"arch": "etdnn", "etdnn": et})
+    sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="audio.")
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); net.eval().cuda()
+    S = 16000 * 3
+    sig = (0.2 * np.sin(2 * np.pi * 310 * np.arange(S) / 16000.0) + 0.05 * wg.gen("fe.enc", (S,))).astype(np.float32)
+    feats = AudioFrontend("mfcc")(torch.from_numpy(sig[None]).cuda())
+    xv, _ = net.extract_embedding(feats)
+    ref_f = torch.from_numpy(O.audio_features(sig.astype(np.float64), "mfcc"))[None]
+    with torch.no_grad():
+        ref, _ = O.speaker_extract_embedding(O.to_torch_sd(sd), ref_f, O.ETDNN_CONTEXT)
+    assert rel_err(xv.cpu().numpy(), ref.numpy()) < 1e-3      # features 1e-4, amplified by 10 layers + pooling
+
+
+@pytest.mark.gpu
+def test_video_frontend_vs_oracle():
+    from deeplip_amd.frontend import VideoFrontend
+    g = torch.Generator().manual_seed(3)
+    gray = torch.randint(0, 256, (2, 5, 96, 96), dtype=torch.uint8, generator=g)
+    rgb = torch.randint(0, 256, (2, 4, 3, 96, 100), dtype=torch.uint8, generator=g)
+    vf = VideoFrontend(88)
+    yg = vf(gray.cuda()); yr = vf(rgb.cuda())
+    torch.cuda.synchronize()
+    assert yg.shape == (2, 1, 5, 88, 88) and yr.shape == (2, 1, 4, 88, 88)
+    for b in range(2):
+        assert np.abs(yg[b, 0].cpu().numpy() - O.video_preprocess_u8(gray[b].numpy())).max() < 1e-5
+        assert np.abs(yr[b, 0].cpu().numpy() - O.video_preprocess_u8(rgb[b].numpy())).max() < 1e-4
+    clips = [gray[0, :3].cuda(), gray[1].cuda()]
+    batch, lengths = vf.collate(clips)
+    assert lengths == [5, 3] and batch.shape == (2, 1, 5, 88, 88)
+    assert np.abs(batch[1, 0, 3:].cpu().numpy() - (0.0 - 0.421) / 0.165).max() < 1e-5   # zero-padded RAW frames
