@@ -43,6 +43,7 @@ SIGNATURES = {
     "dlip_time_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_group_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_meanstd_pool_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
+    "dlip_attentive_stat_pool_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_nct_to_ntc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_ntc_to_nct_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_ingest_rgb_u8": [c_f, c_f, c_i64, c_i32, c_i32, c_stream],

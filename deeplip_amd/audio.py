@@ -32,8 +32,8 @@ class MeanStdPooling(nn.Module):
 
 
 class AttentiveStatPooling(nn.Module):
-    """pooling.py:73-107.  Parameters kept for state-dict compatibility; the attention pooling
-    kernels are SURVEY.md section 8(f) rank 4 (both shipped configs use `pooling: statistic`)."""
+    """pooling.py:73-107: attention over frames, then attention-weighted mean and std.
+    hidden = W x + b is one GEMM launch; score / softmax / weighted statistics one fused kernel."""
 
     def __init__(self, input_size, hidden_size):
         super().__init__()
@@ -45,8 +45,20 @@ class AttentiveStatPooling(nn.Module):
         for p in self.parameters():
             nn.init.xavier_normal_(p)
 
+    def run_ntc(self, x_ntc: Tensor) -> Tensor:
+        """x [B,T,C] -> [B,2C]."""
+        from ._lib import check, lib, ptr, stream_handle
+        B, T, C_ = x_ntc.shape
+        hidden = ops.linear(x_ntc.reshape(B * T, C_), self.W.detach().contiguous(), self.b.detach().reshape(-1).contiguous())
+        y = torch.empty((B, 2 * C_), device=x_ntc.device, dtype=torch.float32)
+        check(lib().dlip_attentive_stat_pool_f32(ptr(x_ntc), ptr(hidden), ptr(self.v.detach().contiguous()),
+                                                 ptr(self.k.detach().contiguous()), ptr(y), B, T, C_, self.hidden_size,
+                                                 stream_handle()), "dlip_attentive_stat_pool_f32")
+        return y
+
     def forward(self, x):
-        raise NotImplementedError("attentive_statistic pooling has no HIP kernel yet (SURVEY.md section 8f rank 4)")
+        """[B,C,T] (reference layout) -> [B,2C]."""
+        return self.run_ntc(ops.nct_to_ntc(x.contiguous()))
 
 
 class TDNN_Block(nn.Module):
@@ -160,7 +172,7 @@ class SpeakerEmbNet(nn.Module):
         elif self.pooling_type == "average":
             h = ops.time_mean(h)
         else:
-            h = self.pooling(h)
+            h = self.pooling.run_ntc(h)
         if taps is not None:
             taps["pooled"] = h
         x_a = ops.linear(h, p["fc1"].w, p["fc1"].b, w_scale=p["fc1"].wscale)

@@ -147,3 +147,61 @@ extern "C" int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_
                      static_cast<hipStream_t>(stream), x, y, B, T, C);
   return dlip_launch_status();
 }
+
+namespace {
+// AttentiveStatPooling tail (models/audio_models/pooling.py:87-107) on N-T-C activations:
+//   e[t]   = relu(hidden[b,t,:]) . v + k            (hidden = x W^T + b comes from the GEMM kernel)
+//   alpha  = softmax_t(e)
+//   mean_c = sum_t alpha[t] x[b,t,c];  std_c = sqrt(sum_t alpha[t] x[b,t,c]^2 - mean_c^2)
+// One workgroup per utterance: phase 1 one wave per frame for e[t] (LDS), phase 2 softmax over T,
+// phase 3 one thread per channel (coalesced) with fp64 accumulation.
+__global__ __launch_bounds__(256) void attentive_stat_kernel(const float* __restrict__ x, const float* __restrict__ hidden,
+                                                             const float* __restrict__ v, const float* __restrict__ kk,
+                                                             float* __restrict__ y, int T, int C, int Hd) {
+  extern __shared__ float alpha[];   // [T]
+  __shared__ float red[2];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* hb = hidden + (long long)b * T * Hd;
+  for (int t = wave; t < T; t += 4) {
+    double s = 0.0;
+    for (int h = lane; h < Hd; h += 64) s += (double)fmaxf(hb[(long long)t * Hd + h], 0.f) * (double)v[h];
+    s = dlip_wave_sum_f64(s);
+    if (lane == 0) alpha[t] = (float)s + kk[0];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mx = -__builtin_inff();
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, alpha[t]);
+    double se = 0.0;
+    for (int t = 0; t < T; ++t) se += exp((double)(alpha[t] - mx));
+    red[0] = mx;
+    red[1] = (float)se;
+  }
+  __syncthreads();
+  const float mx = red[0];
+  const double se = red[1];
+  for (int t = threadIdx.x; t < T; t += 256) alpha[t] = (float)(exp((double)(alpha[t] - mx)) / se);
+  __syncthreads();
+  const float* xb = x + (long long)b * T * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double m = 0.0, q = 0.0;
+    for (int t = 0; t < T; ++t) {
+      const double xv = xb[(long long)t * C + c], a = alpha[t];
+      m += a * xv;
+      q += a * xv * xv;
+    }
+    y[(long long)b * 2 * C + c] = (float)m;
+    y[(long long)b * 2 * C + C + c] = (float)sqrt(q - m * m);
+  }
+}
+}  // namespace
+
+extern "C" int dlip_attentive_stat_pool_f32(const float* x, const float* hidden, const float* v, const float* k,
+                                            float* y, int32_t B, int32_t T, int32_t C, int32_t Hd,
+                                            dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && hidden && v && k && y && B > 0 && T > 0 && C > 0 && Hd > 0 && T <= 16000);
+  hipLaunchKernelGGL(attentive_stat_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float),
+                     static_cast<hipStream_t>(stream), x, hidden, v, k, y, T, C, Hd);
+  return dlip_launch_status();
+}

@@ -124,6 +124,12 @@ int dlip_group_mean_f32(const float* x, const int32_t* group_ptr, float* y, int3
 int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
                           dlip_stream_t stream);
 
+/* AttentiveStatPooling tail (models/audio_models/pooling.py:87-107) on N-T-C: hidden [B,T,Hd] = x W^T + b
+ * (from dlip_conv_nhwc_f32), e = relu(hidden).v + k, alpha = softmax over T, y [B,2C] = weighted mean |
+ * sqrt(weighted E[x^2] - mean^2). */
+int dlip_attentive_stat_pool_f32(const float* x, const float* hidden, const float* v, const float* k, float* y,
+                                 int32_t B, int32_t T, int32_t C, int32_t Hd, dlip_stream_t stream);
+
 /* Layout adapters at the API boundary.
  *   dlip_nct_to_ntc_f32: x [B,C,T] (reference layout, tdnn.py:89) -> y [B,T,Cp] zero-padded to Cp>=C.
  *   dlip_ntc_to_nct_f32: y [B,C,T] <- x [B,T,C].

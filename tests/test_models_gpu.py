@@ -149,6 +149,8 @@ def test_audio_golden_variants(golden):
     net, _ = load(SpeakerEmbNet(etdnn_opts(80)), "audio80.")
     x80 = torch.from_numpy(wg.audio_input(2, 80, 300, key="input.audio.f80")).to(DEV)
     assert rel_err(net.extract_embedding(x80)[0].cpu().numpy(), g["etdnn80_xv"]) < TOL
+    net, _ = load(SpeakerEmbNet(tdnn_opts(pooling="attentive_statistic")), "audio_at.")
+    assert rel_err(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_attentive_xv"]) < TOL
     net, _ = load(SpeakerEmbNet(tdnn_opts(bn_first=False)), "audio_nb.")
     assert rel_err(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_actfirst_xv"]) < TOL
     assert rel_err(net(x).cpu().numpy(), g["tdnn_actfirst_forward"]) < TOL
