@@ -38,6 +38,7 @@ SIGNATURES = {
     "dlip_conv_nhwc_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_stream],
     "dlip_conv_plan": [C.POINTER(ConvDesc), c_i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "dlip_stem3d_bn_act_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_stem3d_bn_act_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_maxpool3x3s2_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_avgpool_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_time_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],

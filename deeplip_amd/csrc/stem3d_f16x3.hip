@@ -1,0 +1,278 @@
+// Video stem in split-fp16 arithmetic: Conv3d(1 -> 64, 5x7x7, stride (1,2,2), pad (2,3,3)) + folded
+// BN + PReLU/ReLU, output [(B*T), Ho, Wo, 64] fp32 (replaces models/video_models/model.py:81-84, like
+// stem3d.hip).  Products are hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation
+// (see conv_igemm_f16x3.hip for the numerics argument).
+//
+// GEMM view per workgroup: M = 8 output rows x Wo pixels (352 px = 22 tiles of 16), N = 64 channels,
+// K = 36 "kernel rows" (kt, kh) x 8 taps (7 real kw + 1 zero) = 288, walked in 9 steps of 32.
+//   * the 5-frame x 21-row x (W+6)-column input window is split ONCE into (hi, lo) fp16 pairs (one
+//     dword per pixel) while it is staged in LDS;
+//   * a lane's 8 consecutive k of a step are the 8 taps of ONE kernel row = 8 consecutive window
+//     dwords: four ds_read_b64 (8-B aligned because the pixel stride is 2) + eight v_perm_b32 to
+//     de-interleave hi and lo -- no per-tap address arithmetic;
+//   * the 64 x 288 split weights (host-packed, per-channel power-of-two scale, 16-B row padding so
+//     the 16 lanes of a fragment read hit 16 different bank groups) live in LDS for the whole
+//     workgroup: B fragments are two ds_read_b128 per 16-channel tile;
+//   * 8 waves = 8 pixel groups (3,3,3,3,3,3,2,2 tiles), each against all 64 channels: one gathered A
+//     fragment feeds 12 MFMAs (an f16 MFMA leaves only half of its 16 cycles for other issue, and the
+//     de-interleave costs 8 VALU per fragment);
+//   * persistent workgroups (one per CU, 154 KB LDS): weights staged once, the next tile's window is
+//     fetched into registers while the current tile is multiplied and lands in a second LDS buffer.
+#include "dlip_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KT = 5, KH = 7;
+constexpr int KROWS = 36;                 // 35 (kt,kh) kernel rows + 1 zero row
+constexpr int STEPS = KROWS / 4;          // 9 k32 steps (4 kernel rows of 8 taps each)
+constexpr int ROWS = 8;                   // output rows per workgroup
+constexpr int PR = 2 * ROWS + 5;          // 21 input rows
+constexpr int WCH_BYTES = KROWS * 32 + 16;  // 1168 B per output channel: [36][hi 16 B | lo 16 B] + pad
+constexpr int WBYTES = 64 * WCH_BYTES;      // 74752
+constexpr int MTW = 3;                    // pixel tiles per wave (each against all 4 channel tiles)
+
+struct StemArgs {
+  const float* x;
+  const uint32_t* w;   // packed split weights, WBYTES per 64 channels (LDS image)
+  const float* wscale;
+  const float* bias;
+  const float* slope;
+  float* y;
+  int T, H, W, Ho, Wo;
+  int row_tiles;
+  int n_tiles;         // B*T*row_tiles
+  uint32_t x_bytes, y_bytes;
+  int pwp;             // window row pitch in dwords (>= W + 6, == 32 mod 64)
+};
+
+__device__ __forceinline__ uint32_t split_pair(float v) {
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  return (uint32_t)__builtin_bit_cast(unsigned short, h) | ((uint32_t)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
+__global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* wl = lds;                                 // [WBYTES / 4]     split weights, staged once
+  const int plane = PR * a.pwp;
+  const int psize = KT * plane;                       // dwords per window buffer (even)
+  uint32_t* patch0 = lds + WBYTES / 4;                // two window buffers: tile i+1 is fetched while
+  uint32_t* patch1 = patch0 + psize;                  // tile i is multiplied
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  // 22 pixel tiles over 8 waves: waves 0-5 take 3, waves 6-7 take 2; every wave covers all 64 channels,
+  // so one gathered A fragment feeds 12 MFMAs (an f16 MFMA leaves only half its cycles for other issue)
+  const int mt0 = wave < 6 ? wave * 3 : 18 + (wave - 6) * 2;
+  const int mcnt = wave < 6 ? 3 : 2;
+  const int npix = ROWS * a.Wo;
+  constexpr int PPER = 20;                                 // 512 * 20 = 10240 >= 5*21*94 window pixels
+
+  // Persistent workgroup (one per CU): tiles tile0, tile0 + grid, ...; a tile = 8 output rows of a frame.
+  const int ntiles = a.n_tiles, G = gridDim.x;
+  float pv[PPER];
+  // window element e = tid + 512*i  ->  (frame tap ft, window row pr, column pc): tile independent
+  // packed as ft << 16 | pr << 8 | pc (one register each); ft = 15 marks "beyond the window"
+  uint32_t wcode[PPER];
+#pragma unroll
+  for (int i = 0; i < PPER; ++i) {
+    const int e = tid + 512 * i;
+    const int row = e / a.pwp;
+    wcode[i] = ((uint32_t)(e < psize ? row / PR : 15) << 16) | ((uint32_t)(row % PR) << 8) | (uint32_t)(e - row * a.pwp);
+  }
+  const __amdgpu_buffer_rsrc_t xr = dlip_make_rsrc(a.x, a.x_bytes);
+  auto fetch_window = [&](int tile) {   // issue the global loads of a tile's window: branch-free, no waits
+    const int rt = tile % a.row_tiles, f = tile / a.row_tiles, t = f % a.T;
+    const int hi0 = 2 * rt * ROWS - 3;
+    const int clip = (f - t) * a.H * a.W;              // element offset of the clip (fits 32 bits: x < 2 GiB)
+#pragma unroll
+    for (int i = 0; i < PPER; ++i) {
+      const int tt = t + (int)(wcode[i] >> 16) - 2, hi = hi0 + (int)((wcode[i] >> 8) & 255), wi = (int)(wcode[i] & 255) - 3;
+      const bool ok = (unsigned)tt < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const uint32_t off = ok ? (uint32_t)((clip + (tt * a.H + hi) * a.W + wi) * 4) : DLIP_OOB_OFFSET;
+      pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)off, 0, 0));
+    }
+  };
+  auto store_window = [&](uint32_t* patch) {   // split into (hi, lo) pairs and write the LDS window
+#pragma unroll
+    for (int i = 0; i < PPER; ++i) {
+      const int e = tid + 512 * i;
+      if (e < psize) patch[e] = split_pair(pv[i]);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.w);
+    uint4* dst = reinterpret_cast<uint4*>(wl);
+    constexpr int WCHUNKS = WBYTES / 16, WPER = (WCHUNKS + 511) / 512;
+    uint4 wv[WPER];
+#pragma unroll
+    for (int i = 0; i < WPER; ++i) {
+      const int c = tid + 512 * i;
+      wv[i] = c < WCHUNKS ? src[c] : uint4{0, 0, 0, 0};
+    }
+    fetch_window(tile);
+#pragma unroll
+    for (int i = 0; i < WPER; ++i) {
+      const int c = tid + 512 * i;
+      if (c < WCHUNKS) dst[c] = wv[i];
+    }
+    store_window(patch0);
+  }
+
+  int pixoff[MTW];   // dword offset of this lane's pixel (tap kw = 0, kernel row (0,0)) in the window
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    int p = (mt0 + (m < mcnt ? m : 0)) * 16 + li;
+    if (p >= npix) p = 0;
+    const int orow = p / a.Wo, ocol = p - orow * a.Wo;
+    pixoff[m] = 2 * orow * a.pwp + 2 * ocol;
+  }
+  // B fragment byte offsets of this lane for its two 16-channel tiles (kernel row added per step)
+  const int boff = li * WCH_BYTES;                      // channel tile nt adds nt * 16 * WCH_BYTES
+  const char* wl8 = reinterpret_cast<const char*>(wl);
+  const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
+  float inv[4], bias[4], slope[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = j * 16 + li;
+    inv[j] = 1.f / a.wscale[n];
+    bias[j] = a.bias ? a.bias[n] : 0.f;
+    slope[j] = a.slope ? a.slope[n] : 1.f;
+  }
+  __syncthreads();
+
+  for (int it = 0; tile < ntiles; tile += G, ++it) {
+    const uint32_t* patch = (it & 1) ? patch1 : patch0;
+    const int next = tile + G;
+    if (next < ntiles) fetch_window(next);          // in flight during this tile's MFMAs
+
+    f32x4 acc[MTW][4];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Software pipeline: the raw window dwords of pixel tile m+1 (and the weight fragments of step s+1)
+    // are requested from LDS before the MFMAs of tile m are issued.
+    auto a_ptr = [&](int s, int m) {
+      const int rho = 4 * s + kq;                      // kernel row (kt, kh) of this lane quarter
+      const int kt = rho / KH, kh = rho - kt * KH;
+      const int koff = rho < KT * KH ? kt * plane + kh * a.pwp : 0;   // zero row: any valid address
+      return reinterpret_cast<const u32x2*>(patch + koff + pixoff[m]);
+    };
+    u32x2 raw[2][4];
+    f16x8 bfr[1][8];   // [channel tile nt: hi at 2*nt, lo at 2*nt + 1] (single set: 32 VGPRs)
+    auto load_b = [&](int par, int s) {
+      const int rho = 4 * s + kq;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bfr[par][2 * nt] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + rho * 32);
+        bfr[par][2 * nt + 1] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + rho * 32 + 16);
+      }
+    };
+    {
+      const u32x2* p0 = a_ptr(0, 0);
+      raw[0][0] = p0[0]; raw[0][1] = p0[1]; raw[0][2] = p0[2]; raw[0][3] = p0[3];
+    }
+#pragma unroll 1
+    for (int s2 = 0; s2 < STEPS + 1; s2 += 2) {        // two steps per trip so buffer parities are static
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const int s = s2 + ss;
+        if (s < STEPS) {
+          load_b(0, s);
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) {
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = (ss * MTW + m) & 1;         // two steps per trip: parity restarts at 0 each trip
+            // prefetch the next tile's raw dwords (next m, or m = 0 of the next step)
+            if (m + 1 < MTW) {
+              const u32x2* pn = a_ptr(s, m + 1);
+              raw[cur ^ 1][0] = pn[0]; raw[cur ^ 1][1] = pn[1]; raw[cur ^ 1][2] = pn[2]; raw[cur ^ 1][3] = pn[3];
+            } else if (s + 1 < STEPS) {
+              const u32x2* pn = a_ptr(s + 1, 0);
+              raw[cur ^ 1][0] = pn[0]; raw[cur ^ 1][1] = pn[1]; raw[cur ^ 1][2] = pn[2]; raw[cur ^ 1][3] = pn[3];
+            }
+            uint32_t hv[4], lv[4];
+            // dword = hi | lo << 16.  v_perm_b32 byte selectors (src0 = bytes 7..4, src1 = bytes 3..0)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              hv[d] = __builtin_amdgcn_perm(raw[cur][d].y, raw[cur][d].x, 0x05040100u);
+              lv[d] = __builtin_amdgcn_perm(raw[cur][d].y, raw[cur][d].x, 0x07060302u);
+            }
+            u32x4 hq = {hv[0], hv[1], hv[2], hv[3]}, lq = {lv[0], lv[1], lv[2], lv[3]};
+            const f16x8 ah = __builtin_bit_cast(f16x8, hq), al = __builtin_bit_cast(f16x8, lq);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bfr[0][2 * nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bfr[0][2 * nt + 1], acc[m][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bfr[0][2 * nt], acc[m][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // next tile's window -> the other LDS buffer (its last readers finished before the previous barrier)
+    if (next < ntiles) store_window((it & 1) ? patch0 : patch1);
+
+    // C/D map of the 16x16 MFMA: column (channel) = lane & 15, row (pixel) = (lane >> 4)*4 + e.
+    const int rt = tile % a.row_tiles, f = tile / a.row_tiles, ho0 = rt * ROWS;
+    const int ybase = (f * a.Ho + ho0) * a.Wo * 64;     // element offset (y < 2 GiB checked on the host)
+    const int rows_left = a.Ho - ho0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = j * 16 + li;
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int p = (mt0 + m) * 16 + kq * 4 + e;    // pixel index inside the tile = orow*Wo + ocol
+          const bool ok = m < mcnt && p < npix && p < rows_left * a.Wo;
+          float v = acc[m][j][e] * inv[j] + bias[j];
+          v = v >= 0.f ? v : v * slope[j];
+          const uint32_t off = ok ? (uint32_t)((ybase + p * 64 + n) * 4) : DLIP_OOB_OFFSET;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)off, 0, 0);
+        }
+      }
+    }
+    __syncthreads();   // window (it+1) complete and window (it) free before the next iteration
+  }
+}
+
+}  // namespace
+
+extern "C" int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, const float* w_scale,
+                                        const float* bias, const float* slope, float* y, int32_t B, int32_t T,
+                                        int32_t H, int32_t W, int32_t K, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && w_split && w_scale && y && B > 0 && T > 0 && H > 0 && W > 0);
+  DLIP_CHECK_ARG(K == 64 && (H & 1) == 0 && (W & 1) == 0);
+  StemArgs a;
+  a.x = x; a.w = static_cast<const uint32_t*>(w_split); a.wscale = w_scale; a.bias = bias; a.slope = slope; a.y = y;
+  a.T = T; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
+  a.row_tiles = (a.Ho + ROWS - 1) / ROWS;
+  // window row pitch == 32 (mod 64) dwords: the two lane quarters a ds_read_b64 services together read
+  // consecutive kernel rows, which then fall in opposite halves of the 64 LDS banks (conflict-free)
+  a.pwp = ((W + 6 - 32 + 63) / 64) * 64 + 32;
+  DLIP_CHECK_ARG(ROWS * a.Wo <= 22 * 16);   // 22 M tiles per workgroup: frames up to 88 pixels wide
+  DLIP_CHECK_ARG(KT * PR * a.pwp <= 512 * 20);   // window pixels one staging pass covers
+  const long long tiles = (long long)B * T * a.row_tiles;
+  if (tiles > 0x7FFFFFFFll) return DLIP_ERANGE;
+  a.n_tiles = (int)tiles;
+  const long long xb = (long long)B * T * H * W * 4, yb = (long long)B * T * a.Ho * a.Wo * 64 * 4;
+  if (xb > DLIP_MAX_BUFFER_BYTES || yb > DLIP_MAX_BUFFER_BYTES) return DLIP_ERANGE;
+  a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
+  const long long grid = tiles < 256 ? tiles : 256;   // persistent: one workgroup per CU (154 KB of LDS each)
+  const size_t ldsb = (size_t)WBYTES + 2 * (size_t)KT * PR * a.pwp * 4;
+  auto kern = stem3d_f16x3_kernel;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, static_cast<hipStream_t>(stream), a);
+  return dlip_launch_status();
+}

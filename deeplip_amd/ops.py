@@ -121,11 +121,23 @@ def conv1d_ntc(x: Tensor, w_ksc: Tensor, bias: Optional[Tensor] = None, *, dilat
     return y.view(B, y.shape[2], y.shape[3])
 
 
-def stem3d(x_bthw: Tensor, w_248xk: Tensor, bias: Tensor, slope: Optional[Tensor]) -> Tensor:
-    """x [B,T,H,W] -> [(B*T), H/2, W/2, 64] (Conv3d 5x7x7 + folded BN + PReLU/ReLU)."""
-    for t, n in ((x_bthw, "x"), (w_248xk, "w"), (bias, "bias"), (slope, "slope")):
+def stem3d(x_bthw: Tensor, w_248xk: Tensor, bias: Tensor, slope: Optional[Tensor],
+           w_scale: Optional[Tensor] = None) -> Tensor:
+    """x [B,T,H,W] -> [(B*T), H/2, W/2, 64] (Conv3d 5x7x7 + folded BN + PReLU/ReLU).  With ``w_scale``
+    the weights are the split-fp16 image of packing.split_stem_weights (3 x f16 MFMA kernel)."""
+    for t, n in ((x_bthw, "x"), (w_248xk, "w"), (bias, "bias"), (slope, "slope"), (w_scale, "w_scale")):
         _req(t, n)
     B, T, H, W = x_bthw.shape
+    if w_scale is not None:
+        y = torch.empty((B * T, H // 2, W // 2, 64), device=x_bthw.device, dtype=torch.float32)
+        hook = LAUNCH_HOOK
+        if hook is not None:
+            tok = hook.begin("stem3d_f16x3_kernel", 2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
+        check(lib().dlip_stem3d_bn_act_f16x3(ptr(x_bthw), ptr(w_248xk), ptr(w_scale), ptr(bias), ptr(slope), ptr(y),
+                                             B, T, H, W, 64, stream_handle()), "dlip_stem3d_bn_act_f16x3")
+        if hook is not None:
+            hook.end(tok)
+        return y
     K = w_248xk.shape[1]
     if w_248xk.shape[0] != 248:
         raise ValueError("stem3d: weights must be packed [248, K]")

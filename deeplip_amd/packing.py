@@ -119,10 +119,29 @@ def pack_linear(weight, bias, bn, device, slope=None) -> Packed:
     return _finish(w.contiguous(), b, device, slope)
 
 
+def split_stem_weights(w: Tensor):
+    """fp64 [64,1,5,7,7] -> (float32 view of the 64 x 1168-byte LDS image of stem3d_f16x3.hip, scale [64]).
+    Per channel: 36 kernel rows (kt*7+kh, row 35 zero) x [8 hi halves | 8 lo halves] (tap 7 zero) + 16 B pad."""
+    K = w.shape[0]
+    rows = torch.zeros(K, 36, 8, dtype=torch.float64)
+    rows[:, :35, :7] = w.reshape(K, 35, 7)
+    amax = rows.reshape(K, -1).abs().amax(dim=1).clamp_min(1e-30)
+    scale = torch.pow(2.0, torch.floor(torch.log2(1023.0 / amax))).to(torch.float64)
+    ws = rows * scale.view(K, 1, 1)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.to(torch.float64)).to(torch.float16)
+    img = torch.zeros(K, 1168 // 2, dtype=torch.float16)
+    img[:, :36 * 16] = torch.cat([hi, lo], dim=2).reshape(K, 36 * 16)
+    return img.contiguous().view(torch.float32).reshape(-1), scale.to(torch.float32)
+
+
 def pack_stem3d(weight, bn, device, slope=None) -> Packed:
-    """[64,1,5,7,7] -> k-major [248,64] (245 taps + 3 zero rows)."""
+    """[64,1,5,7,7] -> k-major [248,64] (245 taps + 3 zero rows); f16x3: the split LDS image."""
     w, b = fold(weight, None, bn)
     K = w.shape[0]
+    if PRECISION == "f16x3":
+        img, sc = split_stem_weights(w)
+        return Packed(img.to(device), _dev(b, device), slope, wscale=sc.to(device))
     wp = torch.zeros(248, K, dtype=torch.float64)
     wp[:245] = w.reshape(K, 245).t()
     return Packed(_dev(wp, device), _dev(b, device), slope)

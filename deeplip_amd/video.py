@@ -346,7 +346,8 @@ class Lipreading(nn.Module):
                              "deeplip_amd.ops.ingest_rgb_u8 for [B,T,3,H,W] uint8 RGB")
         p = _cached_pack(self, x.device, self._pack)
         x = x.contiguous().float()
-        y = ops.stem3d(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope)   # [(B*T),H/2,W/2,64]
+        y = ops.stem3d(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope,
+                       w_scale=p["stem"].wscale if W <= 88 else None)   # [(B*T),H/2,W/2,64]
         if taps is not None:
             taps["stem_act"] = y
         y = ops.maxpool3x3s2(y)

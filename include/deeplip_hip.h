@@ -99,6 +99,14 @@ int dlip_stem3d_bn_act_f32(const float* x, const float* w_k248, const float* bia
                            float* y, int32_t B, int32_t T, int32_t H, int32_t W, int32_t K,
                            dlip_stream_t stream);
 
+/* Split-fp16 variant of dlip_stem3d_bn_act_f32 (3 x v_mfma_f32_16x16x32_f16 per product, fp32
+ * accumulate; fp32 in / fp32 out).  w_split = 64 x 1168 bytes: per output channel [36 kernel rows
+ * (kt*7+kh; row 35 zero)][8 taps (kw; tap 7 zero)] as 8 hi halves then 8 lo halves, + 16 bytes of
+ * padding, pre-multiplied by the power of two w_scale[k] (deeplip_amd.packing.pack_stem3d).  W <= 88. */
+int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, const float* w_scale, const float* bias,
+                             const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
+                             int32_t K, dlip_stream_t stream);
+
 /* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) on NHWC: [N,H,W,C] -> [N,Ho,Wo,C],
  * Ho = (H+2-3)/2+1.  Replaces models/video_models/model.py:85.  C % 4 == 0. */
 int dlip_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C,

@@ -320,3 +320,18 @@ def test_split_weights_roundtrip():
     rec = (h[..., 0, :] + h[..., 1, :]).reshape(7, 3, 3, 64)[..., :40] / sc.double().view(7, 1, 1, 1)
     assert float(((rec - w).abs() / w.abs().clamp_min(1e-30)).max()) < 2.0 ** -20
     assert float(((rec - w).abs().amax(dim=(1, 2, 3)) / w.abs().amax(dim=(1, 2, 3))).max()) < 2.0 ** -21
+
+
+@pytest.mark.parametrize("B,T,HW", [(2, 7, 88), (1, 3, 24)])
+def test_stem3d_f16x3(ops, B, T, HW):
+    from deeplip_amd import packing
+    x = rnd(B, 1, T, HW, HW, seed=11) * 2.0
+    w = rnd(64, 1, 5, 7, 7, seed=12, scale=1.0 / np.sqrt(245))
+    b = rnd(64, seed=13, scale=0.1)
+    slope = torch.rand(64, generator=torch.Generator().manual_seed(14)) * 0.3
+    ref = F.prelu(F.conv3d(x.double(), w.double(), b.double(), stride=(1, 2, 2), padding=(2, 3, 3)), slope.double())
+    img, sc = packing.split_stem_weights(w.double())
+    y = ops.stem3d(x[:, 0].contiguous().cuda(), img.cuda(), b.cuda(), slope.cuda(), w_scale=sc.cuda())
+    torch.cuda.synchronize()
+    got = y.cpu().view(B, T, HW // 2, HW // 2, 64).permute(0, 4, 1, 2, 3)
+    assert rel_err(got.numpy(), ref.numpy()) < TOL

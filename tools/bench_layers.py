@@ -101,6 +101,18 @@ if not a.only or a.only == 'stem':
     us = e0.elapsed_time(e1) * 1e3 / a.iters
     fl = 2.0 * B * 29 * 44 * 44 * 64 * 245
     print(f"{'stem3d':12s} {us:9.1f} {fl / us / 1e6:8.1f} {fl / 1e9:8.2f}")
+    if a.split:
+        from deeplip_amd import packing
+        img, sc = packing.split_stem_weights(torch.randn(64, 1, 5, 7, 7, dtype=torch.float64) * 0.05)
+        img, sc = img.cuda(), sc.cuda()
+        for _ in range(2):
+            ops.stem3d(x, img, b, sl, w_scale=sc)
+        e0.record()
+        for _ in range(a.iters):
+            ops.stem3d(x, img, b, sl, w_scale=sc)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / a.iters
+        print(f"{'stem3d f16x3':12s} {us:9.1f} {fl / us / 1e6:8.1f} {fl / 1e9:8.2f}")
     for _ in range(2):
         ops.maxpool3x3s2(y)
     e0.record()
