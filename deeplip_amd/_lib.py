@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lock = threading.Lock()
 _lib = None
@@ -35,11 +35,13 @@ class ConvDesc(C.Structure):
 SIGNATURES = {
     "dlip_abi_version": [],
     "dlip_conv_nhwc_f32": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_stream],
-    "dlip_conv_nhwc_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_stream],
+    "dlip_conv_nhwc_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_stream],
+    "dlip_split_pack_f32": [c_f, c_f, C.c_int64, c_i32, c_stream],
+    "dlip_split_unpack_f32": [c_f, c_f, C.c_int64, c_i32, c_stream],
     "dlip_conv_plan": [C.POINTER(ConvDesc), c_i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "dlip_stem3d_bn_act_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem3d_bn_act_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
-    "dlip_maxpool3x3s2_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_maxpool3x3s2_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_avgpool_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_time_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_group_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],

@@ -90,9 +90,11 @@ class TDNN_Block(nn.Module):
         p.post_scale, p.post_shift = sc.float().to(device), sh.float().to(device)
         return p
 
-    def run_ntc(self, x: Tensor, p: packing.Packed) -> Tensor:
+    def run_ntc(self, x: Tensor, p: packing.Packed, x_split: bool = False, out_split: bool = False) -> Tensor:
+        """x [B,T,C] -> [B,T',K]; x_split / out_split: split activation format (f16x3 packing only)."""
         return ops.conv1d_ntc(x, p.w, p.b, dilation=self.dilation, pad=self.padding, slope=p.slope,
-                              post_scale=p.post_scale, post_shift=p.post_shift, w_scale=p.wscale)
+                              post_scale=p.post_scale, post_shift=p.post_shift, w_scale=p.wscale,
+                              x_split=x_split, out_split=out_split)
 
     def forward(self, x: Tensor) -> Tensor:
         """[B,C,T] -> [B,K,T'] (reference layout, standalone use)."""
@@ -163,8 +165,13 @@ class SpeakerEmbNet(nn.Module):
         _require_eval(self)
         p = _cached_pack(self, x.device, self._pack)
         h = self._to_ntc(x)
-        for blk, bp in zip(self.tdnn, p["tdnn"]):
-            h = blk.run_ntc(h, bp)
+        # f16x3 packing: frame-level activations travel between layers as (hi, lo) fp16 pairs, written
+        # by the producing layer's epilogue; the last layer hands fp32 to the pooling kernel.
+        split, n = False, len(self.tdnn)
+        for i, (blk, bp) in enumerate(zip(self.tdnn, p["tdnn"])):
+            nxt = bp.wscale is not None and i + 1 < n and blk.output_dim % 32 == 0
+            h = blk.run_ntc(h, bp, x_split=split, out_split=nxt)
+            split = nxt
         if taps is not None:
             taps["tdnn_out"] = h
         if self.pooling_type == "statistic":

@@ -35,7 +35,12 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// ASPLIT: activations x (and the residual) are already stored as (hi, lo) fp16 pairs -- per pixel and
+// 32-channel block: 32 hi halves then 32 lo halves, the same 128 bytes an fp32 block occupies -- so the
+// A operand is a plain 16-B copy like the weights (no conversion, one ds_write_b128).  OSPLIT: the
+// epilogue writes that format, i.e. each activation is split ONCE by its producer instead of once
+// per filter tap and output-column tile by its consumers.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool ASPLIT, bool OSPLIT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(const ConvArgs a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -115,10 +120,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(const ConvArgs
     float* As = smem + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < A_PER; ++j) {
-      f16x4 hi, lo;
-      split4(ra[SET][j], hi, lo);
-      *reinterpret_cast<f16x4*>(&As[a_hi_off + 32 * j * LDK]) = hi;
-      *reinterpret_cast<f16x4*>(&As[a_lo_off + 32 * j * LDK]) = lo;
+      if constexpr (ASPLIT) {
+        *reinterpret_cast<f32x4*>(&As[b_st_off + 32 * j * LDK]) = ra[SET][j];   // chunk cq -> position cq ^ key
+      } else {
+        f16x4 hi, lo;
+        split4(ra[SET][j], hi, lo);
+        *reinterpret_cast<f16x4*>(&As[a_hi_off + 32 * j * LDK]) = hi;
+        *reinterpret_cast<f16x4*>(&As[a_lo_off + 32 * j * LDK]) = lo;
+      }
     }
   };
   auto store_b = [&](auto SETC, int stage) {
@@ -157,8 +166,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(const ConvArgs
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + (e & 3) + 8 * (e >> 2);
-        const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldr + k) * 4) : DLIP_OOB_OFFSET;
-        acc[mi][ni][e] = (bias + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)off, 0, 0))) * ws;
+        float r;
+        if constexpr (ASPLIT) {   // residual in split format: hi at block*128 + 2*(k%32), lo 64 bytes further
+          const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldr + (k & ~31)) * 4 + (k & 31) * 2) : DLIP_OOB_OFFSET;
+          const _Float16 rh = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rr, (int)off, 0, 0));
+          const _Float16 rl = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rr, (int)off + 64, 0, 0));
+          r = (float)rh + (float)rl;
+        } else {
+          const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldr + k) * 4) : DLIP_OOB_OFFSET;
+          r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)off, 0, 0));
+        }
+        acc[mi][ni][e] = (bias + r) * ws;
       }
     }
   }
@@ -264,22 +282,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(const ConvArgs
         float v = acc[mi][ni][e] * inv;
         v = v >= 0.f ? v : v * slope;
         v = v * psc + psh;
-        const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + k) * 4) : DLIP_OOB_OFFSET;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)off, 0, 0);
+        if constexpr (OSPLIT) {
+          const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + (k & ~31)) * 4 + (k & 31) * 2) : DLIP_OOB_OFFSET;
+          const _Float16 h = (_Float16)v;
+          const _Float16 l = (_Float16)(v - (float)h);
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), yr, (int)off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, l), yr, (int)off + 64, 0, 0);
+          if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keeps the epilogue's live set (and the kernel's VGPR count) small
+        } else {
+          const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + k) * 4) : DLIP_OOB_OFFSET;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)off, 0, 0);
+        }
       }
     }
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-int launch(const ConvArgs& a, hipStream_t st) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool ASPLIT, bool OSPLIT>
+int launch_fmt(const ConvArgs& a, hipStream_t st) {
   ConvArgs b = a;
   const int tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.K + BN - 1) / BN;
   const long long grid = (long long)tiles_m * b.tiles_n;
   if (grid <= 0 || grid > 0x7FFFFFFFll) return DLIP_EINVAL;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * LDK * sizeof(float);
-  auto kern = conv_igemm_f16x3_kernel<BM, BN, WAVES_M, WAVES_N>;
+  auto kern = conv_igemm_f16x3_kernel<BM, BN, WAVES_M, WAVES_N, ASPLIT, OSPLIT>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -288,13 +315,27 @@ int launch(const ConvArgs& a, hipStream_t st) {
   return dlip_launch_status();
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(const ConvArgs& a, hipStream_t st, int flags) {
+  switch (flags & 3) {
+    case 0: return launch_fmt<BM, BN, WAVES_M, WAVES_N, false, false>(a, st);
+    case 1: return launch_fmt<BM, BN, WAVES_M, WAVES_N, true, false>(a, st);
+    case 2: return launch_fmt<BM, BN, WAVES_M, WAVES_N, false, true>(a, st);
+    default: return launch_fmt<BM, BN, WAVES_M, WAVES_N, true, true>(a, st);
+  }
+}
+
 }  // namespace
 
 extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split,
                                     const float* w_scale, const float* bias, const float* residual,
                                     const float* slope, const float* post_scale, const float* post_shift,
-                                    float* y, dlip_stream_t stream) {
+                                    float* y, int32_t flags, dlip_stream_t stream) {
   DLIP_CHECK_ARG(d && w_scale);
+  // flags: DLIP_SPLIT_IN (x and residual hold (hi, lo) pairs; C, ldx, ldr multiples of 32),
+  //        DLIP_SPLIT_OUT (y is written in that format; K, ldy multiples of 32)
+  if (flags & 1) DLIP_CHECK_ARG((d->C & 31) == 0 && (d->ldx & 31) == 0 && (residual == nullptr || ((d->ldr & 31) == 0 && (d->K & 31) == 0)));
+  if (flags & 2) DLIP_CHECK_ARG((d->K & 31) == 0 && (d->ldy & 31) == 0);
   const int Cw = (d->C + 31) / 32 * 32;
   ConvArgs a;
   const int rc = dlip_fill_conv_args(d, x, static_cast<const float*>(w_split), bias, residual, slope, post_scale,
@@ -303,10 +344,10 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   a.wscale = w_scale;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (pick_tile(a.M, d->K, kEffF16x3)) {
-    case 0: return launch<128, 128, 2, 2>(a, st);
-    case 1: return launch<128, 64, 2, 2>(a, st);
-    case 2: return launch<64, 64, 2, 2>(a, st);
-    case 3: return launch<64, 128, 1, 4>(a, st);
-    default: return launch<96, 128, 1, 4>(a, st);
+    case 0: return launch<128, 128, 2, 2>(a, st, flags);
+    case 1: return launch<128, 64, 2, 2>(a, st, flags);
+    case 2: return launch<64, 64, 2, 2>(a, st, flags);
+    case 3: return launch<64, 128, 1, 4>(a, st, flags);
+    default: return launch<96, 128, 1, 4>(a, st, flags);
   }
 }

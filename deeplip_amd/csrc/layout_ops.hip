@@ -96,3 +96,50 @@ extern "C" int dlip_affine_act_f32(const float* x, const float* scale, const flo
                      shift, y, (long long)M * C, C, slope, order);
   return dlip_launch_status();
 }
+
+namespace {
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+// fp32 [rows, C] <-> split format [rows, C/32 blocks, (32 hi halves | 32 lo halves)]  (C % 32 == 0).
+// One thread per 4 channels: 16 B in, 8 B of hi + 8 B of lo out (or the reverse).
+__global__ __launch_bounds__(256) void split_pack_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = x[i];
+    h4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hi[k] = (_Float16)v[k]; lo[k] = (_Float16)(v[k] - (float)hi[k]); }
+    const long long blk = i >> 3; const int q = (int)(i & 7);          // 8 float4 per 32-channel block
+    float* b = y + blk * 32;
+    *reinterpret_cast<h4*>(b + q * 2) = hi;        // halves 4q..4q+3 of the hi half (64 B)
+    *reinterpret_cast<h4*>(b + 16 + q * 2) = lo;   // same position in the lo half
+  }
+}
+__global__ __launch_bounds__(256) void split_unpack_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long blk = i >> 3; const int q = (int)(i & 7);
+    const float* b = x + blk * 32;
+    const h4 hi = *reinterpret_cast<const h4*>(b + q * 2), lo = *reinterpret_cast<const h4*>(b + 16 + q * 2);
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (float)hi[k] + (float)lo[k];
+    y[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int dlip_split_pack_f32(const float* x, float* y, int64_t rows, int32_t C, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && rows > 0 && C > 0 && (C & 31) == 0);
+  const long long n4 = rows * (C / 4);
+  long long g = (n4 + 255) / 256; if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(x), y, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_split_unpack_f32(const float* x, float* y, int64_t rows, int32_t C, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && rows > 0 && C > 0 && (C & 31) == 0);
+  const long long n4 = rows * (C / 4);
+  long long g = (n4 + 255) / 256; if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(split_unpack_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     reinterpret_cast<f32x4*>(y), n4);
+  return dlip_launch_status();
+}

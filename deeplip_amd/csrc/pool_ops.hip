@@ -7,6 +7,7 @@
 namespace {
 
 // MaxPool3d((1,3,3), s(1,2,2), p(0,1,1)) == per-frame MaxPool2d(3, 2, 1); padding never wins.
+template <bool OSPLIT>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
                                                            int N, int H, int W, int C4, int Ho, int Wo) {
   const long long total = (long long)N * Ho * Wo * C4;
@@ -30,7 +31,18 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f32x4* __restri
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    y[i] = m;
+    if constexpr (OSPLIT) {   // (hi, lo) fp16 pairs per 32-channel block for the split-fp16 conv kernels
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      h4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { hi[k] = (_Float16)m[k]; lo[k] = (_Float16)(m[k] - (float)hi[k]); }
+      float* b = reinterpret_cast<float*>(y) + (i >> 3) * 32;
+      const int q = (int)(i & 7);
+      *reinterpret_cast<h4*>(b + q * 2) = hi;
+      *reinterpret_cast<h4*>(b + 16 + q * 2) = lo;
+    } else {
+      y[i] = m;
+    }
   }
 }
 
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ 
   }
 }
 
-inline unsigned grid_for(long long total) {
+static inline unsigned grid_for(long long total) {
   long long g = (total + 255) / 256;
   if (g > 256 * 8) g = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
   if (g < 1) g = 1;
@@ -107,12 +119,16 @@ inline unsigned grid_for(long long total) {
 }  // namespace
 
 extern "C" int dlip_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C,
-                                          dlip_stream_t stream) {
-  DLIP_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0);
+                                          int32_t out_split, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (!out_split || (C & 31) == 0));
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo);
+  if (out_split)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<true>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<false>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo);
   return dlip_launch_status();
 }
 

@@ -41,13 +41,14 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
               post_scale: Optional[Tensor] = None, post_shift: Optional[Tensor] = None,
               out: Optional[Tensor] = None, out_channel_offset: int = 0,
               in_channels: Optional[int] = None, in_channel_offset: int = 0,
-              w_scale: Optional[Tensor] = None) -> Tensor:
+              w_scale: Optional[Tensor] = None, x_split: bool = False, out_split: bool = False) -> Tensor:
     """x [N,H,W,Cx] (NHWC), w [K,R,S,C] -> y [N,Ho,Wo,Ky].
 
     ``out`` / ``out_channel_offset`` write the K result channels into a slice of a wider tensor
     (concat-free multibranch blocks); ``in_channels`` / ``in_channel_offset`` read a slice.
     With ``w_scale`` given, ``w_krsc`` is the split (hi, lo) fp16 packing of packing.split_weights
-    ([K,R,S,C32] float32 view) and the launch goes to the 3 x f16-MFMA kernel."""
+    ([K,R,S,C32] float32 view) and the launch goes to the 3 x f16-MFMA kernel; there ``x_split`` says
+    x and residual hold the split activation format (``split_pack``) and ``out_split`` asks for it."""
     for t, n in ((x, "x"), (w_krsc, "w"), (bias, "bias"), (residual, "residual"), (slope, "slope"),
                  (post_scale, "post_scale"), (post_shift, "post_shift"), (out, "out")):
         _req(t, n)
@@ -75,6 +76,14 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
     for v, n in ((bias, "bias"), (slope, "slope"), (post_scale, "post_scale"), (post_shift, "post_shift")):
         if v is not None and v.numel() != K:
             raise ValueError(f"conv_nhwc: {n} has {v.numel()} elements, expected K={K}")
+    if x_split or out_split:
+        if w_scale is None:
+            raise ValueError("conv_nhwc: the split activation format exists only on the f16x3 path (w_scale)")
+        if x_split and (Cin % 32 or Cx % 32 or in_channel_offset % 32
+                        or (residual is not None and (residual.shape[3] % 32 or K % 32))):
+            raise ValueError("conv_nhwc: split input needs channel counts / offsets in multiples of 32")
+        if out_split and (K % 32 or out.shape[3] % 32 or out_channel_offset % 32):
+            raise ValueError("conv_nhwc: split output needs channel counts / offsets in multiples of 32")
     d = ConvDesc(N, H, W, Cin, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], Ho, Wo,
                  Cx, out.shape[3], residual.shape[3] if residual is not None else 0)
     xp = x.data_ptr() + 4 * in_channel_offset
@@ -87,7 +96,8 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
         tok = hook.begin(f"{kname}<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
     if w_scale is not None:
         check(lib().dlip_conv_nhwc_f16x3(C.byref(d), xp, ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(residual),
-                                         ptr(slope), ptr(post_scale), ptr(post_shift), yp, stream_handle()),
+                                         ptr(slope), ptr(post_scale), ptr(post_shift), yp,
+                                         int(x_split) | 2 * int(out_split), stream_handle()),
               "dlip_conv_nhwc_f16x3")
     else:
         check(lib().dlip_conv_nhwc_f32(C.byref(d), xp, ptr(w_krsc), ptr(bias), ptr(residual), ptr(slope),
@@ -152,11 +162,30 @@ def stem3d(x_bthw: Tensor, w_248xk: Tensor, bias: Tensor, slope: Optional[Tensor
     return y
 
 
-def maxpool3x3s2(x: Tensor) -> Tensor:
+def split_pack(x: Tensor) -> Tensor:
+    """fp32 [..., C] -> split activation format (same shape / dtype container; C % 32 == 0)."""
+    _req(x, "x")
+    y = torch.empty_like(x)
+    Cc = x.shape[-1]
+    check(lib().dlip_split_pack_f32(ptr(x), ptr(y), x.numel() // Cc, Cc, stream_handle()), "dlip_split_pack_f32")
+    return y
+
+
+def split_unpack(x: Tensor) -> Tensor:
+    """Inverse of split_pack (hi + lo in fp32)."""
+    _req(x, "x")
+    y = torch.empty_like(x)
+    Cc = x.shape[-1]
+    check(lib().dlip_split_unpack_f32(ptr(x), ptr(y), x.numel() // Cc, Cc, stream_handle()), "dlip_split_unpack_f32")
+    return y
+
+
+def maxpool3x3s2(x: Tensor, out_split: bool = False) -> Tensor:
     _req(x, "x")
     N, H, W, Cc = x.shape
     y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=torch.float32)
-    check(lib().dlip_maxpool3x3s2_nhwc_f32(ptr(x), ptr(y), N, H, W, Cc, stream_handle()), "dlip_maxpool3x3s2_nhwc_f32")
+    check(lib().dlip_maxpool3x3s2_nhwc_f32(ptr(x), ptr(y), N, H, W, Cc, int(out_split), stream_handle()),
+          "dlip_maxpool3x3s2_nhwc_f32")
     return y
 
 

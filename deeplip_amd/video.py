@@ -86,12 +86,17 @@ class BasicBlock(nn.Module):
             p["down"] = packing.pack_conv2d(self.downsample[0].weight, None, self.downsample[1], device)
         return p
 
-    def run(self, x: Tensor, p: Dict[str, packing.Packed]) -> Tensor:
-        """x NHWC.  conv1+bn1+relu1 | (1x1 s2 conv + bn) | conv2+bn2 + residual + relu2."""
+    def run(self, x: Tensor, p: Dict[str, packing.Packed], split: bool = False, out_split: bool = False) -> Tensor:
+        """x NHWC.  conv1+bn1+relu1 | (1x1 s2 conv + bn) | conv2+bn2 + residual + relu2.
+        ``split``: x is in the split activation format (f16x3 packing only) and so are the block's
+        internal tensors; ``out_split`` keeps the result in it for the next block."""
         s = (self.stride, self.stride)
-        h = ops.conv_nhwc(x, p["conv1"].w, p["conv1"].b, stride=s, pad=(1, 1), slope=p["conv1"].slope, w_scale=p["conv1"].wscale)
-        res = ops.conv_nhwc(x, p["down"].w, p["down"].b, stride=s, w_scale=p["down"].wscale) if "down" in p else x
-        return ops.conv_nhwc(h, p["conv2"].w, p["conv2"].b, pad=(1, 1), residual=res, slope=p["conv2"].slope, w_scale=p["conv2"].wscale)
+        h = ops.conv_nhwc(x, p["conv1"].w, p["conv1"].b, stride=s, pad=(1, 1), slope=p["conv1"].slope,
+                          w_scale=p["conv1"].wscale, x_split=split, out_split=split)
+        res = ops.conv_nhwc(x, p["down"].w, p["down"].b, stride=s, w_scale=p["down"].wscale,
+                            x_split=split, out_split=split) if "down" in p else x
+        return ops.conv_nhwc(h, p["conv2"].w, p["conv2"].b, pad=(1, 1), residual=res, slope=p["conv2"].slope,
+                             w_scale=p["conv2"].wscale, x_split=split, out_split=out_split)
 
 
 class ResNet(nn.Module):
@@ -135,12 +140,25 @@ class ResNet(nn.Module):
     def pack(self, device):
         return [b.pack(device) for b in self.blocks()]
 
-    def run(self, x: Tensor, packed, taps: Optional[dict] = None) -> Tensor:
-        """x [N,H,W,64] NHWC -> [N,512]."""
-        for i, (b, p) in enumerate(zip(self.blocks(), packed)):
-            x = b.run(x, p)
+    @staticmethod
+    def wants_split(packed) -> bool:
+        """True when the packing is split-fp16: the trunk then takes (and keeps) its activations in the
+        split activation format, so each one is split once by its producer."""
+        return packed[0]["conv1"].wscale is not None
+
+    def run(self, x: Tensor, packed, taps: Optional[dict] = None, x_split: bool = False) -> Tensor:
+        """x [N,H,W,64] NHWC (in the split activation format if ``x_split``) -> [N,512]."""
+        split = self.wants_split(packed)
+        if split and not x_split:
+            x = ops.split_pack(x)
+        elif x_split and not split:
+            raise ValueError("ResNet.run: split-format input needs the f16x3 packing")
+        blocks = self.blocks()
+        for i, (b, p) in enumerate(zip(blocks, packed)):
+            last = i == len(blocks) - 1
+            x = b.run(x, p, split=split, out_split=split and not last)   # avgpool reads fp32
             if taps is not None and i % 2 == 1:
-                taps[f"layer{i // 2 + 1}"] = x
+                taps[f"layer{i // 2 + 1}"] = ops.split_unpack(x) if (split and not last) else x
         return ops.avgpool(x)
 
     def forward(self, x: Tensor) -> Tensor:
@@ -350,10 +368,11 @@ class Lipreading(nn.Module):
                        w_scale=p["stem"].wscale if W <= 88 else None)   # [(B*T),H/2,W/2,64]
         if taps is not None:
             taps["stem_act"] = y
-        y = ops.maxpool3x3s2(y)
+        split = self.trunk.wants_split(p["trunk"])
+        y = ops.maxpool3x3s2(y, out_split=split)
         if taps is not None:
-            taps["stem"] = y
-        y = self.trunk.run(y, p["trunk"], taps).view(B, T, self.backend_out)
+            taps["stem"] = ops.split_unpack(y) if split else y
+        y = self.trunk.run(y, p["trunk"], taps, x_split=split).view(B, T, self.backend_out)
         return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
 
     def classifier_features(self, x: Tensor, lengths) -> Tensor:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 4
+#define DLIP_ABI_VERSION 5
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -77,11 +77,24 @@ int dlip_conv_nhwc_f32(const dlip_conv_desc* d, const float* x, const float* w_k
  * fp32 accumulate; ~2^-22 relative, see conv_igemm_f16x3.hip).  `w_split` = weights pre-split by the
  * host into (hi, lo) fp16: [K][R][S][C32/32][2][32] halves with C32 = C rounded up to 32 (zero
  * filled), each output channel k pre-multiplied by the power of two `w_scale[k]` (undone exactly in
- * the epilogue).  x, bias, residual, y are plain fp32 as in dlip_conv_nhwc_f32. */
+ * the epilogue).  bias, slope, post_* are fp32.  With flags = 0, x / residual / y are plain fp32 as
+ * in dlip_conv_nhwc_f32.  DLIP_SPLIT_IN: x and residual are in the *split activation format* -- per
+ * pixel and 32-channel block, 32 hi halves then 32 lo halves (value = hi + lo), i.e. the same 128
+ * bytes and the same ld* (counted in fp32 slots) as the fp32 block they replace; C, ldx, ldr (and K
+ * when a residual is given) must be multiples of 32.  DLIP_SPLIT_OUT: y is written in that format
+ * (K, ldy multiples of 32).  Chains of convolutions then split each activation once, in the
+ * producer's epilogue, instead of once per filter tap in every consumer. */
+#define DLIP_SPLIT_IN 1
+#define DLIP_SPLIT_OUT 2
 int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split,
                          const float* w_scale, const float* bias, const float* residual,
                          const float* slope, const float* post_scale, const float* post_shift,
-                         float* y, dlip_stream_t stream);
+                         float* y, int32_t flags, dlip_stream_t stream);
+
+/* fp32 [rows, C] -> split activation format (and back), C % 32 == 0.  Boundary converters for callers
+ * that hold fp32 tensors; inside the encoders the producers write the split format directly. */
+int dlip_split_pack_f32(const float* x, float* y, int64_t rows, int32_t C, dlip_stream_t stream);
+int dlip_split_unpack_f32(const float* x, float* y, int64_t rows, int32_t C, dlip_stream_t stream);
 
 /* Reports the workgroup tile (BM x BN) dlip_conv_nhwc_f32 (split_f16 = 0) or dlip_conv_nhwc_f16x3
  * (split_f16 = 1) will use for `d` -- i.e. which conv_igemm_*_kernel<BM,BN,..> instance a profiler
@@ -108,9 +121,10 @@ int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, const float* w
                              int32_t K, dlip_stream_t stream);
 
 /* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) on NHWC: [N,H,W,C] -> [N,Ho,Wo,C],
- * Ho = (H+2-3)/2+1.  Replaces models/video_models/model.py:85.  C % 4 == 0. */
+ * Ho = (H+2-3)/2+1.  Replaces models/video_models/model.py:85.  C % 4 == 0.  out_split != 0 writes y
+ * in the split activation format of dlip_conv_nhwc_f16x3 (C % 32 == 0). */
 int dlip_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C,
-                               dlip_stream_t stream);
+                               int32_t out_split, dlip_stream_t stream);
 
 /* AdaptiveAvgPool2d(1) + flatten on NHWC: [N,HW,C] -> [N,C].  Replaces resnet.py:83,125-126. */
 int dlip_avgpool_nhwc_f32(const float* x, float* y, int32_t N, int32_t HW, int32_t C,

@@ -335,3 +335,86 @@ def test_stem3d_f16x3(ops, B, T, HW):
     torch.cuda.synchronize()
     got = y.cpu().view(B, T, HW // 2, HW // 2, 64).permute(0, 4, 1, 2, 3)
     assert rel_err(got.numpy(), ref.numpy()) < TOL
+
+
+def _split_ref(x):
+    """CPU statement of the split activation format: per 32-channel block, 32 hi halves then 32 lo halves."""
+    xs = x.reshape(-1, x.shape[-1] // 32, 32)
+    hi = xs.half()
+    lo = (xs - hi.float()).half()
+    return torch.stack([hi, lo], dim=2).reshape(-1, x.shape[-1] * 2).view(torch.float32).reshape(x.shape)
+
+
+def test_split_pack_unpack(ops):
+    x = rnd(5, 7, 96, seed=21) * torch.logspace(-3, 2, 96)
+    p = ops.split_pack(x.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(p.cpu().view(torch.int32), _split_ref(x).view(torch.int32))      # bit-exact layout
+    u = ops.split_unpack(p).cpu()
+    # hi + lo carries ~22 bits; below ~1e-4 the fp16 subnormal quantum (2^-24) bounds the error instead
+    assert float(((u - x).abs() - 2.0 ** -21 * x.abs()).max()) < 2.0 ** -24
+    with pytest.raises(Exception):
+        ops.split_pack(rnd(4, 40).cuda())                                              # C % 32 != 0
+
+
+SPLIT_FMT_CASES = [c for c in F16X3_CASES if c[3] % 32 == 0 and c[4] % 32 == 0]
+
+
+@pytest.mark.parametrize("fmt", ["in", "out", "inout"])
+@pytest.mark.parametrize("case", SPLIT_FMT_CASES, ids=lambda c: "x".join(str(v) for v in c[:10]))
+def test_conv_nhwc_f16x3_split_formats(ops, case, fmt):
+    """The same convolution with x / residual and / or y in the split activation format must give
+    the fp32-format kernel's result: inputs that are exactly representable as hi + lo make the two
+    paths see identical operands, so the results agree to the last bit of the (hi, lo) output rounding."""
+    from deeplip_amd import packing
+    N, H, W, C, K, R, S, stride, pad, dil, use_res, use_slope = case
+    x = _split_ref_value(rnd(N, H, W, C, seed=1) * 3.0)
+    w = rnd(K, R, S, C, seed=2, scale=1.0 / np.sqrt(C * R * S))
+    b = rnd(K, seed=3, scale=0.1)
+    sh, sw = (1, stride) if H == 1 else (stride, stride)
+    ph, pw = (0, pad) if H == 1 else (pad, pad)
+    dh, dw = (1, dil) if H == 1 else (dil, dil)
+    ws, sc = packing.split_weights(w.double())
+    slope = (torch.rand(K, generator=torch.Generator().manual_seed(5)) * 0.3).cuda() if use_slope else None
+    kw = dict(stride=(sh, sw), pad=(ph, pw), dil=(dh, dw), slope=slope, w_scale=sc.cuda())
+    xd = x.cuda()
+    base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), **kw)                 # shape probe + fp32-format result without residual
+    res = _split_ref_value(rnd(*base.shape, seed=4)).cuda() if use_res else None
+    base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), residual=res, **kw)
+    x_split, out_split = fmt in ("in", "inout"), fmt in ("out", "inout")
+    y = ops.conv_nhwc(ops.split_pack(xd) if x_split else xd, ws.cuda(), b.cuda(),
+                      residual=(ops.split_pack(res) if x_split else res) if res is not None else None,
+                      x_split=x_split, out_split=out_split, **kw)
+    if out_split:
+        y = ops.split_unpack(y)
+    torch.cuda.synchronize()
+    if out_split:
+        assert rel_err(y.cpu().numpy(), base.cpu().numpy()) < 2.0 ** -20
+    else:
+        assert torch.equal(y.cpu(), base.cpu())
+
+
+def _split_ref_value(x):
+    """x rounded to what the split format can hold (hi + lo), so both formats carry identical values."""
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    return hi.float() + lo.float()
+
+
+def test_conv_split_format_rejects_bad_args(ops):
+    from deeplip_amd import packing
+    w = rnd(64, 1, 1, 40, seed=2)
+    ws, sc = packing.split_weights(w.double())
+    x = rnd(1, 1, 8, 40).cuda()
+    with pytest.raises(ValueError):
+        ops.conv_nhwc(x, ws.cuda(), w_scale=sc.cuda(), x_split=True)            # C = 40 is not a multiple of 32
+    with pytest.raises(ValueError):
+        ops.conv_nhwc(rnd(1, 1, 8, 64).cuda(), rnd(64, 1, 1, 64).cuda(), out_split=True)   # fp32 kernel has no split format
+
+
+def test_maxpool_split_output(ops):
+    x = rnd(3, 44, 44, 64, seed=31)
+    y = ops.maxpool3x3s2(x.cuda())
+    ys = ops.maxpool3x3s2(x.cuda(), out_split=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ys.cpu().view(torch.int32), _split_ref(y.cpu()).view(torch.int32))
