@@ -327,6 +327,14 @@ int launch(const ConvArgs& a, hipStream_t st, int flags) {
 
 }  // namespace
 
+extern "C" int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int out_split);   // conv_igemm_f16x3_dma.hip
+
+// Development switch (A/B runs): DLIP_CONV_DMA=0 keeps split-format launches on the register-staged kernel.
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_dma_enabled(void) {
+  static const int on = [] { const char* e = getenv("DLIP_CONV_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on;
+}
+
 extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split,
                                     const float* w_scale, const float* bias, const float* residual,
                                     const float* slope, const float* post_scale, const float* post_shift,
@@ -343,6 +351,7 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   if (rc != DLIP_OK) return rc;
   a.wscale = w_scale;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if ((flags & 1) && dlip_conv_dma_enabled()) return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) != 0);
   switch (pick_tile(a.M, d->K, kEffF16x3)) {
     case 0: return launch<128, 128, 2, 2>(a, st, flags);
     case 1: return launch<128, 64, 2, 2>(a, st, flags);

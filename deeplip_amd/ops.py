@@ -91,8 +91,9 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
     hook = LAUNCH_HOOK
     if hook is not None:
         bm, bn = C.c_int32(), C.c_int32()
-        check(lib().dlip_conv_plan(C.byref(d), int(w_scale is not None), C.byref(bm), C.byref(bn)), "dlip_conv_plan")
-        kname = "conv_igemm_f16x3_kernel" if w_scale is not None else "conv_igemm_f32_kernel"
+        mode = 0 if w_scale is None else (3 if x_split else 1)
+        check(lib().dlip_conv_plan(C.byref(d), mode, C.byref(bm), C.byref(bn)), "dlip_conv_plan")
+        kname = ("conv_igemm_f32_kernel", "conv_igemm_f16x3_kernel", "", "conv_igemm_f16x3_dma_kernel")[mode]
         tok = hook.begin(f"{kname}<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
     if w_scale is not None:
         check(lib().dlip_conv_nhwc_f16x3(C.byref(d), xp, ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(residual),

@@ -96,9 +96,10 @@ int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_
 int dlip_split_pack_f32(const float* x, float* y, int64_t rows, int32_t C, dlip_stream_t stream);
 int dlip_split_unpack_f32(const float* x, float* y, int64_t rows, int32_t C, dlip_stream_t stream);
 
-/* Reports the workgroup tile (BM x BN) dlip_conv_nhwc_f32 (split_f16 = 0) or dlip_conv_nhwc_f16x3
- * (split_f16 = 1) will use for `d` -- i.e. which conv_igemm_*_kernel<BM,BN,..> instance a profiler
- * will show.  Host-only, no launch. */
+/* Reports the workgroup tile (BM x BN) dlip_conv_nhwc_f32 (split_f16 = 0), dlip_conv_nhwc_f16x3 on
+ * fp32 activations (split_f16 = 1) or on split-format activations (split_f16 = 3: the LDS-DMA
+ * kernel) will use for `d` -- i.e. which conv_igemm_*_kernel<BM,BN,..> instance a profiler will
+ * show.  Host-only, no launch. */
 int dlip_conv_plan(const dlip_conv_desc* d, int32_t split_f16, int32_t* bm, int32_t* bn);
 
 /* ------------------------------------------------------------------------------------------
