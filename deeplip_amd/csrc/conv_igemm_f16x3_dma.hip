@@ -23,6 +23,9 @@
 // MFMA program order, fragment layout, accumulator initialisation and epilogue are those of
 // conv_igemm_f16x3.hip.
 #include "conv_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -59,8 +62,24 @@ __device__ __forceinline__ void dma_piece(const u32x4 rsrc, uint32_t voff, uint3
       : "memory");   // m0 is reserved: hipcc keeps nothing in it across statements (the ISA dump shows no other m0 use)
 }
 
+// Balanced ("stream-K") work split: the launch's reduction work = tiles x nk slices is cut into G equal
+// contiguous ranges, one per workgroup, G = the number of workgroups the chip holds at once.  A range
+// covers whole tiles plus at most one partial tile at each end; a workgroup that computed only some
+// slices of a tile stores its fp32 accumulators as a slab and takes a ticket on the tile's counter;
+// the workgroup drawing the last ticket adds the other slabs (in part order) and runs the epilogue.
+// Nobody waits for anybody, so residency and dispatch order cannot deadlock it; visibility follows the
+// agent-scope release / acquire counter recipe (slab stores -> vmcnt(0) -> barrier -> release fence ->
+// ticket; last ticket -> acquire fence -> barrier -> plain slab loads).  With G = tiles every range
+// is exactly one tile and no slab is ever written (the plain data-parallel launch).
+struct StreamK {
+  long long iters;   // tiles * nk
+  float* slabs;      // [2 * G][BM * BN] fp32
+  int* counters;     // [tiles], zero between launches (the last arriver resets its tile's word)
+  int G;             // workgroups in the grid
+};
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool OSPLIT, int NSTAGE, int OCC>
-__global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_dma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_dma_kernel(const ConvArgs a, const StreamK sk) {
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int RPP = NT / 8;   // rows one pass of the workgroup covers (8 lanes x 16 B per row)
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be whole passes");
@@ -71,13 +90,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   constexpr int NL = A_PER + B_PER;   // DMA instructions per wave per slice
   constexpr int STAGE_B = (BM + BN) * ROWB;
   constexpr int LDK = 32;             // dwords per LDS row
+  constexpr int PF = NSTAGE - 1;      // slices in flight ahead of the one being multiplied
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tile_n = swz % a.tiles_n;
-  const int tile_m = swz / a.tiles_n;
+  const int g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // neighbours in work order share an XCD (L2)
 
   const int tid = threadIdx.x;
   const int cq = tid & 7;
@@ -86,67 +104,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const int csrc = ((cq ^ key_st) << 2);        // first channel (dword) of the chunk this lane fetches
   const u32x4 xr = make_rsrc_words(a.x, a.x_bytes);
   const u32x4 wr = make_rsrc_words(a.w, a.w_bytes);
-
-  int a_off[A_PER];
-  uint32_t a_mask[A_PER];
-#pragma unroll
-  for (int j = 0; j < A_PER; ++j) {
-    const int m = tile_m * BM + rbase + RPP * j;
-    a_off[j] = 0;
-    a_mask[j] = 0u;
-    if (m < a.M) {
-      const int n = m / a.HoWo;
-      const int rem = m - n * a.HoWo;
-      const int ho = rem / a.Wo;
-      const int wo = rem - ho * a.Wo;
-      const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
-      a_off[j] = (((n * a.H + hi0) * a.W + wi0) * a.ldx + csrc) * 4;
-      uint32_t mk = 0u;
-      for (int r = 0; r < a.R; ++r)
-        for (int s = 0; s < a.S; ++s)
-          if ((unsigned)(hi0 + r * a.dh) < (unsigned)a.H && (unsigned)(wi0 + s * a.dw) < (unsigned)a.W)
-            mk |= 1u << (r * a.S + s);
-      a_mask[j] = mk;
-    }
-  }
-  int b_off[B_PER];
-#pragma unroll
-  for (int j = 0; j < B_PER; ++j) {
-    const int n = tile_n * BN + rbase + RPP * j;
-    b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
-  }
+  const __amdgpu_buffer_rsrc_t rr = dlip_make_rsrc(a.res, a.res ? a.r_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t piece0 = lds0 + wave * 8 * ROWB;   // this wave's 8 rows of pass 0, stage 0, operand A
-
-  int tap = 0, x_tap = 0, w_tap = 0, c0 = 0;
-  int s_pos = 0, x_row = 0;
-  const int x_dr = a.dh * a.W * a.ldx * 4, x_ds = a.dw * a.ldx * 4;
-  const int ntaps = a.R * a.S;
-  // Reduction walk: 32-channel slice OUTER, filter tap INNER (conv_igemm_f16x3.hip).
-  auto advance = [&]() {
-    ++tap;
-    if (++s_pos == a.S) { s_pos = 0; x_row += x_dr; }
-    if (tap == ntaps) { tap = 0; s_pos = 0; x_row = 0; c0 += BK; }
-    x_tap = x_row + s_pos * x_ds + c0 * 4;
-    w_tap = (tap * a.Cw + c0) * 4;
-  };
-  auto issue_a = [&](int stage) {
-    const uint32_t base = piece0 + stage * STAGE_B;
-#pragma unroll
-    for (int j = 0; j < A_PER; ++j) {
-      const bool ok = (a_mask[j] >> tap) & 1u;
-      dma_piece(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
-    }
-  };
-  auto issue_b = [&](int stage) {
-    const uint32_t base = piece0 + stage * STAGE_B + BM * ROWB;
-#pragma unroll
-    for (int j = 0; j < B_PER; ++j)
-      dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
-  };
-
   const int lane = tid & 63;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int lrow = lane & 31, half = lane >> 5;
@@ -160,131 +123,327 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     khi[s] = ((2 * s + half) ^ key_rd) << 2;
     klo[s] = ((4 + 2 * s + half) ^ key_rd) << 2;
   }
+  const int x_dr = a.dh * a.W * a.ldx * 4, x_ds = a.dw * a.ldx * 4;
+  const int ntaps = a.R * a.S;
 
-  // ---- prologue: put the first NSTAGE-1 slices in flight, then initialise the accumulators ----
-  constexpr int PF = NSTAGE - 1;
-  issue_a(0);
-  issue_b(0);
-  if (PF > 1 && a.nk > 1) {
-    advance();
-    issue_a(1);
-    issue_b(1);
-  }
+  const long long it_begin = (long long)g * sk.iters / sk.G, it_end = (long long)(g + 1) * sk.iters / sk.G;
+  for (long long it = it_begin; it < it_end;) {
+    const int tile = (int)(it / a.nk);
+    const int k0 = (int)(it - (long long)tile * a.nk);
+    const int kn = (int)((it_end - it) < (long long)(a.nk - k0) ? (it_end - it) : (long long)(a.nk - k0));
+    const int tile_n = tile % a.tiles_n;
+    const int tile_m = tile / a.tiles_n;
+    // every wave is done reading the previous segment's last stage (and the ticket word) before the ring is refilled
+    if (it != it_begin) __syncthreads();
 
-  // accumulators = (bias + residual) * wscale[k]   (the weight scale is undone in the epilogue)
-  const __amdgpu_buffer_rsrc_t rr = dlip_make_rsrc(a.res, a.res ? a.r_bytes : 0u);
-  f32x16 acc[MI][NI];
+    int a_off[A_PER];
+    uint32_t a_mask[A_PER];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int k = tile_n * BN + wn * WN + ni * 32 + lrow;
-    const bool kok = k < a.K;
-    const float bias = (kok && a.bias) ? a.bias[k] : 0.f;
-    const float ws = kok ? a.wscale[k] : 1.f;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m0 = tile_m * BM + wm * WM + mi * 32 + rquad;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + (e & 3) + 8 * (e >> 2);
-        const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldr + (k & ~31)) * 4 + (k & 31) * 2) : DLIP_OOB_OFFSET;
-        const _Float16 rh = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rr, (int)off, 0, 0));
-        const _Float16 rl = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rr, (int)off + 64, 0, 0));
-        acc[mi][ni][e] = (bias + ((float)rh + (float)rl)) * ws;
+    for (int j = 0; j < A_PER; ++j) {
+      const int m = tile_m * BM + rbase + RPP * j;
+      a_off[j] = 0;
+      a_mask[j] = 0u;
+      if (m < a.M) {
+        const int n = m / a.HoWo;
+        const int rem = m - n * a.HoWo;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+        a_off[j] = (((n * a.H + hi0) * a.W + wi0) * a.ldx + csrc) * 4;
+        uint32_t mk = 0u;
+        for (int r = 0; r < a.R; ++r)
+          for (int s = 0; s < a.S; ++s)
+            if ((unsigned)(hi0 + r * a.dh) < (unsigned)a.H && (unsigned)(wi0 + s * a.dw) < (unsigned)a.W)
+              mk |= 1u << (r * a.S + s);
+        a_mask[j] = mk;
       }
     }
-  }
+    int b_off[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+      const int n = tile_n * BN + rbase + RPP * j;
+      b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
+    }
 
-  f16x8 fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];
-  auto read_frags = [&](int set, int stage, int s) {
-    const float* Aw = smem + stage * (STAGE_B / 4) + a_frag;
-    const float* Bw = smem + stage * (STAGE_B / 4) + b_frag;
+    // Reduction walk: 32-channel slice OUTER, filter tap INNER (conv_igemm_f16x3.hip), entered at slice k0.
+    int c0 = (k0 / ntaps) * BK, tap = k0 % ntaps;
+    int s_pos = tap % a.S, x_row = (tap / a.S) * x_dr;
+    int x_tap = x_row + s_pos * x_ds + c0 * 4, w_tap = (tap * a.Cw + c0) * 4;
+    auto advance = [&]() {
+      ++tap;
+      if (++s_pos == a.S) { s_pos = 0; x_row += x_dr; }
+      if (tap == ntaps) { tap = 0; s_pos = 0; x_row = 0; c0 += BK; }
+      x_tap = x_row + s_pos * x_ds + c0 * 4;
+      w_tap = (tap * a.Cw + c0) * 4;
+    };
+    auto issue_a = [&](int stage) {
+      const uint32_t base = piece0 + stage * STAGE_B;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      fah[set][mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 32 * LDK + khi[s]);
-      fal[set][mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 32 * LDK + klo[s]);
+      for (int j = 0; j < A_PER; ++j) {
+        const bool ok = (a_mask[j] >> tap) & 1u;
+        dma_piece(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+      }
+    };
+    auto issue_b = [&](int stage) {
+      const uint32_t base = piece0 + stage * STAGE_B + BM * ROWB;
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j)
+        dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+    };
+
+    // ---- prologue: put the first NSTAGE-1 slices in flight, then initialise the accumulators ----
+    issue_a(0);
+    issue_b(0);
+    if (PF > 1 && kn > 1) {
+      advance();
+      issue_a(1);
+      issue_b(1);
     }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      fbh[set][ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 32 * LDK + khi[s]);
-      fbl[set][ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 32 * LDK + klo[s]);
-    }
-  };
-  // g = 0: lo*hi, 1: hi*lo, 2: hi*hi  (small terms first)
-  auto mfma_g = [&](int set, int g) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+
+    // the tile's first slices start from (bias + residual) * wscale[k] (the weight scale is undone in the
+    // epilogue); later parts of a split tile start from zero
+    f32x16 acc[MI][NI];
+    if (k0 == 0) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        const f16x8 av = g == 0 ? fal[set][mi] : fah[set][mi];
-        const f16x8 bv = g == 1 ? fbl[set][ni] : fbh[set][ni];
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[mi][ni], 0, 0, 0);
+        const int k = tile_n * BN + wn * WN + ni * 32 + lrow;
+        const bool kok = k < a.K;
+        const float bias = (kok && a.bias) ? a.bias[k] : 0.f;
+        const float ws = kok ? a.wscale[k] : 1.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m0 = tile_m * BM + wm * WM + mi * 32 + rquad;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = m0 + (e & 3) + 8 * (e >> 2);
+            const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldr + (k & ~31)) * 4 + (k & 31) * 2) : DLIP_OOB_OFFSET;
+            const _Float16 rh = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rr, (int)off, 0, 0));
+            const _Float16 rl = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rr, (int)off + 64, 0, 0));
+            acc[mi][ni][e] = (bias + ((float)rh + (float)rl)) * ws;
+          }
+        }
       }
-  };
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    }
+
+    f16x8 fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];
+    auto read_frags = [&](int set, int stage, int s) {
+      const float* Aw = smem + stage * (STAGE_B / 4) + a_frag;
+      const float* Bw = smem + stage * (STAGE_B / 4) + b_frag;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        fah[set][mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 32 * LDK + khi[s]);
+        fal[set][mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 32 * LDK + klo[s]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        fbh[set][ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 32 * LDK + khi[s]);
+        fbl[set][ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 32 * LDK + klo[s]);
+      }
+    };
+    // g = 0: lo*hi, 1: hi*lo, 2: hi*hi  (small terms first)
+    auto mfma_g = [&](int set, int grp) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const f16x8 av = grp == 0 ? fal[set][mi] : fah[set][mi];
+          const f16x8 bv = grp == 1 ? fbl[set][ni] : fbh[set][ni];
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[mi][ni], 0, 0, 0);
+        }
+    };
 #define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-  // slice 0 has landed once at most the (PF - 1) younger slices are outstanding
-  if (PF > 1 && a.nk > 1) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  read_frags(0, 0, 0);
+    // slice 0 has landed once at most the (PF - 1) younger slices are outstanding
+    if (PF > 1 && kn > 1) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0);
 
-  int st_cur = 0, st_iss = (PF > 1 && a.nk > 1) ? 2 % NSTAGE : 1 % NSTAGE;   // stage the next issue goes to
-  for (int kt = 0; kt < a.nk; ++kt) {
-    const bool more1 = (kt + 1) < a.nk, moreP = (kt + PF) < a.nk;
-    const int st_nxt = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
-    // ---- k16 step 0 (fragment set 0) ----
-    mfma_g(0, 0); DLIP_FENCE();
-    read_frags(1, st_cur, 1); DLIP_FENCE();
-    mfma_g(0, 1); DLIP_FENCE();
-    if (moreP) { advance(); issue_a(st_iss); } DLIP_FENCE();
-    mfma_g(0, 2); DLIP_FENCE();
-    if (moreP) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
-    // ---- k16 step 1 (fragment set 1) ----
-    mfma_g(1, 0); DLIP_FENCE();
-    mfma_g(1, 1); DLIP_FENCE();
-    if (more1) {
-      // slice kt+1 must have landed (every wave's share: wait, then barrier); slices beyond it stay in flight
-      if (PF > 1 && (kt + 2) < a.nk) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      read_frags(0, st_nxt, 0);
+    int st_cur = 0, st_iss = (PF > 1 && kn > 1) ? 2 % NSTAGE : 1 % NSTAGE;   // stage the next issue goes to
+    for (int kt = 0; kt < kn; ++kt) {
+      const bool more1 = (kt + 1) < kn, moreP = (kt + PF) < kn;
+      const int st_nxt = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
+      // ---- k16 step 0 (fragment set 0) ----
+      mfma_g(0, 0); DLIP_FENCE();
+      read_frags(1, st_cur, 1); DLIP_FENCE();
+      mfma_g(0, 1); DLIP_FENCE();
+      if (moreP) { advance(); issue_a(st_iss); } DLIP_FENCE();
+      mfma_g(0, 2); DLIP_FENCE();
+      if (moreP) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
+      // ---- k16 step 1 (fragment set 1) ----
+      mfma_g(1, 0); DLIP_FENCE();
+      mfma_g(1, 1); DLIP_FENCE();
+      if (more1) {
+        // slice kt+1 must have landed (every wave's share: wait, then barrier); slices beyond it stay in flight
+        if (PF > 1 && (kt + 2) < kn) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, st_nxt, 0);
+      }
+      DLIP_FENCE();
+      mfma_g(1, 2); DLIP_FENCE();
+      st_cur = st_nxt;
     }
-    DLIP_FENCE();
-    mfma_g(1, 2); DLIP_FENCE();
-    st_cur = st_nxt;
-  }
 #undef DLIP_FENCE
 
-  const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
+    // Lane coordinates re-derived behind an opaque asm: otherwise the compiler hoists every address of the
+    // hand-off and epilogue code (invariant across segments) out of the segment loop and carries ~100
+    // values through the MFMA loop in scratch.
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, lrow_e = tid_e & 31, half_e = (tid_e >> 5) & 1;
+
+    bool finish = true;
+    if (kn != a.nk) {   // split tile (workgroup-uniform branch)
+      constexpr int SLAB = BM * BN;   // floats
+      volatile int* bcast = reinterpret_cast<volatile int*>(smem);
+      const long long t0 = (long long)tile * a.nk;
+      const int gf = (int)(((t0 + 1) * sk.G - 1) / sk.iters);            // owner of the tile's first slice
+      const int gl = (int)(((t0 + a.nk) * sk.G - 1) / sk.iters);         // owner of its last slice
+      const int others = gl - gf;                                        // parts besides this one
+      // 1. peek: if every other part has already published, this workgroup is the last one and keeps its
+      //    part in registers (the usual case for a range's final, head-of-tile segment: the neighbour
+      //    computed the rest of that tile first thing).
+      __syncthreads();   // all waves are past their last fragment reads: LDS word 0 is free
+      if (tid_e == 0) bcast[0] = __hip_atomic_load(sk.counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      finish = bcast[0] == others;
+      if (!finish) {
+        // 2. publish: write-through (sc1) slab stores, drained by every storing wave, then ONE ticket
+        const __amdgpu_buffer_rsrc_t sr = dlip_make_rsrc(sk.slabs + (size_t)(2 * g + (it != it_begin ? 1 : 0)) * SLAB, SLAB * 4);
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int k = tile_n * BN + wn * WN + ni * 32 + lrow;
-    const bool kok = k < a.K;
-    const float inv = kok ? 1.f / a.wscale[k] : 1.f;   // power of two: exact
-    const float slope = (kok && a.slope) ? a.slope[k] : 1.f;
-    const float psc = (kok && a.pscale) ? a.pscale[k] : 1.f;
-    const float psh = (kok && a.pshift) ? a.pshift[k] : 0.f;
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m0 = tile_m * BM + wm * WM + mi * 32 + rquad;
+          for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + (e & 3) + 8 * (e >> 2);
-        float v = acc[mi][ni][e] * inv;
-        v = v >= 0.f ? v : v * slope;
-        v = v * psc + psh;
-        if constexpr (OSPLIT) {
-          const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + (k & ~31)) * 4 + (k & 31) * 2) : DLIP_OOB_OFFSET;
-          const _Float16 h = (_Float16)v;
-          const _Float16 l = (_Float16)(v - (float)h);
-          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), yr, (int)off, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, l), yr, (int)off + 64, 0, 0);
-          if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        } else {
-          const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + k) * 4) : DLIP_OOB_OFFSET;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)off, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v;   // (bit_cast straight from a vector-element lvalue reads element 0: copy out first)
+              v[0] = acc[mi][ni][4 * q]; v[1] = acc[mi][ni][4 * q + 1]; v[2] = acc[mi][ni][4 * q + 2]; v[3] = acc[mi][ni][4 * q + 3];
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sr, (((mi * NI + ni) * 4 + q) * NT + tid_e) * 16, 0, 16);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid_e == 0) bcast[0] = __hip_atomic_fetch_add(sk.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        finish = bcast[0] == others;   // the other parts arrived between the peek and the ticket
+      }
+      if (finish) {
+        if (tid_e == 0) __hip_atomic_store(sk.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the slab loads below the poll
+        // sum the parts in part order (own part from registers): the bits do not depend on who came last;
+        // every slab load is sc1 (served past this CU's L1), matching the sc1 stores
+        f32x16 tot[MI][NI];
+        for (int p = gf; p <= gl; ++p) {
+          const long long pb = (long long)p * sk.iters / sk.G;
+          const __amdgpu_buffer_rsrc_t pr = dlip_make_rsrc(sk.slabs + (size_t)(2 * p + (pb < t0 ? 1 : 0)) * SLAB, SLAB * 4);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+                if (p == g) {
+                  v[0] = acc[mi][ni][4 * q]; v[1] = acc[mi][ni][4 * q + 1]; v[2] = acc[mi][ni][4 * q + 2]; v[3] = acc[mi][ni][4 * q + 3];
+                } else {
+                  v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, (((mi * NI + ni) * 4 + q) * NT + tid_e) * 16, 0, 16));
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) tot[mi][ni][4 * q + c] = p == gf ? v[c] : tot[mi][ni][4 * q + c] + v[c];
+                __builtin_amdgcn_sched_barrier(0);
+              }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = tot[mi][ni];
+      }
+    }
+
+    if (finish) {
+      const int rquad_e = half_e * 4;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int k = tile_n * BN + wn * WN + ni * 32 + lrow_e;
+        const bool kok = k < a.K;
+        const float inv = kok ? 1.f / a.wscale[k] : 1.f;   // power of two: exact
+        const float slope = (kok && a.slope) ? a.slope[k] : 1.f;
+        const float psc = (kok && a.pscale) ? a.pscale[k] : 1.f;
+        const float psh = (kok && a.pshift) ? a.pshift[k] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m0 = tile_m * BM + wm * WM + mi * 32 + rquad_e;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int m = m0 + (e & 3) + 8 * (e >> 2);
+            float v = acc[mi][ni][e] * inv;
+            v = v >= 0.f ? v : v * slope;
+            v = v * psc + psh;
+            if constexpr (OSPLIT) {
+              const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + (k & ~31)) * 4 + (k & 31) * 2) : DLIP_OOB_OFFSET;
+              const _Float16 h = (_Float16)v;
+              const _Float16 l = (_Float16)(v - (float)h);
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), yr, (int)off, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, l), yr, (int)off + 64, 0, 0);
+              if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            } else {
+              const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + k) * 4) : DLIP_OOB_OFFSET;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)off, 0, 0);
+            }
+          }
         }
       }
     }
+    it += kn;
   }
+}
+
+// Per-stream workspace of the balanced split: slabs + ticket counters (zeroed once; every launch leaves
+// them zero).  Launches on one stream are ordered, so they can share it; another stream gets its own.
+struct Workspace {
+  float* slabs = nullptr;
+  int* counters = nullptr;
+  size_t slab_floats = 0;
+};
+constexpr int kMaxSplitTiles = 1 << 16;   // counter words per workspace
+constexpr double kSlotFlops = 0.85e12;    // algorithmic FLOP/s one resident 128x128 workgroup sustains (measured, 2 per CU)
+constexpr double kHandoffUs = 10.0;       // cost of the slab hand-off of a launch at 128x128 tiles (measured)
+
+Workspace* workspace_for(hipStream_t st, size_t slab_floats) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Workspace> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Workspace& w = table[{dev, st}];
+  if (w.counters == nullptr) {
+    if (hipMalloc(reinterpret_cast<void**>(&w.counters), kMaxSplitTiles * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(w.counters, 0, kMaxSplitTiles * sizeof(int)) != hipSuccess) return nullptr;
+  }
+  if (w.slab_floats < slab_floats) {
+    if (w.slabs) {   // earlier launches on this stream may still read the old block
+      if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+      (void)hipFree(w.slabs);
+      w.slabs = nullptr;
+      w.slab_floats = 0;
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&w.slabs), slab_floats * sizeof(float)) != hipSuccess) return nullptr;
+    w.slab_floats = slab_floats;
+  }
+  return &w;
+}
+
+int resident_workgroups(const void* kern, int threads, size_t lds) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess) return 0;
+  return cus * per_cu;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int OCC>
@@ -292,9 +451,10 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
   ConvArgs b = a;
   const int tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.K + BN - 1) / BN;
-  const long long grid = (long long)tiles_m * b.tiles_n;
-  if (grid <= 0 || grid > 0x7FFFFFFFll) return DLIP_EINVAL;
+  const long long tiles = (long long)tiles_m * b.tiles_n;
+  if (tiles <= 0 || tiles > 0x7FFFFFFFll) return DLIP_EINVAL;
   constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB;
+  constexpr int threads = 64 * WAVES_M * WAVES_N;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds a CU");
   auto kern = out_split ? conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, true, NSTAGE, OCC>
                         : conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, false, NSTAGE, OCC>;
@@ -302,40 +462,64 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WAVES_M * WAVES_N), lds, st, b);
+  // One slot table per kernel instance (the occupancy query is not free).
+  static int slots[2] = {0, 0};
+  int& sl = slots[out_split ? 1 : 0];
+  if (sl == 0) sl = resident_workgroups(reinterpret_cast<const void*>(kern), threads, lds);
+  if (sl <= 0) return DLIP_EINVAL;
+
+  StreamK sk;
+  sk.iters = tiles * a.nk;
+  sk.slabs = nullptr;
+  sk.counters = nullptr;
+  long long G = tiles;                                  // plain launch: one tile per workgroup
+  static const int balanced = [] { const char* e = getenv("DLIP_CONV_STREAMK"); return e ? atoi(e) : 1; }();   // 0 never, 2 always
+  if (balanced && tiles <= kMaxSplitTiles) {
+    // Plain: ceil(tiles / slots) rounds of one tile-time.  Balanced: tiles / slots tile-times plus the
+    // slab hand-off (one slab written and read per workgroup, all the reads at the very end).
+    const double tile_us = 2.0 * BM * BN * 32.0 * a.nk / (kSlotFlops * 1e-6);
+    const double plain_us = (double)((tiles + sl - 1) / sl) * tile_us;
+    long long Gb = sl;
+    if (sk.iters < 4 * Gb) Gb = sk.iters / 4 > 0 ? sk.iters / 4 : 1;   // keep at least 4 slices per workgroup
+    const double bal_us = (double)sk.iters / Gb / a.nk * tile_us + kHandoffUs * (BM * BN / 16384.0);
+    if ((balanced == 2 || bal_us < plain_us) && Gb * a.nk != sk.iters) G = Gb;
+  }
+  if (G != tiles) {
+    Workspace* w = workspace_for(st, (size_t)2 * G * BM * BN);
+    if (w == nullptr) return DLIP_EINVAL;
+    sk.slabs = w->slabs;
+    sk.counters = w->counters;
+  }
+  sk.G = (int)G;
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(threads), lds, st, b, sk);
   return dlip_launch_status();
 }
 
 }  // namespace
 
 // Tile menu of the DMA kernel (index = what dlip_conv_plan reports via dlip_conv_dma_tile).
-const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128},
-                           {128, 128}, {256, 128}, {128, 256}, {256, 64}, {128, 128}};   // 5..9: experiments (env only)
-constexpr int NUM_DMA_CFG = 5, NUM_DMA_ALL = 10;
-const float kDmaEff[NUM_DMA_CFG] = {1.00f, 0.85f, 0.85f, 0.70f, 1.05f};
+const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64},
+                           {256, 128}, {128, 128}, {256, 128}, {128, 256}, {256, 64}, {128, 128}};   // 4..9: experiments (DLIP_CONV_DMA_TILE only)
+constexpr int NUM_DMA_ALL = 10;
 
-static int dma_pick(long long M, int K) {
+// Tile choice (measured per layer with tools/bench_dma.py, MI355X, balanced split on): 128x128 is the
+// steady-state winner whenever the tile is deep enough to amortise its set-up; narrow outputs (K <= 64)
+// and short reductions (nk <= 16 slices: 1x1 convolutions, small Linear layers) do better on 128x64
+// with its three-stage ring; M <= 64 (fully connected layers on a batch) uses the 64-row tiles.
+static int dma_pick(long long M, int K, int nk) {
   if (const char* e = getenv("DLIP_CONV_DMA_TILE")) {
     const int v = atoi(e);
     if (v >= 0 && v < NUM_DMA_ALL) return v;
   }
-  int best = 0;
-  double best_cost = 1e300;
-  for (int i = 0; i < NUM_DMA_CFG; ++i) {
-    const TileCfg& c = kDmaCfg[i];
-    const long long tiles = ((M + c.bm - 1) / c.bm) * ((K + c.bn - 1) / c.bn);
-    const long long slots = c.bm * c.bn >= 256 * 128 ? 256 : 512;   // workgroups resident at once
-    const long long rounds = (tiles + slots - 1) / slots;
-    const double cost = (double)rounds * slots * c.bm * c.bn / kDmaEff[i];
-    if (cost < best_cost * 0.999) { best_cost = cost; best = i; }
-  }
-  return best;
+  if (M <= 64) return K <= 64 ? 3 : 2;
+  if (K <= 64 || nk <= 16) return 1;
+  return 0;
 }
 
 // Library-internal entry points (hidden): ConvArgs lives in an unnamed namespace, so it crosses the
 // translation-unit boundary as an opaque pointer.
-extern "C" __attribute__((visibility("hidden"))) void dlip_conv_dma_tile(long long M, int K, int* bm, int* bn) {
-  const TileCfg& c = kDmaCfg[dma_pick(M, K)];
+extern "C" __attribute__((visibility("hidden"))) void dlip_conv_dma_tile(long long M, int K, int nk, int* bm, int* bn) {
+  const TileCfg& c = kDmaCfg[dma_pick(M, K, nk)];
   *bm = c.bm;
   *bn = c.bn;
 }
@@ -344,7 +528,7 @@ extern "C" __attribute__((visibility("hidden"))) void dlip_conv_dma_tile(long lo
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int out_split) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (dma_pick(a.M, a.K)) {
+  switch (dma_pick(a.M, a.K, a.nk)) {
     case 0: return launch_dma<128, 128, 2, 2, 2, 2>(a, st, out_split);
     case 1: return launch_dma<128, 64, 2, 2, 3, 2>(a, st, out_split);
     case 2: return launch_dma<64, 128, 2, 2, 3, 2>(a, st, out_split);

@@ -313,12 +313,13 @@ def test_conv_nhwc_f16x3(ops, case):
 
 def test_split_weights_roundtrip():
     from deeplip_amd import packing
-    w = torch.randn(7, 3, 3, 40, dtype=torch.float64) * torch.logspace(-4, 0, 7, dtype=torch.float64).view(7, 1, 1, 1)
+    w = torch.randn(7, 3, 3, 40, dtype=torch.float64, generator=torch.Generator().manual_seed(7))
+    w = w * torch.logspace(-4, 0, 7, dtype=torch.float64).view(7, 1, 1, 1)
     ws, sc = packing.split_weights(w)
     assert ws.shape == (7, 3, 3, 64) and ws.dtype == torch.float32
     h = ws.view(torch.float16).reshape(7, 3, 3, 2, 2, 32).double()       # [.., block, hi/lo, 32]
     rec = (h[..., 0, :] + h[..., 1, :]).reshape(7, 3, 3, 64)[..., :40] / sc.double().view(7, 1, 1, 1)
-    assert float(((rec - w).abs() / w.abs().clamp_min(1e-30)).max()) < 2.0 ** -20
+    # the error of an element is bounded relative to its output channel's largest weight (the scale's anchor)
     assert float(((rec - w).abs().amax(dim=(1, 2, 3)) / w.abs().amax(dim=(1, 2, 3))).max()) < 2.0 ** -21
 
 
@@ -364,8 +365,9 @@ SPLIT_FMT_CASES = [c for c in F16X3_CASES if c[3] % 32 == 0 and c[4] % 32 == 0]
 @pytest.mark.parametrize("case", SPLIT_FMT_CASES, ids=lambda c: "x".join(str(v) for v in c[:10]))
 def test_conv_nhwc_f16x3_split_formats(ops, case, fmt):
     """The same convolution with x / residual and / or y in the split activation format must give
-    the fp32-format kernel's result: inputs that are exactly representable as hi + lo make the two
-    paths see identical operands, so the results agree to the last bit of the (hi, lo) output rounding."""
+    the fp32-format kernel's result.  Inputs exactly representable as hi + lo make the two paths see
+    identical operands; what differs is the summation tree (split-format launches go to the LDS-DMA
+    kernel, whose balanced work split adds partial tiles) and the (hi, lo) rounding of a split output."""
     from deeplip_amd import packing
     N, H, W, C, K, R, S, stride, pad, dil, use_res, use_slope = case
     x = _split_ref_value(rnd(N, H, W, C, seed=1) * 3.0)
@@ -388,10 +390,7 @@ def test_conv_nhwc_f16x3_split_formats(ops, case, fmt):
     if out_split:
         y = ops.split_unpack(y)
     torch.cuda.synchronize()
-    if out_split:
-        assert rel_err(y.cpu().numpy(), base.cpu().numpy()) < 2.0 ** -20
-    else:
-        assert torch.equal(y.cpu(), base.cpu())
+    assert rel_err(y.cpu().numpy(), base.cpu().numpy()) < 2e-6
 
 
 def _split_ref_value(x):
@@ -399,6 +398,27 @@ def _split_ref_value(x):
     hi = x.half()
     lo = (x - hi.float()).half()
     return hi.float() + lo.float()
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 40, 512, 512, 3), (2, 1, 300, 512, 512, 1), (9, 6, 6, 256, 256, 3), (700, 6, 6, 256, 256, 3)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_dma_balanced_split_is_deterministic(ops, shape):
+    """Tiles shared between workgroups are summed in part order by whoever arrives last: two launches give
+    the same bits, and the ticket counters are back at zero for the next launch (three launches in a row)."""
+    from deeplip_amd import packing
+    N, H, W, C, K, S = shape
+    x = ops.split_pack((rnd(N, H, W, C, seed=41) * 2.0).cuda())
+    R = 1 if H == 1 else S
+    w = rnd(K, R, S, C, seed=42, scale=1.0 / np.sqrt(C * R * S))
+    ws, sc = packing.split_weights(w.double())
+    b = rnd(K, seed=43, scale=0.1).cuda()
+    kw = dict(pad=(0 if H == 1 else S // 2, S // 2), w_scale=sc.cuda(), x_split=True)
+    ys = [ops.conv_nhwc(x, ws.cuda(), b, **kw).clone() for _ in range(3)]
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    ref = F.conv2d(ops.split_unpack(x).cpu().permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.cpu().double(),
+                   padding=kw["pad"])
+    assert rel_err(ys[0].cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
 
 
 def test_conv_split_format_rejects_bad_args(ops):

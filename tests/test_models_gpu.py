@@ -101,14 +101,20 @@ def test_video_relu_variant(golden):
 
 
 def test_video_parity_size_b32_vs_oracle_and_batch_invariance(video_net):
-    """BASELINE parity size [32,1,29,88,88]: HIP vs oracle, and bit-exact batch invariance (each
-    output element is one fixed-order fp32 fma chain, so tiling / batch size cannot change it)."""
+    """BASELINE parity size [32,1,29,88,88]: HIP vs oracle, and batch invariance -- bit-exact in f32 mode
+    (each output element is one fixed-order fp32 fma chain, so tiling / batch size cannot change it);
+    in f16x3 mode the balanced work split of the LDS-DMA conv kernel cuts tiles at batch-dependent
+    slices, so the summation tree (not the operands) may differ: 1e-6."""
     net, sd = video_net
     x = torch.from_numpy(wg.video_input(32, speakers=np.arange(32) % 8))
     em = net.embed(x.to(DEV))
     em4 = net.embed(x[8:12].to(DEV))
     torch.cuda.synchronize()
-    assert torch.equal(em[8:12], em4)
+    from deeplip_amd import packing
+    if packing.PRECISION == "f32":
+        assert torch.equal(em[8:12], em4)
+    else:
+        assert rel_err(em[8:12].cpu().numpy(), em4.cpu().numpy()) < 1e-6
     torch.set_num_threads(max(1, torch.get_num_threads()))
     with torch.no_grad():
         ref = O.video_time_mean(O.lipreading_features(sd, x[:8]))   # 8 clips keep the CPU leg in seconds
