@@ -153,36 +153,42 @@ class SpeakerEmbNet(nn.Module):
                 "fc2": packing.pack_linear(self.fc2.weight, self.fc2.bias, None, device),
                 "bn1": ss(self.bn1), "bn2": ss(self.bn2)}
 
-    def _to_ntc(self, x: Tensor) -> Tensor:
+    def _to_ntc(self, x: Tensor, split: bool = False) -> Tensor:
+        """[B,F,T] -> [B,T,Fp] channels-last; ``split``: Fp = F rounded up to 32, split activation format."""
         if x.dim() == 4:            # [B,1,F,T] (the north-star / train_audio.py:183-184 resnet layout)
             x = x.squeeze(1)
         if x.dim() != 3 or x.shape[1] != self.input_dim:
             raise ValueError(f"SpeakerEmbNet expects [B,{self.input_dim},T] features, got {tuple(x.shape)}")
-        return ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim))
+        h = ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim, 32 if split else 4))
+        return ops.split_pack(h) if split else h
 
     def extract_embedding(self, x: Tensor, taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
         """[B,F,T] -> (xv [B,E] = fc2 output, x_a [B,E] = fc1 output)   (tdnn.py:89-101)."""
         _require_eval(self)
         p = _cached_pack(self, x.device, self._pack)
-        h = self._to_ntc(x)
         # f16x3 packing: frame-level activations travel between layers as (hi, lo) fp16 pairs, written
-        # by the producing layer's epilogue; the last layer hands fp32 to the pooling kernel.
-        split, n = False, len(self.tdnn)
+        # by the producing layer's epilogue; the last layer hands fp32 to the pooling kernel, which
+        # writes the utterance statistics in that format again for fc1.
+        f16x3 = p["tdnn"][0].wscale is not None
+        h = self._to_ntc(x, split=f16x3)
+        split, n = f16x3, len(self.tdnn)
         for i, (blk, bp) in enumerate(zip(self.tdnn, p["tdnn"])):
             nxt = bp.wscale is not None and i + 1 < n and blk.output_dim % 32 == 0
             h = blk.run_ntc(h, bp, x_split=split, out_split=nxt)
             split = nxt
         if taps is not None:
             taps["tdnn_out"] = h
+        pooled_split = False
         if self.pooling_type == "statistic":
-            h = ops.meanstd_pool(h)
+            pooled_split = f16x3 and h.shape[2] % 4 == 0
+            h = ops.meanstd_pool(h, out_split=pooled_split)
         elif self.pooling_type == "average":
             h = ops.time_mean(h)
         else:
             h = self.pooling.run_ntc(h)
         if taps is not None:
-            taps["pooled"] = h
-        x_a = ops.linear(h, p["fc1"].w, p["fc1"].b, w_scale=p["fc1"].wscale)
+            taps["pooled"] = ops.split_unpack(h)[:, :self.fc1.in_features].contiguous() if pooled_split else h
+        x_a = ops.linear(h, p["fc1"].w, p["fc1"].b, w_scale=p["fc1"].wscale, x_split=pooled_split)
         h = ops.affine_act(x_a, p["bn1"][0], p["bn1"][1], LRELU, act_first=not self.bn_first)
         xv = ops.linear(h, p["fc2"].w, p["fc2"].b, w_scale=p["fc2"].wscale)
         return xv, x_a

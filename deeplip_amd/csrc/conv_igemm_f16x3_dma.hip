@@ -480,7 +480,8 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
     const double tile_us = 2.0 * BM * BN * 32.0 * a.nk / (kSlotFlops * 1e-6);
     const double plain_us = (double)((tiles + sl - 1) / sl) * tile_us;
     long long Gb = sl;
-    if (sk.iters < 4 * Gb) Gb = sk.iters / 4 > 0 ? sk.iters / 4 : 1;   // keep at least 4 slices per workgroup
+    // small problems: at least 16 slices per workgroup (every extra part costs the finisher a serial slab read)
+    if (sk.iters < 16 * Gb) Gb = sk.iters / 16 > 0 ? sk.iters / 16 : 1;
     const double bal_us = (double)sk.iters / Gb / a.nk * tile_us + kHandoffUs * (BM * BN / 16384.0);
     if ((balanced == 2 || bal_us < plain_us) && Gb * a.nk != sk.iters) G = Gb;
   }

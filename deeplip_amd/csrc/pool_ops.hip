@@ -89,23 +89,57 @@ __global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict
 }
 
 // y[b, c] = mean_t x[b,t,c];  y[b, C + c] = sqrt( sum_t (x - mean)^2 / (T - 1) )
+// One workgroup per (utterance, 64-channel block): 16 lanes x float4 span the block, 16 row groups
+// split T, so every thread streams T/16 independent 16-B loads; sums and sums of squares are kept
+// in fp64 (the inputs are fp32, so sum x^2 - (sum x)^2 / T loses nothing a two-pass fp32 result has)
+// and the 16 partial rows meet in LDS.  SPLIT writes the [B, ldy] result as (hi, lo) fp16 pairs (the
+// split activation format; ldy = 2C rounded up to 32, padding zeroed) for the LDS-DMA GEMM behind it.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      int B, int T, int C) {
-  const long long total = (long long)B * C;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    const long long b = i / C;
-    const float* p = x + b * T * C + c;
-    double s = 0.0;
-    for (int t = 0; t < T; ++t) s += (double)p[(long long)t * C];
-    const double mean = s / (double)T;
-    double q = 0.0;
-    for (int t = 0; t < T; ++t) {
-      const double d = (double)p[(long long)t * C] - mean;
-      q += d * d;
+                                                      int T, int C, int ldy) {
+  __shared__ double part[16][64][2];
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int lx = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = c0 + lx * 4;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (c < C) {   // C % 4 == 0: a float4 is all inside or all outside
+    const float* p = x + (long long)b * T * C + c;
+    for (int t = g; t < T; t += 16) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + (long long)t * C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s[k] += (double)v[k]; q[k] += (double)v[k] * (double)v[k]; }
     }
-    y[b * 2 * C + c] = (float)mean;
-    y[b * 2 * C + C + c] = (float)sqrt(q / (double)(T - 1));  // T == 1 -> NaN, as torch.std
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { part[g][lx * 4 + k][0] = s[k]; part[g][lx * 4 + k][1] = q[k]; }
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+    const int cc = c0 + threadIdx.x;
+    double ss = 0.0, qq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ss += part[i][threadIdx.x][0]; qq += part[i][threadIdx.x][1]; }
+    const double mean = ss / (double)T;
+    double var = (qq - ss * mean) / (double)(T - 1);   // T == 1 -> NaN, as torch.std
+    if (var < 0.0) var = 0.0;
+    const float out[2] = {(float)mean, (float)sqrt(var)};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = h * C + cc;
+      if (SPLIT) {
+        const _Float16 hi = (_Float16)out[h], lo = (_Float16)(out[h] - (float)hi);
+        _Float16* blk = reinterpret_cast<_Float16*>(y + (long long)b * ldy + (col & ~31));
+        blk[col & 31] = hi;
+        blk[32 + (col & 31)] = lo;
+      } else {
+        y[(long long)b * ldy + col] = out[h];
+      }
+    }
+  }
+  if (SPLIT && blockIdx.x == 0 && (int)threadIdx.x < ldy - 2 * C) {   // zero the channel padding (< 32 values)
+    const int col = 2 * C + threadIdx.x;
+    _Float16* blk = reinterpret_cast<_Float16*>(y + (long long)b * ldy + (col & ~31));
+    blk[col & 31] = (_Float16)0.f;
+    blk[32 + (col & 31)] = (_Float16)0.f;
   }
 }
 
@@ -157,10 +191,15 @@ extern "C" int dlip_group_mean_f32(const float* x, const int32_t* group_ptr, flo
 }
 
 extern "C" int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
-                                     dlip_stream_t stream) {
-  DLIP_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0);
-  hipLaunchKernelGGL(meanstd_kernel, dim3(grid_for((long long)B * C)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, y, B, T, C);
+                                     int32_t out_split, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && B > 0 && B <= 65535 && T > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const dim3 grid((C + 63) / 64, B);
+  if (out_split)
+    hipLaunchKernelGGL(meanstd_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C,
+                       (2 * C + 31) / 32 * 32);
+  else
+    hipLaunchKernelGGL(meanstd_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C, 2 * C);
   return dlip_launch_status();
 }
 

@@ -217,12 +217,16 @@ def group_mean(x: Tensor, group_ptr: Tensor) -> Tensor:
     return y
 
 
-def meanstd_pool(x: Tensor) -> Tensor:
-    """x [B,T,C] -> [B,2C] = cat(mean_t, unbiased std_t)  (pooling.py:24-26)."""
+def meanstd_pool(x: Tensor, out_split: bool = False) -> Tensor:
+    """x [B,T,C] -> [B,2C] = cat(mean_t, unbiased std_t)  (pooling.py:24-26).  ``out_split``: the
+    result is [B, 2C rounded up to 32] in the split activation format (zero padded)."""
     _req(x, "x")
     B, T, Cc = x.shape
-    y = torch.empty((B, 2 * Cc), device=x.device, dtype=torch.float32)
-    check(lib().dlip_meanstd_pool_f32(ptr(x), ptr(y), B, T, Cc, stream_handle()), "dlip_meanstd_pool_f32")
+    if Cc % 4:
+        raise ValueError("meanstd_pool: C must be a multiple of 4")
+    width = (2 * Cc + 31) // 32 * 32 if out_split else 2 * Cc
+    y = torch.empty((B, width), device=x.device, dtype=torch.float32)
+    check(lib().dlip_meanstd_pool_f32(ptr(x), ptr(y), B, T, Cc, int(out_split), stream_handle()), "dlip_meanstd_pool_f32")
     return y
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 5
+#define DLIP_ABI_VERSION 6
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -142,10 +142,11 @@ int dlip_time_mean_f32(const float* x, const int32_t* len, float* y, int32_t B, 
 int dlip_group_mean_f32(const float* x, const int32_t* group_ptr, float* y, int32_t U, int32_t C,
                         dlip_stream_t stream);
 
-/* MeanStdPooling on N-T-C: y[b, 0:C] = mean_t, y[b, C:2C] = unbiased std_t (N-1), two-pass.
- * Replaces models/audio_models/pooling.py:24-26. */
+/* MeanStdPooling on N-T-C: y[b, 0:C] = mean_t, y[b, C:2C] = unbiased std_t (N-1); sums of x and x^2
+ * in fp64.  Replaces models/audio_models/pooling.py:24-26.  C % 4 == 0.  out_split != 0 writes y as
+ * [B, 2C rounded up to 32] in the split activation format of dlip_conv_nhwc_f16x3 (padding zeroed). */
 int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
-                          dlip_stream_t stream);
+                          int32_t out_split, dlip_stream_t stream);
 
 /* AttentiveStatPooling tail (models/audio_models/pooling.py:87-107) on N-T-C: hidden [B,T,Hd] = x W^T + b
  * (from dlip_conv_nhwc_f32), e = relu(hidden).v + k, alpha = softmax over T, y [B,2C] = weighted mean |

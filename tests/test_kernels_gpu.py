@@ -158,12 +158,18 @@ def test_time_and_group_mean(ops):
 
 
 def test_meanstd_pool(ops):
-    x = rnd(3, 1500, 278, seed=20) * 0.3 + 2.0     # large mean: catastrophic for one-pass sum/sumsq
-    ref = torch.cat([x.mean(2), x.std(2)], 1)
-    y = ops.meanstd_pool(x.permute(0, 2, 1).contiguous().cuda())
+    x = rnd(3, 1500, 278, seed=20) * 0.3 + 2.0     # large mean: catastrophic for an fp32 one-pass sum/sumsq (the kernel's sums are fp64)
+    ref = torch.cat([x.double().mean(2), x.double().std(2)], 1)
+    xd = x.permute(0, 2, 1).contiguous().cuda()
+    y = ops.meanstd_pool(xd)
+    ys = ops.meanstd_pool(xd, out_split=True)          # [3, 3008] split format, 8 zero channels of padding
     torch.cuda.synchronize()
     assert rel_err(y.cpu().numpy(), ref.numpy()) < 1e-6
-    assert np.abs(y.cpu().numpy()[:, 1500:] - ref.numpy()[:, 1500:]).max() < 1e-6 * 0.3 * 10
+    assert np.abs(y.cpu().numpy()[:, 1500:] - ref.numpy()[:, 1500:]).max() < 1e-6 * 0.3
+    assert ys.shape == (3, 3008)
+    assert torch.equal(ys.cpu().view(torch.int32), _split_ref(torch.cat([y.cpu(), torch.zeros(3, 8)], 1)).view(torch.int32))
+    with pytest.raises(Exception):
+        ops.meanstd_pool(rnd(2, 9, 6).cuda())          # C % 4 != 0
 
 
 def test_layout_adapters(ops):
