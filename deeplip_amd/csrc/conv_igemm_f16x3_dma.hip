@@ -23,7 +23,10 @@
 // MFMA program order, fragment layout, accumulator initialisation and epilogue are those of
 // conv_igemm_f16x3.hip.
 #include "conv_common.h"
+#include <algorithm>
+#include <cstdio>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <utility>
 
@@ -76,7 +79,16 @@ struct StreamK {
   float* slabs;      // [2 * G][BM * BN] fp32
   int* counters;     // [tiles], zero between launches (the last arriver resets its tile's word)
   int G;             // workgroups in the grid
+#ifdef DLIP_STAMPS
+  unsigned long long* stamps;   // diagnostic build only: [G][8] s_memtime values of each workgroup's first segment
+#endif
 };
+
+#ifdef DLIP_STAMPS
+#define DLIP_STAMP(i) do { if (threadIdx.x == 0 && it == it_begin) sk.stamps[(size_t)g * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DLIP_STAMP(i) do { } while (0)
+#endif
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool OSPLIT, int NSTAGE, int OCC>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_dma_kernel(const ConvArgs a, const StreamK sk) {
@@ -91,6 +103,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   constexpr int STAGE_B = (BM + BN) * ROWB;
   constexpr int LDK = 32;             // dwords per LDS row
   constexpr int PF = NSTAGE - 1;      // slices in flight ahead of the one being multiplied
+  constexpr int RING = NSTAGE * STAGE_B;   // bytes; the epilogue parameter table (5 x BN floats) sits behind it
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -104,7 +117,6 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const int csrc = ((cq ^ key_st) << 2);        // first channel (dword) of the chunk this lane fetches
   const u32x4 xr = make_rsrc_words(a.x, a.x_bytes);
   const u32x4 wr = make_rsrc_words(a.w, a.w_bytes);
-  const __amdgpu_buffer_rsrc_t rr = dlip_make_rsrc(a.res, a.res ? a.r_bytes : 0u);
   const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,28 +147,39 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     const int tile_m = tile / a.tiles_n;
     // every wave is done reading the previous segment's last stage (and the ticket word) before the ring is refilled
     if (it != it_begin) __syncthreads();
+    DLIP_STAMP(0);
 
+    // Per-row gather state, branch-free: byte offset of the row's window origin and a bit per filter tap
+    // that stays inside the image (columns and rows tested separately: R + S steps, not R x S).
     int a_off[A_PER];
     uint32_t a_mask[A_PER];
+    {
+      int hi0[A_PER], wi0[A_PER];
+      uint32_t colbits[A_PER];
 #pragma unroll
-    for (int j = 0; j < A_PER; ++j) {
-      const int m = tile_m * BM + rbase + RPP * j;
-      a_off[j] = 0;
-      a_mask[j] = 0u;
-      if (m < a.M) {
-        const int n = m / a.HoWo;
-        const int rem = m - n * a.HoWo;
+      for (int j = 0; j < A_PER; ++j) {
+        const int m = tile_m * BM + rbase + RPP * j;
+        const int mc = m < a.M ? m : a.M - 1;
+        const int n = mc / a.HoWo;
+        const int rem = mc - n * a.HoWo;
         const int ho = rem / a.Wo;
         const int wo = rem - ho * a.Wo;
-        const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
-        a_off[j] = (((n * a.H + hi0) * a.W + wi0) * a.ldx + csrc) * 4;
-        uint32_t mk = 0u;
-        for (int r = 0; r < a.R; ++r)
-          for (int s = 0; s < a.S; ++s)
-            if ((unsigned)(hi0 + r * a.dh) < (unsigned)a.H && (unsigned)(wi0 + s * a.dw) < (unsigned)a.W)
-              mk |= 1u << (r * a.S + s);
-        a_mask[j] = mk;
+        hi0[j] = ho * a.sh - a.ph;
+        wi0[j] = wo * a.sw - a.pw;
+        a_off[j] = (((n * a.H + hi0[j]) * a.W + wi0[j]) * a.ldx + csrc) * 4;
+        colbits[j] = 0u;
+        a_mask[j] = 0u;
       }
+      for (int sx = 0; sx < a.S; ++sx)
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) colbits[j] |= (uint32_t)((unsigned)(wi0[j] + sx * a.dw) < (unsigned)a.W) << sx;
+      for (int r = 0; r < a.R; ++r)
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j)
+          a_mask[j] |= ((unsigned)(hi0[j] + r * a.dh) < (unsigned)a.H ? colbits[j] : 0u) << (r * a.S);
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j)
+        if (tile_m * BM + rbase + RPP * j >= a.M) a_mask[j] = 0u;
     }
     int b_off[B_PER];
 #pragma unroll
@@ -192,6 +215,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     };
 
     // ---- prologue: put the first NSTAGE-1 slices in flight, then initialise the accumulators ----
+    DLIP_STAMP(1);
     issue_a(0);
     issue_b(0);
     if (PF > 1 && kn > 1) {
@@ -200,36 +224,27 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       issue_b(1);
     }
 
-    // the tile's first slices start from (bias + residual) * wscale[k] (the weight scale is undone in the
-    // epilogue); later parts of a split tile start from zero
+    // Accumulators hold the TRANSPOSED tile (rows = output channels, columns = pixels: the weight
+    // fragment is the MFMA's A operand), so a lane owns 4 consecutive channels of one pixel per
+    // register quad: 8-B (hi) + 8-B (lo) pieces of an output row for the LDS-staged epilogue.
     f32x16 acc[MI][NI];
-    if (k0 == 0) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int k = tile_n * BN + wn * WN + ni * 32 + lrow;
-        const bool kok = k < a.K;
-        const float bias = (kok && a.bias) ? a.bias[k] : 0.f;
-        const float ws = kok ? a.wscale[k] : 1.f;
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int m0 = tile_m * BM + wm * WM + mi * 32 + rquad;
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = m0 + (e & 3) + 8 * (e >> 2);
-            const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldr + (k & ~31)) * 4 + (k & 31) * 2) : DLIP_OOB_OFFSET;
-            const _Float16 rh = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rr, (int)off, 0, 0));
-            const _Float16 rl = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rr, (int)off + 64, 0, 0));
-            acc[mi][ni][e] = (bias + ((float)rh + (float)rl)) * ws;
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    // Per-channel epilogue parameters of this tile's BN channels -> the LDS table behind the ring (read back
+    // as 16-B quads): 1/wscale, bias, slope, post scale, post shift.
+    if (tid < BN) {
+      const int k = tile_n * BN + tid;
+      const bool kok = k < a.K;
+      float* tab = smem + RING / 4;
+      tab[tid] = kok ? 1.f / a.wscale[k] : 0.f;   // power of two: exact
+      tab[BN + tid] = (kok && a.bias) ? a.bias[k] : 0.f;
+      tab[2 * BN + tid] = (kok && a.slope) ? a.slope[k] : 1.f;
+      tab[3 * BN + tid] = (kok && a.pscale) ? a.pscale[k] : 1.f;
+      tab[4 * BN + tid] = (kok && a.pshift) ? a.pshift[k] : 0.f;
     }
 
     f16x8 fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];
@@ -255,14 +270,16 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         for (int ni = 0; ni < NI; ++ni) {
           const f16x8 av = grp == 0 ? fal[set][mi] : fah[set][mi];
           const f16x8 bv = grp == 1 ? fbl[set][ni] : fbh[set][ni];
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mi][ni], 0, 0, 0);
         }
     };
 #define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
     // slice 0 has landed once at most the (PF - 1) younger slices are outstanding
+    DLIP_STAMP(2);
     if (PF > 1 && kn > 1) wait_vmcnt<NL>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    DLIP_STAMP(3);
     read_frags(0, 0, 0);
 
     int st_cur = 0, st_iss = (PF > 1 && kn > 1) ? 2 % NSTAGE : 1 % NSTAGE;   // stage the next issue goes to
@@ -290,6 +307,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       st_cur = st_nxt;
     }
 #undef DLIP_FENCE
+    DLIP_STAMP(4);
 
     // Lane coordinates re-derived behind an opaque asm: otherwise the compiler hoists every address of the
     // hand-off and epilogue code (invariant across segments) out of the segment loop and carries ~100
@@ -366,39 +384,130 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     }
 
     if (finish) {
-      const int rquad_e = half_e * 4;
+      // ---- epilogue through LDS: y = act(acc / wscale + bias + residual) * post_scale + post_shift ----
+      // The ring is free now and stages the output tile in its memory layout (BM rows x BN*4 bytes, in
+      // EPASS row bands when the tile is larger than the ring), 16-B chunk c of row r at position
+      // c ^ (r & 15) (low 4 bits): the residual arrives by LDS-DMA, every lane adds / overwrites the 8-B
+      // pieces of its own pixels, and the tile leaves in 16-B stores (a row is one contiguous segment).
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      constexpr int PITCH = BN * 4;                  // bytes per image row
+      constexpr int CPR = BN / 4;                    // 16-B chunks per row
+      constexpr int EPASS = (BM * PITCH + RING - 1) / RING;
+      constexpr int PROWS = BM / EPASS;              // rows per band
+      static_assert(BM % EPASS == 0 && PROWS % WM == 0 && PROWS * PITCH <= RING, "epilogue bands are whole wave rows");
+      static_assert((PROWS * PITCH) % (NW * 1024) == 0, "a band is a whole number of DMA pieces per wave");
+      constexpr int RES_PIECES = PROWS * PITCH / 1024 / NW;   // per wave
+      constexpr int RPQ = 1024 / PITCH;              // rows per DMA piece
+      const u32x4 rrw = make_rsrc_words(a.res, a.res ? a.r_bytes : 0u);
+      const int kcol0 = tile_n * BN;                 // first output channel of the tile
+      char* img = reinterpret_cast<char*>(smem);
+      const f32x4* tab = reinterpret_cast<const f32x4*>(smem + RING / 4);
+      const bool post = a.pscale != nullptr;
+      __syncthreads();                               // every wave is done with the ring (and the table is written)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int k = tile_n * BN + wn * WN + ni * 32 + lrow_e;
-        const bool kok = k < a.K;
-        const float inv = kok ? 1.f / a.wscale[k] : 1.f;   // power of two: exact
-        const float slope = (kok && a.slope) ? a.slope[k] : 1.f;
-        const float psc = (kok && a.pscale) ? a.pscale[k] : 1.f;
-        const float psh = (kok && a.pshift) ? a.pshift[k] : 0.f;
+      for (int ep = 0; ep < EPASS; ++ep) {
+        const int band0 = ep * PROWS;                // first tile row of this band
+        if (a.res) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int m0 = tile_m * BM + wm * WM + mi * 32 + rquad_e;
+          for (int i = 0; i < RES_PIECES; ++i) {
+            const int piece = i * NW + wave;
+            const int r = piece * RPQ + lane_e / CPR;  // band row
+            const int pp = lane_e % CPR;
+            const int c = (pp & ~15) | ((pp ^ r) & 15);
+            const int m = tile_m * BM + band0 + r;
+            const bool ok = m < a.M && (kcol0 + (c >> 3) * 32) < a.K;
+            dma_piece(rrw, ok ? (uint32_t)((m * a.ldr + kcol0) * 4 + c * 16) : DLIP_OOB_OFFSET, lds0 + piece * 1024);
+          }
+          wait_vmcnt<0>();
+          __syncthreads();
+        }
+        const bool mine = (wm * WM) / PROWS == ep;   // this wave's rows are in the band (wave-uniform)
+        if (mine) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = m0 + (e & 3) + 8 * (e >> 2);
-            float v = acc[mi][ni][e] * inv;
-            v = v >= 0.f ? v : v * slope;
-            v = v * psc + psh;
-            if constexpr (OSPLIT) {
-              const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + (k & ~31)) * 4 + (k & 31) * 2) : DLIP_OOB_OFFSET;
-              const _Float16 h = (_Float16)v;
-              const _Float16 l = (_Float16)(v - (float)h);
-              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), yr, (int)off, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, l), yr, (int)off + 64, 0, 0);
-              if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            } else {
-              const uint32_t off = (kok && m < a.M) ? (uint32_t)((m * a.ldy + k) * 4) : DLIP_OOB_OFFSET;
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yr, (int)off, 0, 0);
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int kl = wn * WN + ni * 32 + 8 * j + 4 * half_e;   // tile-local channel of acc[..][ni][4j..4j+3]
+              const f32x4 inv4 = tab[kl >> 2], bi4 = tab[(BN + kl) >> 2], sl4 = tab[(2 * BN + kl) >> 2];
+              f32x4 ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
+              if (post) { ps4 = tab[(3 * BN + kl) >> 2]; pt4 = tab[(4 * BN + kl) >> 2]; }
+              const int ch = (kl >> 5) * 8 + j;      // hi chunk of these 4 channels within the row (lo: + 4)
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) {
+                const int r = wm * WM - band0 + mi * 32 + lrow_e;      // band row of this lane's pixel
+                char* row = img + r * PITCH + 8 * half_e;
+                const int phi = (ch & ~15) | ((ch ^ r) & 15), plo = ((ch + 4) & ~15) | (((ch + 4) ^ r) & 15);
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = acc[mi][ni][4 * j + c] * inv4[c] + bi4[c];
+                if (a.res) {
+                  const h4 rh = *reinterpret_cast<const h4*>(row + phi * 16), rl = *reinterpret_cast<const h4*>(row + plo * 16);
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) v[c] += (float)rh[c] + (float)rl[c];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  v[c] = v[c] >= 0.f ? v[c] : v[c] * sl4[c];
+                  if (post) v[c] = v[c] * ps4[c] + pt4[c];
+                }
+                if constexpr (OSPLIT) {   // same 8-B pieces the residual came from: no other lane touches them
+                  h4 hi, lo;
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); }
+                  *reinterpret_cast<h4*>(row + phi * 16) = hi;
+                  *reinterpret_cast<h4*>(row + plo * 16) = lo;
+                } else {
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) acc[mi][ni][4 * j + c] = v[c];
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);   // one channel quad at a time
             }
+        }
+        if constexpr (!OSPLIT) {
+          if (a.res) __syncthreads();                // fp32 rows overwrite other lanes' residual pieces
+          if (mine) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int kl = wn * WN + ni * 32 + 8 * j + 4 * half_e;
+                const int ch = kl >> 2;              // the 4 channels are one fp32 chunk
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                  const int r = wm * WM - band0 + mi * 32 + lrow_e;
+                  const int pc = (ch & ~15) | ((ch ^ r) & 15);
+                  f32x4 v;
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) v[c] = acc[mi][ni][4 * j + c];
+                  *reinterpret_cast<f32x4*>(img + r * PITCH + pc * 16) = v;
+                }
+              }
           }
         }
+        __syncthreads();
+        // band -> global: thread t moves chunks t, t + NT, ... (a wave-instruction covers 64 / CPR whole rows)
+#pragma unroll
+        for (int i = 0; i < PROWS * CPR / NT; ++i) {
+          const int idx = i * NT + tid_e;
+          const int r = idx / CPR, pp = idx % CPR;
+          const int c = (pp & ~15) | ((pp ^ r) & 15);
+          const int m = tile_m * BM + band0 + r;
+          const int kfirst = OSPLIT ? kcol0 + (c >> 3) * 32 : kcol0 + c * 4;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(img + r * PITCH + pp * 16);
+          const uint32_t off = (m < a.M && kfirst < a.K) ? (uint32_t)((m * a.ldy + kcol0) * 4 + c * 16) : DLIP_OOB_OFFSET;
+          __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)off, 0, 0);
+        }
+        if (ep + 1 < EPASS) __syncthreads();         // the next band reuses the image
       }
     }
+#ifdef DLIP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && it == it_begin) {
+      sk.stamps[(size_t)g * 8 + 5] = __builtin_amdgcn_s_memtime();
+      sk.stamps[(size_t)g * 8 + 6] = (unsigned long long)kn;
+    }
+#endif
     it += kn;
   }
 }
@@ -453,7 +562,7 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
   b.tiles_n = (a.K + BN - 1) / BN;
   const long long tiles = (long long)tiles_m * b.tiles_n;
   if (tiles <= 0 || tiles > 0x7FFFFFFFll) return DLIP_EINVAL;
-  constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB;
+  constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB + 5 * BN * sizeof(float);   // ring + epilogue parameter table
   constexpr int threads = 64 * WAVES_M * WAVES_N;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds a CU");
   auto kern = out_split ? conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, true, NSTAGE, OCC>
@@ -492,6 +601,32 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
     sk.counters = w->counters;
   }
   sk.G = (int)G;
+#ifdef DLIP_STAMPS
+  {   // diagnostic build (tools/probes/stamps.sh): median cycles between the stamps of each workgroup's first segment
+    static unsigned long long* dbuf = nullptr;
+    static size_t cap = 0;
+    if (cap < (size_t)G * 8) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc(reinterpret_cast<void**>(&dbuf), (size_t)G * 8 * 8); cap = (size_t)G * 8; }
+    (void)hipMemsetAsync(dbuf, 0, (size_t)G * 8 * 8, st);
+    sk.stamps = dbuf;
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(threads), lds, st, b, sk);
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> h((size_t)G * 8);
+    (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
+    if (getenv("DLIP_STAMP_PRINT")) {
+      std::vector<double> d[5], per;
+      for (long long i = 0; i < G; ++i) {
+        const unsigned long long* r = &h[(size_t)i * 8];
+        if (!r[5]) continue;
+        for (int j = 0; j < 5; ++j) d[j].push_back((double)(r[j + 1] - r[j]));
+        per.push_back((double)(r[4] - r[3]) / (double)(r[6] ? r[6] : 1));
+      }
+      auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+      fprintf(stderr, "[stamps %dx%d M=%d K=%d nk=%d G=%lld tiles=%lld] setup %.0f  issue+init %.0f  first-wait %.0f  loop %.0f (%.0f/slice)  tail %.0f  (s_memtime ticks = 100 MHz)\n",
+              BM, BN, a.M, a.K, a.nk, G, tiles, med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(per), med(d[4]));
+    }
+    return dlip_launch_status();
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(threads), lds, st, b, sk);
   return dlip_launch_status();
 }
