@@ -635,20 +635,23 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
 
 // Tile menu of the DMA kernel (index = what dlip_conv_plan reports via dlip_conv_dma_tile).
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64},
-                           {256, 128}, {128, 128}, {256, 128}, {128, 256}, {256, 64}, {128, 128}};   // 4..9: experiments (DLIP_CONV_DMA_TILE only)
+                           {128, 64},
+                           {128, 128}, {256, 128}, {128, 256}, {256, 64}, {128, 128}};   // 5..9: experiments (DLIP_CONV_DMA_TILE only)
 constexpr int NUM_DMA_ALL = 10;
 
 // Tile choice (measured per layer with tools/bench_dma.py, MI355X, balanced split on): 128x128 is the
 // steady-state winner whenever the tile is deep enough to amortise its set-up; narrow outputs (K <= 64)
-// and short reductions (nk <= 16 slices: 1x1 convolutions, small Linear layers) do better on 128x64
-// with its three-stage ring; M <= 64 (fully connected layers on a batch) uses the 64-row tiles.
+// do better on 128x64 with a three-stage ring, short reductions (nk <= 16 slices: 1x1 convolutions,
+// small Linear layers) on 128x64 with a two-stage ring and three workgroups per CU (latency, not
+// MFMA, bounds them); M <= 64 (fully connected layers on a batch) uses the 64-row tiles.
 static int dma_pick(long long M, int K, int nk) {
   if (const char* e = getenv("DLIP_CONV_DMA_TILE")) {
     const int v = atoi(e);
     if (v >= 0 && v < NUM_DMA_ALL) return v;
   }
   if (M <= 64) return K <= 64 ? 3 : 2;
-  if (K <= 64 || nk <= 16) return 1;
+  if (nk <= 16) return 4;
+  if (K <= 64) return 1;
   return 0;
 }
 
@@ -669,7 +672,7 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 1: return launch_dma<128, 64, 2, 2, 3, 2>(a, st, out_split);
     case 2: return launch_dma<64, 128, 2, 2, 3, 2>(a, st, out_split);
     case 3: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, out_split);
-    case 4: return launch_dma<256, 128, 4, 2, 2, 1>(a, st, out_split);
+    case 4: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, out_split);
     case 5: return launch_dma<128, 128, 2, 2, 3, 1>(a, st, out_split);
     case 6: return launch_dma<256, 128, 4, 2, 3, 1>(a, st, out_split);
     case 7: return launch_dma<128, 256, 2, 4, 2, 1>(a, st, out_split);
