@@ -18,6 +18,20 @@
 //     de-interleave costs 8 VALU per fragment);
 //   * persistent workgroups (one per CU, 154 KB LDS): weights staged once, the next tile's window is
 //     fetched into registers while the current tile is multiplied and lands in a second LDS buffer.
+//
+// POOL variant (dlip_stem3d_pool_f16x3): MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) of
+// model.py:85 is applied to the activations before they leave the CU, so the 4x larger pre-pool tensor
+// (0.92 GB at the benchmark batch, written once and read once) never exists:
+//   * a workgroup walks whole frames, row tile after row tile (8 stem rows -> 4 pooled rows), so the one
+//     stem row a pooling window needs from the tile above is carried in LDS instead of recomputed;
+//   * columns: a lane's 4 accumulator values are 4 consecutive pixels of one row, so the odd pooled
+//     column is lane-local and the even one needs the pixel to the left (ds_bpermute from the lane
+//     16 below, the previous M tile's registers, or -- at the 7 wave boundaries -- a 2 KB LDS exchange);
+//   * rows: the column-pooled rows go to an LDS buffer (32 channels at a time), 3-row maxima are taken
+//     from there and stored in the split activation format the trunk's LDS-DMA kernels read;
+//   * LDS: weights 73 KB + ONE window 40 KB + row buffer 28 KB + carried rows 14 KB + exchange 2 KB; the
+//     next window still travels in registers during the MFMAs and is written after the barrier that
+//     ends them.
 #include "dlip_common.h"
 
 namespace {
@@ -46,7 +60,11 @@ struct StemArgs {
   int n_tiles;         // B*T*row_tiles
   uint32_t x_bytes, y_bytes;
   int pwp;             // window row pitch in dwords (>= W + 6, == 32 mod 64)
+  int Hp, Wp;          // POOL: pooled output size
+  int n_frames;        // POOL: B*T
 };
+
+constexpr int HPITCH = 40;   // floats per (row, pooled column) of the POOL row buffer: 32 channels + 8 (bank spread)
 
 __device__ __forceinline__ uint32_t split_pair(float v) {
   const _Float16 h = (_Float16)v;
@@ -54,13 +72,19 @@ __device__ __forceinline__ uint32_t split_pair(float v) {
   return (uint32_t)__builtin_bit_cast(unsigned short, h) | ((uint32_t)__builtin_bit_cast(unsigned short, l) << 16);
 }
 
+template <bool POOL>
 __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* wl = lds;                                 // [WBYTES / 4]     split weights, staged once
   const int plane = PR * a.pwp;
   const int psize = KT * plane;                       // dwords per window buffer (even)
   uint32_t* patch0 = lds + WBYTES / 4;                // two window buffers: tile i+1 is fetched while
-  uint32_t* patch1 = patch0 + psize;                  // tile i is multiplied
+  uint32_t* patch1 = patch0 + psize;                  // tile i is multiplied (POOL: one buffer)
+  // POOL only: column-pooled rows of the tile [8][Wp][HPITCH], the carried row [2 tiles][2 channel halves]
+  // [Wp][HPITCH], and the wave-boundary exchange [8 waves][64 channels]
+  float* hbuf = reinterpret_cast<float*>(patch0 + psize);
+  float* halo = hbuf + ROWS * a.Wp * HPITCH;
+  float* xch = halo + 4 * a.Wp * HPITCH;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -105,7 +129,8 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
     }
   };
 
-  int tile = blockIdx.x;
+  // plain: tiles blockIdx, blockIdx + G, ...; POOL: frames blockIdx, blockIdx + G, ..., each frame's row tiles in order
+  int tile = POOL ? blockIdx.x * a.row_tiles : blockIdx.x;
   if (tile >= ntiles) return;
   {
     const uint4* src = reinterpret_cast<const uint4*>(a.w);
@@ -148,9 +173,15 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
   }
   __syncthreads();
 
-  for (int it = 0; tile < ntiles; tile += G, ++it) {
-    const uint32_t* patch = (it & 1) ? patch1 : patch0;
-    const int next = tile + G;
+  for (int it = 0; tile < ntiles; ++it) {
+    const uint32_t* patch = (!POOL && (it & 1)) ? patch1 : patch0;
+    int next;
+    if constexpr (POOL) {
+      const int rtn = tile % a.row_tiles;
+      next = rtn + 1 < a.row_tiles ? tile + 1 : (tile / a.row_tiles + G) * a.row_tiles;
+    } else {
+      next = tile + G;
+    }
     if (next < ntiles) fetch_window(next);          // in flight during this tile's MFMAs
 
     f32x4 acc[MTW][4];
@@ -219,13 +250,14 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
       }
     }
 
+    const int rt = tile % a.row_tiles, f = tile / a.row_tiles, ho0 = rt * ROWS;
+    const int rows_left = a.Ho - ho0;
+    if constexpr (!POOL) {
     // next tile's window -> the other LDS buffer (its last readers finished before the previous barrier)
     if (next < ntiles) store_window((it & 1) ? patch0 : patch1);
 
     // C/D map of the 16x16 MFMA: column (channel) = lane & 15, row (pixel) = (lane >> 4)*4 + e.
-    const int rt = tile % a.row_tiles, f = tile / a.row_tiles, ho0 = rt * ROWS;
     const int ybase = (f * a.Ho + ho0) * a.Wo * 64;     // element offset (y < 2 GiB checked on the host)
-    const int rows_left = a.Ho - ho0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = j * 16 + li;
@@ -242,6 +274,129 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
         }
       }
     }
+    } else {
+    // ---------------- fused 3x3 / stride-2 max pooling ----------------
+    const float NEG = -__builtin_inff();
+    // activation in place; pixels outside the frame count as -inf
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      const int p0 = (mt0 + m) * 16 + kq * 4;
+      const bool ok = m < mcnt && p0 < npix && p0 < rows_left * a.Wo;   // Wo % 4 == 0: a lane's 4 pixels share a row
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[m][j][e] * inv[j] + bias[j];
+          v = v >= 0.f ? v : v * slope[j];
+          acc[m][j][e] = ok ? v : NEG;
+        }
+    }
+    __syncthreads();   // B1: every wave is done reading the window; the exchange words are free
+    if (next < ntiles) store_window(patch0);
+    if (kq == 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xch[wave * 64 + j * 16 + li] = acc[MTW - 1][j][3];   // waves 6, 7: tile 2 is all -inf, fixed below
+    }
+    if (kq == 3 && mcnt == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xch[wave * 64 + j * 16 + li] = acc[1][j][3];
+    }
+    // the pixel left of a lane's first pixel: lane - 16 (same M tile) or lane + 48 of the previous M tile
+    float left[MTW][4];
+    {
+      float prev[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) prev[j] = NEG;
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float last = acc[m][j][3];   // (a bit_cast straight from a vector-element lvalue reads element 0)
+          const float got = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane - 16) & 63) * 4, __builtin_bit_cast(int, last)));
+          left[m][j] = kq > 0 ? got : prev[j];
+          prev[j] = got;   // for kq == 0 lanes: element 3 of lane + 48 = the last pixel of this M tile
+        }
+    }
+    __syncthreads();   // B2: exchange words visible
+    if (kq == 0 && wave > 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) left[0][j] = xch[(wave - 1) * 64 + j * 16 + li];
+    }
+    // column pooling: even pooled column 2u = max(left, v0, v1), odd 2u+1 = max(v1, v2, v3)
+    int orow[MTW], q0[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      const int p0 = (mt0 + m) * 16 + kq * 4;
+      orow[m] = p0 / a.Wo;
+      const int ocol = p0 - orow[m] * a.Wo;
+      q0[m] = ocol >> 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float l = ocol == 0 ? NEG : left[m][j];
+        const float he = fmaxf(fmaxf(l, acc[m][j][0]), acc[m][j][1]);
+        const float hod = fmaxf(fmaxf(acc[m][j][1], acc[m][j][2]), acc[m][j][3]);
+        acc[m][j][0] = he;
+        acc[m][j][1] = hod;
+      }
+    }
+    const int rows_here = rows_left < ROWS ? rows_left : ROWS;
+    float* halo_cur = halo + (it & 1) * 2 * a.Wp * HPITCH;          // written by the previous tile of this frame
+    float* halo_nxt = halo + ((it + 1) & 1) * 2 * a.Wp * HPITCH;
+    const int prow0 = rt * (ROWS / 2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {            // 32 channels per pass
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        if (m < mcnt && orow[m] < rows_here) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * h + jj;
+            float* dst = hbuf + (orow[m] * a.Wp + q0[m]) * HPITCH + jj * 16 + li;
+            dst[0] = acc[m][j][0];
+            dst[HPITCH] = acc[m][j][1];
+            if (orow[m] == ROWS - 1) {       // the row the next tile's first pooling window reaches up to
+              float* hd = halo_nxt + (h * a.Wp + q0[m]) * HPITCH + jj * 16 + li;
+              hd[0] = acc[m][j][0];
+              hd[HPITCH] = acc[m][j][1];
+            }
+          }
+        }
+      }
+      __syncthreads();   // B3 / B5: the pass's column-pooled rows are in LDS
+      const int items = (ROWS / 2) * a.Wp * 8;          // (pooled row, pooled column, 4-channel group)
+      for (int i = tid; i < items; i += 512) {
+        const int c4 = i & 7;
+        const int q = (i >> 3) % a.Wp;
+        const int prl = (i >> 3) / a.Wp;
+        const int pr = prow0 + prl;
+        if (pr < a.Hp) {
+          const int r1 = 2 * prl;             // local stem rows 2 prl - 1, 2 prl, 2 prl + 1
+          f32x4 v = *reinterpret_cast<const f32x4*>(hbuf + (r1 * a.Wp + q) * HPITCH + c4 * 4);
+          if (r1 + 1 < rows_here) {
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(hbuf + ((r1 + 1) * a.Wp + q) * HPITCH + c4 * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], w2[c]);
+          }
+          if (r1 > 0 || rt > 0) {
+            const float* up = r1 > 0 ? hbuf + ((r1 - 1) * a.Wp + q) * HPITCH : halo_cur + (h * a.Wp + q) * HPITCH;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(up + c4 * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], w0[c]);
+          }
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          h4 hi, lo;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); }
+          // split activation format: pixel = 64 channels = two 128-B blocks of (32 hi | 32 lo) halves
+          const uint32_t off = (uint32_t)(((f * a.Hp + pr) * a.Wp + q) * 256 + h * 128 + c4 * 8);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), yr, (int)off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), yr, (int)off + 64, 0, 0);
+        }
+      }
+      if (h == 0) __syncthreads();   // B4: pass 1 overwrites the row buffer
+    }
+    }
+    tile = next;
     __syncthreads();   // window (it+1) complete and window (it) free before the next iteration
   }
 }
@@ -268,9 +423,40 @@ extern "C" int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, con
   const long long xb = (long long)B * T * H * W * 4, yb = (long long)B * T * a.Ho * a.Wo * 64 * 4;
   if (xb > DLIP_MAX_BUFFER_BYTES || yb > DLIP_MAX_BUFFER_BYTES) return DLIP_ERANGE;
   a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
+  a.Hp = a.Wp = 0; a.n_frames = B * T;
   const long long grid = tiles < 256 ? tiles : 256;   // persistent: one workgroup per CU (154 KB of LDS each)
   const size_t ldsb = (size_t)WBYTES + 2 * (size_t)KT * PR * a.pwp * 4;
-  auto kern = stem3d_f16x3_kernel;
+  auto kern = stem3d_f16x3_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, static_cast<hipStream_t>(stream), a);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_stem3d_pool_f16x3(const float* x, const void* w_split, const float* w_scale, const float* bias,
+                                      const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
+                                      int32_t K, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && w_split && w_scale && y && B > 0 && T > 0 && H > 0 && W > 0);
+  DLIP_CHECK_ARG(K == 64 && (H & 1) == 0 && (W & 7) == 0);   // Wo % 4 == 0: a lane's 4 pixels stay in one row
+  StemArgs a;
+  a.x = x; a.w = static_cast<const uint32_t*>(w_split); a.wscale = w_scale; a.bias = bias; a.slope = slope; a.y = y;
+  a.T = T; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
+  a.Hp = (a.Ho - 1) / 2 + 1; a.Wp = (a.Wo - 1) / 2 + 1;
+  a.row_tiles = (a.Ho + ROWS - 1) / ROWS;
+  a.pwp = ((W + 6 - 32 + 63) / 64) * 64 + 32;
+  DLIP_CHECK_ARG(ROWS * a.Wo <= 22 * 16);
+  DLIP_CHECK_ARG(KT * PR * a.pwp <= 512 * 20);
+  const long long frames = (long long)B * T, tiles = frames * a.row_tiles;
+  if (tiles > 0x7FFFFFFFll) return DLIP_ERANGE;
+  a.n_tiles = (int)tiles;
+  a.n_frames = (int)frames;
+  const long long xb = frames * H * W * 4, yb = frames * a.Hp * a.Wp * 64 * 4;
+  if (xb > DLIP_MAX_BUFFER_BYTES || yb > DLIP_MAX_BUFFER_BYTES) return DLIP_ERANGE;
+  a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
+  const long long grid = frames < 256 ? frames : 256;   // persistent: a workgroup walks whole frames
+  const size_t ldsb = (size_t)WBYTES + (size_t)KT * PR * a.pwp * 4 + (size_t)(ROWS + 4) * a.Wp * HPITCH * 4 + 8 * 64 * 4;
+  DLIP_CHECK_ARG(ldsb <= 160 * 1024);
+  auto kern = stem3d_f16x3_kernel<true>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, static_cast<hipStream_t>(stream), a);

@@ -163,6 +163,24 @@ def stem3d(x_bthw: Tensor, w_248xk: Tensor, bias: Tensor, slope: Optional[Tensor
     return y
 
 
+def stem3d_pool(x_bthw: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Tensor], w_scale: Tensor) -> Tensor:
+    """x [B,T,H,W] -> [(B*T), Hp, Wp, 64] in the split activation format: Conv3d 5x7x7 + folded BN +
+    PReLU/ReLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) in one kernel (split-fp16 weights image only)."""
+    for t, n in ((x_bthw, "x"), (w_img, "w"), (bias, "bias"), (slope, "slope"), (w_scale, "w_scale")):
+        _req(t, n)
+    B, T, H, W = x_bthw.shape
+    Ho, Wo = H // 2, W // 2
+    y = torch.empty((B * T, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), device=x_bthw.device, dtype=torch.float32)
+    hook = LAUNCH_HOOK
+    if hook is not None:
+        tok = hook.begin("stem3d_f16x3_kernel<pool>", 2.0 * B * T * Ho * Wo * 64 * 245)
+    check(lib().dlip_stem3d_pool_f16x3(ptr(x_bthw), ptr(w_img), ptr(w_scale), ptr(bias), ptr(slope), ptr(y),
+                                       B, T, H, W, 64, stream_handle()), "dlip_stem3d_pool_f16x3")
+    if hook is not None:
+        hook.end(tok)
+    return y
+
+
 def split_pack(x: Tensor) -> Tensor:
     """fp32 [..., C] -> split activation format (same shape / dtype container; C % 32 == 0)."""
     _req(x, "x")

@@ -364,14 +364,18 @@ class Lipreading(nn.Module):
                              "deeplip_amd.ops.ingest_rgb_u8 for [B,T,3,H,W] uint8 RGB")
         p = _cached_pack(self, x.device, self._pack)
         x = x.contiguous().float()
-        y = ops.stem3d(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope,
-                       w_scale=p["stem"].wscale if W <= 88 else None)   # [(B*T),H/2,W/2,64]
-        if taps is not None:
-            taps["stem_act"] = y
         split = self.trunk.wants_split(p["trunk"])
-        y = ops.maxpool3x3s2(y, out_split=split)
-        if taps is not None:
-            taps["stem"] = ops.split_unpack(y) if split else y
+        if split and taps is None and p["stem"].wscale is not None and W <= 88 and W % 8 == 0:
+            # stem + max pooling in one kernel: the pre-pool activations (4x the pooled bytes) stay on chip
+            y = ops.stem3d_pool(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope, p["stem"].wscale)
+        else:
+            y = ops.stem3d(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope,
+                           w_scale=p["stem"].wscale if W <= 88 else None)   # [(B*T),H/2,W/2,64]
+            if taps is not None:
+                taps["stem_act"] = y
+            y = ops.maxpool3x3s2(y, out_split=split)
+            if taps is not None:
+                taps["stem"] = ops.split_unpack(y) if split else y
         y = self.trunk.run(y, p["trunk"], taps, x_split=split).view(B, T, self.backend_out)
         return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
 

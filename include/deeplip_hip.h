@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 6
+#define DLIP_ABI_VERSION 7
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -120,6 +120,14 @@ int dlip_stem3d_bn_act_f32(const float* x, const float* w_k248, const float* bia
 int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, const float* w_scale, const float* bias,
                              const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
                              int32_t K, dlip_stream_t stream);
+
+/* dlip_stem3d_bn_act_f16x3 + MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) in one kernel (replaces
+ * models/video_models/model.py:81-85): the pre-pool activations never reach memory.  y is
+ * [(B*T), Hp, Wp, 64] with Hp = (H/2 - 1)/2 + 1, in the split activation format of
+ * dlip_conv_nhwc_f16x3 (what the trunk's first layers read).  W % 8 == 0, W <= 88. */
+int dlip_stem3d_pool_f16x3(const float* x, const void* w_split, const float* w_scale, const float* bias,
+                           const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
+                           int32_t K, dlip_stream_t stream);
 
 /* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) on NHWC: [N,H,W,C] -> [N,Ho,Wo,C],
  * Ho = (H+2-3)/2+1.  Replaces models/video_models/model.py:85.  C % 4 == 0.  out_split != 0 writes y

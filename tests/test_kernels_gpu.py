@@ -444,3 +444,22 @@ def test_maxpool_split_output(ops):
     ys = ops.maxpool3x3s2(x.cuda(), out_split=True)
     torch.cuda.synchronize()
     assert torch.equal(ys.cpu().view(torch.int32), _split_ref(y.cpu()).view(torch.int32))
+
+
+@pytest.mark.parametrize("B,T,H,W", [(2, 7, 88, 88), (1, 3, 24, 24), (1, 2, 40, 56), (3, 1, 72, 88), (300, 1, 16, 16)])
+def test_stem3d_pool_f16x3(ops, B, T, H, W):
+    """Stem + MaxPool fused: the same bits as the split-fp16 stem kernel followed by the pooling kernel
+    (same MFMA order, max is exact), in the split activation format; ragged last row tiles, frames
+    walked by more and by fewer workgroups than there are CUs."""
+    from deeplip_amd import packing
+    x = (rnd(B, T, H, W, seed=51) * 2.0).cuda()
+    w = rnd(64, 1, 5, 7, 7, seed=52, scale=1.0 / np.sqrt(245))
+    b = rnd(64, seed=53, scale=0.1).cuda()
+    slope = (torch.rand(64, generator=torch.Generator().manual_seed(54)) * 0.3).cuda()
+    img, sc = packing.split_stem_weights(w.double())
+    img, sc = img.cuda(), sc.cuda()
+    ref = ops.maxpool3x3s2(ops.stem3d(x, img, b, slope, w_scale=sc), out_split=True)
+    y = ops.stem3d_pool(x, img, b, slope, sc)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert torch.equal(y.cpu().view(torch.int32), ref.cpu().view(torch.int32))
