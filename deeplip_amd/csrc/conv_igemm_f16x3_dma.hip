@@ -61,7 +61,7 @@ __device__ __forceinline__ void dma_piece(const u32x4 rsrc, uint32_t voff, uint3
       "s_nop 0\n\t"
       "buffer_load_dwordx4 %1, %2, 0 offen lds"
       :
-      : "s"(lds_base), "v"(voff), "s"(rsrc)
+      : "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(voff), "s"(rsrc)   // (readfirstlane: the base is wave-uniform by construction; this pins it to an SGPR)
       : "memory");   // m0 is reserved: hipcc keeps nothing in it across statements (the ISA dump shows no other m0 use)
 }
 
@@ -80,12 +80,12 @@ struct StreamK {
   int* counters;     // [tiles], zero between launches (the last arriver resets its tile's word)
   int G;             // workgroups in the grid
 #ifdef DLIP_STAMPS
-  unsigned long long* stamps;   // diagnostic build only: [G][8] s_memtime values of each workgroup's first segment
+  unsigned long long* stamps;   // diagnostic build only: [G][10] s_memtime values of each workgroup's first segment
 #endif
 };
 
 #ifdef DLIP_STAMPS
-#define DLIP_STAMP(i) do { if (threadIdx.x == 0 && it == it_begin) sk.stamps[(size_t)g * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DLIP_STAMP(i) do { if (threadIdx.x == 0 && it == it_begin) sk.stamps[(size_t)g * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DLIP_STAMP(i) do { } while (0)
 #endif
@@ -139,15 +139,26 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const int ntaps = a.R * a.S;
 
   const long long it_begin = (long long)g * sk.iters / sk.G, it_end = (long long)(g + 1) * sk.iters / sk.G;
+#ifdef DLIP_STAMPS
+  if (threadIdx.x == 0) sk.stamps[(size_t)g * 10 + 8] = __builtin_amdgcn_s_memrealtime();
+#endif
   for (long long it = it_begin; it < it_end;) {
     const int tile = (int)(it / a.nk);
     const int k0 = (int)(it - (long long)tile * a.nk);
     const int kn = (int)((it_end - it) < (long long)(a.nk - k0) ? (it_end - it) : (long long)(a.nk - k0));
-    const int tile_n = tile % a.tiles_n;
-    const int tile_m = tile / a.tiles_n;
+    // Tile order: output-channel block OUTER.  A workgroup's range, and (through the XCD remap of g) an
+    // XCD's eighth of the launch, then stays on one 128-channel weight block -- BN x R x S x C x 4 bytes,
+    // which fits the XCD's 4 MiB L2 where the whole filter bank of layer3/4 (2.4 / 9.4 MB) does not --
+    // while the activation rows stream through once per block.
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tile_n = tile / tiles_m;
+    const int tile_m = tile - tile_n * tiles_m;
     // every wave is done reading the previous segment's last stage (and the ticket word) before the ring is refilled
     if (it != it_begin) __syncthreads();
     DLIP_STAMP(0);
+#ifdef DLIP_STAMPS
+    if (threadIdx.x == 0 && it == it_begin) sk.stamps[(size_t)g * 10 + 7] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+#endif
 
     // Per-row gather state, branch-free: byte offset of the row's window origin and a bit per filter tap
     // that stays inside the image (columns and rows tested separately: R + S steps, not R x S).
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
               const f32x4 inv4 = tab[kl >> 2], bi4 = tab[(BN + kl) >> 2], sl4 = tab[(2 * BN + kl) >> 2];
               f32x4 ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
               if (post) { ps4 = tab[(3 * BN + kl) >> 2]; pt4 = tab[(4 * BN + kl) >> 2]; }
-              const int ch = (kl >> 5) * 8 + j;      // hi chunk of these 4 channels within the row (lo: + 4)
+              const int ch = (kl >> 5) * 10 + j;      // hi chunk of these 4 channels within the row (lo: + 4)
 #pragma unroll
               for (int mi = 0; mi < MI; ++mi) {
                 const int r = wm * WM - band0 + mi * 32 + lrow_e;      // band row of this lane's pixel
@@ -504,12 +515,20 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #ifdef DLIP_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && it == it_begin) {
-      sk.stamps[(size_t)g * 8 + 5] = __builtin_amdgcn_s_memtime();
-      sk.stamps[(size_t)g * 8 + 6] = (unsigned long long)kn;
+      sk.stamps[(size_t)g * 10 + 5] = __builtin_amdgcn_s_memtime();
+      sk.stamps[(size_t)g * 10 + 6] = (unsigned long long)kn;
+      sk.stamps[(size_t)g * 10 + 7] = __builtin_amdgcn_s_memrealtime() - sk.stamps[(size_t)g * 10 + 7];
     }
 #endif
     it += kn;
   }
+#ifdef DLIP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) {
+    sk.stamps[(size_t)g * 10 + 9] = __builtin_amdgcn_s_memrealtime();
+    sk.stamps[(size_t)g * 10 + 6] |= (unsigned long long)(blockIdx.x & 7) << 32;
+  }
+#endif
 }
 
 // Per-stream workspace of the balanced split: slabs + ticket counters (zeroed once; every launch leaves
@@ -605,24 +624,64 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
   {   // diagnostic build (tools/probes/stamps.sh): median cycles between the stamps of each workgroup's first segment
     static unsigned long long* dbuf = nullptr;
     static size_t cap = 0;
-    if (cap < (size_t)G * 8) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc(reinterpret_cast<void**>(&dbuf), (size_t)G * 8 * 8); cap = (size_t)G * 8; }
-    (void)hipMemsetAsync(dbuf, 0, (size_t)G * 8 * 8, st);
+    if (cap < (size_t)G * 10) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc(reinterpret_cast<void**>(&dbuf), (size_t)G * 10 * 8); cap = (size_t)G * 10; }
+    (void)hipMemsetAsync(dbuf, 0, (size_t)G * 10 * 8, st);
     sk.stamps = dbuf;
     hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(threads), lds, st, b, sk);
     (void)hipStreamSynchronize(st);
-    std::vector<unsigned long long> h((size_t)G * 8);
+    std::vector<unsigned long long> h((size_t)G * 10);
     (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
     if (getenv("DLIP_STAMP_PRINT")) {
-      std::vector<double> d[5], per;
+      std::vector<double> d[5], per, clk;
       for (long long i = 0; i < G; ++i) {
-        const unsigned long long* r = &h[(size_t)i * 8];
+        const unsigned long long* r = &h[(size_t)i * 10];
         if (!r[5]) continue;
         for (int j = 0; j < 5; ++j) d[j].push_back((double)(r[j + 1] - r[j]));
-        per.push_back((double)(r[4] - r[3]) / (double)(r[6] ? r[6] : 1));
+        per.push_back((double)(r[4] - r[3]) / (double)((r[6] & 0xffffffffull) ? (r[6] & 0xffffffffull) : 1));
+        if (r[7]) clk.push_back((double)(r[5] - r[0]) / (double)r[7] * 100.0);   // MHz: s_memtime ticks per 100 MHz s_memrealtime tick
       }
+      unsigned long long t0 = ~0ull, t1 = 0, s1 = 0;
+      std::vector<double> dur;
+      for (long long i = 0; i < G; ++i) {
+        const unsigned long long* r = &h[(size_t)i * 10];
+        if (!r[9]) continue;
+        t0 = r[8] < t0 ? r[8] : t0; s1 = r[8] > s1 ? r[8] : s1; t1 = r[9] > t1 ? r[9] : t1;
+        dur.push_back((double)(r[9] - r[8]) / 100.0);
+      }
+      {   // busy time by XCD and by number of segments in the workgroup's range
+        double xs[8] = {0}, ss[4] = {0}; int xn[8] = {0}, sn[4] = {0};
+        for (long long i = 0; i < G; ++i) {
+          const unsigned long long* r = &h[(size_t)i * 10];
+          if (!r[9]) continue;
+          const double d = (double)(r[9] - r[8]) / 100.0;
+          const int x = (int)((r[6] >> 32) & 7);
+          xs[x] += d; xn[x]++;
+          const long long b0 = i * sk.iters / G, b1 = (i + 1) * sk.iters / G;
+          const int nseg = (int)((b1 - 1) / a.nk - b0 / a.nk) + 1;
+          ss[nseg < 4 ? nseg : 3] += d; sn[nseg < 4 ? nseg : 3]++;
+        }
+        fprintf(stderr, "[stamps wall] mean busy by XCD:");
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", xn[x] ? xs[x] / xn[x] : 0.0);
+        fprintf(stderr, "   by segments 1/2/3+:");
+        for (int k = 1; k < 4; ++k) fprintf(stderr, " %.1f(n=%d)", sn[k] ? ss[k] / sn[k] : 0.0, sn[k]);
+        fprintf(stderr, "\n");
+      }
+      if (const char* dump = getenv("DLIP_STAMP_DUMP")) {
+        if (FILE* fp = fopen(dump, "w")) {
+          for (long long i = 0; i < G; ++i) {
+            const unsigned long long* r = &h[(size_t)i * 10];
+            fprintf(fp, "%lld,%d,%.2f,%.2f\n", i, (int)((r[6] >> 32) & 7), (double)(r[8] - t0) / 100.0, (double)(r[9] - r[8]) / 100.0);
+          }
+          fclose(fp);
+        }
+      }
+      std::sort(dur.begin(), dur.end());
+      if (!dur.empty())
+        fprintf(stderr, "[stamps wall] kernel span %.1f us; workgroup starts spread %.1f us; workgroup busy min %.1f med %.1f max %.1f us\n",
+                (double)(t1 - t0) / 100.0, (double)(s1 - t0) / 100.0, dur.front(), dur[dur.size() / 2], dur.back());
       auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
-      fprintf(stderr, "[stamps %dx%d M=%d K=%d nk=%d G=%lld tiles=%lld] setup %.0f  issue+init %.0f  first-wait %.0f  loop %.0f (%.0f/slice)  tail %.0f  (s_memtime ticks = 100 MHz)\n",
-              BM, BN, a.M, a.K, a.nk, G, tiles, med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(per), med(d[4]));
+      fprintf(stderr, "[stamps %dx%d M=%d K=%d nk=%d G=%lld tiles=%lld] setup %.0f  issue+init %.0f  first-wait %.0f  loop %.0f (%.0f/slice)  tail %.0f  clock %.0f MHz\n",
+              BM, BN, a.M, a.K, a.nk, G, tiles, med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(per), med(d[4]), med(clk));
     }
     return dlip_launch_status();
   }
