@@ -233,7 +233,7 @@ def main():
                 "traffic": None, "step_achieved": round(step_tf, 2), "step_frac": round(step_tf / peak, 4)}
         if precision != "f32":
             roof["peak_note"] = ("algorithmic (2*M*N*K) FLOP/s ceiling of the split-fp16 scheme = 2500 TFLOP/s dense f16 MFMA / 3 "
-                                 "MFMAs per product; the stem kernel stays exact fp32")
+                                 "MFMAs per product (conv / linear layers and the stem)")
         if not args.no_kernel_events:
             agg = hook.summary()
             name, a = max(agg.items(), key=lambda kv: kv[1]["flops"])

@@ -351,7 +351,13 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   if (rc != DLIP_OK) return rc;
   a.wscale = w_scale;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if ((flags & 1) && dlip_conv_dma_enabled()) return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) != 0);
+  // Split-format activations go to the LDS-DMA kernel.  Its epilogue leaves in 16-byte chunks, so an fp32
+  // output needs K, ldy in multiples of 4 and a 16-byte aligned y (a split output already has K, ldy % 32 == 0);
+  // anything else stays on the register-staged kernel below.
+  const bool dma_ok = (flags & 2) ? (reinterpret_cast<uintptr_t>(y) & 15) == 0
+                                  : ((d->K & 3) == 0 && (d->ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  const bool res_ok = residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
+  if ((flags & 1) && dma_ok && res_ok && dlip_conv_dma_enabled()) return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) != 0);
   switch (pick_tile(a.M, d->K, kEffF16x3)) {
     case 0: return launch<128, 128, 2, 2>(a, st, flags);
     case 1: return launch<128, 64, 2, 2>(a, st, flags);

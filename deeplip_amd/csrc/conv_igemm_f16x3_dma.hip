@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
               const f32x4 inv4 = tab[kl >> 2], bi4 = tab[(BN + kl) >> 2], sl4 = tab[(2 * BN + kl) >> 2];
               f32x4 ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
               if (post) { ps4 = tab[(3 * BN + kl) >> 2]; pt4 = tab[(4 * BN + kl) >> 2]; }
-              const int ch = (kl >> 5) * 10 + j;      // hi chunk of these 4 channels within the row (lo: + 4)
+              const int ch = (kl >> 5) * 8 + j;       // hi chunk of these 4 channels within the row (lo: + 4)
 #pragma unroll
               for (int mi = 0; mi < MI; ++mi) {
                 const int r = wm * WM - band0 + mi * 32 + lrow_e;      // band row of this lane's pixel

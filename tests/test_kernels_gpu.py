@@ -463,3 +463,18 @@ def test_stem3d_pool_f16x3(ops, B, T, H, W):
     torch.cuda.synchronize()
     assert y.shape == ref.shape
     assert torch.equal(y.cpu().view(torch.int32), ref.cpu().view(torch.int32))
+
+
+def test_conv_split_input_odd_output_width(ops):
+    """Split-format input with an output width the LDS-DMA kernel's 16-byte epilogue cannot write
+    (K % 4 != 0): the launch must fall back to the register-staged kernel, not write past rows."""
+    from deeplip_amd import packing
+    x = rnd(2, 1, 50, 64, seed=61)
+    w = rnd(30, 1, 3, 64, seed=62, scale=1.0 / np.sqrt(192))
+    b = rnd(30, seed=63, scale=0.1)
+    ws, sc = packing.split_weights(w.double())
+    xs = ops.split_pack(x.cuda())
+    y = ops.conv_nhwc(xs, ws.cuda(), b.cuda(), pad=(0, 1), w_scale=sc.cuda(), x_split=True)
+    torch.cuda.synchronize()
+    ref = F.conv2d(ops.split_unpack(xs).cpu().permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=(0, 1))
+    assert rel_err(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL

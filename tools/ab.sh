@@ -4,7 +4,7 @@
 #   box:   tools/ab.sh run [bench_dma.py args]   -> interleaved rounds, A = snapshot, B = working tree build
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 if [ "$1" = snapshot ]; then
-  T=$(mktemp -d); git -C $R archive HEAD deeplip_amd/csrc include | tar -x -C $T
+  T=$(mktemp -d); git -C $R archive ${2:-HEAD} deeplip_amd/csrc include | tar -x -C $T
   for f in $T/deeplip_amd/csrc/*.hip; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$T/include -I$T/deeplip_amd/csrc -c $f -o $T/$(basename $f .hip).o &
   done; wait
