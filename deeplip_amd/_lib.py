@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lock = threading.Lock()
 _lib = None
@@ -36,6 +36,8 @@ SIGNATURES = {
     "dlip_abi_version": [],
     "dlip_conv_nhwc_f32": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_stream],
     "dlip_conv_nhwc_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_stream],
+    "dlip_conv_workspace_bytes": [],
+    "dlip_conv_set_workspace": [c_f, c_i64, c_stream],
     "dlip_split_pack_f32": [c_f, c_f, C.c_int64, c_i32, c_stream],
     "dlip_split_unpack_f32": [c_f, c_f, C.c_int64, c_i32, c_stream],
     "dlip_conv_plan": [C.POINTER(ConvDesc), c_i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
@@ -94,6 +96,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
             fn.argtypes = args
             fn.restype = C.c_int
+        l.dlip_conv_workspace_bytes.restype = C.c_int64
         l.dlip_error_string.argtypes = [C.c_int]
         l.dlip_error_string.restype = C.c_char_p
         v = l.dlip_abi_version()
@@ -118,3 +121,22 @@ def ptr(t) -> int | None:
 
 def stream_handle() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+# Workspace of the conv kernel's balanced work split: one torch-owned block per (device, stream),
+# registered with the library the first time that stream launches a convolution, so the library itself
+# never allocates device memory.
+_workspaces: dict = {}
+
+
+def ensure_conv_workspace() -> None:
+    st = torch.cuda.current_stream()
+    key = (torch.cuda.current_device(), st.cuda_stream)
+    if key in _workspaces:
+        return
+    nbytes = int(lib().dlip_conv_workspace_bytes())
+    if nbytes <= 0:
+        raise DeepLipHipError("dlip_conv_workspace_bytes failed (no ROCm device?)")
+    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    check(lib().dlip_conv_set_workspace(buf.data_ptr(), nbytes, st.cuda_stream), "dlip_conv_set_workspace")
+    _workspaces[key] = buf

@@ -531,24 +531,34 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #endif
 }
 
-// Per-stream workspace of the balanced split: slabs + ticket counters (zeroed once; every launch leaves
-// them zero).  Launches on one stream are ordered, so they can share it; another stream gets its own.
+// Per-stream workspace of the balanced split: ticket counters (zeroed once; every launch leaves them
+// zero) + slabs.  Launches on one stream are ordered, so they can share it; another stream needs its own.
+// The caller normally owns it (dlip_conv_workspace_bytes / dlip_conv_set_workspace: the Python
+// binding registers a torch allocation per stream); a stream nobody registered a block for gets a
+// library-owned one on first use, and a registered block that is too small for a launch simply makes
+// that launch a plain (unbalanced) one.
 struct Workspace {
   float* slabs = nullptr;
   int* counters = nullptr;
   size_t slab_floats = 0;
+  bool external = false;
 };
 constexpr int kMaxSplitTiles = 1 << 16;   // counter words per workspace
 constexpr double kSlotFlops = 0.85e12;    // algorithmic FLOP/s one resident 128x128 workgroup sustains (measured, 2 per CU)
 constexpr double kHandoffUs = 10.0;       // cost of the slab hand-off of a launch at 128x128 tiles (measured)
 
+std::mutex& ws_mutex() { static std::mutex m; return m; }
+std::map<std::pair<int, hipStream_t>, Workspace>& ws_table() {
+  static std::map<std::pair<int, hipStream_t>, Workspace> t;
+  return t;
+}
+
 Workspace* workspace_for(hipStream_t st, size_t slab_floats) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Workspace> table;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  Workspace& w = table[{dev, st}];
+  std::lock_guard<std::mutex> lock(ws_mutex());
+  Workspace& w = ws_table()[{dev, st}];
+  if (w.external) return w.slab_floats >= slab_floats ? &w : nullptr;
   if (w.counters == nullptr) {
     if (hipMalloc(reinterpret_cast<void**>(&w.counters), kMaxSplitTiles * sizeof(int)) != hipSuccess) return nullptr;
     if (hipMemset(w.counters, 0, kMaxSplitTiles * sizeof(int)) != hipSuccess) return nullptr;
@@ -615,9 +625,12 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
   }
   if (G != tiles) {
     Workspace* w = workspace_for(st, (size_t)2 * G * BM * BN);
-    if (w == nullptr) return DLIP_EINVAL;
-    sk.slabs = w->slabs;
-    sk.counters = w->counters;
+    if (w == nullptr) {
+      G = tiles;   // no (or too small a) workspace: plain launch
+    } else {
+      sk.slabs = w->slabs;
+      sk.counters = w->counters;
+    }
   }
   sk.G = (int)G;
 #ifdef DLIP_STAMPS
@@ -738,4 +751,37 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 8: return launch_dma<256, 64, 4, 2, 2, 1>(a, st, out_split);
     default: return launch_dma<128, 128, 4, 2, 3, 1>(a, st, out_split);
   }
+}
+
+// ---- caller-owned workspace (include/deeplip_hip.h) ----
+extern "C" int64_t dlip_conv_workspace_bytes(void) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return -1;
+  // counters + two slabs per resident workgroup: 2 per CU x 128x128 fp32 is the largest product on the menu
+  return (int64_t)kMaxSplitTiles * 4 + (int64_t)2 * (2 * cus) * 128 * 128 * 4;
+}
+
+extern "C" int dlip_conv_set_workspace(void* ptr, int64_t bytes, dlip_stream_t stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return DLIP_EINVAL;
+  std::lock_guard<std::mutex> lock(ws_mutex());
+  Workspace& w = ws_table()[{dev, st}];
+  if (ptr == nullptr) {   // unregister: the stream falls back to a library-owned block
+    if (w.external) w = Workspace();
+    return DLIP_OK;
+  }
+  DLIP_CHECK_ARG((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && bytes >= (int64_t)kMaxSplitTiles * 4 + 16);
+  if (!w.external && (w.slabs || w.counters)) {   // drop the library-owned block this stream used so far
+    if (hipStreamSynchronize(st) != hipSuccess) return DLIP_EINVAL;
+    if (w.slabs) (void)hipFree(w.slabs);
+    if (w.counters) (void)hipFree(w.counters);
+  }
+  if (hipMemsetAsync(ptr, 0, (size_t)kMaxSplitTiles * 4, st) != hipSuccess) return DLIP_EINVAL;   // tickets start at zero
+  w.counters = static_cast<int*>(ptr);
+  w.slabs = reinterpret_cast<float*>(static_cast<char*>(ptr) + (size_t)kMaxSplitTiles * 4);
+  w.slab_floats = ((size_t)bytes - (size_t)kMaxSplitTiles * 4) / 4;
+  w.external = true;
+  return DLIP_OK;
 }

@@ -96,6 +96,8 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
         kname = ("conv_igemm_f32_kernel", "conv_igemm_f16x3_kernel", "", "conv_igemm_f16x3_dma_kernel")[mode]
         tok = hook.begin(f"{kname}<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
     if w_scale is not None:
+        if x_split:
+            _lib.ensure_conv_workspace()
         check(lib().dlip_conv_nhwc_f16x3(C.byref(d), xp, ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(residual),
                                          ptr(slope), ptr(post_scale), ptr(post_shift), yp,
                                          int(x_split) | 2 * int(out_split), stream_handle()),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 7
+#define DLIP_ABI_VERSION 8
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -90,6 +90,17 @@ int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_
                          const float* w_scale, const float* bias, const float* residual,
                          const float* slope, const float* post_scale, const float* post_shift,
                          float* y, int32_t flags, dlip_stream_t stream);
+
+/* Workspace of dlip_conv_nhwc_f16x3's balanced ("stream-K") work split on split-format activations:
+ * ticket counters + partial-tile slabs, one block PER STREAM (launches on a stream are ordered and share
+ * it).  dlip_conv_workspace_bytes() = size that covers every launch on the current device;
+ * dlip_conv_set_workspace registers a caller-owned device block for `stream` (16-byte aligned; its counter
+ * words are zeroed asynchronously on that stream; it must stay valid until replaced, unregistered with
+ * ptr = NULL, or the stream's work has completed).  A smaller block is legal: launches that need more
+ * than it holds run as plain launches.  A stream without a registered block gets a library-owned one on
+ * first use (the only allocation the library ever makes). */
+int64_t dlip_conv_workspace_bytes(void);
+int dlip_conv_set_workspace(void* ptr, int64_t bytes, dlip_stream_t stream);
 
 /* fp32 [rows, C] -> split activation format (and back), C % 32 == 0.  Boundary converters for callers
  * that hold fp32 tensors; inside the encoders the producers write the split format directly. */

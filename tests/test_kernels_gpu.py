@@ -478,3 +478,31 @@ def test_conv_split_input_odd_output_width(ops):
     torch.cuda.synchronize()
     ref = F.conv2d(ops.split_unpack(xs).cpu().permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=(0, 1))
     assert rel_err(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+
+
+def test_conv_workspace_is_caller_owned(ops):
+    """The balanced split's workspace is registered per stream by the binding (torch-owned); a stream with
+    a block too small for slabs still computes the same result through plain launches."""
+    from deeplip_amd import _lib, packing
+    lib = _lib.lib()
+    need = int(lib.dlip_conv_workspace_bytes())
+    assert need > (1 << 18)
+    x = ops.split_pack((rnd(700, 6, 6, 256, seed=71) * 2.0).cuda())
+    w = rnd(256, 3, 3, 256, seed=72, scale=1.0 / np.sqrt(2304))
+    ws, sc = packing.split_weights(w.double())
+    ws, sc, b = ws.cuda(), sc.cuda(), rnd(256, seed=73, scale=0.1).cuda()
+    y0 = ops.conv_nhwc(x, ws, b, pad=(1, 1), w_scale=sc, x_split=True)          # default stream: full workspace, balanced split
+    assert (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream) in _lib._workspaces
+    side = torch.cuda.Stream()
+    small = torch.empty((1 << 18) + 4096, dtype=torch.uint8, device="cuda")      # counters + 4 KB: no room for a slab
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        _lib.check(lib.dlip_conv_set_workspace(small.data_ptr(), small.numel(), side.cuda_stream), "dlip_conv_set_workspace")
+        _lib._workspaces[(torch.cuda.current_device(), side.cuda_stream)] = small
+        y1 = ops.conv_nhwc(x, ws, b, pad=(1, 1), w_scale=sc, x_split=True)
+    torch.cuda.synchronize()
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 2e-6
+    with pytest.raises(Exception):
+        _lib.check(lib.dlip_conv_set_workspace(small.data_ptr(), 1024, side.cuda_stream), "dlip_conv_set_workspace")   # too small for the counters
+    _lib.check(lib.dlip_conv_set_workspace(None, 0, side.cuda_stream), "dlip_conv_set_workspace")                      # unregister
+    del _lib._workspaces[(torch.cuda.current_device(), side.cuda_stream)]
