@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lock = threading.Lock()
 _lib = None
@@ -36,6 +36,15 @@ SIGNATURES = {
     "dlip_abi_version": [],
     "dlip_conv_nhwc_f32": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_stream],
     "dlip_conv_nhwc_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_stream],
+    "dlip_bn_rows_chunks": [c_i32],
+    "dlip_bn_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_i32, c_stream],
+    "dlip_bn_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_stream],
+    "dlip_colsum_rows_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
+    "dlip_meanstd_pool_bwd_f32": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_stream],
+    "dlip_permute3_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_pow2_scale_f32": [c_f, c_f, c_i64, C.c_float, c_stream],
+    "dlip_split_pack_scaled_f32": [c_f, c_f, c_f, c_i64, c_i32, c_stream],
+    "dlip_fill_from_scalar_f32": [c_f, c_f, c_i32, c_stream],
     "dlip_conv_workspace_bytes": [],
     "dlip_conv_set_workspace": [c_f, c_i64, c_stream],
     "dlip_split_pack_f32": [c_f, c_f, C.c_int64, c_i32, c_stream],

@@ -162,9 +162,28 @@ class SpeakerEmbNet(nn.Module):
         h = ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim, 32 if split else 4))
         return ops.split_pack(h) if split else h
 
+    def _extract_embedding_train(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+        """extract_embedding under model.train() (train_audio.py:167-183): batch-statistics BatchNorm, every
+        layer differentiable.  Each step is a torch.autograd Function whose forward and backward are dlip_*
+        launches (deeplip_amd/autograd.py: TDNNBlockTrainFn, MeanStdPoolFn, LinearFn, BNRowsActFn)."""
+        from . import autograd as ag
+        if self.pooling_type != "statistic":
+            raise NotImplementedError("train-mode encoder: only pooling='statistic' (the shipped configs)")
+        if self.input_dim % 4:
+            raise ValueError("train-mode encoder: input_dim must be a multiple of 4")
+        h = self._to_ntc(x)                                   # [B,T,F] channels-last
+        for blk in self.tdnn:
+            h = ag.tdnn_block_train(h, blk)
+        h = ag.meanstd_pool(h)
+        x_a = ag.linear(h, self.fc1.weight, self.fc1.bias)
+        h = ag.bn_rows_act_train(x_a, self.bn1, LRELU, act_first=not self.bn_first)
+        xv = ag.linear(h, self.fc2.weight, self.fc2.bias)
+        return xv, x_a
+
     def extract_embedding(self, x: Tensor, taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
         """[B,F,T] -> (xv [B,E] = fc2 output, x_a [B,E] = fc1 output)   (tdnn.py:89-101)."""
-        _require_eval(self)
+        if self.training:
+            return self._extract_embedding_train(x)
         p = _cached_pack(self, x.device, self._pack)
         # f16x3 packing: frame-level activations travel between layers as (hi, lo) fp16 pairs, written
         # by the producing layer's epilogue; the last layer hands fp32 to the pooling kernel, which
@@ -196,5 +215,8 @@ class SpeakerEmbNet(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         """tdnn.py:103-111: extract_embedding()[0] -> bn2 / LeakyReLU."""
         xv, _ = self.extract_embedding(x)
+        if self.training:
+            from . import autograd as ag
+            return ag.bn_rows_act_train(xv, self.bn2, LRELU, act_first=not self.bn_first)
         p = _cached_pack(self, x.device, self._pack)
         return ops.affine_act(xv, p["bn2"][0], p["bn2"][1], LRELU, act_first=not self.bn_first)

@@ -143,3 +143,185 @@ def l2_normalize(x, eps=1e-12):
 
 def margin_ce_loss(logits, labels, scale=1.0, margin=0.0):
     return MarginCELossFn.apply(logits, labels, float(scale), float(margin))
+
+
+# ==========================================================================================
+# Train-mode speech encoder: what torch.autograd does for
+# SpeakerEmbNet.forward under model.train() (train_audio.py:167-183), as dlip_* launches.
+# Channels-last [B,T,C] activations throughout; parameters keep the reference layouts.
+# ==========================================================================================
+def _ws(M: int, C_: int, device):
+    """fp64 workspace of the chunked column reductions (encoder_train_ops.hip)."""
+    return torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 2,), device=device, dtype=torch.float64)
+
+
+def _permute3(x, perm, flip_axis=-1):
+    d0, d1, d2 = x.shape
+    y = torch.empty(tuple(x.shape[p] for p in perm), device=x.device, dtype=torch.float32)
+    check(lib().dlip_permute3_f32(ptr(x), ptr(y), d0, d1, d2, perm[0], perm[1], perm[2], flip_axis, stream_handle()),
+          "dlip_permute3_f32")
+    return y
+
+
+def _bn_rows_fwd(x2, gamma, beta, rm, rv, momentum, eps, slope, act_first):
+    M, C_ = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty((C_,), device=x2.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    check(lib().dlip_bn_rows_train_fwd_f32(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(invstd), ptr(rm), ptr(rv),
+                                           ptr(_ws(M, C_, x2.device)), M, C_, momentum, eps, slope, int(act_first),
+                                           stream_handle()), "dlip_bn_rows_train_fwd_f32")
+    return y, mean, invstd
+
+
+def _bn_rows_bwd(dy2, x2, gamma, beta, mean, invstd, slope, act_first):
+    M, C_ = x2.shape
+    dx = torch.empty_like(x2)
+    dg = torch.empty_like(mean)
+    db = torch.empty_like(mean)
+    check(lib().dlip_bn_rows_train_bwd_f32(ptr(dy2), ptr(x2), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx), ptr(dg),
+                                           ptr(db), ptr(_ws(M, C_, x2.device)), M, C_, slope, int(act_first), stream_handle()),
+          "dlip_bn_rows_train_bwd_f32")
+    return dx, dg, db
+
+
+class BNRowsActFn(Function):
+    """[M,C]: lrelu(bn_train(x)) (act_first=False) or bn_train(lrelu(x)) (True); running stats updated in place
+    (bn1 / bn2 of SpeakerEmbNet, tdnn.py:92-97,105-110)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, act_first):
+        x = x.contiguous()
+        y, mean, invstd = _bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, act_first)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.slope, ctx.act_first = slope, act_first
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        dx, dg, db = _bn_rows_bwd(dy.contiguous(), x, gamma, beta, mean, invstd, ctx.slope, ctx.act_first)
+        return dx, dg, db, None, None, None, None, None, None
+
+
+class TDNNBlockTrainFn(Function):
+    """TDNN_Block under autograd (tdnn.py:35-43): Conv1d(k, dilation, no padding, bias) -> BatchNorm1d (batch
+    statistics) -> LeakyReLU (or Conv -> LeakyReLU -> BN when bn_first=False), x [B,T,C] -> [B,T',K].
+
+    forward: the fp32 implicit-GEMM kernel on the raw (unfolded) weights + the row-BN kernels.
+    backward: BN/activation backward; bias gradient = column sum; DATA gradient = the same conv kernel
+    on the flipped, transposed weights with full padding; WEIGHT gradient = one GEMM per filter tap with
+    the B*T axis as the reduction -- both operands transposed to reduction-major, split into (hi, lo)
+    fp16 pairs (the gradient after a power-of-two lift into fp16's normal range) and sent through the
+    LDS-DMA kernel, whose balanced work split is what makes a 512 x 512 x 19 200 product fill the chip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, slope, dilation, act_first):
+        x = x.contiguous()
+        B, T, Cx = x.shape
+        K, Cw, S = weight.shape
+        if Cw != Cx or Cx % 4 or K % 4:
+            raise ValueError(f"TDNN train path: channels must match and be multiples of 4 (x {Cx}, weight {Cw}, out {K})")
+        w_ksc = _permute3(weight.contiguous(), (0, 2, 1))                      # reference [K,C,S] -> kernel [K,S,C]
+        z = ops.conv1d_ntc(x, w_ksc, bias.contiguous() if bias is not None else None, dilation=dilation)
+        Tp = z.shape[1]
+        y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first)
+        ctx.save_for_backward(x, weight, z, gamma, beta, mean, invstd)
+        ctx.cfg = (dilation, slope, act_first, bias is not None)
+        return y2.view(B, Tp, K)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z, gamma, beta, mean, invstd = ctx.saved_tensors
+        dilation, slope, act_first, has_bias = ctx.cfg
+        B, T, Cx = x.shape
+        K, _, S = weight.shape
+        Tp = z.shape[1]
+        dev = x.device
+        dz2, dgamma, dbeta = _bn_rows_bwd(dy.contiguous().view(B * Tp, K), z.view(B * Tp, K), gamma, beta, mean, invstd,
+                                          slope, act_first)
+        dbias = None
+        if has_bias and ctx.needs_input_grad[2]:
+            dbias = torch.empty((K,), device=dev, dtype=torch.float32)
+            check(lib().dlip_colsum_rows_f32(ptr(dz2), ptr(dbias), ptr(_ws(B * Tp, K, dev)), B * Tp, K, stream_handle()),
+                  "dlip_colsum_rows_f32")
+        dz = dz2.view(B, Tp, K)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w_csk = _permute3(weight.contiguous(), (1, 2, 0), flip_axis=2)     # [K,C,S] -> [C,S',K], taps reversed
+            dx = ops.conv1d_ntc(dz, w_csk, None, dilation=dilation, pad=(S - 1) * dilation)
+        dweight = None
+        if ctx.needs_input_grad[1]:
+            dweight = _conv1d_wgrad(x, dz, S, dilation)
+        return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def _conv1d_wgrad(x, dz, S, dilation):
+    """dW[k,c,s] = sum_{b,t} dz[b,t,k] x[b,t+s*dil,c]  ->  reference layout [K,C,S]."""
+    B, T, Cx = x.shape
+    _, Tp, K = dz.shape
+    dev = x.device
+    dzp = torch.zeros((B, T, K), device=dev, dtype=torch.float32)              # rows t >= T' stay zero: no cross-utterance terms
+    dzp[:, :Tp].copy_(dz)
+    J = B * T - (S - 1) * dilation                                             # rows every tap can read
+    J32 = (J + 31) // 32 * 32
+    xf, dzf = x.view(B * T, Cx), dzp.view(B * T, K)
+    # reduction-major operands: [rows, J32] with the B*T axis contiguous (zero padded)
+    dzT = torch.empty((1, K, J32), device=dev, dtype=torch.float32)
+    check(lib().dlip_nct_to_ntc_f32(ptr(dzf), ptr(dzT), 1, J, K, J32, stream_handle()), "dlip_nct_to_ntc_f32")
+    scale2 = torch.empty((2,), device=dev, dtype=torch.float32)
+    check(lib().dlip_pow2_scale_f32(ptr(dzT), ptr(scale2), dzT.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
+    dzT_s = torch.empty_like(dzT)
+    check(lib().dlip_split_pack_scaled_f32(ptr(dzT), ptr(dzT_s), ptr(scale2), K, J32, stream_handle()), "dlip_split_pack_scaled_f32")
+    inv = torch.empty((K,), device=dev, dtype=torch.float32)
+    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    ones = torch.ones((K,), device=dev, dtype=torch.float32)
+    zeros = torch.zeros((K,), device=dev, dtype=torch.float32)
+    dwt = torch.empty((S, Cx, K), device=dev, dtype=torch.float32)
+    xT = torch.empty((1, Cx, J32), device=dev, dtype=torch.float32)
+    for s in range(S):
+        xs = xf[s * dilation: s * dilation + J]                                # contiguous row slice: no copy
+        check(lib().dlip_nct_to_ntc_f32(ptr(xs), ptr(xT), 1, J, Cx, J32, stream_handle()), "dlip_nct_to_ntc_f32")
+        xT_s = ops.split_pack(xT.view(Cx, J32))
+        ops.conv_nhwc(xT_s.view(1, 1, Cx, J32), dzT_s.view(K, 1, 1, J32), None, w_scale=ones, x_split=True,
+                      post_scale=inv, post_shift=zeros, out=dwt[s].view(1, 1, Cx, K))
+    return _permute3(dwt, (2, 1, 0))                                           # [S,C,K] -> [K,C,S]
+
+
+class MeanStdPoolFn(Function):
+    """MeanStdPooling on [B,T,C] -> [B,2C] (pooling.py:24-26) and its backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = ops.meanstd_pool(x)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        B, T, C_ = x.shape
+        dx = torch.empty_like(x)
+        check(lib().dlip_meanstd_pool_bwd_f32(ptr(x), ptr(y), ptr(dy.contiguous()), ptr(dx), B, T, C_, stream_handle()),
+              "dlip_meanstd_pool_bwd_f32")
+        return dx
+
+
+def tdnn_block_train(x, blk):
+    """blk: deeplip_amd.audio.TDNN_Block in train mode; x [B,T,C] channels-last."""
+    bn = blk.bn
+    y = TDNNBlockTrainFn.apply(x, blk.context_layer.weight, blk.context_layer.bias, bn.weight, bn.bias, bn.running_mean,
+                               bn.running_var, bn.momentum, bn.eps, 0.2, blk.dilation, not blk.bn_first)
+    bn.num_batches_tracked += 1
+    return y
+
+
+def bn_rows_act_train(x, bn, slope, act_first):
+    y = BNRowsActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, slope, act_first)
+    bn.num_batches_tracked += 1
+    return y
+
+
+def meanstd_pool(x):
+    return MeanStdPoolFn.apply(x)

@@ -1,0 +1,327 @@
+// Train-mode kernels of the speech ENCODER (full train_audio.py training):
+// BatchNorm over the B*T' rows of a TDNN layer in training mode fused with LeakyReLU, forward and
+// backward (models/audio_models/tdnn.py:35-43 under autograd), MeanStdPooling backward
+// (pooling.py:24-26), and the layout helpers of the convolution gradients (weight flip / permute,
+// scaled split for the weight-gradient GEMM).  The convolution gradients themselves run on the
+// implicit-GEMM kernels: dgrad = the forward kernel on flipped weights, wgrad = one GEMM per filter tap
+// with the B*T axis as the reduction (deeplip_amd/autograd.py).
+//
+// Column reductions over M = B*T' ~ 2e4 rows: rows are cut into fixed chunks of 512, a workgroup
+// reduces one (chunk, 64-column block) in fp64 (16 row groups x 16 lanes x float4, LDS tree), partials go
+// to a caller-provided workspace and a second kernel adds them in chunk order: deterministic, no atomics.
+#include "dlip_common.h"
+
+namespace {
+
+constexpr int CHUNK_ROWS = 512;
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+
+// MODE 0: s0 = sum a, s1 = sum a^2 where a = act_first ? lrelu(x) : x            (BN forward statistics)
+// MODE 1: s0 = sum g, s1 = sum g * xhat                                          (BN backward)
+//         g = dy * (act_first ? 1 : lrelu'(bn(x))),  xhat = (a - mean) * invstd
+// MODE 2: s0 = sum x, s1 unused                                                   (bias gradient)
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          double* __restrict__ part, int M, int C, float slope, int act_first) {
+  __shared__ double red[16][64][2];
+  const int c0 = blockIdx.x * 64, chunk = blockIdx.y;
+  const int lx = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = c0 + lx * 4;
+  const int r0 = chunk * CHUNK_ROWS, r1 = min(M, r0 + CHUNK_ROWS);
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (c < C) {   // C % 4 == 0
+    f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, ga = {0, 0, 0, 0}, be = {0, 0, 0, 0};
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c);
+      ga = *reinterpret_cast<const f32x4*>(gamma + c); be = *reinterpret_cast<const f32x4*>(beta + c);
+    }
+    for (int r = r0 + rg; r < r1; r += 16) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long long)r * C + c);
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double a = act_first ? lrelu(xv[k], slope) : xv[k];
+          s0[k] += a; s1[k] += a * a;
+        }
+      } else if (MODE == 1) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + (long long)r * C + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a = act_first ? lrelu(xv[k], slope) : xv[k];
+          const float xh = (a - mu[k]) * is[k];
+          float g = gv[k];
+          if (!act_first) g *= (xh * ga[k] + be[k]) >= 0.f ? 1.f : slope;
+          s0[k] += (double)g; s1[k] += (double)g * (double)xh;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s0[k] += (double)xv[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[rg][lx * 4 + k][0] = s0[k]; red[rg][lx * 4 + k][1] = s1[k]; }
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a0 += red[i][threadIdx.x][0]; a1 += red[i][threadIdx.x][1]; }
+    double* p = part + ((long long)chunk * C + c0 + threadIdx.x) * 2;
+    p[0] = a0; p[1] = a1;
+  }
+}
+
+// forward statistics: mean, biased variance -> invstd; running stats with the unbiased variance (torch)
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ save_mean,
+                                                              float* __restrict__ save_invstd, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, int M, int C, int chunks,
+                                                              float momentum, float eps) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < chunks; ++i) { s += part[((long long)i * C + c) * 2]; q += part[((long long)i * C + c) * 2 + 1]; }
+  const double mean = s / M;
+  double var = q / M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(M > 1 ? var * M / (M - 1) : var);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, f32x4* __restrict__ y, long long n4,
+                                                           int C4, float slope, int act_first) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const f32x4 v = x[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (act_first) o[k] = (lrelu(v[k], slope) - mean[c + k]) * invstd[c + k] * gamma[c + k] + beta[c + k];
+      else o[k] = lrelu((v[k] - mean[c + k]) * invstd[c + k] * gamma[c + k] + beta[c + k], slope);
+    }
+    y[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void col_finalize_kernel(const double* __restrict__ part, float* __restrict__ out0,
+                                                           float* __restrict__ out1, int C, int chunks) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < chunks; ++i) { s += part[((long long)i * C + c) * 2]; q += part[((long long)i * C + c) * 2 + 1]; }
+  if (out0) out0[c] = (float)s;
+  if (out1) out1[c] = (float)q;
+}
+
+// dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M), times lrelu'(x) when the activation came first
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           f32x4* __restrict__ dx, long long n4, int C4, int M, float slope,
+                                                           int act_first) {
+  const float invM = 1.f / (float)M;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const f32x4 xv = x[i], gv = dy[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = act_first ? lrelu(xv[k], slope) : xv[k];
+      const float xh = (a - mean[c + k]) * invstd[c + k];
+      float g = gv[k];
+      if (!act_first) g *= (xh * gamma[c + k] + beta[c + k]) >= 0.f ? 1.f : slope;
+      float d = gamma[c + k] * invstd[c + k] * (g - dbeta[c + k] * invM - xh * dgamma[c + k] * invM);
+      if (act_first) d *= xv[k] >= 0.f ? 1.f : slope;
+      o[k] = d;
+    }
+    dx[i] = o;
+  }
+}
+
+// MeanStdPooling backward: y = [mean_t x, std_t x] (unbiased), dx = dmean / T + dstd * (x - mean) / ((T - 1) * std)
+__global__ __launch_bounds__(256) void meanstd_bwd_kernel(const f32x4* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ dy, f32x4* __restrict__ dx, int T, int C4,
+                                                          long long n4) {
+  const int C = C4 * 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const long long b = i / ((long long)T * C4);
+    const float* yb = y + b * 2 * C;
+    const float* gb = dy + b * 2 * C;
+    const f32x4 v = x[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float sd = yb[C + c + k];
+      o[k] = gb[c + k] / (float)T + (sd > 0.f ? gb[C + c + k] * (v[k] - yb[c + k]) / ((float)(T - 1) * sd) : 0.f);
+    }
+    dx[i] = o;
+  }
+}
+
+// y[permuted index] = x[i0, i1, i2] with output axes (p0, p1, p2) naming input axes; flip reverses one INPUT axis.
+__global__ __launch_bounds__(256) void permute3_kernel(const float* __restrict__ x, float* __restrict__ y, int d0, int d1, int d2,
+                                                       int p0, int p1, int p2, int flip) {
+  const long long n = (long long)d0 * d1 * d2;
+  const int dims[3] = {d0, d1, d2};
+  const int o0 = dims[p0], o1 = dims[p1], o2 = dims[p2];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    int oi[3];
+    oi[2] = (int)(i % o2); oi[1] = (int)((i / o2) % o1); oi[0] = (int)(i / ((long long)o2 * o1));
+    int in[3];
+    in[p0] = oi[0]; in[p1] = oi[1]; in[p2] = oi[2];
+    if (flip >= 0) in[flip] = dims[flip] - 1 - in[flip];
+    y[i] = x[((long long)in[0] * d1 + in[1]) * d2 + in[2]];
+    (void)o0;
+  }
+}
+
+// out[0] = 2^floor(log2(target / max|x|)) (1 if x == 0), out[1] = 1 / out[0]; max is order-independent: deterministic
+__global__ __launch_bounds__(1024) void pow2_scale_kernel(const float* __restrict__ x, float* __restrict__ out, long long n,
+                                                          float target) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) s = exp2f(floorf(log2f(target / m)));
+    if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
+    out[0] = s;
+    out[1] = 1.f / s;
+  }
+}
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void split_pack_scaled_kernel(const f32x4* __restrict__ x, float* __restrict__ y,
+                                                                const float* __restrict__ scale, long long n4) {
+  const float s = scale[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = x[i];
+    h4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float t = v[k] * s; hi[k] = (_Float16)t; lo[k] = (_Float16)(t - (float)hi[k]); }
+    const long long blk = i >> 3; const int q = (int)(i & 7);
+    float* b = y + blk * 32;
+    *reinterpret_cast<h4*>(b + q * 2) = hi;
+    *reinterpret_cast<h4*>(b + 16 + q * 2) = lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_from_scalar_kernel(const float* __restrict__ src, float* __restrict__ y, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = src[0];
+}
+
+inline unsigned grid1d(long long n) {
+  long long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int32_t dlip_bn_rows_chunks(int32_t M) { return M > 0 ? (M + CHUNK_ROWS - 1) / CHUNK_ROWS : 0; }
+
+extern "C" int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                          float* save_mean, float* save_invstd, float* running_mean,
+                                          float* running_var, double* workspace, int32_t M, int32_t C, float momentum,
+                                          float eps, float slope, int32_t act_first, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = dlip_bn_rows_chunks(M);
+  hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, workspace, M, C, slope, act_first);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_invstd,
+                     running_mean, running_var, M, C, chunks, momentum, eps);
+  const long long n4 = (long long)M * (C / 4);
+  hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
+                     save_invstd, gamma, beta, reinterpret_cast<f32x4*>(y), n4, C / 4, slope, act_first);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                                          const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                                          float* dbeta, double* workspace, int32_t M, int32_t C, float slope,
+                                          int32_t act_first, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace);
+  DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = dlip_bn_rows_chunks(M);
+  hipLaunchKernelGGL(col_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd,
+                     gamma, beta, workspace, M, C, slope, act_first);
+  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
+  const long long n4 = (long long)M * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
+                     reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
+                     reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_colsum_rows_f32(const float* x, float* y, double* workspace, int32_t M, int32_t C,
+                                    dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && workspace && M > 0 && C > 0 && (C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = dlip_bn_rows_chunks(M);
+  hipLaunchKernelGGL(col_partial_kernel<2>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, workspace, M, C, 1.f, 0);
+  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, y, nullptr, C, chunks);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_meanstd_pool_bwd_f32(const float* x, const float* y, const float* dy, float* dx, int32_t B, int32_t T,
+                                         int32_t C, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && dy && dx && B > 0 && T > 1 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  const long long n4 = (long long)B * T * (C / 4);
+  hipLaunchKernelGGL(meanstd_bwd_kernel, dim3(grid1d(n4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(x), y, dy, reinterpret_cast<f32x4*>(dx), T, C / 4, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_permute3_f32(const float* x, float* y, int32_t d0, int32_t d1, int32_t d2, int32_t p0, int32_t p1,
+                                 int32_t p2, int32_t flip_axis, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && d0 > 0 && d1 > 0 && d2 > 0 && flip_axis >= -1 && flip_axis <= 2);
+  DLIP_CHECK_ARG(p0 >= 0 && p0 < 3 && p1 >= 0 && p1 < 3 && p2 >= 0 && p2 < 3 && p0 != p1 && p0 != p2 && p1 != p2);
+  hipLaunchKernelGGL(permute3_kernel, dim3(grid1d((long long)d0 * d1 * d2)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     y, d0, d1, d2, p0, p1, p2, flip_axis);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_pow2_scale_f32(const float* x, float* scale2, int64_t n, float target, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && scale2 && n > 0 && target > 0.f);
+  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), x, scale2, (long long)n,
+                     target);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_split_pack_scaled_f32(const float* x, float* y, const float* scale, int64_t rows, int32_t C,
+                                          dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && scale && rows > 0 && C > 0 && (C & 31) == 0);
+  const long long n4 = rows * (C / 4);
+  hipLaunchKernelGGL(split_pack_scaled_kernel, dim3(grid1d(n4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(x), y, scale, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(src && y && n > 0);
+  hipLaunchKernelGGL(fill_from_scalar_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), src, y, n);
+  return dlip_launch_status();
+}

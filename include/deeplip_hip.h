@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 8
+#define DLIP_ABI_VERSION 9
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -283,6 +283,52 @@ int dlip_l2_normalize_bwd_f32(const float* x, const float* dy, float* dx, int32_
 /* C[M,N] = op(A)[M,K] * op(B)[K,N], row-major, any sizes (head gradients: dX = dY W, dW = dY^T X). */
 int dlip_gemm_small_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K,
                         int32_t trans_a, int32_t trans_b, dlip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Train-mode kernels of the speech encoder (deeplip_amd/csrc/encoder_train_ops.hip).
+ * They serve torch.autograd Functions in deeplip_amd/autograd.py that replace what autograd does for
+ * SpeakerEmbNet.forward under model.train() (train_audio.py:167-183; models/audio_models/tdnn.py:35-43,
+ * 89-111; pooling.py:24-26).  Column reductions over the M = B*T' rows are deterministic (fixed 512-row
+ * chunks, fp64 partials in `workspace` = dlip_bn_rows_chunks(M) * C * 2 doubles, added in chunk order).
+ * ------------------------------------------------------------------------------------------ */
+int32_t dlip_bn_rows_chunks(int32_t M);
+
+/* BatchNorm over rows, training mode, fused with LeakyReLU(slope): x, y [M,C], C % 4 == 0.
+ * act_first = 0: y = lrelu(bn(x))  (TDNN_Block bn_first=True, tdnn.py:36-38; bn1/bn2 in tdnn.py:93-94,106-107)
+ * act_first = 1: y = bn(lrelu(x))  (bn_first=False, tdnn.py:40-42,96-97,109-110).
+ * Batch statistics: biased variance for the normalisation, unbiased for running_var (momentum update,
+ * nullable pair), as nn.BatchNorm1d.  save_mean / save_invstd [C] feed the backward. */
+int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                               float* save_mean, float* save_invstd, float* running_mean,
+                               float* running_var, double* workspace, int32_t M, int32_t C, float momentum,
+                               float eps, float slope, int32_t act_first, dlip_stream_t stream);
+/* Backward of the above: dy = dL/dy -> dx = dL/dx [M,C], dgamma, dbeta [C]. */
+int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                               float* dbeta, double* workspace, int32_t M, int32_t C, float slope,
+                               int32_t act_first, dlip_stream_t stream);
+/* y[c] = sum_m x[m,c] (bias gradients), same chunked reduction and workspace. */
+int dlip_colsum_rows_f32(const float* x, float* y, double* workspace, int32_t M, int32_t C, dlip_stream_t stream);
+
+/* MeanStdPooling backward (pooling.py:24-26): x [B,T,C], y = forward output [B,2C] (mean | unbiased std),
+ * dy [B,2C] -> dx [B,T,C].  C % 4 == 0, T > 1. */
+int dlip_meanstd_pool_bwd_f32(const float* x, const float* y, const float* dy, float* dx, int32_t B, int32_t T,
+                              int32_t C, dlip_stream_t stream);
+
+/* y = x permuted: x [d0,d1,d2]; output axis i is input axis p_i; flip_axis (-1 = none) reverses one INPUT
+ * axis.  Conv1d weight layouts between the reference's [K,C,S], the forward kernel's [K,S,C], the data
+ * gradient's flipped [C,S,K] and the weight gradient's [S,C,K]. */
+int dlip_permute3_f32(const float* x, float* y, int32_t d0, int32_t d1, int32_t d2, int32_t p0, int32_t p1,
+                      int32_t p2, int32_t flip_axis, dlip_stream_t stream);
+
+/* scale2[0] = 2^floor(log2(target / max|x|)), scale2[1] = 1 / scale2[0] (device scalars; 1 if x == 0):
+ * the power-of-two that lifts a gradient tensor into fp16's normal range before it is split. */
+int dlip_pow2_scale_f32(const float* x, float* scale2, int64_t n, float target, dlip_stream_t stream);
+/* dlip_split_pack_f32 of x * scale[0] (device scalar). */
+int dlip_split_pack_scaled_f32(const float* x, float* y, const float* scale, int64_t rows, int32_t C,
+                               dlip_stream_t stream);
+/* y[0:n] = src[0] (device scalar broadcast: the per-channel 1/scale vector of the weight-gradient GEMM). */
+int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream_t stream);
 
 #ifdef __cplusplus
 }

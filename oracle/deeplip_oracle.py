@@ -406,6 +406,30 @@ def linearfusion_train(p: Dict[str, Tensor], x: Tensor, extract_feats: bool = Fa
     return x1 if extract_feats else F.linear(x1, p["fc2.weight"], p["fc2.bias"])
 
 
+def _bn_train(x: Tensor, p: Dict[str, Tensor], name: str, momentum: float = 0.1) -> Tensor:
+    return F.batch_norm(x, p[name + ".running_mean"], p[name + ".running_var"], p[name + ".weight"], p[name + ".bias"],
+                        training=True, momentum=momentum, eps=BN_EPS)
+
+
+def speaker_forward_train(p: Dict[str, Tensor], x: Tensor, context: Sequence[Sequence[int]], bn_first: bool = True,
+                          momentum: float = 0.1) -> Tensor:
+    """SpeakerEmbNet.forward under model.train() (tdnn.py:35-43,89-111; train_audio.py:167-183): every
+    BatchNorm1d uses batch statistics and updates its running stats in place; statistic pooling."""
+    h = x
+    for i, ctx in enumerate(context):
+        _, d = tdnn_dilation(ctx)
+        h = F.conv1d(h, p[f"tdnn.{i}.context_layer.weight"], p[f"tdnn.{i}.context_layer.bias"], dilation=d)
+        if bn_first:
+            h = F.leaky_relu(_bn_train(h, p, f"tdnn.{i}.bn", momentum), 0.2)
+        else:
+            h = _bn_train(F.leaky_relu(h, 0.2), p, f"tdnn.{i}.bn", momentum)
+    h = mean_std_pooling(h)
+    x_a = F.linear(h, p["fc1.weight"], p["fc1.bias"])
+    h = F.leaky_relu(_bn_train(x_a, p, "bn1", momentum), 0.2) if bn_first else _bn_train(F.leaky_relu(x_a, 0.2), p, "bn1", momentum)
+    xv = F.linear(h, p["fc2.weight"], p["fc2.bias"])
+    return F.leaky_relu(_bn_train(xv, p, "bn2", momentum), 0.2) if bn_first else _bn_train(F.leaky_relu(xv, 0.2), p, "bn2", momentum)
+
+
 def sgd_momentum_step(params: Sequence[Tensor], bufs: List[Optional[Tensor]], lr: float, momentum: float,
                       weight_decay: float) -> None:
     """torch.optim.SGD update (train_fusion.py:120-124; conf/fusion_config.yaml:96-99):

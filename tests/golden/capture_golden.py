@@ -287,8 +287,53 @@ def train():
     print("train:", {k: np.shape(v) for k, v in out.items()})
 
 
+def audio_train():
+    """Two optimisation steps of the FULL speech encoder + LMCL exactly as train_audio.py:167-183 composes them
+    (model.train(): batch-statistics BatchNorm everywhere; SGD lr 0.01 / momentum 0.9 / wd 1e-5:
+    conf/audio_config.yaml:134-136; LMCL s=30, m=0.2).  5-layer TDNN, 8 utterances x 120 frames x 24 MFCCs."""
+    out = {}
+    opts = {"arch": "tdnn", "tdnn": {"input_dim": 24, "hidden_dim": [512] * 4 + [1500],
+                                     "context": [[-2, -1, 0, 1, 2], [-2, 0, 2], [-3, 0, 3], [0], [0]], "tdnn_layers": 5,
+                                     "embedding_dim": 512, "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}}
+    net = SpeakerEmbNet(opts)
+    crit = LMCL(512, 57, 30, 0.2)
+    fill(net, "atrain.audio."); fill(crit, "atrain.lmcl.")
+    net.train(); crit.train()
+    x = torch.from_numpy(wg.audio_input(8, 24, 120, key="atrain.x"))
+    lab = torch.from_numpy(wg.labels(8, 57))
+    opt = torch.optim.SGD([{"params": net.parameters()}, {"params": crit.parameters()}], 0.01, momentum=0.9, weight_decay=1e-5)
+    for step in range(2):
+        opt.zero_grad()
+        output = net(x)
+        loss, logits = crit(output, lab)
+        loss.backward()
+        if step == 0:
+            out["loss0"] = loss.detach().numpy(); out["logits0"] = logits.detach().numpy()
+            out["argmax0"] = torch.max(logits, dim=1)[1].numpy(); out["output0"] = output.detach().numpy()
+            g = {k: v.grad for k, v in net.named_parameters()}
+            out["grad_tdnn0_w"] = g["tdnn.0.context_layer.weight"].numpy().copy()
+            out["grad_tdnn0_b"] = g["tdnn.0.context_layer.bias"].numpy().copy()
+            out["grad_tdnn0_bn_w"] = g["tdnn.0.bn.weight"].numpy().copy()
+            out["grad_tdnn2_w_rows4"] = g["tdnn.2.context_layer.weight"][:4].numpy().copy()
+            out["grad_tdnn4_bn_b"] = g["tdnn.4.bn.bias"].numpy().copy()
+            out["grad_fc1_w_rows4"] = g["fc1.weight"][:4].numpy().copy()
+            out["grad_bn2_w"] = g["bn2.weight"].numpy().copy()
+            for k, v in g.items():
+                out[f"gradnorm_{k}"] = np.array([float(v.double().norm()), float(v.double().sum())])
+        opt.step()
+    out["loss1"] = loss.detach().numpy()
+    for k, v in net.state_dict().items():
+        v = v.detach().double()
+        out[f"after2_{k}_sum"] = np.array([float(v.sum()), float(v.abs().sum())])
+    out["after2_tdnn0_w"] = net.tdnn[0].context_layer.weight.detach().numpy().copy()
+    out["after2_tdnn1_running_var"] = net.tdnn[1].bn.running_var.numpy().copy()
+    out["after2_fc2_w_rows4"] = net.fc2.weight.detach()[:4].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "audio_train_golden.npz"), **out)
+    print("audio_train:", {k: np.shape(v) for k, v in list(out.items())[:12]}, "...", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["video", "audio", "heads", "train"]
+    which = sys.argv[1:] or ["video", "audio", "heads", "train", "audio_train"]
     mpath = os.path.join(HERE, "manifest.json")
     if os.path.exists(mpath):
         manifest.update(json.load(open(mpath)))

@@ -38,10 +38,29 @@ def test_train_audio_test_mode(tmp_path, monkeypatch):
     tr = train_audio.Trainer(overrides={"data.test_speakers": 4, "data.test_utt_per_spk": 3, "data.trials": 200,
                                         "data.trial_targets": 40, "data.audio_frames": 120, "data.n_spk": 6,
                                         "data.utt_per_spk": 3, "train.bs": 8, "train.epoch": 2})
-    tr._train()
+    w0 = tr.model.tdnn[0].context_layer.weight.detach().clone()
+    tr._train()                                          # full-encoder training: model.train(), backward through every layer
+    assert not torch.equal(w0, tr.model.tdnn[0].context_layer.weight.detach())
+    assert int(tr.model.tdnn[0].bn.num_batches_tracked) == 4 and int(tr.model.bn2.num_batches_tracked) == 4
+    assert np.isfinite(tr.last_epoch_stats["loss"]) and tr.last_epoch_stats["utt_per_s"] > 0
+    assert not tr.model.training                         # back in eval mode for extraction
     assert tr.model_average(2) == 2
     table = tr.extract_test_xv()
     assert table.emb.shape == (12, 512)
     assert np.abs(table.emb.norm(dim=1).cpu().numpy() - 1).max() < 1e-5
     eer, _ = tr.eer()
     assert 0 <= eer <= 1
+
+
+@pytest.mark.gpu
+def test_train_audio_frozen_encoder(tmp_path, monkeypatch):
+    import train_audio
+    monkeypatch.chdir(tmp_path)
+    tr = train_audio.Trainer(overrides={"data.test_speakers": 4, "data.test_utt_per_spk": 3, "data.trials": 200,
+                                        "data.trial_targets": 40, "data.audio_frames": 120, "data.n_spk": 6,
+                                        "data.utt_per_spk": 3, "train.bs": 8, "train.epoch": 1, "train.freeze_encoder": True})
+    w0 = tr.model.tdnn[0].context_layer.weight.detach().clone()
+    c0 = tr.criterion.weights.detach().clone()
+    tr._train()
+    assert torch.equal(w0, tr.model.tdnn[0].context_layer.weight.detach())      # encoder untouched
+    assert not torch.equal(c0, tr.criterion.weights.detach())                     # criterion trained

@@ -194,3 +194,50 @@ def test_train_step_oracle(golden, manifest):
         assert abs(float(loss) - float(g[f"{tag}_loss1"])) < 1e-3 * max(1.0, float(g[f"{tag}_loss1"]))
         assert rel_err(lf["fc2.weight"].detach()[:8].numpy(), g[f"{tag}_after2_fc2_w_rows8"]) < 1e-4
         assert rel_err(lf["bn1.running_var"].numpy(), g[f"{tag}_after2_bn1_running_var"]) < 1e-5
+
+
+ATRAIN_CONTEXT = [[-2, -1, 0, 1, 2], [-2, 0, 2], [-3, 0, 3], [0], [0]]
+
+
+def atrain_shapes():
+    s, cin = {}, 24
+    for i, (k, cout) in enumerate(zip((5, 3, 3, 1, 1), [512] * 4 + [1500])):
+        s[f"tdnn.{i}.context_layer.weight"] = (cout, cin, k); s[f"tdnn.{i}.context_layer.bias"] = (cout,)
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            s[f"tdnn.{i}.bn.{n}"] = (cout,)
+        s[f"tdnn.{i}.bn.num_batches_tracked"] = ()
+        cin = cout
+    s["fc1.weight"] = (512, 3000); s["fc1.bias"] = (512,); s["fc2.weight"] = (512, 512); s["fc2.bias"] = (512,)
+    for b in ("bn1", "bn2"):
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{b}.{n}"] = (512,)
+        s[f"{b}.num_batches_tracked"] = ()
+    return s
+
+
+def test_audio_encoder_train_step_oracle(golden):
+    """Two SGD steps of the FULL speech encoder + LMCL (train_audio.py:167-183) -- the oracle's train-mode
+    restatement under torch autograd vs values captured from the reference classes."""
+    g = golden["audio_train"]
+    p = O.to_torch_sd(wg.fill_state_dict(atrain_shapes(), prefix="atrain.audio."))
+    cw = O.to_torch_sd(wg.fill_state_dict({"weights": (57, 512)}, prefix="atrain.lmcl."))["weights"]
+    x = torch.from_numpy(wg.audio_input(8, 24, 120, key="atrain.x"))
+    lab = torch.from_numpy(wg.labels(8, 57))
+    tkeys = [k for k in p if "running" not in k and "num_batches" not in k]
+    params = [p[k].requires_grad_() for k in tkeys] + [cw.requires_grad_()]
+    bufs = [None] * len(params)
+    for step in range(2):
+        out = O.speaker_forward_train(p, x, ATRAIN_CONTEXT)
+        loss, logits = O.lmcl(out, lab, cw, 30, 0.2)
+        loss.backward()
+        if step == 0:
+            assert abs(float(loss) - float(g["loss0"])) < 1e-5 * float(g["loss0"])
+            assert rel_err(out.detach().numpy(), g["output0"]) < 1e-5
+            assert np.array_equal(O.argmax_first(logits).numpy(), g["argmax0"])
+            assert rel_err(p["tdnn.0.context_layer.weight"].grad.numpy(), g["grad_tdnn0_w"]) < 1e-4
+            assert rel_err(p["tdnn.2.context_layer.weight"].grad[:4].numpy(), g["grad_tdnn2_w_rows4"]) < 1e-4
+            assert rel_err(p["fc1.weight"].grad[:4].numpy(), g["grad_fc1_w_rows4"]) < 1e-4
+        O.sgd_momentum_step(params, bufs, 0.01, 0.9, 1e-5)
+    assert abs(float(loss) - float(g["loss1"])) < 1e-4 * float(g["loss1"])
+    assert rel_err(p["tdnn.0.context_layer.weight"].detach().numpy(), g["after2_tdnn0_w"]) < 1e-5
+    assert rel_err(p["tdnn.1.bn.running_var"].numpy(), g["after2_tdnn1_running_var"]) < 1e-5

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Step time of full-encoder speech training at the reference's shapes: E-TDNN, 300 frames,
+batch 64 / 256 (conf/audio_config.yaml bs), LMCL; forward + backward + SGD, HIP events."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from deeplip_amd import weightgen as wg
+from models.audio_models.loss import LMCL
+from models.audio_models.tdnn import SpeakerEmbNet
+from oracle.deeplip_oracle import ETDNN_CONTEXT
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--dim", type=int, default=24)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+et = {"input_dim": a.dim, "hidden_dim": [512] * 9 + [1500], "context": ETDNN_CONTEXT, "tdnn_layers": 10, "embedding_dim": 512,
+      "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+net = SpeakerEmbNet({"arch": "etdnn", "etdnn": et})
+sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="audio.")
+net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+net.cuda().train()
+crit = LMCL(512, 57, 30, 0.2).cuda()
+opt = torch.optim.SGD([{"params": net.parameters()}, {"params": crit.parameters()}], 0.01, momentum=0.9, weight_decay=1e-5)
+x = torch.from_numpy(wg.audio_input(a.batch, a.dim, 300, key="bench.atrain")).cuda()
+lab = torch.from_numpy(wg.labels(a.batch, 57)).cuda()
+
+
+def step():
+    opt.zero_grad()
+    loss, _ = crit(net(x), lab)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(2):
+    step()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.steps):
+    loss = step()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.steps
+fwd_gflop = 2.563 * a.batch
+print(f"full-encoder E-TDNN training step: batch {a.batch} x 300 frames x {a.dim} dims: {ms:.2f} ms/step = {a.batch / ms * 1e3:.0f} utt/s "
+      f"(~{3 * fwd_gflop / ms:.1f} TFLOP/s at 3x forward FLOPs); loss {float(loss.detach()):.4f}")

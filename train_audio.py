@@ -5,9 +5,11 @@ Re-creation of the reference's train_audio.py surface that the A+V hot path uses
 (conf/audio_config.yaml: data / model / train / test), ``Trainer`` with ``extract_test_xv`` (x-vector
 extraction + F.normalize, train_audio.py:343-373), ``model_average`` (checkpoint averaging,
 :216-232), ``_adjust_margin`` (:141-145), ``save`` / ``load``; modes ``test`` (extract + cosine EER)
-and ``train``.  Full-encoder training (TDNN dgrad/wgrad, train-mode BN) is SURVEY.md section 8(f)
-rank 2 and not built yet: ``_train_epoch`` trains the LMCL criterion on frozen encoder embeddings
-(the HIP backward kernels of config C5) and says so.
+and ``train``.  ``train`` is the reference's loop (train_audio.py:167-199): ``model.train()``, forward
+through every TDNN layer with batch-statistics BatchNorm, LMCL / CrossEntropy, ``loss.backward()`` through the
+whole encoder (conv dgrad / wgrad, BN and pooling backward as dlip_* launches -- deeplip_amd/autograd.py),
+SGD over model + criterion parameters, MultiStepLR, margin schedule, per-epoch checkpoints and checkpoint
+averaging.  ``train.freeze_encoder: true`` keeps the older criterion-only step on frozen x-vectors.
 """
 from __future__ import annotations
 
@@ -62,8 +64,10 @@ class Trainer(object):
         else:
             self.criterion = CrossEntropy(E, d["n_spk"]).to(self.device)
         o = self.train_opts["sgd"]
-        self.optim = torch.optim.SGD(self.criterion.parameters(), o["init_lr"], momentum=o["momentum"],
-                                     weight_decay=o["weight_decay"])
+        self.freeze_encoder = bool(self.train_opts.get("freeze_encoder", False))
+        groups = [{"params": self.criterion.parameters()}] if self.freeze_encoder else \
+                 [{"params": self.model.parameters()}, {"params": self.criterion.parameters()}]   # train_audio.py:112
+        self.optim = torch.optim.SGD(groups, o["init_lr"], momentum=o["momentum"], weight_decay=o["weight_decay"])
         self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optim, milestones=self.train_opts["lr_decay_step"], gamma=0.1)
         self.epoch, self.current_epoch = self.train_opts["epoch"], 0
         self.log_time = time.asctime(time.localtime(time.time())).replace(" ", "_")[4:]
@@ -73,28 +77,42 @@ class Trainer(object):
             self.criterion.margin = self.init_margin if self.current_epoch <= 5 else self.end_margin
 
     def _train_epoch(self):
-        """Criterion-only step on frozen-encoder x-vectors (see module docstring)."""
+        """train_audio.py:167-199 on the synthetic set: full-encoder step (or criterion-only with freeze_encoder)."""
         bs = self.train_opts["bs"]
         rng = np.random.Generator(np.random.PCG64([self.current_epoch, 5]))
-        tot = n = 0.0
-        for _ in range(self.train_opts.get("steps_per_epoch", 2)):
+        tot = n = correct = 0.0
+        self.model.train(not self.freeze_encoder)
+        t0 = time.perf_counter()
+        steps = self.train_opts.get("steps_per_epoch", 2)
+        for _ in range(steps):
             idx = rng.integers(0, len(self.trainset), bs)
             x = torch.from_numpy(self.trainset.audio(idx)).to(self.device)
             lab = torch.from_numpy(self.trainset.labels(idx)).to(self.device)
-            with torch.no_grad():
-                emb = self.model(x)                       # SpeakerEmbNet.forward (train_audio.py:187)
             self.optim.zero_grad()
+            if self.freeze_encoder:
+                with torch.no_grad():
+                    emb = self.model(x)
+            else:
+                emb = self.model(x)                       # output of bn2 / LeakyReLU (train_audio.py:187)
             loss, logits = self.criterion(emb, lab)
             loss.backward()
             self.optim.step()
+            correct += float((torch.max(logits, dim=1)[1] == lab).sum())
             tot += float(loss.detach()) * len(idx); n += len(idx)
+        torch.cuda.synchronize()
+        self.last_epoch_stats = {"loss": tot / n, "acc": correct / n, "utt_per_s": n / (time.perf_counter() - t0),
+                                 "steps": steps, "bs": bs}
+        self.model.eval()
         return tot / n
 
     def _train(self):
         for epoch in range(self.current_epoch + 1, self.epoch + 1):
             self.current_epoch = epoch
             self._adjust_margin()
-            print("Epoch {} loss {:.4f}".format(epoch, self._train_epoch()), flush=True)
+            loss = self._train_epoch()
+            st = self.last_epoch_stats
+            print("Epoch {} loss {:.4f} acc {:.3f} ({:.0f} utt/s, {} steps of {})".format(epoch, loss, st["acc"], st["utt_per_s"],
+                                                                                     st["steps"], st["bs"]), flush=True)
             self.lr_scheduler.step()
             self.save()
 
