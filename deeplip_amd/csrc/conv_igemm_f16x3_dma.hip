@@ -90,14 +90,21 @@ struct StreamK {
 #define DLIP_STAMP(i) do { } while (0)
 #endif
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool OSPLIT, int NSTAGE, int OCC>
+// M16 selects the matrix instruction: v_mfma_f32_16x16x32_f16 (one instruction per 32-channel slice and
+// 16x16 block; the shape that holds the higher clock in a dense loop on gfx950) instead of two k16 steps of
+// v_mfma_f32_32x32x16_f16.  LDS image, ring, work split and epilogue are shared; only the lane -> (row, k group)
+// mapping of the fragment reads and of the accumulator registers differs.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OSPLIT, int NSTAGE, int OCC, bool M16>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_dma_kernel(const ConvArgs a, const StreamK sk) {
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int RPP = NT / 8;   // rows one pass of the workgroup covers (8 lanes x 16 B per row)
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be whole passes");
   static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int FR = M16 ? 16 : 32;    // rows of one MFMA fragment
+  constexpr int QN = M16 ? 1 : 4;      // 4-register quads per accumulator block
+  constexpr int MI = WM / FR, NI = WN / FR;
+  using acc_t = typename std::conditional<M16, f32x4, f32x16>::type;
   constexpr int A_PER = BM / RPP, B_PER = BN / RPP;
   constexpr int NL = A_PER + B_PER;   // DMA instructions per wave per slice
   constexpr int STAGE_B = (BM + BN) * ROWB;
@@ -124,16 +131,17 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const uint32_t piece0 = lds0 + wave * 8 * ROWB;   // this wave's 8 rows of pass 0, stage 0, operand A
   const int lane = tid & 63;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int lrow = lane & 31, half = lane >> 5;
+  // 32x32x16: lane = (row 0..31, k half); a k16 step s reads hi chunk 2s + half, lo chunk 4 + 2s + half.
+  // 16x16x32: lane = (row 0..15, k group 0..3); the one step reads hi chunk kgroup, lo chunk 4 + kgroup.
+  const int lrow = lane & (FR - 1), half = lane / FR;
   const int a_frag = (wm * WM + lrow) * LDK;
   const int b_frag = BM * LDK + (wn * WN + lrow) * LDK;
-  const int rquad = half * 4;
-  const int key_rd = (lrow >> 1) & 7;
+  const int key_rd = (lrow >> 1) & 7;   // fragment blocks start at multiples of 16 rows: the key depends on lrow only
   int khi[2], klo[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    khi[s] = ((2 * s + half) ^ key_rd) << 2;
-    klo[s] = ((4 + 2 * s + half) ^ key_rd) << 2;
+    khi[s] = (((M16 ? 0 : 2 * s) + half) ^ key_rd) << 2;
+    klo[s] = ((4 + (M16 ? 0 : 2 * s) + half) ^ key_rd) << 2;
   }
   const int x_dr = a.dh * a.W * a.ldx * 4, x_ds = a.dw * a.ldx * 4;
   const int ntaps = a.R * a.S;
@@ -211,6 +219,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       w_tap = (tap * a.Cw + c0) * 4;
     };
     auto issue_a = [&](int stage) {
+#ifdef DLIP_ABLATE_A   // timing experiment only (wrong results): no activation traffic after the prologue
+      if (stage >= 0 && tap + c0 != (k0 % ntaps) + (k0 / ntaps) * BK) return;
+#endif
       const uint32_t base = piece0 + stage * STAGE_B;
 #pragma unroll
       for (int j = 0; j < A_PER; ++j) {
@@ -219,6 +230,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       }
     };
     auto issue_b = [&](int stage) {
+#ifdef DLIP_ABLATE_B   // timing experiment only (wrong results): no weight traffic after the prologue
+      if (stage >= 0 && tap + c0 != (k0 % ntaps) + (k0 / ntaps) * BK) return;
+#endif
       const uint32_t base = piece0 + stage * STAGE_B + BM * ROWB;
 #pragma unroll
       for (int j = 0; j < B_PER; ++j)
@@ -238,13 +252,13 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     // Accumulators hold the TRANSPOSED tile (rows = output channels, columns = pixels: the weight
     // fragment is the MFMA's A operand), so a lane owns 4 consecutive channels of one pixel per
     // register quad: 8-B (hi) + 8-B (lo) pieces of an output row for the LDS-staged epilogue.
-    f32x16 acc[MI][NI];
+    acc_t acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        for (int e = 0; e < 4 * QN; ++e) acc[mi][ni][e] = 0.f;
     // Per-channel epilogue parameters of this tile's BN channels -> the LDS table behind the ring (read back
     // as 16-B quads): 1/wscale, bias, slope, post scale, post shift.
     if (tid < BN) {
@@ -258,6 +272,8 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       tab[4 * BN + tid] = (kok && a.pshift) ? a.pshift[k] : 0.f;
     }
 
+#define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
+    if constexpr (!M16) {
     f16x8 fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];
     auto read_frags = [&](int set, int stage, int s) {
       const float* Aw = smem + stage * (STAGE_B / 4) + a_frag;
@@ -284,7 +300,6 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[mi][ni], 0, 0, 0);
         }
     };
-#define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
     // slice 0 has landed once at most the (PF - 1) younger slices are outstanding
     DLIP_STAMP(2);
@@ -317,6 +332,68 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       mfma_g(1, 2); DLIP_FENCE();
       st_cur = st_nxt;
     }
+    } else {
+    // ---- 16x16x32 program: per slice 3 groups of MI x NI instructions.  Group order lo*hi, hi*hi, hi*lo:
+    // the last group needs neither the activation-lo nor the weight-hi fragments, so the NEXT slice's first
+    // group's fragments are read (behind the barrier) into registers the tail of this slice does not use. ----
+    f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
+    auto read_first = [&](int stage) {   // what group 0 needs: activation lo, weight hi
+      const float* Aw = smem + stage * (STAGE_B / 4) + a_frag;
+      const float* Bw = smem + stage * (STAGE_B / 4) + b_frag;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fal[mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 16 * LDK + klo[0]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fbh[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + khi[0]);
+    };
+    auto read_rest = [&](int stage) {    // activation hi, weight lo
+      const float* Aw = smem + stage * (STAGE_B / 4) + a_frag;
+      const float* Bw = smem + stage * (STAGE_B / 4) + b_frag;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fah[mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 16 * LDK + khi[0]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + klo[0]);
+    };
+    // grp 0: lo*hi, 1: hi*hi, 2: hi*lo; activation blocks [m0, m1)
+    auto mfma_p = [&](int grp, int m0, int m1) {
+#pragma unroll
+      for (int mi = m0; mi < m1; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const f16x8 av = grp == 0 ? fal[mi] : fah[mi];
+          const f16x8 bv = grp == 2 ? fbl[ni] : fbh[ni];
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[mi][ni], 0, 0, 0);
+        }
+    };
+    constexpr int MH = MI / 2 > 0 ? MI / 2 : 1;   // the part of the last group issued before the barrier
+    DLIP_STAMP(2);
+    if (PF > 1 && kn > 1) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    DLIP_STAMP(3);
+    read_first(0);
+
+    int st_cur = 0, st_iss = (PF > 1 && kn > 1) ? 2 % NSTAGE : 1 % NSTAGE;
+    for (int kt = 0; kt < kn; ++kt) {
+      const bool more1 = (kt + 1) < kn, moreP = (kt + PF) < kn;
+      const int st_nxt = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
+      read_rest(st_cur); DLIP_FENCE();
+      mfma_p(0, 0, MI); DLIP_FENCE();
+      if (moreP) { advance(); issue_a(st_iss); } DLIP_FENCE();
+      mfma_p(1, 0, MH); DLIP_FENCE();
+      if (moreP) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
+      if (MH < MI) mfma_p(1, MH, MI);
+      DLIP_FENCE();
+      mfma_p(2, 0, MH); DLIP_FENCE();
+      if (more1) {
+        if (PF > 1 && (kt + 2) < kn) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        read_first(st_nxt);
+      }
+      DLIP_FENCE();
+      if (MH < MI) mfma_p(2, MH, MI);
+      DLIP_FENCE();
+      st_cur = st_nxt;
+    }
+    }
 #undef DLIP_FENCE
     DLIP_STAMP(4);
 
@@ -325,7 +402,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     // values through the MFMA loop in scratch.
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));
-    const int lane_e = tid_e & 63, lrow_e = tid_e & 31, half_e = (tid_e >> 5) & 1;
+    const int lane_e = tid_e & 63, lrow_e = tid_e & (FR - 1), half_e = (tid_e & 63) / FR;   // pixel in block; channel quad (k half / k group)
 
     bool finish = true;
     if (kn != a.nk) {   // split tile (workgroup-uniform branch)
@@ -350,10 +427,10 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < QN; ++q) {
               f32x4 v;   // (bit_cast straight from a vector-element lvalue reads element 0: copy out first)
               v[0] = acc[mi][ni][4 * q]; v[1] = acc[mi][ni][4 * q + 1]; v[2] = acc[mi][ni][4 * q + 2]; v[3] = acc[mi][ni][4 * q + 3];
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sr, (((mi * NI + ni) * 4 + q) * NT + tid_e) * 16, 0, 16);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sr, (((mi * NI + ni) * QN + q) * NT + tid_e) * 16, 0, 16);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -366,7 +443,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the slab loads below the poll
         // sum the parts in part order (own part from registers): the bits do not depend on who came last;
         // every slab load is sc1 (served past this CU's L1), matching the sc1 stores
-        f32x16 tot[MI][NI];
+        acc_t tot[MI][NI];
         for (int p = gf; p <= gl; ++p) {
           const long long pb = (long long)p * sk.iters / sk.G;
           const __amdgpu_buffer_rsrc_t pr = dlip_make_rsrc(sk.slabs + (size_t)(2 * p + (pb < t0 ? 1 : 0)) * SLAB, SLAB * 4);
@@ -375,12 +452,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
+              for (int q = 0; q < QN; ++q) {
                 f32x4 v;
                 if (p == g) {
                   v[0] = acc[mi][ni][4 * q]; v[1] = acc[mi][ni][4 * q + 1]; v[2] = acc[mi][ni][4 * q + 2]; v[3] = acc[mi][ni][4 * q + 3];
                 } else {
-                  v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, (((mi * NI + ni) * 4 + q) * NT + tid_e) * 16, 0, 16));
+                  v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, (((mi * NI + ni) * QN + q) * NT + tid_e) * 16, 0, 16));
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) tot[mi][ni][4 * q + c] = p == gf ? v[c] : tot[mi][ni][4 * q + c] + v[c];
@@ -437,16 +514,16 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int kl = wn * WN + ni * 32 + 8 * j + 4 * half_e;   // tile-local channel of acc[..][ni][4j..4j+3]
+            for (int j = 0; j < QN; ++j) {
+              const int kl = wn * WN + ni * FR + (M16 ? 4 * half_e : 8 * j + 4 * half_e);   // tile-local channel of acc[..][ni][4j..4j+3]
               const f32x4 inv4 = tab[kl >> 2], bi4 = tab[(BN + kl) >> 2], sl4 = tab[(2 * BN + kl) >> 2];
               f32x4 ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
               if (post) { ps4 = tab[(3 * BN + kl) >> 2]; pt4 = tab[(4 * BN + kl) >> 2]; }
-              const int ch = (kl >> 5) * 8 + j;       // hi chunk of these 4 channels within the row (lo: + 4)
+              const int ch = (kl >> 5) * 8 + ((kl >> 3) & 3);   // hi chunk of these 4 channels within the row (lo: + 4)
 #pragma unroll
               for (int mi = 0; mi < MI; ++mi) {
-                const int r = wm * WM - band0 + mi * 32 + lrow_e;      // band row of this lane's pixel
-                char* row = img + r * PITCH + 8 * half_e;
+                const int r = wm * WM - band0 + mi * FR + lrow_e;      // band row of this lane's pixel
+                char* row = img + r * PITCH + 2 * (kl & 4);            // which 8-B half of the chunk
                 const int phi = (ch & ~15) | ((ch ^ r) & 15), plo = ((ch + 4) & ~15) | (((ch + 4) ^ r) & 15);
                 float v[4];
 #pragma unroll
@@ -481,12 +558,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int kl = wn * WN + ni * 32 + 8 * j + 4 * half_e;
+              for (int j = 0; j < QN; ++j) {
+                const int kl = wn * WN + ni * FR + (M16 ? 4 * half_e : 8 * j + 4 * half_e);
                 const int ch = kl >> 2;              // the 4 channels are one fp32 chunk
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                  const int r = wm * WM - band0 + mi * 32 + lrow_e;
+                  const int r = wm * WM - band0 + mi * FR + lrow_e;
                   const int pc = (ch & ~15) | ((ch ^ r) & 15);
                   f32x4 v;
 #pragma unroll
@@ -584,7 +661,7 @@ int resident_workgroups(const void* kern, int threads, size_t lds) {
   return cus * per_cu;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int OCC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int OCC, bool M16 = false>
 int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
   ConvArgs b = a;
   const int tiles_m = (a.M + BM - 1) / BM;
@@ -594,8 +671,8 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
   constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB + 5 * BN * sizeof(float);   // ring + epilogue parameter table
   constexpr int threads = 64 * WAVES_M * WAVES_N;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds a CU");
-  auto kern = out_split ? conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, true, NSTAGE, OCC>
-                        : conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, false, NSTAGE, OCC>;
+  auto kern = out_split ? conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, true, NSTAGE, OCC, M16>
+                        : conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, false, NSTAGE, OCC, M16>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -705,11 +782,15 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
 
 }  // namespace
 
-// Tile menu of the DMA kernel (index = what dlip_conv_plan reports via dlip_conv_dma_tile).
+// Tile menu of the DMA kernel (index = what dlip_conv_plan reports via dlip_conv_dma_tile).  Entries 0..4 are the
+// product instances, on v_mfma_f32_16x16x32_f16: same cycles per FLOP as 32x32x16 but the chip holds a
+// higher clock under it -- 3-8 % less time per layer, same box, interleaved runs (tools/bench_dma.py
+// --variants 0,10,...); 10..14 are the same tiles on v_mfma_f32_32x32x16_f16, 5..9 experiments.
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64},
                            {128, 64},
-                           {128, 128}, {256, 128}, {128, 256}, {256, 64}, {128, 128}};   // 5..9: experiments (DLIP_CONV_DMA_TILE only)
-constexpr int NUM_DMA_ALL = 10;
+                           {128, 128}, {256, 128}, {128, 256}, {256, 64}, {128, 128},    // 5..9: experiments (DLIP_CONV_DMA_TILE only)
+                           {128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}};       // 10..14: 0..4 on v_mfma_f32_32x32x16_f16
+constexpr int NUM_DMA_ALL = 15;
 
 // Tile choice (measured per layer with tools/bench_dma.py, MI355X, balanced split on): 128x128 is the
 // steady-state winner whenever the tile is deep enough to amortise its set-up; narrow outputs (K <= 64)
@@ -740,16 +821,21 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (dma_pick(a.M, a.K, a.nk)) {
-    case 0: return launch_dma<128, 128, 2, 2, 2, 2>(a, st, out_split);
-    case 1: return launch_dma<128, 64, 2, 2, 3, 2>(a, st, out_split);
-    case 2: return launch_dma<64, 128, 2, 2, 3, 2>(a, st, out_split);
-    case 3: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, out_split);
-    case 4: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, out_split);
+    case 0: return launch_dma<128, 128, 2, 2, 2, 2, true>(a, st, out_split);
+    case 1: return launch_dma<128, 64, 2, 2, 3, 2, true>(a, st, out_split);
+    case 2: return launch_dma<64, 128, 2, 2, 3, 2, true>(a, st, out_split);
+    case 3: return launch_dma<64, 64, 2, 2, 3, 2, true>(a, st, out_split);
+    case 4: return launch_dma<128, 64, 2, 2, 2, 3, true>(a, st, out_split);
     case 5: return launch_dma<128, 128, 2, 2, 3, 1>(a, st, out_split);
     case 6: return launch_dma<256, 128, 4, 2, 3, 1>(a, st, out_split);
     case 7: return launch_dma<128, 256, 2, 4, 2, 1>(a, st, out_split);
     case 8: return launch_dma<256, 64, 4, 2, 2, 1>(a, st, out_split);
-    default: return launch_dma<128, 128, 4, 2, 3, 1>(a, st, out_split);
+    case 9: return launch_dma<128, 128, 4, 2, 3, 1>(a, st, out_split);
+    case 10: return launch_dma<128, 128, 2, 2, 2, 2>(a, st, out_split);
+    case 11: return launch_dma<128, 64, 2, 2, 3, 2>(a, st, out_split);
+    case 12: return launch_dma<64, 128, 2, 2, 3, 2>(a, st, out_split);
+    case 13: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, out_split);
+    default: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, out_split);
   }
 }
 

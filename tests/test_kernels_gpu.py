@@ -399,6 +399,37 @@ def test_conv_nhwc_f16x3_split_formats(ops, case, fmt):
     assert rel_err(y.cpu().numpy(), base.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("case", SPLIT_FMT_CASES, ids=lambda c: "x".join(str(v) for v in c[:10]))
+def test_conv_dma_tile_variants(ops, case, tile, monkeypatch):
+    """Every product instance of the LDS-DMA kernel (tile menu entries 0..4, on v_mfma_f32_16x16x32_f16) and
+    its 32x32x16 twin (10..14) forced onto every split-format case: same result as the fp32-format
+    kernel, whatever tile the shape would normally get."""
+    from deeplip_amd import packing
+    N, H, W, C, K, R, S, stride, pad, dil, use_res, use_slope = case
+    x = _split_ref_value(rnd(N, H, W, C, seed=1) * 3.0)
+    w = rnd(K, R, S, C, seed=2, scale=1.0 / np.sqrt(C * R * S))
+    b = rnd(K, seed=3, scale=0.1)
+    sh, sw = (1, stride) if H == 1 else (stride, stride)
+    ph, pw = (0, pad) if H == 1 else (pad, pad)
+    dh, dw = (1, dil) if H == 1 else (dil, dil)
+    ws, sc = packing.split_weights(w.double())
+    slope = (torch.rand(K, generator=torch.Generator().manual_seed(5)) * 0.3).cuda() if use_slope else None
+    kw = dict(stride=(sh, sw), pad=(ph, pw), dil=(dh, dw), slope=slope, w_scale=sc.cuda())
+    xd = x.cuda()
+    base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), **kw)
+    res = _split_ref_value(rnd(*base.shape, seed=4)).cuda() if use_res else None
+    base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), residual=res, **kw)
+    monkeypatch.setenv("DLIP_CONV_DMA_TILE", str(tile))
+    for out_split in (True, False):
+        y = ops.conv_nhwc(ops.split_pack(xd), ws.cuda(), b.cuda(), residual=ops.split_pack(res) if res is not None else None,
+                          x_split=True, out_split=out_split, **kw)
+        if out_split:
+            y = ops.split_unpack(y)
+        torch.cuda.synchronize()
+        assert rel_err(y.cpu().numpy(), base.cpu().numpy()) < 2e-6, (tile, out_split)
+
+
 def _split_ref_value(x):
     """x rounded to what the split format can hold (hi + lo), so both formats carry identical values."""
     hi = x.half()
