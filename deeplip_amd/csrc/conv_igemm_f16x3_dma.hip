@@ -55,15 +55,24 @@ __device__ __forceinline__ u32x4 make_rsrc_words(const void* p, uint32_t bytes) 
 }
 
 // One LDS-DMA piece: 64 lanes x 16 B from (rsrc, voff) to LDS bytes [lds_base, lds_base + 1024).
+// POL: cache policy of the load -- 0 default, 1 `sc1` (served by L2, does not allocate in this CU's L1), 2 `nt`.
+template <int POL = 0>
 __device__ __forceinline__ void dma_piece(const u32x4 rsrc, uint32_t voff, uint32_t lds_base) {
-  asm volatile(
-      "s_mov_b32 m0, %0\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %1, %2, 0 offen lds"
-      :
-      : "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(voff), "s"(rsrc)   // (readfirstlane: the base is wave-uniform by construction; this pins it to an SGPR)
-      : "memory");   // m0 is reserved: hipcc keeps nothing in it across statements (the ISA dump shows no other m0 use)
+  const uint32_t base = __builtin_amdgcn_readfirstlane(lds_base);   // wave-uniform by construction; this pins it to an SGPR
+  // m0 is reserved: hipcc keeps nothing in it across statements (the ISA dump shows no other m0 use)
+  if constexpr (POL == 1)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen sc1 lds" : : "s"(base), "v"(voff), "s"(rsrc) : "memory");
+  else if constexpr (POL == 2)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" : : "s"(base), "v"(voff), "s"(rsrc) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(base), "v"(voff), "s"(rsrc) : "memory");
 }
+#ifndef DLIP_POL_A
+#define DLIP_POL_A 0
+#endif
+#ifndef DLIP_POL_B
+#define DLIP_POL_B 0
+#endif
 
 // Balanced ("stream-K") work split: the launch's reduction work = tiles x nk slices is cut into G equal
 // contiguous ranges, one per workgroup, G = the number of workgroups the chip holds at once.  A range
@@ -225,8 +234,11 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       const uint32_t base = piece0 + stage * STAGE_B;
 #pragma unroll
       for (int j = 0; j < A_PER; ++j) {
-        const bool ok = (a_mask[j] >> tap) & 1u;
-        dma_piece(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+        bool ok = (a_mask[j] >> tap) & 1u;
+#ifdef DLIP_ABLATE_OOB   // timing experiment only (wrong results): every piece after the prologue is issued out of range (zeros, no L2 traffic)
+        ok = ok && (tap + c0 == (k0 % ntaps) + (k0 / ntaps) * BK);
+#endif
+        dma_piece<DLIP_POL_A>(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
       }
     };
     auto issue_b = [&](int stage) {
@@ -235,8 +247,13 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #endif
       const uint32_t base = piece0 + stage * STAGE_B + BM * ROWB;
 #pragma unroll
-      for (int j = 0; j < B_PER; ++j)
-        dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+      for (int j = 0; j < B_PER; ++j) {
+        bool bok = b_off[j] >= 0;
+#ifdef DLIP_ABLATE_OOB
+        bok = bok && (tap + c0 == (k0 % ntaps) + (k0 / ntaps) * BK);
+#endif
+        dma_piece<DLIP_POL_B>(wr, bok ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+      }
     };
 
     // ---- prologue: put the first NSTAGE-1 slices in flight, then initialise the accumulators ----
@@ -692,7 +709,7 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
   if (balanced && tiles <= kMaxSplitTiles) {
     // Plain: ceil(tiles / slots) rounds of one tile-time.  Balanced: tiles / slots tile-times plus the
     // slab hand-off (one slab written and read per workgroup, all the reads at the very end).
-    const double tile_us = 2.0 * BM * BN * 32.0 * a.nk / (kSlotFlops * 1e-6);
+    const double tile_us = 2.0 * BM * BN * 32.0 * a.nk / (kSlotFlops * (WAVES_M * WAVES_N / 4.0) * 1e-6);   // an 8-wave workgroup owns its CU
     const double plain_us = (double)((tiles + sl - 1) / sl) * tile_us;
     long long Gb = sl;
     // small problems: at least 16 slices per workgroup (every extra part costs the finisher a serial slab read)
@@ -782,29 +799,34 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
 
 }  // namespace
 
-// Tile menu of the DMA kernel (index = what dlip_conv_plan reports via dlip_conv_dma_tile).  Entries 0..4 are the
+// Tile menu of the DMA kernel (index = what dlip_conv_plan reports via dlip_conv_dma_tile).  Entries 0..5 are the
 // product instances, on v_mfma_f32_16x16x32_f16: same cycles per FLOP as 32x32x16 but the chip holds a
 // higher clock under it -- 3-8 % less time per layer, same box, interleaved runs (tools/bench_dma.py
-// --variants 0,10,...); 10..14 are the same tiles on v_mfma_f32_32x32x16_f16, 5..9 experiments.
-const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64},
-                           {128, 64},
-                           {128, 128}, {256, 128}, {128, 256}, {256, 64}, {128, 128},    // 5..9: experiments (DLIP_CONV_DMA_TILE only)
-                           {128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}};       // 10..14: 0..4 on v_mfma_f32_32x32x16_f16
-constexpr int NUM_DMA_ALL = 15;
+// --variants 0,10,...); 10..14 are tiles 0..4 on v_mfma_f32_32x32x16_f16, the rest are experiments.
+const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
+                           {256, 128}, {128, 256}, {256, 64}, {128, 128},                 // 6..9: experiments (DLIP_CONV_DMA_TILE only)
+                           {128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64},        // 10..14: 0..4 on v_mfma_f32_32x32x16_f16
+                           {128, 128}, {256, 128}, {128, 256}, {256, 64}};                // 15..18: experiments
+constexpr int NUM_DMA_ALL = 19;
 
-// Tile choice (measured per layer with tools/bench_dma.py, MI355X, balanced split on): 128x128 is the
-// steady-state winner whenever the tile is deep enough to amortise its set-up; narrow outputs (K <= 64)
-// do better on 128x64 with a three-stage ring, short reductions (nk <= 16 slices: 1x1 convolutions,
-// small Linear layers) on 128x64 with a two-stage ring and three workgroups per CU (latency, not
-// MFMA, bounds them); M <= 64 (fully connected layers on a batch) uses the 64-row tiles.
+// Tile choice (measured per layer with tools/bench_dma.py, MI355X, balanced split on).  The cost of a slice
+// is set by the bytes it pulls from L2 (ablations: pieces issued out of range cost nothing, pieces that fetch
+// cost 30 % of a layer), so the deepest layers take the tile with the fewest bytes per FLOP: 256x128, eight
+// waves, one workgroup per CU, three-stage ring (5-11 % less time than two co-resident 128x128 workgroups
+// on the 3x3 layers of layer2..4).  128x128 (two per CU) serves mid-depth reductions and the M < 8192
+// launches; narrow outputs (K <= 64) do better on 128x64 with a three-stage ring, very short reductions
+// (nk <= 8 slices: the 1x1 down-sampling convolutions) on 128x64 with a two-stage ring and three
+// workgroups per CU (latency, not MFMA, bounds them); M <= 64 (fully connected layers on a batch) uses
+// the 64-row tiles.
 static int dma_pick(long long M, int K, int nk) {
   if (const char* e = getenv("DLIP_CONV_DMA_TILE")) {
     const int v = atoi(e);
     if (v >= 0 && v < NUM_DMA_ALL) return v;
   }
   if (M <= 64) return K <= 64 ? 3 : 2;
-  if (nk <= 16) return 4;
   if (K <= 64) return 1;
+  if (nk <= 8) return 4;
+  if (nk >= 32 && M >= 8192) return 5;
   return 0;
 }
 
@@ -826,7 +848,7 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 2: return launch_dma<64, 128, 2, 2, 3, 2, true>(a, st, out_split);
     case 3: return launch_dma<64, 64, 2, 2, 3, 2, true>(a, st, out_split);
     case 4: return launch_dma<128, 64, 2, 2, 2, 3, true>(a, st, out_split);
-    case 5: return launch_dma<128, 128, 2, 2, 3, 1>(a, st, out_split);
+    case 5: return launch_dma<256, 128, 4, 2, 3, 1, true>(a, st, out_split);
     case 6: return launch_dma<256, 128, 4, 2, 3, 1>(a, st, out_split);
     case 7: return launch_dma<128, 256, 2, 4, 2, 1>(a, st, out_split);
     case 8: return launch_dma<256, 64, 4, 2, 2, 1>(a, st, out_split);
@@ -835,7 +857,11 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 11: return launch_dma<128, 64, 2, 2, 3, 2>(a, st, out_split);
     case 12: return launch_dma<64, 128, 2, 2, 3, 2>(a, st, out_split);
     case 13: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, out_split);
-    default: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, out_split);
+    case 14: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, out_split);
+    case 15: return launch_dma<128, 128, 2, 2, 3, 1>(a, st, out_split);
+    case 16: return launch_dma<256, 128, 4, 2, 2, 1, true>(a, st, out_split);
+    case 17: return launch_dma<128, 256, 2, 4, 2, 1, true>(a, st, out_split);
+    default: return launch_dma<256, 64, 4, 2, 3, 1, true>(a, st, out_split);
   }
 }
 

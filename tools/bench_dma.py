@@ -15,6 +15,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--variants", default="0,1,2,3,4")
+ap.add_argument("--xpad", type=int, default=0, help="extra (unused) channels per input pixel: breaks the power-of-two pixel stride")
 a = ap.parse_args()
 B = a.batch
 N = B * 29
@@ -39,7 +40,7 @@ tot_best = 0.0
 for name, (n, h, w, c), k, r, s, st, pd, dl, res, count in L:
     if a.only and a.only not in name:
         continue
-    x = ops.split_pack(torch.randn(n, h, w, c, device="cuda"))
+    x = ops.split_pack(torch.randn(n, h, w, c + a.xpad, device="cuda"))
     wsp, wsc = packing.split_weights((torch.randn(k, r, s, c, dtype=torch.float64) * 0.05))
     wsp, wsc = wsp.cuda(), wsc.cuda()
     b = torch.randn(k, device="cuda")
@@ -49,6 +50,8 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res, count in L:
     dd = (1, dl) if h == 1 else (dl, dl)
     osp = k % 32 == 0
     kw = dict(stride=sh, pad=pp, dil=dd, slope=sl, w_scale=wsc, x_split=True, out_split=osp)
+    if a.xpad:
+        kw["in_channels"] = c
     y = ops.conv_nhwc(x, wsp, b, **kw)
     rs = ops.split_pack(torch.randn_like(y)) if res else None
     fl = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * k * r * s * c
