@@ -36,6 +36,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int ROWB = 128;  // bytes per LDS row (one 32-channel slice of one pixel / filter)
 
+// Window mode: rows a window holds beyond the tile's BM pixels (>= (R-1) dil W + (S-1) dil of the launch).
+#define DLIP_WIN_SLACK 48
+// Rows per chunk plane of a window: BM + slack + 16 spare rows (always loaded out of range, i.e. zero:
+// the rows masked taps are redirected to), rounded up to whole 64-row DMA pieces.
+constexpr int dlip_win_rows(int BM) { return (BM + DLIP_WIN_SLACK + 16 + 63) / 64 * 64; }
+// Bytes of [weight ring][two window slots].
+constexpr int dlip_win_ring_bytes(int BM, int BN, int NSTAGE) { return NSTAGE * BN * ROWB + 2 * dlip_win_rows(BM) * ROWB; }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -103,7 +111,22 @@ struct StreamK {
 // 16x16 block; the shape that holds the higher clock in a dense loop on gfx950) instead of two k16 steps of
 // v_mfma_f32_32x32x16_f16.  LDS image, ring, work split and epilogue are shared; only the lane -> (row, k group)
 // mapping of the fragment reads and of the accumulator registers differs.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool OSPLIT, int NSTAGE, int OCC, bool M16>
+//
+// WIN ("window" mode, same-size stride-1 convolutions: every 3x3 layer of the trunk): what a slice costs is
+// the bytes it pulls from L2 (ablations in DESIGN.md), and the R x S taps of one 32-channel slice read the
+// same activation rows shifted by whole pixels.  So the activation operand is not re-fetched per tap: per
+// channel slice the workgroup loads ONE window -- the 128-B rows of the BM + (R-1) dil W + (S-1) dil
+// consecutive input pixels its tile touches -- into one of two LDS slots (the next slice's window lands
+// while the taps of this one are multiplied), and a tap reads its fragments from the window at a row
+// offset; rows that fall outside the image (or past M) are redirected per lane to a row that is always
+// zero, by the same per-pixel tap mask the per-tap gather uses.  The LDS ring then carries the weights
+// only: L2 -> LDS bytes per slice drop from (BM + BN) x 128 to BN x 128 + ~(BM + 64) x 128 / (R S).
+// A window is stored as 8 PLANES, one per 16-B chunk of the 128-B pixel row (plane c, row r at
+// (c WRP + r) x 16 B, WRP a multiple of 16): a fragment read takes 16 consecutive rows of one plane,
+// i.e. 256 consecutive bytes, so it is bank-conflict free at EVERY row offset -- no XOR swizzle keyed on
+// the row can be (the key pattern of a 16-row group is not shift invariant; measured 32 % conflict
+// cycles with the row-major image).  An LDS-DMA piece then gathers the same chunk of 64 pixels.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool OSPLIT, int NSTAGE, int OCC, bool M16, bool WIN = false>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_dma_kernel(const ConvArgs a, const StreamK sk) {
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int RPP = NT / 8;   // rows one pass of the workgroup covers (8 lanes x 16 B per row)
@@ -116,10 +139,18 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   using acc_t = typename std::conditional<M16, f32x4, f32x16>::type;
   constexpr int A_PER = BM / RPP, B_PER = BN / RPP;
   constexpr int NL = A_PER + B_PER;   // DMA instructions per wave per slice
-  constexpr int STAGE_B = (BM + BN) * ROWB;
+  constexpr int STAGE_B = WIN ? BN * ROWB : (BM + BN) * ROWB;
   constexpr int LDK = 32;             // dwords per LDS row
   constexpr int PF = NSTAGE - 1;      // slices in flight ahead of the one being multiplied
-  constexpr int RING = NSTAGE * STAGE_B;   // bytes; the epilogue parameter table (5 x BN floats) sits behind it
+  // window mode: [weight ring][window slot 0][window slot 1]; a slot = 8 chunk planes x WRP rows x 16 B
+  constexpr int WRP = dlip_win_rows(BM);         // rows per plane (a multiple of 64: whole DMA pieces)
+  constexpr int WPIECES = 8 * WRP / 64;          // 1-KiB DMA pieces per window (64 rows of one chunk plane each)
+  constexpr int WPER = WPIECES / NW;             // per wave
+  constexpr int WIN_B = WRP * ROWB;
+  constexpr int WIN0 = NSTAGE * STAGE_B;
+  constexpr int RING = WIN ? dlip_win_ring_bytes(BM, BN, NSTAGE)
+                           : NSTAGE * STAGE_B;   // bytes; the epilogue parameter table (5 x BN floats) sits behind it
+  static_assert(!WIN || (M16 && 8 % NW == 0 && WRP >= BM + DLIP_WIN_SLACK + 16 && B_PER + WPER < 64), "window mode layout");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -144,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   // 16x16x32: lane = (row 0..15, k group 0..3); the one step reads hi chunk kgroup, lo chunk 4 + kgroup.
   const int lrow = lane & (FR - 1), half = lane / FR;
   const int a_frag = (wm * WM + lrow) * LDK;
-  const int b_frag = BM * LDK + (wn * WN + lrow) * LDK;
+  const int b_frag = (WIN ? 0 : BM * LDK) + (wn * WN + lrow) * LDK;
   const int key_rd = (lrow >> 1) & 7;   // fragment blocks start at multiples of 16 rows: the key depends on lrow only
   int khi[2], klo[2];
 #pragma unroll
@@ -177,6 +208,197 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     if (threadIdx.x == 0 && it == it_begin) sk.stamps[(size_t)g * 10 + 7] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
 #endif
 
+    acc_t acc[MI][NI];
+#define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
+    if constexpr (WIN) {
+      // ================= window mode (16x16x32 program) =================
+      const int tap0 = k0 % ntaps, cc0 = k0 / ntaps;
+      // tap-validity bits of this lane's MI fragment pixels (the mask of the per-tap gather, for other rows)
+      uint32_t fr_mask[MI];
+      {
+        int hi0[MI], wi0[MI];
+        uint32_t colbits[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m = tile_m * BM + wm * WM + mi * 16 + lrow;
+          const int mc = m < a.M ? m : a.M - 1;
+          const int n = mc / a.HoWo;
+          const int rem = mc - n * a.HoWo;
+          const int ho = rem / a.Wo;
+          hi0[mi] = ho - a.ph;
+          wi0[mi] = rem - ho * a.Wo - a.pw;
+          colbits[mi] = 0u;
+          fr_mask[mi] = 0u;
+        }
+        for (int sx = 0; sx < a.S; ++sx)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) colbits[mi] |= (uint32_t)((unsigned)(wi0[mi] + sx * a.dw) < (unsigned)a.W) << sx;
+        for (int r = 0; r < a.R; ++r)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            fr_mask[mi] |= ((unsigned)(hi0[mi] + r * a.dh) < (unsigned)a.H ? colbits[mi] : 0u) << (r * a.S);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          if (tile_m * BM + wm * WM + mi * 16 + lrow >= a.M) fr_mask[mi] = 0u;
+      }
+      const int fr_row0 = wm * WM + lrow;   // window row of fragment block 0 at tap offset 0
+      // window pieces of this wave: chunk planes wave, wave + NW, ..., 64-row blocks 0 .. WRP/64 - 1 of each; window
+      // row r = input pixel tile_m BM - (ph W + pw) + r (a same-size convolution: output pixel m reads input
+      // pixel m + tap offset).  Rows past BM + slack are never fetched: they stay zero (the masked-tap rows).
+      // Offsets are rebuilt at issue time (once per R S slices) rather than held in registers.
+      const int w_pix0 = tile_m * BM - (a.ph * a.W + a.pw) + lane;
+      int b_off[B_PER];
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) {
+        const int n = tile_n * BN + rbase + RPP * j;
+        b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
+      }
+      int itap = tap0, ic0 = cc0 * BK;
+      int w_tap = (itap * a.Cw + ic0) * 4;
+      auto advance = [&]() {
+        if (++itap == ntaps) { itap = 0; ic0 += BK; }
+        w_tap = (itap * a.Cw + ic0) * 4;
+      };
+      auto issue_b = [&](int stage) {
+        const uint32_t base = piece0 + stage * STAGE_B;
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j)
+          dma_piece<DLIP_POL_B>(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+      };
+      auto issue_win = [&](int slot, int cc) {
+#pragma unroll
+        for (int pl = 0; pl < 8 / NW; ++pl)
+#pragma unroll
+          for (int blk = 0; blk < WRP / 64; ++blk) {
+            const int plane = pl * NW + wave;
+            const int pix = w_pix0 + blk * 64;
+            const bool ok = (blk * 64 + lane) < BM + DLIP_WIN_SLACK && pix >= 0 && pix < a.M;
+            dma_piece<DLIP_POL_A>(xr, ok ? (uint32_t)((pix * a.ldx + cc * BK) * 4 + plane * 16) : DLIP_OOB_OFFSET,
+                                  lds0 + WIN0 + slot * WIN_B + (plane * (WRP / 64) + blk) * 1024);
+          }
+      };
+      auto wait_sel = [&](bool w, bool win) {   // leave the pieces issued after the awaited weight slice in flight
+        if (w) { if (win) wait_vmcnt<B_PER + WPER>(); else wait_vmcnt<B_PER>(); }
+        else   { if (win) wait_vmcnt<WPER>(); else wait_vmcnt<0>(); }
+      };
+
+      // ---- prologue ----
+      DLIP_STAMP(1);
+      issue_win(0, cc0);
+      issue_b(0);
+      const bool two = PF > 1 && kn > 1;
+      if (two) { advance(); issue_b(1); }
+      const bool win1 = (ntaps - tap0) < kn;   // the segment reaches the next channel slice
+      if (win1) issue_win(1, cc0 + 1);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
+      if (tid < BN) {
+        const int k = tile_n * BN + tid;
+        const bool kok = k < a.K;
+        float* tab = smem + RING / 4;
+        tab[tid] = kok ? 1.f / a.wscale[k] : 0.f;   // power of two: exact
+        tab[BN + tid] = (kok && a.bias) ? a.bias[k] : 0.f;
+        tab[2 * BN + tid] = (kok && a.slope) ? a.slope[k] : 1.f;
+        tab[3 * BN + tid] = (kok && a.pscale) ? a.pscale[k] : 1.f;
+        tab[4 * BN + tid] = (kok && a.pshift) ? a.pshift[k] : 0.f;
+      }
+      // the tap being multiplied: index, window slot, row offset; a_ad = byte address of each block's hi chunk
+      int ctap = tap0, cslot = 0, ccur = cc0;
+      int cs = tap0 % a.S, crow = (tap0 / a.S) * a.dh * a.W;
+      int a_ad[MI];
+      const int a_base = WIN0 + (half * WRP + fr_row0) * 16;           // plane `k group`, this lane's row of block 0
+      // masked taps read zeros from the last 16 rows of the plane (never fetched: rows >= BM + slack), at the
+      // row with the same index mod 16 as the real one -- the same bank, so a group with masked lanes stays
+      // conflict free (one shared zero row cost 35 % conflict cycles: it collides with one live lane per group)
+      const int a_zero = WIN0 + (half * WRP + WRP - 16) * 16;
+      auto set_addr = [&]() {
+        const int toff = crow + cs * a.dw;
+        const int off = cslot * WIN_B + toff * 16;
+        const int zad = a_zero + (((lrow + toff) & 15) << 4);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          a_ad[mi] = ((fr_mask[mi] >> ctap) & 1u) ? a_base + mi * 256 + off : zad;
+      };
+      f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
+      const char* lds_c = reinterpret_cast<const char*>(smem);
+      // weight fragment address (hi chunk; lo = ^ 64): rebuilt from the lane id behind an opaque asm where it is
+      // used, so that it is not carried (and spilled: a scratch reload is a VMEM operation, and the vmcnt(0) the
+      // compiler puts behind it would drain the whole DMA ring every slice) through the loop
+      auto b_addr = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int lr = t & 15, kgp = (t >> 4) & 3;
+        return (wn * WN + lr) * ROWB + ((kgp ^ ((lr >> 1) & 7)) << 4);
+      };
+      auto read_first = [&](int stage) {   // group 0: activation lo, weight hi
+        const char* Bw = lds_c + stage * STAGE_B + b_addr();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fal[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi] + 4 * WRP * 16);   // lo planes 4..7
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fbh[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * ROWB);
+      };
+      auto read_rest = [&](int stage) {    // activation hi, weight lo
+        const char* Bw = lds_c + stage * STAGE_B + (b_addr() ^ 64);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fah[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * ROWB);
+      };
+      auto mfma_p = [&](int grp, int m0, int m1) {   // grp 0: lo*hi, 1: hi*hi, 2: hi*lo
+#pragma unroll
+        for (int mi = m0; mi < m1; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const f16x8 av = grp == 0 ? fal[mi] : fah[mi];
+            const f16x8 bv = grp == 2 ? fbl[ni] : fbh[ni];
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[mi][ni], 0, 0, 0);
+          }
+      };
+      constexpr int MH = MI / 2 > 0 ? MI / 2 : 1;
+      set_addr();
+      DLIP_STAMP(2);
+      wait_sel(two, win1);
+      __syncthreads();   // (also publishes the parameter table)
+      DLIP_STAMP(3);
+      read_first(0);
+
+      int st_cur = 0, st_iss = two ? 2 % NSTAGE : 1 % NSTAGE;
+      for (int kt = 0; kt < kn; ++kt) {
+        const bool more1 = (kt + 1) < kn, moreP = (kt + PF) < kn;
+        const int st_nxt = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
+        read_rest(st_cur); DLIP_FENCE();
+        mfma_p(0, 0, MI); DLIP_FENCE();
+        if (moreP) { advance(); issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; }
+        // entering a channel slice: fetch the next one's window into the slot the previous slice has left
+        const bool winnow = kt > 0 && ctap == 0 && (kt + ntaps) < kn;
+#ifdef DLIP_ABLATE_WIN   // timing experiment only (wrong results): in-loop windows are not fetched
+        if (winnow) issue_win(cslot ^ 1, 1 << 24);
+#else
+        if (winnow) issue_win(cslot ^ 1, ccur + 1);
+#endif
+        DLIP_FENCE();
+        // the next tap's fragment addresses: plain VALU, scheduled into the shadow of group 1's instructions
+        // (this slice's activation fragments are in registers already)
+        if (++cs == a.S) { cs = 0; crow += a.dh * a.W; }
+        if (++ctap == ntaps) { ctap = 0; cs = 0; crow = 0; cslot ^= 1; ++ccur; }
+        set_addr();
+        mfma_p(1, 0, MI); DLIP_FENCE();
+        mfma_p(2, 0, MH); DLIP_FENCE();
+        if (more1) {
+          wait_sel(PF > 1 && (kt + 2) < kn, winnow);
+          __builtin_amdgcn_s_barrier();
+          read_first(st_nxt);
+        }
+        DLIP_FENCE();
+        if (MH < MI) mfma_p(2, MH, MI);
+        DLIP_FENCE();
+        st_cur = st_nxt;
+      }
+    } else {
     // Per-row gather state, branch-free: byte offset of the row's window origin and a bit per filter tap
     // that stays inside the image (columns and rows tested separately: R + S steps, not R x S).
     int a_off[A_PER];
@@ -269,7 +491,6 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     // Accumulators hold the TRANSPOSED tile (rows = output channels, columns = pixels: the weight
     // fragment is the MFMA's A operand), so a lane owns 4 consecutive channels of one pixel per
     // register quad: 8-B (hi) + 8-B (lo) pieces of an output row for the LDS-staged epilogue.
-    acc_t acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -289,7 +510,6 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       tab[4 * BN + tid] = (kok && a.pshift) ? a.pshift[k] : 0.f;
     }
 
-#define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
     if constexpr (!M16) {
     f16x8 fah[2][MI], fal[2][MI], fbh[2][NI], fbl[2][NI];
     auto read_frags = [&](int set, int stage, int s) {
@@ -409,6 +629,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       if (MH < MI) mfma_p(2, MH, MI);
       DLIP_FENCE();
       st_cur = st_nxt;
+    }
     }
     }
 #undef DLIP_FENCE
@@ -678,18 +899,19 @@ int resident_workgroups(const void* kern, int threads, size_t lds) {
   return cus * per_cu;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int OCC, bool M16 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int OCC, bool M16 = false, bool WIN = false>
 int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
   ConvArgs b = a;
   const int tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.K + BN - 1) / BN;
   const long long tiles = (long long)tiles_m * b.tiles_n;
   if (tiles <= 0 || tiles > 0x7FFFFFFFll) return DLIP_EINVAL;
-  constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB + 5 * BN * sizeof(float);   // ring + epilogue parameter table
+  constexpr size_t lds = (WIN ? (size_t)dlip_win_ring_bytes(BM, BN, NSTAGE) : (size_t)NSTAGE * (BM + BN) * ROWB)
+                         + 5 * BN * sizeof(float);   // ring (+ windows) + epilogue parameter table
   constexpr int threads = 64 * WAVES_M * WAVES_N;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds a CU");
-  auto kern = out_split ? conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, true, NSTAGE, OCC, M16>
-                        : conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, false, NSTAGE, OCC, M16>;
+  auto kern = out_split ? conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, true, NSTAGE, OCC, M16, WIN>
+                        : conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, false, NSTAGE, OCC, M16, WIN>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -806,8 +1028,15 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
                            {256, 128}, {128, 256}, {256, 64}, {128, 128},                 // 6..9: experiments (DLIP_CONV_DMA_TILE only)
                            {128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64},        // 10..14: 0..4 on v_mfma_f32_32x32x16_f16
-                           {128, 128}, {256, 128}, {128, 256}, {256, 64}};                // 15..18: experiments
-constexpr int NUM_DMA_ALL = 19;
+                           {128, 128}, {256, 128}, {128, 256}, {256, 64},                 // 15..18: experiments
+                           {256, 128}, {128, 64}, {256, 64}, {128, 128}};                 // 19..22: window mode (same-size stride-1 only)
+constexpr int NUM_DMA_ALL = 23;
+
+// Window mode applies to same-size stride-1 convolutions whose taps span at most DLIP_WIN_SLACK pixels.
+static bool win_ok(const ConvArgs& a) {
+  return a.sh == 1 && a.sw == 1 && a.Wo == a.W && a.HoWo == a.H * a.W && a.R * a.S >= 3 &&
+         (a.R - 1) * a.dh * a.W + (a.S - 1) * a.dw <= DLIP_WIN_SLACK;
+}
 
 // Tile choice (measured per layer with tools/bench_dma.py, MI355X, balanced split on).  The cost of a slice
 // is set by the bytes it pulls from L2 (ablations: pieces issued out of range cost nothing, pieces that fetch
@@ -842,7 +1071,9 @@ extern "C" __attribute__((visibility("hidden"))) void dlip_conv_dma_tile(long lo
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int out_split) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (dma_pick(a.M, a.K, a.nk)) {
+  int pick = dma_pick(a.M, a.K, a.nk);
+  if (pick >= 19 && !win_ok(a)) pick = pick == 19 ? 5 : pick == 20 ? 1 : pick == 21 ? 18 : 0;
+  switch (pick) {
     case 0: return launch_dma<128, 128, 2, 2, 2, 2, true>(a, st, out_split);
     case 1: return launch_dma<128, 64, 2, 2, 3, 2, true>(a, st, out_split);
     case 2: return launch_dma<64, 128, 2, 2, 3, 2, true>(a, st, out_split);
@@ -861,7 +1092,11 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 15: return launch_dma<128, 128, 2, 2, 3, 1>(a, st, out_split);
     case 16: return launch_dma<256, 128, 4, 2, 2, 1, true>(a, st, out_split);
     case 17: return launch_dma<128, 256, 2, 4, 2, 1, true>(a, st, out_split);
-    default: return launch_dma<256, 64, 4, 2, 3, 1, true>(a, st, out_split);
+    case 18: return launch_dma<256, 64, 4, 2, 3, 1, true>(a, st, out_split);
+    case 19: return launch_dma<256, 128, 4, 2, 3, 1, true, true>(a, st, out_split);
+    case 20: return launch_dma<128, 64, 2, 2, 3, 2, true, true>(a, st, out_split);
+    case 21: return launch_dma<256, 64, 4, 2, 3, 1, true, true>(a, st, out_split);
+    default: return launch_dma<128, 128, 2, 2, 2, 2, true, true>(a, st, out_split);
   }
 }
 

@@ -399,7 +399,7 @@ def test_conv_nhwc_f16x3_split_formats(ops, case, fmt):
     assert rel_err(y.cpu().numpy(), base.cpu().numpy()) < 2e-6
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 19, 20, 21, 22])
 @pytest.mark.parametrize("case", SPLIT_FMT_CASES, ids=lambda c: "x".join(str(v) for v in c[:10]))
 def test_conv_dma_tile_variants(ops, case, tile, monkeypatch):
     """Every product instance of the LDS-DMA kernel (tile menu entries 0..5, on v_mfma_f32_16x16x32_f16) and
