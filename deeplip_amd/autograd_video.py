@@ -1,0 +1,307 @@
+"""torch.autograd plumbing for the TRAIN-MODE lip-clip encoder.
+
+What torch.autograd does for ``Lipreading.forward`` under ``model.train()`` (train_video.py:108-169 over
+models/video_models/model.py:80-105, resnet.py:28-127, tcn.py:28-116), with every forward and backward
+step a ``dlip_*`` launch: the convolutions (forward, data gradient, weight gradient) on the implicit-GEMM
+kernels, BatchNorm with batch statistics on the row-BN kernels of the speech encoder
+(encoder_train_ops.hip), PReLU / max-pool / average-pool / masked-mean / dropout on
+video_train_ops.hip.  torch supplies the tape, parameter storage, slicing / concatenation of tensors
+and the optimizer.  Activations are channels-last fp32 ([N,H,W,C]; Conv1d as H = 1) throughout;
+parameters keep the reference layouts, so the state dict is the reference's.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import check, lib, ptr, stream_handle
+from .autograd import BNRowsActFn, _permute3, _ws
+
+
+def _colsum_rows(x2):
+    M, C_ = x2.shape
+    y = torch.empty((C_,), device=x2.device, dtype=torch.float32)
+    check(lib().dlip_colsum_rows_f32(ptr(x2), ptr(y), ptr(_ws(M, C_, x2.device)), M, C_, stream_handle()), "dlip_colsum_rows_f32")
+    return y
+
+
+def wgrad_gemm(dz_rows, tap_rows, n_taps):
+    """dW[s, c, k] = sum_j rows_s[j, c] * dz[j, k]: one GEMM per filter tap with the J output positions as the
+    reduction.  Both operands are transposed to reduction-major, split into (hi, lo) fp16 pairs (the gradient
+    after a power-of-two lift into fp16's normal range) and multiplied by the LDS-DMA kernel, whose balanced
+    work split is what fills the chip on a [C x K] product with J ~ 1e5..1e6 (same scheme as the speech
+    encoder's Conv1d weight gradient, autograd._conv1d_wgrad).  ``tap_rows(s)`` -> [J, C] contiguous."""
+    J, K = dz_rows.shape
+    dev = dz_rows.device
+    J32 = (J + 31) // 32 * 32
+    dzT = torch.empty((1, K, J32), device=dev, dtype=torch.float32)
+    check(lib().dlip_nct_to_ntc_f32(ptr(dz_rows), ptr(dzT), 1, J, K, J32, stream_handle()), "dlip_nct_to_ntc_f32")
+    scale2 = torch.empty((2,), device=dev, dtype=torch.float32)
+    check(lib().dlip_pow2_scale_f32(ptr(dzT), ptr(scale2), dzT.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
+    dzT_s = torch.empty_like(dzT)
+    check(lib().dlip_split_pack_scaled_f32(ptr(dzT), ptr(dzT_s), ptr(scale2), K, J32, stream_handle()), "dlip_split_pack_scaled_f32")
+    inv = torch.empty((K,), device=dev, dtype=torch.float32)
+    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    ones = torch.ones((K,), device=dev, dtype=torch.float32)
+    zeros = torch.zeros((K,), device=dev, dtype=torch.float32)
+    out = None
+    xT = None
+    for s in range(n_taps):
+        rows = tap_rows(s)
+        Cx = rows.shape[1]
+        if out is None:
+            out = torch.empty((n_taps, Cx, K), device=dev, dtype=torch.float32)
+            xT = torch.empty((1, Cx, J32), device=dev, dtype=torch.float32)
+        check(lib().dlip_nct_to_ntc_f32(ptr(rows), ptr(xT), 1, J, Cx, J32, stream_handle()), "dlip_nct_to_ntc_f32")
+        xT_s = ops.split_pack(xT.view(Cx, J32))
+        ops.conv_nhwc(xT_s.view(1, 1, Cx, J32), dzT_s.view(K, 1, 1, J32), None, w_scale=ones, x_split=True,
+                      post_scale=inv, post_shift=zeros, out=out[s].view(1, 1, Cx, K))
+    return out
+
+
+class ConvTrainFn(Function):
+    """nn.Conv2d / nn.Conv1d (H = 1) on NHWC activations, raw (unfolded) weights in the reference layout
+    [K,C,R,S]: forward = the fp32 implicit-GEMM kernel; backward = bias column sum, DATA gradient = the same
+    kernel on the flipped / transposed weights (over the zero-inserted dY when strided), WEIGHT gradient = one
+    GEMM per tap over gathered rows (resnet.py:9-16,55-69; tcn.py:39-41,94,101)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        x = x.contiguous()
+        N, H, W, Cx = x.shape
+        K, Cw, R, S = weight.shape
+        if Cw != Cx or Cx % 4 or K % 4:
+            raise ValueError(f"conv train path: channels must match and be multiples of 4 (x {Cx}, weight {Cw}, out {K})")
+        w_krsc = _permute3(weight.contiguous().view(K, Cw, R * S), (0, 2, 1)).view(K, R, S, Cw)
+        y = ops.conv_nhwc(x, w_krsc, bias.contiguous() if bias is not None else None, stride=stride, pad=pad, dil=dil)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, dil, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        (sh, sw), (ph, pw), (dh, dw), has_bias = ctx.cfg
+        dy = dy.contiguous()
+        N, H, W, Cx = x.shape
+        K, _, R, S = weight.shape
+        _, Ho, Wo, _ = dy.shape
+        J = N * Ho * Wo
+        dev = x.device
+        dz_rows = dy.view(J, K)
+        dbias = _colsum_rows(dz_rows) if has_bias and ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w_crsk = _permute3(weight.contiguous().view(K, Cx, R * S), (1, 2, 0), flip_axis=2).view(Cx, R, S, K)
+            src = dy
+            if sh != 1 or sw != 1:
+                Hu, Wu = H + 2 * ph - dh * (R - 1), W + 2 * pw - dw * (S - 1)
+                src = torch.empty((N, Hu, Wu, K), device=dev, dtype=torch.float32)
+                check(lib().dlip_upsample_zero_f32(ptr(dy), ptr(src), N, Ho, Wo, Hu, Wu, K, sh, sw, stream_handle()),
+                      "dlip_upsample_zero_f32")
+            dx = ops.conv_nhwc(src, w_crsk, None, pad=(dh * (R - 1) - ph, dw * (S - 1) - pw), dil=(dh, dw))
+        dweight = None
+        if ctx.needs_input_grad[1]:
+            def tap_rows(t):
+                r, s = divmod(t, S)
+                rows = torch.empty((J, Cx), device=dev, dtype=torch.float32)
+                check(lib().dlip_tap_gather_f32(ptr(x), ptr(rows), N, H, W, Cx, Cx, Ho, Wo, sh, sw, r * dh - ph, s * dw - pw,
+                                                stream_handle()), "dlip_tap_gather_f32")
+                return rows
+            dwt = wgrad_gemm(dz_rows, tap_rows, R * S)                     # [RS, C, K]
+            dweight = _permute3(dwt, (2, 1, 0)).view(K, Cx, R, S)
+        return dx, dweight, dbias, None, None, None
+
+
+class StemConvTrainFn(Function):
+    """Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3), bias=False) on [B,T,H,W] (model.py:82) -> [(B T),H/2,W/2,64]:
+    forward = the fp32 stem kernel with the raw weights (unit scale, zero shift), backward = weight gradient
+    only (the input is data) as one GEMM over the im2col matrix."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        B, T, H, W = x.shape
+        K = weight.shape[0]
+        wk = torch.zeros((248, K), device=x.device, dtype=torch.float32)
+        wk[:245].copy_(_permute3(weight.contiguous().view(1, K, 245), (0, 2, 1)).view(245, K))
+        zero = torch.zeros((K,), device=x.device, dtype=torch.float32)
+        one = torch.ones((K,), device=x.device, dtype=torch.float32)
+        y = ops.stem3d(x, wk, zero, one)
+        ctx.save_for_backward(x)
+        ctx.K = K
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, T, H, W = x.shape
+        K = ctx.K
+        dy = dy.contiguous()
+        J = B * T * (H // 2) * (W // 2)
+        col = torch.empty((J, 248), device=x.device, dtype=torch.float32)
+        check(lib().dlip_stem_im2col_f32(ptr(x), ptr(col), B, T, H, W, stream_handle()), "dlip_stem_im2col_f32")
+        dwt = wgrad_gemm(dy.view(J, K), lambda s: col, 1)                  # [1, 248, K]
+        dweight = _permute3(dwt[:, :245].contiguous(), (0, 2, 1)).view(K, 1, 5, 7, 7)
+        return None, dweight
+
+
+class PReLUFn(Function):
+    """nn.PReLU(C) on [..., C] channels-last; slope gradient = column sums of (x < 0 ? dy x : 0)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = x.contiguous()
+        C_ = x.shape[-1]
+        M = x.numel() // C_
+        y = torch.empty_like(x)
+        check(lib().dlip_prelu_rows_fwd_f32(ptr(x), ptr(slope), ptr(y), M, C_, stream_handle()), "dlip_prelu_rows_fwd_f32")
+        ctx.save_for_backward(x, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, slope = ctx.saved_tensors
+        dy = dy.contiguous()
+        C_ = x.shape[-1]
+        M = x.numel() // C_
+        dx = torch.empty_like(x)
+        terms = torch.empty_like(x)
+        check(lib().dlip_prelu_rows_bwd_f32(ptr(dy), ptr(x), ptr(slope), ptr(dx), ptr(terms), M, C_, stream_handle()),
+              "dlip_prelu_rows_bwd_f32")
+        dslope = _colsum_rows(terms.view(M, C_)) if ctx.needs_input_grad[1] else None
+        return dx, dslope
+
+
+class MaxPoolFn(Function):
+    """MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on [(B T),H,W,C] (model.py:85)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.maxpool3x3s2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        N, H, W, C_ = x.shape
+        dx = torch.empty_like(x)
+        check(lib().dlip_maxpool3x3s2_bwd_f32(ptr(x), ptr(dy.contiguous()), ptr(dx), N, H, W, C_, stream_handle()),
+              "dlip_maxpool3x3s2_bwd_f32")
+        return dx
+
+
+class AvgPoolFn(Function):
+    """AdaptiveAvgPool2d(1) + flatten on [N,H,W,C] -> [N,C] (resnet.py:83,125-126)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.shape = tuple(x.shape)
+        return ops.avgpool(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C_ = ctx.shape
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        check(lib().dlip_row_broadcast_f32(ptr(dy.contiguous()), None, ptr(dx), N, H * W, C_, 1.0 / (H * W), stream_handle()),
+              "dlip_row_broadcast_f32")
+        return dx
+
+
+class TimeMeanFn(Function):
+    """_average_batch (model.py:16-17): mean over t < length of [B,T,C] -> [B,C]."""
+
+    @staticmethod
+    def forward(ctx, x, lengths):
+        x = x.contiguous()
+        ctx.shape = tuple(x.shape)
+        ctx.save_for_backward(lengths)
+        return ops.time_mean(x, lengths)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (lengths,) = ctx.saved_tensors
+        B, T, C_ = ctx.shape
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        check(lib().dlip_row_broadcast_f32(ptr(dy.contiguous()), ptr(lengths), ptr(dx), B, T, C_, 0.0, stream_handle()),
+              "dlip_row_broadcast_f32")
+        return dx, None
+
+
+class MulMaskFn(Function):
+    """y = x * mask * scale: nn.Dropout with an explicit keep-mask (tcn.py:80,85) and, with mask = 1 and two
+    calls, nothing else -- the add of the residual branches is torch's own tensor add."""
+
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        x = x.contiguous()
+        ctx.save_for_backward(mask)
+        ctx.scale = scale
+        y = torch.empty_like(x)
+        check(lib().dlip_mul_mask_f32(ptr(x), ptr(mask), ptr(y), x.numel(), scale, stream_handle()), "dlip_mul_mask_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib().dlip_mul_mask_f32(ptr(dy), ptr(mask), ptr(dx), dy.numel(), ctx.scale, stream_handle()), "dlip_mul_mask_f32")
+        return dx, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# functional helpers used by deeplip_amd.video in train mode
+# ------------------------------------------------------------------------------------------------------
+def conv(x, weight, bias=None, stride=(1, 1), pad=(0, 0), dil=(1, 1)):
+    """x NHWC, weight [K,C,R,S] (reference Conv2d layout) or [K,C,S] (Conv1d: R = 1)."""
+    if weight.dim() == 3:
+        weight = weight.unsqueeze(2)
+    return ConvTrainFn.apply(x, weight, bias, tuple(stride), tuple(pad), tuple(dil))
+
+
+def batchnorm(x, bn):
+    """Train-mode BatchNorm over all leading axes of a channels-last tensor; running stats updated in place
+    (nn.BatchNorm1d/2d/3d: resnet.py:51,64,16; model.py:83; tcn.py:42)."""
+    C_ = x.shape[-1]
+    y = BNRowsActFn.apply(x.contiguous().view(-1, C_), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                          1.0, False)
+    bn.num_batches_tracked += 1
+    return y.view(x.shape)
+
+
+def prelu(x, act):
+    """act: holders.PReLUParams (learnable per-channel slope) or a ReLU marker (slope 0, no parameter)."""
+    w = getattr(act, "weight", None)
+    C_ = x.shape[-1]
+    if w is None:
+        w = torch.zeros((C_,), device=x.device, dtype=torch.float32)
+    elif w.numel() == 1:
+        w = w.expand(C_)
+    return PReLUFn.apply(x, w.contiguous() if not w.is_contiguous() else w)
+
+
+def maxpool(x):
+    return MaxPoolFn.apply(x)
+
+
+def avgpool(x):
+    return AvgPoolFn.apply(x)
+
+
+def time_mean(x, lengths):
+    return TimeMeanFn.apply(x, lengths)
+
+
+def dropout(x, p: float, training: bool = True):
+    if not training or p <= 0.0:
+        return x
+    mask = (torch.rand(x.shape, device=x.device) >= p).float()   # torch's generator: the mask stream is build-owned
+    return MulMaskFn.apply(x, mask, 1.0 / (1.0 - p))
+
+
+def stem_conv(x_bthw, weight):
+    return StemConvTrainFn.apply(x_bthw, weight)

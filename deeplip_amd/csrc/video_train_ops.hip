@@ -1,0 +1,256 @@
+// Train-mode kernels of the lip-clip ENCODER (full train_video.py training, i.e.
+// what torch.autograd does for Lipreading.forward under model.train(): train_video.py:108-169 over
+// models/video_models/model.py:80-105, resnet.py:28-127, tcn.py:28-116).  The convolutions themselves
+// (forward, data gradient, weight gradient) run on the implicit-GEMM kernels; this file holds what sits
+// around them:
+//   * tap gather: the rows one filter tap reads, as a dense [J, C] matrix (zeros for the halo) -- the
+//     operand of the per-tap weight-gradient GEMM of a padded / strided convolution;
+//   * zero insertion: the stride-s data gradient as a stride-1 convolution over the up-sampled dY;
+//   * PReLU with a per-channel learnable slope, forward and backward (resnet.py:52,66; tcn.py:47,105);
+//   * MaxPool3d((1,3,3),(1,2,2),(0,1,1)) backward (model.py:85), gather form: every input pixel looks at the
+//     <= 4 windows that contain it and takes dY from those whose FIRST maximum (row-major scan, the tie
+//     rule of the forward kernel and of ATen) it is -- deterministic, no atomics;
+//   * row broadcast: backward of AdaptiveAvgPool2d(1) (resnet.py:83) and of the masked temporal mean
+//     (model.py:16-17);
+//   * im2col of the 5x7x7 stride-(1,2,2) stem (C_in = 1) for its weight gradient;
+//   * mask multiply (Dropout forward / backward, tcn.py:80,85).
+#include "dlip_common.h"
+
+namespace {
+
+inline unsigned grid_for(long long n, int cap = 1 << 16) {
+  long long g = (n + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict__ x, f32x4* __restrict__ out, int H, int W,
+                                                         int ldx, int C4, int Ho, int Wo, int sh, int sw, int oh, int ow,
+                                                         long long n4) {
+  // oh / ow: input offset of the tap = r * dil_h - pad_h, s * dil_w - pad_w
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const long long j = i / C4;
+    const int wo = (int)(j % Wo);
+    const long long t = j / Wo;
+    const int ho = (int)(t % Ho);
+    const long long n = t / Ho;
+    const int hi = ho * sh + oh, wi = wo * sw + ow;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+      v = *reinterpret_cast<const f32x4*>(x + ((n * H + hi) * W + wi) * ldx + c4 * 4);
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_zero_kernel(const f32x4* __restrict__ dz, f32x4* __restrict__ out, int Ho, int Wo,
+                                                            int Hu, int Wu, int C4, int sh, int sw, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const long long p = i / C4;
+    const int wu = (int)(p % Wu);
+    const long long t = p / Wu;
+    const int hu = (int)(t % Hu);
+    const long long n = t / Hu;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (hu % sh == 0 && wu % sw == 0 && hu / sh < Ho && wu / sw < Wo) v = dz[((n * Ho + hu / sh) * Wo + wu / sw) * C4 + c4];
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void prelu_fwd_kernel(const f32x4* __restrict__ x, const float* __restrict__ slope,
+                                                        f32x4* __restrict__ y, int C4, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const f32x4 v = x[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = v[k] >= 0.f ? v[k] : v[k] * slope[c + k];
+    y[i] = o;
+  }
+}
+
+// dx = dy * (x >= 0 ? 1 : slope);  t = (x >= 0 ? 0 : dy * x)  (column sums of t = the slope gradient)
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
+                                                        const float* __restrict__ slope, f32x4* __restrict__ dx,
+                                                        f32x4* __restrict__ t, int C4, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const f32x4 v = x[i], g = dy[i];
+    f32x4 o, u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k] = v[k] >= 0.f ? g[k] : g[k] * slope[c + k];
+      u[k] = v[k] >= 0.f ? 0.f : g[k] * v[k];
+    }
+    dx[i] = o;
+    t[i] = u;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          f32x4* __restrict__ dx, int H, int W, int Ho, int Wo, int C4,
+                                                          long long n4) {
+  const int C = C4 * 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const long long p = i / C4;
+    const int w = (int)(p % W);
+    const long long t = p / W;
+    const int h = (int)(t % H);
+    const long long n = t / H;
+    const float* xn = x + n * H * W * C + c;
+    const f32x4 me = *reinterpret_cast<const f32x4*>(xn + ((long long)h * W + w) * C);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // windows (ho, wo) with 2 ho - 1 <= h <= 2 ho + 1
+    for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
+      if (ho >= Ho) continue;
+      for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
+        if (wo >= Wo) continue;
+        // first maximum of the window in row-major order; does it sit at (h, w)?
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bh[4] = {-1, -1, -1, -1}, bw[4] = {-1, -1, -1, -1};
+        for (int r = 0; r < 3; ++r) {
+          const int hh = 2 * ho - 1 + r;
+          if ((unsigned)hh >= (unsigned)H) continue;
+          for (int s = 0; s < 3; ++s) {
+            const int ww = 2 * wo - 1 + s;
+            if ((unsigned)ww >= (unsigned)W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xn + ((long long)hh * W + ww) * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (v[k] > best[k] || bh[k] < 0) { best[k] = v[k]; bh[k] = hh; bw[k] = ww; }
+          }
+        }
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((n * Ho + ho) * Wo + wo) * C + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (bh[k] == h && bw[k] == w) acc[k] += g[k];
+      }
+    }
+    (void)me;
+    dx[i] = acc;
+  }
+}
+
+// dx[n, p, :] = dy[n, :] * (lengths ? (p < len[n] ? 1 / len[n] : 0) : scale)
+__global__ __launch_bounds__(256) void row_broadcast_kernel(const f32x4* __restrict__ dy, const int* __restrict__ lengths,
+                                                            f32x4* __restrict__ dx, int P, int C4, float scale, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const long long t = i / C4;
+    const int p = (int)(t % P);
+    const long long n = t / P;
+    float sc = scale;
+    if (lengths) {
+      const int len = lengths[n] < P ? lengths[n] : P;
+      sc = (p < len && len > 0) ? 1.f / (float)len : 0.f;
+    }
+    const f32x4 g = dy[n * C4 + c4];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = g[k] * sc;
+    dx[i] = o;
+  }
+}
+
+// col[j, k]: j = ((b T + t) Ho + ho) Wo + wo, k = (dt 7 + r) 7 + s for k < 245, zero for 245..247
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int T, int H,
+                                                          int W, int Ho, int Wo, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % 248);
+    const long long j = i / 248;
+    float v = 0.f;
+    if (k < 245) {
+      const int s = k % 7, r = (k / 7) % 7, dt = k / 49;
+      const int wo = (int)(j % Wo);
+      const long long q = j / Wo;
+      const int ho = (int)(q % Ho);
+      const long long bt = q / Ho;
+      const int t = (int)(bt % T);
+      const long long b = bt / T;
+      const int tt = t + dt - 2, hh = 2 * ho + r - 3, ww = 2 * wo + s - 3;
+      if ((unsigned)tt < (unsigned)T && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+        v = x[((b * T + tt) * H + hh) * W + ww];
+    }
+    col[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                       float* __restrict__ y, float scale, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * mask[i] * scale;
+}
+
+}  // namespace
+
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int dlip_tap_gather_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                                   int32_t Ho, int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t off_h, int32_t off_w,
+                                   dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && out && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C && Ho > 0 && Wo > 0 &&
+                 stride_h > 0 && stride_w > 0);
+  const long long n4 = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(tap_gather_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), x, reinterpret_cast<f32x4*>(out), H, W, ldx,
+                     C / 4, Ho, Wo, stride_h, stride_w, off_h, off_w, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_upsample_zero_f32(const float* dz, float* out, int64_t N, int32_t Ho, int32_t Wo, int32_t Hu, int32_t Wu,
+                                      int32_t C, int32_t stride_h, int32_t stride_w, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dz && out && N > 0 && Ho > 0 && Wo > 0 && Hu > 0 && Wu > 0 && C > 0 && (C & 3) == 0 && stride_h > 0 && stride_w > 0);
+  const long long n4 = (long long)N * Hu * Wu * (C / 4);
+  hipLaunchKernelGGL(upsample_zero_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), reinterpret_cast<const f32x4*>(dz),
+                     reinterpret_cast<f32x4*>(out), Ho, Wo, Hu, Wu, C / 4, stride_h, stride_w, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_prelu_rows_fwd_f32(const float* x, const float* slope, float* y, int64_t M, int32_t C, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && slope && y && M > 0 && C > 0 && (C & 3) == 0);
+  const long long n4 = (long long)M * (C / 4);
+  hipLaunchKernelGGL(prelu_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), reinterpret_cast<const f32x4*>(x), slope,
+                     reinterpret_cast<f32x4*>(y), C / 4, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_prelu_rows_bwd_f32(const float* dy, const float* x, const float* slope, float* dx, float* dslope_terms,
+                                       int64_t M, int32_t C, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dy && x && slope && dx && dslope_terms && M > 0 && C > 0 && (C & 3) == 0);
+  const long long n4 = (long long)M * (C / 4);
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), reinterpret_cast<const f32x4*>(dy),
+                     reinterpret_cast<const f32x4*>(x), slope, reinterpret_cast<f32x4*>(dx), reinterpret_cast<f32x4*>(dslope_terms),
+                     C / 4, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_maxpool3x3s2_bwd_f32(const float* x, const float* dy, float* dx, int64_t N, int32_t H, int32_t W, int32_t C,
+                                         dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0);
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long n4 = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), x, dy, reinterpret_cast<f32x4*>(dx), H, W, Ho,
+                     Wo, C / 4, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_row_broadcast_f32(const float* dy, const int32_t* lengths, float* dx, int64_t N, int32_t P, int32_t C,
+                                      float scale, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dy && dx && N > 0 && P > 0 && C > 0 && (C & 3) == 0);
+  const long long n4 = (long long)N * P * (C / 4);
+  hipLaunchKernelGGL(row_broadcast_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), reinterpret_cast<const f32x4*>(dy), lengths,
+                     reinterpret_cast<f32x4*>(dx), P, C / 4, scale, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_stem_im2col_f32(const float* x, float* col, int32_t B, int32_t T, int32_t H, int32_t W, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && col && B > 0 && T > 0 && H > 1 && W > 1 && (H & 1) == 0 && (W & 1) == 0);
+  const long long n = (long long)B * T * (H / 2) * (W / 2) * 248;
+  hipLaunchKernelGGL(stem_im2col_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, col, T, H, W, H / 2, W / 2, n);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_mul_mask_f32(const float* x, const float* mask, float* y, int64_t n, float scale, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && mask && y && n > 0);
+  hipLaunchKernelGGL(mul_mask_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, mask, y, scale, (long long)n);
+  return dlip_launch_status();
+}

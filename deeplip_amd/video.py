@@ -99,6 +99,17 @@ class BasicBlock(nn.Module):
                              w_scale=p["conv2"].wscale, x_split=split, out_split=out_split)
 
 
+def _basic_block_train(b: "BasicBlock", x: Tensor) -> Tensor:
+    """BasicBlock.forward under model.train() (resnet.py:55-69): batch-statistics BN, learnable PReLU slopes,
+    every step a differentiable dlip_* launch (deeplip_amd/autograd_video.py).  x NHWC."""
+    from . import autograd_video as av
+    s = (b.stride, b.stride)
+    h = av.prelu(av.batchnorm(av.conv(x, b.conv1.weight, None, stride=s, pad=(1, 1)), b.bn1), b.relu1)
+    h = av.batchnorm(av.conv(h, b.conv2.weight, None, pad=(1, 1)), b.bn2)
+    res = x if b.downsample is None else av.batchnorm(av.conv(x, b.downsample[0].weight, None, stride=s), b.downsample[1])
+    return av.prelu(h + res, b.relu2)
+
+
 class ResNet(nn.Module):
     """resnet.py:72-127 (BasicBlock, [2,2,2,2]); init as resnet.py:86-99."""
 
@@ -251,6 +262,30 @@ class MultibranchTemporalBlock(nn.Module):
         raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
 
 
+def _tcn_block_train(b: "MultibranchTemporalBlock", x: Tensor, p_drop: float) -> Tensor:
+    """MultibranchTemporalBlock.forward under model.train() (tcn.py:89-116).  Each branch convolves with
+    padding (k-1)d on both sides, normalises with the batch statistics of the FULL padded-length output,
+    THEN chomps symmetrically (tcn.py:52-59: conv -> batchnorm -> chomp -> non_lin) -- in train mode the
+    statistics therefore include the edge frames the chomp removes.  x [B,T,C] channels-last."""
+    from . import autograd_video as av
+    B, T, _ = x.shape
+    cur = x
+    for s in (0, 1):
+        outs = []
+        for j, k in enumerate(b.kernel_sizes):
+            m = getattr(b, f"cbcr{s}_{j}")
+            pad = (k - 1) * b.dilation
+            z = av.conv(cur.reshape(B, 1, T, cur.shape[2]), m.conv.weight, m.conv.bias, pad=(0, pad), dil=(1, b.dilation))
+            z = av.batchnorm(z, m.batchnorm)                         # [B,1,T+pad,nb]
+            z = z[:, :, pad // 2: pad // 2 + T].contiguous()         # symmetric chomp
+            outs.append(av.prelu(z, m.non_lin))
+        cur = av.dropout(torch.cat(outs, dim=3).view(B, T, b.n_outputs), p_drop)
+    if b.downsample is None:
+        raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
+    res = av.conv(x.reshape(B, 1, T, x.shape[2]), b.downsample.weight, b.downsample.bias).view(B, T, b.n_outputs)
+    return av.prelu(cur + res, b.relu_final)
+
+
 class MultibranchTemporalConvNet(nn.Module):
     """tcn.py:118-140."""
 
@@ -342,6 +377,7 @@ class Lipreading(nn.Module):
         stem = ConvParams(1, self.frontend_nout, (5, 7, 7), bias=False)
         self.frontend3D = nn.Sequential(stem, BatchNormParams(self.frontend_nout), frontend_relu,
                                         Marker("MaxPool3d((1,3,3),(1,2,2),(0,1,1))"))
+        self.tcn_dropout = float(tcn_options["dropout"])
         tcn_class = TCN if len(tcn_options["kernel_size"]) == 1 else MultiscaleMultibranchTCN
         self.tcn = tcn_class(input_size=self.backend_out,
                              num_channels=[hidden_dim * len(tcn_options["kernel_size"]) * tcn_options["width_mult"]] * tcn_options["num_layers"],
@@ -356,8 +392,30 @@ class Lipreading(nn.Module):
             "tcn": self.tcn.pack(device),
         }
 
+    def _forward_train(self, x: Tensor, lengths):
+        """forward() under model.train() (train_video.py:129,140-146): the whole encoder differentiable, every
+        forward and backward step a dlip_* launch (deeplip_amd/autograd_video.py); BatchNorm uses batch
+        statistics and updates its running buffers, Dropout draws a fresh keep-mask."""
+        from . import autograd as ag, autograd_video as av
+        B, C, T, H, W = x.size()
+        if C != 1:
+            raise ValueError("Lipreading expects grayscale clips [B,1,T,H,W] (model.py:82)")
+        stem, bn, act = self.frontend3D[0], self.frontend3D[1], self.frontend3D[2]
+        y = av.stem_conv(x.contiguous().float().view(B, T, H, W), stem.weight)       # [(B T),H/2,W/2,64]
+        y = av.maxpool(av.prelu(av.batchnorm(y, bn), act))
+        for blk in self.trunk.blocks():
+            y = _basic_block_train(blk, y)
+        y = av.avgpool(y).view(B, T, self.backend_out)
+        if self.extract_feats:
+            return y
+        for blk in self.tcn.mb_ms_tcn.network:
+            y = _tcn_block_train(blk, y, self.tcn_dropout)
+        ln = torch.as_tensor([int(l) for l in lengths], dtype=torch.int32).to(x.device)
+        return ag.linear(av.time_mean(y, ln), self.tcn.tcn_output.weight, self.tcn.tcn_output.bias)
+
     def forward(self, x: Tensor, lengths, taps: Optional[dict] = None):
-        _require_eval(self)
+        if self.training:
+            return self._forward_train(x, lengths)
         B, C, T, H, W = x.size()
         if C != 1:
             raise ValueError("Lipreading expects grayscale clips [B,1,T,H,W] (model.py:82); use "

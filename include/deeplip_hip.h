@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 9
+#define DLIP_ABI_VERSION 10
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -329,6 +329,44 @@ int dlip_split_pack_scaled_f32(const float* x, float* y, const float* scale, int
                                dlip_stream_t stream);
 /* y[0:n] = src[0] (device scalar broadcast: the per-channel 1/scale vector of the weight-gradient GEMM). */
 int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Train-mode kernels of the lip-clip encoder (deeplip_amd/csrc/video_train_ops.hip):
+ * what sits around the implicit-GEMM convolutions when torch.autograd's work for Lipreading.forward under
+ * model.train() (train_video.py:108-169; models/video_models/model.py:80-105, resnet.py:28-127,
+ * tcn.py:28-116) is done by dlip_* launches (deeplip_amd/autograd_video.py).  All tensors NHWC fp32,
+ * C % 4 == 0.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Rows one filter tap reads: out[j, :] = x[n, ho*stride_h + off_h, wo*stride_w + off_w, 0:C] (zeros outside
+ * the image), j = (n*Ho + ho)*Wo + wo; off = tap * dilation - padding.  The operand of the per-tap
+ * weight-gradient GEMM of a padded / strided Conv2d / Conv1d (resnet.py:9-16, tcn.py:39-41). */
+int dlip_tap_gather_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                        int32_t Ho, int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t off_h, int32_t off_w,
+                        dlip_stream_t stream);
+/* out [N,Hu,Wu,C] = dz [N,Ho,Wo,C] with stride-1 zeros inserted (out[n, ho*s, wo*s] = dz[n, ho, wo]): the data
+ * gradient of a strided convolution as a stride-1 convolution (resnet.py:9-16 with stride 2). */
+int dlip_upsample_zero_f32(const float* dz, float* out, int64_t N, int32_t Ho, int32_t Wo, int32_t Hu, int32_t Wu,
+                           int32_t C, int32_t stride_h, int32_t stride_w, dlip_stream_t stream);
+/* nn.PReLU(C) on rows [M,C] (resnet.py:52,66; model.py:84; tcn.py:47,105): y = x >= 0 ? x : slope[c] * x. */
+int dlip_prelu_rows_fwd_f32(const float* x, const float* slope, float* y, int64_t M, int32_t C, dlip_stream_t stream);
+/* Backward: dx, and dslope_terms [M,C] = (x < 0 ? dy * x : 0) whose column sums (dlip_colsum_rows_f32) are
+ * the slope gradient. */
+int dlip_prelu_rows_bwd_f32(const float* dy, const float* x, const float* slope, float* dx, float* dslope_terms,
+                            int64_t M, int32_t C, dlip_stream_t stream);
+/* MaxPool3d((1,3,3),(1,2,2),(0,1,1)) backward (model.py:85): x [N,H,W,C] = the pooled tensor's input,
+ * dy [N,Ho,Wo,C] -> dx; first-maximum tie rule (row-major window scan), deterministic. */
+int dlip_maxpool3x3s2_bwd_f32(const float* x, const float* dy, float* dx, int64_t N, int32_t H, int32_t W, int32_t C,
+                              dlip_stream_t stream);
+/* dx[n, p, :] = dy[n, :] * w, p < P: w = scale (AdaptiveAvgPool2d(1) backward, resnet.py:83: scale = 1/(H W)),
+ * or with lengths != NULL w = (p < len[n] ? 1/len[n] : 0) (masked temporal mean backward, model.py:16-17). */
+int dlip_row_broadcast_f32(const float* dy, const int32_t* lengths, float* dx, int64_t N, int32_t P, int32_t C,
+                           float scale, dlip_stream_t stream);
+/* im2col of the stem Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) (model.py:82): x [B,T,H,W] -> col [B*T*(H/2)*(W/2), 248]
+ * (245 taps + 3 zero columns), the operand of the stem's weight-gradient GEMM. */
+int dlip_stem_im2col_f32(const float* x, float* col, int32_t B, int32_t T, int32_t H, int32_t W, dlip_stream_t stream);
+/* y = x * mask * scale (nn.Dropout forward / backward, tcn.py:80,85). */
+int dlip_mul_mask_f32(const float* x, const float* mask, float* y, int64_t n, float scale, dlip_stream_t stream);
 
 #ifdef __cplusplus
 }

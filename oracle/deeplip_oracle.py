@@ -38,9 +38,24 @@ def to_torch_sd(sd: Mapping[str, np.ndarray]) -> Dict[str, Tensor]:
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
 
 
+_BN_TRAIN = [False]   # set by bn_training(): the video functions below then follow model.train()
+
+
+class bn_training:
+    """Context manager: inside it every BatchNorm of the video restatement uses batch statistics and updates
+    its running buffers in place (momentum 0.1), i.e. the functions restate the reference classes under
+    model.train() (train_video.py:129).  Dropout is not restated (p = 0 in the pinned configuration)."""
+
+    def __enter__(self):
+        _BN_TRAIN.append(True)
+
+    def __exit__(self, *a):
+        _BN_TRAIN.pop()
+
+
 def _bn(x: Tensor, sd: SD, p: str) -> Tensor:
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
-                        sd[p + ".bias"], training=False, eps=BN_EPS)
+                        sd[p + ".bias"], training=_BN_TRAIN[-1], momentum=0.1, eps=BN_EPS)
 
 
 def _act(x: Tensor, sd: SD, p: str, relu_type: str) -> Tensor:
@@ -395,6 +410,14 @@ def fused_av_embedding(video_sd: SD, audio_sd: SD, video: Tensor, audio: Tensor,
 # ----------------------------------------------------------------------------------------
 # Trainable tail (config C5): train_fusion.py:286-299 with the encoders frozen
 # ----------------------------------------------------------------------------------------
+def lipreading_logits_train(p: Dict[str, Tensor], x: Tensor, lengths: Sequence[int], relu_type: str = "prelu") -> Tensor:
+    """Lipreading.forward under model.train() with TCN dropout 0 (train_video.py:129,140-146 over model.py:96-105):
+    batch-statistics BatchNorm in the stem, every BasicBlock and every ConvBatchChompRelu -- there over the FULL
+    padded-length conv output, before the chomp (tcn.py:52-59) -- running buffers of `p` updated in place."""
+    with bn_training():
+        return lipreading_logits(p, x, lengths, relu_type)
+
+
 def linearfusion_train(p: Dict[str, Tensor], x: Tensor, extract_feats: bool = False,
                        momentum: float = 0.1) -> Tensor:
     """Linearfusion.forward in TRAIN mode (model_fusion.py:19-24): BatchNorm1d uses batch statistics

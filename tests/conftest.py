@@ -23,7 +23,7 @@ def manifest():
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: np.load(os.path.join(GOLDEN, f"{n}_golden.npz")) for n in ("video", "audio", "heads", "train", "audio_train")}
+    return {n: np.load(os.path.join(GOLDEN, f"{n}_golden.npz")) for n in ("video", "audio", "heads", "train", "audio_train", "video_train")}
 
 
 def rel_err(a, b):

@@ -332,8 +332,76 @@ def audio_train():
     print("audio_train:", {k: np.shape(v) for k, v in list(out.items())[:12]}, "...", len(out), "arrays")
 
 
+def video_train():
+    """One optimisation step of the FULL lip-clip model exactly as train_video.py:129-147 composes it
+    (model.train(): batch-statistics BatchNorm in stem / trunk / TCN, learnable PReLU slopes; CrossEntropyLoss;
+    Adam lr 3e-4 / wd 1e-4: train_video.py:112-113), then the loss of a second forward.  Dropout is set to 0 in
+    the TCN options (the keep-masks come from torch's generator, which a re-implementation cannot share);
+    2 clips x 7 frames x 88 x 88, lengths [7, 5] (the masked consensus mean, model.py:16-17)."""
+    out = {}
+    opts = dict(TCN_OPTS, dropout=0.0)
+    net = Lipreading(num_classes=54, relu_type="prelu", tcn_options=opts, extract_feats=False)
+    fill(net, "vtrain.video.")
+    net.train()
+    x = torch.from_numpy(wg.video_input(2, frames=7, key="vtrain.x"))
+    lengths = [7, 5]
+    lab = torch.from_numpy(wg.labels(2, 54))
+    opt = torch.optim.Adam(net.parameters(), lr=3e-4, weight_decay=1e-4)
+    crit = torch.nn.CrossEntropyLoss()
+    opt.zero_grad()
+    logits = net(x, lengths=lengths)
+    loss = crit(logits, lab)
+    loss.backward()
+    out["loss0"] = loss.detach().numpy(); out["logits0"] = logits.detach().numpy()
+    out["argmax0"] = torch.max(logits, dim=1)[1].numpy()
+    g = {k: v.grad for k, v in net.named_parameters()}
+    out["grad_stem_w"] = g["frontend3D.0.weight"].numpy().copy()
+    out["grad_stem_bn_w"] = g["frontend3D.1.weight"].numpy().copy()
+    out["grad_stem_prelu"] = g["frontend3D.2.weight"].numpy().copy()
+    out["grad_l1_0_conv1_w_rows4"] = g["trunk.layer1.0.conv1.weight"][:4].numpy().copy()
+    out["grad_l2_0_down_w_rows4"] = g["trunk.layer2.0.downsample.0.weight"][:4].numpy().copy()
+    out["grad_l2_0_conv1_w_rows2"] = g["trunk.layer2.0.conv1.weight"][:2].numpy().copy()
+    out["grad_l4_1_conv2_w_rows2"] = g["trunk.layer4.1.conv2.weight"][:2].numpy().copy()
+    out["grad_l3_1_relu2"] = g["trunk.layer3.1.relu2.weight"].numpy().copy()
+    out["grad_tcn0_cbcr0_1_w_rows4"] = g["tcn.mb_ms_tcn.network.0.cbcr0_1.conv.weight"][:4].numpy().copy()
+    out["grad_tcn3_down_b"] = g["tcn.mb_ms_tcn.network.3.downsample.bias"].numpy().copy()
+    out["grad_tcn_out_w_rows4"] = g["tcn.tcn_output.weight"][:4].numpy().copy()
+    for k, v in g.items():
+        out[f"gradnorm_{k}"] = np.array([float(v.double().norm()), float(v.double().sum())])
+    # the same step in fp64 (same class, parameters and inputs cast to double): the yardstick for how far the
+    # reference's own fp32 arithmetic is from the exact gradients through 18 BatchNorm'd layers on 2 clips
+    import copy
+    net64 = copy.deepcopy(net).double()
+    net64.zero_grad()
+    loss64 = crit(net64(x.double(), lengths=lengths), lab)
+    loss64.backward()
+    g64 = {k: v.grad for k, v in net64.named_parameters()}
+    out["loss0_f64"] = loss64.detach().numpy()
+    for gk, pk, rows in (("grad_stem_w", "frontend3D.0.weight", None), ("grad_stem_bn_w", "frontend3D.1.weight", None),
+                         ("grad_stem_prelu", "frontend3D.2.weight", None), ("grad_l1_0_conv1_w_rows4", "trunk.layer1.0.conv1.weight", 4),
+                         ("grad_l2_0_down_w_rows4", "trunk.layer2.0.downsample.0.weight", 4),
+                         ("grad_l2_0_conv1_w_rows2", "trunk.layer2.0.conv1.weight", 2),
+                         ("grad_l4_1_conv2_w_rows2", "trunk.layer4.1.conv2.weight", 2), ("grad_l3_1_relu2", "trunk.layer3.1.relu2.weight", None),
+                         ("grad_tcn0_cbcr0_1_w_rows4", "tcn.mb_ms_tcn.network.0.cbcr0_1.conv.weight", 4),
+                         ("grad_tcn3_down_b", "tcn.mb_ms_tcn.network.3.downsample.bias", None),
+                         ("grad_tcn_out_w_rows4", "tcn.tcn_output.weight", 4)):
+        v = g64[pk] if rows is None else g64[pk][:rows]
+        out[gk + "_f64"] = v.numpy().copy()
+    for k, v in g64.items():
+        out[f"gradnorm64_{k}"] = np.array([float(v.norm()), float(v.sum())])
+    opt.step()
+    out["after1_stem_running_var"] = net.frontend3D[1].running_var.numpy().copy()
+    out["after1_l4_1_bn2_running_mean"] = net.trunk.layer4[1].bn2.running_mean.numpy().copy()
+    out["after1_tcn0_cbcr0_2_running_var"] = net.tcn.mb_ms_tcn.network[0].cbcr0_2.batchnorm.running_var.numpy().copy()
+    with torch.no_grad():
+        out["loss1"] = crit(net(x, lengths=lengths), lab).numpy()
+    np.savez_compressed(os.path.join(HERE, "video_train_golden.npz"), **out)
+    print("video_train:", {k: np.shape(v) for k, v in list(out.items())[:14]}, "...", len(out), "arrays; loss0", float(out["loss0"]),
+          "loss1", float(out["loss1"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["video", "audio", "heads", "train", "audio_train"]
+    which = sys.argv[1:] or ["video", "audio", "heads", "train", "audio_train", "video_train"]
     mpath = os.path.join(HERE, "manifest.json")
     if os.path.exists(mpath):
         manifest.update(json.load(open(mpath)))

@@ -23,12 +23,20 @@ def test_train_video_cpu_plumbing(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rgb", [False, True])
-def test_train_video_gpu_two_steps(tmp_path, rgb):
+@pytest.mark.parametrize("mode", ["full", "full-rgb", "head-only"])
+def test_train_video_gpu_two_steps(tmp_path, mode):
+    """Default = full-model training as the reference does (model.train(), backward through stem / trunk / TCN on
+    the engine); --head-only = classifier layer on frozen eval-mode features."""
     import train_video
-    argv = ["--save-path", str(tmp_path / "ck"), "--steps", "2", "--frames", "9"] + (["--rgb"] if rgb else [])
+    argv = ["--save-path", str(tmp_path / "ck"), "--steps", "2", "--frames", "9"]
+    argv += {"full": [], "full-rgb": ["--rgb"], "head-only": ["--head-only"]}[mode]
     loss, shape = train_video.main(argv)
     assert np.isfinite(loss) and shape == (4, 54)
+    sd = torch.load(tmp_path / "ck" / "1.pt", map_location="cpu")
+    ref = __import__("deeplip_amd.weightgen", fromlist=["x"]).fill_state_dict({"frontend3D.0.weight": (64, 1, 5, 7, 7)}, prefix="video.")
+    moved = not np.array_equal(sd["frontend3D.0.weight"].numpy(), ref["frontend3D.0.weight"])
+    assert moved == (mode != "head-only")                 # the stem weights train only in full mode
+    assert int(sd["frontend3D.1.num_batches_tracked"]) == (0 if mode == "head-only" else 2)
 
 
 @pytest.mark.gpu

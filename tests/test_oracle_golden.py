@@ -241,3 +241,34 @@ def test_audio_encoder_train_step_oracle(golden):
     assert abs(float(loss) - float(g["loss1"])) < 1e-4 * float(g["loss1"])
     assert rel_err(p["tdnn.0.context_layer.weight"].detach().numpy(), g["after2_tdnn0_w"]) < 1e-5
     assert rel_err(p["tdnn.1.bn.running_var"].numpy(), g["after2_tdnn1_running_var"]) < 1e-5
+
+
+def test_lipreading_train_step_oracle_vs_reference_golden(golden):
+    """One training step of the FULL lip-clip model (train_video.py:129-147; TCN dropout 0) -- the oracle's
+    train-mode restatement under torch autograd vs values captured from the reference class: loss, logits, argmax,
+    gradients from the stem to the classifier, BatchNorm running statistics."""
+    import torch.nn.functional as F
+    g = golden["video_train"]
+    from models.video_models.model import Lipreading
+    tcn = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.0, "dwpw": False, "width_mult": 1}
+    shapes = {k: tuple(v.shape) for k, v in Lipreading(num_classes=54, relu_type="prelu", tcn_options=tcn).state_dict().items()}
+    p = O.to_torch_sd(wg.fill_state_dict(shapes, prefix="vtrain.video."))
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_()
+    x = torch.from_numpy(wg.video_input(2, frames=7, key="vtrain.x"))
+    lab = torch.from_numpy(wg.labels(2, 54))
+    logits = O.lipreading_logits_train(p, x, [7, 5])
+    loss = F.cross_entropy(logits, lab)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss0"])) < 1e-5 * float(g["loss0"])
+    assert rel_err(logits.detach().numpy(), g["logits0"]) < 1e-5
+    assert np.array_equal(O.argmax_first(logits).numpy(), g["argmax0"])
+    assert rel_err(p["frontend3D.0.weight"].grad.numpy(), g["grad_stem_w"]) < 1e-4
+    assert rel_err(p["trunk.layer2.0.downsample.0.weight"].grad[:4].numpy(), g["grad_l2_0_down_w_rows4"]) < 1e-4
+    assert rel_err(p["trunk.layer4.1.conv2.weight"].grad[:2].numpy(), g["grad_l4_1_conv2_w_rows2"]) < 1e-4
+    assert rel_err(p["tcn.mb_ms_tcn.network.0.cbcr0_1.conv.weight"].grad[:4].numpy(), g["grad_tcn0_cbcr0_1_w_rows4"]) < 1e-4
+    assert rel_err(p["tcn.tcn_output.weight"].grad[:4].numpy(), g["grad_tcn_out_w_rows4"]) < 1e-4
+    # running statistics after ONE forward (the optimiser step does not touch buffers)
+    assert rel_err(p["frontend3D.1.running_var"].numpy(), g["after1_stem_running_var"]) < 1e-5
+    assert rel_err(p["tcn.mb_ms_tcn.network.0.cbcr0_2.batchnorm.running_var"].numpy(), g["after1_tcn0_cbcr0_2_running_var"]) < 1e-5

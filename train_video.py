@@ -9,9 +9,14 @@ produced with ``pad_packed_collate`` semantics (zero-pad to the longest clip + l
 models/video_models/dataset.py:123-139); ``--rgb`` feeds uint8 [B,T,3,88,88] frames through the
 GPU ingest kernel (gray + (x/255-0.421)/0.165).
 
-What trains: the classifier layer ``tcn.tcn_output`` on frozen stem + trunk + TCN features (HIP
-Linear / cross-entropy forward+backward kernels).  Training the encoder itself needs conv
-dgrad/wgrad + train-mode BN kernels: SURVEY.md section 8(f) rank 2, not built yet.
+What trains: the FULL model, as in the reference (``model.train()``: batch-statistics BatchNorm in stem /
+trunk / TCN, learnable PReLU slopes, dropout; Adam over all parameters) -- every forward and backward
+step a ``dlip_*`` launch (deeplip_amd/autograd_video.py: conv dgrad / wgrad on the implicit-GEMM kernels,
+train-mode BN, PReLU, max-pool, pooling kernels), pinned by a golden step captured from the reference
+class (tests/test_train_video_gpu.py).  ``--head-only`` trains the classifier layer ``tcn.tcn_output`` on
+frozen eval-mode features instead (the fast path on the fused inference kernels).  Under
+``torch.distributed.run`` every rank draws its own batches and the gradients are averaged with ONE flat
+all-reduce per step over RCCL (the reference uses DataParallel: train_video.py:196).
 ``--device cpu`` runs the plumbing only (config -> model -> batches -> optimiser/scheduler ->
 checkpoint round trip) because the engine has no CPU arithmetic by design.
 """
@@ -62,6 +67,7 @@ def load_args(argv=None):
     p.add_argument("--steps", type=int, default=2, help="synthetic iterations per epoch")
     p.add_argument("--frames", type=int, default=29)
     p.add_argument("--rgb", action="store_true", help="feed uint8 RGB [B,T,3,88,88] through the ingest kernel")
+    p.add_argument("--head-only", action="store_true", help="train tcn.tcn_output on frozen eval-mode features")
     return p.parse_args(argv)
 
 
@@ -111,43 +117,65 @@ def extract_feats(model, clip_thw, device):
     return model(x, lengths=[x.shape[2]])
 
 
+def _allreduce_grads(params, world):
+    """One flat all-reduce (sum) / world over RCCL: the data-parallel gradient exchange."""
+    import torch.distributed as dist
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= world
+    o = 0
+    for g in grads:
+        g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+
+
 def train(model, args, device):
-    from deeplip_amd import ops
-    for p in model.parameters():
-        p.requires_grad = False
+    from deeplip_amd import autograd as ag, ops
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
     head = model.tcn.tcn_output
-    for p in head.parameters():
-        p.requires_grad = True
-    optimizer = torch.optim.Adam(head.parameters(), lr=args.lr, weight_decay=1e-4)
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=5, eta_min=4e-08)
-    model.eval()                    # frozen encoder: running-stat BN (see module docstring)
+    full = not args.head_only and device.type != "cpu"
+    if not full:
+        for p in model.parameters():
+            p.requires_grad = False
+        for p in head.parameters():
+            p.requires_grad = True
+    params = [p for p in model.parameters() if p.requires_grad]
+    optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=1e-4)                      # (:112-113)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=5, eta_min=4e-08)      # (:114)
     last = None
     for epoch in range(int(args.maxepoch)):
         run_loss = run_ok = run_n = 0.0
+        model.train() if full else model.eval()                                                # (:129)
         for it in range(args.steps):
-            inputs, lengths, labels = synthetic_batch(args, epoch * args.steps + it, args.rgb)
+            inputs, lengths, labels = synthetic_batch(args, (epoch * args.steps + it) * world + rank, args.rgb)
             if device.type == "cpu":
                 print(f"[plumbing] batch {tuple(inputs.shape)} lengths {lengths} labels {labels.tolist()} lr {sched.get_last_lr()}")
                 optimizer.step(); sched.step()
                 continue
             labels = labels.to(device)
             x = ops.ingest_rgb_u8(inputs.to(device)) if args.rgb else inputs.unsqueeze(1).to(device)   # :125
-            from deeplip_amd import autograd as ag
-            with torch.no_grad():
-                pooled = model.classifier_features(x, lengths)             # frozen stem + trunk + MS-TCN
             optimizer.zero_grad()
-            logits = ag.linear(pooled, head.weight, head.bias)              # tcn_output (model.py:27)
-            loss = ag.margin_ce_loss(logits, labels, 1.0, 0.0)              # nn.CrossEntropyLoss (:112,138)
+            if full:
+                logits = model(x, lengths=lengths)                          # (:140) whole graph on the engine
+            else:
+                with torch.no_grad():
+                    pooled = model.classifier_features(x, lengths)         # frozen stem + trunk + MS-TCN
+                logits = ag.linear(pooled, head.weight, head.bias)          # tcn_output (model.py:27)
+            loss = ag.margin_ce_loss(logits, labels, 1.0, 0.0)              # nn.CrossEntropyLoss (:115,143)
             loss.backward()
+            if world > 1:
+                _allreduce_grads(params, world)
             optimizer.step()
-            sched.step()                                                    # per-iteration (:143)
+            sched.step()                                                    # per-iteration (:147)
             _, pred = torch.max(torch.softmax(logits.detach(), 1), 1)       # (:145)
             run_loss += float(loss.detach()) * len(labels); run_ok += float((pred == labels).sum()); run_n += len(labels)
             last = (float(loss.detach()), tuple(logits.shape))
-            if it % args.display == 0:
+            if it % args.display == 0 and rank == 0:
                 print(f"epoch {epoch} it {it} loss {run_loss / run_n:.4f} acc {run_ok / run_n:.3f} lr {sched.get_last_lr()[0]:.2e}", flush=True)
-        os.makedirs(args.save_path, exist_ok=True)
-        torch.save(model.state_dict(), os.path.join(args.save_path, f"{epoch + 1}.pt"))      # (:169)
+        if rank == 0:
+            os.makedirs(args.save_path, exist_ok=True)
+            torch.save(model.state_dict(), os.path.join(args.save_path, f"{epoch + 1}.pt"))  # (:169)
     return last
 
 
@@ -164,16 +192,29 @@ def main(argv=None):
         sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, prefix="video.")
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.to(device)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.device == "gpu":
+        import torch.distributed as dist
+        torch.cuda.set_device(device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
     if args.extract_feats and args.mouth_patch_path:
         out = extract_feats(model, np.load(args.mouth_patch_path)["data"], device)
         if args.mouth_embedding_out_path:
             np.savez(args.mouth_embedding_out_path, data=out.cpu().numpy())
         return out
     res = train(model, args, device)
+    if world > 1 and args.device == "gpu":
+        import torch.distributed as dist
+        dist.barrier()
     # checkpoint round trip (bare state_dict, as the reference saves it)
     ck = os.path.join(args.save_path, f"{int(args.maxepoch)}.pt")
     model.load_state_dict(torch.load(ck, map_location="cpu"))
-    print("done:", res, "checkpoint", ck)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("done:", res, "checkpoint", ck)
+    if world > 1 and args.device == "gpu":
+        import torch.distributed as dist
+        dist.destroy_process_group()
     return res
 
 
