@@ -47,6 +47,42 @@ class EmbeddingTable:
             np.save(p, row[None, :])
 
 
+    @classmethod
+    def load_npy_tree(cls, root: str, utt_ids: Sequence[str], device=None, groups: Optional[Dict[str, Sequence[str]]] = None):
+        """Read the reference's on-disk store back: one ``[1, D]`` ``.npy`` per utterance under ``root``
+        (what ``eer_cos_*`` np.load per trial, utils.py:260-261) -> one device-resident table.  ``groups`` maps
+        an utterance id to the clip files whose embeddings are averaged into its row (long videos are stored as
+        several clips per utterance: utils.py:456-463, models/fusion_models/datasets.py:143-150); the mean runs
+        on the GPU (group-mean kernel) when a device is given."""
+        import os
+        rows, gptr = [], [0]
+        for u in utt_ids:
+            files = list(groups[u]) if groups is not None else [u]
+            for f in files:
+                a = np.load(os.path.join(root, f.replace(".wav", ".npy")))
+                rows.append(np.asarray(a, dtype=np.float32).reshape(-1))
+            gptr.append(len(rows))
+        emb = torch.from_numpy(np.stack(rows, 0))
+        if device is not None:
+            emb = emb.to(device)
+        if groups is not None:
+            if emb.is_cuda:
+                emb = ops.group_mean(emb, torch.tensor(gptr, dtype=torch.int32, device=emb.device))
+            else:   # host-side table (I/O tests): plain mean per group, no engine arithmetic involved
+                emb = torch.stack([emb[a:b].mean(0) for a, b in zip(gptr[:-1], gptr[1:])], 0)
+        return cls(utt_ids, emb)
+
+
+def all_pairs_cosine(emb: torch.Tensor) -> torch.Tensor:
+    """Cosine score of every (enrol, test) pair of a table, [N, N]: rows L2-normalised, then one GEMM on the
+    engine -- the dense form of the trial loop (utils.py:251-283) for full score matrices / score
+    normalisation cohorts."""
+    n = ops.l2_normalize(emb.contiguous())
+    if n.shape[1] % 4:
+        raise ValueError("all_pairs_cosine: embedding dimension must be a multiple of 4")
+    return ops.linear(n, n)
+
+
 def read_trial_list(path: str) -> Tuple[np.ndarray, List[Tuple[str, str]]]:
     """`label utt1 utt2` per line (database/trial_grid_v1.txt; utils.py:256-259)."""
     y, pairs = [], []

@@ -100,3 +100,20 @@ def test_trial_list_reader(tmp_path):
     p.write_text("1 a.wav b.wav\n0 a.wav c.wav\n")
     y, pairs = scoring.read_trial_list(str(p))
     assert y.tolist() == [1, 0] and pairs == [("a.wav", "b.wav"), ("a.wav", "c.wav")]
+
+
+def test_embedding_store_npy_tree_roundtrip(tmp_path):
+    """The reference's on-disk store (one [1, D] .npy per utterance, train_fusion.py:361-364; several clip files
+    per utterance averaged into one row, utils.py:456-463) <-> the in-memory table, host side only."""
+    ids = ["s1/a.wav", "s1/b.wav", "s2/c.wav"]
+    emb = torch.arange(3 * 8, dtype=torch.float32).view(3, 8) / 7.0
+    t = scoring.EmbeddingTable(ids, emb)
+    t.save_npy_tree(str(tmp_path / "em"))
+    assert np.load(tmp_path / "em" / "s1" / "a.npy").shape == (1, 8)
+    back = scoring.EmbeddingTable.load_npy_tree(str(tmp_path / "em"), ids)
+    assert back.utt_ids == ids and torch.equal(back.emb, emb)
+    ia, ib = back.trial_indices([("s1/a.wav", "s2/c.wav"), ("s1/b.wav", "s1/a.wav")])
+    assert ia.tolist() == [0, 1] and ib.tolist() == [2, 0]
+    grouped = scoring.EmbeddingTable.load_npy_tree(str(tmp_path / "em"), ["u1", "u2"],
+                                                   groups={"u1": ["s1/a.wav", "s1/b.wav"], "u2": ["s2/c.wav"]})
+    assert torch.allclose(grouped.emb[0], (emb[0] + emb[1]) / 2) and torch.equal(grouped.emb[1], emb[2])

@@ -537,3 +537,21 @@ def test_conv_workspace_is_caller_owned(ops):
         _lib.check(lib.dlip_conv_set_workspace(small.data_ptr(), 1024, side.cuda_stream), "dlip_conv_set_workspace")   # too small for the counters
     _lib.check(lib.dlip_conv_set_workspace(None, 0, side.cuda_stream), "dlip_conv_set_workspace")                      # unregister
     del _lib._workspaces[(torch.cuda.current_device(), side.cuda_stream)]
+
+
+def test_all_pairs_cosine_and_store_group_mean(ops, tmp_path):
+    """Dense [N, N] scoring agrees with the per-trial kernel on every pair; the npy store loads back onto the GPU
+    with clip groups averaged by the group-mean kernel."""
+    from deeplip_amd import scoring
+    emb = rnd(37, 1024, seed=71)
+    full = scoring.all_pairs_cosine(emb.cuda())
+    ia = torch.arange(37, dtype=torch.int32).repeat_interleave(37).cuda()
+    ib = torch.arange(37, dtype=torch.int32).repeat(37).cuda()
+    per = scoring.cosine_scores(emb.cuda(), ia, ib).view(37, 37)
+    torch.cuda.synchronize()
+    assert float((full - per).abs().max()) < 2e-6
+    ids = [f"u{i}.wav" for i in range(6)]
+    scoring.EmbeddingTable(ids, emb[:6]).save_npy_tree(str(tmp_path))
+    t = scoring.EmbeddingTable.load_npy_tree(str(tmp_path), ["a", "b"], device="cuda",
+                                             groups={"a": ids[:4], "b": ids[4:]})
+    assert rel_err(t.emb.cpu().numpy(), torch.stack([emb[:4].mean(0), emb[4:6].mean(0)]).numpy()) < 1e-6
