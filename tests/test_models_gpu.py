@@ -174,6 +174,46 @@ def test_audio_parity_size_b32_f80_vs_oracle():
     assert rel_err(xv.cpu().numpy(), ref.numpy()) < TOL
 
 
+def test_full_size_configs_batch_invariance_and_fusion_properties(video_net):
+    """BASELINE.json full sizes -- configs[1] video [64,1,29,88,88], configs[2] audio [256,1,80,300] -- through
+    size-independent properties (the oracle would need minutes here): a clip / an utterance embeds to the same
+    vector inside the full batch and inside a batch of 4 (bit-exact in f32 mode, 1e-6 in f16x3: the balanced work
+    split moves the summation tree with the batch), duplicated inputs give the same rows, the fused [64,1024]
+    rows are z-normalised per modality, and a trial of a row with itself scores exactly 1."""
+    from deeplip_amd import fusion, packing, scoring
+    from models.audio_models.tdnn import SpeakerEmbNet
+    net, _ = video_net
+    xv = torch.from_numpy(wg.video_input(64, speakers=np.arange(64) % 16, key="full.video"))
+    xv[63] = xv[5]                                                    # a duplicated clip
+    em = net.embed(xv.to(DEV))
+    em4 = net.embed(xv[4:8].to(DEV))
+    anet, _ = load(SpeakerEmbNet(etdnn_opts(80)), "audio80.")
+    xa = torch.from_numpy(wg.audio_input(256, 80, 300, speakers=np.arange(256) % 16, key="full.audio"))
+    xa[255] = xa[5]; xa[63] = xa[5]
+    ea, _ = anet.extract_embedding(xa.unsqueeze(1).to(DEV))
+    ea4, _ = anet.extract_embedding(xa[4:8].unsqueeze(1).to(DEV))
+    torch.cuda.synchronize()
+    assert em.shape == (64, 512) and ea.shape == (256, 512) and bool(torch.isfinite(em).all()) and bool(torch.isfinite(ea).all())
+    if packing.PRECISION == "f32":
+        assert torch.equal(em[4:8], em4) and torch.equal(ea[4:8], ea4)
+    else:
+        assert rel_err(em[4:8].cpu().numpy(), em4.cpu().numpy()) < 1e-6 and rel_err(ea[4:8].cpu().numpy(), ea4.cpu().numpy()) < 1e-6
+    if packing.PRECISION == "f32":                                    # duplicated inputs: identical rows (f16x3: same 1e-6, as above)
+        assert torch.equal(em[63], em[5]) and torch.equal(ea[255], ea[5]) and torch.equal(ea[63], ea[5])
+    else:
+        assert rel_err(em[63].cpu().numpy(), em[5].cpu().numpy()) < 1e-6 and rel_err(ea[255].cpu().numpy(), ea[5].cpu().numpy()) < 1e-6
+    fused = fusion.fuse_av(ea[:64].contiguous(), em)
+    torch.cuda.synchronize()
+    f = fused.cpu().double()
+    for half in (f[:, :512], f[:, 512:]):                            # feature_normalize per modality (train_fusion.py:233-238)
+        assert float(half.mean(1).abs().max()) < 1e-5 and float((half.std(1) - 1).abs().max()) < 1e-4
+    idx = torch.arange(64, dtype=torch.int32, device=DEV)
+    s_self = scoring.cosine_scores(fused, idx, idx).cpu()
+    assert float((s_self - 1).abs().max()) < 1e-6
+    s_dup = scoring.cosine_scores(fused, torch.tensor([5], dtype=torch.int32, device=DEV), torch.tensor([63], dtype=torch.int32, device=DEV))
+    assert abs(float(s_dup.cpu()[0]) - 1.0) < 1e-6
+
+
 def test_pooling_module(golden):
     from models.audio_models.pooling import MeanStdPooling
     xp = torch.from_numpy(wg.gen("input.pool", (3, 40, 50))).to(DEV)
