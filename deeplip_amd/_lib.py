@@ -45,7 +45,7 @@ SIGNATURES = {
     "dlip_pow2_scale_f32": [c_f, c_f, c_i64, C.c_float, c_stream],
     "dlip_split_pack_scaled_f32": [c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_fill_from_scalar_f32": [c_f, c_f, c_i32, c_stream],
-    "dlip_tap_gather_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_tap_gather_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_upsample_zero_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_prelu_rows_fwd_f32": [c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_prelu_rows_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_stream],

@@ -64,7 +64,7 @@ class ConvTrainFn(Function):
     """nn.Conv2d / nn.Conv1d (H = 1) on NHWC activations, raw (unfolded) weights in the reference layout
     [K,C,R,S]: forward = the fp32 implicit-GEMM kernel; backward = bias column sum, DATA gradient = the same
     kernel on the flipped / transposed weights (over the zero-inserted dY when strided), WEIGHT gradient = one
-    GEMM per tap over gathered rows (resnet.py:9-16,55-69; tcn.py:39-41,94,101)."""
+    GEMM over the rows of all taps gathered side by side (resnet.py:9-16,55-69; tcn.py:39-41,94,101)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil):
@@ -103,13 +103,15 @@ class ConvTrainFn(Function):
             dx = ops.conv_nhwc(src, w_crsk, None, pad=(dh * (R - 1) - ph, dw * (S - 1) - pw), dil=(dh, dw))
         dweight = None
         if ctx.needs_input_grad[1]:
-            def tap_rows(t):
+            # all taps side by side in ONE [J, RS*C] matrix -> one GEMM with RS*C output rows (RS times the
+            # tiles of a per-tap GEMM: a 64-channel layer would otherwise be a single 64x64 tile)
+            taps = R * S
+            rows = torch.empty((J, taps * Cx), device=dev, dtype=torch.float32)
+            for t in range(taps):
                 r, s = divmod(t, S)
-                rows = torch.empty((J, Cx), device=dev, dtype=torch.float32)
-                check(lib().dlip_tap_gather_f32(ptr(x), ptr(rows), N, H, W, Cx, Cx, Ho, Wo, sh, sw, r * dh - ph, s * dw - pw,
-                                                stream_handle()), "dlip_tap_gather_f32")
-                return rows
-            dwt = wgrad_gemm(dz_rows, tap_rows, R * S)                     # [RS, C, K]
+                check(lib().dlip_tap_gather_f32(ptr(x), rows.data_ptr() + 4 * t * Cx, N, H, W, Cx, Cx, Ho, Wo, sh, sw,
+                                                r * dh - ph, s * dw - pw, taps * Cx, stream_handle()), "dlip_tap_gather_f32")
+            dwt = wgrad_gemm(dz_rows, lambda _: rows, 1).view(taps, Cx, K)  # [RS, C, K]
             dweight = _permute3(dwt, (2, 1, 0)).view(K, Cx, R, S)
         return dx, dweight, dbias, None, None, None
 

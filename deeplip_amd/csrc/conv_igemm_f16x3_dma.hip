@@ -860,6 +860,7 @@ struct Workspace {
 };
 constexpr int kMaxSplitTiles = 1 << 16;   // counter words per workspace
 constexpr double kSlotFlops = 0.85e12;    // algorithmic FLOP/s one resident 128x128 workgroup sustains (measured, 2 per CU)
+constexpr int kMaxPartsPerTile = 16;      // balanced split: upper bound on the workgroups sharing one tile
 constexpr double kHandoffUs = 10.0;       // cost of the slab hand-off of a launch at 128x128 tiles (measured)
 
 std::mutex& ws_mutex() { static std::mutex m; return m; }
@@ -936,6 +937,10 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
     long long Gb = sl;
     // small problems: at least 16 slices per workgroup (every extra part costs the finisher a serial slab read)
     if (sk.iters < 16 * Gb) Gb = sk.iters / 16 > 0 ? sk.iters / 16 : 1;
+    // few tiles with very long reductions (the weight-gradient GEMMs of training: 1..8 tiles, 10^4 slices):
+    // the finisher adds the parts of a tile one after the other (~2 us each), so a tile is cut into at most
+    // kMaxPartsPerTile parts -- 512 parts of one 64x64 tile cost 1 ms of serial slab reads for 90 us of MFMA
+    if (Gb > tiles * kMaxPartsPerTile) Gb = tiles * kMaxPartsPerTile;
     const double bal_us = (double)sk.iters / Gb / a.nk * tile_us + kHandoffUs * (BM * BN / 16384.0);
     if ((balanced == 2 || bal_us < plain_us) && Gb * a.nk != sk.iters) G = Gb;
   }

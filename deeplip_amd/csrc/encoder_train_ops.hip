@@ -185,24 +185,38 @@ __global__ __launch_bounds__(256) void permute3_kernel(const float* __restrict__
   }
 }
 
-// out[0] = 2^floor(log2(target / max|x|)) (1 if x == 0), out[1] = 1 / out[0]; max is order-independent: deterministic
-__global__ __launch_bounds__(1024) void pow2_scale_kernel(const float* __restrict__ x, float* __restrict__ out, long long n,
-                                                          float target) {
-  __shared__ float red[16];
+// out[0] = 2^floor(log2(target / max|x|)) (1 if x == 0), out[1] = 1 / out[0].  max|x| over the whole grid: a
+// non-negative float orders like its bit pattern, so workgroup maxima meet in one atomicMax on the word that
+// later holds out[0] (zeroed first); order-independent, hence deterministic.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, unsigned* __restrict__ acc, long long n) {
+  __shared__ float red[4];
   float m = 0.f;
-  for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(x[i]));
+  const long long n4 = n >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0)
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
-    float s = 1.f;
-    if (m > 0.f && m < 3.0e38f) s = exp2f(floorf(log2f(target / m)));
-    if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
-    out[0] = s;
-    out[1] = 1.f / s;
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (!(m == m)) m = 3.4e38f;   // NaN: treated as "huge" (scale 1e-30 path below keeps the product finite)
+    atomicMax(acc, __float_as_uint(m));
   }
+}
+
+__global__ void pow2_finalize_kernel(float* __restrict__ out, float target) {
+  const float m = __uint_as_float(reinterpret_cast<const unsigned*>(out)[0]);
+  float s = 1.f;
+  if (m > 0.f && m < 3.0e38f) s = exp2f(floorf(log2f(target / m)));
+  if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
+  out[0] = s;
+  out[1] = 1.f / s;
 }
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -306,8 +320,13 @@ extern "C" int dlip_permute3_f32(const float* x, float* y, int32_t d0, int32_t d
 
 extern "C" int dlip_pow2_scale_f32(const float* x, float* scale2, int64_t n, float target, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && scale2 && n > 0 && target > 0.f);
-  hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), x, scale2, (long long)n,
-                     target);
+  DLIP_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(scale2, 0, 2 * sizeof(float), st) != hipSuccess) return DLIP_EINVAL;
+  const long long blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, st, x,
+                     reinterpret_cast<unsigned*>(scale2), (long long)n);
+  hipLaunchKernelGGL(pow2_finalize_kernel, dim3(1), dim3(1), 0, st, scale2, target);
   return dlip_launch_status();
 }
 

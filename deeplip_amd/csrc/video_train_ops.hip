@@ -23,9 +23,9 @@ inline unsigned grid_for(long long n, int cap = 1 << 16) {
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-__global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict__ x, f32x4* __restrict__ out, int H, int W,
+__global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
                                                          int ldx, int C4, int Ho, int Wo, int sh, int sw, int oh, int ow,
-                                                         long long n4) {
+                                                         int ldo, long long n4) {
   // oh / ow: input offset of the tap = r * dil_h - pad_h, s * dil_w - pad_w
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
       v = *reinterpret_cast<const f32x4*>(x + ((n * H + hi) * W + wi) * ldx + c4 * 4);
-    out[i] = v;
+    *reinterpret_cast<f32x4*>(out + j * ldo + c4 * 4) = v;
   }
 }
 
@@ -187,12 +187,12 @@ __global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__
 
 extern "C" int dlip_tap_gather_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
                                    int32_t Ho, int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t off_h, int32_t off_w,
-                                   dlip_stream_t stream) {
+                                   int32_t ldo, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && out && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C && Ho > 0 && Wo > 0 &&
-                 stride_h > 0 && stride_w > 0);
+                 stride_h > 0 && stride_w > 0 && ldo >= C && (ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
   const long long n4 = (long long)N * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(tap_gather_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), x, reinterpret_cast<f32x4*>(out), H, W, ldx,
-                     C / 4, Ho, Wo, stride_h, stride_w, off_h, off_w, n4);
+  hipLaunchKernelGGL(tap_gather_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), x, out, H, W, ldx, C / 4, Ho, Wo, stride_h,
+                     stride_w, off_h, off_w, ldo, n4);
   return dlip_launch_status();
 }
 

@@ -338,12 +338,13 @@ int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream
  * C % 4 == 0.
  * ------------------------------------------------------------------------------------------ */
 
-/* Rows one filter tap reads: out[j, :] = x[n, ho*stride_h + off_h, wo*stride_w + off_w, 0:C] (zeros outside
- * the image), j = (n*Ho + ho)*Wo + wo; off = tap * dilation - padding.  The operand of the per-tap
- * weight-gradient GEMM of a padded / strided Conv2d / Conv1d (resnet.py:9-16, tcn.py:39-41). */
+/* Rows one filter tap reads: out[j*ldo + 0:C] = x[n, ho*stride_h + off_h, wo*stride_w + off_w, 0:C] (zeros outside
+ * the image), j = (n*Ho + ho)*Wo + wo; off = tap * dilation - padding.  With out = base + tap*C and
+ * ldo = taps*C the taps land side by side in one [J, taps*C] matrix: the operand of the weight-gradient GEMM
+ * of a padded / strided Conv2d / Conv1d (resnet.py:9-16, tcn.py:39-41). */
 int dlip_tap_gather_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
                         int32_t Ho, int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t off_h, int32_t off_w,
-                        dlip_stream_t stream);
+                        int32_t ldo, dlip_stream_t stream);
 /* out [N,Hu,Wu,C] = dz [N,Ho,Wo,C] with stride-1 zeros inserted (out[n, ho*s, wo*s] = dz[n, ho, wo]): the data
  * gradient of a strided convolution as a stride-1 convolution (resnet.py:9-16 with stride 2). */
 int dlip_upsample_zero_f32(const float* dz, float* out, int64_t N, int32_t Ho, int32_t Wo, int32_t Hu, int32_t Wu,

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Step time of full lip-clip model training at the reference's shapes: Lipreading
+(ResNet-18 + MS-TCN), 29-frame 88x88 clips, Adam, CrossEntropy; forward + backward + optimiser, HIP events.
+Also prints the 5 costliest kernels of one step (torch profiler is not used: HIP events around phases)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from deeplip_amd import autograd as ag, weightgen as wg
+from models.video_models.model import Lipreading
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--frames", type=int, default=29)
+ap.add_argument("--steps", type=int, default=3)
+a = ap.parse_args()
+tcn = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
+net = Lipreading(num_classes=54, relu_type="prelu", tcn_options=tcn, extract_feats=False)
+sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="video.")
+net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+net.cuda().train()
+opt = torch.optim.Adam(net.parameters(), lr=3e-4, weight_decay=1e-4)
+x = torch.from_numpy(wg.video_input(a.batch, frames=a.frames, key="bench.vtrain")).cuda()
+lab = torch.from_numpy(wg.labels(a.batch, 54)).cuda()
+lengths = [a.frames] * a.batch
+
+
+def step():
+    opt.zero_grad()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record()
+    loss = ag.margin_ce_loss(net(x, lengths=lengths), lab)
+    e[1].record()
+    loss.backward()
+    e[2].record()
+    opt.step()
+    e[3].record()
+    return loss, e
+
+
+step()
+tot = [0.0, 0.0, 0.0]
+for _ in range(a.steps):
+    loss, e = step()
+    torch.cuda.synchronize()
+    for i in range(3):
+        tot[i] += e[i].elapsed_time(e[i + 1]) / a.steps
+ms = sum(tot)
+fwd_gflop = (18.337 + 2.230) * a.batch * a.frames / 29.0
+print(f"full Lipreading training step: batch {a.batch} x {a.frames} frames: {ms:.1f} ms/step = {a.batch / ms * 1e3:.1f} clips/s "
+      f"(forward {tot[0]:.1f} ms, backward {tot[1]:.1f} ms, Adam {tot[2]:.1f} ms; ~{3 * fwd_gflop / ms:.1f} TFLOP/s at 3x forward FLOPs); "
+      f"loss {float(loss.detach()):.4f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
