@@ -60,3 +60,32 @@ def test_shard_range_partition():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
+        ps[0].grad = torch.full((3, 5), float(rank + 1))
+        ps[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)      # ps[2] has no gradient (frozen)
+        n = ddist.allreduce_grads(ps)
+        q.put((rank, n, ps[0].grad.numpy(), ps[1].grad.numpy(), ps[2].grad is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_grads_world2():
+    """The data-parallel gradient exchange of train_fusion.py / train_video.py: flat all-reduce, mean over ranks,
+    parameters without a gradient skipped."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(60) for p in procs]
+    for rank, n, g0, g1, none2 in res:
+        assert n == 22 and none2
+        assert np.allclose(g0, 1.5) and np.allclose(g1, np.arange(7) * 1.5)
+    assert ddist.allreduce_grads([torch.nn.Parameter(torch.zeros(2))]) == 0      # not distributed: no-op

@@ -178,15 +178,7 @@ class Trainer(object):
     def _allreduce_grads(self):
         if self.world == 1:
             return
-        params = [p for g in self.optim.param_groups for p in g["params"] if p.grad is not None]
-        flat = torch.cat([p.grad.reshape(-1) for p in params])          # one bucket (3.4 MB): latency-bound
-        dist.all_reduce(flat)
-        flat /= self.world
-        o = 0
-        for p in params:
-            n = p.numel()
-            p.grad.copy_(flat[o:o + n].view_as(p))
-            o += n
+        ddist.allreduce_grads([p for g in self.optim.param_groups for p in g["params"]], self.world)   # one bucket (3.4 MB)
 
     def _train_epoch(self):
         self.model_fusion.train()

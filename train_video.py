@@ -117,20 +117,8 @@ def extract_feats(model, clip_thw, device):
     return model(x, lengths=[x.shape[2]])
 
 
-def _allreduce_grads(params, world):
-    """One flat all-reduce (sum) / world over RCCL: the data-parallel gradient exchange."""
-    import torch.distributed as dist
-    grads = [p.grad for p in params if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat)
-    flat /= world
-    o = 0
-    for g in grads:
-        g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
-
-
 def train(model, args, device):
-    from deeplip_amd import autograd as ag, ops
+    from deeplip_amd import autograd as ag, dist as ddist, ops
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     head = model.tcn.tcn_output
@@ -165,7 +153,7 @@ def train(model, args, device):
             loss = ag.margin_ce_loss(logits, labels, 1.0, 0.0)              # nn.CrossEntropyLoss (:115,143)
             loss.backward()
             if world > 1:
-                _allreduce_grads(params, world)
+                ddist.allreduce_grads(params, world)                        # one flat all-reduce over RCCL
             optimizer.step()
             sched.step()                                                    # per-iteration (:147)
             _, pred = torch.max(torch.softmax(logits.detach(), 1), 1)       # (:145)
