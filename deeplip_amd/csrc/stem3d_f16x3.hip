@@ -10,8 +10,8 @@
 //   * a lane's 8 consecutive k of a step are the 8 taps of ONE kernel row = 8 consecutive window
 //     dwords: four ds_read_b64 (8-B aligned because the pixel stride is 2) + eight v_perm_b32 to
 //     de-interleave hi and lo -- no per-tap address arithmetic;
-//   * the 64 x 288 split weights (host-packed, per-channel power-of-two scale, 16-B row padding so
-//     the 16 lanes of a fragment read hit 16 different bank groups) live in LDS for the whole
+//   * the 64 x 288 split weights (host-packed, per-channel power-of-two scale, hi and lo planes, channel
+//     stride 1184 B so the 16 lanes of every fragment-read group hit 16 different bank quads) live in LDS for the whole
 //     workgroup: B fragments are two ds_read_b128 per 16-channel tile;
 //   * 8 waves = 8 pixel groups (3,3,3,3,3,3,2,2 tiles), each against all 64 channels: one gathered A
 //     fragment feeds 12 MFMAs (an f16 MFMA leaves only half of its 16 cycles for other issue, and the
@@ -44,8 +44,15 @@ constexpr int KROWS = 36;                 // 35 (kt,kh) kernel rows + 1 zero row
 constexpr int STEPS = KROWS / 4;          // 9 k32 steps (4 kernel rows of 8 taps each)
 constexpr int ROWS = 8;                   // output rows per workgroup
 constexpr int PR = 2 * ROWS + 5;          // 21 input rows
-constexpr int WCH_BYTES = KROWS * 32 + 16;  // 1168 B per output channel: [36][hi 16 B | lo 16 B] + pad
-constexpr int WBYTES = 64 * WCH_BYTES;      // 74752
+// Per output channel: [36 kernel rows x 16 B of hi][36 x 16 B of lo] + 32 B pad = 1184 B = 74 sixteen-byte
+// slots.  A B-fragment read (ds_read_b128) is served in 16-lane groups that mix 8 channels at k group q with
+// 8 other channels at k group q + 1: with a channel stride of 74 = 10 (mod 16) slots and a k-group stride of ONE
+// slot (hi and lo in separate planes) the 16 addresses of every group fall into 16 different bank quads.  The
+// first layout ([36][hi | lo] + 16 B: channel stride 9, k-group stride 2 slots) put two pairs of lanes of
+// every group on the same banks -- a third of the kernel's LDS cycles were bank conflicts (PMC).
+constexpr int WLO_OFF = KROWS * 16;         // 576: byte offset of the lo plane inside a channel
+constexpr int WCH_BYTES = KROWS * 32 + 32;  // 1184
+constexpr int WBYTES = 64 * WCH_BYTES;      // 75776
 constexpr int MTW = 3;                    // pixel tiles per wave (each against all 4 channel tiles)
 
 struct StemArgs {
@@ -203,8 +210,8 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
       const int rho = 4 * s + kq;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        bfr[par][2 * nt] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + rho * 32);
-        bfr[par][2 * nt + 1] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + rho * 32 + 16);
+        bfr[par][2 * nt] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + rho * 16);
+        bfr[par][2 * nt + 1] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + WLO_OFF + rho * 16);
       }
     };
     {

@@ -120,8 +120,9 @@ def pack_linear(weight, bias, bn, device, slope=None) -> Packed:
 
 
 def split_stem_weights(w: Tensor):
-    """fp64 [64,1,5,7,7] -> (float32 view of the 64 x 1168-byte LDS image of stem3d_f16x3.hip, scale [64]).
-    Per channel: 36 kernel rows (kt*7+kh, row 35 zero) x [8 hi halves | 8 lo halves] (tap 7 zero) + 16 B pad."""
+    """fp64 [64,1,5,7,7] -> (float32 view of the 64 x 1184-byte LDS image of stem3d_f16x3.hip, scale [64]).
+    Per channel: [36 kernel rows (kt*7+kh, row 35 zero) x 8 hi halves (tap 7 zero)][36 x 8 lo halves] + 32 B pad
+    (hi / lo planes and the 74-slot channel stride keep the kernel's fragment reads bank-conflict free)."""
     K = w.shape[0]
     rows = torch.zeros(K, 36, 8, dtype=torch.float64)
     rows[:, :35, :7] = w.reshape(K, 35, 7)
@@ -130,8 +131,9 @@ def split_stem_weights(w: Tensor):
     ws = rows * scale.view(K, 1, 1)
     hi = ws.to(torch.float16)
     lo = (ws - hi.to(torch.float64)).to(torch.float16)
-    img = torch.zeros(K, 1168 // 2, dtype=torch.float16)
-    img[:, :36 * 16] = torch.cat([hi, lo], dim=2).reshape(K, 36 * 16)
+    img = torch.zeros(K, 1184 // 2, dtype=torch.float16)
+    img[:, :36 * 8] = hi.reshape(K, 36 * 8)
+    img[:, 36 * 8:36 * 16] = lo.reshape(K, 36 * 8)
     return img.contiguous().view(torch.float32).reshape(-1), scale.to(torch.float32)
 
 

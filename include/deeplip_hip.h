@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 10
+#define DLIP_ABI_VERSION 11
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -125,9 +125,9 @@ int dlip_stem3d_bn_act_f32(const float* x, const float* w_k248, const float* bia
                            dlip_stream_t stream);
 
 /* Split-fp16 variant of dlip_stem3d_bn_act_f32 (3 x v_mfma_f32_16x16x32_f16 per product, fp32
- * accumulate; fp32 in / fp32 out).  w_split = 64 x 1168 bytes: per output channel [36 kernel rows
- * (kt*7+kh; row 35 zero)][8 taps (kw; tap 7 zero)] as 8 hi halves then 8 lo halves, + 16 bytes of
- * padding, pre-multiplied by the power of two w_scale[k] (deeplip_amd.packing.pack_stem3d).  W <= 88. */
+ * accumulate; fp32 in / fp32 out).  w_split = 64 x 1184 bytes: per output channel a hi plane [36 kernel
+ * rows (kt*7+kh; row 35 zero)][8 taps (kw; tap 7 zero)] of fp16, then the lo plane of the same shape, + 32
+ * bytes of padding, pre-multiplied by the power of two w_scale[k] (deeplip_amd.packing.pack_stem3d).  W <= 88. */
 int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, const float* w_scale, const float* bias,
                              const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
                              int32_t K, dlip_stream_t stream);
