@@ -96,6 +96,7 @@ struct StreamK {
   float* slabs;      // [2 * G][BM * BN] fp32
   int* counters;     // [tiles], zero between launches (the last arriver resets its tile's word)
   int G;             // workgroups in the grid
+  int whole;         // 1: ranges are cut at tile boundaries (persistent workgroups, no tile is shared)
 #ifdef DLIP_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [G][10] s_memtime values of each workgroup's first segment
 #endif
@@ -186,7 +187,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const int x_dr = a.dh * a.W * a.ldx * 4, x_ds = a.dw * a.ldx * 4;
   const int ntaps = a.R * a.S;
 
-  const long long it_begin = (long long)g * sk.iters / sk.G, it_end = (long long)(g + 1) * sk.iters / sk.G;
+  long long it_begin = (long long)g * sk.iters / sk.G, it_end = (long long)(g + 1) * sk.iters / sk.G;
+  if (sk.whole) {   // whole tiles per workgroup: tiles g T / G .. (g + 1) T / G
+    const long long T = sk.iters / a.nk;
+    it_begin = ((long long)g * T / sk.G) * a.nk;
+    it_end = ((long long)(g + 1) * T / sk.G) * a.nk;
+  }
 #ifdef DLIP_STAMPS
   if (threadIdx.x == 0) sk.stamps[(size_t)g * 10 + 8] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -944,7 +950,12 @@ int launch_dma(const ConvArgs& a, hipStream_t st, bool out_split) {
     const double bal_us = (double)sk.iters / Gb / a.nk * tile_us + kHandoffUs * (BM * BN / 16384.0);
     if ((balanced == 2 || bal_us < plain_us) && Gb * a.nk != sk.iters) G = Gb;
   }
-  if (G != tiles) {
+  sk.whole = 0;
+  if (balanced == 3 && tiles > 4 * sl) {   // experiment: persistent workgroups over whole tiles (no slabs, no tickets)
+    G = sl;
+    sk.whole = 1;
+  }
+  if (G != tiles && !sk.whole) {
     Workspace* w = workspace_for(st, (size_t)2 * G * BM * BN);
     if (w == nullptr) {
       G = tiles;   // no (or too small a) workspace: plain launch
