@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lock = threading.Lock()
 _lib = None
@@ -74,6 +74,7 @@ SIGNATURES = {
     "dlip_znorm_cat_f32": [c_f, c_i32, c_f, c_i32, c_f, c_i32, c_i32, c_stream],
     "dlip_l2_normalize_f32": [c_f, c_f, c_i32, c_i32, C.c_float, c_stream],
     "dlip_pair_cosine_f32": [c_f, c_i32, c_i32, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_i32, c_stream],
+    "dlip_plda_llr_f32": [c_f, c_i32, c_i32, c_f, c_f, c_f, c_f, c_i32, c_stream],
     "dlip_logits_argmax_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_margin_ce_loss_f32": [c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_stream],
     "dlip_lowfer_cat_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],

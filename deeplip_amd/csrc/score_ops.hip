@@ -90,6 +90,33 @@ __global__ __launch_bounds__(256) void pair_cosine_kernel(const float* __restric
   if (lane == 0) score[tr] = accumulate ? score[tr] + weight * c : weight * c;
 }
 
+// Two-covariance PLDA same/different log-likelihood ratio of a trial in the model's latent space (u = the
+// embedding after the model's affine map, unit within-class covariance, between-class variances psi):
+//   llr = sum_d [ log(1 + psi) - log(1 + 2 psi) / 2 + psi (u1 + u2)^2 / (2 (1 + 2 psi)) - psi (u1^2 + u2^2) / (2 (1 + psi)) ]
+// One wave per trial, fp64 accumulation, wavefront-shuffle reduction.
+__global__ __launch_bounds__(256) void plda_llr_kernel(const float* __restrict__ u, int N, int D,
+                                                       const float* __restrict__ psi, const int32_t* __restrict__ ia,
+                                                       const int32_t* __restrict__ ib, float* __restrict__ score,
+                                                       int n_trials) {
+  const int lane = threadIdx.x & 63;
+  const int tr = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (tr >= n_trials) return;
+  const int ra = ia[tr], rb = ib[tr];
+  double acc = 0.0;
+  const bool ok = (unsigned)ra < (unsigned)N && (unsigned)rb < (unsigned)N;
+  if (ok) {
+    const float* pa = u + (long long)ra * D;
+    const float* pb = u + (long long)rb * D;
+    for (int i = lane; i < D; i += 64) {
+      const double p = psi[i], a = pa[i], b = pb[i];
+      acc += log1p(p) - 0.5 * log1p(2.0 * p) + p * (a + b) * (a + b) / (2.0 * (1.0 + 2.0 * p)) -
+             p * (a * a + b * b) / (2.0 * (1.0 + p));
+    }
+  }
+  acc = dlip_wave_sum_f64(acc);
+  if (lane == 0) score[tr] = ok ? (float)acc : __builtin_nanf("");
+}
+
 // One workgroup per embedding row.  wnorm/en: 1/max(norm, 1e-12) as F.normalize (eps 1e-12).
 __global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restrict__ e, const float* __restrict__ W,
                                                             const float* __restrict__ bias,
@@ -209,6 +236,14 @@ extern "C" int dlip_pair_cosine_f32(const float* emb, int32_t N, int32_t D, cons
   hipLaunchKernelGGL(pair_cosine_kernel, dim3((n_trials + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), 0,
                      static_cast<hipStream_t>(stream), emb, N, D, idx_a, idx_b, score, n_trials, mode, eps, weight,
                      accumulate);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_plda_llr_f32(const float* u, int32_t N, int32_t D, const float* psi, const int32_t* idx_a,
+                                const int32_t* idx_b, float* score, int32_t n_trials, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(u && psi && idx_a && idx_b && score && N > 0 && D > 0 && n_trials > 0);
+  hipLaunchKernelGGL(plda_llr_kernel, dim3((n_trials + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), u, N, D, psi, idx_a, idx_b, score, n_trials);
   return dlip_launch_status();
 }
 

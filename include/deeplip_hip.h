@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 11
+#define DLIP_ABI_VERSION 12
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -201,6 +201,14 @@ int dlip_znorm_cat_f32(const float* a, int32_t Da, const float* v, int32_t Dv, f
 /* y[u,:] = x[u,:] / max(||x[u,:]||_2, eps)   (F.normalize; loss.py:44, train_audio.py:355). */
 int dlip_l2_normalize_f32(const float* x, float* y, int32_t U, int32_t D, float eps,
                           dlip_stream_t stream);
+
+/* PLDA trial scoring (eer_plda_lomgrid / eer_plda_grid, models/fusion_models/utils.py:285-329: the `plda`
+ * package's model.transform(..., 'D' -> 'U_model') followed by calc_same_diff_log_likelihood_ratio per trial).
+ * u [N,D] = the embeddings already mapped to the model's latent space (an affine map: one dlip_conv_nhwc_f32
+ * GEMM, deeplip_amd/plda.py), psi [D] = the between-class variances there (within-class covariance = I):
+ * score[i] = log p(u_a, u_b | same speaker) - log p(u_a) - log p(u_b). */
+int dlip_plda_llr_f32(const float* u, int32_t N, int32_t D, const float* psi, const int32_t* idx_a,
+                      const int32_t* idx_b, float* score, int32_t n_trials, dlip_stream_t stream);
 
 /* Trial scoring over an [N,D] embedding table: score[i] = cos(emb[idx_a[i]], emb[idx_b[i]]).
  * mode 0: sklearn cosine_similarity semantics (normalise each row, then dot; utils.py:244,262)

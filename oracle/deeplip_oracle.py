@@ -364,6 +364,21 @@ def feature_fusion_scores(audio_emb: np.ndarray, video_emb: np.ndarray, idx_a, i
     return sklearn_cosine_rowwise(fuse(idx_a), fuse(idx_b))
 
 
+def plda_llr_bruteforce(u1: np.ndarray, u2: np.ndarray, psi: np.ndarray) -> float:
+    """Same/different log-likelihood ratio of one trial in a PLDA model's latent space, computed the long way
+    round: explicit Gaussian densities of the stacked pair (models/fusion_models/utils.py:300-304 calls the
+    un-vendored `plda` package's calc_same_diff_log_likelihood_ratio -- parity unpinned; the model is
+    u = v + e, v ~ N(0, diag(psi)), e ~ N(0, I), same speaker = shared v).  fp64."""
+    from scipy.stats import multivariate_normal as mvn
+    u1, u2, psi = (np.asarray(a, dtype=np.float64) for a in (u1, u2, psi))
+    tot = 0.0
+    for d in range(len(psi)):
+        cov_same = np.array([[1.0 + psi[d], psi[d]], [psi[d], 1.0 + psi[d]]])
+        tot += mvn.logpdf([u1[d], u2[d]], mean=[0.0, 0.0], cov=cov_same)
+        tot -= mvn.logpdf(u1[d], mean=0.0, cov=1.0 + psi[d]) + mvn.logpdf(u2[d], mean=0.0, cov=1.0 + psi[d])
+    return float(tot)
+
+
 def eer(y_true: Sequence[int], y_pred: Sequence[float]) -> Tuple[float, float]:
     """utils.py:263-266: roc_curve(y_true, y_pred, pos_label=1); eer = brentq(1-x-interp1d(fpr,tpr)(x),
     0, 1); threshold = interp1d(fpr, thresholds)(eer).  Third-party calls kept verbatim."""

@@ -117,3 +117,42 @@ def test_embedding_store_npy_tree_roundtrip(tmp_path):
     grouped = scoring.EmbeddingTable.load_npy_tree(str(tmp_path / "em"), ["u1", "u2"],
                                                    groups={"u1": ["s1/a.wav", "s1/b.wav"], "u2": ["s2/c.wav"]})
     assert torch.allclose(grouped.emb[0], (emb[0] + emb[1]) / 2) and torch.equal(grouped.emb[1], emb[2])
+
+
+def test_plda_fit_and_latent_space_properties():
+    """Host side of the PLDA back-end (the `plda` package's algorithm, parity unpinned): in the
+    fitted latent space the within-class covariance is ~I and the between-class covariance ~diag(psi); the affine
+    map (with and without the PCA front) reproduces transform; dims are ordered by decreasing psi."""
+    from deeplip_amd.plda import PLDA
+    r = np.random.default_rng(3)
+    K, n, D = 40, 30, 16
+    centers = r.normal(size=(K, D)) * np.linspace(3.0, 0.2, D)
+    X = np.concatenate([c + r.normal(size=(n, D)) * 0.7 for c in centers])
+    y = np.repeat(np.arange(K), n)
+    mixing = r.normal(size=(D, D))
+    X = X @ mixing
+    m = PLDA.fit(X, y)
+    U = m.transform_np(X)
+    within = np.concatenate([U[y == k] - U[y == k].mean(0) for k in range(K)])
+    cw = within.T @ within / (len(within) - K)
+    assert np.abs(cw - np.eye(cw.shape[0])).max() < 0.05
+    means = np.stack([U[y == k].mean(0) for k in range(K)])
+    psi = m.psi[m.relevant]
+    assert np.all(np.diff(psi) <= 1e-12) and psi[0] > 5 * psi[-1]
+    assert np.allclose(np.var(means, axis=0), psi + 1.0 / n, rtol=0.35)
+    m2 = PLDA.fit(X, y, n_principal_components=8)
+    assert m2.transform_np(X).shape[1] <= 8
+    Wt, b = m2.affine()
+    assert np.allclose(X[:5] @ Wt.T + b, m2.transform_np(X[:5]))
+
+
+def test_plda_closed_form_matches_bruteforce_density():
+    """The closed-form per-dimension LLR the kernel implements vs explicit Gaussian densities of the pair."""
+    from oracle import deeplip_oracle as O
+    r = np.random.default_rng(5)
+    psi = np.abs(r.normal(size=12)) * 3 + 0.01
+    for _ in range(5):
+        u1, u2 = r.normal(size=12) * 1.5, r.normal(size=12) * 1.5
+        closed = np.sum(np.log1p(psi) - 0.5 * np.log1p(2 * psi) + psi * (u1 + u2) ** 2 / (2 * (1 + 2 * psi))
+                        - psi * (u1 ** 2 + u2 ** 2) / (2 * (1 + psi)))
+        assert abs(closed - O.plda_llr_bruteforce(u1, u2, psi)) < 1e-9 * max(1.0, abs(closed))
