@@ -328,6 +328,8 @@ int launch(const ConvArgs& a, hipStream_t st, int flags) {
 }  // namespace
 
 extern "C" int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int out_split);   // conv_igemm_f16x3_dma.hip
+extern "C" int dlip_conv_wres_ok(const void* args);                                          // conv_wres_f16x3.hip
+extern "C" int dlip_conv_f16x3_wres_launch(const void* args, void* stream, int out_split);
 
 // Development switch (A/B runs): DLIP_CONV_DMA=0 keeps split-format launches on the register-staged kernel.
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_dma_enabled(void) {
@@ -357,7 +359,13 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   const bool dma_ok = (flags & 2) ? (reinterpret_cast<uintptr_t>(y) & 15) == 0
                                   : ((d->K & 3) == 0 && (d->ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0);
   const bool res_ok = residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
-  if ((flags & 1) && dma_ok && res_ok && dlip_conv_dma_enabled()) return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) != 0);
+  if ((flags & 1) && dma_ok && res_ok && dlip_conv_dma_enabled()) {
+    // 64 -> 64 channel layers (layer1): filter bank resident in LDS, barrier-free waves (conv_wres_f16x3.hip) --
+    // an experiment that lost to the ring kernel (370 vs 328 us): off unless DLIP_CONV_WRES asks for it
+    if (dlip_conv_wres_ok(&a) && (residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 7) == 0))
+      return dlip_conv_f16x3_wres_launch(&a, stream, (flags & 2) != 0);
+    return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) != 0);
+  }
   switch (pick_tile(a.M, d->K, kEffF16x3)) {
     case 0: return launch<128, 128, 2, 2>(a, st, flags);
     case 1: return launch<128, 64, 2, 2>(a, st, flags);

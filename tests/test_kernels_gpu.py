@@ -586,3 +586,38 @@ def test_plda_scoring_kernel_and_eer(ops, tmp_path):
     p.write_text("".join(f"{l} {a} {b}\n" for l, (a, b) in zip(labs, pairs)))
     eer, _ = eer_plda(table, str(p), model)
     assert 0.0 <= eer < 0.2
+
+
+@pytest.mark.parametrize("case", [(3, 22, 22, 64, 64, 3, 3, 1, 1, 1, True, True), (260, 22, 22, 64, 64, 3, 3, 1, 1, 1, True, True),
+                                  (7, 9, 13, 64, 64, 3, 3, 1, 1, 1, False, True), (2, 1, 70, 64, 64, 1, 5, 1, 4, 2, True, False),
+                                  (5, 11, 11, 64, 64, 1, 1, 1, 0, 1, False, True)],
+                         ids=lambda c: "x".join(str(v) for v in c[:10]))
+@pytest.mark.parametrize("out_split", [True, False])
+def test_conv_weights_resident_kernel(ops, case, out_split, monkeypatch):
+    """The experimental 64 -> 64 channel kernel with the filter bank resident in LDS (conv_wres_f16x3.hip; off by
+    default: slower than the ring kernel), forced on whatever the size (DLIP_CONV_WRES=2): same result as the fp32-format kernel, residual / slope / ragged
+    M tail / 1-D dilated taps included; switched off it gives the ring kernel's result (the two differ only by the
+    fp32 summation order)."""
+    from deeplip_amd import packing
+    N, H, W, C, K, R, S, stride, pad, dil, use_res, use_slope = case
+    x = _split_ref_value(rnd(N, H, W, C, seed=1) * 3.0)
+    w = rnd(K, R, S, C, seed=2, scale=1.0 / np.sqrt(C * R * S))
+    b = rnd(K, seed=3, scale=0.1)
+    ph, pw = (0, pad) if H == 1 else (pad, pad)
+    dh, dw = (1, dil) if H == 1 else (dil, dil)
+    ws, sc = packing.split_weights(w.double())
+    slope = (torch.rand(K, generator=torch.Generator().manual_seed(5)) * 0.3).cuda() if use_slope else None
+    kw = dict(pad=(ph, pw), dil=(dh, dw), slope=slope, w_scale=sc.cuda())
+    xd = x.cuda()
+    base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), **kw)
+    res = _split_ref_value(rnd(*base.shape, seed=4)).cuda() if use_res else None
+    base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), residual=res, **kw)
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("DLIP_CONV_WRES", mode)
+        y = ops.conv_nhwc(ops.split_pack(xd), ws.cuda(), b.cuda(), residual=ops.split_pack(res) if res is not None else None,
+                          x_split=True, out_split=out_split, **kw)
+        outs[mode] = ops.split_unpack(y) if out_split else y
+        torch.cuda.synchronize()
+        assert rel_err(outs[mode].cpu().numpy(), base.cpu().numpy()) < 2e-6, mode
+    assert rel_err(outs["2"].cpu().numpy(), outs["0"].cpu().numpy()) < 2e-6
