@@ -126,6 +126,33 @@ class MarginCELossFn(Function):
         return g, None, None, None
 
 
+class AAMMarginFn(Function):
+    """cos(theta) -> cos(theta + m) on the target column of cosine logits (ArcFace / AAM-softmax)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, margin, easy):
+        logits = logits.contiguous()
+        ctx.save_for_backward(logits, labels)
+        ctx.cfg = (float(margin), int(easy))
+        y = torch.empty_like(logits)
+        check(lib().dlip_aam_margin_f32(ptr(logits), ptr(labels), None, ptr(y), logits.shape[0], logits.shape[1], float(margin),
+                                        int(easy), 0, stream_handle()), "dlip_aam_margin_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        logits, labels = ctx.saved_tensors
+        margin, easy = ctx.cfg
+        g = torch.empty_like(logits)
+        check(lib().dlip_aam_margin_f32(ptr(logits), ptr(labels), ptr(dy.contiguous()), ptr(g), logits.shape[0], logits.shape[1],
+                                        margin, easy, 1, stream_handle()), "dlip_aam_margin_f32")
+        return g, None, None, None
+
+
+def aam_margin(logits, labels, margin, easy=False):
+    return AAMMarginFn.apply(logits, labels.contiguous(), margin, easy)
+
+
 def linear(x, w, b=None):
     return LinearFn.apply(x, w, b)
 

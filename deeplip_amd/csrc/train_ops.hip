@@ -133,6 +133,39 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 
 }  // namespace
 
+// Additive angular margin (ArcFace / AAM-softmax; the reference leaves `AAMSoftmax` an empty stub, loss.py:62-67,
+// and the north star names it): on the target column of cosine logits, cos(theta) -> cos(theta + m) where
+// theta + m stays below pi (cos > th = cos(pi - m)), else the CosFace-style fallback cos - m sin(m) (the usual
+// ArcFace recipe; easy_margin: apply only where cos > 0).  mode 0: y = modified logits; mode 1 (backward):
+// y = dL/dlogits given g = dL/dy, i.e. g scaled by d cos(theta + m)/d cos(theta) = cos m + sin m cos/sqrt(1 - cos^2)
+// on the target column.
+__global__ __launch_bounds__(256) void aam_margin_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                         const float* __restrict__ g, float* __restrict__ y, int B, int K,
+                                                         float cos_m, float sin_m, float th, float mm, int easy, int mode) {
+  const long long n = (long long)B * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / K), k = (int)(i - (long long)b * K);
+    const float c = logits[i];
+    const bool tgt = labels[b] == k;
+    if (mode == 0) {
+      float v = c;
+      if (tgt) {
+        const float sine = sqrtf(fmaxf(0.f, 1.f - c * c));
+        const float phi = c * cos_m - sine * sin_m;
+        v = easy ? (c > 0.f ? phi : c) : (c > th ? phi : c - mm);
+      }
+      y[i] = v;
+    } else {
+      float d = 1.f;
+      if (tgt) {
+        const bool use_phi = easy ? c > 0.f : c > th;
+        if (use_phi) d = cos_m + sin_m * c / sqrtf(fmaxf(1e-12f, 1.f - c * c));
+      }
+      y[i] = g[i] * d;
+    }
+  }
+}
+
 extern "C" int dlip_bn1d_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                                        float* save_mean, float* save_invstd, float* running_mean,
                                        float* running_var, int32_t M, int32_t C, float momentum, float eps,
@@ -228,5 +261,17 @@ extern "C" int dlip_gemm_small_f32(const float* A, const float* B, float* C, int
   DLIP_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
   hipLaunchKernelGGL(gemm_small_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0,
                      static_cast<hipStream_t>(stream), A, B, C, M, N, K, trans_a, trans_b);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_aam_margin_f32(const float* logits, const int64_t* labels, const float* g, float* y, int32_t B, int32_t K,
+                                   float margin, int32_t easy_margin, int32_t backward, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(logits && labels && y && B > 0 && K > 0 && (!backward || g));
+  const float cm = cosf(margin), sm = sinf(margin);
+  const float th = cosf(3.14159265358979323846f - margin), mm = sinf(3.14159265358979323846f - margin) * margin;
+  long long blocks = ((long long)B * K + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(aam_margin_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
+                     reinterpret_cast<const long long*>(labels), g, y, B, K, cm, sm, th, mm, easy_margin, backward);
   return dlip_launch_status();
 }

@@ -48,6 +48,41 @@ class LMCL(nn.Module):
         return loss, logits
 
 
+class AAMSoftmax(nn.Module):
+    """Additive angular margin softmax (ArcFace).  Upstream `AAMSoftmax` is an empty TODO stub (loss.py:62-67) that
+    the north star nevertheless names, so this is the published recipe (parity unpinned) behind the interface of
+    the reference's LMCL: ``forward(embeddings, labels) -> (loss, cosine logits)``.
+    loss = CE(s * [cos(theta_y + m) on the target, cos(theta_j) elsewhere]); cos(theta + m) where theta + m < pi,
+    else cos(theta) - m sin(pi - m); ``easy_margin`` applies the margin only where cos(theta) > 0."""
+
+    def __init__(self, embedding_size, num_classes, s=30.0, margin=0.2, easy_margin=False):
+        super().__init__()
+        self.embedding_size, self.num_classes = embedding_size, num_classes
+        self.s, self.margin, self.easy_margin = s, margin, easy_margin
+        self.weights = nn.Parameter(torch.Tensor(num_classes, embedding_size))
+        nn.init.kaiming_normal_(self.weights)
+
+    def predict(self, embeddings, labels=None):
+        from . import autograd as ag
+        w = self.weights.detach().contiguous()
+        logits, amax = ops.logits_argmax(embeddings.detach().contiguous(), w, cosine=True)
+        loss = None
+        if labels is not None:
+            with torch.no_grad():
+                loss = ops.margin_ce_loss(ag.aam_margin(logits, labels, self.margin, self.easy_margin), labels.contiguous(),
+                                          float(self.s), 0.0)
+        return loss, logits, amax
+
+    def forward(self, embeddings, labels):
+        if torch.is_grad_enabled() and (self.weights.requires_grad or embeddings.requires_grad):
+            from . import autograd as ag
+            logits = ag.linear(ag.l2_normalize(embeddings), ag.l2_normalize(self.weights))
+            loss = ag.margin_ce_loss(ag.aam_margin(logits, labels, self.margin, self.easy_margin), labels, self.s, 0.0)
+            return loss, logits
+        loss, logits, _ = self.predict(embeddings, labels)
+        return loss, logits
+
+
 class CrossEntropy(nn.Module):
     """loss.py:6-16: Linear + CE(logits + 1e-8)."""
 
@@ -79,10 +114,6 @@ class _Stub(nn.Module):
 
 
 class ASoftmax(_Stub):
-    pass
-
-
-class AAMSoftmax(_Stub):
     pass
 
 

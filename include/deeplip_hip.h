@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 12
+#define DLIP_ABI_VERSION 13
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -337,6 +337,14 @@ int dlip_split_pack_scaled_f32(const float* x, float* y, const float* scale, int
                                dlip_stream_t stream);
 /* y[0:n] = src[0] (device scalar broadcast: the per-channel 1/scale vector of the weight-gradient GEMM). */
 int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream_t stream);
+
+/* Additive angular margin on cosine logits (ArcFace / AAM-softmax: named by the north star; `AAMSoftmax` is an
+ * empty stub upstream, models/audio_models/loss.py:62-67 -- parity unpinned, the published recipe is restated):
+ * backward == 0: y = logits with the target column cos(theta) replaced by cos(theta + margin) (where cos > cos(pi - m),
+ * else cos - m sin(pi - m); easy_margin: only where cos > 0); backward != 0: y = g * d(modified)/d(logits).
+ * logits, g, y [B,K]; labels int64 [B]. */
+int dlip_aam_margin_f32(const float* logits, const int64_t* labels, const float* g, float* y, int32_t B, int32_t K,
+                        float margin, int32_t easy_margin, int32_t backward, dlip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Train-mode kernels of the lip-clip encoder (deeplip_amd/csrc/video_train_ops.hip):

@@ -262,6 +262,36 @@ def speaker_forward(sd: SD, x: Tensor, context, bn_first: bool = True, pooling: 
 # ----------------------------------------------------------------------------------------
 # Criteria: models/audio_models/loss.py:6-51
 # ----------------------------------------------------------------------------------------
+def audio_resnet_embedding(sd: SD, x: Tensor, hidden: Sequence[int] = (64, 128, 256), layers: Sequence[int] = (3, 3, 3)) -> Tensor:
+    """The build-owned ResNet speech encoder of ``arch: resnet`` (conf/audio_config.yaml:93-102; no source ships
+    upstream -- deeplip_amd/audio_resnet.py states the architecture): conv3x3 - BN - ReLU, stages of BasicBlocks
+    (resnet-style, stride 2 from the second stage on, 1x1 conv + BN shortcuts), global average pooling, Linear.
+    x [B,1,F,T] -> [B,E].  Honours bn_training()."""
+    y = F.relu(_bn(F.conv2d(x, sd["conv1.weight"], None, padding=1), sd, "bn1"))
+    for i, n in enumerate(layers):
+        for j in range(n):
+            y = basic_block(sd, f"layers.{i}.{j}", y, 2 if (i > 0 and j == 0) else 1, "relu")
+    y = F.adaptive_avg_pool2d(y, 1).flatten(1)
+    return F.linear(y, sd["fc.weight"], sd["fc.bias"])
+
+
+def aam_softmax(emb: Tensor, labels: Tensor, weights: Tensor, s: float, margin: float, easy_margin: bool = False) -> Tuple[Tensor, Tensor]:
+    """ArcFace / AAM-softmax as published (the reference's AAMSoftmax is an empty stub, loss.py:62-67):
+    cosine logits, cos(theta_y + m) on the target (fallback cos - m sin(pi - m) where theta + m >= pi), CE at scale s.
+    -> (loss, cosine logits)."""
+    import math
+    logits = F.linear(F.normalize(emb), F.normalize(weights))
+    sine = torch.sqrt(torch.clamp(1.0 - logits * logits, min=0.0))
+    phi = logits * math.cos(margin) - sine * math.sin(margin)
+    if easy_margin:
+        phi = torch.where(logits > 0, phi, logits)
+    else:
+        phi = torch.where(logits > math.cos(math.pi - margin), phi, logits - math.sin(math.pi - margin) * margin)
+    onehot = F.one_hot(labels, logits.shape[1]).bool()
+    out = torch.where(onehot, phi, logits)
+    return F.cross_entropy(s * out, labels), logits
+
+
 def lmcl(emb: Tensor, labels: Tensor, weights: Tensor, s: float, margin: float) -> Tuple[Tensor, Tensor]:
     """LMCL.forward (loss.py:43-51): cosine logits; margin only at the label column;
     CE(s*(cos - m*onehot) + 1e-8) + 1e-5*||W||_1; returns the UN-margined cosine logits."""

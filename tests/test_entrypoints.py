@@ -72,3 +72,23 @@ def test_train_audio_frozen_encoder(tmp_path, monkeypatch):
     tr._train()
     assert torch.equal(w0, tr.model.tdnn[0].context_layer.weight.detach())      # encoder untouched
     assert not torch.equal(c0, tr.criterion.weights.detach())                     # criterion trained
+
+
+@pytest.mark.gpu
+def test_train_audio_resnet_arch_with_aam_softmax(tmp_path, monkeypatch):
+    """`arch: resnet` (config-only upstream, train_audio.py:64-66) + the AAM-softmax criterion: full-encoder training
+    step on [B,1,F,T] features, then extraction and cosine EER."""
+    import train_audio
+    monkeypatch.chdir(tmp_path)
+    tr = train_audio.Trainer(overrides={"model.arch": "resnet", "train.loss": "AAMSoftmax", "data.feat_dim": 24,
+                                        "data.test_speakers": 3, "data.test_utt_per_spk": 2, "data.trials": 30,
+                                        "data.trial_targets": 6, "data.audio_frames": 60, "data.n_spk": 5,
+                                        "data.utt_per_spk": 2, "train.bs": 4, "train.epoch": 1})
+    w0 = tr.model.conv1.weight.detach().clone()
+    tr._train()
+    assert not torch.equal(w0, tr.model.conv1.weight.detach()) and int(tr.model.bn1.num_batches_tracked) == 2
+    assert np.isfinite(tr.last_epoch_stats["loss"])
+    table = tr.extract_test_xv()
+    assert table.emb.shape == (6, 256)
+    eer, _ = tr.eer()
+    assert 0 <= eer <= 1

@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 from deeplip_amd import ops, scoring, weightgen as wg  # noqa: E402
 from deeplip_amd.synthetic import SyntheticAVSet, synthetic_trials  # noqa: E402
 from models.audio_models import tdnn  # noqa: E402
-from models.audio_models.loss import LMCL, CrossEntropy  # noqa: E402
+from models.audio_models.loss import AAMSoftmax, LMCL, CrossEntropy  # noqa: E402
 
 
 class Trainer(object):
@@ -47,11 +47,16 @@ class Trainer(object):
             raise RuntimeError("train_audio.py needs a ROCm GPU: the deeplip_amd engine has no CPU path")
         self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
         arch = self.model_opts["arch"]
-        if arch not in ("tdnn", "etdnn"):
+        if arch in ("tdnn", "etdnn"):
+            self.model = tdnn.SpeakerEmbNet(self.model_opts)
+        elif arch == "resnet":                                               # train_audio.py:64-66 (`import models.resnet`)
+            import models.resnet as resnet
+            self.model = resnet.SpeakerEmbNet(self.model_opts)
+        else:
             raise NotImplementedError("Other models are not implemented!")   # train_audio.py:67-68
-        self.model = tdnn.SpeakerEmbNet(self.model_opts)
         d = self.data_opts
-        F_ = self.model_opts[arch]["input_dim"]
+        # the resnet takes [B,1,F,T] with F = the feature dimension of the data section (train_audio.py:183-184)
+        F_ = self.model_opts[arch]["input_dim"] if arch != "resnet" else int(d.get("feat_dim", 40))
         self.trainset = SyntheticAVSet(d["n_spk"], d["utt_per_spk"], 0, 1, F_, d["audio_frames"], key="atrain")
         self.voxtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="atest")
         sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in self.model.state_dict().items()}, prefix="audio.")
@@ -61,6 +66,9 @@ class Trainer(object):
         if self.train_opts["loss"] == "LMCL":
             self.init_margin, self.end_margin = self.train_opts["margin"]
             self.criterion = LMCL(E, d["n_spk"], self.train_opts["scale"], self.init_margin).to(self.device)
+        elif self.train_opts["loss"] == "AAMSoftmax":                       # a stub upstream (loss.py:62-67); ArcFace here
+            self.init_margin, self.end_margin = self.train_opts["margin"]
+            self.criterion = AAMSoftmax(E, d["n_spk"], self.train_opts["scale"], self.init_margin).to(self.device)
         else:
             self.criterion = CrossEntropy(E, d["n_spk"]).to(self.device)
         o = self.train_opts["sgd"]
@@ -73,7 +81,7 @@ class Trainer(object):
         self.log_time = time.asctime(time.localtime(time.time())).replace(" ", "_")[4:]
 
     def _adjust_margin(self):
-        if isinstance(self.criterion, LMCL):
+        if isinstance(self.criterion, (LMCL, AAMSoftmax)):
             self.criterion.margin = self.init_margin if self.current_epoch <= 5 else self.end_margin
 
     def _train_epoch(self):
