@@ -79,7 +79,6 @@ __global__ __launch_bounds__(512, 1) void conv_wres_f16x3_kernel(const ConvArgs 
   }
   __syncthreads();
 
-  const __amdgpu_buffer_rsrc_t xr = dlip_make_rsrc(a.x, a.x_bytes);
   const __amdgpu_buffer_rsrc_t rr = dlip_make_rsrc(a.res, a.res ? a.r_bytes : 0u);
   const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
   const int px = lane & 15, kg = lane >> 4;
