@@ -11,8 +11,8 @@ import torch
 from deeplip_amd import weightgen as wg
 from models.audio_models.loss import LMCL
 from models.audio_models.tdnn import SpeakerEmbNet
-from oracle.deeplip_oracle import ETDNN_CONTEXT
 
+ETDNN_CONTEXT = [[-2, -1, 0, 1, 2], [0], [-2, 0, 2], [0], [-3, 0, 3], [0], [-4, 0, 4], [0], [0], [0]]   # conf/audio_config.yaml
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--dim", type=int, default=24)
