@@ -109,6 +109,21 @@ def build_models(device, audio_dim):
 AUDIO_STREAM = None   # --audio-stream: the speech encoder runs on a second HIP stream beside the lip-clip encoder
 
 
+def local_step(video, audio, xv, xa):
+    """The per-rank part of a step: launches only (what a StepPlan records)."""
+    from deeplip_amd import fusion
+    return fusion.fuse_av(audio.extract_embedding(xa)[0], video.embed(xv))
+
+
+def exchange(fused, world):
+    """The enrol/verify exchange: every rank gets every rank's fused rows (RCCL all-gather over xGMI)."""
+    if world == 1:
+        return fused
+    out = torch.empty((world * fused.shape[0], fused.shape[1]), device=fused.device, dtype=fused.dtype)
+    dist.all_gather_into_tensor(out, fused)
+    return out
+
+
 def step(video, audio, xv, xa, world):
     from deeplip_amd import fusion
     if AUDIO_STREAM is not None:
@@ -193,6 +208,9 @@ def main():
                     help="run the speech encoder on a second HIP stream beside the lip-clip encoder (kernel tails overlap; "
                          "per-kernel event durations then include the time shared with the other stream)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--eager", action="store_true",
+                    help="issue every launch of every step from Python (round-1 behaviour) instead of replaying a recorded "
+                         "step plan (dlip_plan_run); for A/B runs on one box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,6 +228,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     from deeplip_amd import fusion, ops, packing, weightgen as wg
+    from deeplip_amd.plan import StepPlan
     if args.audio_stream:
         global AUDIO_STREAM
         AUDIO_STREAM = torch.cuda.Stream(device=device)
@@ -225,60 +244,91 @@ def main():
         torch.cuda.synchronize()
 
     def measure(precision):
-        """W warm-up + K timed steps in one arithmetic mode -> (result fields, models, state dicts)."""
+        """W warm-up + K timed steps in one arithmetic mode -> (result fields, models, state dicts).
+        The steady-state loop replays a recorded step plan (one dlip_plan_run per step; --eager issues the
+        launches from Python instead) and runs the all-gather exchange after it when N > 1."""
         packing.set_precision(precision)
         video, audio, sds = build_models(device, args.audio_dim)
         hook = EventHook()
-        ops.LAUNCH_HOOK = None if args.no_kernel_events else hook
-        for _ in range(args.warmup):
-            step(video, audio, xv, xa, world)
-        if not hook.flops:                      # --warmup 0: one untimed step to learn the kernel mix
-            step(video, audio, xv, xa, world)
-        sync_all()
-        # inside the timed region only the dominant kernel instance (most algorithmic FLOPs) is bracketed
-        hook.only = max(hook.flops.items(), key=lambda kv: kv[1])[0] if hook.flops else None
-        hook.enabled = True
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(args.steps):
-            step(video, audio, xv, xa, world)
-        ev1.record()
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        hook.enabled = False
-        gpu_ms = ev0.elapsed_time(ev1)
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        value = world * B * args.steps / elapsed
-        # roofline of the mode: exact fp32 MFMA peak, or the f16 dense peak / 3 (three f16 MFMAs
-        # per fp32-grade product: the ceiling of the split algorithm in ALGORITHMIC FLOP/s)
-        peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
-        step_tf = value / world * GFLOP_PER_FUSED_CLIP / 1e3
-        roof = {"bound": "mfma", "achieved": None, "peak": round(peak, 1), "unit": "TFLOP/s", "frac": None,
-                "traffic": None, "step_achieved": round(step_tf, 2), "step_frac": round(step_tf / peak, 4)}
-        if precision != "f32":
-            roof["peak_note"] = ("algorithmic (2*M*N*K) FLOP/s ceiling of the split-fp16 scheme = 2500 TFLOP/s dense f16 MFMA / 3 "
-                                 "MFMAs per product (conv / linear layers and the stem)")
-        if not args.no_kernel_events and hook.only is not None:
-            name, a = hook.only, hook.summary()[hook.only]
-            tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
-            roof.update({"achieved": round(tf, 2), "frac": round(tf / peak, 4), "kernel": name,
-                         "launches_per_step": a["launches"] // args.steps,
-                         "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
-                         "gflop_per_launch": round(a["flops"] / a["launches"] / 1e9, 3)})
-            # per-instance breakdown of a step: 3 extra, untimed steps with every MFMA launch bracketed
-            hook.records, hook.only, hook.enabled = [], None, True
-            for _ in range(3):
-                step(video, audio, xv, xa, world)
+        ops.LAUNCH_HOOK = hook                  # events off: tallies the algorithmic FLOPs per kernel instance
+        run_stream = torch.cuda.Stream(device=device)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(run_stream):
+            exchange(local_step(video, audio, xv, xa), world)     # one eager step: kernel mix, packing, workspaces
             sync_all()
+            dominant = max(hook.flops.items(), key=lambda kv: kv[1])[0] if hook.flops else None
+            plan = None
+            if args.eager:
+                run_step = lambda: step(video, audio, xv, xa, world)
+                if not args.no_kernel_events:   # eager: the dominant instance is bracketed inside the timed region
+                    hook.only, hook.enabled = dominant, True
+            else:
+                ops.LAUNCH_HOOK = None
+                plan = StepPlan(lambda v, a: local_step(video, audio, v, a), xv, xa, stream=run_stream)
+                run_step = lambda: exchange(plan.run(), world)
+            for _ in range(args.warmup):
+                run_step()
+            sync_all()
+            hook.records = []
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record()
+            for _ in range(args.steps):
+                run_step()
+            ev1.record()
+            sync_all()
+            elapsed = time.perf_counter() - t0
             hook.enabled = False
-            roof["kernels"] = {k: {"launches_per_step": v["launches"] // 3, "ms_per_step": round(v["ms"] / 3, 4),
-                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                               for k, v in sorted(hook.summary().items())}
-            roof["kernels_note"] = "3 untimed steps after the timed region, every MFMA launch bracketed by HIP events"
+            gpu_ms = ev0.elapsed_time(ev1)
+            tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            value = world * B * args.steps / elapsed
+            # roofline of the mode: exact fp32 MFMA peak, or the f16 dense peak / 3 (three f16 MFMAs
+            # per fp32-grade product: the ceiling of the split algorithm in ALGORITHMIC FLOP/s)
+            peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
+            step_tf = value / world * GFLOP_PER_FUSED_CLIP / 1e3
+            roof = {"bound": "mfma", "achieved": None, "peak": round(peak, 1), "unit": "TFLOP/s", "frac": None,
+                    "traffic": None, "step_achieved": round(step_tf, 2), "step_frac": round(step_tf / peak, 4)}
+            if precision != "f32":
+                roof["peak_note"] = ("algorithmic (2*M*N*K) FLOP/s ceiling of the split-fp16 scheme = 2500 TFLOP/s dense f16 MFMA / 3 "
+                                     "MFMAs per product (conv / linear layers and the stem)")
+            if not args.no_kernel_events and dominant is not None:
+                ops.LAUNCH_HOOK = hook
+                if plan is not None:
+                    # A replayed plan has no per-launch host hook: the same launches are issued eagerly for K more
+                    # steps right behind the timed region, the dominant instance bracketed by HIP events on the
+                    # launch stream (its duration does not depend on how the launch was issued; the committed
+                    # rocprofv3 kernel trace of this command, which sees the replayed launches, is the cross-check).
+                    hook.records, hook.only, hook.enabled = [], dominant, True
+                    for _ in range(args.steps):
+                        local_step(video, audio, xv, xa)
+                    sync_all()
+                    hook.enabled = False
+                    roof["events_region"] = f"{args.steps} eagerly issued steps directly after the timed plan-replay region"
+                else:
+                    roof["events_region"] = "inside the timed region"
+                name, a = dominant, hook.summary()[dominant]
+                tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                roof.update({"achieved": round(tf, 2), "frac": round(tf / peak, 4), "kernel": name,
+                             "launches_per_step": a["launches"] // args.steps,
+                             "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2),
+                             "gflop_per_launch": round(a["flops"] / a["launches"] / 1e9, 3)})
+                # per-instance breakdown of a step: 3 extra, untimed steps with every MFMA launch bracketed
+                hook.records, hook.only, hook.enabled = [], None, True
+                for _ in range(3):
+                    local_step(video, audio, xv, xa)
+                sync_all()
+                hook.enabled = False
+                roof["kernels"] = {k: {"launches_per_step": v["launches"] // 3, "ms_per_step": round(v["ms"] / 3, 4),
+                                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                   for k, v in sorted(hook.summary().items())}
+                roof["kernels_ms_sum"] = round(sum(v["ms_per_step"] for v in roof["kernels"].values()), 4)
+                roof["kernels_note"] = "3 untimed eager steps after the timed region, every MFMA launch bracketed by HIP events"
+            if plan is not None:
+                roof["plan_launches"] = plan.launches
+                plan.close()
         ops.LAUNCH_HOOK = None
         try:  # HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))

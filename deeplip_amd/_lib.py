@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lock = threading.Lock()
 _lib = None
@@ -59,6 +59,11 @@ SIGNATURES = {
     "dlip_split_pack_f32": [c_f, c_f, C.c_int64, c_i32, c_stream],
     "dlip_split_unpack_f32": [c_f, c_f, C.c_int64, c_i32, c_stream],
     "dlip_conv_plan": [C.POINTER(ConvDesc), c_i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "dlip_plan_begin": [c_stream],
+    "dlip_plan_end": [c_stream, C.POINTER(C.c_void_p)],
+    "dlip_plan_run": [C.c_void_p, c_stream],
+    "dlip_plan_launches": [C.c_void_p],
+    "dlip_plan_destroy": [C.c_void_p],
     "dlip_stem3d_bn_act_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem3d_bn_act_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem3d_pool_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],

@@ -50,7 +50,7 @@ class AttentiveStatPooling(nn.Module):
         from ._lib import check, lib, ptr, stream_handle
         B, T, C_ = x_ntc.shape
         hidden = ops.linear(x_ntc.reshape(B * T, C_), self.W.detach().contiguous(), self.b.detach().reshape(-1).contiguous())
-        y = torch.empty((B, 2 * C_), device=x_ntc.device, dtype=torch.float32)
+        y = ops._empty((B, 2 * C_), x_ntc.device)
         check(lib().dlip_attentive_stat_pool_f32(ptr(x_ntc), ptr(hidden), ptr(self.v.detach().contiguous()),
                                                  ptr(self.k.detach().contiguous()), ptr(y), B, T, C_, self.hidden_size,
                                                  stream_handle()), "dlip_attentive_stat_pool_f32")

@@ -16,7 +16,30 @@ import torch
 import torch.nn as nn
 
 
+# Generation of the packed-weight caches (deeplip_amd/packing.py) and of recorded step plans (plan.py): bumped
+# whenever a holder's tensors may have been replaced or rewritten wholesale -- load_state_dict, .to()/.cuda()/
+# .float(), train()/eval() switches (an optimizer ran in between) -- so a forward only compares one integer.
+PACK_GEN = [0]
+
+
+def invalidate_packs() -> None:
+    PACK_GEN[0] += 1
+
+
 class _Holder(nn.Module):
+    def _apply(self, fn, *a, **k):
+        invalidate_packs()
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        invalidate_packs()
+        return super()._load_from_state_dict(*a, **k)
+
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            invalidate_packs()
+        return super().train(mode)
+
     def forward(self, *a, **k):  # pragma: no cover - guard
         raise RuntimeError(
             f"{type(self).__name__} only holds parameters; arithmetic runs in the owning model's HIP engine "

@@ -20,6 +20,17 @@ Tensor = torch.Tensor
 # end(token), called around every MFMA kernel launch on the current stream.  None = no overhead.
 LAUNCH_HOOK = None
 
+# Set by deeplip_amd.plan.StepPlan while a step is warmed up / recorded: every result tensor then comes from
+# the plan's arena (same blocks in both passes), so nothing is allocated while the stream is being captured.
+ARENA = None
+
+
+def _empty(shape, device, dtype=torch.float32) -> Tensor:
+    a = ARENA
+    if a is None:
+        return torch.empty(shape, device=device, dtype=dtype)
+    return a.take(tuple(shape), device, dtype)
+
 
 def _req(t: Optional[Tensor], name: str, dtype=torch.float32) -> None:
     if t is None:
@@ -67,7 +78,7 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
     Ho = conv_out_size(H, R, stride[0], pad[0], dil[0])
     Wo = conv_out_size(W, S, stride[1], pad[1], dil[1])
     if out is None:
-        out = torch.empty((N, Ho, Wo, K), device=x.device, dtype=torch.float32)
+        out = _empty((N, Ho, Wo, K), x.device)
         out_channel_offset = 0
     if tuple(out.shape[:3]) != (N, Ho, Wo) or out_channel_offset + K > out.shape[3]:
         raise ValueError(f"conv_nhwc: bad output tensor {tuple(out.shape)} for result {(N, Ho, Wo, K)}")
@@ -142,7 +153,7 @@ def stem3d(x_bthw: Tensor, w_248xk: Tensor, bias: Tensor, slope: Optional[Tensor
         _req(t, n)
     B, T, H, W = x_bthw.shape
     if w_scale is not None:
-        y = torch.empty((B * T, H // 2, W // 2, 64), device=x_bthw.device, dtype=torch.float32)
+        y = _empty((B * T, H // 2, W // 2, 64), x_bthw.device)
         hook = LAUNCH_HOOK
         if hook is not None:
             tok = hook.begin("stem3d_f16x3_kernel", 2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
@@ -154,7 +165,7 @@ def stem3d(x_bthw: Tensor, w_248xk: Tensor, bias: Tensor, slope: Optional[Tensor
     K = w_248xk.shape[1]
     if w_248xk.shape[0] != 248:
         raise ValueError("stem3d: weights must be packed [248, K]")
-    y = torch.empty((B * T, H // 2, W // 2, K), device=x_bthw.device, dtype=torch.float32)
+    y = _empty((B * T, H // 2, W // 2, K), x_bthw.device)
     hook = LAUNCH_HOOK
     if hook is not None:
         tok = hook.begin("stem3d_f32_kernel", 2.0 * B * T * (H // 2) * (W // 2) * K * 245)
@@ -172,7 +183,7 @@ def stem3d_pool(x_bthw: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Ten
         _req(t, n)
     B, T, H, W = x_bthw.shape
     Ho, Wo = H // 2, W // 2
-    y = torch.empty((B * T, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), device=x_bthw.device, dtype=torch.float32)
+    y = _empty((B * T, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), x_bthw.device)
     hook = LAUNCH_HOOK
     if hook is not None:
         tok = hook.begin("stem3d_f16x3_kernel<pool>", 2.0 * B * T * Ho * Wo * 64 * 245)
@@ -186,7 +197,7 @@ def stem3d_pool(x_bthw: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Ten
 def split_pack(x: Tensor) -> Tensor:
     """fp32 [..., C] -> split activation format (same shape / dtype container; C % 32 == 0)."""
     _req(x, "x")
-    y = torch.empty_like(x)
+    y = _empty(x.shape, x.device)
     Cc = x.shape[-1]
     check(lib().dlip_split_pack_f32(ptr(x), ptr(y), x.numel() // Cc, Cc, stream_handle()), "dlip_split_pack_f32")
     return y
@@ -195,7 +206,7 @@ def split_pack(x: Tensor) -> Tensor:
 def split_unpack(x: Tensor) -> Tensor:
     """Inverse of split_pack (hi + lo in fp32)."""
     _req(x, "x")
-    y = torch.empty_like(x)
+    y = _empty(x.shape, x.device)
     Cc = x.shape[-1]
     check(lib().dlip_split_unpack_f32(ptr(x), ptr(y), x.numel() // Cc, Cc, stream_handle()), "dlip_split_unpack_f32")
     return y
@@ -204,7 +215,7 @@ def split_unpack(x: Tensor) -> Tensor:
 def maxpool3x3s2(x: Tensor, out_split: bool = False) -> Tensor:
     _req(x, "x")
     N, H, W, Cc = x.shape
-    y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=torch.float32)
+    y = _empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), x.device)
     check(lib().dlip_maxpool3x3s2_nhwc_f32(ptr(x), ptr(y), N, H, W, Cc, int(out_split), stream_handle()),
           "dlip_maxpool3x3s2_nhwc_f32")
     return y
@@ -213,7 +224,7 @@ def maxpool3x3s2(x: Tensor, out_split: bool = False) -> Tensor:
 def avgpool(x: Tensor) -> Tensor:
     _req(x, "x")
     N, H, W, Cc = x.shape
-    y = torch.empty((N, Cc), device=x.device, dtype=torch.float32)
+    y = _empty((N, Cc), x.device)
     check(lib().dlip_avgpool_nhwc_f32(ptr(x), ptr(y), N, H * W, Cc, stream_handle()), "dlip_avgpool_nhwc_f32")
     return y
 
@@ -223,7 +234,7 @@ def time_mean(x: Tensor, lengths: Optional[Tensor] = None) -> Tensor:
     _req(x, "x")
     _req(lengths, "lengths", torch.int32)
     B, T, Cc = x.shape
-    y = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    y = _empty((B, Cc), x.device)
     check(lib().dlip_time_mean_f32(ptr(x), ptr(lengths), ptr(y), B, T, Cc, Cc, stream_handle()), "dlip_time_mean_f32")
     return y
 
@@ -232,7 +243,7 @@ def group_mean(x: Tensor, group_ptr: Tensor) -> Tensor:
     _req(x, "x")
     _req(group_ptr, "group_ptr", torch.int32)
     U = group_ptr.numel() - 1
-    y = torch.empty((U, x.shape[1]), device=x.device, dtype=torch.float32)
+    y = _empty((U, x.shape[1]), x.device)
     check(lib().dlip_group_mean_f32(ptr(x), ptr(group_ptr), ptr(y), U, x.shape[1], stream_handle()), "dlip_group_mean_f32")
     return y
 
@@ -245,7 +256,7 @@ def meanstd_pool(x: Tensor, out_split: bool = False) -> Tensor:
     if Cc % 4:
         raise ValueError("meanstd_pool: C must be a multiple of 4")
     width = (2 * Cc + 31) // 32 * 32 if out_split else 2 * Cc
-    y = torch.empty((B, width), device=x.device, dtype=torch.float32)
+    y = _empty((B, width), x.device)
     check(lib().dlip_meanstd_pool_f32(ptr(x), ptr(y), B, T, Cc, int(out_split), stream_handle()), "dlip_meanstd_pool_f32")
     return y
 
@@ -254,7 +265,7 @@ def nct_to_ntc(x: Tensor, pad_to: Optional[int] = None) -> Tensor:
     _req(x, "x")
     B, Cc, T = x.shape
     Cp = Cc if pad_to is None else pad_to
-    y = torch.empty((B, T, Cp), device=x.device, dtype=torch.float32)
+    y = _empty((B, T, Cp), x.device)
     check(lib().dlip_nct_to_ntc_f32(ptr(x), ptr(y), B, Cc, T, Cp, stream_handle()), "dlip_nct_to_ntc_f32")
     return y
 
@@ -262,7 +273,7 @@ def nct_to_ntc(x: Tensor, pad_to: Optional[int] = None) -> Tensor:
 def ntc_to_nct(x: Tensor) -> Tensor:
     _req(x, "x")
     B, T, Cc = x.shape
-    y = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+    y = _empty((B, Cc, T), x.device)
     check(lib().dlip_ntc_to_nct_f32(ptr(x), ptr(y), B, T, Cc, stream_handle()), "dlip_ntc_to_nct_f32")
     return y
 
@@ -273,7 +284,7 @@ def ingest_rgb_u8(frames: Tensor) -> Tensor:
     B, T, three, H, W = frames.shape
     if three != 3:
         raise ValueError("ingest_rgb_u8: expected [B,T,3,H,W]")
-    y = torch.empty((B, 1, T, H, W), device=frames.device, dtype=torch.float32)
+    y = _empty((B, 1, T, H, W), frames.device)
     check(lib().dlip_ingest_rgb_u8(ptr(frames), ptr(y), B * T, H, W, stream_handle()), "dlip_ingest_rgb_u8")
     return y
 
@@ -281,7 +292,7 @@ def ingest_rgb_u8(frames: Tensor) -> Tensor:
 def affine_act(x: Tensor, scale: Tensor, shift: Tensor, slope: float = 0.2, act_first: bool = False) -> Tensor:
     """[M,C]: lrelu(x*scale+shift) or lrelu(x)*scale+shift (eval BatchNorm1d + LeakyReLU)."""
     _req(x, "x"); _req(scale, "scale"); _req(shift, "shift")
-    y = torch.empty_like(x)
+    y = _empty(x.shape, x.device)
     check(lib().dlip_affine_act_f32(ptr(x), ptr(scale), ptr(shift), ptr(y), x.numel() // x.shape[-1], x.shape[-1],
                                     slope, int(act_first), stream_handle()), "dlip_affine_act_f32")
     return y
@@ -292,14 +303,14 @@ def znorm_cat(a: Optional[Tensor], v: Optional[Tensor], biased: bool = False) ->
     U = (a if a is not None else v).shape[0]
     Da = a.shape[1] if a is not None else 0
     Dv = v.shape[1] if v is not None else 0
-    y = torch.empty((U, Da + Dv), device=(a if a is not None else v).device, dtype=torch.float32)
+    y = _empty((U, Da + Dv), (a if a is not None else v).device)
     check(lib().dlip_znorm_cat_f32(ptr(a), Da, ptr(v), Dv, ptr(y), U, int(biased), stream_handle()), "dlip_znorm_cat_f32")
     return y
 
 
 def l2_normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
     _req(x, "x")
-    y = torch.empty_like(x)
+    y = _empty(x.shape, x.device)
     check(lib().dlip_l2_normalize_f32(ptr(x), ptr(y), x.shape[0], x.shape[1], eps, stream_handle()), "dlip_l2_normalize_f32")
     return y
 
@@ -310,7 +321,7 @@ def pair_cosine(emb: Tensor, idx_a: Tensor, idx_b: Tensor, mode: int = 0, eps: f
     n = idx_a.numel()
     acc = out is not None
     if out is None:
-        out = torch.empty((n,), device=emb.device, dtype=torch.float32)
+        out = _empty((n,), emb.device)
     _req(out, "out")
     check(lib().dlip_pair_cosine_f32(ptr(emb), emb.shape[0], emb.shape[1], ptr(idx_a), ptr(idx_b), ptr(out), n, mode,
                                      eps, weight, int(acc), stream_handle()), "dlip_pair_cosine_f32")
@@ -321,8 +332,8 @@ def logits_argmax(e: Tensor, W: Tensor, bias: Optional[Tensor] = None, cosine: b
     _req(e, "e"); _req(W, "W"); _req(bias, "bias")
     B, D = e.shape
     K = W.shape[0]
-    logits = torch.empty((B, K), device=e.device, dtype=torch.float32)
-    amax = torch.empty((B,), device=e.device, dtype=torch.int64)
+    logits = _empty((B, K), e.device)
+    amax = _empty((B,), e.device, torch.int64)
     check(lib().dlip_logits_argmax_f32(ptr(e), ptr(W), ptr(bias), ptr(logits), ptr(amax), B, D, K, int(cosine),
                                        stream_handle()), "dlip_logits_argmax_f32")
     return logits, amax
@@ -330,7 +341,7 @@ def logits_argmax(e: Tensor, W: Tensor, bias: Optional[Tensor] = None, cosine: b
 
 def margin_ce_loss(logits: Tensor, labels: Tensor, scale: float = 1.0, margin: float = 0.0) -> Tensor:
     _req(logits, "logits"); _req(labels, "labels", torch.int64)
-    loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
+    loss = _empty((1,), logits.device)
     check(lib().dlip_margin_ce_loss_f32(ptr(logits), ptr(labels), ptr(loss), logits.shape[0], logits.shape[1], scale,
                                         margin, stream_handle()), "dlip_margin_ce_loss_f32")
     return loss[0]
@@ -339,6 +350,6 @@ def margin_ce_loss(logits: Tensor, labels: Tensor, scale: float = 1.0, margin: f
 def lowfer_cat(e1: Tensor, e2: Tensor) -> Tensor:
     _req(e1, "e1"); _req(e2, "e2")
     B, D = e1.shape
-    y = torch.empty((B, 3 * D), device=e1.device, dtype=torch.float32)
+    y = _empty((B, 3 * D), e1.device)
     check(lib().dlip_lowfer_cat_f32(ptr(e1), ptr(e2), ptr(y), B, D, stream_handle()), "dlip_lowfer_cat_f32")
     return y

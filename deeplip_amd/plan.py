@@ -1,0 +1,153 @@
+"""Step plans: record a hot-path step once, replay it with one host call (include/deeplip_hip.h, dlip_plan_*).
+
+The reference walks its test list one utterance at a time from Python (train_fusion.py:338-358); this
+engine batches the list, and a batch step is ~45 dlip_* launches.  Issued one by one from Python the GPU
+waits for the host between them, so the steady-state loop does not issue them at all:
+
+    plan = StepPlan(step_fn, clips, mels)      # runs step_fn twice on a private stream: warm-up, then record
+    fused = plan.run()                         # one dlip_plan_run call; returns the recorded output tensors
+    fused = plan(new_clips, new_mels)          # copies into the recorded input buffers, then runs
+
+What is recorded is exactly what ``step_fn`` launches through ``deeplip_amd.ops`` (every op is one dlip_*
+call on the current stream).  The tensors of the recorded step -- inputs, every intermediate, outputs, the
+packed weights -- are owned by the plan's arena for its lifetime: during the warm-up pass ``ops`` hands out
+fresh ``torch.empty`` blocks and the arena keeps them; during the recorded pass it hands out the SAME blocks
+in the same order (shapes are checked), so nothing is allocated while the stream is being captured and the
+addresses baked into the plan stay valid and private.  ``step_fn`` must be launch-only: no host
+synchronisation, no ``.item()``/``.cpu()``, no host->device copies (pass lengths etc. as device tensors).
+
+A plan is tied to the weights it was recorded with: ``plan.run()`` raises ``StalePlanError`` after a
+``load_state_dict`` / ``.to()`` / train-eval switch of any model (re-record it), mirroring the pack cache
+(deeplip_amd/packing.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import holders, ops
+from ._lib import DeepLipHipError, check, lib
+
+Tensor = torch.Tensor
+
+
+class StalePlanError(DeepLipHipError):
+    pass
+
+
+class Arena:
+    """Owns the buffers of one recorded step.  mode 'collect': allocate and remember; 'replay': hand the
+    remembered buffers out again in order."""
+
+    def __init__(self):
+        self.bufs: List[Tensor] = []
+        self.keep: list = []          # packed weights and anything else the recorded launches address
+        self.mode = "collect"
+        self.cursor = 0
+
+    def take(self, shape: Tuple[int, ...], device, dtype) -> Tensor:
+        if self.mode == "collect":
+            t = torch.empty(shape, device=device, dtype=dtype)
+            self.bufs.append(t)
+            return t
+        if self.cursor >= len(self.bufs):
+            raise DeepLipHipError("StepPlan: the recorded pass allocates more tensors than the warm-up pass did "
+                                  "(the step function must be deterministic in its launches)")
+        t = self.bufs[self.cursor]
+        self.cursor += 1
+        if tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            raise DeepLipHipError(f"StepPlan: allocation #{self.cursor - 1} was {tuple(t.shape)}/{t.dtype} in the warm-up "
+                                  f"pass and is {tuple(shape)}/{dtype} in the recorded pass")
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs)
+
+
+def _flatten(out):
+    if isinstance(out, Tensor):
+        return [out]
+    if isinstance(out, (tuple, list)):
+        return [t for o in out for t in _flatten(o)]
+    if out is None:
+        return []
+    raise TypeError(f"StepPlan: step function returned {type(out).__name__}; expected tensors")
+
+
+class StepPlan:
+    """``fn(*inputs)`` recorded on a private HIP stream; see the module docstring."""
+
+    def __init__(self, fn: Callable, *inputs: Tensor, stream: Optional[torch.cuda.Stream] = None):
+        for i, t in enumerate(inputs):
+            if not (isinstance(t, Tensor) and t.is_cuda):
+                raise DeepLipHipError(f"StepPlan: input {i} must be a CUDA (ROCm) tensor")
+        lib()
+        self.fn = fn
+        self.inputs: Tuple[Tensor, ...] = tuple(t.contiguous() for t in inputs)   # the recorded input buffers
+        self.device = self.inputs[0].device if self.inputs else torch.device("cuda", torch.cuda.current_device())
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        self.arena = Arena()
+        self._handle = C.c_void_p()
+        self.outputs = None
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            self._pass("collect")                 # warm-up: packs weights, registers the workspace, fills the arena
+            self.stream.synchronize()
+            check(lib().dlip_plan_begin(self.stream.cuda_stream), "dlip_plan_begin")
+            try:
+                out = self._pass("replay")
+            except BaseException:
+                h = C.c_void_p()
+                lib().dlip_plan_end(self.stream.cuda_stream, C.byref(h))   # leave capture mode before propagating
+                lib().dlip_plan_destroy(h)
+                raise
+            check(lib().dlip_plan_end(self.stream.cuda_stream, C.byref(self._handle)), "dlip_plan_end")
+        if self.arena.cursor != len(self.arena.bufs):
+            raise DeepLipHipError("StepPlan: the recorded pass made fewer allocations than the warm-up pass")
+        self.outputs = out
+        self._out_flat = _flatten(out)
+        self.launches = int(lib().dlip_plan_launches(self._handle))
+        self._gen = holders.PACK_GEN[0]
+        caller.wait_stream(self.stream)
+
+    def _pass(self, mode: str):
+        self.arena.mode, self.arena.cursor = mode, 0
+        prev = ops.ARENA
+        ops.ARENA = self.arena
+        try:
+            return self.fn(*self.inputs)
+        finally:
+            ops.ARENA = prev
+
+    def run(self):
+        """Replay the step on the current stream (asynchronous); returns the recorded output tensor(s),
+        which the next run overwrites."""
+        if self._gen != holders.PACK_GEN[0]:
+            raise StalePlanError("StepPlan: model weights / placement changed since the plan was recorded; record a new plan")
+        check(lib().dlip_plan_run(self._handle, torch.cuda.current_stream(self.device).cuda_stream), "dlip_plan_run")
+        return self.outputs
+
+    def __call__(self, *new_inputs: Tensor):
+        if len(new_inputs) != len(self.inputs):
+            raise ValueError(f"StepPlan: expected {len(self.inputs)} inputs, got {len(new_inputs)}")
+        for dst, src in zip(self.inputs, new_inputs):
+            if src is not dst:
+                if tuple(src.shape) != tuple(dst.shape):
+                    raise ValueError(f"StepPlan: input shape {tuple(src.shape)} != recorded {tuple(dst.shape)}")
+                dst.copy_(src, non_blocking=True)
+        return self.run()
+
+    def close(self):
+        h, self._handle = self._handle, C.c_void_p()
+        if h:
+            torch.cuda.synchronize(self.device)
+            lib().dlip_plan_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

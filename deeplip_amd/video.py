@@ -6,8 +6,10 @@ import Lipreading`` keeps working and the authors' ``video_model.pth`` loads unc
 Data layout inside the engine is channels-last: the Conv3d stem writes [(B*T),H,W,C] directly, so
 ``threeD_to_2D_tensor`` (model.py:9-13) costs nothing, every BasicBlock conv is one implicit-GEMM
 launch with BN / PReLU / residual fused, and the trunk output [(B*T),512] *is* [B,T,512].
-Encoders run in eval mode only (running-stat BN), as in the reference's fusion pipeline where they
-are frozen (train_fusion.py:198-201,245-252).
+Eval mode (running-statistics BN folded into the packed weights) is the extraction path of the
+fusion pipeline, where the encoders are frozen (train_fusion.py:198-201,245-252); under
+``model.train()`` the same classes run batch-statistics BN, dropout and a full backward through
+the autograd Functions of deeplip_amd/autograd_video.py (train_video.py:108-169).
 """
 from __future__ import annotations
 
@@ -24,10 +26,12 @@ Tensor = torch.Tensor
 
 
 def _require_eval(m: nn.Module):
+    """Standalone sub-module forwards (ResNet, TDNN_Block, the TCN head on their own) exist in eval mode only;
+    train mode runs through the owning model's forward (Lipreading / SpeakerEmbNet), which is differentiable."""
     if m.training:
         raise RuntimeError(
-            f"{type(m).__name__}: the HIP engine implements eval-mode (running-statistics) BatchNorm; call .eval() "
-            "first. Train-mode encoder BN / backward is SURVEY.md section 8(f) rank 2 (not built yet).")
+            f"{type(m).__name__}: standalone forward is eval-mode only (running-statistics BatchNorm); call .eval(), "
+            "or train through the owning model (Lipreading / SpeakerEmbNet), whose forward is differentiable.")
 
 
 def _act_holder(relu_type: str, channels: int):
@@ -251,7 +255,7 @@ class MultibranchTemporalBlock(nn.Module):
         nb = self.n_outputs_branch
         cur = x
         for s in (0, 1):
-            out = torch.empty((B, T, self.n_outputs), device=x.device, dtype=torch.float32)
+            out = ops._empty((B, T, self.n_outputs), x.device)
             for j, k in enumerate(self.kernel_sizes):
                 pk = p[f"cbcr{s}_{j}"]
                 ops.conv1d_ntc(cur, pk.w, pk.b, dilation=self.dilation, pad=(k - 1) * self.dilation // 2,
@@ -322,8 +326,7 @@ class MultiscaleMultibranchTCN(nn.Module):
         here) -> consensus features [B, 768] = _average_batch(mb_ms_tcn(x)) (model.py:16-17,34-36)."""
         for b, bp in zip(self.mb_ms_tcn.network, p["blocks"]):
             x = b.run(x, bp)
-        ln = torch.as_tensor([int(l) for l in lengths], dtype=torch.int32).to(x.device)
-        return ops.time_mean(x, ln)
+        return ops.time_mean(x, _lengths_i32(lengths, x.device))
 
     def run(self, x: Tensor, lengths, p) -> Tensor:
         return ops.linear(self.pooled(x, lengths, p), p["out"].w, p["out"].b, w_scale=p["out"].wscale)   # tcn_output, model.py:27,37
@@ -345,12 +348,22 @@ class TCN(nn.Module):
 # ------------------------------------------------------------------------------------------
 # model.py
 # ------------------------------------------------------------------------------------------
+def _lengths_i32(lengths, device) -> Tensor:
+    """Clip lengths as the int32 device vector the masked temporal mean reads.  A CUDA int32 tensor passes
+    through untouched (what a recorded step plan needs: no host->device copy inside the step)."""
+    if isinstance(lengths, Tensor) and lengths.is_cuda and lengths.dtype == torch.int32:
+        return lengths.contiguous()
+    return torch.as_tensor([int(l) for l in lengths], dtype=torch.int32).to(device)
+
+
 def _cached_pack(module: nn.Module, device, builder):
     ver = packing.state_version(module, device)
     cache = module.__dict__.get("_dlip_pack")
     if cache is None or cache[0] != ver:
         cache = (ver, builder(device))
         module.__dict__["_dlip_pack"] = cache
+    if ops.ARENA is not None:
+        ops.ARENA.keep.append(cache[1])   # a recorded step addresses these weights: the plan keeps them alive
     return cache[1]
 
 
@@ -410,8 +423,7 @@ class Lipreading(nn.Module):
             return y
         for blk in self.tcn.mb_ms_tcn.network:
             y = _tcn_block_train(blk, y, self.tcn_dropout)
-        ln = torch.as_tensor([int(l) for l in lengths], dtype=torch.int32).to(x.device)
-        return ag.linear(av.time_mean(y, ln), self.tcn.tcn_output.weight, self.tcn.tcn_output.bias)
+        return ag.linear(av.time_mean(y, _lengths_i32(lengths, x.device)), self.tcn.tcn_output.weight, self.tcn.tcn_output.bias)
 
     def forward(self, x: Tensor, lengths, taps: Optional[dict] = None):
         if self.training:

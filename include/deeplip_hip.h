@@ -28,13 +28,14 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 13
+#define DLIP_ABI_VERSION 14
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
 #define DLIP_ERANGE (-2)  /* a tensor exceeds the 2 GiB addressing window of one launch */
 
 typedef void* dlip_stream_t; /* hipStream_t */
+typedef void* dlip_plan_t;   /* a recorded step (dlip_plan_end) */
 
 int dlip_abi_version(void);
 /* Human-readable text for a code returned by any dlip_* call. */
@@ -384,6 +385,26 @@ int dlip_row_broadcast_f32(const float* dy, const int32_t* lengths, float* dx, i
 int dlip_stem_im2col_f32(const float* x, float* col, int32_t B, int32_t T, int32_t H, int32_t W, dlip_stream_t stream);
 /* y = x * mask * scale (nn.Dropout forward / backward, tcn.py:80,85). */
 int dlip_mul_mask_f32(const float* x, const float* mask, float* y, int64_t n, float scale, dlip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step plans.  The reference drives its encoders from a Python loop, one utterance and one torch.nn layer
+ * at a time (train_fusion.py:338-358 extraction, :262-293 training step); here a step is ~45 short kernels
+ * and the host must not sit between them.  A plan records every dlip_* launch made on `stream` between
+ * dlip_plan_begin and dlip_plan_end (HIP stream capture, thread-local mode -> an instantiated hipGraph) and
+ * dlip_plan_run replays them with ONE host call, asynchronously on the given stream.
+ *   - `stream` of begin / end must be a created stream (the null stream cannot be captured);
+ *   - between begin and end the caller makes launches only: no allocation, no synchronisation, no host copy
+ *     (warm every kernel once on that stream first, so workspace registration and kernel attributes are set);
+ *   - the plan addresses exactly the buffers of the recorded step: they stay caller-owned and must outlive it;
+ *     new inputs are copied into the recorded input buffers;
+ *   - a plan must not run concurrently with itself (replays on one stream are ordered).
+ * dlip_plan_launches = kernel launches the plan holds.  dlip_plan_destroy(NULL) is a no-op.
+ * ------------------------------------------------------------------------------------------ */
+int dlip_plan_begin(dlip_stream_t stream);
+int dlip_plan_end(dlip_stream_t stream, dlip_plan_t* plan);
+int dlip_plan_run(dlip_plan_t plan, dlip_stream_t stream);
+int dlip_plan_launches(dlip_plan_t plan);
+int dlip_plan_destroy(dlip_plan_t plan);
 
 #ifdef __cplusplus
 }

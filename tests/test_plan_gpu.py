@@ -1,0 +1,93 @@
+"""Step plans (deeplip_amd/plan.py over dlip_plan_*): a recorded step replays bit-identically to the eager
+launches it was recorded from, accepts new inputs, and refuses to run on stale weights."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TCN = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
+CTX = [[-2, -1, 0, 1, 2], [0], [-2, 0, 2], [0], [-3, 0, 3], [0], [-4, 0, 4], [0], [0], [0]]
+
+
+def _models(precision):
+    from deeplip_amd import packing, weightgen as wg
+    from models.audio_models.tdnn import SpeakerEmbNet
+    from models.video_models.model import Lipreading
+    packing.set_precision(precision)
+    video = Lipreading(num_classes=54, relu_type="prelu", tcn_options=TCN, extract_feats=True)
+    et = {"input_dim": 24, "hidden_dim": [512] * 9 + [1500], "context": CTX, "tdnn_layers": 10, "embedding_dim": 512,
+          "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+    audio = SpeakerEmbNet({"arch": "etdnn", "etdnn": et})
+    for name, m in (("video.", video), ("audio.", audio)):
+        sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, prefix=name)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m.eval().cuda()
+    return video, audio
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_plan_replays_the_eager_step_bit_for_bit(precision):
+    from deeplip_amd import fusion, packing, weightgen as wg
+    from deeplip_amd.plan import StepPlan
+    try:
+        video, audio = _models(precision)
+
+        def step(xv, xa):
+            return fusion.fuse_av(audio.extract_embedding(xa)[0], video.embed(xv))
+
+        xv = torch.from_numpy(wg.video_input(3, frames=11, key="plan.video")).cuda()
+        xa = torch.from_numpy(wg.audio_input(3, 24, 150, key="plan.audio")).cuda()
+        ref = step(xv, xa).clone()
+        plan = StepPlan(step, xv.clone(), xa.clone())
+        assert plan.launches >= 30                       # the whole step is in the plan
+        for _ in range(3):
+            out = plan.run()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        # new inputs go through the recorded input buffers
+        xv2 = torch.from_numpy(wg.video_input(3, frames=11, key="plan.video2")).cuda()
+        xa2 = torch.from_numpy(wg.audio_input(3, 24, 150, key="plan.audio2")).cuda()
+        ref2 = step(xv2, xa2).clone()
+        out2 = plan(xv2, xa2)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, ref2)
+        assert not torch.equal(ref2, ref)
+        with pytest.raises(ValueError):
+            plan(xv2[:2], xa2)
+        plan.close()
+    finally:
+        packing.set_precision("f32")
+
+
+def test_plan_is_stale_after_a_weight_change():
+    from deeplip_amd import fusion, packing, weightgen as wg
+    from deeplip_amd.plan import StalePlanError, StepPlan
+    video, audio = _models("f32")
+    xa = torch.from_numpy(wg.audio_input(2, 24, 120, key="plan.stale")).cuda()
+    plan = StepPlan(lambda a: audio.extract_embedding(a)[0], xa)
+    plan.run()
+    sd = audio.state_dict()
+    sd["fc2.bias"] = sd["fc2.bias"] + 1.0
+    audio.load_state_dict(sd)
+    with pytest.raises(StalePlanError):
+        plan.run()
+    # eager forwards pick the new weights up (pack cache invalidated by the same event)
+    a = audio.extract_embedding(xa)[0]
+    plan2 = StepPlan(lambda a: audio.extract_embedding(a)[0], xa)
+    torch.cuda.synchronize()
+    assert torch.equal(plan2.run(), a)
+
+
+def test_pack_cache_sees_in_place_edits():
+    """Eager forwards fingerprint the parameters' version counters: an in-place edit without load_state_dict
+    (an optimizer step, a broadcast) repacks."""
+    from deeplip_amd import weightgen as wg
+    video, audio = _models("f32")
+    xa = torch.from_numpy(wg.audio_input(2, 24, 120, key="plan.inplace")).cuda()
+    a0 = audio.extract_embedding(xa)[0].clone()
+    with torch.no_grad():
+        audio.fc2.bias.add_(0.5)
+    a1 = audio.extract_embedding(xa)[0]
+    torch.cuda.synchronize()
+    np.testing.assert_allclose((a1 - a0).cpu().numpy(), 0.5, atol=1e-5)
