@@ -112,7 +112,7 @@ AUDIO_STREAM = None   # --audio-stream: the speech encoder runs on a second HIP 
 def local_step(video, audio, xv, xa):
     """The per-rank part of a step: launches only (what a StepPlan records)."""
     from deeplip_amd import fusion
-    return fusion.fuse_av(audio.extract_embedding(xa)[0], video.embed(xv))
+    return fusion.fuse_av(audio.extract_embedding(xa)[0], video.embed(xv, finish=False))
 
 
 def exchange(fused, world):

@@ -13,10 +13,12 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lock = threading.Lock()
 _lib = None
+_status = None
+_status_np = None
 
 c_f = C.c_void_p      # device float* (passed as integer address)
 c_i32 = C.c_int32
@@ -36,6 +38,13 @@ SIGNATURES = {
     "dlip_abi_version": [],
     "dlip_conv_nhwc_f32": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_stream],
     "dlip_conv_nhwc_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_stream],
+    "dlip_conv2_nhwc_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
+                              c_i32, c_stream],
+    "dlip_conv_pool_partial_bytes": [C.POINTER(ConvDesc), C.POINTER(C.c_int32)],
+    "dlip_conv_pool_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_stream],
+    "dlip_pool_finish_f32": [c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_stream],
+    "dlip_set_status_words": [c_f],
+    "dlip_debug_set": [c_i32, c_i32],
     "dlip_bn_rows_chunks": [c_i32],
     "dlip_bn_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_i32, c_stream],
     "dlip_bn_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_stream],
@@ -75,9 +84,11 @@ SIGNATURES = {
     "dlip_attentive_stat_pool_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_nct_to_ntc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_ntc_to_nct_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
+    "dlip_nct_to_ntc_split_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_ingest_rgb_u8": [c_f, c_f, c_i64, c_i32, c_i32, c_stream],
     "dlip_affine_act_f32": [c_f, c_f, c_f, c_f, c_i64, c_i32, C.c_float, c_i32, c_stream],
     "dlip_znorm_cat_f32": [c_f, c_i32, c_f, c_i32, c_f, c_i32, c_i32, c_stream],
+    "dlip_znorm_cat_pooled_f32": [c_f, c_i32, c_f, c_i64, c_i32, c_i32, c_i32, c_f, c_i32, c_i32, c_stream],
     "dlip_l2_normalize_f32": [c_f, c_f, c_i32, c_i32, C.c_float, c_stream],
     "dlip_pair_cosine_f32": [c_f, c_i32, c_i32, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_i32, c_stream],
     "dlip_plda_llr_f32": [c_f, c_i32, c_i32, c_f, c_f, c_f, c_f, c_i32, c_stream],
@@ -103,6 +114,12 @@ class DeepLipHipError(RuntimeError):
     pass
 
 
+class DeepLipRangeError(DeepLipHipError):
+    """An activation left the range of the split-fp16 ("f16x3") arithmetic (|v| >= 65520): the results of the
+    launches since the last check are invalid.  Recourse: pack that model in the exact mode,
+    ``deeplip_amd.packing.set_precision("f32")`` (same engine, fp32 MFMA)."""
+
+
 def lib() -> C.CDLL:
     """Load (once) and return the HIP library; raises if it is missing -- never falls back."""
     global _lib
@@ -121,6 +138,7 @@ def lib() -> C.CDLL:
             fn.argtypes = args
             fn.restype = C.c_int
         l.dlip_conv_workspace_bytes.restype = C.c_int64
+        l.dlip_conv_pool_partial_bytes.restype = C.c_int64
         l.dlip_error_string.argtypes = [C.c_int]
         l.dlip_error_string.restype = C.c_char_p
         v = l.dlip_abi_version()
@@ -144,6 +162,8 @@ def ptr(t) -> int | None:
 
 
 def stream_handle() -> int:
+    if _status is None:
+        status_words()      # first launch of the process: register the range-status block
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -164,3 +184,43 @@ def ensure_conv_workspace() -> None:
     buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     check(lib().dlip_conv_set_workspace(buf.data_ptr(), nbytes, st.cuda_stream), "dlip_conv_set_workspace")
     _workspaces[key] = buf
+
+
+# ---- diagnostic overrides (tests, tools): dlip_debug_set ----
+DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK = 0, 1, 2, 3
+
+
+def debug_set(key: int, value: int = -1) -> None:
+    check(lib().dlip_debug_set(key, value), "dlip_debug_set")
+
+
+# ---- range status of the f16x3 arithmetic: four words in host-pinned, device-visible memory ----
+_STATUS_NAMES = ("a convolution / linear epilogue", "the fused stem + pool", "split_pack (a model input or gradient operand)",
+                 "statistics pooling")
+
+
+def status_words():
+    """Registers (once) the status block the kernels report range overflows to.  It lives in pinned host memory,
+    which the GPU addresses directly: the host can look at it at any time without synchronising."""
+    global _status, _status_np
+    if _status is None:
+        t = torch.zeros(4, dtype=torch.int32).pin_memory()
+        check(lib().dlip_set_status_words(t.data_ptr()), "dlip_set_status_words")
+        _status_np = t.numpy()      # same memory: a forward's check is one numpy read
+        _status = t
+    return _status
+
+
+def check_range(sync: bool = False) -> None:
+    """Raise DeepLipRangeError if a kernel reported an activation beyond fp16 range since the last call.  Without
+    ``sync`` only launches that have completed are covered (the call is a host memory read); callers that are
+    about to consume results synchronise first (or pass sync=True)."""
+    t = status_words()
+    if sync:
+        torch.cuda.synchronize()
+    if _status_np.any():
+        where = [n for n, v in zip(_STATUS_NAMES, t.tolist()) if v]
+        t.zero_()
+        raise DeepLipRangeError("f16x3 arithmetic: an activation with |v| >= 65520 (not representable as hi + lo fp16) was "
+                                f"produced by {', '.join(where)}; results since the last check are invalid. Pack the model "
+                                "with deeplip_amd.packing.set_precision('f32') (exact fp32 MFMA, same engine).")

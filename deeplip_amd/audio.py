@@ -13,12 +13,17 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import ops, packing
+from . import _lib, ops, packing
 from .holders import BatchNormParams, ConvParams, LinearParams, Marker
 from .video import _cached_pack, _require_eval
 
 Tensor = torch.Tensor
 LRELU = 0.2
+
+# f16x3 extraction path: statistics pooling comes out of the last TDNN layer's epilogue as pooled partial sums
+# (dlip_conv_pool_f16x3 + dlip_pool_finish_f32) instead of a [B,T',1500] tensor written and read back once
+# (pooling.py:24-26).  The unfused twin stays for the tests, for taps and for utterances shorter than a tile.
+FUSE_POOL = True
 
 
 class MeanStdPooling(nn.Module):
@@ -96,6 +101,18 @@ class TDNN_Block(nn.Module):
                               post_scale=p.post_scale, post_shift=p.post_shift, w_scale=p.wscale,
                               x_split=x_split, out_split=out_split)
 
+    def run_pooled(self, x: Tensor, p: packing.Packed):
+        """x [B,T,C] split format -> ops.Pooled column sums of the layer's output over each utterance's T' frames (the
+        input of statistics pooling), or None when T' is shorter than the workgroup tile the launch would use."""
+        B, T, Cx = x.shape
+        Tp = ops.conv_out_size(T, self.kernel_size, 1, self.padding, self.dilation)
+        xv = x.view(B, 1, T, Cx)
+        wv = p.w.view(p.w.shape[0], 1, p.w.shape[1], p.w.shape[2])
+        kw = dict(pad=(0, self.padding), dil=(1, self.dilation))
+        if Tp < ops.conv_pool_tile_rows(xv, wv, **kw):
+            return None
+        return ops.conv_pool(xv, wv, p.b, p.wscale, Tp, slope=p.slope, post_scale=p.post_scale, post_shift=p.post_shift, **kw)
+
     def forward(self, x: Tensor) -> Tensor:
         """[B,C,T] -> [B,K,T'] (reference layout, standalone use)."""
         _require_eval(self)
@@ -159,8 +176,8 @@ class SpeakerEmbNet(nn.Module):
             x = x.squeeze(1)
         if x.dim() != 3 or x.shape[1] != self.input_dim:
             raise ValueError(f"SpeakerEmbNet expects [B,{self.input_dim},T] features, got {tuple(x.shape)}")
-        h = ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim, 32 if split else 4))
-        return ops.split_pack(h) if split else h
+        return ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim, 32 if split else 4),
+                              out_split=split)
 
     def _extract_embedding_train(self, x: Tensor) -> Tuple[Tensor, Tensor]:
         """extract_embedding under model.train() (train_audio.py:167-183): batch-statistics BatchNorm, every
@@ -184,6 +201,7 @@ class SpeakerEmbNet(nn.Module):
         """[B,F,T] -> (xv [B,E] = fc2 output, x_a [B,E] = fc1 output)   (tdnn.py:89-101)."""
         if self.training:
             return self._extract_embedding_train(x)
+        _lib.check_range()      # an overflow reported by an earlier f16x3 launch surfaces here (host read, no sync)
         p = _cached_pack(self, x.device, self._pack)
         # f16x3 packing: frame-level activations travel between layers as (hi, lo) fp16 pairs, written
         # by the producing layer's epilogue; the last layer hands fp32 to the pooling kernel, which
@@ -191,14 +209,23 @@ class SpeakerEmbNet(nn.Module):
         f16x3 = p["tdnn"][0].wscale is not None
         h = self._to_ntc(x, split=f16x3)
         split, n = f16x3, len(self.tdnn)
+        pooled = None
         for i, (blk, bp) in enumerate(zip(self.tdnn, p["tdnn"])):
             nxt = bp.wscale is not None and i + 1 < n and blk.output_dim % 32 == 0
+            if (i + 1 == n and split and FUSE_POOL and taps is None and self.pooling_type == "statistic"
+                    and blk.output_dim % 4 == 0):
+                pooled = blk.run_pooled(h, bp)       # None when an utterance is shorter than a workgroup tile
+                if pooled is not None:
+                    break
             h = blk.run_ntc(h, bp, x_split=split, out_split=nxt)
             split = nxt
         if taps is not None:
             taps["tdnn_out"] = h
         pooled_split = False
-        if self.pooling_type == "statistic":
+        if pooled is not None:
+            pooled_split = True
+            h = ops.pool_finish(pooled, "meanstd", out_split=True)
+        elif self.pooling_type == "statistic":
             pooled_split = f16x3 and h.shape[2] % 4 == 0
             h = ops.meanstd_pool(h, out_split=pooled_split)
         elif self.pooling_type == "average":

@@ -1,6 +1,8 @@
 """Build libdeeplip_hip.so (gfx950) in-tree with hipcc.
 
     python -m deeplip_amd.build            # rebuild if sources are newer than the library
+    python -m deeplip_amd.build --lab      # libdeeplip_hip_lab.so: -DDLIP_LAB (experimental tiles, in-kernel stamps);
+                                           # used by tools/ through DLIP_LIB_PATH, never by the product
 
 hipcc cross-compiles without a GPU.  The library lands in deeplip_amd/lib/ so that it travels
 with the repo snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
@@ -17,7 +19,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libdeeplip_hip.so")
-SOURCES = ["capi.hip", "plan.hip", "conv_igemm.hip", "conv_igemm_f16x3.hip", "conv_igemm_f16x3_dma.hip", "conv_wres_f16x3.hip", "stem3d.hip", "stem3d_f16x3.hip", "pool_ops.hip", "score_ops.hip", "layout_ops.hip", "train_ops.hip", "encoder_train_ops.hip", "video_train_ops.hip", "frontend_ops.hip"]
+SOURCES = ["capi.hip", "plan.hip", "conv_igemm.hip", "conv_igemm_f16x3.hip", "conv_igemm_f16x3_dma.hip", "stem3d.hip", "stem3d_f16x3.hip", "pool_ops.hip", "score_ops.hip", "layout_ops.hip", "train_ops.hip", "encoder_train_ops.hip", "video_train_ops.hip", "frontend_ops.hip"]
 ARCH = "gfx950"
 
 
@@ -37,17 +39,23 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
+    if lab:
+        return _build(os.path.join(LIBDIR, "libdeeplip_hip_lab.so"), ["-DDLIP_LAB"], verbose, "lab_")
     if not force and not needs_build():
         return LIB
+    return _build(LIB, [], verbose, "")
+
+
+def _build(LIB: str, extra, verbose: bool, tag: str) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
     hipcc = _hipcc()
     common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-              "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+              "-I" + CSRC, "-Wall", "-Wno-unused-function"] + list(extra)
     procs = []
     for s in SOURCES:
-        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        o = os.path.join(LIBDIR, tag + s.replace(".hip", ".o"))
         objs.append(o)
         cmd = common + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
@@ -66,4 +74,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, lab="--lab" in sys.argv))

@@ -10,3 +10,23 @@ extern "C" const char* dlip_error_string(int code) {
   if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
   return "deeplip_hip: unknown error code";
 }
+
+// ---- diagnostic overrides and range status (include/deeplip_hip.h) ----
+int dlip_dbg_value[DLIP_DBG_COUNT] = {-1, -1, -1, -1};
+
+extern "C" int dlip_debug_set(int32_t key, int32_t value) {
+  DLIP_CHECK_ARG(key >= 0 && key < DLIP_DBG_COUNT);
+  dlip_dbg_value[key] = value;
+  return DLIP_OK;
+}
+
+namespace {
+int32_t* g_status_words = nullptr;
+}
+
+extern "C" int32_t* dlip_status_words(void) { return g_status_words; }
+
+extern "C" int dlip_set_status_words(int32_t* words) {
+  g_status_words = words;
+  return DLIP_OK;
+}

@@ -29,6 +29,16 @@ struct ConvArgs {
   uint32_t x_bytes, w_bytes, r_bytes, y_bytes;
   const float* wscale;  // split-fp16 path: per-output-channel power-of-two weight scale (NULL otherwise)
   int Cw;               // channels per tap in the PACKED weights (C, or C rounded up to 32)
+  // ---- LDS-DMA kernel only (conv_igemm_f16x3_dma.hip) ----
+  // second reduction source (dlip_conv2_nhwc_f16x3): after the nk1 = R S cchunks slices of x, nk2 slices of a
+  // 1x1 strided convolution over x2 [N,H2,W2,C2] (same N, same output grid), weights behind the taps in each row
+  const float* x2;
+  uint32_t x2_bytes;
+  int H2, W2, ldx2, s2h, s2w, nk2;
+  // pooled epilogue (dlip_conv_pool_f16x3): per tile row band and row-group segment, column sums of y and y^2
+  double* pool;
+  int pool_group;       // rows per group (>= the tile's BM)
+  int32_t* status;      // range-status word (NULL: not reported)
 };
 
 
@@ -75,6 +85,9 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
   a.r_bytes = (uint32_t)r_bytes; a.y_bytes = (uint32_t)y_bytes;
   a.wscale = nullptr;
   a.Cw = Cw;
+  a.x2 = nullptr; a.x2_bytes = 0; a.H2 = a.W2 = a.ldx2 = a.s2h = a.s2w = a.nk2 = 0;
+  a.pool = nullptr; a.pool_group = 0;
+  a.status = nullptr;
   return DLIP_OK;
 }
 
@@ -87,10 +100,7 @@ const float kEffF32[NUM_CFG] = {0.90f, 0.97f, 0.93f, 1.00f, 0.97f};
 const float kEffF16x3[NUM_CFG] = {0.95f, 0.93f, 0.80f, 1.00f, 0.90f};
 
 inline int pick_tile(long long M, int K, const float* eff = kEffF32) {
-  if (const char* e = getenv("DLIP_CONV_TILE")) {  // development override (A/B runs)
-    const int v = atoi(e);
-    if (v >= 0 && v < NUM_CFG) return v;
-  }
+  if (const int v = dlip_dbg_value[DLIP_DBG_CONV_TILE]; v >= 0 && v < NUM_CFG) return v;   // dlip_debug_set (A/B runs, tests)
   int best = 0;
   double best_cost = 1e300;
   for (int i = 0; i < NUM_CFG; ++i) {

@@ -327,31 +327,41 @@ int launch(const ConvArgs& a, hipStream_t st, int flags) {
 
 }  // namespace
 
-extern "C" int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int out_split);   // conv_igemm_f16x3_dma.hip
-extern "C" int dlip_conv_wres_ok(const void* args);                                          // conv_wres_f16x3.hip
-extern "C" int dlip_conv_f16x3_wres_launch(const void* args, void* stream, int out_split);
+extern "C" int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int epi);   // conv_igemm_f16x3_dma.hip
+extern "C" void dlip_conv_dma_tile(long long M, int K, int nk, int epi, int* bm, int* bn);
 
-// Development switch (A/B runs): DLIP_CONV_DMA=0 keeps split-format launches on the register-staged kernel.
-extern "C" __attribute__((visibility("hidden"))) int dlip_conv_dma_enabled(void) {
-  static const int on = [] { const char* e = getenv("DLIP_CONV_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on;
-}
+// Diagnostic switch (dlip_debug_set DLIP_DBG_DMA_ENABLE = 0): keeps split-format launches on the register-staged kernel.
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_dma_enabled(void) { return dlip_dbg_value[DLIP_DBG_DMA_ENABLE] != 0; }
 
-extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split,
-                                    const float* w_scale, const float* bias, const float* residual,
-                                    const float* slope, const float* post_scale, const float* post_shift,
-                                    float* y, int32_t flags, dlip_stream_t stream) {
+namespace {
+
+// Shared argument checks of the three split-fp16 entry points; fills `a`.
+int fill_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, const float* w_scale, const float* bias,
+               const float* residual, const float* slope, const float* post_scale, const float* post_shift, float* y,
+               int32_t flags, ConvArgs* a) {
   DLIP_CHECK_ARG(d && w_scale);
   // flags: DLIP_SPLIT_IN (x and residual hold (hi, lo) pairs; C, ldx, ldr multiples of 32),
   //        DLIP_SPLIT_OUT (y is written in that format; K, ldy multiples of 32)
   if (flags & 1) DLIP_CHECK_ARG((d->C & 31) == 0 && (d->ldx & 31) == 0 && (residual == nullptr || ((d->ldr & 31) == 0 && (d->K & 31) == 0)));
   if (flags & 2) DLIP_CHECK_ARG((d->K & 31) == 0 && (d->ldy & 31) == 0);
   const int Cw = (d->C + 31) / 32 * 32;
-  ConvArgs a;
   const int rc = dlip_fill_conv_args(d, x, static_cast<const float*>(w_split), bias, residual, slope, post_scale,
-                                     post_shift, y, Cw, &a);
+                                     post_shift, y, Cw, a);
   if (rc != DLIP_OK) return rc;
-  a.wscale = w_scale;
+  a->wscale = w_scale;
+  if (int32_t* st = dlip_status_words()) a->status = st + DLIP_ST_CONV;
+  return DLIP_OK;
+}
+
+}  // namespace
+
+extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split,
+                                    const float* w_scale, const float* bias, const float* residual,
+                                    const float* slope, const float* post_scale, const float* post_shift,
+                                    float* y, int32_t flags, dlip_stream_t stream) {
+  ConvArgs a;
+  const int rc = fill_f16x3(d, x, w_split, w_scale, bias, residual, slope, post_scale, post_shift, y, flags, &a);
+  if (rc != DLIP_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // Split-format activations go to the LDS-DMA kernel.  Its epilogue leaves in 16-byte chunks, so an fp32
   // output needs K, ldy in multiples of 4 and a 16-byte aligned y (a split output already has K, ldy % 32 == 0);
@@ -359,13 +369,8 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   const bool dma_ok = (flags & 2) ? (reinterpret_cast<uintptr_t>(y) & 15) == 0
                                   : ((d->K & 3) == 0 && (d->ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0);
   const bool res_ok = residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
-  if ((flags & 1) && dma_ok && res_ok && dlip_conv_dma_enabled()) {
-    // 64 -> 64 channel layers (layer1): filter bank resident in LDS, barrier-free waves (conv_wres_f16x3.hip) --
-    // an experiment that lost to the ring kernel (370 vs 328 us): off unless DLIP_CONV_WRES asks for it
-    if (dlip_conv_wres_ok(&a) && (residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 7) == 0))
-      return dlip_conv_f16x3_wres_launch(&a, stream, (flags & 2) != 0);
-    return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) != 0);
-  }
+  if ((flags & 1) && dma_ok && res_ok && dlip_conv_dma_enabled())
+    return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) ? 1 : 0);
   switch (pick_tile(a.M, d->K, kEffF16x3)) {
     case 0: return launch<128, 128, 2, 2>(a, st, flags);
     case 1: return launch<128, 64, 2, 2>(a, st, flags);
@@ -373,4 +378,63 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
     case 3: return launch<64, 128, 1, 4>(a, st, flags);
     default: return launch<96, 128, 1, 4>(a, st, flags);
   }
+}
+
+// conv + 1x1 strided shortcut convolution in ONE reduction (include/deeplip_hip.h).
+extern "C" int dlip_conv2_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const float* x2, int32_t H2, int32_t W2,
+                                     int32_t C2, int32_t ldx2, int32_t stride2_h, int32_t stride2_w, const void* w_split,
+                                     const float* w_scale, const float* bias, const float* residual, const float* slope,
+                                     const float* post_scale, const float* post_shift, float* y, int32_t flags,
+                                     dlip_stream_t stream) {
+  DLIP_CHECK_ARG(d && x2 && (flags & 1) && H2 > 0 && W2 > 0 && C2 > 0 && (C2 & 31) == 0 && (ldx2 & 31) == 0 && ldx2 >= C2);
+  DLIP_CHECK_ARG(stride2_h > 0 && stride2_w > 0 && (reinterpret_cast<uintptr_t>(x2) & 15) == 0);
+  ConvArgs a;
+  const int rc = fill_f16x3(d, x, w_split, w_scale, bias, residual, slope, post_scale, post_shift, y, flags, &a);
+  if (rc != DLIP_OK) return rc;
+  // the shortcut reads pixel (ho * s2h, wo * s2w) of x2 for output pixel (ho, wo): it must exist for every one
+  DLIP_CHECK_ARG((d->Ho - 1) * stride2_h < H2 && (d->Wo - 1) * stride2_w < W2);
+  const long long x2_bytes = (((long long)d->N * H2 * W2 - 1) * ldx2 + C2) * 4;
+  const long long w_bytes = (long long)d->K * ((long long)a.rsc + C2) * 4;
+  if (x2_bytes > DLIP_MAX_BUFFER_BYTES || w_bytes > DLIP_MAX_BUFFER_BYTES) return DLIP_ERANGE;
+  a.x2 = x2; a.x2_bytes = (uint32_t)x2_bytes;
+  a.H2 = H2; a.W2 = W2; a.ldx2 = ldx2; a.s2h = stride2_h; a.s2w = stride2_w;
+  a.nk2 = C2 / 32;
+  a.nk += a.nk2;
+  a.rsc += C2;
+  a.w_bytes = (uint32_t)w_bytes;
+  const bool y_ok = (flags & 2) ? true : ((d->K & 3) == 0 && (d->ldy & 3) == 0);
+  DLIP_CHECK_ARG(y_ok && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 15) == 0));
+  return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) ? 1 : 0);
+}
+
+// conv whose epilogue keeps only segmented column sums (include/deeplip_hip.h).
+extern "C" int64_t dlip_conv_pool_partial_bytes(const dlip_conv_desc* d, int32_t* tile_rows) {
+  if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->K <= 0) return DLIP_EINVAL;
+  int bm = 0, bn = 0;
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  dlip_conv_dma_tile(M, d->K, d->R * d->S * ((d->C + 31) / 32), 2, &bm, &bn);
+  if (tile_rows) *tile_rows = bm;
+  const long long tiles_m = (M + bm - 1) / bm, Kp = (long long)(d->K + bn - 1) / bn * bn;
+  return tiles_m * 4 * Kp * 8;
+}
+
+extern "C" int dlip_conv_pool_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, const float* w_scale,
+                                    const float* bias, const float* residual, const float* slope, const float* post_scale,
+                                    const float* post_shift, double* partials, int64_t partial_bytes, int32_t group_rows,
+                                    dlip_stream_t stream) {
+  DLIP_CHECK_ARG(d && partials && group_rows > 0 && (reinterpret_cast<uintptr_t>(partials) & 7) == 0);
+  ConvArgs a;
+  dlip_conv_desc dd = *d;
+  dd.ldy = d->K;   // no y: the descriptor's output stride is not used
+  float* no_y = reinterpret_cast<float*>(partials);   // (never written: the pooled epilogue has no y stores)
+  const int rc = fill_f16x3(&dd, x, w_split, w_scale, bias, residual, slope, post_scale, post_shift, no_y, DLIP_SPLIT_IN, &a);
+  if (rc != DLIP_OK) return rc;
+  int32_t bm = 0;
+  const int64_t need = dlip_conv_pool_partial_bytes(d, &bm);
+  DLIP_CHECK_ARG(need > 0 && partial_bytes >= need && group_rows >= bm);
+  DLIP_CHECK_ARG(residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+  a.y = nullptr; a.y_bytes = 0;
+  a.pool = partials;
+  a.pool_group = group_rows;
+  return dlip_conv_f16x3_dma_launch(&a, stream, 2);
 }

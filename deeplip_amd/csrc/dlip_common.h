@@ -17,6 +17,24 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     if (!(cond)) return DLIP_EINVAL; \
   } while (0)
 
+// Diagnostic overrides (dlip_debug_set, include/deeplip_hip.h): -1 = the built-in choice.  Plain ints read on
+// the launch path -- the library itself reads no environment variable there.
+enum { DLIP_DBG_CONV_TILE = 0, DLIP_DBG_DMA_TILE = 1, DLIP_DBG_DMA_ENABLE = 2, DLIP_DBG_STREAMK = 3, DLIP_DBG_COUNT = 4 };
+extern "C" __attribute__((visibility("hidden"))) int dlip_dbg_value[DLIP_DBG_COUNT];
+
+// Range-status words (dlip_set_status_words): where the f16x3 kernels report an activation the split format
+// cannot hold.  NULL = not registered (nothing is reported).  One word per kernel family.
+enum { DLIP_ST_CONV = 0, DLIP_ST_STEM = 1, DLIP_ST_PACK = 2, DLIP_ST_POOL = 3, DLIP_ST_COUNT = 4 };
+extern "C" __attribute__((visibility("hidden"))) int32_t* dlip_status_words(void);
+#define DLIP_F16_OVERFLOW 65520.0f   // the smallest magnitude that rounds to infinity in fp16
+
+// Called once per wave at the end of a producer of split-format values: amax = the largest |v| the lane converted.
+__device__ __forceinline__ void dlip_report_range(float amax, int32_t* status_word) {
+  if (status_word != nullptr && __builtin_amdgcn_ballot_w64(!(amax < DLIP_F16_OVERFLOW)) != 0ull) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(status_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 static inline int dlip_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DLIP_OK : (int)e;

@@ -221,18 +221,20 @@ __global__ void pow2_finalize_kernel(float* __restrict__ out, float target) {
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void split_pack_scaled_kernel(const f32x4* __restrict__ x, float* __restrict__ y,
-                                                                const float* __restrict__ scale, long long n4) {
+                                                                const float* __restrict__ scale, long long n4, int32_t* status) {
   const float s = scale[0];
+  float amax = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const f32x4 v = x[i];
     h4 hi, lo;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const float t = v[k] * s; hi[k] = (_Float16)t; lo[k] = (_Float16)(t - (float)hi[k]); }
+    for (int k = 0; k < 4; ++k) { const float t = v[k] * s; hi[k] = (_Float16)t; lo[k] = (_Float16)(t - (float)hi[k]); amax = fmaxf(amax, fabsf(t)); }
     const long long blk = i >> 3; const int q = (int)(i & 7);
     float* b = y + blk * 32;
     *reinterpret_cast<h4*>(b + q * 2) = hi;
     *reinterpret_cast<h4*>(b + 16 + q * 2) = lo;
   }
+  dlip_report_range(amax, status);
 }
 
 __global__ __launch_bounds__(256) void fill_from_scalar_kernel(const float* __restrict__ src, float* __restrict__ y, int n) {
@@ -335,7 +337,7 @@ extern "C" int dlip_split_pack_scaled_f32(const float* x, float* y, const float*
   DLIP_CHECK_ARG(x && y && scale && rows > 0 && C > 0 && (C & 31) == 0);
   const long long n4 = rows * (C / 4);
   hipLaunchKernelGGL(split_pack_scaled_kernel, dim3(grid1d(n4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const f32x4*>(x), y, scale, n4);
+                     reinterpret_cast<const f32x4*>(x), y, scale, n4, dlip_status_words() ? dlip_status_words() + DLIP_ST_PACK : nullptr);
   return dlip_launch_status();
 }
 

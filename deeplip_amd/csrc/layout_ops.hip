@@ -26,6 +26,37 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
   }
 }
 
+// x [B,Cc,T] -> y [B,T,Cp] in the split activation format (Cp % 32 == 0, channels Cc..Cp-1 zero): the speech
+// encoder's input adapter and its split in one pass (one 32 x 32 tile per workgroup: 32 frames x one channel block).
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              int Cc, int T, int Cp, int32_t* status) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* xb = x + (long long)b * Cc * T;
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int c = c0 + ty + j, t = t0 + tx;
+    tile[ty + j][tx] = (c < Cc && t < T) ? xb[(long long)c * T + t] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int t = t0 + ty + j;
+    if (t < T) {
+      const float v = tile[tx][ty + j];
+      const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+      amax = fmaxf(amax, fabsf(v));
+      _Float16* blk = reinterpret_cast<_Float16*>(y + ((long long)b * T + t) * Cp + c0);
+      blk[tx] = hi;
+      blk[32 + tx] = lo;
+    }
+  }
+  dlip_report_range(amax, status);
+}
+
 __global__ __launch_bounds__(256) void ingest_rgb_kernel(const uint8_t* __restrict__ x, float* __restrict__ y,
                                                          long long n_frames, int HW) {
   const long long total = n_frames * HW;
@@ -46,6 +77,15 @@ extern "C" int dlip_nct_to_ntc_f32(const float* x, float* y, int32_t B, int32_t 
   // rows = C, cols = T  ->  y [B, T, Cp]
   dim3 grid((T + 31) / 32, (Cp + 31) / 32, B);
   hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, C, T, Cp);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_nct_to_ntc_split_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t Cp,
+                                         dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0 && Cp >= C && (Cp & 31) == 0 && B <= 65535);
+  dim3 grid((T + 31) / 32, Cp / 32, B);
+  hipLaunchKernelGGL(transpose_split_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, C, T, Cp,
+                     dlip_status_words() ? dlip_status_words() + DLIP_ST_PACK : nullptr);
   return dlip_launch_status();
 }
 
@@ -101,17 +141,20 @@ namespace {
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // fp32 [rows, C] <-> split format [rows, C/32 blocks, (32 hi halves | 32 lo halves)]  (C % 32 == 0).
 // One thread per 4 channels: 16 B in, 8 B of hi + 8 B of lo out (or the reverse).
-__global__ __launch_bounds__(256) void split_pack_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long long n4) {
+__global__ __launch_bounds__(256) void split_pack_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long long n4,
+                                                         int32_t* status) {
+  float amax = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const f32x4 v = x[i];
     h4 hi, lo;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { hi[k] = (_Float16)v[k]; lo[k] = (_Float16)(v[k] - (float)hi[k]); }
+    for (int k = 0; k < 4; ++k) { hi[k] = (_Float16)v[k]; lo[k] = (_Float16)(v[k] - (float)hi[k]); amax = fmaxf(amax, fabsf(v[k])); }
     const long long blk = i >> 3; const int q = (int)(i & 7);          // 8 float4 per 32-channel block
     float* b = y + blk * 32;
     *reinterpret_cast<h4*>(b + q * 2) = hi;        // halves 4q..4q+3 of the hi half (64 B)
     *reinterpret_cast<h4*>(b + 16 + q * 2) = lo;   // same position in the lo half
   }
+  dlip_report_range(amax, status);
 }
 __global__ __launch_bounds__(256) void split_unpack_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long long n4) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -131,7 +174,7 @@ extern "C" int dlip_split_pack_f32(const float* x, float* y, int64_t rows, int32
   const long long n4 = rows * (C / 4);
   long long g = (n4 + 255) / 256; if (g > 2048) g = 2048;
   hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const f32x4*>(x), y, n4);
+                     reinterpret_cast<const f32x4*>(x), y, n4, dlip_status_words() ? dlip_status_words() + DLIP_ST_PACK : nullptr);
   return dlip_launch_status();
 }
 

@@ -9,8 +9,9 @@ namespace {
 // MaxPool3d((1,3,3), s(1,2,2), p(0,1,1)) == per-frame MaxPool2d(3, 2, 1); padding never wins.
 template <bool OSPLIT>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
-                                                           int N, int H, int W, int C4, int Ho, int Wo) {
+                                                           int N, int H, int W, int C4, int Ho, int Wo, int32_t* status) {
   const long long total = (long long)N * Ho * Wo * C4;
+  float amax = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C4);
     long long p = i / C4;
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f32x4* __restri
       typedef _Float16 h4 __attribute__((ext_vector_type(4)));
       h4 hi, lo;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { hi[k] = (_Float16)m[k]; lo[k] = (_Float16)(m[k] - (float)hi[k]); }
+      for (int k = 0; k < 4; ++k) { hi[k] = (_Float16)m[k]; lo[k] = (_Float16)(m[k] - (float)hi[k]); amax = fmaxf(amax, fabsf(m[k])); }
       float* b = reinterpret_cast<float*>(y) + (i >> 3) * 32;
       const int q = (int)(i & 7);
       *reinterpret_cast<h4*>(b + q * 2) = hi;
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f32x4* __restri
       y[i] = m;
     }
   }
+  if constexpr (OSPLIT) dlip_report_range(amax, status);
 }
 
 // y[n,c] = mean over hw of x[n,hw,c]   (sequential fp32 sum, then one divide: AdaptiveAvgPool2d(1))
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict
 // split activation format; ldy = 2C rounded up to 32, padding zeroed) for the LDS-DMA GEMM behind it.
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      int T, int C, int ldy) {
+                                                      int T, int C, int ldy, int32_t* status) {
   __shared__ double part[16][64][2];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int lx = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ 
         _Float16* blk = reinterpret_cast<_Float16*>(y + (long long)b * ldy + (col & ~31));
         blk[col & 31] = hi;
         blk[32 + (col & 31)] = lo;
+        if (!(fabsf(out[h]) < DLIP_F16_OVERFLOW) && status) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       } else {
         y[(long long)b * ldy + col] = out[h];
       }
@@ -159,10 +162,11 @@ extern "C" int dlip_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, i
   const long long total = (long long)N * Ho * Wo * (C / 4);
   if (out_split)
     hipLaunchKernelGGL(maxpool3x3s2_kernel<true>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo);
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo,
+                       dlip_status_words() ? dlip_status_words() + DLIP_ST_PACK : nullptr);
   else
     hipLaunchKernelGGL(maxpool3x3s2_kernel<false>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo);
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo, nullptr);
   return dlip_launch_status();
 }
 
@@ -197,9 +201,10 @@ extern "C" int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_
   const dim3 grid((C + 63) / 64, B);
   if (out_split)
     hipLaunchKernelGGL(meanstd_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C,
-                       (2 * C + 31) / 32 * 32);
+                       (2 * C + 31) / 32 * 32, dlip_status_words() ? dlip_status_words() + DLIP_ST_POOL : nullptr);
   else
-    hipLaunchKernelGGL(meanstd_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C, 2 * C);
+    hipLaunchKernelGGL(meanstd_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C, 2 * C,
+                       (int32_t*)nullptr);
   return dlip_launch_status();
 }
 
@@ -258,5 +263,87 @@ extern "C" int dlip_attentive_stat_pool_f32(const float* x, const float* hidden,
   DLIP_CHECK_ARG(x && hidden && v && k && y && B > 0 && T > 0 && C > 0 && Hd > 0 && T <= 16000);
   hipLaunchKernelGGL(attentive_stat_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float),
                      static_cast<hipStream_t>(stream), x, hidden, v, k, y, T, C, Hd);
+  return dlip_launch_status();
+}
+
+namespace {
+// Finisher of the pooled convolution epilogue (conv_igemm_f16x3_dma.hip, EPI 2): partials [tiles_m][4][Kp] fp64 =
+// per tile the column sums {sum, sumsq} of the rows before the tile's group boundary (segment 0) and after it
+// (segment 1).  Group g = rows [g Gs, (g+1) Gs) touches tiles g Gs / BM .. ((g+1) Gs - 1) / BM; in each it is
+// segment 0 if the tile's first row belongs to g, else segment 1.  Tiles are added in row order.
+template <int MODE, bool SPLIT>
+__global__ __launch_bounds__(256) void pool_finish_kernel(const double* __restrict__ part, float* __restrict__ y, long long M,
+                                                          int K, int Kp, int BM, int Gs, int G, int ldy, int32_t* status) {
+  const long long total = (long long)G * K;
+  float amax = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    const long long g = i / K;
+    const long long r0 = g * Gs;
+    long long r1 = r0 + Gs;
+    if (r1 > M) r1 = M;
+    double s = 0.0, q = 0.0;
+    for (long long tm = r0 / BM; tm <= (r1 - 1) / BM; ++tm) {
+      const int seg = (tm * BM) / Gs == g ? 0 : 1;
+      const double* p = part + ((size_t)tm * 4 + 2 * seg) * Kp + k;
+      s += p[0];
+      q += p[Kp];
+    }
+    const double n = (double)(r1 - r0);
+    const double mean = s / n;
+    if (MODE == 0) {
+      y[g * ldy + k] = (float)mean;
+    } else {
+      double var = (q - s * mean) / (n - 1.0);   // n == 1 -> NaN, as torch.std
+      if (var < 0.0) var = 0.0;
+      const float out[2] = {(float)mean, (float)sqrt(var)};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = h * K + k;
+        if (SPLIT) {
+          const _Float16 hi = (_Float16)out[h], lo = (_Float16)(out[h] - (float)hi);
+          _Float16* blk = reinterpret_cast<_Float16*>(y + g * ldy + (col & ~31));
+          blk[col & 31] = hi;
+          blk[32 + (col & 31)] = lo;
+          amax = fmaxf(amax, fabsf(out[h]));
+        } else {
+          y[g * ldy + col] = out[h];
+        }
+      }
+    }
+  }
+  if (SPLIT) {
+    const long long pad_total = (long long)G * (ldy - 2 * K);   // zero the channel padding (< 32 values per row)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pad_total; i += (long long)gridDim.x * 256) {
+      const long long g = i / (ldy - 2 * K);
+      const int col = 2 * K + (int)(i % (ldy - 2 * K));
+      _Float16* blk = reinterpret_cast<_Float16*>(y + g * ldy + (col & ~31));
+      blk[col & 31] = (_Float16)0.f;
+      blk[32 + (col & 31)] = (_Float16)0.f;
+    }
+    dlip_report_range(amax, status);
+  }
+}
+}  // namespace
+
+extern "C" int dlip_pool_finish_f32(const double* partials, int64_t M, int32_t K, int32_t tile_rows, int32_t group_rows,
+                                    int32_t mode, int32_t out_split, float* y, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(partials && y && M > 0 && K > 0 && tile_rows > 0 && group_rows >= tile_rows && (mode == 0 || mode == 1));
+  DLIP_CHECK_ARG(!(out_split && mode == 0));
+  const int Kp = (K + 127) / 128 * 128;   // the pooled epilogue exists on the 128-column tiles only
+  const long long G = (M + group_rows - 1) / group_rows;
+  DLIP_CHECK_ARG(G <= 0x7FFFFFFF);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned grid = grid_for(G * K);
+  int32_t* status = dlip_status_words() ? dlip_status_words() + DLIP_ST_POOL : nullptr;
+  if (mode == 0)
+    hipLaunchKernelGGL((pool_finish_kernel<0, false>), dim3(grid), dim3(256), 0, st, partials, y, (long long)M, K, Kp, tile_rows,
+                       group_rows, (int)G, K, status);
+  else if (out_split)
+    hipLaunchKernelGGL((pool_finish_kernel<1, true>), dim3(grid), dim3(256), 0, st, partials, y, (long long)M, K, Kp, tile_rows,
+                       group_rows, (int)G, (2 * K + 31) / 32 * 32, status);
+  else
+    hipLaunchKernelGGL((pool_finish_kernel<1, false>), dim3(grid), dim3(256), 0, st, partials, y, (long long)M, K, Kp, tile_rows,
+                       group_rows, (int)G, 2 * K, status);
   return dlip_launch_status();
 }

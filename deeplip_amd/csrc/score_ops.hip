@@ -37,6 +37,32 @@ __global__ __launch_bounds__(256) void znorm_cat_kernel(const float* __restrict_
   if (Dv > 0) znorm_row(v + (long long)row * Dv, out + Da, Dv, lane, biased != 0);
 }
 
+// znorm_cat whose second table is still the pooled partial sums of the trunk's last convolution (dlip_conv_pool_f16x3):
+// the wave first finishes its clip's mean exactly as dlip_pool_finish_f32 mode 0 does (tiles in row order, fp64,
+// rounded to fp32 once), into its own slice of the output row, then z-normalises that slice in place.
+__global__ __launch_bounds__(256) void znorm_cat_pooled_kernel(const float* __restrict__ a, int Da,
+                                                               const double* __restrict__ part, long long M, int K, int Kp,
+                                                               int BM, int Gs, float* __restrict__ y, int U, int biased) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= U) return;
+  float* out = y + (long long)row * (Da + K);
+  if (Da > 0) znorm_row(a + (long long)row * Da, out, Da, lane, biased != 0);
+  const long long r0 = (long long)row * Gs;
+  long long r1 = r0 + Gs;
+  if (r1 > M) r1 = M;
+  const double n = (double)(r1 - r0);
+  for (int i = lane; i < K; i += 64) {
+    double s = 0.0;
+    for (long long tm = r0 / BM; tm <= (r1 - 1) / BM; ++tm) {
+      const int seg = (tm * BM) / Gs == row ? 0 : 1;
+      s += part[((size_t)tm * 4 + 2 * seg) * Kp + i];
+    }
+    out[Da + i] = (float)(s / n);
+  }
+  znorm_row(out + Da, out + Da, K, lane, biased != 0);   // a lane reads back only what it wrote itself
+}
+
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                      int U, int D, float eps) {
   const int lane = threadIdx.x & 63;
@@ -218,6 +244,17 @@ extern "C" int dlip_znorm_cat_f32(const float* a, int32_t Da, const float* v, in
   DLIP_CHECK_ARG((Da == 0 || a) && (Dv == 0 || v));
   hipLaunchKernelGGL(znorm_cat_kernel, dim3((U + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a, Da, v, Dv, y, U, biased);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_znorm_cat_pooled_f32(const float* a, int32_t Da, const double* partials, int64_t M, int32_t K,
+                                         int32_t tile_rows, int32_t group_rows, float* y, int32_t U, int32_t biased,
+                                         dlip_stream_t stream) {
+  DLIP_CHECK_ARG(y && partials && U > 0 && Da >= 0 && K > 0 && M > 0 && tile_rows > 0 && group_rows >= tile_rows);
+  DLIP_CHECK_ARG((Da == 0 || a) && (M + group_rows - 1) / group_rows == U);
+  hipLaunchKernelGGL(znorm_cat_pooled_kernel, dim3((U + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a, Da, partials, (long long)M, K, (K + 127) / 128 * 128, tile_rows,
+                     group_rows, y, U, biased);
   return dlip_launch_status();
 }
 

@@ -69,6 +69,7 @@ struct StemArgs {
   int pwp;             // window row pitch in dwords (>= W + 6, == 32 mod 64)
   int Hp, Wp;          // POOL: pooled output size
   int n_frames;        // POOL: B*T
+  int32_t* status;     // range-status word (NULL: not reported)
 };
 
 constexpr int HPITCH = 40;   // floats per (row, pooled column) of the POOL row buffer: 32 channels + 8 (bank spread)
@@ -128,11 +129,13 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
       pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)off, 0, 0));
     }
   };
+  float amax = 0.f;   // largest magnitude this lane splits (input pixels; POOL: output activations too)
   auto store_window = [&](uint32_t* patch) {   // split into (hi, lo) pairs and write the LDS window
 #pragma unroll
     for (int i = 0; i < PPER; ++i) {
       const int e = tid + 512 * i;
       if (e < psize) patch[e] = split_pair(pv[i]);
+      amax = fmaxf(amax, fabsf(pv[i]));
     }
   };
 
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
           typedef _Float16 h4 __attribute__((ext_vector_type(4)));
           h4 hi, lo;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); }
+          for (int c = 0; c < 4; ++c) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); amax = fmaxf(amax, fabsf(v[c])); }
           // split activation format: pixel = 64 channels = two 128-B blocks of (32 hi | 32 lo) halves
           const uint32_t off = (uint32_t)(((f * a.Hp + pr) * a.Wp + q) * 256 + h * 128 + c4 * 8);
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), yr, (int)off, 0, 0);
@@ -406,6 +409,7 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
     tile = next;
     __syncthreads();   // window (it+1) complete and window (it) free before the next iteration
   }
+  dlip_report_range(amax, a.status);
 }
 
 }  // namespace
@@ -434,8 +438,13 @@ extern "C" int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, con
   const long long grid = tiles < 256 ? tiles : 256;   // persistent: one workgroup per CU (154 KB of LDS each)
   const size_t ldsb = (size_t)WBYTES + 2 * (size_t)KT * PR * a.pwp * 4;
   auto kern = stem3d_f16x3_kernel<false>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-  if (e != hipSuccess) return (int)e;
+  a.status = dlip_status_words() ? dlip_status_words() + DLIP_ST_STEM : nullptr;
+  static size_t lds_set = 0;   // the attribute is raised once per size (not on every launch)
+  if (ldsb > lds_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) return (int)e;
+    lds_set = ldsb;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, static_cast<hipStream_t>(stream), a);
   return dlip_launch_status();
 }
@@ -464,8 +473,13 @@ extern "C" int dlip_stem3d_pool_f16x3(const float* x, const void* w_split, const
   const size_t ldsb = (size_t)WBYTES + (size_t)KT * PR * a.pwp * 4 + (size_t)(ROWS + 4) * a.Wp * HPITCH * 4 + 8 * 64 * 4;
   DLIP_CHECK_ARG(ldsb <= 160 * 1024);
   auto kern = stem3d_f16x3_kernel<true>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-  if (e != hipSuccess) return (int)e;
+  a.status = dlip_status_words() ? dlip_status_words() + DLIP_ST_STEM : nullptr;
+  static size_t lds_set = 0;   // the attribute is raised once per size (not on every launch)
+  if (ldsb > lds_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) return (int)e;
+    lds_set = ldsb;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, static_cast<hipStream_t>(stream), a);
   return dlip_launch_status();
 }

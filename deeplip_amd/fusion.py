@@ -74,6 +74,10 @@ def feature_normalize(data: torch.Tensor) -> torch.Tensor:
     return ops.znorm_cat(data.contiguous(), None)
 
 
-def fuse_av(xv_audio: torch.Tensor, em_video: torch.Tensor) -> torch.Tensor:
-    """train_fusion.py:353-358: cat([znorm(audio), znorm(video)], 1) in one launch -> [U, Da+Dv]."""
+def fuse_av(xv_audio: torch.Tensor, em_video) -> torch.Tensor:
+    """train_fusion.py:353-358: cat([znorm(audio), znorm(video)], 1) in one launch -> [U, Da+Dv].  ``em_video`` may be
+    the per-clip means [U,512] or what ``Lipreading.embed(x, finish=False)`` returns while they are still pooled partial
+    sums (ops.Pooled): the temporal mean of train_fusion.py:348 is then finished inside the same launch."""
+    if isinstance(em_video, ops.Pooled):
+        return ops.znorm_cat_pooled(xv_audio.contiguous(), em_video)
     return ops.znorm_cat(xv_audio.contiguous(), em_video.contiguous())

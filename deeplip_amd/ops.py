@@ -121,6 +121,118 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
     return out
 
 
+def conv2_nhwc(x: Tensor, x2: Tensor, w_split: Tensor, bias: Tensor, w_scale: Tensor, *, stride=(1, 1), pad=(0, 0),
+               dil=(1, 1), stride2=(2, 2), residual: Optional[Tensor] = None, slope: Optional[Tensor] = None,
+               out_split: bool = True) -> Tensor:
+    """One reduction over two sources (dlip_conv2_nhwc_f16x3): y = act(conv(x, w[..., taps]) + conv1x1(x2[::s2], w[..., tail])
+    + bias).  x [N,H,W,C], x2 [N,H2,W2,C2], both in the split activation format; ``w_split`` [K, R*S*C32 + C2] float32 view
+    of the jointly scaled split weights (packing.pack_conv2d_shortcut).  The BasicBlock shortcut (resnet.py:13-17,62-66)."""
+    for t, n in ((x, "x"), (x2, "x2"), (w_split, "w"), (bias, "bias"), (w_scale, "w_scale"), (residual, "residual"), (slope, "slope")):
+        _req(t, n)
+    N, H, W, Cx = x.shape
+    N2, H2, W2, C2 = x2.shape
+    K, RSC = w_split.shape
+    R = S = 3 if (RSC - C2) == 9 * Cx else 1
+    if N2 != N or RSC != R * S * Cx + C2 or Cx % 32 or C2 % 32:
+        raise ValueError(f"conv2_nhwc: weights {tuple(w_split.shape)} do not match x {tuple(x.shape)} + x2 {tuple(x2.shape)}")
+    Ho = conv_out_size(H, R, stride[0], pad[0], dil[0])
+    Wo = conv_out_size(W, S, stride[1], pad[1], dil[1])
+    if (Ho - 1) * stride2[0] >= H2 or (Wo - 1) * stride2[1] >= W2:
+        raise ValueError("conv2_nhwc: the shortcut source does not cover the output grid")
+    if out_split and K % 32:
+        raise ValueError("conv2_nhwc: split output needs K % 32 == 0")
+    out = _empty((N, Ho, Wo, K), x.device)
+    if residual is not None and tuple(residual.shape) != (N, Ho, Wo, K):
+        raise ValueError("conv2_nhwc: residual shape")
+    d = ConvDesc(N, H, W, Cx, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], Ho, Wo, Cx, K,
+                 K if residual is not None else 0)
+    hook = LAUNCH_HOOK
+    if hook is not None:
+        bm, bn = C.c_int32(), C.c_int32()
+        check(lib().dlip_conv_plan(C.byref(d), 3, C.byref(bm), C.byref(bn)), "dlip_conv_plan")
+        tok = hook.begin(f"conv_igemm_f16x3_dma_kernel<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * (R * S * Cx + C2))
+    _lib.ensure_conv_workspace()
+    check(lib().dlip_conv2_nhwc_f16x3(C.byref(d), ptr(x), ptr(x2), H2, W2, C2, C2, stride2[0], stride2[1], ptr(w_split),
+                                      ptr(w_scale), ptr(bias), ptr(residual), ptr(slope), None, None, ptr(out),
+                                      1 | 2 * int(out_split), stream_handle()), "dlip_conv2_nhwc_f16x3")
+    if hook is not None:
+        hook.end(tok)
+    return out
+
+
+class Pooled:
+    """Partial column sums of a pooled convolution (conv_pool) + what pool_finish needs to read them."""
+    __slots__ = ("partials", "M", "K", "tile_rows", "group_rows")
+
+    def __init__(self, partials, M, K, tile_rows, group_rows):
+        self.partials, self.M, self.K, self.tile_rows, self.group_rows = partials, M, K, tile_rows, group_rows
+
+
+def conv_pool_tile_rows(x: Tensor, w_krsc: Tensor, *, stride=(1, 1), pad=(0, 0), dil=(1, 1)) -> int:
+    """Rows of the workgroup tile conv_pool would use for this launch (group_rows must be >= it)."""
+    N, H, W, Cx = x.shape
+    K, R, S, Cw = w_krsc.shape
+    Ho = conv_out_size(H, R, stride[0], pad[0], dil[0])
+    Wo = conv_out_size(W, S, stride[1], pad[1], dil[1])
+    d = ConvDesc(N, H, W, Cx, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], Ho, Wo, Cx, K, 0)
+    bm = C.c_int32()
+    if int(lib().dlip_conv_pool_partial_bytes(C.byref(d), C.byref(bm))) <= 0:
+        raise _lib.DeepLipHipError("dlip_conv_pool_partial_bytes failed")
+    return bm.value
+
+
+def conv_pool(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor], w_scale: Tensor, group_rows: int, *, stride=(1, 1),
+              pad=(0, 0), dil=(1, 1), residual: Optional[Tensor] = None, slope: Optional[Tensor] = None,
+              post_scale: Optional[Tensor] = None, post_shift: Optional[Tensor] = None) -> Pooled:
+    """dlip_conv_pool_f16x3: the convolution of conv_nhwc (split-format x / residual) whose output is never written --
+    per workgroup tile only the fp64 column sums of y and y^2, cut at the boundaries of consecutive ``group_rows``-row
+    groups.  pool_finish turns them into group means (AdaptiveAvgPool + temporal mean, resnet.py:125-126 +
+    train_fusion.py:348) or mean | std (MeanStdPooling, pooling.py:24-26)."""
+    for t, n in ((x, "x"), (w_krsc, "w"), (bias, "bias"), (w_scale, "w_scale"), (residual, "residual"), (slope, "slope"),
+                 (post_scale, "post_scale"), (post_shift, "post_shift")):
+        _req(t, n)
+    N, H, W, Cx = x.shape
+    K, R, S, Cw = w_krsc.shape
+    if Cx % 32 or Cw != Cx:
+        raise ValueError("conv_pool: split-format input with C % 32 == 0 and matching split weights required")
+    Ho = conv_out_size(H, R, stride[0], pad[0], dil[0])
+    Wo = conv_out_size(W, S, stride[1], pad[1], dil[1])
+    if residual is not None and (tuple(residual.shape[:3]) != (N, Ho, Wo) or residual.shape[3] != K or K % 32):
+        raise ValueError("conv_pool: residual shape")
+    d = ConvDesc(N, H, W, Cx, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], Ho, Wo, Cx, K,
+                 K if residual is not None else 0)
+    bm = C.c_int32()
+    nbytes = int(lib().dlip_conv_pool_partial_bytes(C.byref(d), C.byref(bm)))
+    if nbytes <= 0:
+        raise _lib.DeepLipHipError("dlip_conv_pool_partial_bytes failed")
+    if group_rows < bm.value:
+        raise ValueError(f"conv_pool: group_rows {group_rows} < tile rows {bm.value}; use the unfused path")
+    part = _empty((nbytes // 8,), x.device, torch.float64)
+    hook = LAUNCH_HOOK
+    if hook is not None:
+        tok = hook.begin(f"conv_igemm_f16x3_dma_kernel<{bm.value},128>", 2.0 * N * Ho * Wo * K * R * S * Cx)
+    _lib.ensure_conv_workspace()
+    check(lib().dlip_conv_pool_f16x3(C.byref(d), ptr(x), ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(residual), ptr(slope),
+                                     ptr(post_scale), ptr(post_shift), ptr(part), nbytes, group_rows, stream_handle()),
+          "dlip_conv_pool_f16x3")
+    if hook is not None:
+        hook.end(tok)
+    return Pooled(part, N * Ho * Wo, K, bm.value, group_rows)
+
+
+def pool_finish(p: Pooled, mode: str = "mean", out_split: bool = False) -> Tensor:
+    """Pooled partial sums -> [G,K] group means ('mean') or [G,2K] mean | unbiased std ('meanstd'; ``out_split``: [G, 2K
+    rounded up to 32] in the split activation format)."""
+    G = (p.M + p.group_rows - 1) // p.group_rows
+    if mode == "mean":
+        y = _empty((G, p.K), p.partials.device)
+    else:
+        y = _empty((G, (2 * p.K + 31) // 32 * 32 if out_split else 2 * p.K), p.partials.device)
+    check(lib().dlip_pool_finish_f32(ptr(p.partials), p.M, p.K, p.tile_rows, p.group_rows, 0 if mode == "mean" else 1,
+                                     int(out_split), ptr(y), stream_handle()), "dlip_pool_finish_f32")
+    return y
+
+
 def linear(x: Tensor, w_kc: Tensor, bias: Optional[Tensor] = None, **kw) -> Tensor:
     """x [M,C] @ w [K,C]^T (+ epilogue) -> [M,K], through the same implicit-GEMM kernel."""
     M, Cx = x.shape
@@ -261,11 +373,15 @@ def meanstd_pool(x: Tensor, out_split: bool = False) -> Tensor:
     return y
 
 
-def nct_to_ntc(x: Tensor, pad_to: Optional[int] = None) -> Tensor:
+def nct_to_ntc(x: Tensor, pad_to: Optional[int] = None, out_split: bool = False) -> Tensor:
+    """[B,C,T] -> [B,T,Cp] channels-last, zero-padded to Cp; ``out_split``: in the split activation format (Cp % 32 == 0)."""
     _req(x, "x")
     B, Cc, T = x.shape
     Cp = Cc if pad_to is None else pad_to
     y = _empty((B, T, Cp), x.device)
+    if out_split:
+        check(lib().dlip_nct_to_ntc_split_f32(ptr(x), ptr(y), B, Cc, T, Cp, stream_handle()), "dlip_nct_to_ntc_split_f32")
+        return y
     check(lib().dlip_nct_to_ntc_f32(ptr(x), ptr(y), B, Cc, T, Cp, stream_handle()), "dlip_nct_to_ntc_f32")
     return y
 
@@ -305,6 +421,19 @@ def znorm_cat(a: Optional[Tensor], v: Optional[Tensor], biased: bool = False) ->
     Dv = v.shape[1] if v is not None else 0
     y = _empty((U, Da + Dv), (a if a is not None else v).device)
     check(lib().dlip_znorm_cat_f32(ptr(a), Da, ptr(v), Dv, ptr(y), U, int(biased), stream_handle()), "dlip_znorm_cat_f32")
+    return y
+
+
+def znorm_cat_pooled(a: Optional[Tensor], p: "Pooled", biased: bool = False) -> Tensor:
+    """znorm_cat(a, pool_finish(p, 'mean')) in one launch (bit-identical to the two)."""
+    _req(a, "a")
+    U = (p.M + p.group_rows - 1) // p.group_rows
+    Da = a.shape[1] if a is not None else 0
+    if a is not None and a.shape[0] != U:
+        raise ValueError(f"znorm_cat_pooled: {a.shape[0]} rows of a, {U} pooled groups")
+    y = _empty((U, Da + p.K), p.partials.device)
+    check(lib().dlip_znorm_cat_pooled_f32(ptr(a), Da, ptr(p.partials), p.M, p.K, p.tile_rows, p.group_rows, ptr(y), U,
+                                          int(biased), stream_handle()), "dlip_znorm_cat_pooled_f32")
     return y
 
 

@@ -104,6 +104,23 @@ def pack_conv2d(weight, bias, bn, device, slope=None) -> Packed:
     return _finish(w.permute(0, 2, 3, 1).contiguous(), b, device, slope)
 
 
+def pack_conv2d_shortcut(weight, bn, down_weight, down_bn, device, slope=None) -> Packed:
+    """conv2 [K,C,3,3] + bn2 and the shortcut's 1x1 stride-2 conv [K,C2,1,1] + BatchNorm (resnet.py:13-17) as ONE
+    reduction: rows [K, 9*C32 | C2] under one per-channel power-of-two scale, bias = sum of the folded biases
+    (dlip_conv2_nhwc_f16x3).  f16x3 packing only."""
+    if PRECISION != "f16x3":
+        raise ValueError("pack_conv2d_shortcut: split-fp16 packing only")
+    w, b = fold(weight, None, bn)
+    wd, bd = fold(down_weight, None, down_bn)
+    K, C = w.shape[0], w.shape[1]
+    C2 = wd.shape[1]
+    if C % 32 or C2 % 32:
+        raise ValueError("pack_conv2d_shortcut: channel counts must be multiples of 32")
+    rows = torch.cat([w.permute(0, 2, 3, 1).reshape(K, -1), wd.reshape(K, C2)], dim=1)   # [K, 9C + C2], 32-blocks intact
+    ws, sc = split_weights(rows)
+    return Packed(ws.contiguous().to(device), _dev(b + bd, device), slope, wscale=sc.to(device))
+
+
 def pack_conv1d(weight, bias, bn, device, slope=None, cin_pad: Optional[int] = None) -> Packed:
     """[K,C,S] -> [K,S,Cp] (input channels zero-padded to Cp)."""
     w, b = fold(weight, bias, bn)

@@ -28,7 +28,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 
 from . import holders, ops
-from ._lib import DeepLipHipError, check, lib
+from ._lib import DeepLipHipError, check, check_range, lib
 
 Tensor = torch.Tensor
 
@@ -127,6 +127,7 @@ class StepPlan:
         which the next run overwrites."""
         if self._gen != holders.PACK_GEN[0]:
             raise StalePlanError("StepPlan: model weights / placement changed since the plan was recorded; record a new plan")
+        check_range()           # f16x3 overflow reported by an earlier replay (host read, no synchronisation)
         check(lib().dlip_plan_run(self._handle, torch.cuda.current_stream(self.device).cuda_stream), "dlip_plan_run")
         return self.outputs
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 14
+#define DLIP_ABI_VERSION 15
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -91,6 +91,41 @@ int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_
                          const float* w_scale, const float* bias, const float* residual,
                          const float* slope, const float* post_scale, const float* post_shift,
                          float* y, int32_t flags, dlip_stream_t stream);
+
+/* dlip_conv_nhwc_f16x3 with a SECOND reduction source: y = epilogue( conv(x, w[:, taps]) + conv1x1_strided(x2, w[:, tail]) ).
+ * Replaces conv2 + bn2 and the shortcut's 1x1 stride-2 convolution + BatchNorm of a down-sampling BasicBlock
+ * (models/video_models/resnet.py:13-17 downsample_basic_block, :55-69 forward: `out += residual` with
+ * residual = self.downsample(x)) in ONE launch: both BatchNorms are folded into the weights, so the sum of the two
+ * convolutions is one reduction over [R*S*C32 taps | C2 shortcut channels] (what w_split holds per output channel,
+ * under one power-of-two scale w_scale[k]); bias = the sum of the two folded biases.  x2 is [N,H2,W2,C2] in the
+ * split activation format (DLIP_SPLIT_IN is mandatory), read at pixel (ho*stride2_h, wo*stride2_w) for output pixel
+ * (ho, wo); C2, ldx2 multiples of 32.  residual may still be given (added after both).  Split-format kernel only. */
+int dlip_conv2_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const float* x2, int32_t H2, int32_t W2,
+                          int32_t C2, int32_t ldx2, int32_t stride2_h, int32_t stride2_w, const void* w_split,
+                          const float* w_scale, const float* bias, const float* residual, const float* slope,
+                          const float* post_scale, const float* post_shift, float* y, int32_t flags,
+                          dlip_stream_t stream);
+
+/* dlip_conv_nhwc_f16x3 (DLIP_SPLIT_IN) whose epilogue keeps only POOLED STATISTICS of its output: the rows
+ * m = (n, ho, wo) are cut into consecutive groups of `group_rows` (a clip's T*Ho*Wo feature-map pixels; an
+ * utterance's T' frames) and every workgroup tile stores, per group segment it contains, the fp64 column sums of
+ * y and y^2 -- the [M,K] output itself never reaches memory.  dlip_pool_finish_f32 turns the partial sums into
+ *   mode 0: the group means  [G,K]   (AdaptiveAvgPool2d(1) + the temporal mean of the lip-clip features:
+ *           models/video_models/resnet.py:125-126, train_fusion.py:274,348 -- a mean of equal-sized means)
+ *   mode 1: mean | unbiased std [G,2K] (MeanStdPooling, models/audio_models/pooling.py:24-26), optionally in the
+ *           split activation format ([G, 2K rounded up to 32], what fc1's kernel reads).
+ * partials: caller-owned, dlip_conv_pool_partial_bytes(d, &tile_rows) bytes (8-byte aligned); group_rows must be
+ * >= tile_rows (a tile then holds at most one group boundary) -- callers fall back to the unfused kernels
+ * otherwise.  Sums are formed in a fixed order: results do not depend on scheduling. */
+int64_t dlip_conv_pool_partial_bytes(const dlip_conv_desc* d, int32_t* tile_rows);
+int dlip_conv_pool_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, const float* w_scale,
+                         const float* bias, const float* residual, const float* slope, const float* post_scale,
+                         const float* post_shift, double* partials, int64_t partial_bytes, int32_t group_rows,
+                         dlip_stream_t stream);
+/* M = rows of the pooled convolution, K its channels, tile_rows as reported by dlip_conv_pool_partial_bytes.
+ * y: mode 0 [G,K]; mode 1 [G,2K] or, with out_split != 0, [G, 2K rounded up to 32] split format (padding zeroed). */
+int dlip_pool_finish_f32(const double* partials, int64_t M, int32_t K, int32_t tile_rows, int32_t group_rows,
+                         int32_t mode, int32_t out_split, float* y, dlip_stream_t stream);
 
 /* Workspace of dlip_conv_nhwc_f16x3's balanced ("stream-K") work split on split-format activations:
  * ticket counters + partial-tile slabs, one block PER STREAM (launches on a stream are ordered and share
@@ -183,6 +218,9 @@ int dlip_nct_to_ntc_f32(const float* x, float* y, int32_t B, int32_t C, int32_t 
                         dlip_stream_t stream);
 int dlip_ntc_to_nct_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
                         dlip_stream_t stream);
+/* dlip_nct_to_ntc_f32 + dlip_split_pack_f32 in one pass: y [B,T,Cp] in the split activation format, Cp % 32 == 0. */
+int dlip_nct_to_ntc_split_f32(const float* x, float* y, int32_t B, int32_t C, int32_t T, int32_t Cp,
+                              dlip_stream_t stream);
 int dlip_ingest_rgb_u8(const uint8_t* x, float* y, int64_t n_frames, int32_t H, int32_t W,
                        dlip_stream_t stream);
 
@@ -198,6 +236,14 @@ int dlip_affine_act_f32(const float* x, const float* scale, const float* shift, 
  * (models/fusion_models/utils.py:524-527, feature-fusion scoring). */
 int dlip_znorm_cat_f32(const float* a, int32_t Da, const float* v, int32_t Dv, float* y, int32_t U,
                        int32_t biased, dlip_stream_t stream);
+
+/* dlip_znorm_cat_f32 whose second table is the per-clip mean still held as pooled partial sums (dlip_conv_pool_f16x3
+ * over groups of T*Ho*Wo rows; M, K, tile_rows, group_rows as for dlip_pool_finish_f32, U = number of groups): the
+ * temporal mean of train_fusion.py:348 and the fusion of :353-358 in one launch; bit-identical to
+ * dlip_pool_finish_f32 (mode 0) followed by dlip_znorm_cat_f32. */
+int dlip_znorm_cat_pooled_f32(const float* a, int32_t Da, const double* partials, int64_t M, int32_t K,
+                              int32_t tile_rows, int32_t group_rows, float* y, int32_t U, int32_t biased,
+                              dlip_stream_t stream);
 
 /* y[u,:] = x[u,:] / max(||x[u,:]||_2, eps)   (F.normalize; loss.py:44, train_audio.py:355). */
 int dlip_l2_normalize_f32(const float* x, float* y, int32_t U, int32_t D, float eps,
@@ -385,6 +431,23 @@ int dlip_row_broadcast_f32(const float* dy, const int32_t* lengths, float* dx, i
 int dlip_stem_im2col_f32(const float* x, float* col, int32_t B, int32_t T, int32_t H, int32_t W, dlip_stream_t stream);
 /* y = x * mask * scale (nn.Dropout forward / backward, tcn.py:80,85). */
 int dlip_mul_mask_f32(const float* x, const float* mask, float* y, int64_t n, float scale, dlip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Range status of the split-fp16 ("f16x3") arithmetic.  The reference computes in fp32 end to end
+ * (models/video_models/model.py:82-85); the split activation format stores a value as hi + lo fp16, so a value
+ * of magnitude >= 65520 becomes infinite.  Every kernel that PRODUCES split-format values (conv epilogues with
+ * DLIP_SPLIT_OUT, dlip_split_pack*_f32, the fused stem + pool, pooling with out_split) stores 1 into its word of
+ * a caller-owned status block when it meets such a value; the host reads the words (device memory after a
+ * synchronisation, or host-pinned device-visible memory at any time), raises, and the documented recourse is to
+ * re-pack that model in the exact "f32" mode (same engine).  words = int32[4] {conv, stem, split_pack, pooling},
+ * zeroed by the caller; NULL unregisters (nothing is reported).  One block per process (one process per GPU).
+ * ------------------------------------------------------------------------------------------ */
+int dlip_set_status_words(int32_t* words);
+
+/* Diagnostic overrides for tests and A/B runs (the launch path reads no environment variable):
+ * key 0 tile of dlip_conv_nhwc_f32 / the register-staged f16x3 kernel, 1 tile of the LDS-DMA kernel,
+ * 2 LDS-DMA kernel on/off (0 = off), 3 balanced split (0 never, 2 always); value -1 restores the built-in choice. */
+int dlip_debug_set(int32_t key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------
  * Step plans.  The reference drives its encoders from a Python loop, one utterance and one torch.nn layer

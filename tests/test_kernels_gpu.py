@@ -399,12 +399,20 @@ def test_conv_nhwc_f16x3_split_formats(ops, case, fmt):
     assert rel_err(y.cpu().numpy(), base.cpu().numpy()) < 2e-6
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 19, 20, 21, 22])
+@pytest.fixture
+def force_dma_tile():
+    """Forces a tile of the LDS-DMA kernel through dlip_debug_set (the library reads no environment variable on
+    the launch path) and restores the built-in choice afterwards."""
+    from deeplip_amd import _lib
+    yield lambda tile: _lib.debug_set(_lib.DBG_DMA_TILE, tile)
+    _lib.debug_set(_lib.DBG_DMA_TILE, -1)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", SPLIT_FMT_CASES, ids=lambda c: "x".join(str(v) for v in c[:10]))
-def test_conv_dma_tile_variants(ops, case, tile, monkeypatch):
-    """Every product instance of the LDS-DMA kernel (tile menu entries 0..5, on v_mfma_f32_16x16x32_f16) and
-    its 32x32x16 twin (10..14) forced onto every split-format case: same result as the fp32-format
-    kernel, whatever tile the shape would normally get."""
+def test_conv_dma_tile_variants(ops, case, tile, force_dma_tile):
+    """Every instance of the LDS-DMA kernel (tile menu entries 0..5) forced onto every split-format case: same
+    result as the fp32-format kernel, whatever tile the shape would normally get."""
     from deeplip_amd import packing
     N, H, W, C, K, R, S, stride, pad, dil, use_res, use_slope = case
     x = _split_ref_value(rnd(N, H, W, C, seed=1) * 3.0)
@@ -420,7 +428,7 @@ def test_conv_dma_tile_variants(ops, case, tile, monkeypatch):
     base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), **kw)
     res = _split_ref_value(rnd(*base.shape, seed=4)).cuda() if use_res else None
     base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), residual=res, **kw)
-    monkeypatch.setenv("DLIP_CONV_DMA_TILE", str(tile))
+    force_dma_tile(tile)
     for out_split in (True, False):
         y = ops.conv_nhwc(ops.split_pack(xd), ws.cuda(), b.cuda(), residual=ops.split_pack(res) if res is not None else None,
                           x_split=True, out_split=out_split, **kw)
@@ -588,36 +596,149 @@ def test_plda_scoring_kernel_and_eer(ops, tmp_path):
     assert 0.0 <= eer < 0.2
 
 
-@pytest.mark.parametrize("case", [(3, 22, 22, 64, 64, 3, 3, 1, 1, 1, True, True), (260, 22, 22, 64, 64, 3, 3, 1, 1, 1, True, True),
-                                  (7, 9, 13, 64, 64, 3, 3, 1, 1, 1, False, True), (2, 1, 70, 64, 64, 1, 5, 1, 4, 2, True, False),
-                                  (5, 11, 11, 64, 64, 1, 1, 1, 0, 1, False, True)],
-                         ids=lambda c: "x".join(str(v) for v in c[:10]))
-@pytest.mark.parametrize("out_split", [True, False])
-def test_conv_weights_resident_kernel(ops, case, out_split, monkeypatch):
-    """The experimental 64 -> 64 channel kernel with the filter bank resident in LDS (conv_wres_f16x3.hip; off by
-    default: slower than the ring kernel), forced on whatever the size (DLIP_CONV_WRES=2): same result as the fp32-format kernel, residual / slope / ragged
-    M tail / 1-D dilated taps included; switched off it gives the ring kernel's result (the two differ only by the
-    fp32 summation order)."""
+
+
+# ---- fusions of round 2: shortcut convolution as extra reduction slices, pooled epilogue, fused input adapter ----
+SHORTCUT_CASES = [  # N, H (= W) of the block input, C2 = inplanes, K = planes, out_split, forced tile
+    (5, 10, 64, 128, True, None), (5, 10, 64, 128, False, None), (3, 11, 128, 256, True, 0), (40, 6, 256, 512, True, 5),
+    (7, 9, 64, 64, True, 1), (2, 6, 64, 128, True, 4), (1, 4, 32, 64, False, 3), (1, 6, 32, 128, True, 2),
+]
+
+
+@pytest.mark.parametrize("case", SHORTCUT_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv2_shortcut_matches_two_convolutions(ops, case, force_dma_tile):
+    """dlip_conv2_nhwc_f16x3: conv3x3(h) + conv1x1_stride2(x) + bias in ONE reduction == the two launches it replaces
+    (BasicBlock with downsample, resnet.py:13-17,62-68), against an fp64 reference; every tile of the menu."""
     from deeplip_amd import packing
-    N, H, W, C, K, R, S, stride, pad, dil, use_res, use_slope = case
-    x = _split_ref_value(rnd(N, H, W, C, seed=1) * 3.0)
-    w = rnd(K, R, S, C, seed=2, scale=1.0 / np.sqrt(C * R * S))
-    b = rnd(K, seed=3, scale=0.1)
+    N, Hin, C2, K, out_split, tile = case
+    Ho = (Hin - 1) // 2 + 1
+    x = _split_ref_value(rnd(N, Hin, Hin, C2, seed=51) * 2.0)            # block input (shortcut source)
+    h = _split_ref_value(rnd(N, Ho, Ho, K, seed=52) * 2.0)               # conv1 output (conv2 source)
+    w2 = rnd(K, K, 3, 3, seed=53, scale=1.0 / np.sqrt(9 * K))
+    wd = rnd(K, C2, 1, 1, seed=54, scale=1.0 / np.sqrt(C2))
+    b = rnd(K, seed=55, scale=0.1)
+    slope = (torch.rand(K, generator=torch.Generator().manual_seed(5)) * 0.3)
+    ref = F.conv2d(h.permute(0, 3, 1, 2).double(), w2.double(), None, padding=1) + \
+        F.conv2d(x.permute(0, 3, 1, 2).double(), wd.double(), None, stride=2) + b.double().view(1, K, 1, 1)
+    ref = torch.where(ref >= 0, ref, ref * slope.double().view(1, K, 1, 1)).permute(0, 2, 3, 1)
+    rows = torch.cat([w2.double().permute(0, 2, 3, 1).reshape(K, -1), wd.double().reshape(K, C2)], dim=1)
+    ws, sc = packing.split_weights(rows)
+    if tile is not None:
+        force_dma_tile(tile)
+    y = ops.conv2_nhwc(ops.split_pack(h.cuda()), ops.split_pack(x.cuda()), ws.cuda(), b.cuda(), sc.cuda(), pad=(1, 1),
+                       stride2=(2, 2), slope=slope.cuda(), out_split=out_split)
+    if out_split:
+        y = ops.split_unpack(y)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < TOL
+    assert np.abs(y.cpu().numpy() - ref.numpy()).max() < 2e-5 * np.abs(ref.numpy()).max()
+
+
+POOL_CASES = [  # N, H, W, C, K, R, S, pad, dil, group rows (in output pixels), residual, post-affine
+    (58, 3, 3, 512, 512, 3, 3, 1, 1, 29 * 9, True, False),      # 2 clips of 29 frames: the trunk's last convolution (128x128 tile)
+    (64 * 29, 3, 3, 512, 512, 3, 3, 1, 1, 29 * 9, True, False), # bench shape: 256x128 tile, balanced split, 64 groups
+    (5, 1, 278, 512, 1500, 1, 1, 0, 1, 278, False, False),     # tdnn.9: K tail (1500), groups = utterances
+    (3, 1, 150, 512, 192, 1, 3, 0, 2, 146, False, True),       # dilated taps, conv -> LReLU -> BN order, ragged last tile
+    (2, 1, 300, 64, 96, 1, 1, 0, 1, 128, False, False),        # group == tile rows: every tile starts a new group
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_pool_epilogue(ops, case):
+    """dlip_conv_pool_f16x3 + dlip_pool_finish_f32 == the convolution followed by the group mean (AdaptiveAvgPool +
+    temporal mean, resnet.py:125-126 / train_fusion.py:348) and by mean | unbiased std (pooling.py:24-26)."""
+    from deeplip_amd import packing
+    N, H, W, C, K, R, S, pad, dil, group, use_res, post = case
+    x = _split_ref_value(rnd(N, H, W, C, seed=61) * 2.0)
+    w = rnd(K, R, S, C, seed=62, scale=1.0 / np.sqrt(C * R * S))
+    b = rnd(K, seed=63, scale=0.1)
+    slope = (torch.rand(K, generator=torch.Generator().manual_seed(7)) * 0.3).cuda()
     ph, pw = (0, pad) if H == 1 else (pad, pad)
     dh, dw = (1, dil) if H == 1 else (dil, dil)
     ws, sc = packing.split_weights(w.double())
-    slope = (torch.rand(K, generator=torch.Generator().manual_seed(5)) * 0.3).cuda() if use_slope else None
-    kw = dict(pad=(ph, pw), dil=(dh, dw), slope=slope, w_scale=sc.cuda())
-    xd = x.cuda()
-    base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), **kw)
-    res = _split_ref_value(rnd(*base.shape, seed=4)).cuda() if use_res else None
-    base = ops.conv_nhwc(xd, ws.cuda(), b.cuda(), residual=res, **kw)
-    outs = {}
-    for mode in ("2", "0"):
-        monkeypatch.setenv("DLIP_CONV_WRES", mode)
-        y = ops.conv_nhwc(ops.split_pack(xd), ws.cuda(), b.cuda(), residual=ops.split_pack(res) if res is not None else None,
-                          x_split=True, out_split=out_split, **kw)
-        outs[mode] = ops.split_unpack(y) if out_split else y
-        torch.cuda.synchronize()
-        assert rel_err(outs[mode].cpu().numpy(), base.cpu().numpy()) < 2e-6, mode
-    assert rel_err(outs["2"].cpu().numpy(), outs["0"].cpu().numpy()) < 2e-6
+    kw = dict(pad=(ph, pw), dil=(dh, dw), slope=slope)
+    if post:
+        kw["post_scale"] = (0.5 + torch.rand(K, generator=torch.Generator().manual_seed(8))).cuda()
+        kw["post_shift"] = rnd(K, seed=9, scale=0.1).cuda()
+    xs = ops.split_pack(x.cuda())
+    full = ops.conv_nhwc(xs, ws.cuda(), b.cuda(), w_scale=sc.cuda(), x_split=True, **kw)          # shape probe
+    res = _split_ref_value(rnd(*full.shape, seed=64)).cuda() if use_res else None
+    rs = ops.split_pack(res) if res is not None else None
+    full = ops.conv_nhwc(xs, ws.cuda(), b.cuda(), w_scale=sc.cuda(), x_split=True, residual=rs, **kw)
+    rows = full.reshape(-1, K).double().cpu()
+    M = rows.shape[0]
+    G = (M + group - 1) // group
+    pooled = ops.conv_pool(xs, ws.cuda(), b.cuda(), sc.cuda(), group, residual=rs, **kw)
+    assert pooled.group_rows >= pooled.tile_rows and pooled.M == M
+    mean = ops.pool_finish(pooled, "mean")
+    ms = ops.pool_finish(pooled, "meanstd")
+    mss = ops.split_unpack(ops.pool_finish(pooled, "meanstd", out_split=True))
+    torch.cuda.synchronize()
+    ref_mean = torch.stack([rows[g * group:(g + 1) * group].mean(0) for g in range(G)])
+    ref_std = torch.stack([rows[g * group:(g + 1) * group].std(0) for g in range(G)])
+    assert mean.shape == (G, K) and ms.shape == (G, 2 * K)
+    assert rel_err(mean.cpu().numpy(), ref_mean.numpy()) < 1e-6
+    assert rel_err(ms[:, :K].cpu().numpy(), ref_mean.numpy()) < 1e-6
+    assert rel_err(ms[:, K:].cpu().numpy(), ref_std.numpy()) < 1e-6
+    assert rel_err(mss[:, :2 * K].cpu().numpy(), ms.cpu().numpy()) < 1e-6
+    assert float(mss[:, 2 * K:].abs().max()) == 0.0 if mss.shape[1] > 2 * K else True
+    # deterministic: a second launch gives the same bits
+    again = ops.pool_finish(ops.conv_pool(xs, ws.cuda(), b.cuda(), sc.cuda(), group, residual=rs, **kw), "meanstd")
+    torch.cuda.synchronize()
+    assert torch.equal(again, ms)
+
+
+def test_conv_pool_rejects_short_groups(ops):
+    from deeplip_amd import packing
+    x = ops.split_pack(rnd(2, 1, 300, 64, seed=1).cuda())
+    ws, sc = packing.split_weights(rnd(96, 1, 1, 64, seed=2).double())
+    with pytest.raises(ValueError):
+        ops.conv_pool(x, ws.cuda(), None, sc.cuda(), 100)      # a 128-row tile could hold two group boundaries
+
+
+@pytest.mark.parametrize("shape", [(3, 24, 150), (2, 80, 300), (1, 33, 37)], ids=str)
+def test_nct_to_ntc_split_is_transpose_then_split_pack(ops, shape):
+    B, Cc, T = shape
+    x = (rnd(B, Cc, T, seed=71) * 4.0).cuda()
+    Cp = (Cc + 31) // 32 * 32
+    two = ops.split_pack(ops.nct_to_ntc(x, pad_to=Cp))
+    one = ops.nct_to_ntc(x, pad_to=Cp, out_split=True)
+    torch.cuda.synchronize()
+    assert torch.equal(one.view(torch.int32), two.view(torch.int32))
+
+
+def test_conv_dma_balanced_split_stress_under_uneven_load(ops):
+    """The slab hand-off of the balanced split (sc1 write-through slab stores -> drained -> barrier -> relaxed agent
+    ticket; finisher: agent acquire -> barrier -> sc1 slab loads) over hundreds of launches with the split FORCED on
+    (dlip_debug_set DLIP_DBG_STREAMK = 2), a second stream hammering HBM beside it (uneven load, consumers L1-warm from
+    the previous launch): every launch must give the same bits as the first, and those must be right."""
+    from deeplip_amd import _lib, packing
+    try:
+        _lib.debug_set(_lib.DBG_STREAMK, 2)
+        side = torch.cuda.Stream()
+        junk = torch.empty(64 << 20, device="cuda")
+        for shape in [(700, 6, 6, 256, 256, 3), (64, 1, 296, 512, 512, 1)]:
+            N, H, W, C, K, S = shape
+            x = ops.split_pack((rnd(N, H, W, C, seed=91) * 2.0).cuda())
+            R = 1 if H == 1 else S
+            w = rnd(K, R, S, C, seed=92, scale=1.0 / np.sqrt(C * R * S))
+            ws, sc = packing.split_weights(w.double())
+            ws, sc = ws.cuda(), sc.cuda()
+            b = rnd(K, seed=93, scale=0.1).cuda()
+            kw = dict(pad=(0 if H == 1 else S // 2, S // 2), w_scale=sc, x_split=True)
+            first = ops.conv_nhwc(x, ws, b, **kw).clone()
+            y = torch.empty_like(first)
+            bad = 0
+            for i in range(150):
+                if i % 3 == 0:
+                    with torch.cuda.stream(side):
+                        junk.add_(1.0)                 # HBM traffic on other CUs while the tiles hand over
+                ops.conv_nhwc(x, ws, b, out=y, **kw)
+                bad += int(not torch.equal(y, first))
+            torch.cuda.synchronize()
+            assert bad == 0, (shape, bad)
+            ref = F.conv2d(ops.split_unpack(x).cpu().permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.cpu().double(),
+                           padding=kw["pad"])
+            assert rel_err(first.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    finally:
+        _lib.debug_set(_lib.DBG_STREAMK, -1)

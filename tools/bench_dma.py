@@ -8,13 +8,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from deeplip_amd import ops, packing
+from deeplip_amd import _lib, ops, packing
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
-ap.add_argument("--variants", default="0,1,2,3,4")
+ap.add_argument("--variants", default="-1", help="comma list of DMA tile ids (dlip_debug_set; -1 = built-in choice; 6..9 need the lab build via DLIP_LIB_PATH)")
 ap.add_argument("--xpad", type=int, default=0, help="extra (unused) channels per input pixel: breaks the power-of-two pixel stride")
 a = ap.parse_args()
 B = a.batch
@@ -58,7 +58,7 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res, count in L:
     best = {v: 1e30 for v in variants}
     for rnd in range(3):
         for v in variants:
-            os.environ["DLIP_CONV_DMA_TILE"] = v
+            _lib.debug_set(_lib.DBG_DMA_TILE, int(v))
             ops.conv_nhwc(x, wsp, b, residual=rs, out=y, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -67,7 +67,7 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res, count in L:
             e1.record()
             torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) * 1e3 / a.iters)
-    os.environ.pop("DLIP_CONV_DMA_TILE")
+    _lib.debug_set(_lib.DBG_DMA_TILE, -1)
     for v in variants:
         tot[v] += best[v] * count
     tot_best += min(best.values()) * count

@@ -8,14 +8,14 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from deeplip_amd import ops
+from deeplip_amd import _lib, ops
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--split", action="store_true", help="also time the split-fp16 (f16x3) kernel")
-ap.add_argument("--variants", default="-1", help="comma list of DLIP_CONV_TILE ids (-1 = built-in choice)")
+ap.add_argument("--variants", default="-1", help="comma list of tile ids of the fp32 / register-staged menu (dlip_debug_set) (-1 = built-in choice)")
 a = ap.parse_args()
 B = a.batch
 N = B * 29
@@ -59,7 +59,7 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res in L:
     best = {v: 1e30 for v in variants}
     for rnd in range(4):          # interleaved rounds, report the min per variant
         for v in variants:
-            os.environ["DLIP_CONV_TILE"] = v.split(":")[0]
+            _lib.debug_set(_lib.DBG_CONV_TILE, int(v.split(":")[0]))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
@@ -76,7 +76,7 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res in L:
         y2 = torch.empty_like(y)
         for rnd in range(4):
             for v in variants:
-                os.environ["DLIP_CONV_TILE"] = v.split(":")[0]; pass
+                _lib.debug_set(_lib.DBG_CONV_TILE, int(v.split(":")[0]))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.iters):
