@@ -8,6 +8,25 @@ namespace {
 
 constexpr int BK = 32;  // reduction slice: 32 channels of one filter tap
 
+// Exact unsigned division of n < 2^31 by a launch constant: q = umulhi(n, mul) >> shift (mul = ceil(2^(32+shift) / d),
+// shift = ceil(log2 d) - 1; d == 1 is mul == 0).  Two divisions per gathered row in every tile's set-up were a
+// quarter of it as plain `/` (hipcc expands a 32-bit division into ~30 instructions).
+struct FastDiv {
+  uint32_t mul, shift;
+};
+inline FastDiv dlip_fastdiv(uint32_t d) {
+  FastDiv f = {0u, 0u};
+  if (d <= 1) return f;
+  uint32_t s = 0;
+  while ((1ull << (s + 1)) < d) ++s;            // s = ceil(log2 d) - 1
+  f.shift = s;
+  f.mul = (uint32_t)((((unsigned long long)1 << (32 + s)) + d - 1) / d);
+  return f;
+}
+__device__ __forceinline__ int dlip_div(int n, const FastDiv f) {
+  return f.mul == 0u ? n : (int)(__umulhi((uint32_t)n, f.mul) >> f.shift);
+}
+
 struct ConvArgs {
   const float* x;
   const float* w;
@@ -39,6 +58,7 @@ struct ConvArgs {
   double* pool;
   int pool_group;       // rows per group (>= the tile's BM)
   int32_t* status;      // range-status word (NULL: not reported)
+  FastDiv div_howo, div_wo;
 };
 
 
@@ -88,6 +108,8 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
   a.x2 = nullptr; a.x2_bytes = 0; a.H2 = a.W2 = a.ldx2 = a.s2h = a.s2w = a.nk2 = 0;
   a.pool = nullptr; a.pool_group = 0;
   a.status = nullptr;
+  a.div_howo = dlip_fastdiv((uint32_t)a.HoWo);
+  a.div_wo = dlip_fastdiv((uint32_t)a.Wo);
   return DLIP_OK;
 }
 

@@ -111,7 +111,10 @@ struct StreamK {
 //   0  fp32 rows of y;  1  split-format rows of y (reports |v| >= 65520 to the range-status word);
 //   2  no y: per tile and row-group segment, the column sums of v and v^2 in fp64 (a.pool)
 // DUAL: the reduction continues over a second source x2 (1x1, strided) after the taps of x.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, int OCC, bool DUAL>
+// VAR (lab build experiments on the 8-wave tiles, bit 0: s_setprio 1 for the second-dispatched half of the waves;
+// bit 1: that half issues its LDS-DMA pieces half a slice later than the first half -- measured 15 % slower: the
+// pieces need their full two slices of lead; bit 2: every wave issues them at the top of the slice): 0 in the product.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, int OCC, bool DUAL, int VAR = 0>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_dma_kernel(const ConvArgs a, const StreamK sk) {
   constexpr bool OSPLIT = EPI == 1;
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
@@ -194,9 +197,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       for (int j = 0; j < A_PER; ++j) {
         const int m = tile_m * BM + rbase + RPP * j;
         const int mc = m < a.M ? m : a.M - 1;
-        const int n = mc / a.HoWo;
+        const int n = dlip_div(mc, a.div_howo);
         const int rem = mc - n * a.HoWo;
-        const int ho = rem / a.Wo;
+        const int ho = dlip_div(rem, a.div_wo);
         const int wo = rem - ho * a.Wo;
         hi0[j] = ho * a.sh - a.ph;
         wi0[j] = wo * a.sw - a.pw;
@@ -341,17 +344,28 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       read_first(0);
 
       int st_cur = 0, st_iss = (PF > 1 && kn > 1) ? 2 % NSTAGE : 1 % NSTAGE;   // stage the next issue goes to
+      const bool late = (VAR & 2) && wave >= NW / 2;    // (wave-uniform)
+      if ((VAR & 1) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
       for (int kt = 0; kt < kn; ++kt) {
         const bool more1 = (kt + 1) < kn, moreP = (kt + PF) < kn;
         const int st_nxt = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
+        // The slice's LDS-DMA pieces go out at the very top of the slice, right behind the barrier that frees their
+        // stage: they need all the lead the ring gives them (issued half a slice LATER a layer takes 15 % longer; at
+        // the top 3-4 % less than from the MFMA shadow of groups 0 / 1 on 256x128, 2-3 % on 128x128 and on the
+        // two-stage 128x64; the three-stage 128x64 of layer 1 is address-unit bound and 1 % slower: lab builds, round 2).
+        constexpr bool early = (VAR & 4) != 0 || NW == 8 || (BM == 128 && BN == 128) || (BM == 128 && BN == 64 && NSTAGE == 2);
+        if (early && moreP) { advance(); issue_a(st_iss); issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; }
+        DLIP_FENCE();
         read_rest(st_cur); DLIP_FENCE();
         mfma_p(0, 0, MI); DLIP_FENCE();
-        if (moreP) { advance(); issue_a(st_iss); } DLIP_FENCE();
+        if (moreP && !late && !early) { advance(); issue_a(st_iss); } DLIP_FENCE();
         mfma_p(1, 0, MH); DLIP_FENCE();
-        if (moreP) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
+        if (moreP && !late && !early) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
         if (MH < MI) mfma_p(1, MH, MI);
         DLIP_FENCE();
+        if (moreP && late) { advance(); issue_a(st_iss); } DLIP_FENCE();
         mfma_p(2, 0, MH); DLIP_FENCE();
+        if (moreP && late) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
         if (more1) {
           // slice kt+1 must have landed (every wave's share: wait, then barrier); slices beyond it stay in flight
           if (PF > 1 && (kt + 2) < kn) wait_vmcnt<NL>(); else wait_vmcnt<0>();
@@ -363,6 +377,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         DLIP_FENCE();
         st_cur = st_nxt;
       }
+      if (VAR & 1) __builtin_amdgcn_s_setprio(0);
     }
 #undef DLIP_FENCE
     DLIP_STAMP(4);
@@ -440,6 +455,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       // EPASS row bands when the tile is larger than the ring), 16-B chunk c of row r at position
       // c ^ (r & 15) (low 4 bits): the residual arrives by LDS-DMA, every lane adds / overwrites the 8-B
       // pieces of its own pixels, and the tile leaves in 16-B stores (a row is one contiguous segment).
+      // (Measured and rejected in round 2: the residual fetched as 8-B pieces straight into the accumulators
+      // during the prologue -- no epilogue fetch, wait or barrier -- was 2-7 % SLOWER on every layer with a
+      // residual: 32 scattered 8-B loads per lane cost the address unit more than 8 row-contiguous DMA pieces.)
       typedef _Float16 h4 __attribute__((ext_vector_type(4)));
       constexpr int PITCH = BN * 4;                  // bytes per image row
       constexpr int CPR = BN / 4;                    // 16-B chunks per row
@@ -725,7 +743,7 @@ int kernel_slots(KernelSlots& ks, int dev, K kern, int threads, size_t lds) {
   return ks.slots[dev];
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int OCC, int EPI, bool DUAL>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int OCC, int EPI, bool DUAL, int VAR = 0>
 int launch_one(const ConvArgs& a, hipStream_t st) {
   ConvArgs b = a;
   const int tiles_m = (a.M + BM - 1) / BM;
@@ -736,7 +754,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
   constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB + 5 * BN * sizeof(float);   // ring + epilogue parameter table
   constexpr int threads = 64 * WAVES_M * WAVES_N;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds a CU");
-  auto kern = conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, OCC, DUAL>;
+  auto kern = conv_igemm_f16x3_dma_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, OCC, DUAL, VAR>;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return DLIP_EINVAL;
   static KernelSlots ks;   // one per instantiation
@@ -762,7 +780,12 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     // kMaxPartsPerTile parts -- 512 parts of one 64x64 tile cost 1 ms of serial slab reads for 90 us of MFMA
     if (Gb > tiles * kMaxPartsPerTile) Gb = tiles * kMaxPartsPerTile;
     const double bal_us = (double)sk.iters / Gb / a.nk * tile_us + kHandoffUs * (BM * BN / 16384.0);
-    if ((balanced == 2 || bal_us < plain_us) && Gb * a.nk != sk.iters) G = Gb;
+    // Short reductions on a full chip (nk <= 16 slices, at least one tile per slot: the k = 1 TDNN layers) run
+    // plain: a tile's slab hand-off costs as much as a third of such a tile, and the under-filled last round of a
+    // plain launch runs faster than the model's whole tile-time (measured: 53.9 vs 57.6 us on tdnn.k1, 113.9 vs
+    // 115.3 on tdnn.9; the deep 3x3 / dilated layers gain 12 % from the split and keep it).
+    const bool short_full = a.nk <= 16 && tiles >= sl;
+    if ((balanced == 2 || (bal_us < plain_us && !short_full)) && Gb * a.nk != sk.iters) G = Gb;
   }
   if (G != tiles) {
     Workspace* w = workspace_for(dev, st, (size_t)2 * G * BM * BN);
@@ -784,11 +807,17 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
 
 // Instances: every tile x {fp32, split} output, plain and with the second reduction source; the pooled
 // epilogue on the two tiles its callers reach (128x128: tdnn.9 and small clips; 256x128: the trunk's last conv).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int OCC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int OCC, int VAR = 0>
 int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
   const bool dual = a.x2 != nullptr;
+  if constexpr (VAR != 0) {   // lab experiments: plain launches only
+    if (epi == 2 || dual) return DLIP_EINVAL;
+    return epi ? launch_one<BM, BN, WAVES_M, WAVES_N, NSTAGE, OCC, 1, false, VAR>(a, st)
+               : launch_one<BM, BN, WAVES_M, WAVES_N, NSTAGE, OCC, 0, false, VAR>(a, st);
+  }
   if (epi == 2) {
-    if constexpr ((BM == 128 || BM == 256) && BN == 128) {
+    // (the product tiles 0 and 5: the whole fp32 tile image must fit the ring in one band)
+    if constexpr (BN == 128 && ((BM == 128 && WAVES_M == 2) || (BM == 256 && NSTAGE == 3))) {
       if (!dual) return launch_one<BM, BN, WAVES_M, WAVES_N, NSTAGE, OCC, 2, false>(a, st);
     }
     return DLIP_EINVAL;
@@ -806,7 +835,7 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 // (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
 #ifdef DLIP_LAB
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {256, 128}, {128, 256}, {256, 64}, {128, 128}};
+                           {128, 128}, {128, 64}, {128, 64}, {64, 128}};   // 6..9: tiles 0, 1, 4, 2 with VAR 4 (early issue)
 constexpr int NUM_DMA_ALL = 10;
 #else
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
@@ -852,12 +881,12 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 3: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, epi);
     case 4: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, epi);
 #ifdef DLIP_LAB
-    case 6: return launch_dma<256, 128, 4, 2, 2, 1>(a, st, epi);
-    case 7: return launch_dma<128, 256, 2, 4, 2, 1>(a, st, epi);
-    case 8: return launch_dma<256, 64, 4, 2, 3, 1>(a, st, epi);
-    case 9: return launch_dma<128, 128, 4, 2, 3, 1>(a, st, epi);
+    case 6: return launch_dma<128, 128, 2, 2, 2, 2, 4>(a, st, epi);
+    case 7: return launch_dma<128, 64, 2, 2, 3, 2, 4>(a, st, epi);
+    case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
+    case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);
 #endif
-    default: return launch_dma<256, 128, 4, 2, 3, 1>(a, st, epi);
+    default: return launch_dma<256, 128, 4, 2, 3, 1, 0>(a, st, epi);
   }
 }
 

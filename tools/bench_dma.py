@@ -15,6 +15,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--variants", default="-1", help="comma list of DMA tile ids (dlip_debug_set; -1 = built-in choice; 6..9 need the lab build via DLIP_LIB_PATH)")
+ap.add_argument("--streamk", type=int, default=-1, help="balanced split: -1 built-in cost model, 0 never, 2 always (dlip_debug_set)")
 ap.add_argument("--xpad", type=int, default=0, help="extra (unused) channels per input pixel: breaks the power-of-two pixel stride")
 a = ap.parse_args()
 B = a.batch
@@ -35,6 +36,7 @@ L = [
     ("tdnn9", (B, 1, 278, 512), 1500, 1, 1, 1, 0, 1, False, 1),
 ]
 variants = a.variants.split(",")
+_lib.debug_set(_lib.DBG_STREAMK, a.streamk)
 tot = {v: 0.0 for v in variants}
 tot_best = 0.0
 for name, (n, h, w, c), k, r, s, st, pd, dl, res, count in L:
