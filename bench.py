@@ -109,6 +109,13 @@ def build_models(device, audio_dim):
 AUDIO_STREAM = None   # --audio-stream: the speech encoder runs on a second HIP stream beside the lip-clip encoder
 
 
+def kernel_source_sha():
+    """sha256 (16 hex digits) of the dominant kernel's source: what profiles/traffic_latest.json is stamped with."""
+    import hashlib
+    with open(os.path.join(ROOT, "deeplip_amd", "csrc", "conv_igemm_f16x3_dma.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def local_step(video, audio, xv, xa):
     """The per-rank part of a step: launches only (what a StepPlan records)."""
     from deeplip_amd import fusion
@@ -193,6 +200,151 @@ def cpu_baseline(sds, audio_dim, budget_s=12.0, sample=8):
                       f"[{sample},{audio_dim},300] (torch-CPU fp32, {best_n} of {cores} usable cores, {el:.1f}s)"}, ref, xv, xa
 
 
+def _timed_replay(run, steps, warmup, sync):
+    """warmup + steps calls of ``run`` bracketed by HIP events on the current stream -> ms per call."""
+    for _ in range(warmup):
+        run()
+    sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        run()
+    e1.record()
+    sync()
+    return e0.elapsed_time(e1) / steps
+
+
+def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan):
+    """The other BASELINE.json configurations, measured beside the headline: every entry is
+    plan replay over inputs resident in HBM, HIP-event timed; failures are recorded, never fatal to the headline.
+      C2 video-only clip embed [B,1,29,88,88]; C3 speech-encoder embed [256,1,F,300] (configs[2]);
+      C4 fused extraction of a 256-utterance test list + 20 000 cosine trials shaped like trial_grid_v1.txt + EER;
+      C5 one rank's DP training step of the fusion head (frozen encoders, bs 60): where its time goes."""
+    from deeplip_amd import fusion, ops, scoring, weightgen as wg
+    from deeplip_amd.synthetic import SyntheticAVSet, synthetic_trials
+    out = {}
+    sync = torch.cuda.synchronize
+    B = xv.shape[0]
+    st, wu = max(5, args.steps // 2), 2
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as ex:   # noqa: BLE001 -- a broken side configuration must not take the headline down
+            out[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
+    def c2():
+        plan = StepPlan(lambda v: video.embed(v), xv)
+        ms = _timed_replay(plan.run, st, wu, sync)
+        plan.close()
+        tf = B / ms * 18.337           # clips per ms x GFLOP per 29-frame clip (BASELINE.md section 2) = TFLOP/s
+        return {"workload": f"video-only embed [{B},1,29,88,88] -> [{B},512]", "value": round(1e3 * B / ms, 1), "unit": "lip-clips/sec",
+                "ms_per_step": round(ms, 4), "step_tflops": round(tf, 1), "step_frac": round(tf / peak, 4)}
+
+    def c3():
+        Ba = 256
+        xa3 = torch.from_numpy(wg.audio_input(Ba, args.audio_dim, 300, key="bench.audio.c3")).unsqueeze(1).to(device)
+        hook = EventHook()
+        ops.LAUNCH_HOOK = hook
+        try:
+            audio.extract_embedding(xa3)
+            hook.enabled = True
+            hook.records = []
+            audio.extract_embedding(xa3)
+            sync()
+        finally:
+            ops.LAUNCH_HOOK = None
+        agg = hook.summary()
+        dom = max(agg.items(), key=lambda kv: kv[1]["flops"])
+        plan = StepPlan(lambda a_: audio.extract_embedding(a_)[0], xa3)
+        ms = _timed_replay(plan.run, st, wu, sync)
+        plan.close()
+        gf = 2.563 + (0.085 if args.audio_dim == 80 else 0.0)      # GFLOP per 300-frame utterance (BASELINE.md section 2)
+        tf = Ba / ms * gf
+        dtf = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+        return {"workload": f"speech-encoder embed [{Ba},1,{args.audio_dim},300] -> [{Ba},512] (BASELINE configs[2])",
+                "value": round(1e3 * Ba / ms, 1), "unit": "utt/sec", "ms_per_step": round(ms, 4), "step_tflops": round(tf, 1),
+                "step_frac": round(tf / peak, 4),
+                "dominant_kernel": {"kernel": dom[0], "launches": dom[1]["launches"], "tflops": round(dtf, 1), "frac": round(dtf / peak, 4)}}
+
+    def c4():
+        ds = SyntheticAVSet(32, 8, 1, 29, args.audio_dim, 300, key="bench.c4")        # 256 utterances, 32 speakers, 1 clip each
+        n = len(ds)
+        vb = torch.empty((B,) + tuple(xv.shape[1:]), device=device)
+        ab = torch.empty((B,) + tuple(xa.shape[1:]), device=device)
+        plan = StepPlan(lambda v, a_: fusion.fuse_av(audio.extract_embedding(a_)[0], video.embed(v, finish=False)), vb, ab)
+        host = []
+        for b0 in range(0, n, B):
+            idx = list(range(b0, b0 + B))
+            host.append((torch.from_numpy(ds.video(idx)[0]).pin_memory(), torch.from_numpy(ds.audio(idx)).unsqueeze(1).pin_memory()))
+        table = torch.empty((n, 1024), device=device)
+        sync()
+        t0 = time.perf_counter()
+        for i, (hv, ha) in enumerate(host):          # pinned host -> the plan's recorded input buffers, then one replay
+            plan.inputs[0].copy_(hv, non_blocking=True)
+            plan.inputs[1].copy_(ha, non_blocking=True)
+            table[i * B:(i + 1) * B].copy_(plan.run())
+        sync()
+        extract_s = time.perf_counter() - t0
+        plan.close()
+        y, pairs = synthetic_trials(ds, 20000, 4000)
+        tab = scoring.EmbeddingTable(ds.utt_ids, table)
+        ia, ib = tab.trial_indices(pairs)
+        ms = _timed_replay(lambda: scoring.cosine_scores(table, ia, ib), 20, 3, sync)
+        scores = scoring.cosine_scores(table, ia, ib).cpu().numpy()
+        eer, thr = scoring.eer_from_scores(y, scores)
+        return {"workload": f"fused A+V extraction of {n} utterances (H2D included) + 20000 cosine trials (4000 target / 16000 "
+                            "non-target, trial_grid_v1.txt shape) + EER", "extract_utt_per_s": round(n / extract_s, 1),
+                "trials_per_s": round(20000 / (ms * 1e-3), 0), "scoring_ms": round(ms, 4), "eer": round(float(eer), 6),
+                "eer_note": "random-init weights do not separate speakers: the EER value carries no meaning, its agreement with the oracle does",
+                "threshold": round(float(thr), 6), "_table": table, "_trials": (y, ia.cpu().numpy(), ib.cpu().numpy(), scores)}
+
+    def c5():
+        from models.audio_models.loss import LMCL
+        from models.fusion_models import model_fusion
+        bs = 60                                      # conf/fusion_config.yaml:91
+        vb = xv[:bs].contiguous() if B >= bs else xv
+        ab = xa[:vb.shape[0]].contiguous()
+        nb = vb.shape[0]
+        plan = StepPlan(lambda v, a_: (audio.extract_embedding(a_)[0], video.embed(v)), vb, ab)
+        enc_ms = _timed_replay(plan.run, st, wu, sync)
+        xa_e, xv_e = (t.clone() for t in plan.run())
+        plan.close()
+        head = model_fusion.model_fusion(1024, 512, 57, extract_feats=False).to(device)
+        crit = LMCL(512, 57, 30.0, 0.2).to(device)
+        head.train()
+        opt = torch.optim.SGD([{"params": head.parameters()}, {"params": crit.parameters()}], 0.5, momentum=0.9, weight_decay=1e-5)
+        labels = (torch.arange(nb, device=device) % 57).long()
+        feats = torch.cat([fusion.feature_normalize(xa_e), fusion.feature_normalize(xv_e)], 1)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(10)]
+        for i in range(12):
+            e = ev[max(i - 2, 0)]
+            opt.zero_grad()
+            e[0].record()
+            loss, logits = crit(head(feats), labels)
+            e[1].record()
+            loss.backward()
+            e[2].record()
+            opt.step()
+            e[3].record()
+        sync()
+        f = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)
+        b = sum(e[1].elapsed_time(e[2]) for e in ev) / len(ev)
+        o = sum(e[2].elapsed_time(e[3]) for e in ev) / len(ev)
+        tot = enc_ms + f + b + o
+        return {"workload": f"one rank's DP step of the fusion head: {nb} A+V pairs, frozen encoders, Linearfusion + LMCL, SGD "
+                            "(conf/fusion_config.yaml:87-99); gradients of the 3.4 MB head are one flat all-reduce at N > 1",
+                "pairs_per_s": round(1e3 * nb / tot, 1), "ms": {"encoders_frozen_extract": round(enc_ms, 4), "head_forward": round(f, 4),
+                                                                   "head_backward": round(b, 4), "optimizer": round(o, 4)},
+                "loss": round(float(loss.detach()), 4)}
+
+    guarded("C2_video_embed", c2)
+    guarded("C3_audio_embed", c3)
+    guarded("C4_fusion_scoring", c4)
+    guarded("C5_fusion_train_step", c5)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +360,7 @@ def main():
                     help="run the speech encoder on a second HIP stream beside the lip-clip encoder (kernel tails overlap; "
                          "per-kernel event durations then include the time shared with the other stream)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configurations (C2..C5) reported under `configs`")
     ap.add_argument("--eager", action="store_true",
                     help="issue every launch of every step from Python (round-1 behaviour) instead of replaying a recorded "
                          "step plan (dlip_plan_run); for A/B runs on one box")
@@ -227,7 +380,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    from deeplip_amd import fusion, ops, packing, weightgen as wg
+    from deeplip_amd import _lib, fusion, ops, packing, weightgen as wg
     from deeplip_amd.plan import StepPlan
     if args.audio_stream:
         global AUDIO_STREAM
@@ -280,11 +433,23 @@ def main():
             elapsed = time.perf_counter() - t0
             hook.enabled = False
             gpu_ms = ev0.elapsed_time(ev1)
+            my_elapsed = elapsed
             tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
             value = world * B * args.steps / elapsed
+            ranks = None
+            if world > 1:
+                # self-check of a scaling run: what every rank saw (RCCL's own world size, its wall time over the same K
+                # steps, the all-gather of [B,1024] rows timed on its own)
+                fused_probe = torch.zeros((B, 1024), device=device)
+                ag_ms = _timed_replay(lambda: exchange(fused_probe, world), 20, 3, sync_all)
+                mine = {"rank": rank, "device": torch.cuda.get_device_name(device), "rccl_world_size": dist.get_world_size(),
+                        "clips_per_s": round(B * args.steps / my_elapsed, 1), "ms_per_step": round(1e3 * my_elapsed / args.steps, 4),
+                        "allgather_us": round(1e3 * ag_ms, 1)}
+                ranks = [None] * world
+                dist.all_gather_object(ranks, mine)
             # roofline of the mode: exact fp32 MFMA peak, or the f16 dense peak / 3 (three f16 MFMAs
             # per fp32-grade product: the ceiling of the split algorithm in ALGORITHMIC FLOP/s)
             peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
@@ -330,17 +495,25 @@ def main():
                 roof["plan_launches"] = plan.launches
                 plan.close()
         ops.LAUNCH_HOOK = None
-        try:  # HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        # HBM traffic per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot be collected from
+        # inside this process, so it comes from the committed PMC passes of this same command (tools/collect_profiles.sh
+        # -> profiles/traffic_latest.json) -- and only if that file was produced by THIS kernel source (sha of
+        # conv_igemm_f16x3_dma.hip + library ABI stamped into it); otherwise null rather than a stale number.
+        try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            meta = tr.get("_meta", {})
             key = roof.get("kernel", "")
-            if key in tr and "hbm_read_bytes_per_launch" in tr[key]:
+            if meta.get("kernel_sha") != kernel_source_sha() or meta.get("abi") != _lib.ABI_VERSION:
+                roof["traffic_source"] = "profiles/traffic_latest.json is from another kernel build (sha / ABI mismatch): ignored"
+            elif key in tr and "hbm_read_bytes_per_launch" in tr[key]:
                 roof["traffic"] = round(tr[key]["hbm_read_bytes_per_launch"] + tr[key]["hbm_write_bytes_per_launch"])
-                roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per launch, FETCH x2 gfx950 correction)"
+                roof["traffic_source"] = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per "
+                                          "launch, FETCH x2 gfx950 correction; stamped with this kernel source's sha)")
         except Exception:
             pass
         fields = {"value": round(value, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                   "dtype": DTYPE_NAME[precision], "dtype_note": DTYPE_NOTE[precision], "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),
-                  "roofline": roof}
+                  "roofline": roof, "ranks": ranks, "peak": peak}
         return fields, video, audio, sds
 
     def parity(precision, video, audio, ref, cxv, cxa):
@@ -354,6 +527,11 @@ def main():
                 "tolerance": 1e-4}
 
     main_fields, video, audio, sds = measure(args.precision)
+    configs = None
+    if rank == 0 and not args.no_configs:
+        configs = extra_configs(args, device, video, audio, xv, xa, main_fields["peak"], StepPlan)
+    if world > 1:
+        dist.barrier()
     alt = None
     if not args.single_mode:
         alt_prec = "f32" if args.precision != "f32" else "f16x3"
@@ -374,12 +552,30 @@ def main():
                        "dtype_note": main_fields["dtype_note"]},
             "roofline": main_fields["roofline"],
         }
+        if main_fields["ranks"] is not None:
+            res["ranks"] = main_fields["ranks"]
+        c4_private = None
+        if configs is not None:
+            c4 = configs.get("C4_fusion_scoring", {})
+            c4_private = (c4.pop("_table", None), c4.pop("_trials", None))
+            res["configs"] = configs
         if alt is not None:
             res["alt_mode"] = {k: alt[1][k] for k in ("dtype", "dtype_note", "value", "ms_per_step", "roofline")}
         if not args.no_cpu_baseline:
             cb, ref, cxv, cxa = cpu_baseline(sds, args.audio_dim)
             res["cpu_baseline"] = cb
             res["parity"] = parity(args.precision, video, audio, ref, cxv, cxa)
+            if c4_private and c4_private[0] is not None:
+                # C4's "EER delta": the oracle's trial scoring + EER (sklearn / scipy semantics restated) on the SAME
+                # embedding table the GPU scored -- the checker beside the GPU number, never the thing timed
+                from oracle import deeplip_oracle as O
+                y, ia, ib, gpu_scores = c4_private[1]
+                osc = O.cosine_trial_scores(c4_private[0].cpu().numpy(), ia, ib)
+                oeer, _ = O.eer(list(y), list(osc))
+                c4 = res["configs"]["C4_fusion_scoring"]
+                c4["oracle_eer"] = round(float(oeer), 6)
+                c4["abs_delta_eer"] = float(f"{abs(float(oeer) - c4['eer']):.3e}")
+                c4["max_abs_score_err_vs_oracle"] = float(f"{float(np.abs(osc.reshape(-1) - gpu_scores.reshape(-1)).max()):.3e}")
             if alt is not None:
                 res["alt_mode"]["parity"] = parity(alt[0], alt[2], alt[3], ref, cxv, cxa)
         print(json.dumps(res), flush=True)

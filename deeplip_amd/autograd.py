@@ -120,8 +120,9 @@ class MarginCELossFn(Function):
     def backward(ctx, dloss):
         logits, labels = ctx.saved_tensors
         g = torch.empty_like(logits)
+        dl = dloss.reshape(1).to(torch.float32).contiguous()       # stays on the device: no host read-back per step
         check(lib().dlip_margin_ce_bwd_f32(ptr(logits), ptr(labels), ptr(g), logits.shape[0], logits.shape[1],
-                                           ctx.scale, ctx.margin, float(dloss), stream_handle()),
+                                           ctx.scale, ctx.margin, 1.0, ptr(dl), stream_handle()),
               "dlip_margin_ce_bwd_f32")
         return g, None, None, None
 

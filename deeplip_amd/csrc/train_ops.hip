@@ -90,10 +90,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void margin_ce_bwd_kernel(const float* __restrict__ logits,
                                                             const long long* __restrict__ labels,
                                                             float* __restrict__ dlogits, int B, int K, float scale,
-                                                            float margin, float gscale) {
+                                                            float margin, float gscale_host,
+                                                            const float* __restrict__ gscale_dev) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
+  const float gscale = gscale_dev ? gscale_host * gscale_dev[0] : gscale_host;
   const float* p = logits + (long long)b * K;
   const int lab = (int)labels[b];
   float mx = -__builtin_inff();
@@ -204,10 +206,10 @@ extern "C" int dlip_colsum_f32(const float* x, float* y, int32_t M, int32_t C, d
 
 extern "C" int dlip_margin_ce_bwd_f32(const float* logits, const int64_t* labels, float* dlogits, int32_t B,
                                       int32_t K, float scale, float margin, float grad_scale,
-                                      dlip_stream_t stream) {
+                                      const float* grad_scale_dev, dlip_stream_t stream) {
   DLIP_CHECK_ARG(logits && labels && dlogits && B > 0 && K > 0);
   hipLaunchKernelGGL(margin_ce_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
-                     reinterpret_cast<const long long*>(labels), dlogits, B, K, scale, margin, grad_scale);
+                     reinterpret_cast<const long long*>(labels), dlogits, B, K, scale, margin, grad_scale, grad_scale_dev);
   return dlip_launch_status();
 }
 

@@ -7,6 +7,7 @@ scoring; scoring can then shard by trial range.  Nothing here does arithmetic.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Tuple
 
 import torch
@@ -64,23 +65,139 @@ def allreduce_metrics(values: List[float], device) -> List[float]:
     return t.tolist()
 
 
+def init_from_env(device: Optional[torch.device] = None) -> Tuple[int, int]:
+    """Join the job torch.distributed.run started (RANK / WORLD_SIZE / MASTER_* in the environment): backend nccl
+    (= RCCL over xGMI) bound to ``device`` for a GPU rank, gloo for a CPU rank.  No-op for a single process.
+    Returns (rank, world size)."""
+    w = int(os.environ.get("WORLD_SIZE", "1"))
+    if w > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if device is not None and device.type == "cuda":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    return world()
+
+
+def broadcast_params(params, src: int = 0) -> None:
+    """Replicas start identical (what nn.DataParallel's per-step broadcast guarantees: train_audio.py:83)."""
+    if world()[1] > 1:
+        for p in params:
+            dist.broadcast(p.data, src)
+
+
 def allreduce_grads(params, world_size: Optional[int] = None) -> int:
-    """Data-parallel gradient exchange: ONE flat all-reduce (sum) of every ``p.grad`` divided by the world size
-    (backend nccl = RCCL on the GPU box, gloo in the CPU tests).  One bucket on purpose: the trainable sets here
-    are 3.4 MB (fusion head), 25 MB (speech encoder), 144 MB (lip-clip model) -- on the point-to-point xGMI
-    ring the largest takes ~2 ms beside a 60 ms step, so neither bucketing nor overlap with backward pays.
-    Returns the number of elements reduced (0 when not distributed)."""
+    """Data-parallel gradient exchange in ONE flat all-reduce (sum / world size) -- for small trainable sets (the
+    3.4 MB fusion head: latency-bound on xGMI, a single message is the right shape).  The flat buffer is built from
+    the FIXED parameter list, a parameter without a gradient on this rank contributing zeros, so every rank reduces
+    the same layout whatever its batch touched; such a parameter then receives the (mean) gradient of the others.
+    Larger models use GradBuckets (overlapped with backward).  Returns the number of elements reduced (0 when not
+    distributed)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 0
     w = world_size or dist.get_world_size()
-    grads = [p.grad for p in params if p.grad is not None]
-    if w == 1 or not grads:
+    params = [p for p in params if p.requires_grad]
+    if w == 1 or not params:
         return 0
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=params[0].device)
+    dist.all_reduce(has)                                       # which parameters got a gradient on ANY rank
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat)
     flat /= w
-    o = 0
-    for g in grads:
-        g.copy_(flat[o:o + g.numel()].view_as(g))
-        o += g.numel()
-    return o
+    o = n = 0
+    for p, h in zip(params, has.tolist()):
+        k = p.numel()
+        if h > 0:
+            if p.grad is None:
+                p.grad = flat[o:o + k].view_as(p).clone()
+            else:
+                p.grad.copy_(flat[o:o + k].view_as(p))
+            n += k
+        o += k
+    return n
+
+
+class GradBuckets:
+    """Bucketed gradient all-reduce overlapped with backward (what replaces nn.DataParallel's
+    gather of gradients, train_audio.py:83 / train_video.py:206-207, on one process per GPU over RCCL).
+
+    The parameters' ``.grad`` tensors are VIEWS into a few flat buckets (filled in reverse registration order, the
+    order backward produces them), so there is no concatenation and no copy-back: a post-accumulate hook counts a
+    bucket's gradients as they land, and the moment a bucket is complete its all-reduce is launched asynchronously
+    -- on RCCL's own stream, beside the rest of the backward kernels.  ``finish()`` launches whatever is left
+    (parameters a batch did not touch keep their zeros: every rank reduces the same layout), waits, and divides by
+    the world size.  Use ``optimizer.zero_grad(set_to_none=False)`` (or ``buckets.zero()``) so the views survive.
+    xGMI is point-to-point (7 links x ~153 GB/s): a ring all-reduce is bound by one link, so buckets are sized for
+    a few hundred microseconds each (default 32 MB ~ 0.5 ms at 8 ranks) -- large enough to be bandwidth- rather than
+    latency-bound, small enough that the last one does not stick out behind backward."""
+
+    def __init__(self, params, bucket_bytes: int = 32 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world()[1]
+        self.buckets: List[torch.Tensor] = []
+        self._slot = {}            # id(param) -> bucket index
+        self._pending: List[int] = []
+        self._count: List[int] = []
+        self._works: list = []
+        self._launched: List[bool] = []
+        cur, cur_n = [], 0
+        groups = []
+        for p in reversed(self.params):
+            if cur and (cur_n + p.numel()) * p.element_size() > bucket_bytes:
+                groups.append(cur); cur, cur_n = [], 0
+            cur.append(p); cur_n += p.numel()
+        if cur:
+            groups.append(cur)
+        for bi, g in enumerate(groups):
+            flat = torch.zeros(sum(p.numel() for p in g), dtype=g[0].dtype, device=g[0].device)
+            o = 0
+            for p in g:
+                p.grad = flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+                self._slot[id(p)] = bi
+                p.register_post_accumulate_grad_hook(self._hook)
+            self.buckets.append(flat)
+            self._count.append(len(g))
+        self._reset()
+
+    def _reset(self):
+        self._pending = list(self._count)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def _launch(self, bi: int):
+        if self._launched[bi]:
+            return
+        self._launched[bi] = True
+        if self.world > 1:
+            self._works.append(dist.all_reduce(self.buckets[bi], async_op=True))
+
+    def _hook(self, p):
+        bi = self._slot[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def zero(self):
+        for b in self.buckets:
+            b.zero_()
+
+    def finish(self) -> int:
+        """Call after backward: reduce the buckets that are not on their way yet, wait for all, average.  Returns the
+        number of elements reduced (0 when not distributed)."""
+        for p in self.params:       # an optimizer.zero_grad() with set_to_none=True would have detached the views
+            b = self.buckets[self._slot[id(p)]]
+            if p.grad is None or not (b.data_ptr() <= p.grad.data_ptr() < b.data_ptr() + b.numel() * b.element_size()):
+                raise RuntimeError("GradBuckets: a parameter's .grad no longer lives in its bucket; clear gradients with "
+                                   "optimizer.zero_grad(set_to_none=False) or GradBuckets.zero()")
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        for w in self._works:
+            w.wait()
+        n = 0
+        if self.world > 1:
+            for b in self.buckets:
+                b.div_(self.world)
+                n += b.numel()
+        self._reset()
+        return n

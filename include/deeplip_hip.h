@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 15
+#define DLIP_ABI_VERSION 16
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -328,10 +328,12 @@ int dlip_lrelu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, fl
                        dlip_stream_t stream);
 /* y[c] = sum_m x[m,c]  (bias gradients). */
 int dlip_colsum_f32(const float* x, float* y, int32_t M, int32_t C, dlip_stream_t stream);
-/* dlogits = grad_scale * d/dlogits mean_b CE(scale*(logits - margin*onehot) + 1e-8, labels). */
+/* dlogits = grad_scale * grad_scale_dev[0] * d/dlogits mean_b CE(scale*(logits - margin*onehot) + 1e-8, labels);
+ * grad_scale_dev = the upstream gradient of the scalar loss as a DEVICE scalar (NULL = 1): autograd's backward
+ * does not have to read it back to the host. */
 int dlip_margin_ce_bwd_f32(const float* logits, const int64_t* labels, float* dlogits, int32_t B,
                            int32_t K, float scale, float margin, float grad_scale,
-                           dlip_stream_t stream);
+                           const float* grad_scale_dev, dlip_stream_t stream);
 /* Backward of dlip_l2_normalize_f32. */
 int dlip_l2_normalize_bwd_f32(const float* x, const float* dy, float* dx, int32_t U, int32_t D,
                               float eps, dlip_stream_t stream);

@@ -528,9 +528,28 @@ def _psf_frames(signal: np.ndarray, frame_len: int, frame_step: int, preemph: fl
     return pad[idx.astype(np.int32)]                                          # rectangular window (winfunc = ones)
 
 
+def psf_get_filterbanks(nfilt=26, nfft=512, samplerate=16000, lowfreq=0.0, highfreq=None) -> np.ndarray:
+    """base.get_filterbanks restated on its own (NOT the product's deeplip_amd.frontend.mel_filterbank, so that a
+    filterbank bug in the product cannot cancel out of the front-end parity tests): nfilt triangular filters whose
+    corners are nfilt + 2 points equally spaced on the mel scale (hz2mel = 2595 log10(1 + hz / 700)), mapped to FFT
+    bins floor((nfft + 1) * hz / samplerate); filter j rises linearly over bins [b_j, b_j+1) and falls over
+    [b_j+1, b_j+2).  Built here with vectorised ramps instead of the package's per-bin loops."""
+    highfreq = highfreq or samplerate / 2
+    mel_lo, mel_hi = 2595.0 * np.log10(1.0 + lowfreq / 700.0), 2595.0 * np.log10(1.0 + highfreq / 700.0)
+    mels = mel_lo + (mel_hi - mel_lo) * np.arange(nfilt + 2) / (nfilt + 1)
+    hz = 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+    b = np.floor((nfft + 1) * hz / samplerate)
+    k = np.arange(nfft // 2 + 1, dtype=np.float64)[None, :]
+    lo, mid, hi = b[:-2, None], b[1:-1, None], b[2:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        up = np.where((k >= lo) & (k < mid), (k - lo) / (mid - lo), 0.0)
+        down = np.where((k >= mid) & (k < hi), (hi - k) / (hi - mid), 0.0)
+    return np.nan_to_num(up + down)
+
+
 def psf_fbank(signal, rate=16000, winlen=0.025, winstep=0.01, nfilt=26, nfft=512, preemph=0.97):
     """base.fbank -> (feat [NF, nfilt], energy [NF])."""
-    from deeplip_amd.frontend import mel_filterbank   # constant construction only (same published formula)
+    mel_filterbank = psf_get_filterbanks
     frames = _psf_frames(np.asarray(signal, dtype=np.float64), int(round(winlen * rate)), int(round(winstep * rate)), preemph)
     pspec = 1.0 / nfft * np.square(np.absolute(np.fft.rfft(frames, nfft)))    # sigproc.powspec
     energy = np.sum(pspec, 1)

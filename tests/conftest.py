@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a long CPU-oracle leg (tens of seconds); runs by default")
 
 
 @pytest.fixture(scope="session")
@@ -31,3 +32,19 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def assert_close_rel(a, b, rtol=1e-4, afloor=1e-6, what=""):
+    """The north star's bar, element by element: |a - b| <= rtol * |b| + afloor * max|b| for EVERY element
+    ("within 1e-4 relative"; the absolute floor, one millionth of the tensor's largest magnitude, only keeps
+    elements that are themselves ~0 from being held to a relative bar they cannot have).  Stricter than rel_err,
+    which compares the largest error with the largest magnitude."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bound = rtol * np.abs(b) + afloor * max(float(np.abs(b).max()), 1e-30)
+    bad = np.abs(a - b) > bound
+    if bad.any():
+        i = np.unravel_index(int(np.argmax(np.abs(a - b) - bound)), a.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())} of {a.size} elements outside |a-b| <= {rtol}|b| + {afloor} max|b|; worst at {i}: "
+                             f"got {a[i]!r}, want {b[i]!r}")

@@ -89,3 +89,93 @@ def test_allreduce_grads_world2():
         assert n == 22 and none2
         assert np.allclose(g0, 1.5) and np.allclose(g1, np.arange(7) * 1.5)
     assert ddist.allreduce_grads([torch.nn.Parameter(torch.zeros(2))]) == 0      # not distributed: no-op
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)                                   # identical replicas
+        net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                                  torch.nn.Linear(16, 3))
+        unused = torch.nn.Parameter(torch.ones(5))             # never touched by the loss: must stay consistent
+        params = list(net.parameters()) + [unused]
+        buckets = ddist.GradBuckets(params, bucket_bytes=600)  # several small buckets
+        g = torch.Generator().manual_seed(100)                 # the GLOBAL batch; each rank takes its half
+        x = torch.randn(8, 6, generator=g); y = torch.randn(8, 3, generator=g)
+        lo, hi = ddist.shard_range(8)
+        out = []
+        for step in range(2):                                  # two steps: the views must survive zeroing
+            buckets.zero()
+            loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+            loss.backward()
+            n = buckets.finish()
+            out.append([p.grad.clone().numpy() for p in params])
+        q.put((rank, n, len(buckets.buckets), out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_buckets_world2_equal_full_batch_gradient():
+    """deeplip_amd.dist.GradBuckets (the DP exchange of train_audio.py / train_video.py): gradients accumulate into
+    bucket views, bucket all-reduces are launched from the accumulation hooks, and after finish() every rank holds
+    the mean over ranks == the gradient of the full batch; a parameter no rank touched keeps a zero gradient."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(60) for p in procs]
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                              torch.nn.Linear(16, 3))
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(8, 6, generator=g); y = torch.randn(8, 3, generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    ref = [p.grad.numpy() for p in net.parameters()]
+    for rank, n, nb, out in res:
+        assert nb >= 3 and n == sum(p.numel() for p in net.parameters()) + 5
+        for step in out:
+            for a, b in zip(step[:-1], ref):
+                assert np.allclose(a, b, atol=1e-6)
+            assert np.array_equal(step[-1], np.zeros(5, dtype=np.float32))
+
+
+def test_grad_buckets_detects_detached_views():
+    p = torch.nn.Parameter(torch.zeros(4))
+    b = ddist.GradBuckets([p])
+    p.grad = None                                              # what optimizer.zero_grad() (set_to_none=True) does
+    with pytest.raises(RuntimeError, match="set_to_none=False"):
+        b.finish()
+
+
+def _bench_exchange_worker(rank, world, port, q):
+    """bench.py's step() exchange and train_fusion's epoch reduction with stand-in encoders (their arithmetic needs a
+    GPU; what runs here is exactly the N > 1 control flow: shard -> local rows -> all-gather -> every rank holds all)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank))
+    assert ddist.init_from_env(torch.device("cpu")) == (rank, world)
+    try:
+        import bench
+        B = 4
+        fused = torch.arange(B * 8, dtype=torch.float32).view(B, 8) + 1000 * rank      # this rank's [B, D] rows
+        full = bench.exchange(fused, world)
+        stats = ddist.allreduce_metrics([2.5 * (rank + 1), float(B)], "cpu")
+        q.put((rank, full.numpy(), stats))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_exchange_and_metric_reduction_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=180) for _ in procs]
+    [p.join(60) for p in procs]
+    base = np.arange(32, dtype=np.float32).reshape(4, 8)
+    want = np.concatenate([base, base + 1000], 0)
+    for rank, full, stats in res:
+        assert full.shape == (8, 8) and np.array_equal(full, want)
+        assert stats == [7.5, 8.0]

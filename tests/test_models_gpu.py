@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_close_rel, rel_err
 from deeplip_amd import weightgen as wg
 from oracle import deeplip_oracle as O
 
@@ -19,6 +19,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 TCN_OPTS = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
 DEV = "cuda"
+
+
+def close(got, want, tol=TOL, what=""):
+    """Both bars: largest error against largest magnitude (rel_err), and the north star's element-wise
+    |got - want| <= tol * |want| + 1e-6 * max|want| (conftest.assert_close_rel)."""
+    assert rel_err(got, want) < tol, (what, rel_err(got, want))
+    assert_close_rel(got, want, rtol=tol, what=what)
 
 
 def load(module, prefix):
@@ -59,11 +66,14 @@ def test_video_golden_features_and_taps(golden, video_net):
     feats = net(x, lengths=[29] * 4, taps=taps)
     torch.cuda.synchronize()
     assert feats.shape == (4, 29, 512)
-    assert rel_err(feats[:2].cpu().numpy(), g["feats_b2"]) < TOL
-    assert rel_err(feats.mean(1).cpu().numpy(), g["feats_time_mean"]) < TOL
-    assert rel_err(net.embed(x).cpu().numpy(), g["feats_time_mean"]) < TOL
+    close(feats[:2].cpu().numpy(), g["feats_b2"])
+    close(feats.mean(1).cpu().numpy(), g["feats_time_mean"])
+    close(net.embed(x).cpu().numpy(), g["feats_time_mean"])
     b, t = [int(v) for v in g["tap_frame"]]
     f = b * 29 + t
+    # per-stage taps of one frame (debuggability): intermediate activations are sums of large cancelling terms, so an
+    # element near zero carries the absolute error of its summands -- they are held to the tensor-level measure; the
+    # element-wise bar is for what the path outputs (features, embeddings, logits, scores)
     assert rel_err(taps["stem_act"][f, :, :, :8].permute(2, 0, 1).cpu().numpy(), g["tap_stem_act_c8"]) < TOL
     assert rel_err(taps["stem"][f].permute(2, 0, 1).cpu().numpy(), g["tap_stem"]) < TOL
     for li in range(1, 5):
@@ -85,8 +95,8 @@ def test_video_golden_tcn_logits(golden, video_net):
         torch.cuda.synchronize()
     finally:
         net.extract_feats = True
-    assert rel_err(logits.cpu().numpy(), g["tcn_logits"]) < TOL
-    assert rel_err(full.cpu().numpy(), g["tcn_logits_full"]) < TOL
+    close(logits.cpu().numpy(), g["tcn_logits"])
+    close(full.cpu().numpy(), g["tcn_logits_full"])
     assert np.array_equal(torch.max(logits, 1)[1].cpu().numpy(), g["tcn_argmax"])
 
 
@@ -97,9 +107,10 @@ def test_video_relu_variant(golden):
     x = torch.from_numpy(wg.video_input(1, frames=5, key="input.video.short")).to(DEV)
     f = net(x, lengths=[5])
     torch.cuda.synchronize()
-    assert rel_err(f.cpu().numpy(), golden["video"]["relu_feats_t5"]) < TOL
+    close(f.cpu().numpy(), golden["video"]["relu_feats_t5"])
 
 
+@pytest.mark.slow
 def test_video_parity_size_b32_vs_oracle_and_batch_invariance(video_net):
     """BASELINE parity size [32,1,29,88,88]: HIP vs oracle, and batch invariance -- bit-exact in f32 mode
     (each output element is one fixed-order fp32 fma chain, so tiling / batch size cannot change it);
@@ -115,10 +126,9 @@ def test_video_parity_size_b32_vs_oracle_and_batch_invariance(video_net):
         assert torch.equal(em[8:12], em4)
     else:
         assert rel_err(em[8:12].cpu().numpy(), em4.cpu().numpy()) < 1e-6
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    with torch.no_grad():
-        ref = O.video_time_mean(O.lipreading_features(sd, x[:8]))   # 8 clips keep the CPU leg in seconds
-    assert rel_err(em[:8].cpu().numpy(), ref.numpy()) < TOL
+    with torch.no_grad():                                            # all 32 clips through the CPU oracle (~1 s each)
+        ref = torch.cat([O.video_time_mean(O.lipreading_features(sd, x[i:i + 8])) for i in range(0, 32, 8)])
+    close(em.cpu().numpy(), ref.numpy(), what="B=32 clip embeddings")
 
 
 @pytest.fixture(scope="module")
@@ -135,13 +145,13 @@ def test_audio_golden_etdnn(golden, audio_net):
     xv, xa = net.extract_embedding(x, taps=taps)
     fwd = net(x)
     torch.cuda.synchronize()
-    assert rel_err(xv.cpu().numpy(), g["etdnn_xv"]) < TOL
-    assert rel_err(xa.cpu().numpy(), g["etdnn_xa"]) < TOL
-    assert rel_err(fwd.cpu().numpy(), g["etdnn_forward"]) < TOL
-    assert rel_err(taps["pooled"].cpu().numpy(), g["etdnn_pooled"]) < TOL
+    close(xv.cpu().numpy(), g["etdnn_xv"])
+    close(xa.cpu().numpy(), g["etdnn_xa"])
+    close(fwd.cpu().numpy(), g["etdnn_forward"])
+    assert rel_err(taps["pooled"].cpu().numpy(), g["etdnn_pooled"]) < TOL                      # (taps: tensor-level measure)
     assert rel_err(taps["tdnn_out"][:, :, :16].permute(0, 2, 1).cpu().numpy(), g["etdnn_tdnn_out_c16"]) < TOL
     x200 = torch.from_numpy(wg.audio_input(2, 24, 200, key="input.audio.t200")).to(DEV)
-    assert rel_err(net.extract_embedding(x200)[0].cpu().numpy(), g["etdnn_xv_t200"]) < TOL
+    close(net.extract_embedding(x200)[0].cpu().numpy(), g["etdnn_xv_t200"])
     # [B,1,F,T] north-star layout is accepted and squeezed
     assert torch.equal(net.extract_embedding(x.unsqueeze(1))[0], xv)
 
@@ -151,15 +161,15 @@ def test_audio_golden_variants(golden):
     g = golden["audio"]
     x = torch.from_numpy(wg.audio_input(4, 24, 300)).to(DEV)
     net, _ = load(SpeakerEmbNet(tdnn_opts()), "audio5.")
-    assert rel_err(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_xv"]) < TOL
+    close(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_xv"])
     net, _ = load(SpeakerEmbNet(etdnn_opts(80)), "audio80.")
     x80 = torch.from_numpy(wg.audio_input(2, 80, 300, key="input.audio.f80")).to(DEV)
-    assert rel_err(net.extract_embedding(x80)[0].cpu().numpy(), g["etdnn80_xv"]) < TOL
+    close(net.extract_embedding(x80)[0].cpu().numpy(), g["etdnn80_xv"])
     net, _ = load(SpeakerEmbNet(tdnn_opts(pooling="attentive_statistic")), "audio_at.")
-    assert rel_err(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_attentive_xv"]) < TOL
+    close(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_attentive_xv"])
     net, _ = load(SpeakerEmbNet(tdnn_opts(bn_first=False)), "audio_nb.")
-    assert rel_err(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_actfirst_xv"]) < TOL
-    assert rel_err(net(x).cpu().numpy(), g["tdnn_actfirst_forward"]) < TOL
+    close(net.extract_embedding(x)[0].cpu().numpy(), g["tdnn_actfirst_xv"])
+    close(net(x).cpu().numpy(), g["tdnn_actfirst_forward"])
 
 
 def test_audio_parity_size_b32_f80_vs_oracle():
@@ -171,7 +181,7 @@ def test_audio_parity_size_b32_f80_vs_oracle():
     torch.cuda.synchronize()
     with torch.no_grad():
         ref, _ = O.speaker_extract_embedding(sd, x, O.ETDNN_CONTEXT)
-    assert rel_err(xv.cpu().numpy(), ref.numpy()) < TOL
+    close(xv.cpu().numpy(), ref.numpy())
 
 
 def test_full_size_configs_batch_invariance_and_fusion_properties(video_net):
@@ -230,7 +240,7 @@ def test_heads_golden(golden):
     with torch.no_grad():                      # inference path (grad-enabled forward is covered by test_train_gpu)
         loss, logits = crit(emb, lab)
     _, _, amax = crit.predict(emb)
-    assert rel_err(logits.cpu().numpy(), g["lmcl_logits"]) < TOL
+    close(logits.cpu().numpy(), g["lmcl_logits"])
     assert abs(float(loss) - float(g["lmcl_loss"])) < TOL * float(g["lmcl_loss"])
     assert np.array_equal(amax.cpu().numpy(), g["lmcl_argmax"])          # int64, bit-exact
     assert amax.dtype == torch.int64
@@ -238,12 +248,12 @@ def test_heads_golden(golden):
     ce, _ = load(CrossEntropy(1024, 57), "ce.")
     with torch.no_grad():
         loss, logits = ce(emb2, lab)
-    assert rel_err(logits.cpu().numpy(), g["ce_logits"]) < TOL
+    close(logits.cpu().numpy(), g["ce_logits"])
     assert abs(float(loss) - float(g["ce_loss"])) < TOL * float(g["ce_loss"])
     assert np.array_equal(ce.predict(emb2)[2].cpu().numpy(), g["ce_argmax"])
     for ef in (False, True):
         lf, _ = load(model_fusion(1024, 512, 57, ef), "lf.")
-        assert rel_err(lf(emb2).cpu().numpy(), g[f"linearfusion_extract{int(ef)}"]) < TOL
+        close(lf(emb2).cpu().numpy(), g[f"linearfusion_extract{int(ef)}"])
 
 
 def test_fusion_and_scoring_golden(golden):
@@ -266,8 +276,8 @@ def test_fusion_and_scoring_golden(golden):
 
 def test_end_to_end_fused_av_trials_vs_oracle(video_net, audio_net):
     """Config C4 in miniature: 16 utterances (4 speakers x 4), one clip each -> fused [16,1024]
-    -> all 120 pairs scored; HIP vs oracle: scores within 1e-4, EER equal to 1e-9 given equal
-    score ordering."""
+    -> all 120 pairs scored; HIP vs oracle: scores within 1e-4; the EER is a function of the score ORDER only, so it
+    is equal to 1e-9 when the two orderings agree (asserted), and otherwise may move by one trial's weight."""
     from deeplip_amd import fusion, scoring
     vnet, vsd = video_net
     anet, asd = audio_net
@@ -281,9 +291,10 @@ def test_end_to_end_fused_av_trials_vs_oracle(video_net, audio_net):
     torch.cuda.synchronize()
     ref_fused = O.fused_av_embedding(vsd, asd, xv_in, xa_in)
     ref_s = O.cosine_trial_scores(ref_fused.numpy(), ia, ib)
-    assert rel_err(fused.cpu().numpy(), ref_fused.numpy()) < TOL
+    close(fused.cpu().numpy(), ref_fused.numpy())
     assert np.abs(s.cpu().numpy() - ref_s).max() < TOL
     y = (spk[ia] == spk[ib]).astype(int)
     e_hip, _ = scoring.eer_from_scores(y, s.cpu().numpy())
     e_ref, _ = O.eer(y, [np.array([v]) for v in ref_s])
-    assert abs(e_hip - e_ref) < 1e-3
+    same_order = np.array_equal(np.argsort(s.cpu().numpy(), kind="stable"), np.argsort(np.asarray(ref_s).reshape(-1), kind="stable"))
+    assert abs(e_hip - e_ref) < (1e-9 if same_order else 1.0 / min(int(y.sum()), int((1 - y).sum())))

@@ -49,6 +49,12 @@ def main():
             if name in c:
                 e[name + "_per_launch"] = c[name] / n
         res[k] = e
+    # stamp: which kernel build these counters belong to (bench.py ignores the file on a mismatch)
+    import hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "deeplip_amd", "csrc", "conv_igemm_f16x3_dma.hip")
+    abi = int(re.search(r"#define DLIP_ABI_VERSION (\d+)", open(os.path.join(root, "include", "deeplip_hip.h")).read()).group(1))
+    res["_meta"] = {"kernel_sha": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "abi": abi, "steps": steps}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
 

@@ -10,6 +10,11 @@ through every TDNN layer with batch-statistics BatchNorm, LMCL / CrossEntropy, `
 whole encoder (conv dgrad / wgrad, BN and pooling backward as dlip_* launches -- deeplip_amd/autograd.py),
 SGD over model + criterion parameters, MultiStepLR, margin schedule, per-epoch checkpoints and checkpoint
 averaging.  ``train.freeze_encoder: true`` keeps the older criterion-only step on frozen x-vectors.
+
+Data parallelism (the reference wraps the model in nn.DataParallel over ``gpus_id``, train_audio.py:80-83): launched
+under ``torch.distributed.run`` every rank draws its own batches, replicas start from rank 0's weights, gradients are
+averaged by bucketed all-reduces over RCCL that overlap the backward pass (deeplip_amd.dist.GradBuckets), metrics are
+summed over ranks and rank 0 alone writes checkpoints.
 """
 from __future__ import annotations
 
@@ -25,7 +30,7 @@ import yaml
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from deeplip_amd import ops, scoring, weightgen as wg  # noqa: E402
+from deeplip_amd import _lib, dist as ddist, ops, scoring, weightgen as wg  # noqa: E402
 from deeplip_amd.synthetic import SyntheticAVSet, synthetic_trials  # noqa: E402
 from models.audio_models import tdnn  # noqa: E402
 from models.audio_models.loss import AAMSoftmax, LMCL, CrossEntropy  # noqa: E402
@@ -46,6 +51,8 @@ class Trainer(object):
         if not torch.cuda.is_available():
             raise RuntimeError("train_audio.py needs a ROCm GPU: the deeplip_amd engine has no CPU path")
         self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+        torch.cuda.set_device(self.device)
+        self.rank, self.world = ddist.init_from_env(self.device)
         arch = self.model_opts["arch"]
         if arch in ("tdnn", "etdnn"):
             self.model = tdnn.SpeakerEmbNet(self.model_opts)
@@ -79,6 +86,12 @@ class Trainer(object):
         self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optim, milestones=self.train_opts["lr_decay_step"], gamma=0.1)
         self.epoch, self.current_epoch = self.train_opts["epoch"], 0
         self.log_time = time.asctime(time.localtime(time.time())).replace(" ", "_")[4:]
+        if self.world > 1:          # one directory name for the job (rank 0's clock), identical replicas
+            name = [self.log_time]
+            torch.distributed.broadcast_object_list(name, 0)
+            self.log_time = name[0]
+        ddist.broadcast_params(list(self.model.parameters()) + list(self.criterion.parameters()))
+        self.buckets = None         # built on the first training step (gradient views need the final placement)
 
     def _adjust_margin(self):
         if isinstance(self.criterion, (LMCL, AAMSoftmax)):
@@ -87,29 +100,35 @@ class Trainer(object):
     def _train_epoch(self):
         """train_audio.py:167-199 on the synthetic set: full-encoder step (or criterion-only with freeze_encoder)."""
         bs = self.train_opts["bs"]
-        rng = np.random.Generator(np.random.PCG64([self.current_epoch, 5]))
+        rng = np.random.Generator(np.random.PCG64([self.current_epoch, 5, self.rank]))    # every rank its own batches
         tot = n = correct = 0.0
         self.model.train(not self.freeze_encoder)
+        if self.world > 1 and self.buckets is None:
+            params = [p for g in self.optim.param_groups for p in g["params"]]
+            self.buckets = ddist.GradBuckets(params)
         t0 = time.perf_counter()
         steps = self.train_opts.get("steps_per_epoch", 2)
         for _ in range(steps):
             idx = rng.integers(0, len(self.trainset), bs)
             x = torch.from_numpy(self.trainset.audio(idx)).to(self.device)
             lab = torch.from_numpy(self.trainset.labels(idx)).to(self.device)
-            self.optim.zero_grad()
+            self.optim.zero_grad(set_to_none=self.buckets is None)
             if self.freeze_encoder:
                 with torch.no_grad():
                     emb = self.model(x)
             else:
                 emb = self.model(x)                       # output of bn2 / LeakyReLU (train_audio.py:187)
             loss, logits = self.criterion(emb, lab)
-            loss.backward()
+            loss.backward()                               # bucket all-reduces start as the gradients land
+            if self.buckets is not None:
+                self.buckets.finish()
             self.optim.step()
             correct += float((torch.max(logits, dim=1)[1] == lab).sum())
             tot += float(loss.detach()) * len(idx); n += len(idx)
-        torch.cuda.synchronize()
+        _lib.check_range(sync=True)                       # f16x3 packing: an overflow in this epoch is an error, not a NaN
+        tot, correct, n = ddist.allreduce_metrics([tot, correct, n], self.device)
         self.last_epoch_stats = {"loss": tot / n, "acc": correct / n, "utt_per_s": n / (time.perf_counter() - t0),
-                                 "steps": steps, "bs": bs}
+                                 "steps": steps, "bs": bs * self.world}
         self.model.eval()
         return tot / n
 
@@ -123,9 +142,13 @@ class Trainer(object):
                                                                                      st["steps"], st["bs"]), flush=True)
             self.lr_scheduler.step()
             self.save()
+            if self.world > 1:
+                torch.distributed.barrier()     # rank 0's checkpoint is on disk before anybody averages / resumes
 
     def save(self, filename=None):
         path = "exp/{}/{}".format(self.log_time, filename or "net_{}.pth".format(self.current_epoch))
+        if self.rank != 0:          # replicas are identical: one writer
+            return path
         os.makedirs(os.path.dirname(path), exist_ok=True)
         # keys carry the DataParallel 'module.' prefix like the reference's checkpoints (train_audio.py:262)
         torch.save({"epoch": self.current_epoch, "state_dict": {"module." + k: v for k, v in self.model.state_dict().items()},
@@ -133,10 +156,17 @@ class Trainer(object):
         return path
 
     def load(self, resume):
-        ck = torch.load(resume, map_location="cpu")
-        self.model.load_state_dict({k.replace("module.", ""): v for k, v in ck["state_dict"].items()})
-        self.criterion.load_state_dict(ck["criterion"])
-        self.current_epoch = ck["epoch"]
+        """Resume from one of this trainer's checkpoints or from a reference one (train_audio.py:234-296): there
+        ``criterion`` is the pickled criterion MODULE (train_audio.py:264), and ``net_avg.pth`` (written by
+        model_average, :229-232) has neither ``criterion`` nor ``epoch``."""
+        ck = torch.load(resume, map_location="cpu", weights_only=False)
+        self.model.load_state_dict({k.replace("module.", "", 1) if k.startswith("module.") else k: v for k, v in ck["state_dict"].items()})
+        crit = ck.get("criterion")
+        if crit is not None:
+            if isinstance(crit, torch.nn.Module):
+                crit = crit.state_dict()
+            self.criterion.load_state_dict(crit)
+        self.current_epoch = int(ck.get("epoch", self.current_epoch))
 
     def model_average(self, avg_num=4):
         """train_audio.py:216-232: average the state dicts of the last ``avg_num`` epoch checkpoints."""
@@ -146,8 +176,11 @@ class Trainer(object):
         for p in paths:
             sd = torch.load(p, map_location="cpu")["state_dict"]
             avg = {k: v.clone().double() for k, v in sd.items()} if avg is None else {k: avg[k] + v.double() for k, v in sd.items()}
-        avg = {k.replace("module.", ""): (v / len(paths)).to(self.model.state_dict()[k.replace("module.", "")].dtype) for k, v in avg.items()}
+        own = self.model.state_dict()
+        avg = {k.replace("module.", "", 1): (v / len(paths)).to(own[k.replace("module.", "", 1)].dtype) for k, v in avg.items()}
         self.model.load_state_dict(avg)
+        if self.rank == 0 and paths:      # the file the reference's extract_* methods load (train_audio.py:229-232,300,346)
+            torch.save({"state_dict": {"module." + k: v for k, v in avg.items()}}, "exp/{}/net_avg.pth".format(self.log_time))
         return len(paths)
 
     def extract_test_xv(self, batch=64):
@@ -179,7 +212,11 @@ def main():
         tr.model_average(min(4, tr.epoch))
     tr.extract_test_xv()
     eer, thr = tr.eer()
-    print("EER: {:.6f}%".format(eer * 100))
+    if tr.rank == 0:
+        print("EER: {:.6f}%".format(eer * 100))
+    if tr.world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ step a ``dlip_*`` launch (deeplip_amd/autograd_video.py: conv dgrad / wgrad on t
 train-mode BN, PReLU, max-pool, pooling kernels), pinned by a golden step captured from the reference
 class (tests/test_train_video_gpu.py).  ``--head-only`` trains the classifier layer ``tcn.tcn_output`` on
 frozen eval-mode features instead (the fast path on the fused inference kernels).  Under
-``torch.distributed.run`` every rank draws its own batches and the gradients are averaged with ONE flat
+``torch.distributed.run`` every rank draws its own batches and the gradients are averaged by bucketed
 all-reduce per step over RCCL (the reference uses DataParallel: train_video.py:196).
 ``--device cpu`` runs the plumbing only (config -> model -> batches -> optimiser/scheduler ->
 checkpoint round trip) because the engine has no CPU arithmetic by design.
@@ -129,6 +129,8 @@ def train(model, args, device):
         for p in head.parameters():
             p.requires_grad = True
     params = [p for p in model.parameters() if p.requires_grad]
+    # DP: gradients live in flat buckets whose all-reduces (RCCL) start while backward is still running
+    buckets = ddist.GradBuckets(params) if (world > 1 and device.type != "cpu") else None
     optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=1e-4)                      # (:112-113)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=5, eta_min=4e-08)      # (:114)
     last = None
@@ -143,7 +145,7 @@ def train(model, args, device):
                 continue
             labels = labels.to(device)
             x = ops.ingest_rgb_u8(inputs.to(device)) if args.rgb else inputs.unsqueeze(1).to(device)   # :125
-            optimizer.zero_grad()
+            optimizer.zero_grad(set_to_none=buckets is None)
             if full:
                 logits = model(x, lengths=lengths)                          # (:140) whole graph on the engine
             else:
@@ -152,8 +154,8 @@ def train(model, args, device):
                 logits = ag.linear(pooled, head.weight, head.bias)          # tcn_output (model.py:27)
             loss = ag.margin_ce_loss(logits, labels, 1.0, 0.0)              # nn.CrossEntropyLoss (:115,143)
             loss.backward()
-            if world > 1:
-                ddist.allreduce_grads(params, world)                        # one flat all-reduce over RCCL
+            if buckets is not None:
+                buckets.finish()                                            # wait for the bucket all-reduces, average
             optimizer.step()
             sched.step()                                                    # per-iteration (:147)
             _, pred = torch.max(torch.softmax(logits.detach(), 1), 1)       # (:145)
@@ -169,7 +171,8 @@ def train(model, args, device):
 
 def main(argv=None):
     args = load_args(argv)
-    torch.manual_seed(SEED); np.random.seed(SEED)
+    # the reference seeds once (train_video.py:70-73); under DP every rank needs its own dropout masks
+    torch.manual_seed(SEED + int(os.environ.get("RANK", "0"))); np.random.seed(SEED)
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))) if args.device == "gpu" else torch.device("cpu")
     if args.device == "gpu" and not torch.cuda.is_available():
         raise RuntimeError("no ROCm GPU visible: use --device cpu for the plumbing-only run")
@@ -183,9 +186,10 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and args.device == "gpu":
         import torch.distributed as dist
+        from deeplip_amd import dist as ddist
         torch.cuda.set_device(device)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        ddist.init_from_env(device)
+        ddist.broadcast_params(list(model.parameters()) + list(model.buffers()))
     if args.extract_feats and args.mouth_patch_path:
         out = extract_feats(model, np.load(args.mouth_patch_path)["data"], device)
         if args.mouth_embedding_out_path:
