@@ -81,3 +81,25 @@ def fuse_av(xv_audio: torch.Tensor, em_video) -> torch.Tensor:
     if isinstance(em_video, ops.Pooled):
         return ops.znorm_cat_pooled(xv_audio.contiguous(), em_video)
     return ops.znorm_cat(xv_audio.contiguous(), em_video.contiguous())
+
+
+_side_streams: dict = {}
+
+
+def embed_av(model_audio, model_video, feats_audio: torch.Tensor, clips: torch.Tensor, two_streams: bool = True) -> torch.Tensor:
+    """One batch of the test-time pipeline (train_fusion.py:338-358): x-vectors, per-clip lip embeddings, z-norm + concat
+    -> [B, 1024].  ``two_streams``: the speech encoder is issued on a second HIP stream (fork / join by events), so the
+    two encoders' launches -- each of which fills the chip's LDS on its own -- overlap at their heads and tails;
+    recorded into a step plan the fork / join becomes two branches of the graph (measured +4.5-5 % on the B = 64 step)."""
+    if not two_streams:
+        return fuse_av(model_audio.extract_embedding(feats_audio)[0], model_video.embed(clips, finish=False))
+    cur = torch.cuda.current_stream(clips.device)
+    side = _side_streams.get((clips.device, cur.cuda_stream))
+    if side is None:
+        side = _side_streams[(clips.device, cur.cuda_stream)] = torch.cuda.Stream(device=clips.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        xv_audio = model_audio.extract_embedding(feats_audio)[0]
+    em_video = model_video.embed(clips, finish=False)
+    cur.wait_stream(side)
+    return fuse_av(xv_audio, em_video)

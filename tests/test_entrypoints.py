@@ -92,3 +92,38 @@ def test_train_audio_resnet_arch_with_aam_softmax(tmp_path, monkeypatch):
     assert table.emb.shape == (6, 256)
     eer, _ = tr.eer()
     assert 0 <= eer <= 1
+
+
+@pytest.mark.gpu
+def test_train_audio_loads_reference_style_checkpoints(tmp_path, monkeypatch):
+    """Trainer.load takes the three checkpoint forms the reference produces (train_audio.py:209-232,259-266): its own
+    epoch files (criterion as a state dict here), a file whose ``criterion`` is the pickled criterion MODULE, and
+    ``net_avg.pth`` -- state_dict only, 'module.'-prefixed keys -- which model_average() now also writes."""
+    import train_audio
+    monkeypatch.chdir(tmp_path)
+    ov = {"data.test_speakers": 3, "data.test_utt_per_spk": 2, "data.trials": 30, "data.trial_targets": 6,
+          "data.audio_frames": 100, "data.n_spk": 5, "data.utt_per_spk": 2, "train.bs": 4, "train.epoch": 2}
+    tr = train_audio.Trainer(overrides=ov)
+    tr._train()
+    assert tr.model_average(2) == 2
+    avg_path = "exp/{}/net_avg.pth".format(tr.log_time)
+    assert os.path.exists(avg_path)
+    ck = torch.load(avg_path, map_location="cpu")
+    assert set(ck) == {"state_dict"} and all(k.startswith("module.") for k in ck["state_dict"])
+    want = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    # (1) net_avg.pth: no criterion, no epoch
+    tr2 = train_audio.Trainer(overrides=ov)
+    tr2.load(avg_path)
+    for k, v in tr2.model.state_dict().items():
+        assert torch.equal(v.cpu(), want[k]), k
+    # (2) criterion pickled as a Module, the way the reference saves it
+    p2 = str(tmp_path / "ref_style.pth")
+    torch.save({"epoch": 7, "state_dict": {"module." + k: v for k, v in want.items()}, "criterion": tr.criterion.cpu(),
+                "optimizer": {}}, p2)
+    tr3 = train_audio.Trainer(overrides=ov)
+    tr3.load(p2)
+    assert tr3.current_epoch == 7
+    assert torch.equal(tr3.criterion.weights.detach().cpu(), tr.criterion.weights.detach().cpu())
+    # (3) this trainer's own epoch file
+    tr3.load("exp/{}/net_2.pth".format(tr.log_time))
+    assert tr3.current_epoch == 2

@@ -91,3 +91,26 @@ def test_pack_cache_sees_in_place_edits():
     a1 = audio.extract_embedding(xa)[0]
     torch.cuda.synchronize()
     np.testing.assert_allclose((a1 - a0).cpu().numpy(), 0.5, atol=1e-5)
+
+
+def test_two_stream_step_is_bit_identical_eager_and_recorded():
+    """fusion.embed_av issues the speech encoder on a second stream (fork / join); recorded into a plan the two encoders
+    are parallel branches of the graph.  Same bits as the sequential step, eagerly and replayed."""
+    from deeplip_amd import fusion, packing, weightgen as wg
+    from deeplip_amd.plan import StepPlan
+    try:
+        video, audio = _models("f16x3")
+        xv = torch.from_numpy(wg.video_input(3, frames=29, key="plan2s.video")).cuda()
+        xa = torch.from_numpy(wg.audio_input(3, 24, 300, key="plan2s.audio")).cuda()
+        seq = fusion.embed_av(audio, video, xa, xv, two_streams=False).clone()
+        par = fusion.embed_av(audio, video, xa, xv, two_streams=True).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(seq, par)
+        plan = StepPlan(lambda v, a: fusion.embed_av(audio, video, a, v), xv.clone(), xa.clone())
+        for _ in range(4):
+            out = plan.run()
+        torch.cuda.synchronize()
+        assert torch.equal(out, seq)
+        plan.close()
+    finally:
+        packing.set_precision("f32")
