@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _lock = threading.Lock()
 _lib = None
@@ -68,6 +68,7 @@ SIGNATURES = {
     "dlip_split_pack_f32": [c_f, c_f, C.c_int64, c_i32, c_stream],
     "dlip_split_unpack_f32": [c_f, c_f, C.c_int64, c_i32, c_stream],
     "dlip_conv_plan": [C.POINTER(ConvDesc), c_i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "dlip_conv_kernel_kind": [C.POINTER(ConvDesc)],
     "dlip_plan_begin": [c_stream],
     "dlip_plan_end": [c_stream, C.POINTER(C.c_void_p)],
     "dlip_plan_run": [C.c_void_p, c_stream],
@@ -187,7 +188,7 @@ def ensure_conv_workspace() -> None:
 
 
 # ---- diagnostic overrides (tests, tools): dlip_debug_set ----
-DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK = 0, 1, 2, 3
+DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK, DBG_WIN = 0, 1, 2, 3, 4
 
 
 def debug_set(key: int, value: int = -1) -> None:

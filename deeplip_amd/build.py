@@ -19,7 +19,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libdeeplip_hip.so")
-SOURCES = ["capi.hip", "plan.hip", "conv_igemm.hip", "conv_igemm_f16x3.hip", "conv_igemm_f16x3_dma.hip", "stem3d.hip", "stem3d_f16x3.hip", "pool_ops.hip", "score_ops.hip", "layout_ops.hip", "train_ops.hip", "encoder_train_ops.hip", "video_train_ops.hip", "frontend_ops.hip"]
+SOURCES = ["capi.hip", "plan.hip", "conv_igemm.hip", "conv_igemm_f16x3.hip", "conv_igemm_f16x3_dma.hip", "conv_win_f16x3.hip", "stem3d.hip", "stem3d_f16x3.hip", "pool_ops.hip", "score_ops.hip", "layout_ops.hip", "train_ops.hip", "encoder_train_ops.hip", "video_train_ops.hip", "frontend_ops.hip"]
 ARCH = "gfx950"
 
 
@@ -34,7 +34,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "dlip_common.h"), os.path.join(CSRC, "conv_common.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "dlip_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv_dma_common.h"),
                                                        os.path.join(ROOT, "include", "deeplip_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

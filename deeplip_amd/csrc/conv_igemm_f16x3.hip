@@ -329,6 +329,8 @@ int launch(const ConvArgs& a, hipStream_t st, int flags) {
 
 extern "C" int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int epi);   // conv_igemm_f16x3_dma.hip
 extern "C" void dlip_conv_dma_tile(long long M, int K, int nk, int epi, int* bm, int* bn);
+extern "C" int dlip_conv_win_ok(const void* args);                                          // conv_win_f16x3.hip
+extern "C" int dlip_conv_f16x3_win_launch(const void* args, void* stream, int out_split);
 
 // Diagnostic switch (dlip_debug_set DLIP_DBG_DMA_ENABLE = 0): keeps split-format launches on the register-staged kernel.
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_dma_enabled(void) { return dlip_dbg_value[DLIP_DBG_DMA_ENABLE] != 0; }
@@ -369,8 +371,11 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   const bool dma_ok = (flags & 2) ? (reinterpret_cast<uintptr_t>(y) & 15) == 0
                                   : ((d->K & 3) == 0 && (d->ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0);
   const bool res_ok = residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 15) == 0;
-  if ((flags & 1) && dma_ok && res_ok && dlip_conv_dma_enabled())
+  if ((flags & 1) && dma_ok && res_ok && dlip_conv_dma_enabled()) {
+    // narrow same-size 3x3 layers (layer 1: 64 -> 64): one activation window per channel slice instead of nine tap fetches
+    if (dlip_conv_win_ok(&a)) return dlip_conv_f16x3_win_launch(&a, stream, (flags & 2) ? 1 : 0);
     return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) ? 1 : 0);
+  }
   switch (pick_tile(a.M, d->K, kEffF16x3)) {
     case 0: return launch<128, 128, 2, 2>(a, st, flags);
     case 1: return launch<128, 64, 2, 2>(a, st, flags);
@@ -438,3 +443,4 @@ extern "C" int dlip_conv_pool_f16x3(const dlip_conv_desc* d, const float* x, con
   a.pool_group = group_rows;
   return dlip_conv_f16x3_dma_launch(&a, stream, 2);
 }
+

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 16
+#define DLIP_ABI_VERSION 17
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -148,6 +148,10 @@ int dlip_split_unpack_f32(const float* x, float* y, int64_t rows, int32_t C, dli
  * kernel) will use for `d` -- i.e. which conv_igemm_*_kernel<BM,BN,..> instance a profiler will
  * show.  Host-only, no launch. */
 int dlip_conv_plan(const dlip_conv_desc* d, int32_t split_f16, int32_t* bm, int32_t* bn);
+/* 1 if a split-format (DLIP_SPLIT_IN) launch of `d` runs on the window kernel (conv_win_f16x3_kernel<128,64>: same-size
+ * stride-1 3x3 convolutions with K <= 64 -- one activation window per channel slice in LDS instead of one fetch per
+ * tap), 0 if on the LDS-DMA ring kernel dlip_conv_plan describes.  Host-only. */
+int dlip_conv_kernel_kind(const dlip_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------
  * Video stem: Conv3d(1->K, 5x7x7, stride (1,2,2), pad (2,3,3), no bias) + BatchNorm3d + PReLU|ReLU
@@ -448,7 +452,8 @@ int dlip_set_status_words(int32_t* words);
 
 /* Diagnostic overrides for tests and A/B runs (the launch path reads no environment variable):
  * key 0 tile of dlip_conv_nhwc_f32 / the register-staged f16x3 kernel, 1 tile of the LDS-DMA kernel,
- * 2 LDS-DMA kernel on/off (0 = off), 3 balanced split (0 never, 2 always); value -1 restores the built-in choice. */
+ * 2 LDS-DMA kernel on/off (0 = off), 3 balanced split (0 never, 2 always), 4 window kernel on/off (0 = off);
+ * value -1 restores the built-in choice. */
 int dlip_debug_set(int32_t key, int32_t value);
 
 /* ------------------------------------------------------------------------------------------

@@ -742,3 +742,55 @@ def test_conv_dma_balanced_split_stress_under_uneven_load(ops):
             assert rel_err(first.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
     finally:
         _lib.debug_set(_lib.DBG_STREAMK, -1)
+
+
+WIN_CASES = [  # N, H, W, C, K, pad (= dil for same-size 3x3), dil, residual, slope, out_split
+    (3, 22, 22, 64, 64, 1, 1, True, True, True),        # layer 1's shape
+    (260, 22, 22, 64, 64, 1, 1, True, True, True),      # many tiles, M tail inside an image
+    (7, 9, 13, 64, 64, 1, 1, False, True, False),       # odd width: tiles start mid-row, fp32 output
+    (5, 11, 11, 128, 64, 1, 1, True, False, True),      # four channel slices: windows fetched inside the loop
+    (2, 6, 6, 32, 32, 1, 1, False, True, True),         # one channel slice, K = 32 (half-empty column block)
+    (4, 11, 11, 96, 48, 2, 2, True, True, False),       # dilation 2 (halo 48 = the window's slack), ragged K
+    (1, 3, 3, 64, 64, 1, 1, True, True, True),          # image smaller than a tile: every border case at once
+    (9, 1, 20, 64, 64, 1, 1, False, True, True),        # H = 1 with a 3x3 kernel: row taps all fall outside
+]
+
+
+@pytest.mark.parametrize("case", WIN_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_conv_window_kernel(ops, case):
+    """conv_win_f16x3_kernel (same-size stride-1 3x3, K <= 64): against fp64, and against the ring kernel it replaces
+    (dlip_debug_set DLIP_DBG_WIN = 0) -- the two differ only in where the activation fragments come from."""
+    from deeplip_amd import _lib, packing
+    from deeplip_amd._lib import ConvDesc
+    N, H, W, C, K, pad, dil, use_res, use_slope, out_split = case
+    x = _split_ref_value(rnd(N, H, W, C, seed=81) * 2.0)
+    w = rnd(K, 3, 3, C, seed=82, scale=1.0 / np.sqrt(9 * C))
+    b = rnd(K, seed=83, scale=0.1)
+    ws, sc = packing.split_weights(w.double())
+    slope = (torch.rand(K, generator=torch.Generator().manual_seed(5)) * 0.3) if use_slope else None
+    res = _split_ref_value(rnd(N, H, W, K, seed=84)) if use_res else None
+    d = ConvDesc(N, H, W, C, K, 3, 3, 1, 1, pad, pad, dil, dil, H, W, C, K, K if use_res else 0)
+    assert _lib.lib().dlip_conv_kernel_kind(d) == 1                      # this shape IS served by the window kernel
+    kw = dict(pad=(pad, pad), dil=(dil, dil), slope=slope.cuda() if use_slope else None, w_scale=sc.cuda(), x_split=True,
+              out_split=out_split and K % 32 == 0, residual=ops.split_pack(res.cuda()) if (use_res and K % 32 == 0) else None)
+    if use_res and K % 32:
+        res = None
+    xs = ops.split_pack(x.cuda())
+    y = ops.conv_nhwc(xs, ws.cuda(), b.cuda(), **kw)
+    try:
+        _lib.debug_set(_lib.DBG_WIN, 0)
+        assert _lib.lib().dlip_conv_kernel_kind(d) == 0
+        y_ring = ops.conv_nhwc(xs, ws.cuda(), b.cuda(), **kw)
+    finally:
+        _lib.debug_set(_lib.DBG_WIN, -1)
+    if kw["out_split"]:
+        y, y_ring = ops.split_unpack(y), ops.split_unpack(y_ring)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=pad, dilation=dil)
+    if res is not None:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    if use_slope:
+        ref = torch.where(ref >= 0, ref, ref * slope.double().view(1, K, 1, 1))
+    ref = ref.permute(0, 2, 3, 1)
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < TOL
+    assert rel_err(y.cpu().numpy(), y_ring.cpu().numpy()) < 2e-6
