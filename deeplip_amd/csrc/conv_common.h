@@ -59,6 +59,7 @@ struct ConvArgs {
   int pool_group;       // rows per group (>= the tile's BM)
   int32_t* status;      // range-status word (NULL: not reported)
   FastDiv div_howo, div_wo;
+  int n_inner;          // LDS-DMA kernel: tile order with the output-channel block inner
 };
 
 
@@ -110,6 +111,7 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
   a.status = nullptr;
   a.div_howo = dlip_fastdiv((uint32_t)a.HoWo);
   a.div_wo = dlip_fastdiv((uint32_t)a.Wo);
+  a.n_inner = 0;
   return DLIP_OK;
 }
 

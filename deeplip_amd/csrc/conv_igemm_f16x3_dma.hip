@@ -134,13 +134,16 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     const int tile = (int)(it / a.nk);
     const int k0 = (int)(it - (long long)tile * a.nk);
     const int kn = (int)((it_end - it) < (long long)(a.nk - k0) ? (it_end - it) : (long long)(a.nk - k0));
-    // Tile order: output-channel block OUTER.  A workgroup's range, and (through the XCD remap of g) an
-    // XCD's eighth of the launch, then stays on one 128-channel weight block -- BN x R x S x C x 4 bytes,
-    // which fits the XCD's 4 MiB L2 where the whole filter bank of layer3/4 (2.4 / 9.4 MB) does not --
-    // while the activation rows stream through once per block.
+    // Tile order (chosen per launch, launch_one): output-channel block OUTER -- a workgroup's range, and (through the
+    // XCD remap of g) an XCD's eighth of the launch, stays on one 128-channel weight block while the activation rows
+    // stream through once per block -- or INNER (a.n_inner) when the whole filter bank fits the XCD's L2.
     const int tiles_m = (a.M + BM - 1) / BM;
-    const int tile_n = tile / tiles_m;
-    const int tile_m = tile - tile_n * tiles_m;
+    int tile_n = tile / tiles_m;
+    int tile_m = tile - tile_n * tiles_m;
+    if (a.n_inner) {   // column block INNER: consecutive tiles (one workgroup's range, one XCD's eighth) share their activation rows
+      tile_m = tile / a.tiles_n;
+      tile_n = tile - tile_m * a.tiles_n;
+    }
     // every wave is done reading the previous segment's last stage (and the ticket word) before the ring is refilled
     if (it != it_begin) __syncthreads();
     DLIP_STAMP(0);
@@ -762,6 +765,13 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     }
   }
   sk.G = (int)G;
+  // Tile order.  Column block INNER when the whole filter bank stays in an XCD's 4 MiB L2 beside the activation rows in
+  // flight (<= 3.25 MB: the TDNN layers incl. tdnn.9's 12 column blocks, layer 3): the column blocks of one row block run
+  // back to back, so its activation rows come from HBM once instead of once per column block (tdnn.9 108 -> 98 us,
+  // tdnn k=1 50 -> 48, layer 3 -1..5 %).  Larger banks (layer 4: 9.4 MB) keep the column block OUTER -- there each XCD
+  // stays on one 128-channel weight block and re-streams the (L2-sized) activations instead (+4 % if forced inner).
+  b.n_inner = (b.tiles_n > 1 && (size_t)a.K * a.rsc * 4 <= (size_t)3407872) ? 1 : 0;
+  if (dlip_dbg_value[DLIP_DBG_NINNER] >= 0) b.n_inner = dlip_dbg_value[DLIP_DBG_NINNER] > 0 ? 1 : 0;
 #ifdef DLIP_LAB
   sk.stamps = nullptr;
   if (getenv("DLIP_STAMP_PRINT")) return dlip_lab_stamped_launch(kern, (unsigned)G, threads, lds, st, b, sk, BM, BN);

@@ -452,7 +452,8 @@ int dlip_set_status_words(int32_t* words);
 
 /* Diagnostic overrides for tests and A/B runs (the launch path reads no environment variable):
  * key 0 tile of dlip_conv_nhwc_f32 / the register-staged f16x3 kernel, 1 tile of the LDS-DMA kernel,
- * 2 LDS-DMA kernel on/off (0 = off), 3 balanced split (0 never, 2 always), 4 window kernel on/off (0 = off);
+ * 2 LDS-DMA kernel on/off (0 = off), 3 balanced split (0 never, 2 always), 4 window kernel on/off (0 = off),
+ * 5 tile order of the LDS-DMA kernel (0 column block outer, 1 inner);
  * value -1 restores the built-in choice. */
 int dlip_debug_set(int32_t key, int32_t value);
 

@@ -16,6 +16,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--variants", default="-1", help="comma list of DMA tile ids (dlip_debug_set; -1 = built-in choice; 6..9 need the lab build via DLIP_LIB_PATH)")
 ap.add_argument("--streamk", type=int, default=-1, help="balanced split: -1 built-in cost model, 0 never, 2 always (dlip_debug_set)")
+ap.add_argument("--ninner", type=int, default=-1, help="1: tile order with the output-channel block inner (experiment)")
 ap.add_argument("--xpad", type=int, default=0, help="extra (unused) channels per input pixel: breaks the power-of-two pixel stride")
 a = ap.parse_args()
 B = a.batch
@@ -37,6 +38,7 @@ L = [
 ]
 variants = a.variants.split(",")
 _lib.debug_set(_lib.DBG_STREAMK, a.streamk)
+_lib.debug_set(5, a.ninner)
 tot = {v: 0.0 for v in variants}
 tot_best = 0.0
 for name, (n, h, w, c), k, r, s, st, pd, dl, res, count in L:
