@@ -56,6 +56,51 @@ __global__ __launch_bounds__(256) void powspec_kernel(const float* __restrict__ 
   if (lane == 0) energy[r] = e == 0.0 ? 2.220446049250313e-16f : (float)e;
 }
 
+// Power spectrum with the DFT carried in fp64 (numpy's rfft, which python_speech_features calls, runs in double): one
+// workgroup per frame, the frame and the nfft twiddles (cos, sin of 2 pi j / nfft) in LDS, one thread per bin.  For banks
+// whose lowest filters sit on bins holding ~1e-9 of the spectrum (80 bands at nfft = 512) the fp32-GEMM DFT's rounding
+// noise is the signal; this path holds 1e-4 there too (nfft a power of two, <= 1024).
+__global__ __launch_bounds__(256) void powspec_dft64_kernel(const float* __restrict__ frames, float* __restrict__ pw,
+                                                            float* __restrict__ energy, int NB, int NBp, int nfft) {
+  extern __shared__ double sh[];          // [nfft] frame | [nfft] cos | [nfft] sin | [4] wave sums
+  double* fr = sh;
+  double* cs = sh + nfft;
+  double* sn = sh + 2 * nfft;
+  double* part = sh + 3 * nfft;
+  const int r = blockIdx.x;
+  for (int j = threadIdx.x; j < nfft; j += 256) {
+    fr[j] = (double)frames[(long long)r * nfft + j];
+    double s, c;
+    sincospi(2.0 * (double)j / (double)nfft, &s, &c);
+    cs[j] = c;
+    sn[j] = s;
+  }
+  __syncthreads();
+  double e = 0.0;
+  for (int k = threadIdx.x; k < NBp; k += 256) {
+    float p = 0.f;
+    if (k < NB) {
+      double re = 0.0, im = 0.0;
+      for (int n = 0; n < nfft; ++n) {
+        const int idx = (k * n) & (nfft - 1);
+        re += fr[n] * cs[idx];
+        im -= fr[n] * sn[idx];
+      }
+      const double pp = (re * re + im * im) / (double)nfft;
+      p = (float)pp;
+      e += pp;
+    }
+    pw[(long long)r * NBp + k] = p;
+  }
+  e = dlip_wave_sum_f64(e);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = part[0] + part[1] + part[2] + part[3];
+    energy[r] = t == 0.0 ? 2.220446049250313e-16f : (float)t;
+  }
+}
+
 // y = log(x == 0 ? eps : x) elementwise (base.logfbank / base.mfcc)
 __global__ __launch_bounds__(256) void log_floor_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -87,6 +132,27 @@ __global__ __launch_bounds__(256) void cmvn_kernel(const float* __restrict__ fea
   const float den = normalize ? (float)sqrt(q / NF) + 2e-12f : 1.f;
   float* o = y + (b * C + c) * NF;
   for (int f = 0; f < NF; ++f) o[f] = ((en ? logf(en[f]) : p[(long long)f * ldf]) - mu) / den;
+}
+
+// python_speech_features.delta as SpkTrainDataset._delta applies it (datasets.py:55-63): x [B, C, NF] (channel first, as
+// the loaders hold features) -> y [B, (1 + order) C, NF] = [x | delta(x, N=1) | delta(x, N=2)] -- BOTH differences are
+// taken of the base features (the reference does not difference the deltas again):
+//   delta(x, N)[t] = sum_{n=-N..N} n x[clamp(t + n)] / (2 sum_{n=1..N} n^2)        (edge padding)
+__global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int C,
+                                                    int NF, int order) {
+  const long long total = rows * NF;                 // rows = B * C
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int t = (int)(i % NF);
+    const long long r = i / NF;
+    const long long b = r / C;
+    const int c = (int)(r - b * C);
+    const float* p = x + r * NF;
+    auto at = [&](int u) { return p[u < 0 ? 0 : (u >= NF ? NF - 1 : u)]; };
+    float* o = y + (b * (1 + order) * C + c) * NF + t;
+    o[0] = p[t];
+    if (order >= 1) o[(long long)C * NF] = (at(t + 1) - at(t - 1)) / 2.0f;
+    if (order >= 2) o[(long long)2 * C * NF] = (2.0f * at(t + 2) + at(t + 1) - at(t - 1) - 2.0f * at(t - 2)) / 10.0f;
+  }
 }
 
 // uint8 frames [N, CH, H, W] (CH = 1 gray or 3 RGB) -> centre crop [N, CS, CS] float, normalised.
@@ -131,6 +197,15 @@ extern "C" int dlip_powspec_f32(const float* spec, float* pw, float* energy, int
   return dlip_launch_status();
 }
 
+extern "C" int dlip_powspec_dft64_f32(const float* frames, float* pw, float* energy, int32_t R, int32_t NB, int32_t NBp,
+                                      int32_t nfft, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(frames && pw && energy && R > 0 && NB > 0 && NBp >= NB && nfft >= 2 && nfft <= 1024 && (nfft & (nfft - 1)) == 0);
+  DLIP_CHECK_ARG(NB <= nfft / 2 + 1);
+  hipLaunchKernelGGL(powspec_dft64_kernel, dim3(R), dim3(256), (size_t)(3 * nfft + 4) * sizeof(double),
+                     static_cast<hipStream_t>(stream), frames, pw, energy, NB, NBp, nfft);
+  return dlip_launch_status();
+}
+
 extern "C" int dlip_log_floor_f32(const float* x, float* y, int64_t n, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && y && n > 0);
   hipLaunchKernelGGL(log_floor_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, (long long)n);
@@ -142,6 +217,15 @@ extern "C" int dlip_cmvn_nct_f32(const float* feat, const float* energy, float* 
   DLIP_CHECK_ARG(feat && y && B > 0 && NF > 0 && C > 0 && ldf >= C);
   hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)(((long long)B * C + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), feat, energy, y, B, NF, C, ldf, normalize);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_delta_nct_f32(const float* x, float* y, int32_t B, int32_t C, int32_t NF, int32_t order,
+                                  dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && y && B > 0 && C > 0 && NF > 0 && (order == 1 || order == 2));
+  const long long rows = (long long)B * C;
+  hipLaunchKernelGGL(delta_kernel, dim3(grid_for(rows * NF)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, rows, C, NF,
+                     order);
   return dlip_launch_status();
 }
 

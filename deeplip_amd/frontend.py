@@ -54,13 +54,17 @@ def num_frames(n_samples: int, frame_len: int, frame_step: int) -> int:
 class AudioFrontend:
     def __init__(self, feat_type: str = "mfcc", rate: int = 16000, win_len: float = 0.025, win_shift: float = 0.01,
                  nfft: int = 512, num_bin: int = 26, num_cep: int = 24, preemph: float = 0.97, ceplifter: int = 22,
-                 energy: bool = True, normalize: bool = True, device="cuda"):
+                 energy: bool = True, normalize: bool = True, delta: bool = False, dft64: Optional[bool] = None, device="cuda"):
         if feat_type not in ("mfcc", "fbank", "logfbank"):
             raise NotImplementedError("Other features are not implemented!")   # datasets.py:75-76
         self.feat_type, self.rate, self.nfft = feat_type, rate, nfft
         self.frame_len = int(round(win_len * rate))      # sigproc uses round_half_up; 400 / 160 are exact
         self.frame_step = int(round(win_shift * rate))
         self.num_bin, self.num_cep, self.preemph, self.normalize, self.energy = num_bin, num_cep, preemph, normalize, energy
+        self.delta = delta            # datasets.py:81-82: [feat | delta(N=1) | delta(N=2)] after the normalisation
+        # fp64 DFT (one direct-DFT kernel) instead of the fp32 MFMA GEMM: needed where the lowest filters sit on bins at the
+        # fp32 noise floor of a 512-point DFT -- banks denser than the shipped 24 / 26 / 60 bands (default: > 60 bands)
+        self.dft64 = (num_bin > 60) if dft64 is None else bool(dft64)
         self.device = torch.device(device)
         nb = nfft // 2 + 1
         self.nb, self.nbp = nb, (nb + 3) // 4 * 4
@@ -80,7 +84,7 @@ class AudioFrontend:
 
     @property
     def feat_dim(self) -> int:
-        return self.num_cep if self.feat_type == "mfcc" else self.num_bin
+        return (3 if self.delta else 1) * (self.num_cep if self.feat_type == "mfcc" else self.num_bin)
 
     def __call__(self, wave: torch.Tensor) -> torch.Tensor:
         """wave [B, S] float32 (cuda) -> features [B, F, NF] float32."""
@@ -91,11 +95,15 @@ class AudioFrontend:
         frames = torch.empty((R, self.nfft), device=wave.device, dtype=torch.float32)
         check(lib().dlip_frame_preemph_f32(ptr(wave), ptr(frames), B, S, NF, self.frame_len, self.frame_step, self.nfft,
                                            self.preemph, stream_handle()), "dlip_frame_preemph_f32")
-        spec = ops.linear(frames, self.w_dft)                                  # [R, 2*nb]  (DFT as GEMM)
         pw = torch.empty((R, self.nbp), device=wave.device, dtype=torch.float32)
         energy = torch.empty((R,), device=wave.device, dtype=torch.float32)
-        check(lib().dlip_powspec_f32(ptr(spec), ptr(pw), ptr(energy), R, self.nb, self.nbp, self.nfft, stream_handle()),
-              "dlip_powspec_f32")
+        if self.dft64:
+            check(lib().dlip_powspec_dft64_f32(ptr(frames), ptr(pw), ptr(energy), R, self.nb, self.nbp, self.nfft, stream_handle()),
+                  "dlip_powspec_dft64_f32")
+        else:
+            spec = ops.linear(frames, self.w_dft)                              # [R, 2*nb]  (DFT as GEMM)
+            check(lib().dlip_powspec_f32(ptr(spec), ptr(pw), ptr(energy), R, self.nb, self.nbp, self.nfft, stream_handle()),
+                  "dlip_powspec_f32")
         mel = torch.zeros((R, self.nfp), device=wave.device, dtype=torch.float32)
         ops.conv_nhwc(pw.view(1, 1, R, self.nbp), self.w_mel.view(self.num_bin, 1, 1, self.nbp),
                       out=mel.view(1, 1, R, self.nfp))                         # [R, num_bin] (+ zero pad)
@@ -111,6 +119,10 @@ class AudioFrontend:
         out = torch.empty((B, C_, NF), device=wave.device, dtype=torch.float32)
         check(lib().dlip_cmvn_nct_f32(ptr(feat), ptr(en), ptr(out), B, NF, C_, feat.shape[1], int(self.normalize),
                                       stream_handle()), "dlip_cmvn_nct_f32")
+        if self.delta:
+            out3 = torch.empty((B, 3 * C_, NF), device=wave.device, dtype=torch.float32)
+            check(lib().dlip_delta_nct_f32(ptr(out), ptr(out3), B, C_, NF, 2, stream_handle()), "dlip_delta_nct_f32")
+            return out3
         return out
 
 

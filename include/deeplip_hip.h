@@ -300,12 +300,21 @@ int dlip_frame_preemph_f32(const float* x, float* frames, int32_t B, int32_t S, 
 /* spec [R, 2*NB] (re | im) -> pw [R, NBp] = |.|^2 / nfft (zero padded), energy [R] = row sum (0 -> eps). */
 int dlip_powspec_f32(const float* spec, float* pw, float* energy, int32_t R, int32_t NB, int32_t NBp,
                      int32_t nfft, dlip_stream_t stream);
+/* frames [R, nfft] (dlip_frame_preemph_f32) -> pw / energy as dlip_powspec_f32, the DFT itself evaluated in fp64 (numpy's
+ * rfft under python_speech_features is double): for filterbanks whose lowest bands hold ~1e-9 of the spectrum (80 bands at
+ * nfft 512) the fp32-GEMM DFT's rounding noise is larger than the signal.  nfft a power of two <= 1024. */
+int dlip_powspec_dft64_f32(const float* frames, float* pw, float* energy, int32_t R, int32_t NB, int32_t NBp,
+                           int32_t nfft, dlip_stream_t stream);
 /* y = log(x == 0 ? eps : x). */
 int dlip_log_floor_f32(const float* x, float* y, int64_t n, dlip_stream_t stream);
 /* feat [B,NF,C] (row stride ldf; channel 0 := log(energy) when energy != NULL) -> per-utterance
  * (x - mean)/(std + 2e-12) when normalize != 0 -> y [B,C,NF] (the reference loaders' layout). */
 int dlip_cmvn_nct_f32(const float* feat, const float* energy, float* y, int32_t B, int32_t NF, int32_t C,
                       int32_t ldf, int32_t normalize, dlip_stream_t stream);
+/* Delta features as SpkTrainDataset._delta appends them (models/audio_models/datasets.py:55-63, `delta: true`):
+ * x [B,C,NF] -> y [B,(1+order)C,NF] = [x | delta(x, N=1) | delta(x, N=2)], python_speech_features.delta with edge
+ * padding; order 1 or 2. */
+int dlip_delta_nct_f32(const float* x, float* y, int32_t B, int32_t C, int32_t NF, int32_t order, dlip_stream_t stream);
 /* uint8 frames [n, channels(1|3), H, W] -> centre crop [n, crop, crop] float = ((gray)/255 - 0.421)/0.165
  * (models/video_models/dataloaders.py:11-22; RGB -> gray with the BT.601 weights). */
 int dlip_crop_normalize_u8(const uint8_t* x, float* y, int64_t n_frames, int32_t channels, int32_t H,

@@ -575,7 +575,27 @@ def psf_mfcc(signal, rate=16000, winlen=0.025, winstep=0.01, numcep=24, nfilt=26
     return feat
 
 
-def audio_features(signal, feat_type="mfcc", normalize=True, **kw) -> np.ndarray:
+def psf_delta(feat: np.ndarray, N: int) -> np.ndarray:
+    """base.delta: feat [NF, F] -> [NF, F]; d[t] = sum_{n=1..N} n (f[t+n] - f[t-n]) / (2 sum n^2), edge-padded."""
+    nf = len(feat)
+    denom = 2 * sum(i ** 2 for i in range(1, N + 1))
+    padded = np.pad(feat, ((N, N), (0, 0)), mode="edge")
+    out = np.empty_like(feat)
+    for t in range(nf):
+        out[t] = np.dot(np.arange(-N, N + 1), padded[t:t + 2 * N + 1]) / denom
+    return out
+
+
+def add_deltas(feat: np.ndarray, order: int = 2) -> np.ndarray:
+    """SpkTrainDataset._delta (datasets.py:55-63): hstack of the features, delta(N=1) and -- order 2 -- delta(N=2),
+    both taken of the BASE features.  feat [NF, F] -> [NF, (1 + order) F]."""
+    parts = [feat, psf_delta(feat, 1)]
+    if order == 2:
+        parts.append(psf_delta(feat, 2))
+    return np.hstack(parts)
+
+
+def audio_features(signal, feat_type="mfcc", normalize=True, delta=False, **kw) -> np.ndarray:
     """SpkTrainDataset._extract_feature + _normalize (datasets.py:52-53,65-83) -> [F, NF] float32."""
     if feat_type == "mfcc":
         feat = psf_mfcc(signal, **kw)
@@ -587,6 +607,8 @@ def audio_features(signal, feat_type="mfcc", normalize=True, **kw) -> np.ndarray
         raise NotImplementedError("Other features are not implemented!")
     if normalize:
         feat = (feat - feat.mean(axis=0)) / (feat.std(axis=0) + 2e-12)
+    if delta:                                     # datasets.py:81-82, after the normalisation
+        feat = add_deltas(feat, order=2)
     return feat.T.astype(np.float32)
 
 

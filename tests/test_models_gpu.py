@@ -298,3 +298,20 @@ def test_end_to_end_fused_av_trials_vs_oracle(video_net, audio_net):
     e_ref, _ = O.eer(y, [np.array([v]) for v in ref_s])
     same_order = np.array_equal(np.argsort(s.cpu().numpy(), kind="stable"), np.argsort(np.asarray(ref_s).reshape(-1), kind="stable"))
     assert abs(e_hip - e_ref) < (1e-9 if same_order else 1.0 / min(int(y.sum()), int((1 - y).sum())))
+
+
+def test_average_pooling_head_is_build_owned():
+    """`pooling: average` (tdnn.py:68-69,79-80): the reference's own path cannot run -- AdaptiveAvgPool1d(1) leaves
+    [B,1500,1], `x.squeeze_(1)` (tdnn.py:91) is a no-op on it and fc1 then fails with a shape error (checked against
+    the reference class in the build container) -- so no golden can exist.  The engine computes what the
+    configuration evidently means, mean over frames -> fc1 -> ..., and is held to the oracle's statement of that:
+    parity unpinned upstream by construction."""
+    from models.audio_models.tdnn import SpeakerEmbNet
+    net, sd = load(SpeakerEmbNet(tdnn_opts(pooling="average")), "audio_avg.")
+    x = torch.from_numpy(wg.audio_input(3, 24, 200, key="input.audio.avg"))
+    xv, xa = net.extract_embedding(x.to(DEV))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        rxv, rxa = O.speaker_extract_embedding(sd, x, O.TDNN_CONTEXT, pooling="average")
+    close(xa.cpu().numpy(), rxa.numpy())
+    close(xv.cpu().numpy(), rxv.numpy())
