@@ -152,7 +152,7 @@ def conv2_nhwc(x: Tensor, x2: Tensor, w_split: Tensor, bias: Tensor, w_scale: Te
     if hook is not None:
         bm, bn = C.c_int32(), C.c_int32()
         check(lib().dlip_conv_plan(C.byref(d), 3, C.byref(bm), C.byref(bn)), "dlip_conv_plan")
-        tok = hook.begin(f"conv_igemm_f16x3_dma_kernel<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * (R * S * Cx + C2))
+        tok = hook.begin(f"conv_igemm_f16x3_dma_kernel<{bm.value},{bn.value},dual>", 2.0 * N * Ho * Wo * K * (R * S * Cx + C2))
     _lib.ensure_conv_workspace()
     check(lib().dlip_conv2_nhwc_f16x3(C.byref(d), ptr(x), ptr(x2), H2, W2, C2, C2, stride2[0], stride2[1], ptr(w_split),
                                       ptr(w_scale), ptr(bias), ptr(residual), ptr(slope), None, None, ptr(out),
@@ -212,7 +212,7 @@ def conv_pool(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor], w_scale: Tensor
     part = _empty((nbytes // 8,), x.device, torch.float64)
     hook = LAUNCH_HOOK
     if hook is not None:
-        tok = hook.begin(f"conv_igemm_f16x3_dma_kernel<{bm.value},128>", 2.0 * N * Ho * Wo * K * R * S * Cx)
+        tok = hook.begin(f"conv_igemm_f16x3_dma_kernel<{bm.value},128,pool>", 2.0 * N * Ho * Wo * K * R * S * Cx)
     _lib.ensure_conv_workspace()
     check(lib().dlip_conv_pool_f16x3(C.byref(d), ptr(x), ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(residual), ptr(slope),
                                      ptr(post_scale), ptr(post_shift), ptr(part), nbytes, group_rows, stream_handle()),

@@ -12,7 +12,7 @@ tail -c 2500 $O/bench.json
 STEPS=5
 ARGS="$R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline"
 PARGS="$ARGS --single-mode --no-configs --no-kernel-events"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ARGS > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ARGS --no-configs > $O/stats.log 2>&1
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $P | cut -d" " -f1)
   rocprofv3 --pmc $P --output-format csv -d $O/pmc_$N -- python3 $PARGS > $O/pmc_$N.log 2>&1

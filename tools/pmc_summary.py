@@ -15,7 +15,13 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(conv_igemm_\w+?_kernel<\d+, \d+)", name)
+    """Kernel names as bench.py reports them: <BM,BN> plus ',dual' / ',pool' for the LDS-DMA kernel's variants
+    (template arguments <BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, OCC, DUAL, VAR>)."""
+    m = re.search(r"conv_igemm_f16x3_dma_kernel<(\d+), (\d+), \d+, \d+, (\d+), \d+, \d+, (true|false)", name)
+    if m:
+        tag = ",dual" if m.group(4) == "true" else (",pool" if m.group(3) == "2" else "")
+        return f"conv_igemm_f16x3_dma_kernel<{m.group(1)},{m.group(2)}{tag}>"
+    m = re.search(r"(conv_\w+?_kernel<\d+, \d+)", name)
     if m:
         return m.group(1).replace(" ", "") + ">"
     m = re.search(r"(\w+_kernel)", name)
