@@ -17,14 +17,23 @@
 // touches 16 distinct slots = all 64 banks once; a DMA piece fills 4 bank rows = 4 chunks (the hi or the lo half of
 // the slice) x 16 rows, i.e. 64 contiguous bytes of each of 16 pixels.
 //
-//   LDS: [window slot 0][window slot 1][zero block][weight ring: 3 stages][epilogue table]; the epilogue image
-//   overlays the window slots.  Taps that fall outside the image are redirected per lane to the zero block at the
-//   slot with the same index (same banks: a group with masked lanes stays conflict free).
-//   Window c+1 is fetched one piece per slice during the first taps of channel slice c (no burst, uniform vmcnt).
+//   Taps that fall outside the image are redirected per lane to a zero block at the slot with the same index (same
+//   banks: a group with masked lanes stays conflict free).  Window c+1 is fetched one piece per slice during the first
+//   taps of channel slice c (no burst, uniform vmcnt).
+//
+// With the operand traffic gone, what a 18-slice tile costs is its fixed part: set-up, the latency of its first
+// fetches, the epilogue.  So the workgroups are PERSISTENT (two per CU, each walking a contiguous range of row blocks)
+// and pipeline consecutive tiles: a tile's epilogue issues the next tile's window 0 and first weight slices -- into LDS
+// regions its own output image does not touch -- behind its residual fetch, and computes the next tile's tap masks
+// while it waits for the residual (LDS map in the kernel).
 #include "conv_common.h"
 #include "conv_dma_common.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -37,28 +46,42 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   constexpr int FR = 16;
   constexpr int MI = WM / FR, NI = WN / FR;
   constexpr int RPP = NT / 8, B_PER = BN / RPP;
-  constexpr int NSTAGE = 3, PF = NSTAGE - 1;
+  constexpr int NSTAGE = 3;
   constexpr int WBLK0 = (BM + WIN_SLACK + 15) / 16;
   constexpr int WBLK = (WBLK0 + NW / 2 - 1) / (NW / 2) * (NW / 2);   // 16-row blocks per window: 2 WBLK pieces, whole per wave
   constexpr int WPER = 2 * WBLK / NW;                                // window pieces per wave
   constexpr int SLOT_B = WBLK * 2048;
-  constexpr int ZERO_OFF = 2 * SLOT_B;
-  constexpr int BRING_OFF = ZERO_OFF + 2048;
   constexpr int BSTAGE_B = BN * ROWB;
-  constexpr int TAB_OFF = BRING_OFF + NSTAGE * BSTAGE_B;
+  // LDS map.  The workgroup is PERSISTENT and pipelines consecutive tiles: while a tile's epilogue stages its image in
+  // [0, IMG), the next tile's window 0 and first two weight slices are already landing in regions the image does not touch.
+  //   [0, SLOT_B)                      window slot 1 (odd channel slices)        } epilogue image [0, IMG), IMG <= SLOT_B + BSTAGE_B
+  //   [SLOT_B, +BSTAGE_B)              weight ring stage 2                       }
+  //   [SLOT_B + BSTAGE_B, +2 BSTAGE_B) weight ring stages 0, 1 (prefetched during the previous epilogue)
+  //   then the zero block (2 KB), window slot 0 (even channel slices; prefetched during the previous epilogue), the table
+  constexpr int W1_OFF = 0;
+  constexpr int ZERO_OFF = SLOT_B + NSTAGE * BSTAGE_B;
+  constexpr int W0_OFF = ZERO_OFF + 2048;
+  constexpr int TAB_OFF = W0_OFF + SLOT_B;
   constexpr int LDK = 32;
+  constexpr int PITCH = BN * 4;                    // bytes per image row
+  constexpr int CPR = BN / 4;                      // 16-B chunks per image row
+  constexpr int NSTORE = BM * CPR / NT;            // 16-B output stores per thread
+  constexpr int RES_PIECES = BM * PITCH / 1024 / NW;
+  constexpr int RPQ = 1024 / PITCH;
   static_assert(BN % RPP == 0 && WM % 16 == 0 && 2 * WBLK % NW == 0, "tile / window layout");
-  static_assert(BM * BN * 4 <= 2 * SLOT_B, "the epilogue image overlays the window slots");
+  static_assert(BM * PITCH <= SLOT_B + BSTAGE_B, "the epilogue image must not reach the prefetched weight stages");
+  static_assert((BM * PITCH) % (NW * 1024) == 0 && (BM * CPR) % NT == 0, "the tile image is whole DMA pieces / stores per wave");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds_c = reinterpret_cast<char*>(smem);
+  auto stage_off = [](int st) { return SLOT_B + (st == 2 ? 0 : (st + 1) * BSTAGE_B); };   // stages 0, 1 outside the image
+  auto slot_off = [](int slot) { return (slot & 1) ? W1_OFF : W0_OFF; };
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // neighbours share an XCD (L2)
-  const int tiles_m = (a.M + BM - 1) / BM;
-  const int tile_n = tile / tiles_m;
-  const int tile_m = tile - tile_n * tiles_m;
-  const int m0 = tile_m * BM;
+  const int g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // neighbours in tile order share an XCD (L2)
+  const int tiles_m = (a.M + BM - 1) / BM;                                                     // (one column block: K <= BN)
+  const int t_begin = (int)((long long)g * tiles_m / nwg), t_end = (int)((long long)(g + 1) * tiles_m / nwg);
+  if (t_begin >= t_end) return;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,14 +91,11 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const u32x4 xr = make_rsrc_words(a.x, a.x_bytes);
   const u32x4 wr = make_rsrc_words(a.w, a.w_bytes);
-  const int ntaps = a.R * a.S;
   const int halo_lo = a.ph * a.W + a.pw;                                 // window row of output pixel m0 at tap (0, 0) is 0
   const int need_rows = BM + (a.R - 1) * a.dh * a.W + (a.S - 1) * a.dw;  // rows a window really holds (<= BM + WIN_SLACK)
-  const int p0 = m0 - halo_lo;                                           // input pixel of window row 0 (may be negative)
 
-  // ---- tap validity of this lane's MI fragment pixels (bit r*S + s), as the ring kernel's per-row gather mask ----
-  uint32_t fr_mask[MI];
-  {
+  // tap validity of this lane's MI fragment pixels of the tile starting at row m0 (bit r*S + s)
+  auto tile_masks = [&](int m0, uint32_t* mask) {
     int hi0[MI], wi0[MI];
     uint32_t colbits[MI];
 #pragma unroll
@@ -88,7 +108,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
       hi0[mi] = ho - a.ph;
       wi0[mi] = rem - ho * a.Wo - a.pw;
       colbits[mi] = 0u;
-      fr_mask[mi] = 0u;
+      mask[mi] = 0u;
     }
     for (int sx = 0; sx < a.S; ++sx)
 #pragma unroll
@@ -96,57 +116,50 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
     for (int r = 0; r < a.R; ++r)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        fr_mask[mi] |= ((unsigned)(hi0[mi] + r * a.dh) < (unsigned)a.H ? colbits[mi] : 0u) << (r * a.S);
+        mask[mi] |= ((unsigned)(hi0[mi] + r * a.dh) < (unsigned)a.H ? colbits[mi] : 0u) << (r * a.S);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
-      if (m0 + wm * WM + mi * 16 + lrow >= a.M) fr_mask[mi] = 0u;
-  }
+      if (m0 + wm * WM + mi * 16 + lrow >= a.M) mask[mi] = 0u;
+  };
 
-  // ---- weight ring addressing (as the ring kernel: XOR swizzle on the source side) ----
+  // ---- weight ring addressing (as the ring kernel: XOR swizzle on the source side); the same for every tile ----
   const int cq = tid & 7, rbase = tid >> 3;
   const int key_st = (rbase >> 1) & 7;
   const int csrc = ((cq ^ key_st) << 2);
   int b_off[B_PER];
 #pragma unroll
   for (int j = 0; j < B_PER; ++j) {
-    const int n = tile_n * BN + rbase + RPP * j;
+    const int n = rbase + RPP * j;
     b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
   }
-  const uint32_t bpiece0 = lds0 + BRING_OFF + wave * 8 * ROWB;
+  const uint32_t bpiece0 = lds0 + wave * 8 * ROWB;
   auto issue_b = [&](int stage, int w_tap) {
 #pragma unroll
     for (int j = 0; j < B_PER; ++j)
-      dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, bpiece0 + stage * BSTAGE_B + j * RPP * ROWB);
+      dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, bpiece0 + stage_off(stage) + j * RPP * ROWB);
   };
-  // window piece q (= 2 block + half) of channel slice cc -> slot: 4 chunks (hi or lo half) x 16 rows
-  auto issue_win = [&](int slot, int cc, int q) {
+  // window piece q (= 2 block + half) of channel slice cc of the tile whose window starts at input pixel p0 -> slot
+  auto issue_win = [&](int slot, int cc, int q, int p0) {
     const int wrow = (q >> 1) * 16 + lrow;
     const int p = p0 + wrow;
     const bool ok = wrow < need_rows && p >= 0 && p < a.M;
     dma_piece(xr, ok ? (uint32_t)((p * a.ldx + cc * BK) * 4 + ((q & 1) * 4 + half) * 16) : DLIP_OOB_OFFSET,
-              lds0 + slot * SLOT_B + q * 1024);
+              lds0 + slot_off(slot) + q * 1024);
+  };
+  // what a tile needs before its first slice: window 0 and the weights of slices 0 and 1
+  auto issue_tile_head = [&](int p0) {
+#pragma unroll
+    for (int j = 0; j < WPER; ++j) issue_win(0, 0, wave + NW * j, p0);
+    issue_b(0, 0);
+    issue_b(1, a.Cw * 4);   // slice 1 = tap 1 of channel slice 0
   };
 
-  // ---- prologue ----
-#pragma unroll
-  for (int j = 0; j < WPER; ++j) issue_win(0, 0, wave + NW * j);
-  const int nk = a.nk;
-  // the walk over slices: channel slice outer, tap inner; ks = slice whose weights are issued next
-  int is_tap = 0, is_c0 = 0;
-  auto w_tap_of = [&]() { return (is_tap * a.Cw + is_c0) * 4; };
-  auto is_advance = [&]() { if (++is_tap == ntaps) { is_tap = 0; is_c0 += BK; } };
-  issue_b(0, w_tap_of());
-  if (nk > 1) { is_advance(); issue_b(1, w_tap_of()); }
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
+  int m0 = t_begin * BM;
+  uint32_t fr_mask[MI];
+  tile_masks(m0, fr_mask);
+  issue_tile_head(m0 - halo_lo);
   if (tid < BN) {
-    const int k = tile_n * BN + tid;
+    const int k = tid;
     const bool kok = k < a.K;
     float* tab = smem + TAB_OFF / 4;
     tab[tid] = kok ? 1.f / a.wscale[k] : 0.f;
@@ -157,187 +170,245 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   }
   if (tid < 128) *reinterpret_cast<f32x4*>(lds_c + ZERO_OFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // the zero block
 
-  // the tap being multiplied: index, its window row offset, channel slice, window slot
-  int ctap = 0, cs = 0, crow = 0, cc = 0;
-  int a_ad[MI];
   const int a_lane = (wm * WM / 16) * 2048 + half * 256;    // this lane's chunk row of its first block
   const int z_lane = ZERO_OFF + half * 256;
-  auto set_addr = [&]() {
-    const int u = lrow + crow + cs * a.dw;
-    const int a0 = (cc & 1) * SLOT_B + a_lane + (u >> 4) * 2048 + (u & 15) * 16;
-    const int zad = z_lane + (u & 15) * 16;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a_ad[mi] = ((fr_mask[mi] >> ctap) & 1u) ? a0 + mi * 2048 : zad;
-  };
-  auto tap_advance = [&]() {
-    if (++cs == a.S) { cs = 0; crow += a.dh * a.W; }
-    if (++ctap == ntaps) { ctap = 0; cs = 0; crow = 0; ++cc; }
-  };
-
   const int b_frag = (wn * WN + lrow) * LDK;
   const int key_rd = (lrow >> 1) & 7;
   const int khi = (half ^ key_rd) << 2, klo = ((4 + half) ^ key_rd) << 2;
-  f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
-  auto read_first = [&](int stage) {   // activation lo, weight hi
-    const float* Bw = smem + (BRING_OFF + stage * BSTAGE_B) / 4 + b_frag;
+  const u32x4 rrw = make_rsrc_words(a.res, a.res ? a.r_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
+  const bool post = a.pscale != nullptr;
+  float amax = 0.f;
+
+#ifdef DLIP_LAB
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.pool);   // lab: [G][8] s_memtime of each workgroup's 2nd tile
+#define WIN_STAMP(i) do { if (stamps && tid == 0 && t == t_begin + 1) stamps[(size_t)g * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WIN_STAMP(i) do { } while (0)
+#endif
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool first = t == t_begin, has_next = t + 1 < t_end;
+    WIN_STAMP(0);
+    // The walk over slices: channel slice outer (runtime), the NINE taps of the 3x3 filter inner and fully unrolled --
+    // tap index, window row offset, ring stages and the piece schedule are then compile-time per tap: no tap counters,
+    // no per-slice scalar bookkeeping (the rolled loop spent 47 vector + 85 scalar instructions per slice on it; the
+    // stamps showed 1 720 cycles per slice against 384 of MFMA issue per wave).
+    static_assert(NSTAGE == 3, "stage of a slice = tap % 3 (9 taps per channel slice)");
+    constexpr int NTAPS = 9;
+    const int cchunks = a.cchunks;
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) fal[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi] + 1024);
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) fbh[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + khi);
-  };
-  auto read_rest = [&](int stage) {    // activation hi, weight lo
-    const float* Bw = smem + (BRING_OFF + stage * BSTAGE_B) / 4 + b_frag;
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) fah[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi]);
+        for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
+    // per tap: slot-relative fragment address of this lane's first block, and its zero-block twin (same slot index)
+    const int dW = a.dh * a.W, dS = a.dw;
+    int a_ad[MI];
+    auto set_addr = [&](int tap, int slot_base) {   // tap: compile-time after unrolling
+      const int u = lrow + (tap / 3) * dW + (tap % 3) * dS;
+      const int a0 = slot_base + a_lane + (u >> 4) * 2048 + (u & 15) * 16;
+      const int zad = z_lane + (u & 15) * 16;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + klo);
-  };
-  auto mfma_p = [&](int grp, int m_lo, int m_hi) {   // grp 0: lo*hi, 1: hi*hi, 2: hi*lo
+      for (int mi = 0; mi < MI; ++mi) a_ad[mi] = (fr_mask[mi] & (1u << tap)) ? a0 + mi * 2048 : zad;
+    };
+    f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
+    auto read_first = [&](int stage) {   // activation lo, weight hi
+      const float* Bw = smem + stage_off(stage) / 4 + b_frag;
 #pragma unroll
-    for (int mi = m_lo; mi < m_hi; ++mi)
+      for (int mi = 0; mi < MI; ++mi) fal[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi] + 1024);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const f16x8 av = grp == 0 ? fal[mi] : fah[mi];
-        const f16x8 bv = grp == 2 ? fbl[ni] : fbh[ni];
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[mi][ni], 0, 0, 0);
-      }
-  };
-  constexpr int MH = MI / 2 > 0 ? MI / 2 : 1;
+      for (int ni = 0; ni < NI; ++ni) fbh[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + khi);
+    };
+    auto read_rest = [&](int stage) {    // activation hi, weight lo
+      const float* Bw = smem + stage_off(stage) / 4 + b_frag;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fah[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + klo);
+    };
+    auto mfma_p = [&](int grp) {   // grp 0: lo*hi, 1: hi*hi, 2: hi*lo
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const f16x8 av = grp == 0 ? fal[mi] : fah[mi];
+          const f16x8 bv = grp == 2 ? fbl[ni] : fbh[ni];
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[mi][ni], 0, 0, 0);
+        }
+    };
 #define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
-  set_addr();
-  // weights of slice 0 (and, older in the queue, the whole of window 0) have landed once only slice 1's pieces are outstanding
-  if (nk > 1) wait_vmcnt<B_PER>(); else wait_vmcnt<0>();
-  __syncthreads();   // (also publishes the table and the zero block)
-  read_first(0);
+    set_addr(0, slot_off(0));
+    // Slice 0's weights (and, older in the queue, the whole of window 0) have landed once only what was issued after
+    // them is outstanding: slice 1's pieces and -- after the first tile -- the previous epilogue's NSTORE output stores.
+    // (later tiles: their head was streamed in behind the previous tile's last slices; only its output stores are younger)
+    if (first) wait_vmcnt<B_PER>(); else wait_vmcnt<NSTORE>();
+    __syncthreads();   // window 0 / weights visible; the previous image fully read before this tile's DMA overwrites it
+    WIN_STAMP(1);
+    read_first(0);
 
-  int st_cur = 0, st_iss = nk > 1 ? 2 % NSTAGE : 1 % NSTAGE;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more1 = (kt + 1) < nk, moreP = (kt + PF) < nk;
-    const int st_nxt = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
-    // top of the slice, right behind the barrier: one piece of the NEXT channel slice's window (its slot was read last in
-    // the previous channel slice), then the weights two slices ahead
-    const bool win_now = ctap < WPER && (cc + 1) * BK < a.Cw;
-    if (win_now) issue_win((cc + 1) & 1, cc + 1, wave + NW * ctap);
-    if (moreP) { is_advance(); issue_b(st_iss, w_tap_of()); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; }
-    DLIP_FENCE();
-    read_rest(st_cur); DLIP_FENCE();
-    mfma_p(0, 0, MI); DLIP_FENCE();
-    tap_advance();
-    set_addr();        // next tap's fragment addresses: plain VALU in the shadow of group 1
-    DLIP_FENCE();
-    mfma_p(1, 0, MI); DLIP_FENCE();
-    mfma_p(2, 0, MH); DLIP_FENCE();
-    if (more1) {
-      // slice kt+1's weights must have landed; what was issued after them (this slice) stays in flight
-      if (moreP) { if (win_now) wait_vmcnt<B_PER + 1>(); else wait_vmcnt<B_PER>(); }
-      else       { if (win_now) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
-      __builtin_amdgcn_s_barrier();
-      read_first(st_nxt);
+    const int p0 = m0 - halo_lo;
+    const int m0n = m0 + BM;
+    uint32_t next_mask[MI];
+    for (int c = 0; c < cchunks; ++c) {
+      const bool last_c = c + 1 == cchunks;
+      // The slice stream does not stop at a tile's end: "the next channel slice" of the LAST one is channel slice 0 of the
+      // NEXT tile (window slot 0 is free since this tile's slice 0 ... 8 or, with an odd number of channel slices, is the
+      // slot the next tile would use anyway), and the weights "two slices ahead" of the last two taps are the next tile's
+      // slices 0 and 1 (ring stages 0 and 1: outside the epilogue's image).  The epilogue then runs with the next tile's
+      // head already landed or in flight.
+      const bool stream_on = !last_c || has_next;
+      const bool stream_win = !last_c || (has_next && (cchunks & 1) == 0);   // (an odd count leaves the last slice in slot 0)
+      const int sb = slot_off(c), sb_next = last_c ? slot_off(0) : slot_off(c + 1);
+      const int wbase = c * BK * 4;                     // byte offset of this channel slice inside a tap's weights
+#pragma unroll
+      for (int tap = 0; tap < NTAPS; ++tap) {
+        // slice (c, tap) sits in ring stage tap % 3; the weights two slices ahead go to stage (tap + 2) % 3
+        const bool more1 = !(last_c && tap == NTAPS - 1);
+        const bool moreP = tap + 2 < NTAPS || stream_on;
+        // top of the slice, right behind the barrier: one piece of the NEXT channel slice's window (its slot was read last
+        // in the previous channel slice), then the weights two slices ahead
+        const bool win_now = tap < WPER && stream_win;
+        if (win_now) { if (last_c) issue_win(0, 0, wave + NW * tap, m0n - halo_lo); else issue_win(c + 1, c + 1, wave + NW * tap, p0); }
+        if (moreP) {
+          const int wnext = last_c ? 0 : wbase + BK * 4;   // first channel slice of the next tile, or this tile's next one
+          issue_b((tap + 2) % 3, tap + 2 < NTAPS ? (tap + 2) * a.Cw * 4 + wbase : (tap + 2 - NTAPS) * a.Cw * 4 + wnext);
+        }
+        DLIP_FENCE();
+        read_rest(tap % 3); DLIP_FENCE();
+        mfma_p(0); DLIP_FENCE();
+        // next tap's fragment addresses: plain VALU in the shadow of the matrix instructions (and, once per tile, the next
+        // tile's tap masks; the last slice's set_addr runs again at the next tile's start, with those masks)
+        if (tap + 1 < NTAPS) set_addr(tap + 1, sb); else set_addr(0, sb_next);
+        if (tap == 0 && last_c && has_next) tile_masks(m0n, next_mask);
+        DLIP_FENCE();
+        mfma_p(1); DLIP_FENCE();
+        if (more1) {
+          // Slice kt+1's weights must have landed; what was issued after them stays in flight: this slice's pieces and -- in
+          // a later tile's very first slice -- the previous epilogue's NSTORE output stores, which sit between slice 1's
+          // weights and this slice's pieces in the queue.  Every LDS read of this slice is complete (lgkmcnt) before the
+          // barrier releases its stage; the last group's MFMAs then cover the next slice's first fragment reads.
+          if (!first && c == 0 && tap == 0) { if (win_now) wait_vmcnt<B_PER + 1 + NSTORE>(); else wait_vmcnt<B_PER + NSTORE>(); }
+          else if (moreP) { if (win_now) wait_vmcnt<B_PER + 1>(); else wait_vmcnt<B_PER>(); }
+          else            { if (win_now) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          read_first((tap + 1) % 3);
+        }
+        DLIP_FENCE();
+        mfma_p(2);
+        DLIP_FENCE();
+      }
     }
-    DLIP_FENCE();
-    if (MH < MI) mfma_p(2, MH, MI);
-    DLIP_FENCE();
-    st_cur = st_nxt;
-  }
 #undef DLIP_FENCE
+    WIN_STAMP(2);
 
-  // ---- epilogue through LDS (the ring kernel's, fp32 / split rows): y = act(acc / wscale + bias + residual) * ps + pt ----
-  {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    constexpr int PITCH = BN * 4;
-    constexpr int CPR = BN / 4;
-    constexpr int RES_PIECES = BM * PITCH / 1024 / NW;
-    constexpr int RPQ = 1024 / PITCH;
-    static_assert((BM * PITCH) % (NW * 1024) == 0, "the tile image is a whole number of DMA pieces per wave");
-    const u32x4 rrw = make_rsrc_words(a.res, a.res ? a.r_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
-    const int kcol0 = tile_n * BN;
-    char* img = lds_c;
-    const f32x4* tab = reinterpret_cast<const f32x4*>(smem + TAB_OFF / 4);
-    const bool post = a.pscale != nullptr;
-    float amax = 0.f;
-    __syncthreads();   // every wave is done with the windows
-    if (a.res) {
+    // ---- epilogue through LDS (the ring kernel's, fp32 / split rows): y = act(acc / wscale + bias + residual) * ps + pt,
+    // with the NEXT tile's head (window 0, weights of slices 0 and 1) in flight underneath it ----
+    {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      char* img = lds_c;
+      const f32x4* tab = reinterpret_cast<const f32x4*>(smem + TAB_OFF / 4);
+      __syncthreads();   // every wave is done with the windows and the weight ring
+      if (a.res) {       // the residual tile first (the epilogue waits for it alone), then the next tile's head
 #pragma unroll
-      for (int i = 0; i < RES_PIECES; ++i) {
-        const int piece = i * NW + wave;
-        const int r = piece * RPQ + lane / CPR;
-        const int pp = lane % CPR;
-        const int c = (pp & ~15) | ((pp ^ r) & 15);
-        const int m = m0 + r;
-        const bool ok = m < a.M && (kcol0 + (c >> 3) * 32) < a.K;
-        dma_piece(rrw, ok ? (uint32_t)((m * a.ldr + kcol0) * 4 + c * 16) : DLIP_OOB_OFFSET, lds0 + piece * 1024);
-      }
-      wait_vmcnt<0>();
-      __syncthreads();
-    }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int kl = wn * WN + ni * FR + 4 * half;
-      const f32x4 inv4 = tab[kl >> 2], bi4 = tab[(BN + kl) >> 2], sl4 = tab[(2 * BN + kl) >> 2];
-      f32x4 ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
-      if (post) { ps4 = tab[(3 * BN + kl) >> 2]; pt4 = tab[(4 * BN + kl) >> 2]; }
-      const int ch = (kl >> 5) * 8 + ((kl >> 3) & 3);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int r = wm * WM + mi * FR + lrow;
-        char* row = img + r * PITCH + 2 * (kl & 4);
-        const int phi = (ch & ~15) | ((ch ^ r) & 15), plo = ((ch + 4) & ~15) | (((ch + 4) ^ r) & 15);
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = acc[mi][ni][c] * inv4[c] + bi4[c];
-        if (a.res) {
-          const h4 rh = *reinterpret_cast<const h4*>(row + phi * 16), rl = *reinterpret_cast<const h4*>(row + plo * 16);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] += (float)rh[c] + (float)rl[c];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          v[c] = v[c] >= 0.f ? v[c] : v[c] * sl4[c];
-          if (post) v[c] = v[c] * ps4[c] + pt4[c];
-        }
-        if constexpr (OSPLIT) {
-          h4 hi, lo;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); }
-          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-          *reinterpret_cast<h4*>(row + phi * 16) = hi;
-          *reinterpret_cast<h4*>(row + plo * 16) = lo;
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[mi][ni][c] = v[c];
+        for (int i = 0; i < RES_PIECES; ++i) {
+          const int piece = i * NW + wave;
+          const int r = piece * RPQ + lane / CPR;
+          const int pp = lane % CPR;
+          const int c = (pp & ~15) | ((pp ^ r) & 15);
+          const int m = m0 + r;
+          const bool ok = m < a.M && (c >> 3) * 32 < a.K;
+          dma_piece(rrw, ok ? (uint32_t)(m * a.ldr * 4 + c * 16) : DLIP_OOB_OFFSET, lds0 + piece * 1024);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (!OSPLIT) {
-      if (a.res) __syncthreads();
+      const bool head_here = has_next && (cchunks & 1) != 0;   // odd channel-slice count: window 0 could not be streamed
+      if (head_here) {
+#pragma unroll
+        for (int j = 0; j < WPER; ++j) issue_win(0, 0, wave + NW * j, m0n - halo_lo);
+      }
+      WIN_STAMP(3);
+      if (a.res) {
+        if (head_here) wait_vmcnt<WPER>(); else wait_vmcnt<0>();
+        __syncthreads();
+      }
+      WIN_STAMP(4);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int kl = wn * WN + ni * FR + 4 * half;
-        const int ch = kl >> 2;
+        const f32x4 inv4 = tab[kl >> 2], bi4 = tab[(BN + kl) >> 2], sl4 = tab[(2 * BN + kl) >> 2];
+        f32x4 ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
+        if (post) { ps4 = tab[(3 * BN + kl) >> 2]; pt4 = tab[(4 * BN + kl) >> 2]; }
+        const int ch = (kl >> 5) * 8 + ((kl >> 3) & 3);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const int r = wm * WM + mi * FR + lrow;
-          const int pc = (ch & ~15) | ((ch ^ r) & 15);
-          *reinterpret_cast<f32x4*>(img + r * PITCH + pc * 16) = acc[mi][ni];
+          char* row = img + r * PITCH + 2 * (kl & 4);
+          const int phi = (ch & ~15) | ((ch ^ r) & 15), plo = ((ch + 4) & ~15) | (((ch + 4) ^ r) & 15);
+          float v[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = acc[mi][ni][c] * inv4[c] + bi4[c];
+          if (a.res) {
+            const h4 rh = *reinterpret_cast<const h4*>(row + phi * 16), rl = *reinterpret_cast<const h4*>(row + plo * 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += (float)rh[c] + (float)rl[c];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            v[c] = v[c] >= 0.f ? v[c] : v[c] * sl4[c];
+            if (post) v[c] = v[c] * ps4[c] + pt4[c];
+          }
+          if constexpr (OSPLIT) {
+            h4 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); }
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            *reinterpret_cast<h4*>(row + phi * 16) = hi;
+            *reinterpret_cast<h4*>(row + plo * 16) = lo;
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[mi][ni][c] = v[c];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (!OSPLIT) {
+        if (a.res) __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int kl = wn * WN + ni * FR + 4 * half;
+          const int ch = kl >> 2;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int r = wm * WM + mi * FR + lrow;
+            const int pc = (ch & ~15) | ((ch ^ r) & 15);
+            *reinterpret_cast<f32x4*>(img + r * PITCH + pc * 16) = acc[mi][ni];
+          }
         }
       }
-    }
-    __syncthreads();
+      __syncthreads();
+      WIN_STAMP(5);
 #pragma unroll
-    for (int i = 0; i < BM * CPR / NT; ++i) {
-      const int idx = i * NT + tid;
-      const int r = idx / CPR, pp = idx % CPR;
-      const int c = (pp & ~15) | ((pp ^ r) & 15);
-      const int m = m0 + r;
-      const int kfirst = OSPLIT ? kcol0 + (c >> 3) * 32 : kcol0 + c * 4;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(img + r * PITCH + pp * 16);
-      const uint32_t off = (m < a.M && kfirst < a.K) ? (uint32_t)((m * a.ldy + kcol0) * 4 + c * 16) : DLIP_OOB_OFFSET;
-      __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)off, 0, 0);
+      for (int i = 0; i < NSTORE; ++i) {   // exactly NSTORE stores per thread (out-of-range ones included): the next tile counts them
+        const int idx = i * NT + tid;
+        const int r = idx / CPR, pp = idx % CPR;
+        const int c = (pp & ~15) | ((pp ^ r) & 15);
+        const int m = m0 + r;
+        const int kfirst = OSPLIT ? (c >> 3) * 32 : c * 4;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(img + r * PITCH + pp * 16);
+        const uint32_t off = (m < a.M && kfirst < a.K) ? (uint32_t)(m * a.ldy * 4 + c * 16) : DLIP_OOB_OFFSET;
+        __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)off, 0, 0);
+      }
+      WIN_STAMP(6);
+      if (has_next) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fr_mask[mi] = next_mask[mi];
+        m0 = m0n;
+      }
     }
-    if constexpr (OSPLIT) dlip_report_range(amax, a.status);
   }
+  if constexpr (OSPLIT) dlip_report_range(amax, a.status);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OCC>
@@ -351,6 +422,7 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
   constexpr int WBLK0 = (BM + WIN_SLACK + 15) / 16;
   constexpr int WBLK = (WBLK0 + NW / 2 - 1) / (NW / 2) * (NW / 2);
   constexpr size_t lds = (size_t)2 * WBLK * 2048 + 2048 + (size_t)3 * BN * ROWB + 5 * BN * sizeof(float);
+  if (b.tiles_n != 1) return DLIP_EINVAL;   // one column block (K <= BN): the kernel's tile index is the row block
   static_assert(lds <= 160 * 1024, "LDS exceeds a CU");
   auto kern = out_split ? conv_win_f16x3_kernel<BM, BN, WAVES_M, WAVES_N, true, OCC> : conv_win_f16x3_kernel<BM, BN, WAVES_M, WAVES_N, false, OCC>;
   static std::mutex mu;
@@ -363,18 +435,51 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
       attr_set[out_split ? 1 : 0] = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds, st, b);
+  // persistent workgroups: as many as the chip holds at once (2 per CU), each walking a contiguous range of tiles
+  static int slots[2] = {0, 0};
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    int& sl = slots[out_split ? 1 : 0];
+    if (sl == 0) {
+      int dev = 0, cus = 0, per_cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * NW, lds) != hipSuccess || per_cu <= 0)
+        return DLIP_EINVAL;
+      sl = cus * per_cu;
+    }
+  }
+  const long long grid = tiles < slots[out_split ? 1 : 0] ? tiles : slots[out_split ? 1 : 0];
+#ifdef DLIP_LAB
+  if (getenv("DLIP_STAMP_PRINT")) {   // median cycles between the phase stamps of every workgroup's second tile
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), 4096 * 8 * 8);
+    (void)hipMemsetAsync(dbuf, 0, 4096 * 8 * 8, st);
+    b.pool = reinterpret_cast<double*>(dbuf);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, st, b);
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> d[6];
+    for (long long i = 0; i < grid; ++i)
+      if (h[i * 8 + 6]) for (int j = 0; j < 6; ++j) d[j].push_back((double)(h[i * 8 + j + 1] - h[i * 8 + j]));
+    auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    fprintf(stderr, "[win stamps %dx%d M=%d nk=%d res=%d] head-wait %.0f  loop %.0f  issue-next+masks %.0f  residual-wait %.0f  epilogue-compute %.0f  stores %.0f\n",
+            BM, BN, b.M, b.nk, b.res != nullptr, med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(d[4]), med(d[5]));
+    return dlip_launch_status();
+  }
+#endif
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, st, b);
   return dlip_launch_status();
 }
 
 }  // namespace
 
-// The window kernel serves same-size stride-1 convolutions with >= 9 taps (a wave's six window pieces go out one per
-// slice and must be older in the queue than the weights of the next channel slice's first tap), a halo within WIN_SLACK,
+// The window kernel serves same-size stride-1 3x3 convolutions (the nine taps are unrolled; a wave's six window pieces go
+// out one per slice and must be older in the queue than the weights of the next channel slice's first tap), a halo within WIN_SLACK,
 // K <= 64 (one 64-channel column block: layer 1) and no second reduction source / pooled epilogue.
 static bool win_shape_ok(int sh, int sw, int H, int W, int Ho, int Wo, int R, int S, int dh, int dw, int ph, int pw, int K) {
   if (dlip_dbg_value[DLIP_DBG_WIN] == 0) return false;
-  return sh == 1 && sw == 1 && Wo == W && Ho == H && R * S >= 9 && K <= 64 && (K & 3) == 0 &&
+  return sh == 1 && sw == 1 && Wo == W && Ho == H && R == 3 && S == 3 && K <= 64 && (K & 3) == 0 &&
          (R - 1) * dh * W + (S - 1) * dw <= WIN_SLACK && ph * W + pw <= WIN_SLACK;
 }
 
@@ -396,5 +501,7 @@ extern "C" int dlip_conv_kernel_kind(const dlip_conv_desc* d) {
 
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_win_launch(const void* args, void* stream, int out_split) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
+  if (dlip_dbg_value[DLIP_DBG_WIN] == 2)   // experiment: eight waves per workgroup (four per SIMD with two workgroups per CU)
+    return launch_win<128, 64, 4, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
   return launch_win<128, 64, 2, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
 }
