@@ -332,6 +332,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         if (MH < MI) mfma_p(1, MH, MI);
         DLIP_FENCE();
         if (moreP && late) { advance(); issue_a(st_iss); } DLIP_FENCE();
+        // (the barrier one half-group earlier, behind group 1 -- what the window kernel does -- measured 1-7 % SLOWER here)
         mfma_p(2, 0, MH); DLIP_FENCE();
         if (moreP && late) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
         if (more1) {
@@ -810,7 +811,7 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 // (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
 #ifdef DLIP_LAB
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {128, 128}, {128, 64}, {128, 64}, {64, 128}};   // 6..9: tiles 0, 1, 4, 2 with VAR 4 (early issue)
+                           {256, 128}, {128, 256}, {128, 64}, {64, 128}};   // 6: tile 5 with VAR 1 (s_setprio); 7: 128x256; 8, 9: tiles 4, 2 with VAR 4
 constexpr int NUM_DMA_ALL = 10;
 #else
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
@@ -856,8 +857,8 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 3: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, epi);
     case 4: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, epi);
 #ifdef DLIP_LAB
-    case 6: return launch_dma<128, 128, 2, 2, 2, 2, 4>(a, st, epi);
-    case 7: return launch_dma<128, 64, 2, 2, 3, 2, 4>(a, st, epi);
+    case 6: return launch_dma<256, 128, 4, 2, 3, 1, 1>(a, st, epi);
+    case 7: return launch_dma<128, 256, 2, 4, 2, 1, 4>(a, st, epi);
     case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
     case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);
 #endif

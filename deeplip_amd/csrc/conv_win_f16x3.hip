@@ -501,7 +501,6 @@ extern "C" int dlip_conv_kernel_kind(const dlip_conv_desc* d) {
 
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_win_launch(const void* args, void* stream, int out_split) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
-  if (dlip_dbg_value[DLIP_DBG_WIN] == 2)   // experiment: eight waves per workgroup (four per SIMD with two workgroups per CU)
-    return launch_win<128, 64, 4, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
+  // four waves, two workgroups per CU (eight waves in one workgroup per CU: 258 vs 218 us on layer 1, same box)
   return launch_win<128, 64, 2, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
 }

@@ -12,7 +12,12 @@ tail -c 2500 $O/bench.json
 STEPS=5
 ARGS="$R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline"
 PARGS="$ARGS --single-mode --no-configs --no-kernel-events"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ARGS --no-configs > $O/stats.log 2>&1
+# kernel durations: single-stream run (what bench.py's HIP events time; with the two encoders overlapped on two streams a
+# trace charges each kernel the time it shared the chip) -> kernel_stats.csv; the default two-stream command -> kernel_stats_two_stream.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ARGS --no-configs --single-stream > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python3 $ARGS --no-configs > $O/stats2.log 2>&1
+cp $(find $O/stats2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_two_stream.csv
+rm -rf $O/stats2/*/*kernel_trace.csv
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $P | cut -d" " -f1)
   rocprofv3 --pmc $P --output-format csv -d $O/pmc_$N -- python3 $PARGS > $O/pmc_$N.log 2>&1
