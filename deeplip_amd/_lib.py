@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lock = threading.Lock()
 _lib = None
@@ -76,7 +76,8 @@ SIGNATURES = {
     "dlip_plan_destroy": [C.c_void_p],
     "dlip_stem3d_bn_act_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem3d_bn_act_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
-    "dlip_stem3d_pool_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_stem3d_pool_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_stem3d_pool_workspace_bytes": [c_i32, c_i32, c_i32, c_i32],
     "dlip_maxpool3x3s2_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_avgpool_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_time_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
@@ -142,6 +143,7 @@ def lib() -> C.CDLL:
             fn.restype = C.c_int
         l.dlip_conv_workspace_bytes.restype = C.c_int64
         l.dlip_conv_pool_partial_bytes.restype = C.c_int64
+        l.dlip_stem3d_pool_workspace_bytes.restype = C.c_int64
         l.dlip_error_string.argtypes = [C.c_int]
         l.dlip_error_string.restype = C.c_char_p
         v = l.dlip_abi_version()

@@ -78,7 +78,9 @@ struct StreamK {
 // DUAL: the reduction continues over a second source x2 (1x1, strided) after the taps of x.
 // VAR (lab build experiments on the 8-wave tiles, bit 0: s_setprio 1 for the second-dispatched half of the waves;
 // bit 1: that half issues its LDS-DMA pieces half a slice later than the first half -- measured 15 % slower: the
-// pieces need their full two slices of lead; bit 2: every wave issues them at the top of the slice): 0 in the product.
+// pieces need their full two slices of lead; bit 2: every wave issues them at the top of the slice; bit 3: the two halves
+// of the waves -- one wave of each SIMD in either -- take turns as the slice's issuer: the half whose turn it is moves the
+// WHOLE slice (its own rows and its partner's) while the other half goes straight to its matrix work): 0 in the product.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, int OCC, bool DUAL, int VAR = 0>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_dma_kernel(const ConvArgs a, const StreamK sk) {
   constexpr bool OSPLIT = EPI == 1;
@@ -95,6 +97,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   constexpr int LDK = 32;             // dwords per LDS row
   constexpr int PF = NSTAGE - 1;      // slices in flight ahead of the one being multiplied
   constexpr int RING = NSTAGE * STAGE_B;   // bytes; the epilogue parameter table (5 x BN floats) sits behind it
+  constexpr bool ALT = (VAR & 8) != 0;     // alternating issuer halves
+  static_assert(!ALT || (NW == 8 && NSTAGE == 3), "alternating issuers: eight waves, three stages");
+  constexpr int AQ = ALT ? 2 * A_PER : A_PER, BQ = ALT ? 2 * B_PER : B_PER;   // rows a lane addresses: its own passes (+ its partner wave's)
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t piece0 = lds0 + wave * 8 * ROWB;   // this wave's 8 rows of pass 0, stage 0, operand A
+  const int pdelta = ((wave ^ (NW / 2)) - wave) * 8 * ROWB;   // (ALT) from there to the partner wave's rows
   const int lane = tid & 63;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   // lane = (row 0..15, k group 0..3); the one step of a slice reads hi chunk kgroup, lo chunk 4 + kgroup
@@ -155,15 +161,16 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
     // Per-row gather state, branch-free: byte offset of the row's window origin and a bit per filter tap
     // that stays inside the image (columns and rows tested separately: R + S steps, not R x S).
-    int a_off[A_PER];
-    uint32_t a_mask[A_PER];
-    int a2_off[DUAL ? A_PER : 1];   // second source: byte offset of the row's pixel, < 0 past M
+    int a_off[AQ];
+    uint32_t a_mask[AQ];
+    int a2_off[DUAL ? AQ : 1];   // second source: byte offset of the row's pixel, < 0 past M
+    auto row_of = [&](int j) { return (j < A_PER ? rbase : rbase ^ (RPP / 2)) + RPP * (j % A_PER); };   // j >= A_PER: the partner wave's row
     {
-      int hi0[A_PER], wi0[A_PER];
-      uint32_t colbits[A_PER];
+      int hi0[AQ], wi0[AQ];
+      uint32_t colbits[AQ];
 #pragma unroll
-      for (int j = 0; j < A_PER; ++j) {
-        const int m = tile_m * BM + rbase + RPP * j;
+      for (int j = 0; j < AQ; ++j) {
+        const int m = tile_m * BM + row_of(j);
         const int mc = m < a.M ? m : a.M - 1;
         const int n = dlip_div(mc, a.div_howo);
         const int rem = mc - n * a.HoWo;
@@ -178,19 +185,19 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       }
       for (int sx = 0; sx < a.S; ++sx)
 #pragma unroll
-        for (int j = 0; j < A_PER; ++j) colbits[j] |= (uint32_t)((unsigned)(wi0[j] + sx * a.dw) < (unsigned)a.W) << sx;
+        for (int j = 0; j < AQ; ++j) colbits[j] |= (uint32_t)((unsigned)(wi0[j] + sx * a.dw) < (unsigned)a.W) << sx;
       for (int r = 0; r < a.R; ++r)
 #pragma unroll
-        for (int j = 0; j < A_PER; ++j)
+        for (int j = 0; j < AQ; ++j)
           a_mask[j] |= ((unsigned)(hi0[j] + r * a.dh) < (unsigned)a.H ? colbits[j] : 0u) << (r * a.S);
 #pragma unroll
-      for (int j = 0; j < A_PER; ++j)
-        if (tile_m * BM + rbase + RPP * j >= a.M) a_mask[j] = 0u;
+      for (int j = 0; j < AQ; ++j)
+        if (tile_m * BM + row_of(j) >= a.M) a_mask[j] = 0u;
     }
-    int b_off[B_PER];
+    int b_off[BQ];
 #pragma unroll
-    for (int j = 0; j < B_PER; ++j) {
-      const int n = tile_n * BN + rbase + RPP * j;
+    for (int j = 0; j < BQ; ++j) {
+      const int n = tile_n * BN + (j < B_PER ? rbase : rbase ^ (RPP / 2)) + RPP * (j % B_PER);
       b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
     }
 
@@ -218,35 +225,41 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       w_tap = (tap * a.Cw + c0) * 4;
       if (DUAL && c0 >= a.Cw) { x_tap = (c0 - a.Cw) * 4; w_tap = (ntaps * a.Cw + c0 - a.Cw) * 4; }
     };
-    auto issue_a = [&](int stage) {
+    // (nj = A_PER / B_PER: this wave's own pieces; AQ / BQ: its partner's too)
+    auto issue_a = [&](int stage, auto nj) {
       const uint32_t base = piece0 + stage * STAGE_B;
       if (DUAL && c0 >= a.Cw) {          // (wave-uniform)
 #pragma unroll
-        for (int j = 0; j < A_PER; ++j)
-          dma_piece(x2r, a2_off[DUAL ? j : 0] >= 0 ? (uint32_t)(a2_off[DUAL ? j : 0] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+        for (int j = 0; j < nj(); ++j)
+          dma_piece(x2r, a2_off[DUAL ? j : 0] >= 0 ? (uint32_t)(a2_off[DUAL ? j : 0] + x_tap) : DLIP_OOB_OFFSET,
+                    base + (j % A_PER) * RPP * ROWB + (j < A_PER ? 0 : pdelta));
         return;
       }
 #pragma unroll
-      for (int j = 0; j < A_PER; ++j) {
+      for (int j = 0; j < nj(); ++j) {
         const bool ok = (a_mask[j] >> tap) & 1u;
-        dma_piece(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+        dma_piece(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + (j % A_PER) * RPP * ROWB + (j < A_PER ? 0 : pdelta));
       }
     };
-    auto issue_b = [&](int stage) {
+    auto issue_b = [&](int stage, auto nj) {
       const uint32_t base = piece0 + stage * STAGE_B + BM * ROWB;
 #pragma unroll
-      for (int j = 0; j < B_PER; ++j)
-        dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+      for (int j = 0; j < nj(); ++j)
+        dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + (j % B_PER) * RPP * ROWB + (j < B_PER ? 0 : pdelta));
     };
+    constexpr std::integral_constant<int, A_PER> own_a{};
+    constexpr std::integral_constant<int, B_PER> own_b{};
+    constexpr std::integral_constant<int, AQ> all_a{};
+    constexpr std::integral_constant<int, BQ> all_b{};
 
     // ---- prologue: put the first NSTAGE-1 slices in flight, then initialise the accumulators ----
     DLIP_STAMP(1);
-    issue_a(0);
-    issue_b(0);
+    issue_a(0, own_a);
+    issue_b(0, own_b);
     if (PF > 1 && kn > 1) {
       advance();
-      issue_a(1);
-      issue_b(1);
+      issue_a(1, own_a);
+      issue_b(1, own_b);
     }
 
     // Accumulators hold the TRANSPOSED tile (rows = output channels, columns = pixels: the weight
@@ -322,22 +335,31 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         // the top 3-4 % less than from the MFMA shadow of groups 0 / 1 on 256x128, 2-3 % on 128x128 and on the
         // two-stage 128x64; the three-stage 128x64 of layer 1 is address-unit bound and 1 % slower: lab builds, round 2).
         constexpr bool early = (VAR & 4) != 0 || NW == 8 || (BM == 128 && BN == 128) || (BM == 128 && BN == 64 && NSTAGE == 2);
-        if (early && moreP) { advance(); issue_a(st_iss); issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; }
+        const bool my_turn = !ALT || (kt & 1) == (wave >= NW / 2 ? 1 : 0);   // (wave-uniform)
+        if (early && moreP) {
+          advance();
+          if (my_turn) { issue_a(st_iss, all_a); issue_b(st_iss, all_b); }
+          st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1;
+        }
         DLIP_FENCE();
         read_rest(st_cur); DLIP_FENCE();
         mfma_p(0, 0, MI); DLIP_FENCE();
-        if (moreP && !late && !early) { advance(); issue_a(st_iss); } DLIP_FENCE();
+        if (moreP && !late && !early) { advance(); issue_a(st_iss, own_a); } DLIP_FENCE();
         mfma_p(1, 0, MH); DLIP_FENCE();
-        if (moreP && !late && !early) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
+        if (moreP && !late && !early) { issue_b(st_iss, own_b); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
         if (MH < MI) mfma_p(1, MH, MI);
         DLIP_FENCE();
-        if (moreP && late) { advance(); issue_a(st_iss); } DLIP_FENCE();
+        if (moreP && late) { advance(); issue_a(st_iss, own_a); } DLIP_FENCE();
         // (the barrier one half-group earlier, behind group 1 -- what the window kernel does -- measured 1-7 % SLOWER here)
         mfma_p(2, 0, MH); DLIP_FENCE();
-        if (moreP && late) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
+        if (moreP && late) { issue_b(st_iss, own_b); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
         if (more1) {
           // slice kt+1 must have landed (every wave's share: wait, then barrier); slices beyond it stay in flight
-          if (PF > 1 && (kt + 2) < kn) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+          if constexpr (ALT) {   // the issuer of this slice keeps its 2 NL newest pieces (slice kt + 2) in flight; its partner has none younger than kt + 1's
+            if (my_turn && moreP) wait_vmcnt<2 * NL>(); else wait_vmcnt<0>();
+          } else {
+            if (PF > 1 && (kt + 2) < kn) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+          }
           __builtin_amdgcn_s_barrier();
           read_first(st_nxt);
         }
@@ -811,7 +833,7 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 // (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
 #ifdef DLIP_LAB
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {256, 128}, {128, 256}, {128, 64}, {64, 128}};   // 6: tile 5 with VAR 1 (s_setprio); 7: 128x256; 8, 9: tiles 4, 2 with VAR 4
+                           {256, 128}, {128, 256}, {128, 64}, {64, 128}};   // 6: tile 5 with VAR 8 (alternating issuer halves); 7: 128x256; 8, 9: tiles 4, 2 with VAR 4
 constexpr int NUM_DMA_ALL = 10;
 #else
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
@@ -857,7 +879,7 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 3: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, epi);
     case 4: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, epi);
 #ifdef DLIP_LAB
-    case 6: return launch_dma<256, 128, 4, 2, 3, 1, 1>(a, st, epi);
+    case 6: return launch_dma<256, 128, 4, 2, 3, 1, 8>(a, st, epi);
     case 7: return launch_dma<128, 256, 2, 4, 2, 1, 4>(a, st, epi);
     case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
     case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);

@@ -1,6 +1,6 @@
 // Split-fp16 implicit-GEMM convolution, WINDOW variant: same-size stride-1 R x S convolutions with few output
-// channels (K <= 64: the four 3x3 convolutions of the trunk's layer 1, resnet.py:55-69 at 64 -> 64 channels --
-// a quarter of the step's time on the ring kernel).
+// channels (K <= 128, one column block: the four 3x3 convolutions of the trunk's layer 1, resnet.py:55-69 at 64 -> 64
+// channels -- a quarter of the step's time on the ring kernel -- and the two 128 -> 128 ones of layer 2's second block).
 //
 // Why a second kernel.  With BN = 64 the ring kernel (conv_igemm_f16x3_dma.hip) moves (128 + 64) x 128 B of operands
 // per slice for 24 MFMAs per wave: the address unit (64 B / clk / CU) needs as many cycles per slice as the matrix
@@ -54,12 +54,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   constexpr int BSTAGE_B = BN * ROWB;
   // LDS map.  The workgroup is PERSISTENT and pipelines consecutive tiles: while a tile's epilogue stages its image in
   // [0, IMG), the next tile's window 0 and first two weight slices are already landing in regions the image does not touch.
-  //   [0, SLOT_B)                      window slot 1 (odd channel slices)        } epilogue image [0, IMG), IMG <= SLOT_B + BSTAGE_B
-  //   [SLOT_B, +BSTAGE_B)              weight ring stage 2                       }
-  //   [SLOT_B + BSTAGE_B, +2 BSTAGE_B) weight ring stages 0, 1 (prefetched during the previous epilogue)
-  //   then the zero block (2 KB), window slot 0 (even channel slices; prefetched during the previous epilogue), the table
+  //   [0, SLOT_B)                      window slot 1 (odd channel slices)        } epilogue image [0, IMG_B); with 128 output
+  //   [SLOT_B, +BSTAGE_B)              weight ring stage 2                       } columns it is longer than these two: padding
+  //   [HEAD_OFF, +2 BSTAGE_B)          weight ring stages 0, 1 (the next tile's arrive during the epilogue)
+  //   then the zero block (2 KB), window slot 0 (even channel slices; the next tile's arrives during the last slices), the table
   constexpr int W1_OFF = 0;
-  constexpr int ZERO_OFF = SLOT_B + NSTAGE * BSTAGE_B;
+  constexpr int IMG_B = BM * BN * 4;                                                  // the epilogue's output image [0, IMG_B)
+  constexpr int HEAD_OFF = IMG_B > SLOT_B + BSTAGE_B ? IMG_B : SLOT_B + BSTAGE_B;    // stages 0, 1 start behind the image
+  constexpr int ZERO_OFF = HEAD_OFF + 2 * BSTAGE_B;
   constexpr int W0_OFF = ZERO_OFF + 2048;
   constexpr int TAB_OFF = W0_OFF + SLOT_B;
   constexpr int LDK = 32;
@@ -69,11 +71,11 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   constexpr int RES_PIECES = BM * PITCH / 1024 / NW;
   constexpr int RPQ = 1024 / PITCH;
   static_assert(BN % RPP == 0 && WM % 16 == 0 && 2 * WBLK % NW == 0, "tile / window layout");
-  static_assert(BM * PITCH <= SLOT_B + BSTAGE_B, "the epilogue image must not reach the prefetched weight stages");
+  static_assert(BM * PITCH == IMG_B && IMG_B <= HEAD_OFF, "the epilogue image must not reach the prefetched weight stages");
   static_assert((BM * PITCH) % (NW * 1024) == 0 && (BM * CPR) % NT == 0, "the tile image is whole DMA pieces / stores per wave");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds_c = reinterpret_cast<char*>(smem);
-  auto stage_off = [](int st) { return SLOT_B + (st == 2 ? 0 : (st + 1) * BSTAGE_B); };   // stages 0, 1 outside the image
+  auto stage_off = [](int st) { return st == 2 ? SLOT_B : HEAD_OFF + st * BSTAGE_B; };   // stages 0, 1 outside the image
   auto slot_off = [](int slot) { return (slot & 1) ? W1_OFF : W0_OFF; };
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -421,7 +423,9 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WBLK0 = (BM + WIN_SLACK + 15) / 16;
   constexpr int WBLK = (WBLK0 + NW / 2 - 1) / (NW / 2) * (NW / 2);
-  constexpr size_t lds = (size_t)2 * WBLK * 2048 + 2048 + (size_t)3 * BN * ROWB + 5 * BN * sizeof(float);
+  constexpr size_t slot_b = (size_t)WBLK * 2048, bst = (size_t)BN * ROWB, img = (size_t)BM * BN * 4;
+  constexpr size_t head = img > slot_b + bst ? img : slot_b + bst;
+  constexpr size_t lds = head + 2 * bst + 2048 + slot_b + 5 * BN * sizeof(float);
   if (b.tiles_n != 1) return DLIP_EINVAL;   // one column block (K <= BN): the kernel's tile index is the row block
   static_assert(lds <= 160 * 1024, "LDS exceeds a CU");
   auto kern = out_split ? conv_win_f16x3_kernel<BM, BN, WAVES_M, WAVES_N, true, OCC> : conv_win_f16x3_kernel<BM, BN, WAVES_M, WAVES_N, false, OCC>;
@@ -474,12 +478,13 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
 
 }  // namespace
 
-// The window kernel serves same-size stride-1 3x3 convolutions (the nine taps are unrolled; a wave's six window pieces go
+// The window kernel serves same-size stride-1 3x3 convolutions (the nine taps are unrolled; a wave's window pieces go
 // out one per slice and must be older in the queue than the weights of the next channel slice's first tap), a halo within WIN_SLACK,
-// K <= 64 (one 64-channel column block: layer 1) and no second reduction source / pooled epilogue.
+// K <= 128 (ONE column block: layer 1 on the 128x64 instance, layer 2 on the 128x128 one; dlip_debug_set(DLIP_DBG_WIN, 1)
+// keeps it to K <= 64) and no second reduction source / pooled epilogue.
 static bool win_shape_ok(int sh, int sw, int H, int W, int Ho, int Wo, int R, int S, int dh, int dw, int ph, int pw, int K) {
   if (dlip_dbg_value[DLIP_DBG_WIN] == 0) return false;
-  return sh == 1 && sw == 1 && Wo == W && Ho == H && R == 3 && S == 3 && K <= 64 && (K & 3) == 0 &&
+  return sh == 1 && sw == 1 && Wo == W && Ho == H && R == 3 && S == 3 && K <= (dlip_dbg_value[DLIP_DBG_WIN] == 1 ? 64 : 128) && (K & 3) == 0 &&
          (R - 1) * dh * W + (S - 1) * dw <= WIN_SLACK && ph * W + pw <= WIN_SLACK;
 }
 
@@ -501,6 +506,9 @@ extern "C" int dlip_conv_kernel_kind(const dlip_conv_desc* d) {
 
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_win_launch(const void* args, void* stream, int out_split) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
-  // four waves, two workgroups per CU (eight waves in one workgroup per CU: 258 vs 218 us on layer 1, same box)
+  // K <= 64: four waves, two workgroups per CU (eight waves in one workgroup per CU: 258 vs 218 us on layer 1, same box).
+  // 64 < K <= 128 (layer 2, 128 -> 128 channels on 11x11 maps): eight waves on a 128x128 tile, one workgroup per CU (the
+  // fp32 epilogue image alone is 64 KB): 178 us vs 200-210 on the 256x128 ring kernel without a residual, 211-223 vs 241-275 with.
+  if (a.K > 64) return launch_win<128, 128, 4, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
   return launch_win<128, 64, 2, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
 }

@@ -19,20 +19,13 @@
 //   * persistent workgroups (one per CU, 154 KB LDS): weights staged once, the next tile's window is
 //     fetched into registers while the current tile is multiplied and lands in a second LDS buffer.
 //
-// POOL variant (dlip_stem3d_pool_f16x3): MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) of
-// model.py:85 is applied to the activations before they leave the CU, so the 4x larger pre-pool tensor
-// (0.92 GB at the benchmark batch, written once and read once) never exists:
-//   * a workgroup walks whole frames, row tile after row tile (8 stem rows -> 4 pooled rows), so the one
-//     stem row a pooling window needs from the tile above is carried in LDS instead of recomputed;
-//   * columns: a lane's 4 accumulator values are 4 consecutive pixels of one row, so the odd pooled
-//     column is lane-local and the even one needs the pixel to the left (ds_bpermute from the lane
-//     16 below, the previous M tile's registers, or -- at the 7 wave boundaries -- a 2 KB LDS exchange);
-//   * rows: the column-pooled rows go to an LDS buffer (32 channels at a time), 3-row maxima are taken
-//     from there and stored in the split activation format the trunk's LDS-DMA kernels read;
-//   * LDS: weights 73 KB + ONE window 40 KB + row buffer 28 KB + carried rows 14 KB + exchange 2 KB; the
-//     next window still travels in registers during the MFMAs and is written after the barrier that
-//     ends them.
-#include "dlip_common.h"
+// The fused stem + max-pool kernel (dlip_stem3d_pool_f16x3) is the second kernel of this file: same weights
+// image, window layout and tap gather, different pixel -> lane map (chosen for the pooling) and window transport.
+#include "conv_dma_common.h"
+#include <algorithm>
+#include <type_traits>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -67,12 +60,19 @@ struct StemArgs {
   int n_tiles;         // B*T*row_tiles
   uint32_t x_bytes, y_bytes;
   int pwp;             // window row pitch in dwords (>= W + 6, == 32 mod 64)
-  int Hp, Wp;          // POOL: pooled output size
-  int n_frames;        // POOL: B*T
+  int Hp, Wp;          // pooled output size (stem + pool kernel)
+  int n_frames;        // B*T
   int32_t* status;     // range-status word (NULL: not reported)
+#ifdef DLIP_LAB
+  unsigned long long* stamps;   // lab build: [grid][8] s_memtime of each workgroup's second tile
+#endif
 };
 
-constexpr int HPITCH = 40;   // floats per (row, pooled column) of the POOL row buffer: 32 channels + 8 (bank spread)
+#ifdef DLIP_LAB
+#define STEM_STAMP(i) do { if (threadIdx.x == 0 && it == 1 && a.stamps) a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STEM_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint32_t split_pair(float v) {
   const _Float16 h = (_Float16)v;
@@ -80,19 +80,13 @@ __device__ __forceinline__ uint32_t split_pair(float v) {
   return (uint32_t)__builtin_bit_cast(unsigned short, h) | ((uint32_t)__builtin_bit_cast(unsigned short, l) << 16);
 }
 
-template <bool POOL>
 __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* wl = lds;                                 // [WBYTES / 4]     split weights, staged once
   const int plane = PR * a.pwp;
   const int psize = KT * plane;                       // dwords per window buffer (even)
   uint32_t* patch0 = lds + WBYTES / 4;                // two window buffers: tile i+1 is fetched while
-  uint32_t* patch1 = patch0 + psize;                  // tile i is multiplied (POOL: one buffer)
-  // POOL only: column-pooled rows of the tile [8][Wp][HPITCH], the carried row [2 tiles][2 channel halves]
-  // [Wp][HPITCH], and the wave-boundary exchange [8 waves][64 channels]
-  float* hbuf = reinterpret_cast<float*>(patch0 + psize);
-  float* halo = hbuf + ROWS * a.Wp * HPITCH;
-  float* xch = halo + 4 * a.Wp * HPITCH;
+  uint32_t* patch1 = patch0 + psize;                  // tile i is multiplied
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -129,7 +123,7 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
       pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)off, 0, 0));
     }
   };
-  float amax = 0.f;   // largest magnitude this lane splits (input pixels; POOL: output activations too)
+  float amax = 0.f;   // largest magnitude this lane splits (input pixels)
   auto store_window = [&](uint32_t* patch) {   // split into (hi, lo) pairs and write the LDS window
 #pragma unroll
     for (int i = 0; i < PPER; ++i) {
@@ -139,8 +133,7 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
     }
   };
 
-  // plain: tiles blockIdx, blockIdx + G, ...; POOL: frames blockIdx, blockIdx + G, ..., each frame's row tiles in order
-  int tile = POOL ? blockIdx.x * a.row_tiles : blockIdx.x;
+  int tile = blockIdx.x;
   if (tile >= ntiles) return;
   {
     const uint4* src = reinterpret_cast<const uint4*>(a.w);
@@ -184,14 +177,9 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
   __syncthreads();
 
   for (int it = 0; tile < ntiles; ++it) {
-    const uint32_t* patch = (!POOL && (it & 1)) ? patch1 : patch0;
-    int next;
-    if constexpr (POOL) {
-      const int rtn = tile % a.row_tiles;
-      next = rtn + 1 < a.row_tiles ? tile + 1 : (tile / a.row_tiles + G) * a.row_tiles;
-    } else {
-      next = tile + G;
-    }
+    const uint32_t* patch = (it & 1) ? patch1 : patch0;
+    const int next = tile + G;
+    STEM_STAMP(0);
     if (next < ntiles) fetch_window(next);          // in flight during this tile's MFMAs
 
     f32x4 acc[MTW][4];
@@ -260,9 +248,10 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
       }
     }
 
+    STEM_STAMP(1);
     const int rt = tile % a.row_tiles, f = tile / a.row_tiles, ho0 = rt * ROWS;
     const int rows_left = a.Ho - ho0;
-    if constexpr (!POOL) {
+    {
     // next tile's window -> the other LDS buffer (its last readers finished before the previous barrier)
     if (next < ntiles) store_window((it & 1) ? patch0 : patch1);
 
@@ -284,130 +273,293 @@ __global__ __launch_bounds__(512) void stem3d_f16x3_kernel(const StemArgs a) {
         }
       }
     }
-    } else {
-    // ---------------- fused 3x3 / stride-2 max pooling ----------------
-    const float NEG = -__builtin_inff();
-    // activation in place; pixels outside the frame count as -inf
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-      const int p0 = (mt0 + m) * 16 + kq * 4;
-      const bool ok = m < mcnt && p0 < npix && p0 < rows_left * a.Wo;   // Wo % 4 == 0: a lane's 4 pixels share a row
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[m][j][e] * inv[j] + bias[j];
-          v = v >= 0.f ? v : v * slope[j];
-          acc[m][j][e] = ok ? v : NEG;
-        }
-    }
-    __syncthreads();   // B1: every wave is done reading the window; the exchange words are free
-    if (next < ntiles) store_window(patch0);
-    if (kq == 3) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xch[wave * 64 + j * 16 + li] = acc[MTW - 1][j][3];   // waves 6, 7: tile 2 is all -inf, fixed below
-    }
-    if (kq == 3 && mcnt == 2) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xch[wave * 64 + j * 16 + li] = acc[1][j][3];
-    }
-    // the pixel left of a lane's first pixel: lane - 16 (same M tile) or lane + 48 of the previous M tile
-    float left[MTW][4];
-    {
-      float prev[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) prev[j] = NEG;
-#pragma unroll
-      for (int m = 0; m < MTW; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float last = acc[m][j][3];   // (a bit_cast straight from a vector-element lvalue reads element 0)
-          const float got = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane - 16) & 63) * 4, __builtin_bit_cast(int, last)));
-          left[m][j] = kq > 0 ? got : prev[j];
-          prev[j] = got;   // for kq == 0 lanes: element 3 of lane + 48 = the last pixel of this M tile
-        }
-    }
-    __syncthreads();   // B2: exchange words visible
-    if (kq == 0 && wave > 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) left[0][j] = xch[(wave - 1) * 64 + j * 16 + li];
-    }
-    // column pooling: even pooled column 2u = max(left, v0, v1), odd 2u+1 = max(v1, v2, v3)
-    int orow[MTW], q0[MTW];
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-      const int p0 = (mt0 + m) * 16 + kq * 4;
-      orow[m] = p0 / a.Wo;
-      const int ocol = p0 - orow[m] * a.Wo;
-      q0[m] = ocol >> 1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float l = ocol == 0 ? NEG : left[m][j];
-        const float he = fmaxf(fmaxf(l, acc[m][j][0]), acc[m][j][1]);
-        const float hod = fmaxf(fmaxf(acc[m][j][1], acc[m][j][2]), acc[m][j][3]);
-        acc[m][j][0] = he;
-        acc[m][j][1] = hod;
-      }
-    }
-    const int rows_here = rows_left < ROWS ? rows_left : ROWS;
-    float* halo_cur = halo + (it & 1) * 2 * a.Wp * HPITCH;          // written by the previous tile of this frame
-    float* halo_nxt = halo + ((it + 1) & 1) * 2 * a.Wp * HPITCH;
-    const int prow0 = rt * (ROWS / 2);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {            // 32 channels per pass
-#pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        if (m < mcnt && orow[m] < rows_here) {
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int j = 2 * h + jj;
-            float* dst = hbuf + (orow[m] * a.Wp + q0[m]) * HPITCH + jj * 16 + li;
-            dst[0] = acc[m][j][0];
-            dst[HPITCH] = acc[m][j][1];
-            if (orow[m] == ROWS - 1) {       // the row the next tile's first pooling window reaches up to
-              float* hd = halo_nxt + (h * a.Wp + q0[m]) * HPITCH + jj * 16 + li;
-              hd[0] = acc[m][j][0];
-              hd[HPITCH] = acc[m][j][1];
-            }
-          }
-        }
-      }
-      __syncthreads();   // B3 / B5: the pass's column-pooled rows are in LDS
-      const int items = (ROWS / 2) * a.Wp * 8;          // (pooled row, pooled column, 4-channel group)
-      for (int i = tid; i < items; i += 512) {
-        const int c4 = i & 7;
-        const int q = (i >> 3) % a.Wp;
-        const int prl = (i >> 3) / a.Wp;
-        const int pr = prow0 + prl;
-        if (pr < a.Hp) {
-          const int r1 = 2 * prl;             // local stem rows 2 prl - 1, 2 prl, 2 prl + 1
-          f32x4 v = *reinterpret_cast<const f32x4*>(hbuf + (r1 * a.Wp + q) * HPITCH + c4 * 4);
-          if (r1 + 1 < rows_here) {
-            const f32x4 w2 = *reinterpret_cast<const f32x4*>(hbuf + ((r1 + 1) * a.Wp + q) * HPITCH + c4 * 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], w2[c]);
-          }
-          if (r1 > 0 || rt > 0) {
-            const float* up = r1 > 0 ? hbuf + ((r1 - 1) * a.Wp + q) * HPITCH : halo_cur + (h * a.Wp + q) * HPITCH;
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(up + c4 * 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], w0[c]);
-          }
-          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-          h4 hi, lo;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); amax = fmaxf(amax, fabsf(v[c])); }
-          // split activation format: pixel = 64 channels = two 128-B blocks of (32 hi | 32 lo) halves
-          const uint32_t off = (uint32_t)(((f * a.Hp + pr) * a.Wp + q) * 256 + h * 128 + c4 * 8);
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), yr, (int)off, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), yr, (int)off + 64, 0, 0);
-        }
-      }
-      if (h == 0) __syncthreads();   // B4: pass 1 overwrites the row buffer
-    }
     }
     tile = next;
+    STEM_STAMP(5);
     __syncthreads();   // window (it+1) complete and window (it) free before the next iteration
+    STEM_STAMP(6);
+  }
+  dlip_report_range(amax, a.status);
+}
+
+
+// ---------------- fused stem + max pooling: the 12-wave kernel (round 2) ----------------
+// The POOL variant above spends half of a tile's ~28 k cycles behind its MFMA loop (in-kernel stamps: loop 14.0 k,
+// activation + barrier 5.2 k, window store 2.2 k, column pooling 1.0 k, two row passes through LDS 5.5 k; six
+// barriers).  Two things make the pooling expensive there: 22 pixel tiles do not divide over 8 waves, and with
+// row-major pixel tiles a pooling window's nine members sit in unrelated lanes and registers, so everything goes
+// through an LDS row buffer, 32 channels at a time.  Here the PIXEL -> (wave, tile, lane) map is chosen for the pooling
+// (it is free: every lane gathers its own pixel's taps from the window anyway):
+//   * a tile's 8 stem rows x Wo (<= 44) columns are cut into 3 column STRIPS of 16 (columns 0-15, 14-29, 28-43: two
+//     columns of overlap, 24 pixel tiles instead of 22 -- but 24 = 12 waves x 2, where 22 = 8 x 2.75 already cost 24);
+//   * wave (strip, row pair rp) owns stem rows 2 rp and 2 rp + 1 of its strip, one pixel tile per row: lane & 15 =
+//     column inside the strip.  The accumulators are TRANSPOSED (weights are the MFMA's first operand), so a lane holds
+//     4 consecutive channels of ONE pixel per register quad;
+//   * column pooling = two DPP row shifts per register (pooled column q = columns 2q-1, 2q, 2q+1: all inside the strip
+//     that owns q -- strip 0: q 0-7, strip 1: q 8-14, strip 2: q 15-21; a shift past the strip's edge reads -inf, which is
+//     exactly the padding at column -1);
+//   * row pooling = v_max3 of registers: pooled row = (row above, row 2 rp, row 2 rp + 1); only the row above comes from
+//     another wave -- every wave exports its lower row's column-pooled values (2 KB, even lanes) and imports its
+//     neighbour's behind ONE barrier (the last row pair's export is the next tile's carried row: two alternating slots);
+//   * the pooled values leave as 8-B (hi) + 8-B (lo) pieces of the split activation format straight from registers.
+// The WINDOW no longer passes through registers either (20 loads, 20 splits and 20 ds_write_b32 per lane and tile in the
+// kernel above): a pre-pass (stem_split_input_kernel, ~25 us at the bench's batch) writes the clip once as (hi, lo) fp16
+// pairs with the window's row pitch and its 3 + 5 zero columns, so a window row is 24 contiguous 16-B chunks and a window
+// plane arrives as 8 LDS-DMA pieces whose out-of-frame rows (offset out of range) are zeros.  The reduction walks the
+// five frame planes in order, so the NEXT tile's plane p is fetched as soon as the last step that reads plane p is
+// behind a barrier (after steps 1, 3, 5, 6 and 8): the fetch latency hides under the remaining steps.
+// No row buffer; 3 waves per SIMD (<= 168 VGPRs).
+constexpr int PWAVES = 12, PTHREADS = 64 * PWAVES;
+constexpr int CARRY_SLOTS = 18, CARRY_B = 2048; // [strip][rp 0..2] 12 same-tile slots (9 used) + [parity][strip] 6 tile-to-tile slots
+
+__device__ __forceinline__ float dpp_from_left(float v, float edge) {    // lane i <- lane i - 1 within its row of 16; lane 0 <- edge
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_right(float v, float edge) {   // lane i <- lane i + 1; lane 15 <- edge
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
+}
+
+// x fp32 [F, H, W] -> xs [F, H, pwp] dwords (hi | lo << 16), columns 3 .. W + 2 = the pixels, the rest zero.
+__global__ __launch_bounds__(256) void stem_split_input_kernel(const float* __restrict__ x, uint32_t* __restrict__ xs, int rows, int W, int pwp,
+                                                               int32_t* status) {
+  const int cpr = pwp >> 2;                            // 16-B chunks per row
+  const long long total = (long long)rows * cpr;
+  float amax = 0.f;
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < total; c += (long long)gridDim.x * 256) {
+    const int row = (int)(c / cpr), ch = (int)(c - (long long)row * cpr);
+    const float* src = x + (size_t)row * W;
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int wi = 4 * ch + e - 3;
+      const float v = (unsigned)wi < (unsigned)W ? src[wi] : 0.f;
+      amax = fmaxf(amax, fabsf(v));
+      o[e] = split_pair(v);
+    }
+    *reinterpret_cast<u32x4*>(xs + (size_t)c * 4) = o;
+  }
+  dlip_report_range(amax, status);
+}
+
+__global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* wl = lds;                                 // [WBYTES / 4] split weights, staged once
+  const int cpr = a.pwp >> 2;                         // 16-B chunks per window row
+  const int np = (PR * cpr + 63) >> 6;                // LDS-DMA pieces per window plane (the plane is padded to whole pieces)
+  const int plane = np * 256 + 32;                    // dwords per plane: == 32 (mod 64) like the row pitch, so lane quarters that
+                                                      // straddle two planes (kernel rows 6 | 7, 20 | 21) still split the 64 banks
+  uint32_t* patch = lds + WBYTES / 4;
+  char* carry = reinterpret_cast<char*>(patch + KT * plane);
+  float* tab = reinterpret_cast<float*>(carry + CARRY_SLOTS * CARRY_B);   // 1/wscale | bias | slope, 64 each
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int strip = wave >> 2, rp = wave & 3;
+  const int col = 14 * strip + li;                    // stem column of this lane's pixels
+  const bool col_ok = col < a.Wo;
+  const int ntiles = a.n_tiles, G = gridDim.x;
+
+  // Window fetch: wave w < np moves piece w of a plane; this lane's chunk = (window row wrow, 16-B chunk wch) of the plane.
+  const u32x4 xr = make_rsrc_words(a.x, a.x_bytes);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const int wchunk = wave * 64 + lane;
+  const int wrow = wchunk / cpr, wch = wchunk - wrow * cpr;
+  auto fetch_plane = [&](int tile, int kt) {          // (call with wave < np only: wave-uniform)
+    const int rt = tile % a.row_tiles, f = tile / a.row_tiles, t = f % a.T;
+    const int tt = t + kt - 2, hi = 2 * rt * ROWS - 3 + wrow;
+    const bool ok = (unsigned)tt < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && wrow < PR;
+    const uint32_t off = ok ? (uint32_t)((((f - t + tt) * a.H + hi) * cpr + wch) * 16) : DLIP_OOB_OFFSET;
+    dma_piece(xr, off, lds0 + WBYTES + (kt * plane + wave * 256) * 4);
+  };
+
+  int tile = blockIdx.x * a.row_tiles;                // a workgroup walks whole frames, row tile after row tile
+  if (tile >= ntiles) return;
+  if (wave < np) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) fetch_plane(tile, kt);
+  }
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.w);
+    uint4* dst = reinterpret_cast<uint4*>(wl);
+    constexpr int WCHUNKS = WBYTES / 16, WPER = (WCHUNKS + PTHREADS - 1) / PTHREADS;
+#pragma unroll
+    for (int i = 0; i < WPER; ++i) {
+      const int c = tid + PTHREADS * i;
+      if (c < WCHUNKS) dst[c] = src[c];
+    }
+    if (tid < 64) {
+      tab[tid] = 1.f / a.wscale[tid];                 // power of two: exact
+      tab[64 + tid] = a.bias ? a.bias[tid] : 0.f;
+      tab[128 + tid] = a.slope ? a.slope[tid] : 1.f;
+    }
+  }
+
+  int pixoff[2];                                      // dword offset of this lane's pixel (tap 0 of kernel row (0,0)) in the window
+#pragma unroll
+  for (int m = 0; m < 2; ++m) pixoff[m] = 2 * (2 * rp + m) * a.pwp + 2 * (col_ok ? col : 0);
+  int koff[STEPS];                                    // window offset of this lane quarter's kernel row (kt, kh) per step
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const int rho = 4 * s + kq;
+    const int kt = rho / KH, kh = rho - kt * KH;
+    koff[s] = rho < KT * KH ? kt * plane + kh * a.pwp : (KT - 1) * plane;   // zero row (zero weights): finite data of a plane live in step 8
+  }
+  const int boff = li * WCH_BYTES;
+  const char* wl8 = reinterpret_cast<const char*>(wl);
+  const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
+  const f32x4* tab4 = reinterpret_cast<const f32x4*>(tab);
+  const float NEG = -__builtin_inff();
+  float amax = 0.f;                                   // largest magnitude this lane stores
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const bool mono = __builtin_amdgcn_ballot_w64(tab[128 + lane] < 0.f) == 0;   // every slope >= 0 (workgroup-uniform)
+
+  for (int it = 0; tile < ntiles; ++it) {
+    const int rt = tile % a.row_tiles, f = tile / a.row_tiles, ho0 = rt * ROWS;
+    const int next = rt + 1 < a.row_tiles ? tile + 1 : (f + G) * a.row_tiles;
+    const bool refill = next < ntiles && wave < np;   // (wave-uniform)
+    STEM_STAMP(0);
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x2 raw[2][4];
+    f16x8 bfr[8];                                     // channel tile nt: hi at 2 nt, lo at 2 nt + 1
+    {
+      const u32x2* p0 = reinterpret_cast<const u32x2*>(patch + koff[0] + pixoff[0]);
+      raw[0][0] = p0[0]; raw[0][1] = p0[1]; raw[0][2] = p0[2]; raw[0][3] = p0[3];
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int rho16 = (4 * s + kq) * 16;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bfr[2 * nt] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + rho16);
+        bfr[2 * nt + 1] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + WLO_OFF + rho16);
+      }
+      // Frame plane p is read by the steps 4 s + kq in [7 p, 7 p + 6]: its last reader is step 1, 3, 5, 6, 8 for p = 0 .. 4.
+      // Behind that step's reads (its second pixel tile's taps are requested while the first is multiplied) every wave
+      // waits for its LDS reads, the workgroup meets, and the NEXT tile's plane p is fetched over it.
+      const bool frees = ((1 << 1 | 1 << 3 | 1 << 5 | 1 << 6) >> s) & 1;   // (folds once the step loop is unrolled)
+      const int freed = s == 1 ? 0 : s == 3 ? 1 : s == 5 ? 2 : 3;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (m == 0) {                                 // the other pixel tile's taps of this step
+          const u32x2* pn = reinterpret_cast<const u32x2*>(patch + koff[s] + pixoff[1]);
+          raw[1][0] = pn[0]; raw[1][1] = pn[1]; raw[1][2] = pn[2]; raw[1][3] = pn[3];
+        }
+        uint32_t hv[4], lv[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          hv[d] = __builtin_amdgcn_perm(raw[m][d].y, raw[m][d].x, 0x05040100u);
+          lv[d] = __builtin_amdgcn_perm(raw[m][d].y, raw[m][d].x, 0x07060302u);
+        }
+        u32x4 hq = {hv[0], hv[1], hv[2], hv[3]}, lq = {lv[0], lv[1], lv[2], lv[3]};
+        const f16x8 ah = __builtin_bit_cast(f16x8, hq), al = __builtin_bit_cast(f16x8, lq);
+        if (m == 1 && frees) {                        // every read of the freed plane has been consumed (hq, lq above): meet, refill
+          // Step 6 is also where this tile's plane 4 must have landed (steps 7, 8 read it; it was issued behind the previous
+          // tile's MFMA loop and stayed in flight across the tile boundary).  vmcnt counts in issue order: behind that piece
+          // this wave has issued the previous tile's 8 output stores and at most three pieces of the next window.
+          if (s == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (refill) fetch_plane(next, freed);
+        }
+        if (m == 1 && s + 1 < STEPS) {                // the next step's first taps (a plane that is still live)
+          const u32x2* pn = reinterpret_cast<const u32x2*>(patch + koff[s + 1 < STEPS ? s + 1 : s] + pixoff[0]);
+          raw[0][0] = pn[0]; raw[0][1] = pn[1]; raw[0][2] = pn[2]; raw[0][3] = pn[3];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[2 * nt], al, acc[m][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[2 * nt + 1], ah, acc[m][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[2 * nt], ah, acc[m][nt], 0, 0, 0);
+      }
+    }
+    STEM_STAMP(1);
+
+    // ---- epilogue: activation, column pooling in registers (acc[m][j][e] = pixel (row 2 rp + m, col), channel
+    // 16 j + 4 kq + e), one exported row, row pooling, split-format store.  MONO (every PReLU slope >= 0; 1 / wscale
+    // is positive): the folded-BN affine and the activation are non-decreasing, so they commute with the maxima --
+    // bit for bit, max only selects -- and are applied to the pooled values, a quarter of the registers. ----
+    auto epilogue = [&](auto mono_c) {
+      constexpr bool MONO = decltype(mono_c)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 inv4, bi4, sl4;
+        if constexpr (!MONO) { inv4 = tab4[4 * j + kq]; bi4 = tab4[16 + 4 * j + kq]; sl4 = tab4[32 + 4 * j + kq]; }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const bool ok = col_ok && (ho0 + 2 * rp + m) < a.Ho;   // pixels outside the frame count as -inf
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[m][j][e];
+            if constexpr (!MONO) {
+              v = v * inv4[e] + bi4[e];
+              v = v >= 0.f ? v : v * sl4[e];
+            }
+            v = ok ? v : NEG;
+            acc[m][j][e] = fmaxf(fmaxf(v, dpp_from_left(v, NEG)), dpp_from_right(v, NEG));
+          }
+        }
+      }
+      // the lower row's column maxima go to the wave below (the last row pair's: to the next tile's first wave)
+      {
+        const int slot = rp < 3 ? strip * 4 + rp : 12 + 3 * (it & 1) + strip;
+        if ((li & 1) == 0) {
+          f32x4* dst = reinterpret_cast<f32x4*>(carry + slot * CARRY_B) + kq * 8 + (li >> 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dst[j * 32] = acc[1][j];
+        }
+      }
+      STEM_STAMP(2);
+      __syncthreads();   // every wave is done reading the window (plane 4 is free); the exported rows are visible
+      STEM_STAMP(3);
+      if (refill) fetch_plane(next, 4);
+      STEM_STAMP(4);
+
+      // row pooling: (row above, row 2 rp, row 2 rp + 1), then the split-format store of the even lanes
+      const int slot = rp > 0 ? strip * 4 + rp - 1 : 12 + 3 * ((it + 1) & 1) + strip;
+      const bool has_up = rp > 0 || rt > 0;           // (the frame's first row has nothing above it)
+      const f32x4* src = reinterpret_cast<const f32x4*>(carry + slot * CARRY_B) + kq * 8 + (li >> 1);
+      const int pr = rt * (ROWS / 2) + rp;            // pooled row
+      const bool lane_ok = (li & 1) == 0 && (strip == 0 || li >= 2) && col_ok && pr < a.Hp;
+      const uint32_t base = (uint32_t)(((f * a.Hp + pr) * a.Wp + (col >> 1)) * 256 + kq * 8);
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 up = src[j * 32];
+        f32x4 inv4, bi4, sl4;
+        if constexpr (MONO) { inv4 = tab4[4 * j + kq]; bi4 = tab4[16 + 4 * j + kq]; sl4 = tab4[32 + 4 * j + kq]; }
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = fmaxf(fmaxf(has_up ? up[e] : NEG, acc[0][j][e]), acc[1][j][e]);
+          if constexpr (MONO) {
+            v = v * inv4[e] + bi4[e];
+            v = v >= 0.f ? v : v * sl4[e];
+          }
+          hi[e] = (_Float16)v;
+          lo[e] = (_Float16)(v - (float)hi[e]);
+          amax = lane_ok ? fmaxf(amax, fabsf(v)) : amax;
+        }
+        // split activation format: pixel = 64 channels = two 128-B blocks of (32 hi | 32 lo) halves; channels 16 j + 4 kq ..
+        const uint32_t off = lane_ok ? base + (uint32_t)((j >> 1) * 128 + (j & 1) * 32) : DLIP_OOB_OFFSET;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), yr, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), yr, (int)(lane_ok ? off + 64 : DLIP_OOB_OFFSET), 0, 0);
+      }
+    };
+    if (mono) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    tile = next;
+    STEM_STAMP(5);
+    // planes 0 .. 3 of the next window have landed (issued during the MFMA loop: older than plane 4's piece and the 8 stores)
+    asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the next window's planes 0 .. 3 are complete; every import is done before the next tile's exports
+    STEM_STAMP(6);
   }
   dlip_report_range(amax, a.status);
 }
@@ -437,7 +589,7 @@ extern "C" int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, con
   a.Hp = a.Wp = 0; a.n_frames = B * T;
   const long long grid = tiles < 256 ? tiles : 256;   // persistent: one workgroup per CU (154 KB of LDS each)
   const size_t ldsb = (size_t)WBYTES + 2 * (size_t)KT * PR * a.pwp * 4;
-  auto kern = stem3d_f16x3_kernel<false>;
+  auto kern = stem3d_f16x3_kernel;
   a.status = dlip_status_words() ? dlip_status_words() + DLIP_ST_STEM : nullptr;
   static size_t lds_set = 0;   // the attribute is raised once per size (not on every launch)
   if (ldsb > lds_set) {
@@ -445,41 +597,94 @@ extern "C" int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, con
     if (e != hipSuccess) return (int)e;
     lds_set = ldsb;
   }
+#ifdef DLIP_LAB
+  a.stamps = nullptr;
+  if (getenv("DLIP_STAMP_PRINT")) {
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), 256 * 8 * 8);
+    (void)hipMemset(dbuf, 0, 256 * 8 * 8);
+    a.stamps = dbuf;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, static_cast<hipStream_t>(stream), a);
+    (void)hipDeviceSynchronize();
+    unsigned long long h[256 * 8];
+    (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+    double d[6] = {0, 0, 0, 0, 0, 0};
+    int n = 0;
+    for (int g = 0; g < (int)grid; ++g)
+      if (h[g * 8 + 6]) { for (int j = 0; j < 6; ++j) d[j] += (double)(h[g * 8 + j + 1] - h[g * 8 + j]); ++n; }
+    if (n) fprintf(stderr, "[stem stamps, mean of %d workgroups' second tile] mfma loop %.0f  act+B1 %.0f  window store %.0f  left/colpool %.0f  row passes %.0f  end barrier %.0f\n",
+                   n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n);
+    return dlip_launch_status();
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, static_cast<hipStream_t>(stream), a);
   return dlip_launch_status();
 }
 
-extern "C" int dlip_stem3d_pool_f16x3(const float* x, const void* w_split, const float* w_scale, const float* bias,
+extern "C" int64_t dlip_stem3d_pool_workspace_bytes(int32_t B, int32_t T, int32_t H, int32_t W) {
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return -1;
+  const int64_t pwp = ((W + 6 - 32 + 63) / 64) * 64 + 32;
+  return (int64_t)B * T * H * pwp * 4;
+}
+
+extern "C" int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void* w_split, const float* w_scale, const float* bias,
                                       const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
                                       int32_t K, dlip_stream_t stream) {
-  DLIP_CHECK_ARG(x && w_split && w_scale && y && B > 0 && T > 0 && H > 0 && W > 0);
-  DLIP_CHECK_ARG(K == 64 && (H & 1) == 0 && (W & 7) == 0);   // Wo % 4 == 0: a lane's 4 pixels stay in one row
+  DLIP_CHECK_ARG(x && x_split && w_split && w_scale && y && B > 0 && T > 0 && H > 0 && W > 0);
+  DLIP_CHECK_ARG(K == 64 && (H & 1) == 0 && (W & 1) == 0 && (reinterpret_cast<uintptr_t>(x_split) & 15) == 0);
   StemArgs a;
-  a.x = x; a.w = static_cast<const uint32_t*>(w_split); a.wscale = w_scale; a.bias = bias; a.slope = slope; a.y = y;
+  a.x = static_cast<const float*>(x_split); a.w = static_cast<const uint32_t*>(w_split); a.wscale = w_scale; a.bias = bias; a.slope = slope; a.y = y;
   a.T = T; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
   a.Hp = (a.Ho - 1) / 2 + 1; a.Wp = (a.Wo - 1) / 2 + 1;
   a.row_tiles = (a.Ho + ROWS - 1) / ROWS;
   a.pwp = ((W + 6 - 32 + 63) / 64) * 64 + 32;
-  DLIP_CHECK_ARG(ROWS * a.Wo <= 22 * 16);
-  DLIP_CHECK_ARG(KT * PR * a.pwp <= 512 * 20);
+  DLIP_CHECK_ARG(a.Wo <= 44);                          // three column strips of 16 (stride 14): frames up to 88 pixels wide
+  const int np = (PR * (a.pwp / 4) + 63) / 64;         // LDS-DMA pieces per window plane: one per wave
+  DLIP_CHECK_ARG(np <= PWAVES);
   const long long frames = (long long)B * T, tiles = frames * a.row_tiles;
   if (tiles > 0x7FFFFFFFll) return DLIP_ERANGE;
   a.n_tiles = (int)tiles;
   a.n_frames = (int)frames;
-  const long long xb = frames * H * W * 4, yb = frames * a.Hp * a.Wp * 64 * 4;
+  const long long xb = frames * H * a.pwp * 4, yb = frames * a.Hp * a.Wp * 64 * 4;
   if (xb > DLIP_MAX_BUFFER_BYTES || yb > DLIP_MAX_BUFFER_BYTES) return DLIP_ERANGE;
   a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
-  const long long grid = frames < 256 ? frames : 256;   // persistent: a workgroup walks whole frames
-  const size_t ldsb = (size_t)WBYTES + (size_t)KT * PR * a.pwp * 4 + (size_t)(ROWS + 4) * a.Wp * HPITCH * 4 + 8 * 64 * 4;
-  DLIP_CHECK_ARG(ldsb <= 160 * 1024);
-  auto kern = stem3d_f16x3_kernel<true>;
   a.status = dlip_status_words() ? dlip_status_words() + DLIP_ST_STEM : nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  {   // pre-pass: the clip as (hi, lo) pairs at the window's row pitch
+    const long long chunks = frames * H * (a.pwp / 4);
+    const unsigned pgrid = (unsigned)std::min<long long>((chunks + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(stem_split_input_kernel, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), W, a.pwp, a.status);
+  }
+  const long long grid = frames < 256 ? frames : 256;   // persistent: a workgroup walks whole frames
+  const size_t ldsb = (size_t)WBYTES + (size_t)KT * (np * 256 + 32) * 4 + (size_t)CARRY_SLOTS * CARRY_B + 3 * 64 * 4;
+  DLIP_CHECK_ARG(ldsb <= 160 * 1024);
+  auto kern = stem3d_pool_f16x3_kernel;
   static size_t lds_set = 0;   // the attribute is raised once per size (not on every launch)
   if (ldsb > lds_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     if (e != hipSuccess) return (int)e;
     lds_set = ldsb;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsb, static_cast<hipStream_t>(stream), a);
+#ifdef DLIP_LAB
+  a.stamps = nullptr;
+  if (getenv("DLIP_STAMP_PRINT")) {
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), 256 * 8 * 8);
+    (void)hipMemset(dbuf, 0, 256 * 8 * 8);
+    a.stamps = dbuf;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PTHREADS), ldsb, st, a);
+    (void)hipDeviceSynchronize();
+    unsigned long long h[256 * 8];
+    (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+    double d[6] = {0, 0, 0, 0, 0, 0};
+    int n = 0;
+    for (int g = 0; g < (int)grid; ++g)
+      if (h[g * 8 + 6]) { for (int j = 0; j < 6; ++j) d[j] += (double)(h[g * 8 + j + 1] - h[g * 8 + j]); ++n; }
+    if (n) fprintf(stderr, "[stem+pool stamps, mean of %d workgroups' second tile] mfma loop %.0f  act+colpool+export %.0f  barrier %.0f  plane-4 issue %.0f  row pool+stores %.0f  wait+end barrier %.0f\n",
+                   n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n);
+    return dlip_launch_status();
+  }
+#endif
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PTHREADS), ldsb, st, a);
   return dlip_launch_status();
 }

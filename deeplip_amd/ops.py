@@ -106,7 +106,7 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
         check(lib().dlip_conv_plan(C.byref(d), mode, C.byref(bm), C.byref(bn)), "dlip_conv_plan")
         kname = ("conv_igemm_f32_kernel", "conv_igemm_f16x3_kernel", "", "conv_igemm_f16x3_dma_kernel")[mode]
         if mode == 3 and lib().dlip_conv_kernel_kind(C.byref(d)) == 1:
-            kname, bm.value, bn.value = "conv_win_f16x3_kernel", 128, 64
+            kname, bm.value, bn.value = "conv_win_f16x3_kernel", 128, (128 if K > 64 else 64)
         tok = hook.begin(f"{kname}<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
     if w_scale is not None:
         if x_split:
@@ -298,10 +298,11 @@ def stem3d_pool(x_bthw: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Ten
     B, T, H, W = x_bthw.shape
     Ho, Wo = H // 2, W // 2
     y = _empty((B * T, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), x_bthw.device)
+    ws = _empty((int(lib().dlip_stem3d_pool_workspace_bytes(B, T, H, W)) // 4,), x_bthw.device)   # the clip as (hi, lo) pairs
     hook = LAUNCH_HOOK
     if hook is not None:
-        tok = hook.begin("stem3d_f16x3_kernel<pool>", 2.0 * B * T * Ho * Wo * 64 * 245)
-    check(lib().dlip_stem3d_pool_f16x3(ptr(x_bthw), ptr(w_img), ptr(w_scale), ptr(bias), ptr(slope), ptr(y),
+        tok = hook.begin("stem3d_pool_f16x3_kernel", 2.0 * B * T * Ho * Wo * 64 * 245)
+    check(lib().dlip_stem3d_pool_f16x3(ptr(x_bthw), ptr(ws), ptr(w_img), ptr(w_scale), ptr(bias), ptr(slope), ptr(y),
                                        B, T, H, W, 64, stream_handle()), "dlip_stem3d_pool_f16x3")
     if hook is not None:
         hook.end(tok)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 17
+#define DLIP_ABI_VERSION 18
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -148,8 +148,8 @@ int dlip_split_unpack_f32(const float* x, float* y, int64_t rows, int32_t C, dli
  * kernel) will use for `d` -- i.e. which conv_igemm_*_kernel<BM,BN,..> instance a profiler will
  * show.  Host-only, no launch. */
 int dlip_conv_plan(const dlip_conv_desc* d, int32_t split_f16, int32_t* bm, int32_t* bn);
-/* 1 if a split-format (DLIP_SPLIT_IN) launch of `d` runs on the window kernel (conv_win_f16x3_kernel<128,64>: same-size
- * stride-1 3x3 convolutions with K <= 64 -- one activation window per channel slice in LDS instead of one fetch per
+/* 1 if a split-format (DLIP_SPLIT_IN) launch of `d` runs on the window kernel (conv_win_f16x3_kernel<128,64> for K <= 64, <128,128> above: same-size
+ * stride-1 3x3 convolutions with K <= 128 -- one activation window per channel slice in LDS instead of one fetch per
  * tap), 0 if on the LDS-DMA ring kernel dlip_conv_plan describes.  Host-only. */
 int dlip_conv_kernel_kind(const dlip_conv_desc* d);
 
@@ -172,13 +172,17 @@ int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, const float* w
                              const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
                              int32_t K, dlip_stream_t stream);
 
-/* dlip_stem3d_bn_act_f16x3 + MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) in one kernel (replaces
+/* dlip_stem3d_bn_act_f16x3 + MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) (replaces
  * models/video_models/model.py:81-85): the pre-pool activations never reach memory.  y is
  * [(B*T), Hp, Wp, 64] with Hp = (H/2 - 1)/2 + 1, in the split activation format of
- * dlip_conv_nhwc_f16x3 (what the trunk's first layers read).  W % 8 == 0, W <= 88. */
-int dlip_stem3d_pool_f16x3(const float* x, const void* w_split, const float* w_scale, const float* bias,
-                           const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
-                           int32_t K, dlip_stream_t stream);
+ * dlip_conv_nhwc_f16x3 (what the trunk's first layers read).  H, W even, W <= 88.
+ * x_split: caller-owned scratch of dlip_stem3d_pool_workspace_bytes(B, T, H, W) bytes, 16-B aligned -- a
+ * pre-pass writes the clip there once as (hi, lo) fp16 pairs at the kernel's window row pitch, and the
+ * kernel fetches its windows from it by LDS-DMA (two launches on `stream`). */
+int64_t dlip_stem3d_pool_workspace_bytes(int32_t B, int32_t T, int32_t H, int32_t W);
+int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void* w_split, const float* w_scale,
+                           const float* bias, const float* slope, float* y, int32_t B, int32_t T, int32_t H,
+                           int32_t W, int32_t K, dlip_stream_t stream);
 
 /* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) on NHWC: [N,H,W,C] -> [N,Ho,Wo,C],
  * Ho = (H+2-3)/2+1.  Replaces models/video_models/model.py:85.  C % 4 == 0.  out_split != 0 writes y

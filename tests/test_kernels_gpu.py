@@ -485,16 +485,23 @@ def test_maxpool_split_output(ops):
     assert torch.equal(ys.cpu().view(torch.int32), _split_ref(y.cpu()).view(torch.int32))
 
 
-@pytest.mark.parametrize("B,T,H,W", [(2, 7, 88, 88), (1, 3, 24, 24), (1, 2, 40, 56), (3, 1, 72, 88), (300, 1, 16, 16)])
-def test_stem3d_pool_f16x3(ops, B, T, H, W):
+@pytest.mark.parametrize("B,T,H,W", [(2, 7, 88, 88), (1, 3, 24, 24), (1, 2, 40, 56), (3, 1, 72, 88), (300, 1, 16, 16),
+                                     (1, 6, 42, 52), (2, 2, 20, 30), (1, 1, 88, 60)])
+@pytest.mark.parametrize("neg_slopes", [False, True], ids=["slopes>=0", "some-slopes<0"])
+def test_stem3d_pool_f16x3(ops, B, T, H, W, neg_slopes):
     """Stem + MaxPool fused: the same bits as the split-fp16 stem kernel followed by the pooling kernel
-    (same MFMA order, max is exact), in the split activation format; ragged last row tiles, frames
-    walked by more and by fewer workgroups than there are CUs."""
+    (same MFMA order, max is exact), in the split activation format; ragged last row tiles, widths that are
+    not multiples of 8, frames walked by more and by fewer workgroups than there are CUs.  With every PReLU
+    slope >= 0 the kernel applies affine + activation AFTER the pooling (they commute with max bit for bit);
+    a negative slope makes it activate first."""
     from deeplip_amd import packing
     x = (rnd(B, T, H, W, seed=51) * 2.0).cuda()
     w = rnd(64, 1, 5, 7, 7, seed=52, scale=1.0 / np.sqrt(245))
     b = rnd(64, seed=53, scale=0.1).cuda()
-    slope = (torch.rand(64, generator=torch.Generator().manual_seed(54)) * 0.3).cuda()
+    slope = torch.rand(64, generator=torch.Generator().manual_seed(54)) * 0.3
+    if neg_slopes:
+        slope[5::7] = -slope[5::7] - 0.05
+    slope = slope.cuda()
     img, sc = packing.split_stem_weights(w.double())
     img, sc = img.cuda(), sc.cuda()
     ref = ops.maxpool3x3s2(ops.stem3d(x, img, b, slope, w_scale=sc), out_split=True)
@@ -753,12 +760,15 @@ WIN_CASES = [  # N, H, W, C, K, pad (= dil for same-size 3x3), dil, residual, sl
     (4, 11, 11, 96, 48, 2, 2, True, True, False),       # dilation 2 (halo 48 = the window's slack), ragged K
     (1, 3, 3, 64, 64, 1, 1, True, True, True),          # image smaller than a tile: every border case at once
     (9, 1, 20, 64, 64, 1, 1, False, True, True),        # H = 1 with a 3x3 kernel: row taps all fall outside
+    (40, 11, 11, 128, 128, 1, 1, True, True, True),     # layer 2's shape: the 128-column instance (eight waves)
+    (3, 7, 9, 64, 96, 1, 1, False, True, False),        # 64 < K < 128: ragged column block, fp32 output
+    (130, 6, 6, 256, 128, 1, 1, True, False, True),     # eight channel slices, many tiles on the 128-column instance
 ]
 
 
 @pytest.mark.parametrize("case", WIN_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))
 def test_conv_window_kernel(ops, case):
-    """conv_win_f16x3_kernel (same-size stride-1 3x3, K <= 64): against fp64, and against the ring kernel it replaces
+    """conv_win_f16x3_kernel (same-size stride-1 3x3, K <= 128): against fp64, and against the ring kernel it replaces
     (dlip_debug_set DLIP_DBG_WIN = 0) -- the two differ only in where the activation fragments come from."""
     from deeplip_amd import _lib, packing
     from deeplip_amd._lib import ConvDesc

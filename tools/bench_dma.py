@@ -17,6 +17,8 @@ ap.add_argument("--only", default="")
 ap.add_argument("--variants", default="-1", help="comma list of DMA tile ids (dlip_debug_set; -1 = built-in choice; 6..9 need the lab build via DLIP_LIB_PATH)")
 ap.add_argument("--streamk", type=int, default=-1, help="balanced split: -1 built-in cost model, 0 never, 2 always (dlip_debug_set)")
 ap.add_argument("--ninner", type=int, default=-1, help="1: tile order with the output-channel block inner (experiment)")
+ap.add_argument("--win", type=int, default=-1, help="window kernel: -1 built-in rule, 0 off (ring kernel everywhere), 1 K <= 64 only")
+ap.add_argument("--check", action="store_true", help="compare every variant's output with the first variant's")
 ap.add_argument("--xpad", type=int, default=0, help="extra (unused) channels per input pixel: breaks the power-of-two pixel stride")
 a = ap.parse_args()
 B = a.batch
@@ -39,6 +41,7 @@ L = [
 variants = a.variants.split(",")
 _lib.debug_set(_lib.DBG_STREAMK, a.streamk)
 _lib.debug_set(5, a.ninner)
+_lib.debug_set(_lib.DBG_WIN, a.win)
 tot = {v: 0.0 for v in variants}
 tot_best = 0.0
 for name, (n, h, w, c), k, r, s, st, pd, dl, res, count in L:
@@ -60,6 +63,15 @@ for name, (n, h, w, c), k, r, s, st, pd, dl, res, count in L:
     rs = ops.split_pack(torch.randn_like(y)) if res else None
     fl = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * k * r * s * c
     best = {v: 1e30 for v in variants}
+    if a.check:
+        outs = []
+        for v in variants:
+            _lib.debug_set(_lib.DBG_DMA_TILE, int(v))
+            outs.append(ops.conv_nhwc(x, wsp, b, residual=rs, out=torch.empty_like(y), **kw).clone())
+        u0 = ops.split_unpack(outs[0]) if osp else outs[0]
+        for v, o in zip(variants[1:], outs[1:]):
+            u = ops.split_unpack(o) if osp else o
+            print(f"   check v{v} vs v{variants[0]}: max|d|/max = {float((u - u0).abs().max() / u0.abs().max()):.2e}", flush=True)
     for rnd in range(3):
         for v in variants:
             _lib.debug_set(_lib.DBG_DMA_TILE, int(v))
