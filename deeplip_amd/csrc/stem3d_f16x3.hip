@@ -26,6 +26,7 @@
 #include <type_traits>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -70,8 +71,10 @@ struct StemArgs {
 
 #ifdef DLIP_LAB
 #define STEM_STAMP(i) do { if (threadIdx.x == 0 && it == 1 && a.stamps) a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STEM_WSTAMP(i) do { if ((threadIdx.x & 63) == 0 && it == 2 && a.stamps) a.stamps[((size_t)blockIdx.x * 12 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STEM_STAMP(i) do { } while (0)
+#define STEM_WSTAMP(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ uint32_t split_pair(float v) {
@@ -351,6 +354,9 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
   uint32_t* patch = lds + WBYTES / 4;
   char* carry = reinterpret_cast<char*>(patch + KT * plane);
   float* tab = reinterpret_cast<float*>(carry + CARRY_SLOTS * CARRY_B);   // 1/wscale | bias | slope, 64 each
+  // per carry slot: 1 + the iteration whose export it holds (explicit LDS address space: a generic volatile pointer would
+  // poll with flat loads, which count in vmcnt and would drain the window pieces in flight)
+  volatile __attribute__((address_space(3))) int* flags = (volatile __attribute__((address_space(3))) int*)(__attribute__((address_space(3))) char*)(tab + 192);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -365,10 +371,10 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   const int wchunk = wave * 64 + lane;
   const int wrow = wchunk / cpr, wch = wchunk - wrow * cpr;
-  auto fetch_plane = [&](int tile, int kt) {          // (call with wave < np only: wave-uniform)
+  auto fetch_plane = [&](int tile, int kt) {          // (call with wave < np only: wave-uniform); tile >= ntiles: zeros
     const int rt = tile % a.row_tiles, f = tile / a.row_tiles, t = f % a.T;
     const int tt = t + kt - 2, hi = 2 * rt * ROWS - 3 + wrow;
-    const bool ok = (unsigned)tt < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && wrow < PR;
+    const bool ok = tile < ntiles && (unsigned)tt < (unsigned)a.T && (unsigned)hi < (unsigned)a.H && wrow < PR;
     const uint32_t off = ok ? (uint32_t)((((f - t + tt) * a.H + hi) * cpr + wch) * 16) : DLIP_OOB_OFFSET;
     dma_piece(xr, off, lds0 + WBYTES + (kt * plane + wave * 256) * 4);
   };
@@ -392,6 +398,7 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
       tab[tid] = 1.f / a.wscale[tid];                 // power of two: exact
       tab[64 + tid] = a.bias ? a.bias[tid] : 0.f;
       tab[128 + tid] = a.slope ? a.slope[tid] : 1.f;
+      if (tid < CARRY_SLOTS) flags[tid] = 0;
     }
   }
 
@@ -418,8 +425,8 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
   for (int it = 0; tile < ntiles; ++it) {
     const int rt = tile % a.row_tiles, f = tile / a.row_tiles, ho0 = rt * ROWS;
     const int next = rt + 1 < a.row_tiles ? tile + 1 : (f + G) * a.row_tiles;
-    const bool refill = next < ntiles && wave < np;   // (wave-uniform)
-    STEM_STAMP(0);
+    const bool duty = wave < np;                      // this wave moves one piece of every plane (wave-uniform)
+    STEM_WSTAMP(0);
 
     f32x4 acc[2][4];
 #pragma unroll
@@ -440,9 +447,14 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
         bfr[2 * nt] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + rho16);
         bfr[2 * nt + 1] = *reinterpret_cast<const f16x8*>(wl8 + boff + nt * 16 * WCH_BYTES + WLO_OFF + rho16);
       }
-      // Frame plane p is read by the steps 4 s + kq in [7 p, 7 p + 6]: its last reader is step 1, 3, 5, 6, 8 for p = 0 .. 4.
-      // Behind that step's reads (its second pixel tile's taps are requested while the first is multiplied) every wave
-      // waits for its LDS reads, the workgroup meets, and the NEXT tile's plane p is fetched over it.
+      // Frame plane p is read by the steps 4 s + kq in [7 p, 7 p + 6]: first by step 0, 1, 3, 5, 7 and last by step 1, 3, 5, 6, 8
+      // for p = 0 .. 4.  The tile's ONLY barriers stand behind the reads of steps 1, 3, 5 and 6; behind each the plane that step
+      // frees is refilled for the NEXT tile (out of range -> zeros when there is none), and behind step 1 -- every wave has left
+      // the previous tile's reduction -- plane 4 of THIS tile as well.  What a barrier certifies (each duty wave waits for its
+      // own pieces first; vmcnt counts in issue order, and every wave issues the same sequence per tile:
+      //   [step 1: plane 4, next 0] [step 3: next 1] [step 5: next 2] [step 6: next 3] [epilogue: 8 stores]):
+      //   step 1: this tile's planes 2, 3 (issued in the previous tile; only its 8 stores are younger)       -> vmcnt(8)
+      //   step 6: this tile's plane 4 and the next tile's planes 0, 1 (only next 2 is younger)                  -> vmcnt(1)
       const bool frees = ((1 << 1 | 1 << 3 | 1 << 5 | 1 << 6) >> s) & 1;   // (folds once the step loop is unrolled)
       const int freed = s == 1 ? 0 : s == 3 ? 1 : s == 5 ? 2 : 3;
 #pragma unroll
@@ -460,13 +472,14 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
         u32x4 hq = {hv[0], hv[1], hv[2], hv[3]}, lq = {lv[0], lv[1], lv[2], lv[3]};
         const f16x8 ah = __builtin_bit_cast(f16x8, hq), al = __builtin_bit_cast(f16x8, lq);
         if (m == 1 && frees) {                        // every read of the freed plane has been consumed (hq, lq above): meet, refill
-          // Step 6 is also where this tile's plane 4 must have landed (steps 7, 8 read it; it was issued behind the previous
-          // tile's MFMA loop and stayed in flight across the tile boundary).  vmcnt counts in issue order: behind that piece
-          // this wave has issued the previous tile's 8 output stores and at most three pieces of the next window.
-          if (s == 6) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+          if (s == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+          else if (s == 6) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          if (refill) fetch_plane(next, freed);
+          if (duty) {
+            if (s == 1) fetch_plane(tile, 4);
+            fetch_plane(next, freed);
+          }
         }
         if (m == 1 && s + 1 < STEPS) {                // the next step's first taps (a plane that is still live)
           const u32x2* pn = reinterpret_cast<const u32x2*>(patch + koff[s + 1 < STEPS ? s + 1 : s] + pixoff[0]);
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
         for (int nt = 0; nt < 4; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[2 * nt], ah, acc[m][nt], 0, 0, 0);
       }
     }
-    STEM_STAMP(1);
+    STEM_WSTAMP(1);
 
     // ---- epilogue: activation, column pooling in registers (acc[m][j][e] = pixel (row 2 rp + m, col), channel
     // 16 j + 4 kq + e), one exported row, row pooling, split-format store.  MONO (every PReLU slope >= 0; 1 / wscale
@@ -488,6 +501,7 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
     // bit for bit, max only selects -- and are applied to the pooled values, a quarter of the registers. ----
     auto epilogue = [&](auto mono_c) {
       constexpr bool MONO = decltype(mono_c)::value;
+      const bool inside = 14 * strip + 15 < a.Wo && ho0 + 2 * rp + 1 < a.Ho;   // the wave's 2 x 16 pixels are all inside the frame (wave-uniform)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4 inv4, bi4, sl4;
@@ -502,7 +516,7 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
               v = v * inv4[e] + bi4[e];
               v = v >= 0.f ? v : v * sl4[e];
             }
-            v = ok ? v : NEG;
+            if (!inside) v = ok ? v : NEG;
             acc[m][j][e] = fmaxf(fmaxf(v, dpp_from_left(v, NEG)), dpp_from_right(v, NEG));
           }
         }
@@ -516,26 +530,38 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
           for (int j = 0; j < 4; ++j) dst[j * 32] = acc[1][j];
         }
       }
-      STEM_STAMP(2);
-      __syncthreads();   // every wave is done reading the window (plane 4 is free); the exported rows are visible
-      STEM_STAMP(3);
-      if (refill) fetch_plane(next, 4);
-      STEM_STAMP(4);
+      // (LDS executes one wave's instructions in order: whoever sees the flag sees the row)
+      asm volatile("" ::: "memory");
+      if (lane == 0) flags[rp < 3 ? strip * 4 + rp : 12 + 3 * (it & 1) + strip] = it + 1;
+      STEM_WSTAMP(2);
 
       // row pooling: (row above, row 2 rp, row 2 rp + 1), then the split-format store of the even lanes
       const int slot = rp > 0 ? strip * 4 + rp - 1 : 12 + 3 * ((it + 1) & 1) + strip;
       const bool has_up = rp > 0 || rt > 0;           // (the frame's first row has nothing above it)
+      // No workgroup barrier here: the row above is the ONLY thing this wave needs from another one, so it waits for that
+      // wave's flag (its own strip's previous row pair in this tile, or the last row pair of the previous tile) and goes on
+      // to its stores and the next tile while its SIMD's other waves are still multiplying.  The exporter never waits for
+      // anybody, and the next tile's barriers stand between this import and the slot's next export.
+      if (has_up) {
+        const int expect = rp > 0 ? it + 1 : it;
+        while (flags[slot] < expect) __builtin_amdgcn_s_sleep(4);
+      }
+      asm volatile("" ::: "memory");
+      STEM_WSTAMP(3);
+      STEM_WSTAMP(4);
       const f32x4* src = reinterpret_cast<const f32x4*>(carry + slot * CARRY_B) + kq * 8 + (li >> 1);
       const int pr = rt * (ROWS / 2) + rp;            // pooled row
       const bool lane_ok = (li & 1) == 0 && (strip == 0 || li >= 2) && col_ok && pr < a.Hp;
       const uint32_t base = (uint32_t)(((f * a.Hp + pr) * a.Wp + (col >> 1)) * 256 + kq * 8);
       typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      float tmax = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 up = src[j * 32];
         f32x4 inv4, bi4, sl4;
         if constexpr (MONO) { inv4 = tab4[4 * j + kq]; bi4 = tab4[16 + 4 * j + kq]; sl4 = tab4[32 + 4 * j + kq]; }
         h4 hi, lo;
+        float v4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = fmaxf(fmaxf(has_up ? up[e] : NEG, acc[0][j][e]), acc[1][j][e]);
@@ -545,22 +571,23 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
           }
           hi[e] = (_Float16)v;
           lo[e] = (_Float16)(v - (float)hi[e]);
-          amax = lane_ok ? fmaxf(amax, fabsf(v)) : amax;
+          v4[e] = v;
         }
+        tmax = fmaxf(fmaxf(tmax, fabsf(v4[0])), fabsf(v4[1]));   // (v_max3 with |.| operands; lanes that do not store are dropped below)
+        tmax = fmaxf(fmaxf(tmax, fabsf(v4[2])), fabsf(v4[3]));
         // split activation format: pixel = 64 channels = two 128-B blocks of (32 hi | 32 lo) halves; channels 16 j + 4 kq ..
         const uint32_t off = lane_ok ? base + (uint32_t)((j >> 1) * 128 + (j & 1) * 32) : DLIP_OOB_OFFSET;
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), yr, (int)off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), yr, (int)(lane_ok ? off + 64 : DLIP_OOB_OFFSET), 0, 0);
       }
+      amax = lane_ok ? fmaxf(amax, tmax) : amax;
     };
     if (mono) epilogue(std::true_type{}); else epilogue(std::false_type{});
     tile = next;
-    STEM_STAMP(5);
-    // planes 0 .. 3 of the next window have landed (issued during the MFMA loop: older than plane 4's piece and the 8 stores)
-    asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // the next window's planes 0 .. 3 are complete; every import is done before the next tile's exports
-    STEM_STAMP(6);
+    STEM_WSTAMP(5);
+    STEM_WSTAMP(6);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last tile's refills -- zeros -- have landed before the LDS is released)
   dlip_report_range(amax, a.status);
 }
 
@@ -656,7 +683,7 @@ extern "C" int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void*
     hipLaunchKernelGGL(stem_split_input_kernel, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), W, a.pwp, a.status);
   }
   const long long grid = frames < 256 ? frames : 256;   // persistent: a workgroup walks whole frames
-  const size_t ldsb = (size_t)WBYTES + (size_t)KT * (np * 256 + 32) * 4 + (size_t)CARRY_SLOTS * CARRY_B + 3 * 64 * 4;
+  const size_t ldsb = (size_t)WBYTES + (size_t)KT * (np * 256 + 32) * 4 + (size_t)CARRY_SLOTS * CARRY_B + 3 * 64 * 4 + 128;
   DLIP_CHECK_ARG(ldsb <= 160 * 1024);
   auto kern = stem3d_pool_f16x3_kernel;
   static size_t lds_set = 0;   // the attribute is raised once per size (not on every launch)
@@ -669,19 +696,26 @@ extern "C" int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void*
   a.stamps = nullptr;
   if (getenv("DLIP_STAMP_PRINT")) {
     static unsigned long long* dbuf = nullptr;
-    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), 256 * 8 * 8);
-    (void)hipMemset(dbuf, 0, 256 * 8 * 8);
+    constexpr size_t NS = 256 * 12 * 8;
+    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), NS * 8);
+    (void)hipMemset(dbuf, 0, NS * 8);
     a.stamps = dbuf;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PTHREADS), ldsb, st, a);
     (void)hipDeviceSynchronize();
-    unsigned long long h[256 * 8];
-    (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
-    double d[6] = {0, 0, 0, 0, 0, 0};
-    int n = 0;
-    for (int g = 0; g < (int)grid; ++g)
-      if (h[g * 8 + 6]) { for (int j = 0; j < 6; ++j) d[j] += (double)(h[g * 8 + j + 1] - h[g * 8 + j]); ++n; }
-    if (n) fprintf(stderr, "[stem+pool stamps, mean of %d workgroups' second tile] mfma loop %.0f  act+colpool+export %.0f  barrier %.0f  plane-4 issue %.0f  row pool+stores %.0f  wait+end barrier %.0f\n",
-                   n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n);
+    std::vector<unsigned long long> h(NS);
+    (void)hipMemcpy(h.data(), dbuf, NS * 8, hipMemcpyDeviceToHost);
+    // per wave (mean over workgroups, third tile): cycles from the tile's start (wave 0's stamp 0) to each stamp
+    for (int w = 0; w < 12; ++w) {
+      double d[7] = {0, 0, 0, 0, 0, 0, 0};
+      int n = 0;
+      for (int g = 0; g < (int)grid; ++g) {
+        const unsigned long long* r = &h[((size_t)g * 12 + w) * 8];
+        const unsigned long long t0 = h[(size_t)g * 12 * 8];
+        if (r[6] && t0) { for (int j = 0; j < 7; ++j) d[j] += (double)(long long)(r[j] - t0); ++n; }
+      }
+      if (n) fprintf(stderr, "[stem+pool wave %2d] start %6.0f  loop end %6.0f  exported %6.0f  past B1 %6.0f  p4 issued %6.0f  stores issued %6.0f  past end barrier %6.0f\n",
+                     w, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6] / n);
+    }
     return dlip_launch_status();
   }
 #endif
