@@ -10,8 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -c 2500 $O/bench.json
 STEPS=5
-ARGS="$R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline"
-PARGS="$ARGS --single-mode --no-configs --no-kernel-events"
+SSTEPS=40   # the kernel-trace runs: long enough to sit at the chip's steady (power-capped) clocks like bench.py's own timed region
+ARGS="$R/bench.py --steps $SSTEPS --warmup 5 --no-cpu-baseline --single-mode"
+PARGS="$R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --single-mode --no-configs --no-kernel-events"
 # kernel durations: single-stream run (what bench.py's HIP events time; with the two encoders overlapped on two streams a
 # trace charges each kernel the time it shared the chip) -> kernel_stats.csv; the default two-stream command -> kernel_stats_two_stream.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ARGS --no-configs --single-stream > $O/stats.log 2>&1
