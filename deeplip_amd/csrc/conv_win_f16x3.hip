@@ -17,8 +17,8 @@
 // touches 16 distinct slots = all 64 banks once; a DMA piece fills 4 bank rows = 4 chunks (the hi or the lo half of
 // the slice) x 16 rows, i.e. 64 contiguous bytes of each of 16 pixels.
 //
-//   Taps that fall outside the image are redirected per lane to a zero block at the slot with the same index (same
-//   banks: a group with masked lanes stays conflict free).  Window c+1 is fetched one piece per slice during the first
+//   Taps that fall outside the image read at an address beyond the workgroup's LDS allocation (bit 18 set per lane): an
+//   out-of-range ds_read returns zeros on gfx950 (probed).  Window c+1 is fetched one piece per slice during the first
 //   taps of channel slice c (no burst, uniform vmcnt).
 //
 // With the operand traffic gone, what a 18-slice tile costs is its fixed part: set-up, the latency of its first
@@ -57,12 +57,11 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   //   [0, SLOT_B)                      window slot 1 (odd channel slices)        } epilogue image [0, IMG_B); with 128 output
   //   [SLOT_B, +BSTAGE_B)              weight ring stage 2                       } columns it is longer than these two: padding
   //   [HEAD_OFF, +2 BSTAGE_B)          weight ring stages 0, 1 (the next tile's arrive during the epilogue)
-  //   then the zero block (2 KB), window slot 0 (even channel slices; the next tile's arrives during the last slices), the table
+  //   then window slot 0 (even channel slices; the next tile's arrives during the last slices), the table
   constexpr int W1_OFF = 0;
   constexpr int IMG_B = BM * BN * 4;                                                  // the epilogue's output image [0, IMG_B)
   constexpr int HEAD_OFF = IMG_B > SLOT_B + BSTAGE_B ? IMG_B : SLOT_B + BSTAGE_B;    // stages 0, 1 start behind the image
-  constexpr int ZERO_OFF = HEAD_OFF + 2 * BSTAGE_B;
-  constexpr int W0_OFF = ZERO_OFF + 2048;
+  constexpr int W0_OFF = HEAD_OFF + 2 * BSTAGE_B;
   constexpr int TAB_OFF = W0_OFF + SLOT_B;
   constexpr int LDK = 32;
   constexpr int PITCH = BN * 4;                    // bytes per image row
@@ -71,6 +70,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   constexpr int RES_PIECES = BM * PITCH / 1024 / NW;
   constexpr int RPQ = 1024 / PITCH;
   static_assert(BN % RPP == 0 && WM % 16 == 0 && 2 * WBLK % NW == 0, "tile / window layout");
+  static_assert(WPER <= 7, "the last window piece of a channel slice goes out at least two slices before the slice ends");
   static_assert(BM * PITCH == IMG_B && IMG_B <= HEAD_OFF, "the epilogue image must not reach the prefetched weight stages");
   static_assert((BM * PITCH) % (NW * 1024) == 0 && (BM * CPR) % NT == 0, "the tile image is whole DMA pieces / stores per wave");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -159,6 +159,8 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   int m0 = t_begin * BM;
   uint32_t fr_mask[MI];
   tile_masks(m0, fr_mask);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) fr_mask[mi] = ~fr_mask[mi];   // kept INVERTED: bit tap set = that tap falls outside the image
   issue_tile_head(m0 - halo_lo);
   if (tid < BN) {
     const int k = tid;
@@ -170,10 +172,8 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
     tab[3 * BN + tid] = (kok && a.pscale) ? a.pscale[k] : 1.f;
     tab[4 * BN + tid] = (kok && a.pshift) ? a.pshift[k] : 0.f;
   }
-  if (tid < 128) *reinterpret_cast<f32x4*>(lds_c + ZERO_OFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // the zero block
 
   const int a_lane = (wm * WM / 16) * 2048 + half * 256;    // this lane's chunk row of its first block
-  const int z_lane = ZERO_OFF + half * 256;
   const int b_frag = (wn * WN + lrow) * LDK;
   const int key_rd = (lrow >> 1) & 7;
   const int khi = (half ^ key_rd) << 2, klo = ((4 + half) ^ key_rd) << 2;
@@ -185,8 +185,11 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
 #ifdef DLIP_LAB
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.pool);   // lab: [G][8] s_memtime of each workgroup's 2nd tile
 #define WIN_STAMP(i) do { if (stamps && tid == 0 && t == t_begin + 1) stamps[(size_t)g * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// inside ONE slice (channel slice 0, tap 4 of the second tile): [4096 * 8 + g * 8 + i]
+#define WIN_SSTAMP(i) do { if (stamps && tid == 0 && t == t_begin + 1 && c == 0 && tap == 4) stamps[(size_t)4096 * 8 + (size_t)g * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WIN_STAMP(i) do { } while (0)
+#define WIN_SSTAMP(i) do { } while (0)
 #endif
   for (int t = t_begin; t < t_end; ++t) {
     const bool first = t == t_begin, has_next = t + 1 < t_end;
@@ -205,28 +208,32 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
-    // per tap: slot-relative fragment address of this lane's first block, and its zero-block twin (same slot index)
+    // Per tap: the fragment address of this lane's first 16-row block; block mi is 2048 mi further (an immediate of the read).
+    // A tap that falls outside the image gets bit 18 set: the address is then beyond the workgroup's LDS allocation, and an
+    // out-of-range ds_read returns ZEROS on gfx950 (tools/probes/lds_oob.hip: 0 of 524 288 lanes read anything else, with
+    // several workgroups sharing the CU) -- no zero block, no select, no per-(tap, block) lane masks held in scalar registers
+    // (the select form cost 44 vector instructions per slice, 12 of them v_readlane of spilled masks, against 24 MFMAs: the
+    // loop was bound by vector issue, PMC: 3.6 VALU per MFMA).  u >> 4 blocks of 2048 B + (u & 15) slots of 16 B == 1792 (u >> 4) + 16 u.
     const int dW = a.dh * a.W, dS = a.dw;
     int a_ad[MI];
     auto set_addr = [&](int tap, int slot_base) {   // tap: compile-time after unrolling
       const int u = lrow + (tap / 3) * dW + (tap % 3) * dS;
-      const int a0 = slot_base + a_lane + (u >> 4) * 2048 + (u & 15) * 16;
-      const int zad = z_lane + (u & 15) * 16;
+      const int a0 = (u >> 4) * 1792 + (u << 4) + (slot_base + a_lane);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a_ad[mi] = (fr_mask[mi] & (1u << tap)) ? a0 + mi * 2048 : zad;
+      for (int mi = 0; mi < MI; ++mi) a_ad[mi] = a0 | (int)(((fr_mask[mi] >> tap) & 1u) << 18);
     };
     f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
     auto read_first = [&](int stage) {   // activation lo, weight hi
       const float* Bw = smem + stage_off(stage) / 4 + b_frag;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) fal[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi] + 1024);
+      for (int mi = 0; mi < MI; ++mi) fal[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi] + mi * 2048 + 1024);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) fbh[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + khi);
     };
     auto read_rest = [&](int stage) {    // activation hi, weight lo
       const float* Bw = smem + stage_off(stage) / 4 + b_frag;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) fah[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi]);
+      for (int mi = 0; mi < MI; ++mi) fah[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_ad[mi] + mi * 2048);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + klo);
     };
@@ -271,36 +278,51 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
         const bool moreP = tap + 2 < NTAPS || stream_on;
         // top of the slice, right behind the barrier: one piece of the NEXT channel slice's window (its slot was read last
         // in the previous channel slice), then the weights two slices ahead
+        // ORDER MATTERS: vmcnt counts in issue order, and the wait at this slice's end may leave in flight only what was issued
+        // AFTER the weights of the next slice.  The window piece is the long fetch (a first touch: HBM or the Infinity Cache;
+        // the weights come from L2) and is not needed before the next channel slice -- issued BEHIND the slice's weight pieces
+        // it may stay in flight across two slice ends instead of one (in-kernel stamps: with the window piece first the wave
+        // stood 1 000 - 1 300 cycles in that wait in six slices of nine).
         const bool win_now = tap < WPER && stream_win;
-        if (win_now) { if (last_c) issue_win(0, 0, wave + NW * tap, m0n - halo_lo); else issue_win(c + 1, c + 1, wave + NW * tap, p0); }
+        const bool win_prev = tap >= 1 && tap - 1 < WPER && stream_win;   // a window piece went out in the previous slice
+        WIN_SSTAMP(0);
         if (moreP) {
           const int wnext = last_c ? 0 : wbase + BK * 4;   // first channel slice of the next tile, or this tile's next one
           issue_b((tap + 2) % 3, tap + 2 < NTAPS ? (tap + 2) * a.Cw * 4 + wbase : (tap + 2 - NTAPS) * a.Cw * 4 + wnext);
         }
+        if (win_now) { if (last_c) issue_win(0, 0, wave + NW * tap, m0n - halo_lo); else issue_win(c + 1, c + 1, wave + NW * tap, p0); }
         DLIP_FENCE();
+        WIN_SSTAMP(1);
         read_rest(tap % 3); DLIP_FENCE();
         mfma_p(0); DLIP_FENCE();
+        WIN_SSTAMP(2);
         // next tap's fragment addresses: plain VALU in the shadow of the matrix instructions (and, once per tile, the next
         // tile's tap masks; the last slice's set_addr runs again at the next tile's start, with those masks)
         if (tap + 1 < NTAPS) set_addr(tap + 1, sb); else set_addr(0, sb_next);
         if (tap == 0 && last_c && has_next) tile_masks(m0n, next_mask);
         DLIP_FENCE();
         mfma_p(1); DLIP_FENCE();
+        WIN_SSTAMP(3);
         if (more1) {
           // Slice kt+1's weights must have landed; what was issued after them stays in flight: this slice's pieces and -- in
           // a later tile's very first slice -- the previous epilogue's NSTORE output stores, which sit between slice 1's
           // weights and this slice's pieces in the queue.  Every LDS read of this slice is complete (lgkmcnt) before the
           // barrier releases its stage; the last group's MFMAs then cover the next slice's first fragment reads.
-          if (!first && c == 0 && tap == 0) { if (win_now) wait_vmcnt<B_PER + 1 + NSTORE>(); else wait_vmcnt<B_PER + NSTORE>(); }
-          else if (moreP) { if (win_now) wait_vmcnt<B_PER + 1>(); else wait_vmcnt<B_PER>(); }
-          else            { if (win_now) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
+          // (younger than the next slice's weights: the previous slice's window piece, this slice's weights and window piece)
+          const int wn = (win_now ? 1 : 0) + (win_prev ? 1 : 0);
+          if (!first && c == 0 && tap == 0) { if (wn) wait_vmcnt<B_PER + 1 + NSTORE>(); else wait_vmcnt<B_PER + NSTORE>(); }
+          else if (moreP) { if (wn == 2) wait_vmcnt<B_PER + 2>(); else if (wn == 1) wait_vmcnt<B_PER + 1>(); else wait_vmcnt<B_PER>(); }
+          else            { if (wn == 2) wait_vmcnt<2>(); else if (wn == 1) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          WIN_SSTAMP(4);
           __builtin_amdgcn_s_barrier();
+          WIN_SSTAMP(5);
           read_first((tap + 1) % 3);
         }
         DLIP_FENCE();
         mfma_p(2);
         DLIP_FENCE();
+        WIN_SSTAMP(6);
       }
     }
 #undef DLIP_FENCE
@@ -405,7 +427,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
       WIN_STAMP(6);
       if (has_next) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fr_mask[mi] = next_mask[mi];
+        for (int mi = 0; mi < MI; ++mi) fr_mask[mi] = ~next_mask[mi];
         m0 = m0n;
       }
     }
@@ -456,8 +478,8 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
 #ifdef DLIP_LAB
   if (getenv("DLIP_STAMP_PRINT")) {   // median cycles between the phase stamps of every workgroup's second tile
     static unsigned long long* dbuf = nullptr;
-    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), 4096 * 8 * 8);
-    (void)hipMemsetAsync(dbuf, 0, 4096 * 8 * 8, st);
+    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), 2 * 4096 * 8 * 8);
+    (void)hipMemsetAsync(dbuf, 0, 2 * 4096 * 8 * 8, st);
     b.pool = reinterpret_cast<double*>(dbuf);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, st, b);
     (void)hipStreamSynchronize(st);
@@ -469,6 +491,12 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
     auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     fprintf(stderr, "[win stamps %dx%d M=%d nk=%d res=%d] head-wait %.0f  loop %.0f  issue-next+masks %.0f  residual-wait %.0f  epilogue-compute %.0f  stores %.0f\n",
             BM, BN, b.M, b.nk, b.res != nullptr, med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(d[4]), med(d[5]));
+    (void)hipMemcpy(h.data(), dbuf + 4096 * 8, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> e[6];
+    for (long long i = 0; i < grid; ++i)
+      if (h[i * 8 + 6]) for (int j = 0; j < 6; ++j) e[j].push_back((double)(h[i * 8 + j + 1] - h[i * 8 + j]));
+    fprintf(stderr, "[win slice (c 0, tap 4)] piece issue %.0f  rest reads + group 0 %.0f  addresses + group 1 %.0f  vmcnt + lgkmcnt %.0f  barrier %.0f  first reads + group 2 %.0f\n",
+            med(e[0]), med(e[1]), med(e[2]), med(e[3]), med(e[4]), med(e[5]));
     return dlip_launch_status();
   }
 #endif

@@ -16,7 +16,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "conv_igemm" not in k: continue
+        if "conv_" not in k: continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 for k, c in agg.items():
     nl = max(n[(k, x)] for x in c)
