@@ -68,8 +68,11 @@ struct StreamK {
 
 #ifdef DLIP_LAB
 #define DLIP_STAMP(i) do { if (threadIdx.x == 0 && it == it_begin && sk.stamps) sk.stamps[(size_t)g * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// inside ONE slice (the 9th of each workgroup's first segment): [(G + g) * 10 + i]
+#define DLIP_SSTAMP(i) do { if (threadIdx.x == 0 && it == it_begin && kt == 8 && sk.stamps) sk.stamps[((size_t)sk.G + g) * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DLIP_STAMP(i) do { } while (0)
+#define DLIP_SSTAMP(i) do { } while (0)
 #endif
 
 // EPI: what the epilogue does with act(acc / wscale + bias + residual) * post_scale + post_shift
@@ -247,6 +250,17 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       for (int j = 0; j < nj(); ++j)
         dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + (j % B_PER) * RPP * ROWB + (j < B_PER ? 0 : pdelta));
     };
+    auto issue_one = [&](int stage, int i) {   // piece i of this wave's NL of the slice the walk stands on: activations first
+      if (i < A_PER) {
+        const uint32_t base = piece0 + stage * STAGE_B;
+        const bool ok = (a_mask[i] >> tap) & 1u;
+        dma_piece(xr, ok ? (uint32_t)(a_off[i] + x_tap) : DLIP_OOB_OFFSET, base + i * RPP * ROWB);
+      } else {
+        const int j = i - A_PER;
+        const uint32_t base = piece0 + stage * STAGE_B + BM * ROWB;
+        dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+      }
+    };
     constexpr std::integral_constant<int, A_PER> own_a{};
     constexpr std::integral_constant<int, B_PER> own_b{};
     constexpr std::integral_constant<int, AQ> all_a{};
@@ -336,14 +350,40 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         // two-stage 128x64; the three-stage 128x64 of layer 1 is address-unit bound and 1 % slower: lab builds, round 2).
         constexpr bool early = (VAR & 4) != 0 || NW == 8 || (BM == 128 && BN == 128) || (BM == 128 && BN == 64 && NSTAGE == 2);
         const bool my_turn = !ALT || (kt & 1) == (wave >= NW / 2 ? 1 : 0);   // (wave-uniform)
+        DLIP_SSTAMP(0);
+        constexpr bool SPREAD = (VAR & 64) == 0 && NW == 8 && early && NL == 6 && MI == 4 && !ALT;   // the 256x128 tile (lab: VAR bit 6 switches it off)
+        bool spread = false;                       // (wave-uniform)
+        const int st_now = st_iss;
         if (early && moreP) {
           advance();
-          if (my_turn) { issue_a(st_iss, all_a); issue_b(st_iss, all_b); }
+          // a slice whose activation rows were fetched by an earlier tap of the same channel slice: every piece is an L2 hit
+          if constexpr (SPREAD) spread = tap != 0 && !(DUAL && c0 >= a.Cw);
+          if (spread) { if (!((VAR & 32) != 0 && wave >= NW / 2)) issue_one(st_now, 0); }
+          else if (my_turn) { issue_a(st_iss, all_a); issue_b(st_iss, all_b); }
           st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1;
         }
         DLIP_FENCE();
+        DLIP_SSTAMP(1);
         read_rest(st_cur); DLIP_FENCE();
+        if constexpr (SPREAD) {
+          // Twelve quarter-groups of NI MFMAs; a spread slice's six pieces go out one at a time behind quarters -1 (the
+          // advance above), 1, 3, 5, 7, 9 -- or, in the waves that share their SIMDs with those (VAR bit 5), behind quarters
+          // 0, 2, 4, 6, 8, 9: the two waves of a SIMD then never stand in the address unit's queue at the same time.
+          const bool odd = (VAR & 32) != 0 && wave >= NW / 2;   // (wave-uniform)
+          auto slot = [&](int q) {                               // q: compile-time
+            if (!spread) return;
+            if (q == 9) { issue_one(st_now, 5); return; }
+            if (!odd && (q & 1) && q > 0) issue_one(st_now, (q + 1) / 2);
+            if (odd && !(q & 1) && q >= 0) issue_one(st_now, q / 2);
+          };
+#pragma unroll
+          for (int q = 0; q < 10; ++q) {
+            mfma_p(q / 4 == 0 ? 0 : q / 4 == 1 ? 1 : 2, q % 4, q % 4 + 1); DLIP_FENCE();
+            slot(q); DLIP_FENCE();
+          }
+        } else {
         mfma_p(0, 0, MI); DLIP_FENCE();
+        DLIP_SSTAMP(2);
         if (moreP && !late && !early) { advance(); issue_a(st_iss, own_a); } DLIP_FENCE();
         mfma_p(1, 0, MH); DLIP_FENCE();
         if (moreP && !late && !early) { issue_b(st_iss, own_b); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
@@ -353,6 +393,8 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         // (the barrier one half-group earlier, behind group 1 -- what the window kernel does -- measured 1-7 % SLOWER here)
         mfma_p(2, 0, MH); DLIP_FENCE();
         if (moreP && late) { issue_b(st_iss, own_b); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
+        }
+        DLIP_SSTAMP(3);
         if (more1) {
           // slice kt+1 must have landed (every wave's share: wait, then barrier); slices beyond it stay in flight
           if constexpr (ALT) {   // the issuer of this slice keeps its 2 NL newest pieces (slice kt + 2) in flight; its partner has none younger than kt + 1's
@@ -360,12 +402,15 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
           } else {
             if (PF > 1 && (kt + 2) < kn) wait_vmcnt<NL>(); else wait_vmcnt<0>();
           }
+          DLIP_SSTAMP(4);
           __builtin_amdgcn_s_barrier();
+          DLIP_SSTAMP(5);
           read_first(st_nxt);
         }
         DLIP_FENCE();
-        if (MH < MI) mfma_p(2, MH, MI);
+        if (MH < MI) mfma_p(2, MH, MI);   // (quarters 10, 11 of a SPREAD build)
         DLIP_FENCE();
+        DLIP_SSTAMP(6);
         st_cur = st_nxt;
       }
       if (VAR & 1) __builtin_amdgcn_s_setprio(0);
@@ -628,12 +673,12 @@ template <typename K>
 int dlip_lab_stamped_launch(K kern, unsigned G, int threads, size_t lds, hipStream_t st, const ConvArgs& b, StreamK sk, int BM, int BN) {
   static unsigned long long* dbuf = nullptr;
   static size_t cap = 0;
-  if (cap < (size_t)G * 10) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc(reinterpret_cast<void**>(&dbuf), (size_t)G * 10 * 8); cap = (size_t)G * 10; }
-  (void)hipMemsetAsync(dbuf, 0, (size_t)G * 10 * 8, st);
+  if (cap < (size_t)G * 20) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc(reinterpret_cast<void**>(&dbuf), (size_t)G * 20 * 8); cap = (size_t)G * 20; }
+  (void)hipMemsetAsync(dbuf, 0, (size_t)G * 20 * 8, st);
   sk.stamps = dbuf;
   hipLaunchKernelGGL(kern, dim3(G), dim3(threads), lds, st, b, sk);
   (void)hipStreamSynchronize(st);
-  std::vector<unsigned long long> h((size_t)G * 10);
+  std::vector<unsigned long long> h((size_t)G * 20);
   (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
   std::vector<double> d[5], per, clk, dur;
   unsigned long long t0 = ~0ull, t1 = 0, s1 = 0;
@@ -656,6 +701,13 @@ int dlip_lab_stamped_launch(K kern, unsigned G, int threads, size_t lds, hipStre
             (double)(t1 - t0) / 100.0, (double)(s1 - t0) / 100.0, dur.front(), dur[dur.size() / 2], dur.back());
   fprintf(stderr, "[stamps %dx%d M=%d K=%d nk=%d G=%u] setup %.0f  issue+init %.0f  first-wait %.0f  loop %.0f (%.0f/slice)  tail %.0f  clock %.0f MHz\n",
           BM, BN, b.M, b.K, b.nk, G, med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(per), med(d[4]), med(clk));
+  std::vector<double> e[6];
+  for (unsigned i = 0; i < G; ++i) {
+    const unsigned long long* r = &h[((size_t)G + i) * 10];
+    if (r[6] && r[0]) for (int j = 0; j < 6; ++j) e[j].push_back((double)(r[j + 1] - r[j]));
+  }
+  fprintf(stderr, "[slice 8 of the first segment, wave 0] piece issue %.0f  rest reads + group 0 %.0f  group 1 + half of 2 %.0f  vmcnt wait %.0f  barrier %.0f  first reads + rest of group 2 %.0f\n",
+          med(e[0]), med(e[1]), med(e[2]), med(e[3]), med(e[4]), med(e[5]));
   return dlip_launch_status();
 }
 #endif
@@ -833,7 +885,7 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 // (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
 #ifdef DLIP_LAB
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {256, 128}, {128, 256}, {128, 64}, {64, 128}};   // 6: tile 5 with VAR 8 (alternating issuer halves); 7: 128x256; 8, 9: tiles 4, 2 with VAR 4
+                           {256, 128}, {256, 128}, {128, 64}, {64, 128}};   // 6, 7: tile 5 with VAR 64 / 32 (no spreading of the pieces; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
 constexpr int NUM_DMA_ALL = 10;
 #else
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
@@ -882,8 +934,8 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 3: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, epi);
     case 4: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, epi);
 #ifdef DLIP_LAB
-    case 6: return launch_dma<256, 128, 4, 2, 3, 1, 8>(a, st, epi);
-    case 7: return launch_dma<128, 256, 2, 4, 2, 1, 4>(a, st, epi);
+    case 6: return launch_dma<256, 128, 4, 2, 3, 1, 64>(a, st, epi);
+    case 7: return launch_dma<256, 128, 4, 2, 3, 1, 32>(a, st, epi);
     case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
     case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);
 #endif
