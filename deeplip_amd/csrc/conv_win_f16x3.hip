@@ -447,7 +447,7 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
   constexpr int WBLK = (WBLK0 + NW / 2 - 1) / (NW / 2) * (NW / 2);
   constexpr size_t slot_b = (size_t)WBLK * 2048, bst = (size_t)BN * ROWB, img = (size_t)BM * BN * 4;
   constexpr size_t head = img > slot_b + bst ? img : slot_b + bst;
-  constexpr size_t lds = head + 2 * bst + 2048 + slot_b + 5 * BN * sizeof(float);
+  constexpr size_t lds = head + 2 * bst + slot_b + 5 * BN * sizeof(float);
   if (b.tiles_n != 1) return DLIP_EINVAL;   // one column block (K <= BN): the kernel's tile index is the row block
   static_assert(lds <= 160 * 1024, "LDS exceeds a CU");
   auto kern = out_split ? conv_win_f16x3_kernel<BM, BN, WAVES_M, WAVES_N, true, OCC> : conv_win_f16x3_kernel<BM, BN, WAVES_M, WAVES_N, false, OCC>;
@@ -538,5 +538,7 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_win_launch(
   // 64 < K <= 128 (layer 2, 128 -> 128 channels on 11x11 maps): eight waves on a 128x128 tile, one workgroup per CU (the
   // fp32 epilogue image alone is 64 KB): 178 us vs 200-210 on the 256x128 ring kernel without a residual, 211-223 vs 241-275 with.
   if (a.K > 64) return launch_win<128, 128, 4, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
+  // (256x64 with eight waves in ONE workgroup per CU -- the weights fetched once per 256 rows instead of per 128 -- measured
+  // 9-20 % slower than the two independent 128x64 workgroups: 239-249 vs 219-225 us, with a residual 348-357 vs 292-297)
   return launch_win<128, 64, 2, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
 }
