@@ -574,7 +574,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         constexpr bool early = (VAR & 4) != 0 || NW == 8 || (BM == 128 && BN == 128) || (BM == 128 && BN == 64 && NSTAGE == 2);
         const bool my_turn = !ALT || (kt & 1) == (wave >= NW / 2 ? 1 : 0);   // (wave-uniform)
         DLIP_SSTAMP(0);
-        constexpr bool SPREAD = (VAR & 64) == 0 && NW == 8 && early && NL == 6 && MI == 4 && !ALT;   // the 256x128 tile (lab: VAR bit 6 switches it off)
+        constexpr bool SPREAD = (VAR & 16) != 0 && NW == 8 && early && NL == 6 && MI == 4 && !ALT;   // (lab: the 256x128 tile)
         bool spread = false;                       // (wave-uniform)
         const int st_now = st_iss;
         if (early && moreP) {
@@ -1116,7 +1116,7 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 // (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
 #ifdef DLIP_LAB
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {256, 128}, {256, 128}, {128, 64}, {64, 128}};   // 6, 7: tile 5 with VAR 64 / 32 (no spreading of the pieces; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
+                           {256, 128}, {256, 128}, {128, 64}, {64, 128}};   // 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
 constexpr int NUM_DMA_ALL = 10;
 #else
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
@@ -1180,8 +1180,8 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 3: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, epi);
     case 4: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, epi);
 #ifdef DLIP_LAB
-    case 6: return launch_dma<256, 128, 4, 2, 3, 1, 64>(a, st, epi);
-    case 7: return launch_dma<256, 128, 4, 2, 3, 1, 32>(a, st, epi);
+    case 6: return launch_dma<256, 128, 4, 2, 3, 1, 16>(a, st, epi);
+    case 7: return launch_dma<256, 128, 4, 2, 3, 1, 48>(a, st, epi);
     case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
     case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);
 #endif
