@@ -369,6 +369,10 @@ def main():
     ap.add_argument("--eager", action="store_true",
                     help="issue every launch of every step from Python (round-1 behaviour) instead of replaying a recorded "
                          "step plan (dlip_plan_run); for A/B runs on one box")
+    ap.add_argument("--dbg", action="append", default=[], metavar="KEY=VALUE",
+                    help="development: dlip_debug_set(KEY, VALUE) before anything is launched (tile / split / window / tile-order "
+                         "choices of the convolution kernels, include/deeplip_hip.h); for whole-step A/B runs on one box -- the line "
+                         "then carries `debug`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -389,6 +393,10 @@ def main():
     from deeplip_amd.plan import StepPlan
     global SINGLE_STREAM
     SINGLE_STREAM = args.single_stream
+    for kv in args.dbg:
+        from deeplip_amd import _lib as _dl
+        key, val = kv.split("=")
+        _dl.debug_set(int(key), int(val))
     if args.audio_stream:
         global AUDIO_STREAM
         AUDIO_STREAM = torch.cuda.Stream(device=device)
@@ -553,6 +561,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_fields["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": main_fields["dtype"], "data": "synthetic",
+            **({"debug": args.dbg} if args.dbg else {}),
             "config": {"workload": f"fused A+V embed: video [{B},1,29,88,88] 3D-stem+ResNet-18 + audio [{B},1,{args.audio_dim},300] "
                                    f"E-TDNN -> z-norm concat [{B},1024] per rank per step (BASELINE configs[1] clip batch)",
                        "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random-init (name-keyed, seed 1)",
