@@ -567,11 +567,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       for (int kt = 0; kt < kn; ++kt) {
         const bool more1 = (kt + 1) < kn, moreP = (kt + PF) < kn;
         const int st_nxt = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
-        // The slice's LDS-DMA pieces go out at the very top of the slice, right behind the barrier that frees their
-        // stage: they need all the lead the ring gives them (issued half a slice LATER a layer takes 15 % longer; at
-        // the top 3-4 % less than from the MFMA shadow of groups 0 / 1 on 256x128, 2-3 % on 128x128 and on the
-        // two-stage 128x64; the three-stage 128x64 of layer 1 is address-unit bound and 1 % slower: lab builds, round 2).
-        constexpr bool early = (VAR & 4) != 0 || NW == 8 || (BM == 128 && BN == 128) || (BM == 128 && BN == 64 && NSTAGE == 2);
+        // WHERE the slice's LDS-DMA pieces go out.  At the very top of the slice, right behind the barrier that frees their stage
+        // (`early`), a layer that runs back to back takes 3-4 % less time on 256x128 and 2-3 % less on 128x128 and the two-stage
+        // 128x64 than with the pieces in the MFMA shadow of groups 0 / 1 (tools/bench_dma.py; issued half a slice LATER: +15 %).
+        // On the STEP, at the board's power limit, the 256x128 tile is the other way round (tools/ab_step.sh, three rounds, same
+        // box): shadow issue 15 225 vs 15 033 clips/s, this kernel 339 vs 326 TFLOP/s -- the burst leaves the matrix core idle and
+        // then runs it flat out, the interleaved issue draws less power for the same work.  128x128 keeps the early issue (-6.5 %
+        // in the step without it); the three-stage 128x64 never had it.
+        constexpr bool early = (VAR & 4) != 0 || (BM == 128 && BN == 128) || (BM == 128 && BN == 64 && NSTAGE == 2);
         const bool my_turn = !ALT || (kt & 1) == (wave >= NW / 2 ? 1 : 0);   // (wave-uniform)
         DLIP_SSTAMP(0);
         constexpr bool SPREAD = (VAR & 16) != 0 && NW == 8 && early && NL == 6 && MI == 4 && !ALT;   // (lab: the 256x128 tile)
