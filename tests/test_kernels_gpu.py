@@ -486,14 +486,15 @@ def test_maxpool_split_output(ops):
 
 
 @pytest.mark.parametrize("B,T,H,W", [(2, 7, 88, 88), (1, 3, 24, 24), (1, 2, 40, 56), (3, 1, 72, 88), (300, 1, 16, 16),
-                                     (1, 6, 42, 52), (2, 2, 20, 30), (1, 1, 88, 60)])
+                                     (1, 6, 42, 52), (2, 2, 20, 30), (1, 1, 88, 60), (10, 29, 88, 88)])
 @pytest.mark.parametrize("neg_slopes", [False, True], ids=["slopes>=0", "some-slopes<0"])
 def test_stem3d_pool_f16x3(ops, B, T, H, W, neg_slopes):
     """Stem + MaxPool fused: the same bits as the split-fp16 stem kernel followed by the pooling kernel
     (same MFMA order, max is exact), in the split activation format; ragged last row tiles, widths that are
     not multiples of 8, frames walked by more and by fewer workgroups than there are CUs.  With every PReLU
     slope >= 0 the kernel applies affine + activation AFTER the pooling (they commute with max bit for bit);
-    a negative slope makes it activate first."""
+    a negative slope makes it activate first.  The last shape has more frames (290) than the chip has workgroup slots: some
+    workgroups walk two frames of six row tiles each (carried rows, flags and window refills across a frame boundary)."""
     from deeplip_amd import packing
     x = (rnd(B, T, H, W, seed=51) * 2.0).cuda()
     w = rnd(64, 1, 5, 7, 7, seed=52, scale=1.0 / np.sqrt(245))
