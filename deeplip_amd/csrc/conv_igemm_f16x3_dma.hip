@@ -103,9 +103,13 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   // "valid" convolutions and the balanced split, but 11 % SLOWER than the ring as it stands: 3 570 against 2 720 cycles per
   // slice on layer 3.  The per-slice bookkeeping of a ROLLED tap loop -- position walk, piece schedule, a counted wait whose
   // count varies -- is ~50 scalar branches and ~35 vector instructions per slice, the lesson conv_win_f16x3.hip learned at
-  // 1 720 -> 650 cycles per slice by unrolling its nine taps; the version of this mode that would win is that kernel's loop
-  // with this kernel's split and epilogues, next round's work): for stride-1 convolutions whose taps share rows the
-  // activations do not go through the ring.  Per 32-channel slice the workgroup holds ONE window -- the BM + halo consecutive
+  // 1 720 -> 650 cycles per slice by unrolling its nine taps.  Tried next: the taps unrolled here too (3x3 and 1x3 instances,
+  // static ring stages, piece schedule and wait counts; the per-tap addresses kept from being hoisted into 570 B of scratch by
+  // opaque asm) -- still bit-identical and still 13-15 % behind the ring, 2 710 against 2 540 cycles per slice, and 27 % behind
+  // with the barrier behind group 1 as in conv_win.  So neither the bytes nor the bookkeeping is what a 256x128 slice costs:
+  // two lock-stepped waves per SIMD pay ~1 000 cycles of issue + wait + barrier per slice around 1 536 of MFMA whichever way the
+  // operands arrive; conv_win's advantage is its TWO INDEPENDENT workgroups per CU): for stride-1 convolutions whose taps
+  // share rows the activations do not go through the ring.  Per 32-channel slice the workgroup holds ONE window -- the BM + halo consecutive
   // input pixels its tile touches, one 128-B row each -- every tap reads its fragments there at a row offset, a tap outside the
   // image reads beyond the LDS allocation (zeros on gfx950: tools/probes/lds_oob.hip), and only the weights are fetched per
   // slice: 20 KB per 256-row slice instead of 48 -- the L2 -> LDS path, not the matrix core, is what bounds the ring
