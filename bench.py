@@ -5,6 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 outside a torch.distributed job starts that job itself (deeplip_amd/launch.py: a child
+`python -m torch.distributed.run ... bench.py <same arguments>`, started before anything touches the GPU), relays rank 0's
+JSON line and exits with the job's return code -- one command starts every GPU, as the reference's `python train_fusion.py`
+does (train_fusion.py:88-93).  `--dry-launch` rehearses exactly that launch on CPU ranks (gloo, a stand-in step): it tests
+the launcher, the rendezvous, the exchange and the one-line contract where no second GPU exists, and measures nothing.
+
 One "step" = one pass of the hot path over one batch of synthetic A+V pairs PER RANK
 (BASELINE.json configs[1] clip batch, one utterance per clip -- SURVEY.md section 8d C2/C3/C4):
     video  [B,1,29,88,88] -> Lipreading(extract_feats) -> temporal mean -> [B,512]
@@ -36,6 +42,18 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+from deeplip_amd import launch as _launch
+
+if __name__ == "__main__" and not _launch.in_job():
+    # N > 1 asked of a plain process: become the launcher NOW -- before torch is imported, long before any torch.cuda call
+    def _relay(line):       # stdout carries rank 0's JSON line and nothing else; library chatter of the ranks goes to stderr
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
+    _n = _launch.argv_gpus(sys.argv[1:])
+    if _n > 1:
+        sys.exit(_launch.self_launch(os.path.abspath(__file__), sys.argv[1:], _n, relay=_relay))
 
 import numpy as np
 import torch
@@ -348,6 +366,55 @@ def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan):
     return out
 
 
+def dry_launch(args, world, rank):
+    """Rehearsal of the N-rank launch where there is no second GPU: CPU ranks, backend gloo, a stand-in for the per-rank step
+    (a [B,1024] row block filled with the rank id), then the REAL protocol of a scaling run -- exchange() after every step,
+    barrier-bracketed wall time, MAX over ranks, per-rank self-check records, ONE JSON line from rank 0.  It measures nothing
+    (value is null) and touches no kernel: what it proves is that `python bench.py --gpus N` starts N ranks that find each
+    other and that a failing rank fails the command."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    if rank == args.dry_fail_rank:
+        sys.exit(3)
+    B = args.batch
+    rows = torch.full((B, 1024), float(rank))
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        exchange(rows, world)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allrows = exchange(rows, world)
+    sync_all()
+    my_elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([my_elapsed], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ok = all(float(allrows[r * B, 0]) == float(r) for r in range(world))      # every rank's block arrived in rank order
+    mine = {"rank": rank, "backend": "gloo", "world_size": dist.get_world_size() if world > 1 else 1, "pid": os.getpid(),
+            "launched_by": os.environ.get("DLIP_LAUNCHED_BY"), "exchange_ok": bool(ok)}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+    if rank == 0:
+        print(json.dumps({"metric": "lip-clips/sec (fused A+V embed)", "value": None, "unit": "lip-clips/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * float(tmax.item()) / max(1, args.steps), 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
+                          "dry_launch": True, "config": {"workload": "launcher rehearsal: CPU ranks over gloo, stand-in step, "
+                                                                      "real exchange protocol; not a measurement"},
+                          "ranks": ranks}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,14 +440,21 @@ def main():
                     help="development: dlip_debug_set(KEY, VALUE) before anything is launched (tile / split / window / tile-order "
                          "choices of the convolution kernels, include/deeplip_hip.h); for whole-step A/B runs on one box -- the line "
                          "then carries `debug`")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher rehearsal on CPU ranks (gloo): stand-in step + the real exchange, one JSON line, no measurement")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help="with --dry-launch: this rank exits 3 (tests return-code propagation)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        # inside a job the launcher's world size is the truth; outside one, N > 1 was already turned into a job at import
+        # time (top of this file) -- reaching this line with a mismatch means an inconsistent hand-made launch
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (self-launching) "
+                 "or torch.distributed.run --nproc-per-node N")
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -455,6 +529,7 @@ def main():
             elapsed = float(tmax.item())
             value = world * B * args.steps / elapsed
             ranks = None
+            n1_alone = None
             if world > 1:
                 # self-check of a scaling run: what every rank saw (RCCL's own world size, its wall time over the same K
                 # steps, the all-gather of [B,1024] rows timed on its own)
@@ -465,6 +540,18 @@ def main():
                         "allgather_us": round(1e3 * ag_ms, 1)}
                 ranks = [None] * world
                 dist.all_gather_object(ranks, mine)
+                # the N = 1 figure of THIS job: rank 0 replays the same K steps alone (no exchange) while the others wait
+                # at the barrier -- lets a scaling run be checked against the single-GPU bench line it sits next to
+                n1 = None
+                if rank == 0:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        plan.run() if plan is not None else step(video, audio, xv, xa, 1)
+                    torch.cuda.synchronize()
+                    n1 = round(B * args.steps / (time.perf_counter() - t1), 2)
+                sync_all()
+                n1_alone = n1
             # roofline of the mode: exact fp32 MFMA peak, or the f16 dense peak / 3 (three f16 MFMAs
             # per fp32-grade product: the ceiling of the split algorithm in ALGORITHMIC FLOP/s)
             peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
@@ -529,7 +616,7 @@ def main():
             pass
         fields = {"value": round(value, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                   "dtype": DTYPE_NAME[precision], "dtype_note": DTYPE_NOTE[precision], "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 4),
-                  "roofline": roof, "ranks": ranks, "peak": peak}
+                  "roofline": roof, "ranks": ranks, "n1_alone": n1_alone, "peak": peak}
         return fields, video, audio, sds
 
     def parity(precision, video, audio, ref, cxv, cxa):
@@ -571,6 +658,7 @@ def main():
         }
         if main_fields["ranks"] is not None:
             res["ranks"] = main_fields["ranks"]
+            res["n1_value_rank0_alone"] = main_fields["n1_alone"]
         c4_private = None
         if configs is not None:
             c4 = configs.get("C4_fusion_scoring", {})
@@ -603,4 +691,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

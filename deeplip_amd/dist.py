@@ -80,10 +80,14 @@ def init_from_env(device: Optional[torch.device] = None) -> Tuple[int, int]:
 
 
 def broadcast_params(params, src: int = 0) -> None:
-    """Replicas start identical (what nn.DataParallel's per-step broadcast guarantees: train_audio.py:83)."""
+    """Replicas start identical (what nn.DataParallel's per-step broadcast guarantees: train_audio.py:83).  The write goes
+    through ``p.data`` (no version-counter bump), so the packed-weight cache and any recorded step plan are invalidated
+    explicitly: a forward run before the broadcast must not leave stale packs on the non-source ranks."""
     if world()[1] > 1:
         for p in params:
             dist.broadcast(p.data, src)
+        from . import holders
+        holders.invalidate_packs()
 
 
 def allreduce_grads(params, world_size: Optional[int] = None) -> int:
@@ -164,6 +168,17 @@ class GradBuckets:
         self._pending = list(self._count)
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._next = 0             # buckets [0, _next) have been launched: launches go out in INDEX ORDER only
+
+    def _launch_upto(self):
+        """Launch, in bucket-index order, every bucket that is complete and whose predecessors have all been launched.
+        Collectives are matched across ranks by issue order, not by tensor: if one rank's backward completes buckets in a
+        different order, or never completes one (a parameter its batch did not reach), launching "whatever is ready" would
+        pair different buckets -- different sizes -- on different ranks and hang or mis-reduce on RCCL.  So a complete bucket
+        waits for every lower-numbered one (DDP's rule), and finish() flushes the remainder in the same order."""
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, bi: int):
         if self._launched[bi]:
@@ -175,8 +190,11 @@ class GradBuckets:
     def _hook(self, p):
         bi = self._slot[id(p)]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        if self._pending[bi] < 0:
+            raise RuntimeError("GradBuckets: a parameter received a second gradient before finish() -- a second backward() "
+                               "(gradient accumulation) would add into a bucket whose all-reduce may already be in flight; "
+                               "call finish() after every backward()")
+        self._launch_upto()
 
     def zero(self):
         for b in self.buckets:
@@ -190,7 +208,7 @@ class GradBuckets:
             if p.grad is None or not (b.data_ptr() <= p.grad.data_ptr() < b.data_ptr() + b.numel() * b.element_size()):
                 raise RuntimeError("GradBuckets: a parameter's .grad no longer lives in its bucket; clear gradients with "
                                    "optimizer.zero_grad(set_to_none=False) or GradBuckets.zero()")
-        for bi in range(len(self.buckets)):
+        for bi in range(self._next, len(self.buckets)):       # the rest, still in index order on every rank
             self._launch(bi)
         for w in self._works:
             w.wait()

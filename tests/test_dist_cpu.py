@@ -179,3 +179,73 @@ def test_bench_exchange_and_metric_reduction_world2():
     for rank, full, stats in res:
         assert full.shape == (8, 8) and np.array_equal(full, want)
         assert stats == [7.5, 8.0]
+
+
+def _branchy_bucket_worker(rank, world, port, q):
+    """One rank's graph skips a parameter that sits in a MIDDLE bucket (a length-dependent branch): its bucket never
+    completes there during backward.  Launches must still pair up across ranks (index order), not "whatever is ready"."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        a, mid, b = torch.nn.Linear(6, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 3)
+        params = list(a.parameters()) + list(mid.parameters()) + list(b.parameters())
+        buckets = ddist.GradBuckets(params, bucket_bytes=300)        # b | mid.bias | mid.weight | a ...: different sizes
+        sizes = [int(t.numel()) for t in buckets.buckets]
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(8, 6, generator=g); y = torch.randn(8, 3, generator=g)
+        lo, hi = ddist.shard_range(8)
+        order = []
+        real_launch = buckets._launch
+        buckets._launch = lambda bi: (order.append(bi), real_launch(bi))[1]
+        buckets.zero()
+        h = torch.tanh(a(x[lo:hi]))
+        if rank == 0:
+            h = h + torch.tanh(mid(h))                               # rank 1 never touches `mid`
+        ((b(h) - y[lo:hi]) ** 2).mean().backward()
+        buckets.finish()
+        q.put((rank, sizes, order, [p.grad.clone().numpy() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_buckets_launch_in_index_order_when_a_rank_skips_a_middle_bucket():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_branchy_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    torch.manual_seed(0)
+    a, mid, b = torch.nn.Linear(6, 16), torch.nn.Linear(16, 16), torch.nn.Linear(16, 3)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, generator=g); y = torch.randn(8, 3, generator=g)
+    params = list(a.parameters()) + list(mid.parameters()) + list(b.parameters())
+    # reference: mean over ranks of the per-rank gradients (rank 1's graph has no `mid`)
+    per_rank = []
+    for rank, (lo, hi) in enumerate(((0, 4), (4, 8))):
+        for p in params:
+            p.grad = None
+        h = torch.tanh(a(x[lo:hi]))
+        if rank == 0:
+            h = h + torch.tanh(mid(h))
+        ((b(h) - y[lo:hi]) ** 2).mean().backward()
+        per_rank.append([torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in params])
+    ref = [(u + v).numpy() / 2 for u, v in zip(*per_rank)]
+    sizes = res[0][1]
+    assert len(sizes) >= 3 and len(set(sizes)) > 1                  # distinct sizes: a mis-paired launch could not pass
+    for rank, _, order, grads in res:
+        assert order == list(range(len(sizes))), (rank, order)     # every rank: the same, index, order
+        for got, want in zip(grads, ref):
+            assert np.allclose(got, want, atol=1e-6)
+
+
+def test_grad_buckets_second_backward_before_finish_raises():
+    p = torch.nn.Parameter(torch.ones(4))
+    b = ddist.GradBuckets([p])
+    (p * 2).sum().backward()
+    with pytest.raises(RuntimeError, match="second gradient"):
+        (p * 3).sum().backward()
+    b.finish()                                                      # single process: nothing in flight, state resets
+    (p * 2).sum().backward()

@@ -200,12 +200,36 @@ class Trainer(object):
         return scoring.eer_from_scores(y, scoring.cosine_scores(self.table.emb, ia, ib).cpu().numpy())
 
 
+def _self_launch(gpus, config, overrides, key="train.gpus_id"):
+    """Outside a torch.distributed job and asked for N > 1 GPUs (--gpus, or the config's gpus_id list): start the N-rank job
+    of this same command and return its exit code (deeplip_amd/launch.py); runs before anything touches the GPU."""
+    from deeplip_amd import launch
+    if launch.in_job():
+        return None
+    if gpus is None:
+        with open(os.path.join(ROOT, config) if not os.path.isabs(config) else config) as f:
+            d = yaml.safe_load(f)
+        ids = overrides.get(key)
+        if ids is None:
+            for part in key.split("."):
+                d = d.get(part, {}) if isinstance(d, dict) else {}
+            ids = d
+        gpus = len(ids) if isinstance(ids, (list, tuple)) else 1
+    return launch.maybe_self_launch(os.path.abspath(__file__), sys.argv[1:], gpus)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="test", choices=["train", "test"])    # reference: hard-coded at :485
     ap.add_argument("--config", default="conf/audio_config.yaml")
     ap.add_argument("--set", nargs="*", default=[])
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node, one process each (default: len(train.gpus_id), as the reference sizes nn.DataParallel: "
+                         "train_audio.py:80-83)")
     a = ap.parse_args()
+    rc = _self_launch(a.gpus, a.config, {k: yaml.safe_load(v) for k, v in (kv.split("=", 1) for kv in a.set)})
+    if rc is not None:
+        sys.exit(rc)
     tr = Trainer(a.config, {k: yaml.safe_load(v) for k, v in (kv.split("=", 1) for kv in a.set)})
     if a.mode == "train":
         tr._train()

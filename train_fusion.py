@@ -15,6 +15,8 @@ three structural changes:
     all-gather of test embeddings), replacing nn.DataParallel (:91-93).
 
     python train_fusion.py --mode train            # single GPU
+    python train_fusion.py --mode train --gpus 8   # starts its own 8-rank job (deeplip_amd/launch.py); so does a config
+                                                   # whose train.gpus_id lists 8 devices, as in the reference
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_fusion.py --mode train
     python train_fusion.py --mode av_test | av_fusion
 """
@@ -286,16 +288,41 @@ class Trainer(object):
         return scoring.eer_from_scores(y, s.cpu().numpy())
 
 
+def _self_launch(gpus, config, overrides, key):
+    """One command starts every GPU (the reference: gpus_id -> nn.DataParallel).  Outside a torch.distributed job and asked
+    for N > 1 GPUs -- by --gpus or by the length of the config's gpus_id list -- this process becomes the launcher of an
+    N-rank job of the same command (deeplip_amd/launch.py) and returns its exit code; nothing has touched the GPU yet."""
+    from deeplip_amd import launch
+    if launch.in_job():
+        return None
+    if gpus is None:
+        with open(os.path.join(ROOT, config) if not os.path.isabs(config) else config) as f:
+            d = yaml.safe_load(f)
+        ids = overrides.get(key)
+        if ids is None:
+            for part in key.split("."):
+                d = d.get(part, {}) if isinstance(d, dict) else {}
+            ids = d
+        gpus = len(ids) if isinstance(ids, (list, tuple)) else 1
+    return launch.maybe_self_launch(os.path.abspath(__file__), sys.argv[1:], gpus)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="av_test", choices=["train", "av_test", "av_fusion"])   # reference: hard-coded at :424
     ap.add_argument("--config", default="conf/fusion_config.yaml")
     ap.add_argument("--set", nargs="*", default=[], help="overrides, e.g. train.bs=8 data.trials=2000")
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node to use, one process each (default: len(train.gpus_id) of the config, as the "
+                         "reference sizes nn.DataParallel: train_fusion.py:88-93)")
     args = ap.parse_args()
     ov = {}
     for kv in args.set:
         k, v = kv.split("=", 1)
         ov[k] = yaml.safe_load(v)
+    rc = _self_launch(args.gpus, args.config, ov, "train.gpus_id")
+    if rc is not None:
+        sys.exit(rc)
     trainer = Trainer(args.mode, args.config, ov)
     rank0 = trainer.rank == 0
     if args.mode == "train":

@@ -64,6 +64,8 @@ def load_args(argv=None):
     p.add_argument("--save-path", type=str, default="exp/video/epoch")
     # build-owned
     p.add_argument("--device", default="gpu", choices=["gpu", "cpu"])
+    p.add_argument("--gpus", type=int, default=1, help="GPUs of this node, one process each over RCCL (the reference: "
+                   "nn.DataParallel over every visible GPU, train_video.py:206-207); N > 1 starts its own N-rank job")
     p.add_argument("--steps", type=int, default=2, help="synthetic iterations per epoch")
     p.add_argument("--frames", type=int, default=29)
     p.add_argument("--rgb", action="store_true", help="feed uint8 RGB [B,T,3,88,88] through the ingest kernel")
@@ -171,6 +173,11 @@ def train(model, args, device):
 
 def main(argv=None):
     args = load_args(argv)
+    if args.device == "gpu" and args.gpus > 1:
+        from deeplip_amd import launch
+        rc = launch.maybe_self_launch(os.path.abspath(__file__), list(sys.argv[1:] if argv is None else argv), args.gpus)
+        if rc is not None:      # this process was the launcher of the N-rank job; nothing here touched the GPU
+            sys.exit(rc)
     # the reference seeds once (train_video.py:70-73); under DP every rank needs its own dropout masks
     torch.manual_seed(SEED + int(os.environ.get("RANK", "0"))); np.random.seed(SEED)
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))) if args.device == "gpu" else torch.device("cpu")
