@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lock = threading.Lock()
 _lib = None
@@ -77,7 +77,9 @@ SIGNATURES = {
     "dlip_stem3d_bn_act_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem3d_bn_act_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem3d_pool_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_stem3d_pool_u8_f16x3": [c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem3d_pool_workspace_bytes": [c_i32, c_i32, c_i32, c_i32],
+    "dlip_selftest_lds_oob": [c_f, c_i32, c_stream],
     "dlip_maxpool3x3s2_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_avgpool_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_time_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],

@@ -30,3 +30,21 @@ extern "C" int dlip_set_status_words(int32_t* words) {
   g_status_words = words;
   return DLIP_OK;
 }
+
+// ---- device identity (cached per device) ----
+extern "C" int dlip_device_is_gfx950(void) {
+  static std::mutex mu;
+  static signed char known[DLIP_MAX_DEVICES] = {};   // 0 unknown, 1 yes, -1 no
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DLIP_MAX_DEVICES) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (known[dev] == 0) {
+    hipDeviceProp_t prop;
+    known[dev] = -1;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      const char* n = prop.gcnArchName;     // "gfx950:sramecc+:xnack-"
+      if (n[0] == 'g' && n[1] == 'f' && n[2] == 'x' && n[3] == '9' && n[4] == '5' && n[5] == '0' && (n[6] == 0 || n[6] == ':')) known[dev] = 1;
+    }
+  }
+  return known[dev] > 0;
+}

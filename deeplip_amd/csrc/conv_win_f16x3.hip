@@ -451,30 +451,19 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
   if (b.tiles_n != 1) return DLIP_EINVAL;   // one column block (K <= BN): the kernel's tile index is the row block
   static_assert(lds <= 160 * 1024, "LDS exceeds a CU");
   auto kern = out_split ? conv_win_f16x3_kernel<BM, BN, WAVES_M, WAVES_N, true, OCC> : conv_win_f16x3_kernel<BM, BN, WAVES_M, WAVES_N, false, OCC>;
-  static std::mutex mu;
-  static bool attr_set[2] = {false, false};
+  static DlipKernelState state[2];      // per instance (plain | split output); per-device inside
+  DlipKernelState& ks = state[out_split ? 1 : 0];
   if (lds > 64 * 1024) {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!attr_set[out_split ? 1 : 0]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      attr_set[out_split ? 1 : 0] = true;
-    }
+    const int e = ks.ensure_lds(reinterpret_cast<const void*>(kern), lds);
+    if (e != DLIP_OK) return e;
   }
-  // persistent workgroups: as many as the chip holds at once (2 per CU), each walking a contiguous range of tiles
-  static int slots[2] = {0, 0};
+  // persistent workgroups: as many as the device holds at once (2 per CU), each walking a contiguous range of tiles
+  int slots = 0;
   {
-    std::lock_guard<std::mutex> lock(mu);
-    int& sl = slots[out_split ? 1 : 0];
-    if (sl == 0) {
-      int dev = 0, cus = 0, per_cu = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * NW, lds) != hipSuccess || per_cu <= 0)
-        return DLIP_EINVAL;
-      sl = cus * per_cu;
-    }
+    const int e = ks.resident(reinterpret_cast<const void*>(kern), 64 * NW, lds, &slots);
+    if (e != DLIP_OK) return e;
   }
-  const long long grid = tiles < slots[out_split ? 1 : 0] ? tiles : slots[out_split ? 1 : 0];
+  const long long grid = tiles < slots ? tiles : slots;
 #ifdef DLIP_LAB
   if (getenv("DLIP_STAMP_PRINT")) {   // median cycles between the phase stamps of every workgroup's second tile
     static unsigned long long* dbuf = nullptr;
@@ -512,6 +501,9 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
 // keeps it to K <= 64) and no second reduction source / pooled epilogue.
 static bool win_shape_ok(int sh, int sw, int H, int W, int Ho, int Wo, int R, int S, int dh, int dw, int ph, int pw, int K) {
   if (dlip_dbg_value[DLIP_DBG_WIN] == 0) return false;
+  // masked taps read past the workgroup's LDS allocation and rely on the hardware returning zeros: probed on gfx950
+  // (tests/test_kernels_gpu.py::test_lds_read_beyond_allocation_returns_zero), never assumed elsewhere
+  if (!dlip_device_is_gfx950()) return false;
   return sh == 1 && sw == 1 && Wo == W && Ho == H && R == 3 && S == 3 && K <= (dlip_dbg_value[DLIP_DBG_WIN] == 1 ? 64 : 128) && (K & 3) == 0 &&
          (R - 1) * dh * W + (S - 1) * dw <= WIN_SLACK && ph * W + pw <= WIN_SLACK;
 }
@@ -520,6 +512,40 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_win_ok(const void
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
   return a.x2 == nullptr && a.pool == nullptr &&
          win_shape_ok(a.sh, a.sw, a.H, a.W, a.HoWo / a.Wo, a.Wo, a.R, a.S, a.dh, a.dw, a.ph, a.pw, a.K);
+}
+
+// ---- the hardware behaviour the masked taps stand on, as a callable check (tests/test_kernels_gpu.py) ----
+// A tap outside the image reads its fragment at an LDS address with bit 18 set -- beyond any workgroup's allocation and beyond
+// the CU's 160 KiB -- and the kernel takes the zeros gfx950 returns there as the convolution's padding.  This probe runs
+// that access pattern under the kernel's conditions (several workgroups per CU, each with its own allocation full of a
+// non-zero pattern, ds_read_b128 at base + 2^18 + lane offsets) and counts what comes back.
+namespace {
+__global__ __launch_bounds__(256) void lds_oob_probe_kernel(int32_t* counts, int alloc_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t probe_lds[];
+  for (int i = threadIdx.x; i < alloc_bytes / 4; i += blockDim.x) probe_lds[i] = 0xABCD0000u + blockIdx.x;
+  __syncthreads();
+  const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)probe_lds;
+  const uint32_t offs[4] = {0u, 1u << 18, (1u << 18) + 40000u, (1u << 18) + 130000u};
+  bool in_ok = false, oob_nonzero = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t addr = base + offs[k] + (threadIdx.x * 16u) % (uint32_t)alloc_bytes;
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    if (k == 0) in_ok = (v[0] >> 16) == 0xABCDu && (v[3] >> 16) == 0xABCDu;
+    else oob_nonzero |= (v[0] | v[1] | v[2] | v[3]) != 0u;
+  }
+  if (in_ok) atomicAdd(&counts[0], 1);
+  if (oob_nonzero) atomicAdd(&counts[1], 1);
+}
+}  // namespace
+
+extern "C" int dlip_selftest_lds_oob(int32_t* counts, int32_t blocks, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(counts && blocks > 0 && blocks <= 65536);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st) != hipSuccess) return DLIP_EINVAL;
+  hipLaunchKernelGGL(lds_oob_probe_kernel, dim3((unsigned)blocks), dim3(256), 8192, st, counts, 8192);
+  return dlip_launch_status();
 }
 
 extern "C" int dlip_conv_dma_enabled(void);   // conv_igemm_f16x3.hip

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 #include "deeplip_hip.h"
 
@@ -34,6 +35,60 @@ __device__ __forceinline__ void dlip_report_range(float amax, int32_t* status_wo
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(status_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+// Pixel arithmetic of the clip ingest (models/video_models/dataloaders.py:11-22 "val" pipeline: Normalize(0,255) ->
+// CenterCrop -> Normalize(0.421, 0.165); BT.601 gray of preprocess.py:44 kept in float).  ONE definition for every kernel
+// that turns uint8 frames into normalised pixels (ingest_rgb_kernel, crop_norm_kernel, the stem's uint8 pre-pass), with
+// contraction off: mul, add, IEEE divide in exactly the oracle's order (numpy float32, oracle/deeplip_oracle.py
+// ingest_rgb_u8 / video_preprocess_u8), so the kernels agree with each other AND with the oracle bit for bit.
+__device__ __forceinline__ float dlip_gray601(float r, float g, float b) {
+#pragma clang fp contract(off)
+  return (0.299f * r + 0.587f * g) + 0.114f * b;
+}
+__device__ __forceinline__ float dlip_pixel_norm(float gray_0_255) {
+#pragma clang fp contract(off)
+  return (gray_0_255 / 255.0f - 0.421f) / 0.165f;
+}
+
+// Launch-side state that HIP keeps PER DEVICE: the MaxDynamicSharedMemorySize attribute of a kernel and how many of its
+// workgroups the device holds at once.  One instance per kernel instantiation (a function-local static); a process that
+// drives several GPUs (one thread per device, or hipSetDevice in a loop) gets the attribute set and the grid sized on each.
+#define DLIP_MAX_DEVICES 32
+struct DlipKernelState {
+  std::mutex mu;
+  size_t lds_set[DLIP_MAX_DEVICES] = {};
+  int slots[DLIP_MAX_DEVICES] = {};
+  // raise the dynamic-LDS limit of `kern` on the current device to `bytes` (once per device and size)
+  int ensure_lds(const void* kern, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DLIP_MAX_DEVICES) return DLIP_EINVAL;
+    std::lock_guard<std::mutex> lock(mu);
+    if (bytes > lds_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) return (int)e;
+      lds_set[dev] = bytes;
+    }
+    return DLIP_OK;
+  }
+  // CUs x resident workgroups per CU of `kern` on the current device (persistent grids)
+  int resident(const void* kern, int threads, size_t lds, int* out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DLIP_MAX_DEVICES) return DLIP_EINVAL;
+    std::lock_guard<std::mutex> lock(mu);
+    if (slots[dev] == 0) {
+      int cus = 0, per_cu = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu <= 0)
+        return DLIP_EINVAL;
+      slots[dev] = cus * per_cu;
+    }
+    *out = slots[dev];
+    return DLIP_OK;
+  }
+};
+// 1 when the current device is gfx950 (cached per device; capi.hip).  Kernels that lean on probed gfx950 behaviour (conv_win's
+// out-of-allocation ds_read returning zeros) are only selected there.
+extern "C" __attribute__((visibility("hidden"))) int dlip_device_is_gfx950(void);
 
 static inline int dlip_launch_status() {
   hipError_t e = hipGetLastError();

@@ -166,9 +166,9 @@ __global__ __launch_bounds__(256) void crop_norm_kernel(const uint8_t* __restric
     const long long n = i / ((long long)CS * CS);
     const uint8_t* p = x + (n * CH * H + (oy + cy)) * W + ox + cx;
     float g;
-    if (CH == 3) g = 0.299f * (float)p[0] + 0.587f * (float)p[(long long)H * W] + 0.114f * (float)p[2LL * H * W];
+    if (CH == 3) g = dlip_gray601((float)p[0], (float)p[(long long)H * W], (float)p[2LL * H * W]);
     else g = (float)p[0];
-    y[i] = (g / 255.0f - 0.421f) / 0.165f;
+    y[i] = dlip_pixel_norm(g);
   }
 }
 

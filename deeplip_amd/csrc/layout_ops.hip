@@ -64,8 +64,7 @@ __global__ __launch_bounds__(256) void ingest_rgb_kernel(const uint8_t* __restri
     const long long f = i / HW;
     const int p = (int)(i - f * HW);
     const uint8_t* px = x + f * 3 * HW + p;
-    const float g = 0.299f * (float)px[0] + 0.587f * (float)px[HW] + 0.114f * (float)px[2 * HW];
-    y[i] = (g / 255.0f - 0.421f) / 0.165f;
+    y[i] = dlip_pixel_norm(dlip_gray601((float)px[0], (float)px[HW], (float)px[2 * HW]));
   }
 }
 

@@ -322,22 +322,46 @@ __device__ __forceinline__ float dpp_from_right(float v, float edge) {   // lane
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
 }
 
-// x fp32 [F, H, W] -> xs [F, H, pwp] dwords (hi | lo << 16), columns 3 .. W + 2 = the pixels, the rest zero.
-__global__ __launch_bounds__(256) void stem_split_input_kernel(const float* __restrict__ x, uint32_t* __restrict__ xs, int rows, int W, int pwp,
-                                                               int32_t* status) {
+// The clip -> xs [F, H, pwp] dwords (hi | lo << 16), columns 3 .. W + 2 = the pixels, the rest zero.
+//   SRC 0: x fp32 [F, H, W], already normalised (the reference's [B,1,T,H,W] input, model.py:97);
+//   SRC 1: uint8 frames [F, CH, Hs, Ws] as a loader hands them over (CH = 1 gray | 3 RGB = the north star's
+//          [B,T,3,H,W]), centre-cropped to H x W at (oy, ox) and normalised HERE, (x / 255 - 0.421) / 0.165 on the BT.601
+//          gray (dataloaders.py:11-22, preprocess.py:32-46): the fp32 clip (4 B per pixel written by an ingest kernel and
+//          read back by this pre-pass, 4 B per pixel over PCIe) never exists.  Same arithmetic, same order as
+//          ingest_rgb_kernel / crop_norm_kernel (dlip_common.h): bit-identical to ingest -> fp32 -> SRC 0.
+template <int SRC>
+__global__ __launch_bounds__(256) void stem_split_input_kernel(const void* __restrict__ xin, uint32_t* __restrict__ xs, int rows, int H, int W,
+                                                               int pwp, int CH, int Hs, int Ws, int oy, int ox, int32_t* status) {
   const int cpr = pwp >> 2;                            // 16-B chunks per row
   const long long total = (long long)rows * cpr;
   float amax = 0.f;
   for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < total; c += (long long)gridDim.x * 256) {
     const int row = (int)(c / cpr), ch = (int)(c - (long long)row * cpr);
-    const float* src = x + (size_t)row * W;
     u32x4 o;
+    if constexpr (SRC == 0) {
+      const float* src = static_cast<const float*>(xin) + (size_t)row * W;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int wi = 4 * ch + e - 3;
-      const float v = (unsigned)wi < (unsigned)W ? src[wi] : 0.f;
-      amax = fmaxf(amax, fabsf(v));
-      o[e] = split_pair(v);
+      for (int e = 0; e < 4; ++e) {
+        const int wi = 4 * ch + e - 3;
+        const float v = (unsigned)wi < (unsigned)W ? src[wi] : 0.f;
+        amax = fmaxf(amax, fabsf(v));
+        o[e] = split_pair(v);
+      }
+    } else {
+      const int f = row / H, h = row - f * H;
+      const size_t plane = (size_t)Hs * Ws;
+      const uint8_t* src = static_cast<const uint8_t*>(xin) + ((size_t)f * CH * Hs + (size_t)(oy + h)) * Ws + ox;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int wi = 4 * ch + e - 3;
+        float v = 0.f;                                 // the convolution's zero padding (of the NORMALISED clip)
+        if ((unsigned)wi < (unsigned)W) {
+          const float g = CH == 3 ? dlip_gray601((float)src[wi], (float)src[plane + wi], (float)src[2 * plane + wi]) : (float)src[wi];
+          v = dlip_pixel_norm(g);
+        }
+        amax = fmaxf(amax, fabsf(v));
+        o[e] = split_pair(v);
+      }
     }
     *reinterpret_cast<u32x4*>(xs + (size_t)c * 4) = o;
   }
@@ -618,11 +642,10 @@ extern "C" int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, con
   const size_t ldsb = (size_t)WBYTES + 2 * (size_t)KT * PR * a.pwp * 4;
   auto kern = stem3d_f16x3_kernel;
   a.status = dlip_status_words() ? dlip_status_words() + DLIP_ST_STEM : nullptr;
-  static size_t lds_set = 0;   // the attribute is raised once per size (not on every launch)
-  if (ldsb > lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    if (e != hipSuccess) return (int)e;
-    lds_set = ldsb;
+  static DlipKernelState ks;   // the attribute is raised once per device and size (not on every launch)
+  {
+    const int e = ks.ensure_lds(reinterpret_cast<const void*>(kern), ldsb);
+    if (e != DLIP_OK) return e;
   }
 #ifdef DLIP_LAB
   a.stamps = nullptr;
@@ -654,11 +677,13 @@ extern "C" int64_t dlip_stem3d_pool_workspace_bytes(int32_t B, int32_t T, int32_
   return (int64_t)B * T * H * pwp * 4;
 }
 
-extern "C" int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void* w_split, const float* w_scale, const float* bias,
-                                      const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
-                                      int32_t K, dlip_stream_t stream) {
+// src_kind 0: x = fp32 [B,T,H,W]; 1: x = uint8 [B,T,CH,Hs,Ws] cropped to H x W at (oy, ox)
+static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws, int oy, int ox, void* x_split, const void* w_split,
+                            const float* w_scale, const float* bias, const float* slope, float* y, int32_t B, int32_t T, int32_t H,
+                            int32_t W, int32_t K, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && x_split && w_split && w_scale && y && B > 0 && T > 0 && H > 0 && W > 0);
   DLIP_CHECK_ARG(K == 64 && (H & 1) == 0 && (W & 1) == 0 && (reinterpret_cast<uintptr_t>(x_split) & 15) == 0);
+  if (src_kind == 1) DLIP_CHECK_ARG((CH == 1 || CH == 3) && oy >= 0 && ox >= 0 && oy + H <= Hs && ox + W <= Ws);
   StemArgs a;
   a.x = static_cast<const float*>(x_split); a.w = static_cast<const uint32_t*>(w_split); a.wscale = w_scale; a.bias = bias; a.slope = slope; a.y = y;
   a.T = T; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
@@ -680,17 +705,22 @@ extern "C" int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void*
   {   // pre-pass: the clip as (hi, lo) pairs at the window's row pitch
     const long long chunks = frames * H * (a.pwp / 4);
     const unsigned pgrid = (unsigned)std::min<long long>((chunks + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(stem_split_input_kernel, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), W, a.pwp, a.status);
+    if (frames * H > 0x7FFFFFFFll) return DLIP_ERANGE;
+    if (src_kind == 0)
+      hipLaunchKernelGGL(stem_split_input_kernel<0>, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), H, W, a.pwp,
+                         1, H, W, 0, 0, a.status);
+    else
+      hipLaunchKernelGGL(stem_split_input_kernel<1>, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), H, W, a.pwp,
+                         CH, Hs, Ws, oy, ox, a.status);
   }
   const long long grid = frames < 256 ? frames : 256;   // persistent: a workgroup walks whole frames
   const size_t ldsb = (size_t)WBYTES + (size_t)KT * (np * 256 + 32) * 4 + (size_t)CARRY_SLOTS * CARRY_B + 3 * 64 * 4 + 128;
   DLIP_CHECK_ARG(ldsb <= 160 * 1024);
   auto kern = stem3d_pool_f16x3_kernel;
-  static size_t lds_set = 0;   // the attribute is raised once per size (not on every launch)
-  if (ldsb > lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    if (e != hipSuccess) return (int)e;
-    lds_set = ldsb;
+  static DlipKernelState ks;   // the attribute is raised once per device and size (not on every launch)
+  {
+    const int e = ks.ensure_lds(reinterpret_cast<const void*>(kern), ldsb);
+    if (e != DLIP_OK) return e;
   }
 #ifdef DLIP_LAB
   a.stamps = nullptr;
@@ -721,4 +751,17 @@ extern "C" int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void*
 #endif
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PTHREADS), ldsb, st, a);
   return dlip_launch_status();
+}
+
+extern "C" int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void* w_split, const float* w_scale, const float* bias,
+                                      const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
+                                      int32_t K, dlip_stream_t stream) {
+  return stem_pool_launch(x, 0, 1, H, W, 0, 0, x_split, w_split, w_scale, bias, slope, y, B, T, H, W, K, stream);
+}
+
+extern "C" int dlip_stem3d_pool_u8_f16x3(const uint8_t* frames, int32_t channels, int32_t Hs, int32_t Ws, int32_t oy, int32_t ox,
+                                         void* x_split, const void* w_split, const float* w_scale, const float* bias,
+                                         const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W, int32_t K,
+                                         dlip_stream_t stream) {
+  return stem_pool_launch(frames, 1, channels, Hs, Ws, oy, ox, x_split, w_split, w_scale, bias, slope, y, B, T, H, W, K, stream);
 }

@@ -309,6 +309,39 @@ def stem3d_pool(x_bthw: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Ten
     return y
 
 
+def center_crop_origin(size: int, crop: int) -> int:
+    """CenterCrop's offset (models/video_models/preprocess.py): int(round((size - crop) / 2.)) with Python's round."""
+    return int(round((size - crop) / 2.0))
+
+
+def stem3d_pool_u8(frames: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Tensor], w_scale: Tensor, crop: int = 88) -> Tensor:
+    """uint8 frames [B,T,Hs,Ws] (gray) or [B,T,3,Hs,Ws] (RGB) -> [(B*T), Hp, Wp, 64] split format: centre crop + gray +
+    (x/255 - 0.421)/0.165 inside the stem's pre-pass (dlip_stem3d_pool_u8_f16x3) -- no fp32 clip in HBM or over PCIe."""
+    _req(frames, "frames", torch.uint8)
+    for t, n in ((w_img, "w"), (bias, "bias"), (slope, "slope"), (w_scale, "w_scale")):
+        _req(t, n)
+    if frames.dim() not in (4, 5) or (frames.dim() == 5 and frames.shape[2] != 3):
+        raise ValueError("stem3d_pool_u8: expected uint8 [B,T,H,W] or [B,T,3,H,W]")
+    ch = 3 if frames.dim() == 5 else 1
+    B, T = frames.shape[0], frames.shape[1]
+    Hs, Ws = frames.shape[-2], frames.shape[-1]
+    H = W = crop
+    if Hs < H or Ws < W:
+        raise ValueError(f"stem3d_pool_u8: frames {Hs}x{Ws} are smaller than the {crop}x{crop} crop")
+    oy, ox = center_crop_origin(Hs, H), center_crop_origin(Ws, W)
+    Ho, Wo = H // 2, W // 2
+    y = _empty((B * T, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), frames.device)
+    ws = _empty((int(lib().dlip_stem3d_pool_workspace_bytes(B, T, H, W)) // 4,), frames.device)
+    hook = LAUNCH_HOOK
+    if hook is not None:
+        tok = hook.begin("stem3d_pool_f16x3_kernel", 2.0 * B * T * Ho * Wo * 64 * 245)
+    check(lib().dlip_stem3d_pool_u8_f16x3(ptr(frames), ch, Hs, Ws, oy, ox, ptr(ws), ptr(w_img), ptr(w_scale), ptr(bias), ptr(slope),
+                                          ptr(y), B, T, H, W, 64, stream_handle()), "dlip_stem3d_pool_u8_f16x3")
+    if hook is not None:
+        hook.end(tok)
+    return y
+
+
 def split_pack(x: Tensor) -> Tensor:
     """fp32 [..., C] -> split activation format (same shape / dtype container; C % 32 == 0)."""
     _req(x, "x")

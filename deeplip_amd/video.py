@@ -457,6 +457,8 @@ class Lipreading(nn.Module):
         if self.training:
             return self._forward_train(x, lengths)
         _lib.check_range()      # an overflow reported by an earlier f16x3 launch surfaces here (host read, no sync)
+        if x.dtype == torch.uint8:
+            return self._forward_u8(x, lengths, taps, pooled)
         B, C, T, H, W = x.size()
         if C != 1:
             raise ValueError("Lipreading expects grayscale clips [B,1,T,H,W] (model.py:82); use "
@@ -478,6 +480,27 @@ class Lipreading(nn.Module):
         if pooled:
             return self.trunk.run(y, p["trunk"], None, x_split=split, pool_frames=T)
         y = self.trunk.run(y, p["trunk"], taps, x_split=split).view(B, T, self.backend_out)
+        return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
+
+    def _forward_u8(self, frames: Tensor, lengths, taps, pooled: bool):
+        """forward() for uint8 frames as a loader hands them over -- [B,T,Hs,Ws] gray (the reference's npz mouth crops) or
+        [B,T,3,Hs,Ws] RGB (BASELINE.json's input) -- instead of the normalised float clip [B,1,T,88,88].  On the split-format
+        path the centre crop, the gray conversion and (x/255 - 0.421)/0.165 (dataloaders.py:11-22) happen inside the stem's
+        pre-pass; otherwise (f32 packing, taps) the ingest kernel writes the float clip and forward() carries on with it.
+        Either way HIP kernels do it; there is no host-side path."""
+        if frames.dim() not in (4, 5) or (frames.dim() == 5 and frames.shape[2] != 3):
+            raise ValueError("Lipreading: uint8 input must be [B,T,H,W] (gray) or [B,T,3,H,W] (RGB)")
+        frames = frames.contiguous()
+        p = _cached_pack(self, frames.device, self._pack)
+        split = self.trunk.wants_split(p["trunk"])
+        B, T = frames.shape[0], frames.shape[1]
+        if not (split and taps is None and p["stem"].wscale is not None):
+            from .frontend import VideoFrontend
+            return self.forward(VideoFrontend(88)(frames), lengths, taps, pooled)
+        y = ops.stem3d_pool_u8(frames, p["stem"].w, p["stem"].b, p["stem"].slope, p["stem"].wscale, crop=88)
+        if pooled:
+            return self.trunk.run(y, p["trunk"], None, x_split=True, pool_frames=T)
+        y = self.trunk.run(y, p["trunk"], None, x_split=True).view(B, T, self.backend_out)
         return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
 
     def classifier_features(self, x: Tensor, lengths) -> Tensor:
@@ -509,7 +532,10 @@ class Lipreading(nn.Module):
         p = _cached_pack(self, x.device, self._pack)
         if not self.trunk.wants_split(p["trunk"]) or p["stem"].wscale is None:
             return False
-        B, _, T, H, W = x.shape
+        if x.dtype == torch.uint8:          # [B,T,Hs,Ws] / [B,T,3,Hs,Ws] frames: cropped to 88 x 88 by the pre-pass
+            B, T, H, W = x.shape[0], x.shape[1], 88, 88
+        else:
+            B, _, T, H, W = x.shape
         if not (W <= 88 and W % 8 == 0):
             return False
         h, w = H // 2, W // 2

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 18
+#define DLIP_ABI_VERSION 19
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -183,6 +183,27 @@ int64_t dlip_stem3d_pool_workspace_bytes(int32_t B, int32_t T, int32_t H, int32_
 int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void* w_split, const float* w_scale,
                            const float* bias, const float* slope, float* y, int32_t B, int32_t T, int32_t H,
                            int32_t W, int32_t K, dlip_stream_t stream);
+
+/* dlip_stem3d_pool_f16x3 fed with the frames as a loader hands them over: uint8, `channels` = 1 (gray [B,T,Hs,Ws], what the
+ * reference's npz mouth crops hold: models/video_models/dataset.py) or 3 (RGB [B,T,3,Hs,Ws], BASELINE.json's input shape).
+ * The pre-pass centre-crops H x W at row oy, column ox (CenterCrop: preprocess.py; oy = int(round((Hs - H) / 2.))) and
+ * normalises while it writes the split clip: gray = 0.299 R + 0.587 G + 0.114 B kept in float (preprocess.py:32-46),
+ * (gray / 255 - 0.421) / 0.165 (dataloaders.py:11-22), mul / add / IEEE divide in that order, uncontracted -- bit-identical
+ * to dlip_ingest_rgb_u8 (or dlip_crop_normalize_u8) followed by dlip_stem3d_pool_f16x3, without the fp32 clip: a quarter of
+ * the host-to-device bytes, one HBM write and one read of 4 B per pixel less.  Replaces train_fusion.py:346-348's
+ * `.to(device)` of a float clip + model.py:81-85. */
+int dlip_stem3d_pool_u8_f16x3(const uint8_t* frames, int32_t channels, int32_t Hs, int32_t Ws, int32_t oy, int32_t ox,
+                              void* x_split, const void* w_split, const float* w_scale, const float* bias,
+                              const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W, int32_t K,
+                              dlip_stream_t stream);
+
+/* Self-test of a hardware behaviour the layer-1 / layer-2 window kernel (conv_win_f16x3.hip) relies on: a ds_read_b128 at an
+ * LDS address with bit 18 set (beyond every allocation) returns zeros on gfx950 -- the kernel uses that as the zero
+ * padding of taps outside the image, and is selected on gfx950 devices only.  `blocks` workgroups of 256 lanes, 8 KB of
+ * LDS each (several per CU), fill their allocation with a pattern and read inside and beyond it; counts (device int32[2])
+ * receives [lanes whose in-range read returned the pattern, lanes whose out-of-range reads returned anything non-zero]:
+ * expected [256 * blocks, 0]. */
+int dlip_selftest_lds_oob(int32_t* counts, int32_t blocks, dlip_stream_t stream);
 
 /* MaxPool3d((1,3,3), stride (1,2,2), pad (0,1,1)) on NHWC: [N,H,W,C] -> [N,Ho,Wo,C],
  * Ho = (H+2-3)/2+1.  Replaces models/video_models/model.py:85.  C % 4 == 0.  out_split != 0 writes y

@@ -185,11 +185,56 @@ def test_layout_adapters(ops):
 
 
 def test_ingest_rgb(ops):
+    """The ingest arithmetic is uncontracted mul / add / IEEE divide in the oracle's order (dlip_common.h): bit-exact."""
     from oracle import deeplip_oracle as O
     u8 = torch.randint(0, 256, (2, 3, 3, 16, 20), dtype=torch.uint8, generator=torch.Generator().manual_seed(22))
     y = ops.ingest_rgb_u8(u8.cuda())
     torch.cuda.synchronize()
-    assert np.abs(y.cpu().numpy() - O.ingest_rgb_u8(u8.numpy())).max() < 1e-5
+    assert np.array_equal(y.cpu().numpy(), O.ingest_rgb_u8(u8.numpy()))
+    full = torch.arange(256, dtype=torch.uint8).view(1, 1, 1, 16, 16).expand(1, 1, 3, 16, 16).contiguous()   # every gray level
+    assert np.array_equal(ops.ingest_rgb_u8(full.cuda()).cpu().numpy(), O.ingest_rgb_u8(full.numpy()))
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 3, 88, 88), (2, 5, 88, 88), (1, 3, 96, 96), (1, 2, 3, 100, 97), (3, 29, 3, 88, 88)],
+                         ids=["rgb88", "gray88", "gray96-crop", "rgb100x97-crop", "rgb-clip29"])
+def test_stem3d_pool_u8_prepass_bit_identical(ops, shape):
+    """uint8 frames straight into the stem's pre-pass (dlip_stem3d_pool_u8_f16x3): centre crop + BT.601 gray +
+    (x/255 - 0.421)/0.165 while the split clip is written.  Three statements, all exact:
+      * the normalised clip the pre-pass splits == the oracle's ingest_rgb_u8 / video_preprocess_u8 (bit for bit);
+      * the stem + pool output == ingest kernel -> fp32 clip -> dlip_stem3d_pool_f16x3 (bit for bit);
+      * gray and RGB sources, frames larger than the crop (even and odd margins), a whole 29-frame clip."""
+    from deeplip_amd import packing
+    from deeplip_amd.frontend import VideoFrontend
+    from oracle import deeplip_oracle as O
+    u8 = torch.randint(0, 256, shape, dtype=torch.uint8, generator=torch.Generator().manual_seed(71))
+    w = rnd(64, 1, 5, 7, 7, seed=72, scale=1.0 / np.sqrt(245))
+    b = rnd(64, seed=73, scale=0.1).cuda()
+    slope = (torch.rand(64, generator=torch.Generator().manual_seed(74)) * 0.3).cuda()
+    img, sc = packing.split_stem_weights(w.double())
+    img, sc = img.cuda(), sc.cuda()
+    clip = VideoFrontend(88)(u8.cuda())                                  # [B,1,T,88,88] fp32 (crop_norm kernel)
+    want = np.stack([O.video_preprocess_u8(c) for c in u8.numpy()])      # oracle: dataloaders.py "val" pipeline per clip
+    assert np.array_equal(clip.cpu().numpy()[:, 0], want)
+    ref = ops.stem3d_pool(clip[:, 0].contiguous(), img, b, slope, sc)
+    got = ops.stem3d_pool_u8(u8.cuda(), img, b, slope, sc, crop=88)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    assert torch.equal(got.cpu().view(torch.int32), ref.cpu().view(torch.int32))
+
+
+def test_lds_read_beyond_allocation_returns_zero():
+    """conv_win_f16x3's masked taps read LDS at addresses with bit 18 set and take the zeros gfx950 returns as the
+    convolution's padding (the kernel is only selected on gfx950: dlip_device_is_gfx950).  The hardware behaviour itself,
+    under the kernel's conditions: many workgroups per CU, every allocation full of a non-zero pattern."""
+    from deeplip_amd import _lib
+    from deeplip_amd.ops import ptr, stream_handle
+    counts = torch.full((2,), -1, dtype=torch.int32, device="cuda")
+    blocks = 4096
+    _lib.check(_lib.lib().dlip_selftest_lds_oob(ptr(counts), blocks, stream_handle()), "dlip_selftest_lds_oob")
+    torch.cuda.synchronize()
+    in_range_ok, oob_nonzero = counts.cpu().tolist()
+    assert in_range_ok == 256 * blocks       # the probe really reads LDS: inside the allocation the pattern comes back
+    assert oob_nonzero == 0                  # beyond it: zeros, for every lane of every workgroup
 
 
 def test_znorm_l2_cosine(ops):

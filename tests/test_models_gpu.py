@@ -315,3 +315,25 @@ def test_average_pooling_head_is_build_owned():
         rxv, rxa = O.speaker_extract_embedding(sd, x, O.TDNN_CONTEXT, pooling="average")
     close(xa.cpu().numpy(), rxa.numpy())
     close(xv.cpu().numpy(), rxv.numpy())
+
+
+@pytest.mark.parametrize("T", [9, 29])
+def test_uint8_frames_in_equal_float_clip_in(video_net, T):
+    """uint8 RGB [B,T,3,88,88] (BASELINE.json's input shape) and uint8 gray [B,T,96,96] (the reference's npz mouth crops,
+    centre-cropped to 88: dataloaders.py:17-24) given straight to Lipreading: identical -- bit for bit -- to handing over the
+    normalised float clip the oracle's ingest computes from the same frames, and within the bar of the oracle's features.
+    In f16x3 mode the frames go into the stem's pre-pass (no float clip exists); in f32 mode through the ingest kernel."""
+    net, sd = video_net
+    g = torch.Generator().manual_seed(5)
+    rgb = torch.randint(0, 256, (2, T, 3, 88, 88), dtype=torch.uint8, generator=g)
+    gray = torch.randint(0, 256, (2, T, 96, 96), dtype=torch.uint8, generator=g)
+    for frames, clip in ((rgb, torch.from_numpy(O.ingest_rgb_u8(rgb.numpy()))),
+                         (gray, torch.from_numpy(np.stack([O.video_preprocess_u8(c) for c in gray.numpy()]))[:, None])):
+        got = net.embed(frames.to(DEV)).clone()
+        want = net.embed(clip.to(DEV)).clone()
+        feats = net(frames.to(DEV), None).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want.cpu())
+        ref = O.lipreading_features(sd, clip)
+        close(feats.cpu().numpy(), ref.numpy(), what="features from uint8 frames")
+        close(got.cpu().numpy(), O.video_time_mean(ref).numpy(), what="clip embedding from uint8 frames")
