@@ -10,8 +10,8 @@ fit the link four times over.  So the copies get their own stream and the inputs
 
 ``depth`` input sets, one recorded StepPlan per set (a plan addresses fixed buffers; 1.7 GB of arena each at B = 64 -- of
 288 GB), two events per set: READY (recorded on the copy stream behind the set's copies, awaited by the run stream) and FREE
-(recorded on the run stream behind the plan's replay, awaited by the copy stream before the set is overwritten).  The host
-only enqueues -- a few async copies and one plan replay per batch -- and never waits inside the loop.
+(recorded on the run stream behind the plan's replay, awaited by the HOST before the set is overwritten: the host stays at most
+`depth` batches ahead, see run()).  Per batch the host enqueues a few async copies and one plan replay.
 
 Inputs are whatever the step function takes: normalised float clips [B,1,T,88,88], or the uint8 frames a loader holds
 ([B,T,3,H,W] RGB / [B,T,H,W] gray), which the lip-clip encoder's pre-pass normalises on the fly (a quarter of the bytes over PCIe).
@@ -74,9 +74,13 @@ class ExtractPipeline:
             rows = int(hb[0].shape[0])
             if rows > self.batch or len(hb) != len(ins):
                 raise ValueError("ExtractPipeline: batch does not match the recorded inputs")
+            if i >= self.depth:
+                # Bounded run-ahead: the HOST waits here until the replay that read this set has finished, so it is never more
+                # than `depth` batches ahead of the GPU.  Measured (tools/probes/h2d_timeline.py, B = 64, uint8 RGB): with the
+                # host free to enqueue all 40 batches at once the replays behind the enqueue burst take 5.2-6.2 ms instead of
+                # 4.2 (and the enqueue itself 2.3 ms per batch); throttled, every batch takes 4.23 ms -- the resident rate.
+                self.free[k].synchronize()
             with torch.cuda.stream(self.copy_stream):
-                if i >= self.depth:
-                    self.copy_stream.wait_event(self.free[k])          # the plan that read this set has finished
                 for dst, src in zip(ins, hb):
                     (dst if rows == self.batch else dst[:rows]).copy_(src, non_blocking=True)
                 self.ready[k].record(self.copy_stream)

@@ -49,6 +49,14 @@ class SyntheticAVSet:
         return np.stack(clips), np.asarray(ptr, dtype=np.int32)
 
 
+def frames_u8_from_clips(clips: np.ndarray, rgb: bool = True) -> np.ndarray:
+    """Normalised float clips [G,1,T,H,W] -> the uint8 frames a loader would have held before dataloaders.py:17-24 normalised
+    them: gray = round(255 * (x * 0.165 + 0.421)), as [G,T,3,H,W] RGB with R = G = B (BASELINE.json's input shape) or
+    [G,T,H,W] gray.  (The engine's ingest of these frames gives the clip back up to the uint8 quantisation.)"""
+    g = np.clip(np.rint((clips[:, 0].astype(np.float64) * 0.165 + 0.421) * 255.0), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2)) if rgb else g
+
+
 def synthetic_trials(dataset: SyntheticAVSet, n_trials: int = 20000, n_target: int = 4000, seed: int = 3):
     """(labels [n], pairs [(utt1, utt2)]) with the target / non-target split of trial_grid_v1.txt."""
     r = np.random.Generator(np.random.PCG64(seed))

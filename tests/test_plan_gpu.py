@@ -114,3 +114,45 @@ def test_two_stream_step_is_bit_identical_eager_and_recorded():
         plan.close()
     finally:
         packing.set_precision("f32")
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_extract_pipeline_rows_equal_the_direct_step(precision):
+    """deeplip_amd.pipeline.ExtractPipeline: uint8 RGB frames + mel batches from pinned host memory, H2D on a copy stream into
+    one of two input sets while the other set's plan replays.  Seven batches (three distinct, a short last one) -> every
+    table row equals the row the direct, un-pipelined step gives for that batch -- bit for bit, in list order."""
+    from deeplip_amd import fusion, packing, weightgen as wg
+    from deeplip_amd.pipeline import ExtractPipeline
+    from deeplip_amd.synthetic import frames_u8_from_clips
+    try:
+        video, audio = _models(precision)
+
+        def step(frames, xa):
+            return fusion.embed_av(audio, video, xa, frames)
+
+        B = 3
+        host = []
+        for r in range(3):
+            fr = torch.from_numpy(frames_u8_from_clips(wg.video_input(B, frames=11, key=f"pipe.v{r}"), rgb=True)).pin_memory()
+            xa = torch.from_numpy(wg.audio_input(B, 24, 150, key=f"pipe.a{r}")).pin_memory()
+            host.append((fr, xa))
+        assert host[0][0].dtype == torch.uint8 and tuple(host[0][0].shape) == (B, 11, 3, 88, 88)
+        want = [step(fr.cuda(), xa.cuda()).clone() for fr, xa in host]
+        torch.cuda.synchronize()
+        order = [0, 1, 2, 1, 0, 2]
+        batches = [host[i] for i in order] + [(host[1][0][:2], host[1][1][:2])]      # a short last batch
+        pipe = ExtractPipeline(step, host[0][0].cuda(), host[0][1].cuda())
+        table = torch.full((len(order) * B + 2, 1024), float("nan"), device="cuda")
+        n = pipe.run(batches, table)
+        pipe.finish()
+        assert n == table.shape[0]
+        for j, i in enumerate(order):
+            assert torch.equal(table[j * B:(j + 1) * B], want[i]), (j, i)
+        assert torch.equal(table[-2:], want[1][:2])
+        # a second run reuses the sets (FREE events of the previous run are behind us)
+        table2 = torch.empty_like(table)
+        pipe.run(batches, table2); pipe.finish()
+        assert torch.equal(table2, table)
+        pipe.close()
+    finally:
+        packing.set_precision("f32")
