@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lock = threading.Lock()
 _lib = None
@@ -44,6 +44,8 @@ SIGNATURES = {
     "dlip_conv_pool_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_pool_finish_f32": [c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_stream],
     "dlip_set_status_words": [c_f],
+    "dlip_range_scope_begin": [c_f, c_i32],
+    "dlip_range_scope_end": [c_stream],
     "dlip_debug_set": [c_i32, c_i32],
     "dlip_bn_rows_chunks": [c_i32],
     "dlip_bn_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_i32, c_stream],
@@ -146,6 +148,8 @@ def lib() -> C.CDLL:
         l.dlip_conv_workspace_bytes.restype = C.c_int64
         l.dlip_conv_pool_partial_bytes.restype = C.c_int64
         l.dlip_stem3d_pool_workspace_bytes.restype = C.c_int64
+        l.dlip_source_sha.argtypes = []
+        l.dlip_source_sha.restype = C.c_char_p
         l.dlip_error_string.argtypes = [C.c_int]
         l.dlip_error_string.restype = C.c_char_p
         v = l.dlip_abi_version()
@@ -201,17 +205,18 @@ def debug_set(key: int, value: int = -1) -> None:
     check(lib().dlip_debug_set(key, value), "dlip_debug_set")
 
 
-# ---- range status of the f16x3 arithmetic: four words in host-pinned, device-visible memory ----
+# ---- range status of the f16x3 arithmetic: eight words in host-pinned, device-visible memory ----
 _STATUS_NAMES = ("a convolution / linear epilogue", "the fused stem + pool", "split_pack (a model input or gradient operand)",
                  "statistics pooling")
+_ST_LOW = 4
 
 
 def status_words():
-    """Registers (once) the status block the kernels report range overflows to.  It lives in pinned host memory,
+    """Registers (once) the status block the kernels report range violations to.  It lives in pinned host memory,
     which the GPU addresses directly: the host can look at it at any time without synchronising."""
     global _status, _status_np
     if _status is None:
-        t = torch.zeros(4, dtype=torch.int32).pin_memory()
+        t = torch.zeros(8, dtype=torch.int32).pin_memory()
         check(lib().dlip_set_status_words(t.data_ptr()), "dlip_set_status_words")
         _status_np = t.numpy()      # same memory: a forward's check is one numpy read
         _status = t
@@ -219,15 +224,90 @@ def status_words():
 
 
 def check_range(sync: bool = False) -> None:
-    """Raise DeepLipRangeError if a kernel reported an activation beyond fp16 range since the last call.  Without
-    ``sync`` only launches that have completed are covered (the call is a host memory read); callers that are
-    about to consume results synchronise first (or pass sync=True)."""
+    """Raise DeepLipRangeError if a kernel reported an activation outside what the split format holds since the last call:
+    |v| >= 65520 (infinite in fp16), or a whole produced tensor with its largest magnitude in (0, 2^-6) (lo is subnormal
+    there: relative accuracy below fp32 grade; include/deeplip_hip.h).  Without ``sync`` only launches that have completed are
+    covered (the call is a host memory read); callers that are about to consume results synchronise first (or pass sync=True)."""
     t = status_words()
     if sync:
         torch.cuda.synchronize()
     if _status_np.any():
-        where = [n for n, v in zip(_STATUS_NAMES, t.tolist()) if v]
+        words = t.tolist()
         t.zero_()
-        raise DeepLipRangeError("f16x3 arithmetic: an activation with |v| >= 65520 (not representable as hi + lo fp16) was "
-                                f"produced by {', '.join(where)}; results since the last check are invalid. Pack the model "
-                                "with deeplip_amd.packing.set_precision('f32') (exact fp32 MFMA, same engine).")
+        high = [n for n, v in zip(_STATUS_NAMES, words[:4]) if v]
+        recourse = ("results since the last check are invalid. Pack the model with deeplip_amd.packing.set_precision('f32') "
+                    "(exact fp32 MFMA, same engine).")
+        if high:
+            raise DeepLipRangeError("f16x3 arithmetic: an activation with |v| >= 65520 (not representable as hi + lo fp16) was "
+                                    f"produced by {', '.join(high)}; " + recourse)
+        fam = words[_ST_LOW] - 1
+        who = _STATUS_NAMES[fam] if 0 <= fam < len(_STATUS_NAMES) else "a split-format producer"
+        raise DeepLipRangeError(f"f16x3 arithmetic: {who} produced a tensor whose largest magnitude is below 2^-6 = 0.0156: its "
+                                "lo halves are fp16 subnormals and the result is no longer fp32-grade (relative error 3e-8 / max|v|); "
+                                + recourse)
+
+
+# ---- low-side range scopes: one evidence word per split-producing launch (dlip_range_scope_*) ----
+_SCOPE_SLOTS = 512           # launches per scope (a B = 64 fused step makes ~40)
+_RING_CHUNKS = 16
+_ring = None
+_ring_next = 0
+_scope_depth = threading.local()
+
+
+def scope_slots(device=None):
+    """A zeroed block of evidence words owned by the caller (a StepPlan keeps one for its lifetime)."""
+    return torch.zeros(_SCOPE_SLOTS, dtype=torch.int32, device=device if device is not None else "cuda")
+
+
+class range_scope:
+    """``with range_scope():`` around the launches of one forward pass; the verdict kernel goes out on the current stream at
+    exit (join side streams first).  Nested scopes fold into the outermost one of the thread.  Eager scopes draw their words from
+    a ring of chunks (a scope's verdict re-zeroes its chunk, so a chunk is clean again long before the ring comes round); a
+    StepPlan passes its own block, which the recorded launches then address for the plan's lifetime."""
+
+    def __init__(self, slots=None):
+        self.slots = slots
+        self.outer = False
+
+    def __enter__(self):
+        global _ring, _ring_next
+        d = getattr(_scope_depth, "n", 0)
+        _scope_depth.n = d + 1
+        self.outer = d == 0
+        if not self.outer:
+            return self
+        if _status is None:
+            status_words()
+        slots = self.slots
+        if slots is None:
+            with _lock:
+                if _ring is None or _ring.device.index != torch.cuda.current_device():
+                    _ring = torch.zeros(_RING_CHUNKS * _SCOPE_SLOTS, dtype=torch.int32, device="cuda")
+                    _ring_next = 0
+                slots = _ring[_ring_next * _SCOPE_SLOTS:(_ring_next + 1) * _SCOPE_SLOTS]
+                _ring_next = (_ring_next + 1) % _RING_CHUNKS
+        check(lib().dlip_range_scope_begin(slots.data_ptr(), min(_SCOPE_SLOTS, slots.numel())), "dlip_range_scope_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _scope_depth.n -= 1
+        if self.outer:
+            rc = lib().dlip_range_scope_end(torch.cuda.current_stream().cuda_stream)
+            if et is None:
+                check(rc, "dlip_range_scope_end")
+        return False
+
+
+def scoped_eval(fn):
+    """Method decorator: an eval-mode call runs inside a low-side range scope (train mode is left alone: its split operands
+    carry explicit power-of-two scales, deeplip_amd/autograd*.py)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        if getattr(self, "training", False):
+            return fn(self, *a, **k)
+        with range_scope():
+            return fn(self, *a, **k)
+    return wrapper

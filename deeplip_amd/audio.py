@@ -197,6 +197,7 @@ class SpeakerEmbNet(nn.Module):
         xv = ag.linear(h, self.fc2.weight, self.fc2.bias)
         return xv, x_a
 
+    @_lib.scoped_eval
     def extract_embedding(self, x: Tensor, taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
         """[B,F,T] -> (xv [B,E] = fc2 output, x_a [B,E] = fc1 output)   (tdnn.py:89-101)."""
         if self.training:

@@ -30,13 +30,44 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build libdeeplip_hip.so)")
 
 
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "dlip_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv_dma_common.h"),
+                                                       os.path.join(CSRC, "conv_dma_winmode_lab.inc"), os.path.join(ROOT, "include", "deeplip_hip.h")]
+
+
+def source_sha() -> str:
+    """sha256 over every source and header the library is built from (names and bytes, in a fixed order): what
+    dlip_source_sha() of a library built from THIS tree returns."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+_MARK = b"DLIP_SOURCE_SHA="
+
+
+def library_sha(path: str = None) -> str:
+    """The source hash stamped into a built library, read from the file's bytes (no dlopen: a process that already holds an
+    older copy of the library would be handed that one again); '' if the file has none."""
+    try:
+        with open(path or LIB, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return ""
+    i = blob.find(_MARK)
+    return blob[i + len(_MARK): i + len(_MARK) + 64].decode("ascii", "replace") if i >= 0 else ""
+
+
 def needs_build() -> bool:
+    """True unless the library exists AND was built from exactly these sources (hash stamped into it at link time -- file
+    times say nothing once a tree has been copied, checked out or shipped to another box)."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "dlip_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv_dma_common.h"),
-                                                       os.path.join(ROOT, "include", "deeplip_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return library_sha() != source_sha()
 
 
 def build(force: bool = False, verbose: bool = True, lab: bool = False) -> str:
@@ -64,6 +95,14 @@ def _build(LIB: str, extra, verbose: bool, tag: str) -> str:
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
+    # the stamp: a generated translation unit that answers "which sources am I?" (include/deeplip_hip.h: dlip_source_sha)
+    stamp_c = os.path.join(LIBDIR, tag + "stamp.cpp")
+    stamp_o = os.path.join(LIBDIR, tag + "stamp.o")
+    with open(stamp_c, "w") as f:
+        f.write('extern "C" const char* dlip_source_sha(void) { static const char s[] = "DLIP_SOURCE_SHA=%s"; return s + 16; }\n' % source_sha())
+    subprocess.check_call([hipcc, "-O2", "-fPIC", "-c", "-x", "c++", stamp_c, "-o", stamp_o])
+    os.remove(stamp_c)
+    objs.append(stamp_o)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -71,6 +110,21 @@ def _build(LIB: str, extra, verbose: bool, tag: str) -> str:
     for o in objs:
         os.remove(o)
     return LIB
+
+
+def prove_compile(source: str = "capi.hip", verbose: bool = True) -> float:
+    """Compile ONE translation unit of the tree for gfx950 into a scratch object and throw it away: shows that the toolchain
+    and the sources as they lie here still compile, whatever prebuilt library the tree carries.  Returns the seconds taken."""
+    import tempfile
+    import time
+    with tempfile.TemporaryDirectory() as td:
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+               "-c", os.path.join(CSRC, source), "-o", os.path.join(td, "probe.o")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        t0 = time.time()
+        subprocess.check_call(cmd)
+        return time.time() - t0
 
 
 if __name__ == "__main__":

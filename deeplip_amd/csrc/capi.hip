@@ -26,6 +26,61 @@ int32_t* g_status_words = nullptr;
 
 extern "C" int32_t* dlip_status_words(void) { return g_status_words; }
 
+// ---- low-side range scope (include/deeplip_hip.h: dlip_range_scope_begin / _end) ----
+// Thread-local like stream capture: a scope belongs to the host thread that issues the launches of one forward pass.
+namespace {
+struct RangeScope {
+  int32_t* slots = nullptr;
+  int n = 0, cur = 0, depth = 0;
+};
+thread_local RangeScope g_scope;
+
+// One thread per evidence word: bit 1 without bit 0 = the launch's whole tensor lay in (0, 2^-6) -> its kernel family + 1 into
+// the host-pinned word DLIP_ST_LOW (sticky until the host clears it); every word is reset for the scope's next use.
+__global__ __launch_bounds__(256) void range_verdict_kernel(int32_t* slots, int n, int32_t* status) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = slots[i];
+  if (v != 0) slots[i] = 0;
+  if ((v & 3) == 2 && status != nullptr) __hip_atomic_store(status + DLIP_ST_LOW, v >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+DlipRange dlip_range_for(int family) {
+  DlipRange r;
+  if (g_status_words != nullptr) r.status = g_status_words + family;
+  RangeScope& sc = g_scope;
+  if (sc.slots != nullptr && sc.cur < sc.n) r.lo = sc.slots + sc.cur++;
+  r.code = family + 1;
+  return r;
+}
+
+extern "C" int dlip_range_scope_begin(int32_t* slots, int32_t n) {
+  DLIP_CHECK_ARG(slots && n > 0);
+  RangeScope& sc = g_scope;
+  if (sc.depth++ == 0) {
+    sc.slots = slots;
+    sc.n = n;
+    sc.cur = 0;
+  }
+  return DLIP_OK;
+}
+
+extern "C" int dlip_range_scope_end(dlip_stream_t stream) {
+  RangeScope& sc = g_scope;
+  DLIP_CHECK_ARG(sc.depth > 0);
+  if (--sc.depth > 0) return DLIP_OK;          // an inner scope: the outermost one owns the verdict
+  int32_t* slots = sc.slots;
+  const int used = sc.cur;
+  sc = RangeScope{};
+  if (used > 0) {
+    hipLaunchKernelGGL(range_verdict_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), slots, used,
+                       g_status_words);
+    return dlip_launch_status();
+  }
+  return DLIP_OK;
+}
+
 extern "C" int dlip_set_status_words(int32_t* words) {
   g_status_words = words;
   return DLIP_OK;

@@ -351,7 +351,7 @@ int fill_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, con
                                      post_shift, y, Cw, a);
   if (rc != DLIP_OK) return rc;
   a->wscale = w_scale;
-  if (int32_t* st = dlip_status_words()) a->status = st + DLIP_ST_CONV;
+  a->status = dlip_range_for(DLIP_ST_CONV);
   return DLIP_OK;
 }
 

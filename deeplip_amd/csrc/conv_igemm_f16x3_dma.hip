@@ -99,34 +99,15 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   constexpr int STAGE_B = (BM + BN) * ROWB;
   constexpr int LDK = 32;             // dwords per LDS row
   constexpr int PF = NSTAGE - 1;      // slices in flight ahead of the one being multiplied
-  // WINDOW MODE (VAR bit 7; LAB BUILD ONLY -- correct, bit-identical to the ring on every shape tried incl. dilated and 1-D
-  // "valid" convolutions and the balanced split, but 11 % SLOWER than the ring as it stands: 3 570 against 2 720 cycles per
-  // slice on layer 3.  The per-slice bookkeeping of a ROLLED tap loop -- position walk, piece schedule, a counted wait whose
-  // count varies -- is ~50 scalar branches and ~35 vector instructions per slice, the lesson conv_win_f16x3.hip learned at
-  // 1 720 -> 650 cycles per slice by unrolling its nine taps.  Tried next: the taps unrolled here too (3x3 and 1x3 instances,
-  // static ring stages, piece schedule and wait counts; the per-tap addresses kept from being hoisted into 570 B of scratch by
-  // opaque asm) -- still bit-identical and still 13-15 % behind the ring, 2 710 against 2 540 cycles per slice, and 27 % behind
-  // with the barrier behind group 1 as in conv_win.  So neither the bytes nor the bookkeeping is what a 256x128 slice costs:
-  // two lock-stepped waves per SIMD pay ~1 000 cycles of issue + wait + barrier per slice around 1 536 of MFMA whichever way the
-  // operands arrive; conv_win's advantage is its TWO INDEPENDENT workgroups per CU): for stride-1 convolutions whose taps
-  // share rows the activations do not go through the ring.  Per 32-channel slice the workgroup holds ONE window -- the BM + halo consecutive
-  // input pixels its tile touches, one 128-B row each -- every tap reads its fragments there at a row offset, a tap outside the
-  // image reads beyond the LDS allocation (zeros on gfx950: tools/probes/lds_oob.hip), and only the weights are fetched per
-  // slice: 20 KB per 256-row slice instead of 48 -- the L2 -> LDS path, not the matrix core, is what bounds the ring
-  // (DESIGN.md section 4).  Window image: chunk c of window row u at position c ^ (u & 7) -- with THAT key a ds_read_b128
-  // of 16 consecutive rows is bank-conflict free at EVERY row offset (the ring image's key (u >> 1) & 7 is conflict free for
-  // aligned blocks only: 2-way at three offsets of four), and a window piece stays what a ring piece is, 8 whole rows = 8
-  // contiguous 128-B segments (conv_win_f16x3.hip's 16-row-block image is conflict free too, but its pieces are 64 separate
-  // 16-B requests to the address unit: tried here first, 12 % slower than the ring).
-  // Two window slots (the next channel slice's window arrives piece by piece behind the weights of the current one's
-  // taps) + three weight stages; the balanced split, tile order, hand-off and epilogues are the ring kernel's own.
-  constexpr bool WIN = (VAR & 128) != 0;
-  constexpr int WIN_SLACK = 48;            // window rows beyond BM: halo of the taps (+ the image shift of a 1-D "valid" convolution)
-  constexpr int WROWS = BM + WIN_SLACK, WPIECES = WROWS / 8;   // 8 rows per piece
-  constexpr int WPER = (WPIECES + NW - 1) / NW;                // window pieces per wave (the last round is partial)
-  constexpr int SLOT_B = WROWS * ROWB, BST_B = BN * ROWB, B0_OFF = 2 * SLOT_B;
-  static_assert(!WIN || (NW == 8 && NSTAGE == 3 && !DUAL && MI == 4 && WROWS % 8 == 0 && B_PER + 2 * WPER <= 15), "window mode: the 256x128 tile");
-  constexpr int RING_W = B0_OFF + NSTAGE * BST_B > BM * BN * 4 ? B0_OFF + NSTAGE * BST_B : BM * BN * 4;   // (room for the whole fp32 tile image)
+  // (window mode -- VAR bit 7, activations from a per-slice window instead of the ring -- is a lab experiment: conv_dma_winmode_lab.inc)
+#ifdef DLIP_LAB
+#define DLIP_WINMODE_SECTION 1
+#include "conv_dma_winmode_lab.inc"
+#else
+  constexpr bool WIN = false;
+  constexpr int RING_W = 0;
+  static_assert((VAR & 128) == 0, "window mode exists in the lab build only");
+#endif
   constexpr int RING = WIN ? RING_W : NSTAGE * STAGE_B;   // bytes; the epilogue parameter table (5 x BN floats) sits behind it
   constexpr bool ALT = (VAR & 8) != 0;     // alternating issuer halves
   static_assert(!ALT || (NW == 8 && NSTAGE == 3), "alternating issuers: eight waves, three stages");
@@ -191,203 +172,10 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     f32x4 acc[MI][NI];
 #define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
     if constexpr (WIN) {
-      // ================= window mode =================
-      constexpr int MH = MI / 2;
-      char* lds_c = reinterpret_cast<char*>(smem);
-      const int ntaps_w = a.R * a.S;
-      const int m0 = tile_m * BM;
-      const int D = a.H * a.W - a.HoWo;                      // 0 (same-size) or, for a 1-D "valid" convolution, W - Wo per image
-      const int n0 = dlip_div(m0 < a.M ? m0 : a.M - 1, a.div_howo);
-      const int p0 = m0 + n0 * D - (a.ph * a.W + a.pw);      // input pixel of window row 0
-      const int need_rows = BM + (a.R - 1) * a.dh * a.W + (a.S - 1) * a.dw + (D ? ((BM + a.HoWo - 1) / a.HoWo) * D : 0);
-      // this lane's MI fragment pixels: window row at tap (0,0), and the INVERTED tap validity (bit r*S + s set = outside)
-      int ub[MI];
-      uint32_t inv[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * WM + mi * FR + lrow;
-        const int mc = m < a.M ? m : a.M - 1;
-        const int n = dlip_div(mc, a.div_howo);
-        const int rem = mc - n * a.HoWo;
-        const int ho = dlip_div(rem, a.div_wo);
-        const int wo = rem - ho * a.Wo;
-        ub[mi] = (m - m0) + (n - n0) * D;
-        uint32_t colbits = 0u, bits = 0u;
-        for (int sx = 0; sx < a.S; ++sx) colbits |= (uint32_t)((unsigned)(wo - a.pw + sx * a.dw) < (unsigned)a.W) << sx;
-        for (int r = 0; r < a.R; ++r) bits |= ((unsigned)(ho - a.ph + r * a.dh) < (unsigned)a.H ? colbits : 0u) << (r * a.S);
-        inv[mi] = m < a.M ? ~bits : ~0u;
-      }
-      int b_off[B_PER];
-#pragma unroll
-      for (int j = 0; j < B_PER; ++j) {
-        const int n = tile_n * BN + rbase + RPP * j;
-        b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
-      }
-      // issue walk (weights, PF slices ahead) and compute walk (the slice being multiplied)
-      int ic0 = (k0 / ntaps_w) * BK, itap = k0 % ntaps_w;
-      auto issue_b = [&](int stage) {
-        const uint32_t base = piece0 + B0_OFF + stage * BST_B;
-        const int w_tap = (itap * a.Cw + ic0) * 4;
-#pragma unroll
-        for (int j = 0; j < B_PER; ++j)
-          dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
-      };
-      auto iadvance = [&]() { if (++itap == ntaps_w) { itap = 0; ic0 += BK; } };
-      // window piece q (rows 8 q .. 8 q + 7) of channel slice cc -> slot; lane (row tid >> 3 & 7, position cq) fetches chunk cq ^ row
-      auto issue_win = [&](int slot, int cc, int q) {
-        const int wr8 = (tid >> 3) & 7, wrow = q * 8 + wr8;
-        const bool ok = q < WPIECES && wrow < need_rows;     // (a pixel before / behind the tensor: offset out of range -> zeros)
-        if (q < WPIECES)                                     // (wave-uniform: the last round of pieces is partial)
-          dma_piece(xr, ok ? (uint32_t)(((p0 + wrow) * a.ldx + cc * BK) * 4 + ((cq ^ wr8) << 4)) : DLIP_OOB_OFFSET,
-                    lds0 + slot * SLOT_B + q * 1024);
-      };
-      int cc = k0 / ntaps_w, tapc = k0 % ntaps_w;            // compute walk: channel slice, tap
-      int sc = tapc % a.S, urow = (tapc / a.S) * a.dh * a.W; // its column position and row shift (pixels)
-      int cslot = 0;                                         // window slot of channel slice cc
-      int wq = 0;                                            // pieces of the NEXT channel slice's window this wave has issued
-      int a_hi[MI], a_lo[MI];                                 // fragment addresses: hi chunk `half`, lo chunk 4 + half (= the hi position ^ 4)
-      const bool flat = D == 0;                               // (workgroup-uniform) the lane's MI pixels are 16 window rows apart
-      auto set_addr = [&](int ushift, int slot, int tapbit) {
-        if (flat) {   // rows u + 16 mi share their key (u & 7): one address, MI constant offsets
-          const int u = ub[0] + ushift;
-          const int a0 = (u << 7) + (((u & 7) ^ half) << 4) + slot * SLOT_B;
-          const int dlo = (u & 4) ? -64 : 64;
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            a_hi[mi] = (a0 + mi * 2048) | (int)(((inv[mi] >> tapbit) & 1u) << 18);
-            a_lo[mi] = a_hi[mi] + dlo;
-          }
-        } else {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            const int u = ub[mi] + ushift;
-            a_hi[mi] = ((u << 7) + (((u & 7) ^ half) << 4) + slot * SLOT_B) | (int)(((inv[mi] >> tapbit) & 1u) << 18);
-            a_lo[mi] = a_hi[mi] ^ 64;
-          }
-        }
-      };
-      const int bfw = (wn * WN + lrow) * LDK;
-      f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
-      auto read_first = [&](int stage) {   // activation lo, weight hi
-        const float* Bw = smem + (B0_OFF + stage * BST_B) / 4 + bfw;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fal[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_lo[mi]);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fbh[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + khi);
-      };
-      auto read_rest = [&](int stage) {    // activation hi, weight lo
-        const float* Bw = smem + (B0_OFF + stage * BST_B) / 4 + bfw;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fah[mi] = *reinterpret_cast<const f16x8*>(lds_c + a_hi[mi]);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + klo);
-      };
-      auto mfma_p = [&](int grp, int m0_, int m1_) {
-#pragma unroll
-        for (int mi = m0_; mi < m1_; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            const f16x8 av = grp == 0 ? fal[mi] : fah[mi];
-            const f16x8 bv = grp == 2 ? fbl[ni] : fbh[ni];
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[mi][ni], 0, 0, 0);
-          }
-      };
-      auto wait_dyn = [&](int n) {   // s_waitcnt vmcnt(n), n wave-uniform in [0, 15]
-        switch (n) {
-          case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
-          case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
-          case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
-          case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
-          case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break;
-          default: wait_vmcnt<15>(); break;
-        }
-      };
-
-      // ---- prologue: the first channel slice's window, then the weights of the first PF slices ----
-      DLIP_STAMP(1);
-#pragma unroll
-      for (int j = 0; j < WPER; ++j) issue_win(0, cc, wave + NW * j);
-      issue_b(0);
-      if (kn > 1) { iadvance(); issue_b(1); }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
-      if (tid < BN) {
-        const int k = tile_n * BN + tid;
-        const bool kok = k < a.K;
-        float* tab = smem + RING / 4;
-        tab[tid] = kok ? 1.f / a.wscale[k] : 0.f;   // power of two: exact
-        tab[BN + tid] = (kok && a.bias) ? a.bias[k] : 0.f;
-        tab[2 * BN + tid] = (kok && a.slope) ? a.slope[k] : 1.f;
-        tab[3 * BN + tid] = (kok && a.pscale) ? a.pscale[k] : 1.f;
-        tab[4 * BN + tid] = (kok && a.pshift) ? a.pshift[k] : 0.f;
-      }
-      set_addr(urow + sc * a.dw, cslot, tapc);
-      DLIP_STAMP(2);
-      if (kn > 1) wait_vmcnt<B_PER>(); else wait_vmcnt<0>();   // the window and slice 0's weights have landed
-      __builtin_amdgcn_s_barrier();
-      DLIP_STAMP(3);
-      read_first(0);
-
-      int st_cur = 0, st_iss = kn > 1 ? 2 % NSTAGE : 1 % NSTAGE;
-      int nw_prev = 0;
-      for (int kt = 0; kt < kn; ++kt) {
-        const bool more1 = (kt + 1) < kn, moreP = (kt + PF) < kn;
-        const int st_nxt = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
-        const bool last_tap = tapc + 1 == ntaps_w;
-        // the next channel slice's window: needed iff this segment goes on past the current channel slice
-        const bool reach_next = (kt + (ntaps_w - tapc)) < kn;
-        int nw_cur = 0;
-        DLIP_SSTAMP(0);
-        // ORDER: weights first, window pieces behind them -- the counted wait at a slice's end may leave in flight only what is
-        // YOUNGER than the next slice's weights, and the window piece is the long fetch (first touch).  On a channel slice's
-        // LAST tap the order is reversed: there the wait must cover every piece of the window the next slice reads.
-        const int wmine = wave + NW * (WPER - 1) < WPIECES ? WPER : WPER - 1;   // pieces of a window this wave moves
-        if (last_tap && reach_next && wq < wmine) {
-          for (; wq < wmine; ++wq) issue_win(cslot ^ 1, cc + 1, wave + NW * wq);
-        }
-        if (moreP) { iadvance(); issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; }
-        if (!last_tap && reach_next && wq < wmine) {
-          const int avail = ntaps_w - 1 - tapc;                  // slices before the last tap, this one included (>= 1)
-          const int n = wmine - wq <= avail ? 1 : wmine - wq;    // one piece per slice while that is enough, else all that is left
-          for (int i = 0; i < n; ++i) issue_win(cslot ^ 1, cc + 1, wave + NW * (wq + i));
-          wq += n;
-          nw_cur = n;
-        }
-        DLIP_FENCE();
-        DLIP_SSTAMP(1);
-        read_rest(st_cur); DLIP_FENCE();
-        mfma_p(0, 0, MI); DLIP_FENCE();
-        DLIP_SSTAMP(2);
-        // the next slice's position and fragment addresses, in the shadow of the matrix instructions (fal / fah of this slice
-        // are in registers: the address registers are free)
-        int tapn = tapc + 1, scn = sc + 1, urown = urow, ccn = cc, slotn = cslot;
-        if (scn == a.S) { scn = 0; urown += a.dh * a.W; }
-        if (tapn == ntaps_w) { tapn = 0; scn = 0; urown = 0; ccn = cc + 1; slotn = cslot ^ 1; }
-        mfma_p(1, 0, MI); DLIP_FENCE();
-        mfma_p(2, 0, MH); DLIP_FENCE();
-        DLIP_SSTAMP(3);
-        if (more1) {
-          set_addr(urown + scn * a.dw, slotn, tapn);   // (between the halves of group 1 instead: 9 % slower)
-          const int nb = moreP ? B_PER : 0;
-          wait_dyn(last_tap ? nb : nb + nw_prev + nw_cur);
-          DLIP_SSTAMP(4);
-          __builtin_amdgcn_s_barrier();
-          DLIP_SSTAMP(5);
-          read_first(st_nxt);
-        }
-        DLIP_FENCE();
-        if (MH < MI) mfma_p(2, MH, MI);
-        DLIP_FENCE();
-        DLIP_SSTAMP(6);
-        nw_prev = last_tap ? 0 : nw_cur;
-        if (tapn == 0) wq = 0;
-        tapc = tapn; sc = scn; urow = urown; cc = ccn; cslot = slotn;
-        st_cur = st_nxt;
-      }
+#ifdef DLIP_LAB
+#define DLIP_WINMODE_SECTION 2
+#include "conv_dma_winmode_lab.inc"
+#endif
     } else {
     // Per-row gather state, branch-free: byte offset of the row's window origin and a bit per filter tap
     // that stays inside the image (columns and rows tested separately: R + S steps, not R x S).

@@ -25,14 +25,44 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_dbg_value[DLIP_DBG_COU
 
 // Range-status words (dlip_set_status_words): where the f16x3 kernels report an activation the split format
 // cannot hold.  NULL = not registered (nothing is reported).  One word per kernel family.
-enum { DLIP_ST_CONV = 0, DLIP_ST_STEM = 1, DLIP_ST_PACK = 2, DLIP_ST_POOL = 3, DLIP_ST_COUNT = 4 };
+enum { DLIP_ST_CONV = 0, DLIP_ST_STEM = 1, DLIP_ST_PACK = 2, DLIP_ST_POOL = 3, DLIP_ST_LOW = 4, DLIP_ST_COUNT = 8 };
 extern "C" __attribute__((visibility("hidden"))) int32_t* dlip_status_words(void);
 #define DLIP_F16_OVERFLOW 65520.0f   // the smallest magnitude that rounds to infinity in fp16
+// Low side of the split format.  hi keeps 11 significant bits down to 6.1e-5, but lo = v - hi is ~2^-11 |v|: it is a NORMAL
+// fp16 number only while |v| >= 2^-3, below that a subnormal on the fixed grid 2^-24 -- an absolute error of up to 2^-25 = 3e-8
+// per element, whatever the element's size.  What that costs a contraction depends on the SCALE of the tensor: measured on a
+// 3-layer 3x3 chain of Gaussian activations (tests/test_range_gpu.py) the result is 5.9e-7 off at sigma = 1, 2.8e-5 at sigma =
+// 1e-3 (largest element 4.5e-3) and 3.1e-2 at sigma = 1e-6, i.e. 1e-5 is crossed at a largest element of ~1.2e-2.  A produced
+// tensor whose largest magnitude lies in (0, DLIP_SPLIT_LOW) is therefore REPORTED like an overflow (an all-zero tensor is
+// exact and is not).
+#define DLIP_SPLIT_LOW 0.015625f   // 2^-6
 
-// Called once per wave at the end of a producer of split-format values: amax = the largest |v| the lane converted.
-__device__ __forceinline__ void dlip_report_range(float amax, int32_t* status_word) {
-  if (status_word != nullptr && __builtin_amdgcn_ballot_w64(!(amax < DLIP_F16_OVERFLOW)) != 0ull) {
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(status_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// What a producer of split-format values is handed per launch: the host-pinned overflow word of its kernel family and a
+// device word that collects the launch's low-side evidence (dlip_range_scope_*; NULL outside a scope: low side unguarded).
+struct DlipRange {
+  int32_t* status = nullptr;
+  int32_t* lo = nullptr;
+  int32_t code = 0;        // family + 1, carried in the evidence word's bits 8.. (names the kernel in the error)
+};
+__attribute__((visibility("hidden"))) DlipRange dlip_range_for(int family);
+
+// Called by every wave at the end of a producer of split-format values: amax = the largest |v| the lane converted.
+//   high side: any lane >= 65520 -> 1 into the family's host-pinned word (system scope);
+//   low side : bit 0 of the launch's evidence word = "a wave saw |v| >= 2^-6", bit 1 = "a wave saw 0 < |v| < 2^-6 and nothing
+//              larger"; the scope's verdict kernel (capi.hip) reports the launch iff bit 1 is set and bit 0 is not, i.e. iff the
+//              whole tensor's largest magnitude lies in (0, 2^-6).  One cached load per wave, an atomic only for a new bit.
+__device__ __forceinline__ void dlip_report_range(float amax, const DlipRange r) {
+  if (r.status != nullptr && __builtin_amdgcn_ballot_w64(!(amax < DLIP_F16_OVERFLOW)) != 0ull) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(r.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (r.lo != nullptr) {
+    const bool big = __builtin_amdgcn_ballot_w64(amax >= DLIP_SPLIT_LOW) != 0ull;
+    const bool some = __builtin_amdgcn_ballot_w64(amax > 0.f) != 0ull;
+    const int32_t bits = big ? 1 : (some ? 2 : 0);
+    if ((threadIdx.x & 63) == 0 && bits != 0) {
+      const int32_t cur = __hip_atomic_load(r.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((cur & bits) != bits) __hip_atomic_fetch_or(r.lo, bits | (r.code << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

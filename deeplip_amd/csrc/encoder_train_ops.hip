@@ -221,7 +221,7 @@ __global__ void pow2_finalize_kernel(float* __restrict__ out, float target) {
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void split_pack_scaled_kernel(const f32x4* __restrict__ x, float* __restrict__ y,
-                                                                const float* __restrict__ scale, long long n4, int32_t* status) {
+                                                                const float* __restrict__ scale, long long n4, DlipRange status) {
   const float s = scale[0];
   float amax = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -337,7 +337,7 @@ extern "C" int dlip_split_pack_scaled_f32(const float* x, float* y, const float*
   DLIP_CHECK_ARG(x && y && scale && rows > 0 && C > 0 && (C & 31) == 0);
   const long long n4 = rows * (C / 4);
   hipLaunchKernelGGL(split_pack_scaled_kernel, dim3(grid1d(n4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const f32x4*>(x), y, scale, n4, dlip_status_words() ? dlip_status_words() + DLIP_ST_PACK : nullptr);
+                     reinterpret_cast<const f32x4*>(x), y, scale, n4, dlip_range_for(DLIP_ST_PACK));
   return dlip_launch_status();
 }
 

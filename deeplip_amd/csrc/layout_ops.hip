@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 // x [B,Cc,T] -> y [B,T,Cp] in the split activation format (Cp % 32 == 0, channels Cc..Cp-1 zero): the speech
 // encoder's input adapter and its split in one pass (one 32 x 32 tile per workgroup: 32 frames x one channel block).
 __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                              int Cc, int T, int Cp, int32_t* status) {
+                                                              int Cc, int T, int Cp, DlipRange status) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
@@ -84,7 +84,7 @@ extern "C" int dlip_nct_to_ntc_split_f32(const float* x, float* y, int32_t B, in
   DLIP_CHECK_ARG(x && y && B > 0 && C > 0 && T > 0 && Cp >= C && (Cp & 31) == 0 && B <= 65535);
   dim3 grid((T + 31) / 32, Cp / 32, B);
   hipLaunchKernelGGL(transpose_split_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, C, T, Cp,
-                     dlip_status_words() ? dlip_status_words() + DLIP_ST_PACK : nullptr);
+                     dlip_range_for(DLIP_ST_PACK));
   return dlip_launch_status();
 }
 
@@ -141,7 +141,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // fp32 [rows, C] <-> split format [rows, C/32 blocks, (32 hi halves | 32 lo halves)]  (C % 32 == 0).
 // One thread per 4 channels: 16 B in, 8 B of hi + 8 B of lo out (or the reverse).
 __global__ __launch_bounds__(256) void split_pack_kernel(const f32x4* __restrict__ x, float* __restrict__ y, long long n4,
-                                                         int32_t* status) {
+                                                         DlipRange status) {
   float amax = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const f32x4 v = x[i];
@@ -173,7 +173,7 @@ extern "C" int dlip_split_pack_f32(const float* x, float* y, int64_t rows, int32
   const long long n4 = rows * (C / 4);
   long long g = (n4 + 255) / 256; if (g > 2048) g = 2048;
   hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const f32x4*>(x), y, n4, dlip_status_words() ? dlip_status_words() + DLIP_ST_PACK : nullptr);
+                     reinterpret_cast<const f32x4*>(x), y, n4, dlip_range_for(DLIP_ST_PACK));
   return dlip_launch_status();
 }
 

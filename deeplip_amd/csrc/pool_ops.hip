@@ -9,7 +9,7 @@ namespace {
 // MaxPool3d((1,3,3), s(1,2,2), p(0,1,1)) == per-frame MaxPool2d(3, 2, 1); padding never wins.
 template <bool OSPLIT>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
-                                                           int N, int H, int W, int C4, int Ho, int Wo, int32_t* status) {
+                                                           int N, int H, int W, int C4, int Ho, int Wo, DlipRange status) {
   const long long total = (long long)N * Ho * Wo * C4;
   float amax = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -98,11 +98,12 @@ __global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict
 // split activation format; ldy = 2C rounded up to 32, padding zeroed) for the LDS-DMA GEMM behind it.
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      int T, int C, int ldy, int32_t* status) {
+                                                      int T, int C, int ldy, DlipRange status) {
   __shared__ double part[16][64][2];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int lx = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int c = c0 + lx * 4;
+  float amax = 0.f;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (c < C) {   // C % 4 == 0: a float4 is all inside or all outside
     const float* p = x + (long long)b * T * C + c;
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ 
         _Float16* blk = reinterpret_cast<_Float16*>(y + (long long)b * ldy + (col & ~31));
         blk[col & 31] = hi;
         blk[32 + (col & 31)] = lo;
-        if (!(fabsf(out[h]) < DLIP_F16_OVERFLOW) && status) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        amax = fmaxf(amax, fabsf(out[h]));
+        if (!(fabsf(out[h]) < DLIP_F16_OVERFLOW)) amax = __builtin_inff();   // (a NaN too: fmaxf would drop it)
       } else {
         y[(long long)b * ldy + col] = out[h];
       }
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ 
     blk[col & 31] = (_Float16)0.f;
     blk[32 + (col & 31)] = (_Float16)0.f;
   }
+  if (SPLIT) dlip_report_range(amax, status);
 }
 
 static inline unsigned grid_for(long long total) {
@@ -163,10 +166,10 @@ extern "C" int dlip_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, i
   if (out_split)
     hipLaunchKernelGGL(maxpool3x3s2_kernel<true>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo,
-                       dlip_status_words() ? dlip_status_words() + DLIP_ST_PACK : nullptr);
+                       dlip_range_for(DLIP_ST_PACK));
   else
     hipLaunchKernelGGL(maxpool3x3s2_kernel<false>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo, nullptr);
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), N, H, W, C / 4, Ho, Wo, DlipRange{});
   return dlip_launch_status();
 }
 
@@ -201,10 +204,10 @@ extern "C" int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_
   const dim3 grid((C + 63) / 64, B);
   if (out_split)
     hipLaunchKernelGGL(meanstd_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C,
-                       (2 * C + 31) / 32 * 32, dlip_status_words() ? dlip_status_words() + DLIP_ST_POOL : nullptr);
+                       (2 * C + 31) / 32 * 32, dlip_range_for(DLIP_ST_POOL));
   else
     hipLaunchKernelGGL(meanstd_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C, 2 * C,
-                       (int32_t*)nullptr);
+                       DlipRange{});
   return dlip_launch_status();
 }
 
@@ -273,7 +276,7 @@ namespace {
 // segment 0 if the tile's first row belongs to g, else segment 1.  Tiles are added in row order.
 template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(256) void pool_finish_kernel(const double* __restrict__ part, float* __restrict__ y, long long M,
-                                                          int K, int Kp, int BM, int Gs, int G, int ldy, int32_t* status) {
+                                                          int K, int Kp, int BM, int Gs, int G, int ldy, DlipRange status) {
   const long long total = (long long)G * K;
   float amax = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -335,7 +338,7 @@ extern "C" int dlip_pool_finish_f32(const double* partials, int64_t M, int32_t K
   DLIP_CHECK_ARG(G <= 0x7FFFFFFF);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned grid = grid_for(G * K);
-  int32_t* status = dlip_status_words() ? dlip_status_words() + DLIP_ST_POOL : nullptr;
+  const DlipRange status = (mode == 1 && out_split) ? dlip_range_for(DLIP_ST_POOL) : DlipRange{};   // only a split output is a producer
   if (mode == 0)
     hipLaunchKernelGGL((pool_finish_kernel<0, false>), dim3(grid), dim3(256), 0, st, partials, y, (long long)M, K, Kp, tile_rows,
                        group_rows, (int)G, K, status);

@@ -63,7 +63,7 @@ struct StemArgs {
   int pwp;             // window row pitch in dwords (>= W + 6, == 32 mod 64)
   int Hp, Wp;          // pooled output size (stem + pool kernel)
   int n_frames;        // B*T
-  int32_t* status;     // range-status word (NULL: not reported)
+  DlipRange status;    // range reporting of the split-format output (dlip_common.h)
 #ifdef DLIP_LAB
   unsigned long long* stamps;   // lab build: [grid][8] s_memtime of each workgroup's second tile
 #endif
@@ -331,7 +331,7 @@ __device__ __forceinline__ float dpp_from_right(float v, float edge) {   // lane
 //          ingest_rgb_kernel / crop_norm_kernel (dlip_common.h): bit-identical to ingest -> fp32 -> SRC 0.
 template <int SRC>
 __global__ __launch_bounds__(256) void stem_split_input_kernel(const void* __restrict__ xin, uint32_t* __restrict__ xs, int rows, int H, int W,
-                                                               int pwp, int CH, int Hs, int Ws, int oy, int ox, int32_t* status) {
+                                                               int pwp, int CH, int Hs, int Ws, int oy, int ox, DlipRange status) {
   const int cpr = pwp >> 2;                            // 16-B chunks per row
   const long long total = (long long)rows * cpr;
   float amax = 0.f;
@@ -659,7 +659,7 @@ extern "C" int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, con
   const long long grid = tiles < 256 ? tiles : 256;   // persistent: one workgroup per CU (154 KB of LDS each)
   const size_t ldsb = (size_t)WBYTES + 2 * (size_t)KT * PR * a.pwp * 4;
   auto kern = stem3d_f16x3_kernel;
-  a.status = dlip_status_words() ? dlip_status_words() + DLIP_ST_STEM : nullptr;
+  a.status = dlip_range_for(DLIP_ST_STEM);
   static DlipKernelState ks;   // the attribute is raised once per device and size (not on every launch)
   {
     const int e = ks.ensure_lds(reinterpret_cast<const void*>(kern), ldsb);
@@ -718,7 +718,7 @@ static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws,
   const long long xb = frames * H * a.pwp * 4, yb = frames * a.Hp * a.Wp * 64 * 4;
   if (xb > DLIP_MAX_BUFFER_BYTES || yb > DLIP_MAX_BUFFER_BYTES) return DLIP_ERANGE;
   a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
-  a.status = dlip_status_words() ? dlip_status_words() + DLIP_ST_STEM : nullptr;
+  a.status = dlip_range_for(DLIP_ST_STEM);
   hipStream_t st = static_cast<hipStream_t>(stream);
   {   // pre-pass: the clip as (hi, lo) pairs at the window's row pitch
     const long long chunks = frames * H * (a.pwp / 4);

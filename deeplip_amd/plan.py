@@ -28,7 +28,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 
 from . import holders, ops
-from ._lib import DeepLipHipError, check, check_range, lib
+from ._lib import DeepLipHipError, check, check_range, lib, range_scope, scope_slots
 
 Tensor = torch.Tensor
 
@@ -89,6 +89,7 @@ class StepPlan:
         self.device = self.inputs[0].device if self.inputs else torch.device("cuda", torch.cuda.current_device())
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
         self.arena = Arena()
+        self._range_slots = scope_slots(self.device)
         self._handle = C.c_void_p()
         self.outputs = None
         caller = torch.cuda.current_stream(self.device)
@@ -118,7 +119,10 @@ class StepPlan:
         prev = ops.ARENA
         ops.ARENA = self.arena
         try:
-            return self.fn(*self.inputs)
+            # one low-side range scope per pass over the plan's own evidence words: the verdict kernel is the last launch of
+            # the recorded step, so every replay reports (and re-zeroes) for itself
+            with range_scope(self._range_slots):
+                return self.fn(*self.inputs)
         finally:
             ops.ARENA = prev
 
@@ -146,6 +150,7 @@ class StepPlan:
         if h:
             torch.cuda.synchronize(self.device)
             lib().dlip_plan_destroy(h)
+            check_range()       # a range report of the LAST replay (every earlier one surfaced at the next run())
 
     def __del__(self):
         try:

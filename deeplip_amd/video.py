@@ -451,6 +451,7 @@ class Lipreading(nn.Module):
             y = _tcn_block_train(blk, y, self.tcn_dropout)
         return ag.linear(av.time_mean(y, _lengths_i32(lengths, x.device)), self.tcn.tcn_output.weight, self.tcn.tcn_output.bias)
 
+    @_lib.scoped_eval
     def forward(self, x: Tensor, lengths, taps: Optional[dict] = None, pooled: bool = False):
         """``pooled`` (eval, f16x3 packing, extract path): return the ops.Pooled sums of the last convolution over each
         clip instead of the [B,T,512] features -- what embed() finishes into the per-clip mean."""
@@ -513,6 +514,7 @@ class Lipreading(nn.Module):
             self.extract_feats = ef
         return self.tcn.pooled(feats, lengths, _cached_pack(self, x.device, self._pack)["tcn"])
 
+    @_lib.scoped_eval
     def embed(self, x: Tensor, finish: bool = True):
         """[B,1,T,H,W] -> [B,512]: per-clip temporal mean of the features, the quantity the fusion
         pipeline consumes (train_fusion.py:274,348).  ``finish=False`` may return the means as pooled partial sums

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 19
+#define DLIP_ABI_VERSION 20
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -38,6 +38,9 @@ typedef void* dlip_stream_t; /* hipStream_t */
 typedef void* dlip_plan_t;   /* a recorded step (dlip_plan_end) */
 
 int dlip_abi_version(void);
+/* sha256 (hex) over the sources and headers this library was built from, stamped at link time by deeplip_amd/build.py: the
+ * build check compares it with the tree's own hash, so a stale prebuilt library is rebuilt and a fresh one is proven fresh. */
+const char* dlip_source_sha(void);
 /* Human-readable text for a code returned by any dlip_* call. */
 const char* dlip_error_string(int code);
 
@@ -479,10 +482,25 @@ int dlip_mul_mask_f32(const float* x, const float* mask, float* y, int64_t n, fl
  * DLIP_SPLIT_OUT, dlip_split_pack*_f32, the fused stem + pool, pooling with out_split) stores 1 into its word of
  * a caller-owned status block when it meets such a value; the host reads the words (device memory after a
  * synchronisation, or host-pinned device-visible memory at any time), raises, and the documented recourse is to
- * re-pack that model in the exact "f32" mode (same engine).  words = int32[4] {conv, stem, split_pack, pooling},
- * zeroed by the caller; NULL unregisters (nothing is reported).  One block per process (one process per GPU).
+ * re-pack that model in the exact "f32" mode (same engine).  words = int32[8] {conv, stem, split_pack, pooling, low side (below),
+ * 3 reserved}, zeroed by the caller; NULL unregisters (nothing is reported).  One block per process (one process per GPU).
  * ------------------------------------------------------------------------------------------ */
 int dlip_set_status_words(int32_t* words);
+
+/* The LOW side of that range.  hi keeps 11 significant bits down to 6.1e-5, but lo = v - hi is a normal fp16 number only while
+ * |v| >= 2^-3; below, lo sits on the subnormal grid 2^-24: an absolute error of up to 3e-8 per element, whatever its size.  Measured
+ * on a 3-layer chain of Gaussian activations the result is 5.9e-7 off at sigma 1, 2.8e-5 at sigma 1e-3 (largest element 4.5e-3),
+ * 3.1e-2 at sigma 1e-6.  A checkpoint whose BatchNorm statistics put a whole layer's activations down there would lose
+ * fp32-grade accuracy silently, so a produced tensor whose largest magnitude lies in (0, 2^-6) is reported -- word 4 of the
+ * status block (int32[8]: {conv, stem, split_pack, pooling, LOW, 3 reserved}) receives the kernel family + 1 -- and the host
+ * raises exactly as for an overflow (same recourse: "f32" packing).
+ * Per-launch evidence needs a word per launch: between dlip_range_scope_begin and dlip_range_scope_end (thread-local, may
+ * nest: the outermost pair counts) every producer launched by this thread takes the next word of `slots` (device int32[n],
+ * zeroed once by the caller); _end launches a one-block verdict kernel on `stream` -- which must be ordered behind every launch
+ * of the scope (join side streams first) -- that reports and re-zeroes the words.  Recorded into a step plan the verdict is
+ * part of every replay.  Outside a scope the low side is not guarded (the high side always is). */
+int dlip_range_scope_begin(int32_t* slots, int32_t n);
+int dlip_range_scope_end(dlip_stream_t stream);
 
 /* Diagnostic overrides for tests and A/B runs (the launch path reads no environment variable):
  * key 0 tile of dlip_conv_nhwc_f32 / the register-staged f16x3 kernel, 1 tile of the LDS-DMA kernel,
