@@ -133,7 +133,12 @@ class GradBuckets:
     the world size.  Use ``optimizer.zero_grad(set_to_none=False)`` (or ``buckets.zero()``) so the views survive.
     xGMI is point-to-point (7 links x ~153 GB/s): a ring all-reduce is bound by one link, so buckets are sized for
     a few hundred microseconds each (default 32 MB ~ 0.5 ms at 8 ranks) -- large enough to be bandwidth- rather than
-    latency-bound, small enough that the last one does not stick out behind backward."""
+    latency-bound, small enough that the last one does not stick out behind backward.
+
+    One difference from a single-GPU run to know about: a parameter that NO rank's batch reached keeps an all-zero gradient here
+    (its ``.grad`` is a bucket view, never None), so an optimizer with momentum or weight decay still updates it, where the
+    single-process run -- ``.grad is None`` -- skips it.  The shipped models touch every trainable parameter in every step, so
+    the two coincide; a model with truly conditional parameters should exclude them from weight decay."""
 
     def __init__(self, params, bucket_bytes: int = 32 << 20):
         self.params = [p for p in params if p.requires_grad]

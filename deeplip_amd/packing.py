@@ -190,5 +190,5 @@ def state_version(module: torch.nn.Module, device) -> tuple:
         module.__dict__["_dlip_tensors"] = c
     v = 0
     for t in c[1]:
-        v += t._version
+        v += t._version + (t.data_ptr() & 0xFFFFFFFF)     # in-place updates bump _version; `p.data = other` moves data_ptr
     return (gen, device, PRECISION, v)

@@ -44,6 +44,7 @@ class Arena:
     def __init__(self):
         self.bufs: List[Tensor] = []
         self.keep: list = []          # packed weights and anything else the recorded launches address
+        self.modules: dict = {}       # id(module) -> (module, device, state_version at record time): whose packs those are
         self.mode = "collect"
         self.cursor = 0
 
@@ -131,6 +132,13 @@ class StepPlan:
         which the next run overwrites."""
         if self._gen != holders.PACK_GEN[0]:
             raise StalePlanError("StepPlan: model weights / placement changed since the plan was recorded; record a new plan")
+        # in-place parameter updates (optimizer.step() on an eval-mode model, hand edits, `p.data = ...`) leave the generation
+        # alone but change the fingerprint the eager path compares too: a replay must not run on packs baked from older values
+        from . import packing
+        for module, device, ver in self.arena.modules.values():
+            if packing.state_version(module, device) != ver:
+                raise StalePlanError("StepPlan: a model's parameters were modified in place since the plan was recorded (its packed "
+                                     "weights are stale); record a new plan")
         check_range()           # f16x3 overflow reported by an earlier replay (host read, no synchronisation)
         check(lib().dlip_plan_run(self._handle, torch.cuda.current_stream(self.device).cuda_stream), "dlip_plan_run")
         return self.outputs

@@ -390,6 +390,7 @@ def _cached_pack(module: nn.Module, device, builder):
         module.__dict__["_dlip_pack"] = cache
     if ops.ARENA is not None:
         ops.ARENA.keep.append(cache[1])   # a recorded step addresses these weights: the plan keeps them alive
+        ops.ARENA.modules[id(module)] = (module, device, ver)   # ... and checks on every replay that they still are the weights
     return cache[1]
 
 

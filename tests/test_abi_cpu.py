@@ -28,9 +28,11 @@ def test_library_exports_every_declared_symbol():
 
 def test_binding_matches_header():
     from deeplip_amd import _lib
-    assert sorted(list(_lib.SIGNATURES) + ["dlip_error_string"]) == header_symbols()
+    assert sorted(list(_lib.SIGNATURES) + ["dlip_error_string", "dlip_source_sha"]) == header_symbols()
     l = _lib.lib()
     assert l.dlip_abi_version() == _lib.ABI_VERSION
+    from deeplip_amd import build
+    assert l.dlip_source_sha().decode() == build.source_sha() == build.library_sha()      # the library IS these sources
     assert l.dlip_error_string(0) == b"ok"
     assert b"invalid argument" in l.dlip_error_string(-1)
 

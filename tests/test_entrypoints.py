@@ -23,13 +23,15 @@ def test_train_video_cpu_plumbing(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["full", "full-rgb", "head-only"])
+@pytest.mark.parametrize("mode", ["full", "full-rgb", "head-only", "c1-size"])
 def test_train_video_gpu_two_steps(tmp_path, mode):
     """Default = full-model training as the reference does (model.train(), backward through stem / trunk / TCN on
-    the engine); --head-only = classifier layer on frozen eval-mode features."""
+    the engine); --head-only = classifier layer on frozen eval-mode features.  ``c1-size`` is BASELINE config C1's shape --
+    conf/video_config.json, [4, (3 ->) 1, 29, 88, 88] from uint8 RGB, 54 classes, 2 optimisation steps -- whose "finite loss,
+    logits [4,54]" half can only be computed on the GPU (the CPU run is plumbing-only by design)."""
     import train_video
-    argv = ["--save-path", str(tmp_path / "ck"), "--steps", "2", "--frames", "9"]
-    argv += {"full": [], "full-rgb": ["--rgb"], "head-only": ["--head-only"]}[mode]
+    argv = ["--save-path", str(tmp_path / "ck"), "--steps", "2", "--frames", "29" if mode == "c1-size" else "9"]
+    argv += {"full": [], "full-rgb": ["--rgb"], "head-only": ["--head-only"], "c1-size": ["--rgb"]}[mode]
     loss, shape = train_video.main(argv)
     assert np.isfinite(loss) and shape == (4, 54)
     sd = torch.load(tmp_path / "ck" / "1.pt", map_location="cpu")
@@ -121,6 +123,9 @@ def test_train_audio_loads_reference_style_checkpoints(tmp_path, monkeypatch):
     torch.save({"epoch": 7, "state_dict": {"module." + k: v for k, v in want.items()}, "criterion": tr.criterion.cpu(),
                 "optimizer": {}}, p2)
     tr3 = train_audio.Trainer(overrides=ov)
+    with pytest.raises(RuntimeError, match="pickled objects"):      # a pickled Module executes code on load: refused by default
+        tr3.load(p2)
+    tr3.train_opts["allow_pickled_checkpoints"] = True
     tr3.load(p2)
     assert tr3.current_epoch == 7
     assert torch.equal(tr3.criterion.weights.detach().cpu(), tr.criterion.weights.detach().cpu())

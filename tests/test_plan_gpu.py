@@ -79,6 +79,26 @@ def test_plan_is_stale_after_a_weight_change():
     assert torch.equal(plan2.run(), a)
 
 
+def test_plan_is_stale_after_in_place_edits_too():
+    """What the generation counter does not see -- an optimizer step on an eval-mode model, `p.data = other`, a hand edit --
+    changes the fingerprint the eager path compares (version counters + data pointers): a replay refuses the stale packs."""
+    from deeplip_amd import weightgen as wg
+    from deeplip_amd.plan import StalePlanError, StepPlan
+    video, audio = _models("f32")
+    xa = torch.from_numpy(wg.audio_input(2, 24, 120, key="plan.stale2")).cuda()
+    plan = StepPlan(lambda a: audio.extract_embedding(a)[0], xa)
+    plan.run()
+    with torch.no_grad():
+        audio.fc2.bias.add_(0.5)                                   # in place: _version moves
+    with pytest.raises(StalePlanError, match="in place"):
+        plan.run()
+    plan = StepPlan(lambda a: audio.extract_embedding(a)[0], xa)
+    plan.run()
+    audio.fc2.bias.data = audio.fc2.bias.data.clone() + 1.0         # through .data: only the pointer moves
+    with pytest.raises(StalePlanError, match="in place"):
+        plan.run()
+
+
 def test_pack_cache_sees_in_place_edits():
     """Eager forwards fingerprint the parameters' version counters: an in-place edit without load_state_dict
     (an optimizer step, a broadcast) repacks."""

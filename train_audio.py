@@ -159,7 +159,16 @@ class Trainer(object):
         """Resume from one of this trainer's checkpoints or from a reference one (train_audio.py:234-296): there
         ``criterion`` is the pickled criterion MODULE (train_audio.py:264), and ``net_avg.pth`` (written by
         model_average, :229-232) has neither ``criterion`` nor ``epoch``."""
-        ck = torch.load(resume, map_location="cpu", weights_only=False)
+        try:
+            ck = torch.load(resume, map_location="cpu", weights_only=True)       # tensors and plain containers only
+        except Exception as ex:   # noqa: BLE001 -- torch raises UnpicklingError for anything beyond that
+            # a reference checkpoint pickles the criterion MODULE: loading it executes the pickle, i.e. arbitrary code.
+            # Allowed only on request (train.allow_pickled_checkpoints: True / DLIP_ALLOW_PICKLED_CHECKPOINTS=1).
+            if not (self.train_opts.get("allow_pickled_checkpoints") or os.environ.get("DLIP_ALLOW_PICKLED_CHECKPOINTS") == "1"):
+                raise RuntimeError(f"{resume} holds pickled objects (a reference-style checkpoint stores the criterion module); loading it "
+                                   "runs code from the file. Set train.allow_pickled_checkpoints: True (or "
+                                   "DLIP_ALLOW_PICKLED_CHECKPOINTS=1) if you trust it.") from ex
+            ck = torch.load(resume, map_location="cpu", weights_only=False)
         self.model.load_state_dict({k.replace("module.", "", 1) if k.startswith("module.") else k: v for k, v in ck["state_dict"].items()})
         crit = ck.get("criterion")
         if crit is not None:
@@ -192,6 +201,7 @@ class Trainer(object):
                 xv, _ = self.model.extract_embedding(torch.from_numpy(self.voxtestset.audio(idx)).to(self.device))
                 rows.append(ops.l2_normalize(xv))
         self.table = scoring.EmbeddingTable(self.voxtestset.utt_ids, torch.cat(rows))
+        _lib.check_range(sync=True)       # a range report of the LAST batch must surface here, not at some later call
         return self.table
 
     def eer(self):

@@ -264,6 +264,8 @@ class Trainer(object):
         xv = torch.cat(fv) if fv else torch.empty((0, D), device=self.device)
         em = fusion.fuse_av(xa, xv) if xa.shape[0] else torch.empty((0, 2 * D), device=self.device)  # :353-358
         n = len(dataset)
+        from deeplip_amd import _lib
+        _lib.check_range(sync=True)       # every launch of the extraction has completed: reports of the last batch included
         em, xa, xv = (ddist.gather_rows(t, n) for t in (em, xa, xv))
         return (scoring.EmbeddingTable(dataset.utt_ids, em), scoring.EmbeddingTable(dataset.utt_ids, xa),
                 scoring.EmbeddingTable(dataset.utt_ids, xv))

@@ -116,7 +116,10 @@ def extract_feats(model, clip_thw, device):
     """:99-106: model(FloatTensor(data)[None,None], lengths=[T]) with extract_feats=True."""
     model.eval()
     x = torch.as_tensor(clip_thw, dtype=torch.float32)[None, None].to(device)
-    return model(x, lengths=[x.shape[2]])
+    y = model(x, lengths=[x.shape[2]])
+    from deeplip_amd import _lib
+    _lib.check_range(sync=True)           # the caller consumes y next: a range report of this very forward surfaces now
+    return y
 
 
 def train(model, args, device):
@@ -136,6 +139,10 @@ def train(model, args, device):
     optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=1e-4)                      # (:112-113)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=5, eta_min=4e-08)      # (:114)
     last = None
+    if device.type == "cpu" and rank == 0:
+        print("[plumbing] --device cpu exercises config / collate / optimizer / scheduler / checkpoint plumbing ONLY (BASELINE config C1): the "
+              "engine has no CPU arithmetic path by design, so no forward runs and no loss or logits exist here; the same command on "
+              "--device gpu computes them (C1-size run: tests/test_entrypoints.py::test_train_video_gpu_two_steps[c1-size]).")
     for epoch in range(int(args.maxepoch)):
         run_loss = run_ok = run_n = 0.0
         model.train() if full else model.eval()                                                # (:129)
