@@ -251,7 +251,11 @@ class TDNNBlockTrainFn(Function):
         if Cw != Cx or Cx % 4 or K % 4:
             raise ValueError(f"TDNN train path: channels must match and be multiples of 4 (x {Cx}, weight {Cw}, out {K})")
         w_ksc = _permute3(weight.contiguous(), (0, 2, 1))                      # reference [K,C,S] -> kernel [K,S,C]
-        z = ops.conv1d_ntc(x, w_ksc, bias.contiguous() if bias is not None else None, dilation=dilation)
+        from .autograd_video import conv_train
+        B_, T_, C_in = x.shape
+        z = conv_train(x.view(B_, 1, T_, C_in), w_ksc.view(w_ksc.shape[0], 1, w_ksc.shape[1], w_ksc.shape[2]),
+                       bias.contiguous() if bias is not None else None, (1, 1), (0, 0), (1, dilation))
+        z = z.view(B_, z.shape[2], z.shape[3])
         Tp = z.shape[1]
         y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first)
         ctx.save_for_backward(x, weight, z, gamma, beta, mean, invstd)
@@ -277,7 +281,10 @@ class TDNNBlockTrainFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             w_csk = _permute3(weight.contiguous(), (1, 2, 0), flip_axis=2)     # [K,C,S] -> [C,S',K], taps reversed
-            dx = ops.conv1d_ntc(dz, w_csk, None, dilation=dilation, pad=(S - 1) * dilation)
+            from .autograd_video import conv_train
+            dzc = dz.contiguous()
+            dx = conv_train(dzc.view(B, 1, Tp, K), w_csk.view(Cx, 1, S, K), None, (1, 1), (0, (S - 1) * dilation), (1, dilation), lift=True)
+            dx = dx.view(B, dx.shape[2], Cx)
         dweight = None
         if ctx.needs_input_grad[1]:
             dweight = _conv1d_wgrad(x, dz, S, dilation)
@@ -289,6 +296,11 @@ def _conv1d_wgrad(x, dz, S, dilation):
     B, T, Cx = x.shape
     _, Tp, K = dz.shape
     dev = x.device
+    if Cx % 4 == 0 and K % 4 == 0:
+        # a "valid" 1-D convolution is the H = 1 case of the fused operand path (autograd_video.wgrad_conv_fused)
+        from .autograd_video import wgrad_conv_fused
+        dwt = wgrad_conv_fused(x.contiguous().view(B, 1, T, Cx), dz.contiguous().view(B, 1, Tp, K), 1, S, (1, 1), (0, 0), (1, dilation))
+        return _permute3(dwt, (2, 1, 0))                                       # [S,C,K] -> [K,C,S]
     dzp = torch.zeros((B, T, K), device=dev, dtype=torch.float32)              # rows t >= T' stay zero: no cross-utterance terms
     dzp[:, :Tp].copy_(dz)
     J = B * T - (S - 1) * dilation                                             # rows every tap can read

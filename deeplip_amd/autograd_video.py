@@ -60,6 +60,67 @@ def wgrad_gemm(dz_rows, tap_rows, n_taps):
     return out
 
 
+# Arithmetic of the convolutions of a TRAINING step (forward and data gradient; the weight gradient has always been split-fp16):
+# "f16x3" = the split-fp16 kernels of the extraction path -- activations split once per convolution (dlip_split_pack_f32; a
+# gradient after its power-of-two lift), the CURRENT weights split on the device (dlip_split_weights_rows_f32), fp32 out: 2.6x the
+# rate of the exact-fp32 MFMA kernel at fp32-grade accuracy -- or "f32", the exact kernel (what the training path used before).
+TRAIN_CONV = "f16x3"
+
+
+def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False):
+    """One convolution of a training step on NHWC fp32 ``x`` with CURRENT weights ``w_krsc`` [K,R,S,C] -> fp32 NHWC.
+    ``lift``: x is a gradient (tiny magnitudes): multiply by a power of two into fp16's normal range before the split and
+    divide the result by it (the conv epilogue's post_scale) -- exact."""
+    N, H, W, Cx = x.shape
+    K = w_krsc.shape[0]
+    if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or w_krsc.shape[3] != Cx:
+        return ops.conv_nhwc(x, w_krsc, bias, stride=stride, pad=pad, dil=dil)
+    dev = x.device
+    L = w_krsc.numel() // K
+    ws = torch.empty_like(w_krsc)
+    wsc = torch.empty((K,), device=dev, dtype=torch.float32)
+    check(lib().dlip_split_weights_rows_f32(ptr(w_krsc), ptr(ws), ptr(wsc), K, L, stream_handle()), "dlip_split_weights_rows_f32")
+    if not lift:
+        return ops.conv_nhwc(ops.split_pack(x), ws, bias, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True)
+    scale2 = torch.empty((2,), device=dev, dtype=torch.float32)
+    check(lib().dlip_pow2_scale_f32(ptr(x), ptr(scale2), x.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
+    xs = torch.empty_like(x)
+    check(lib().dlip_split_pack_scaled_f32(ptr(x), ptr(xs), ptr(scale2), x.numel() // Cx, Cx, stream_handle()), "dlip_split_pack_scaled_f32")
+    inv = torch.empty((K,), device=dev, dtype=torch.float32)
+    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    zeros = torch.zeros((K,), device=dev, dtype=torch.float32)
+    return ops.conv_nhwc(xs, ws, None, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True, post_scale=inv, post_shift=zeros)
+
+
+def wgrad_conv_fused(x, dy, R, S, stride, pad, dil):
+    """dW[(tap, c), k] of a Conv2d / Conv1d on NHWC tensors with BOTH operands written by dlip_wgrad_operand_f32: one pass over
+    x (all R*S taps, reduction-major, split) and one over dy (power-of-two lift, reduction-major, split), then the one GEMM.
+    Replaces tap gather + transpose + split (three round trips of a matrix R*S times the activation; 15 of the 61 ms of a
+    B = 32 training step were those passes).  Returns [R*S, C, K]."""
+    N, H, W, Cx = x.shape
+    _, Ho, Wo, K = dy.shape
+    dev = x.device
+    J = N * Ho * Wo
+    J32 = (J + 31) // 32 * 32
+    taps = R * S
+    scale2 = torch.empty((2,), device=dev, dtype=torch.float32)
+    check(lib().dlip_pow2_scale_f32(ptr(dy), ptr(scale2), dy.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
+    dzT_s = torch.empty((K, J32), device=dev, dtype=torch.float32)
+    check(lib().dlip_wgrad_operand_f32(ptr(dy), ptr(dzT_s), N, Ho, Wo, K, K, Ho, Wo, 1, 1, 1, 1, 1, 1, 0, 0, ptr(scale2), stream_handle()),
+          "dlip_wgrad_operand_f32")
+    xT_s = torch.empty((taps * Cx, J32), device=dev, dtype=torch.float32)
+    check(lib().dlip_wgrad_operand_f32(ptr(x), ptr(xT_s), N, H, W, Cx, x.stride(2), Ho, Wo, stride[0], stride[1], R, S, dil[0], dil[1],
+                                       pad[0], pad[1], None, stream_handle()), "dlip_wgrad_operand_f32")
+    inv = torch.empty((K,), device=dev, dtype=torch.float32)
+    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    ones = torch.ones((K,), device=dev, dtype=torch.float32)
+    zeros = torch.zeros((K,), device=dev, dtype=torch.float32)
+    out = torch.empty((taps * Cx, K), device=dev, dtype=torch.float32)
+    ops.conv_nhwc(xT_s.view(1, 1, taps * Cx, J32), dzT_s.view(K, 1, 1, J32), None, w_scale=ones, x_split=True, post_scale=inv,
+                  post_shift=zeros, out=out.view(1, 1, taps * Cx, K))
+    return out.view(taps, Cx, K)
+
+
 class ConvTrainFn(Function):
     """nn.Conv2d / nn.Conv1d (H = 1) on NHWC activations, raw (unfolded) weights in the reference layout
     [K,C,R,S]: forward = the fp32 implicit-GEMM kernel; backward = bias column sum, DATA gradient = the same
@@ -74,7 +135,7 @@ class ConvTrainFn(Function):
         if Cw != Cx or Cx % 4 or K % 4:
             raise ValueError(f"conv train path: channels must match and be multiples of 4 (x {Cx}, weight {Cw}, out {K})")
         w_krsc = _permute3(weight.contiguous().view(K, Cw, R * S), (0, 2, 1)).view(K, R, S, Cw)
-        y = ops.conv_nhwc(x, w_krsc, bias.contiguous() if bias is not None else None, stride=stride, pad=pad, dil=dil)
+        y = conv_train(x, w_krsc, bias.contiguous() if bias is not None else None, stride, pad, dil)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
         return y
@@ -100,12 +161,15 @@ class ConvTrainFn(Function):
                 src = torch.empty((N, Hu, Wu, K), device=dev, dtype=torch.float32)
                 check(lib().dlip_upsample_zero_f32(ptr(dy), ptr(src), N, Ho, Wo, Hu, Wu, K, sh, sw, stream_handle()),
                       "dlip_upsample_zero_f32")
-            dx = ops.conv_nhwc(src, w_crsk, None, pad=(dh * (R - 1) - ph, dw * (S - 1) - pw), dil=(dh, dw))
+            dx = conv_train(src, w_crsk, None, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), lift=True)
         dweight = None
         if ctx.needs_input_grad[1]:
             # all taps side by side in ONE [J, RS*C] matrix -> one GEMM with RS*C output rows (RS times the
             # tiles of a per-tap GEMM: a 64-channel layer would otherwise be a single 64x64 tile)
             taps = R * S
+            if Cx % 4 == 0 and K % 4 == 0:
+                dwt = wgrad_conv_fused(x, dy, R, S, (sh, sw), (ph, pw), (dh, dw))
+                return dx, _permute3(dwt, (2, 1, 0)).view(K, Cx, R, S), dbias, None, None, None
             rows = torch.empty((J, taps * Cx), device=dev, dtype=torch.float32)
             for t in range(taps):
                 r, s = divmod(t, S)

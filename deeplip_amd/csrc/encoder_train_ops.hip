@@ -75,14 +75,33 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
 }
 
 // forward statistics: mean, biased variance -> invstd; running stats with the unbiased variance (torch)
+// Sum of the per-chunk partials {s, q} of 16 channels by one 256-thread workgroup: thread (channel cl = tid & 15, lane group
+// g = tid >> 4) adds chunks g, g + 16, ... in order, the 16 groups meet in LDS and are added in group order -- a fixed
+// association (deterministic bits) with a dependent chain of chunks / 16 loads.  (One thread per channel walking all chunks
+// serially -- 877 of them for layer 1's M = 449 k rows -- took 40-50 us per call, 7 ms of a 61 ms training step.)
+__device__ __forceinline__ bool col_reduce16(const double* __restrict__ part, int C, int chunks, double& s, double& q) {
+  __shared__ double red[16][16][2];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int i = g; i < chunks; i += 16) { a += part[((long long)i * C + c) * 2]; b += part[((long long)i * C + c) * 2 + 1]; }
+  red[g][cl][0] = a; red[g][cl][1] = b;
+  __syncthreads();
+  if (g != 0 || c >= C) return false;
+  s = 0.0; q = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { s += red[i][cl][0]; q += red[i][cl][1]; }
+  return true;
+}
+
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ save_mean,
                                                               float* __restrict__ save_invstd, float* __restrict__ running_mean,
                                                               float* __restrict__ running_var, int M, int C, int chunks,
                                                               float momentum, float eps) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int i = 0; i < chunks; ++i) { s += part[((long long)i * C + c) * 2]; q += part[((long long)i * C + c) * 2 + 1]; }
+  double s, q;
+  if (!col_reduce16(part, C, chunks, s, q)) return;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   const double mean = s / M;
   double var = q / M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -113,10 +132,9 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const f32x4* __restri
 
 __global__ __launch_bounds__(256) void col_finalize_kernel(const double* __restrict__ part, float* __restrict__ out0,
                                                            float* __restrict__ out1, int C, int chunks) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int i = 0; i < chunks; ++i) { s += part[((long long)i * C + c) * 2]; q += part[((long long)i * C + c) * 2 + 1]; }
+  double s, q;
+  if (!col_reduce16(part, C, chunks, s, q)) return;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   if (out0) out0[c] = (float)s;
   if (out1) out1[c] = (float)q;
 }
@@ -237,6 +255,34 @@ __global__ __launch_bounds__(256) void split_pack_scaled_kernel(const f32x4* __r
   dlip_report_range(amax, status);
 }
 
+// Weights of a training step -> the split-fp16 operand image, on the device (packing.split_weights does this once per
+// load_state_dict on the host; under training the weights change every step).  One workgroup per output-channel row [L]:
+// row maximum -> scale[k] = 2^floor(log2(1023 / max)) (lands the row's largest weight in [512, 1024): lo stays a normal fp16
+// down to ~1e-4 of it) -> per 32-value block 32 hi halves | 32 lo halves.  An all-zero row gets scale 1.
+__global__ __launch_bounds__(256) void split_weights_rows_kernel(const float* __restrict__ w, float* __restrict__ ws, float* __restrict__ scale,
+                                                                 int L) {
+  __shared__ float red[4];
+  const float* row = w + (long long)blockIdx.x * L;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < L; i += 256) m = fmaxf(m, fabsf(row[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sc = 1.f;
+  if (m > 0.f && m < 3.0e38f) sc = exp2f(floorf(log2f(1023.0f / m)));
+  if (threadIdx.x == 0) scale[blockIdx.x] = sc;
+  _Float16* out = reinterpret_cast<_Float16*>(ws + (long long)blockIdx.x * L);
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const float t = row[i] * sc;
+    const _Float16 hi = (_Float16)t, lo = (_Float16)(t - (float)hi);
+    const int b = i >> 5, q = i & 31;
+    out[b * 64 + q] = hi;
+    out[b * 64 + 32 + q] = lo;
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_from_scalar_kernel(const float* __restrict__ src, float* __restrict__ y, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) y[i] = src[0];
@@ -263,7 +309,7 @@ extern "C" int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, co
   const int chunks = dlip_bn_rows_chunks(M);
   hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                      nullptr, nullptr, workspace, M, C, slope, act_first);
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, save_mean, save_invstd,
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_invstd,
                      running_mean, running_var, M, C, chunks, momentum, eps);
   const long long n4 = (long long)M * (C / 4);
   hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
@@ -282,7 +328,7 @@ extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const
   const int chunks = dlip_bn_rows_chunks(M);
   hipLaunchKernelGGL(col_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd,
                      gamma, beta, workspace, M, C, slope, act_first);
-  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
+  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
   const long long n4 = (long long)M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                      reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
@@ -297,7 +343,7 @@ extern "C" int dlip_colsum_rows_f32(const float* x, float* y, double* workspace,
   const int chunks = dlip_bn_rows_chunks(M);
   hipLaunchKernelGGL(col_partial_kernel<2>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                      nullptr, nullptr, workspace, M, C, 1.f, 0);
-  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, y, nullptr, C, chunks);
+  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, y, nullptr, C, chunks);
   return dlip_launch_status();
 }
 
@@ -338,6 +384,12 @@ extern "C" int dlip_split_pack_scaled_f32(const float* x, float* y, const float*
   const long long n4 = rows * (C / 4);
   hipLaunchKernelGGL(split_pack_scaled_kernel, dim3(grid1d(n4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const f32x4*>(x), y, scale, n4, dlip_range_for(DLIP_ST_PACK));
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_split_weights_rows_f32(const float* w, float* w_split, float* w_scale, int32_t K, int32_t L, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(w && w_split && w_scale && K > 0 && L > 0 && (L & 31) == 0);
+  hipLaunchKernelGGL(split_weights_rows_kernel, dim3((unsigned)K), dim3(256), 0, static_cast<hipStream_t>(stream), w, w_split, w_scale, L);
   return dlip_launch_status();
 }
 

@@ -42,6 +42,59 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict
   }
 }
 
+// One operand of a weight-gradient GEMM in ONE pass (replaces tap gather -> transpose -> split: three round trips of a matrix
+// RS times the activation).  dW[(tap, c), k] = sum_j x[pixel(j) + tap][c] * dy[j][k] reduces over the J output positions, and
+// the LDS-DMA kernel wants both operands reduction-major in the split format (per row, blocks of 32 consecutive j as 32 hi
+// halves | 32 lo halves).  This kernel reads the NHWC tensor where it lies and writes that image directly:
+//   out[(tap * C + c) * J32 + j]  <-  scale * x[n, ho * sh + r * dh - ph, wo * sw + s * dw - pw, c]   (zero outside the image, j >= J)
+// One workgroup = 32 positions x 32 channels of one tap through a 32 x 33 LDS tile: coalesced 128-B reads along c, whole 128-B
+// split blocks written along j.  With R = S = 1 and no padding it is the dy operand (scale = the gradient's power-of-two lift).
+__global__ __launch_bounds__(256) void wgrad_operand_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int ldx,
+                                                            int C, int Ho, int Wo, int sh, int sw, int S, int dh, int dw, int ph, int pw,
+                                                            long long J, long long J32, const float* __restrict__ scale, DlipRange status) {
+  __shared__ float tile[32][33];
+  const long long j0 = (long long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, tap = blockIdx.z;
+  const int r = tap / S, s_ = tap - r * S;
+  const int oh = r * dh - ph, ow = s_ * dw - pw;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float sc = scale ? scale[0] : 1.f;
+#pragma unroll
+  for (int jj = 0; jj < 32; jj += 8) {
+    const long long j = j0 + ty + jj;
+    float v = 0.f;
+    if (j < J) {
+      const int wo = (int)(j % Wo);
+      const long long t = j / Wo;
+      const int ho = (int)(t % Ho);
+      const long long n = t / Ho;
+      const int hi = ho * sh + oh, wi = wo * sw + ow;
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W && c0 + tx < C) v = x[((n * H + hi) * W + wi) * ldx + c0 + tx] * sc;
+    }
+    tile[ty + jj][tx] = v;
+  }
+  __syncthreads();
+  // write phase: a row's 128-B block = 8 sixteen-byte pieces (4 of hi halves, 4 of lo halves, 8 positions each): thread ->
+  // (channel row cr = tid >> 3, piece pq = tid & 7), one 16-B store each (2-byte stores made this kernel 5.7 ms of a step)
+  float amax = 0.f;
+  {
+    const int cr = threadIdx.x >> 3, pq = threadIdx.x & 7;
+    const int c = c0 + cr;
+    const int jb = (pq & 3) * 8;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = tile[jb + e][cr];
+      const _Float16 hi = (_Float16)v;
+      o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
+      amax = fmaxf(amax, fabsf(v));
+    }
+    if (c < C) *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + ((long long)tap * C + c) * J32 + j0) + (pq < 4 ? 0 : 32) + jb) = o;
+  }
+  dlip_report_range(amax, status);
+}
+
 __global__ __launch_bounds__(256) void upsample_zero_kernel(const f32x4* __restrict__ dz, f32x4* __restrict__ out, int Ho, int Wo,
                                                             int Hu, int Wu, int C4, int sh, int sw, long long n4) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -193,6 +246,18 @@ extern "C" int dlip_tap_gather_f32(const float* x, float* out, int64_t N, int32_
   const long long n4 = (long long)N * Ho * Wo * (C / 4);
   hipLaunchKernelGGL(tap_gather_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), x, out, H, W, ldx, C / 4, Ho, Wo, stride_h,
                      stride_w, off_h, off_w, ldo, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_wgrad_operand_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t Ho,
+                                      int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t R, int32_t S, int32_t dil_h, int32_t dil_w,
+                                      int32_t pad_h, int32_t pad_w, const float* scale, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && out && N > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && Ho > 0 && Wo > 0 && stride_h > 0 &&
+                 stride_w > 0 && R > 0 && S > 0 && R * S <= 65535 && (reinterpret_cast<uintptr_t>(out) & 127) == 0);
+  const long long J = (long long)N * Ho * Wo, J32 = (J + 31) / 32 * 32;
+  DLIP_CHECK_ARG(J32 / 32 <= 0x7FFFFFFFll && (C + 31) / 32 <= 65535);
+  hipLaunchKernelGGL(wgrad_operand_kernel, dim3((unsigned)(J32 / 32), (unsigned)((C + 31) / 32), (unsigned)(R * S)), dim3(256), 0, ST(stream), x, out, H, W,
+                     ldx, C, Ho, Wo, stride_h, stride_w, S, dil_h, dil_w, pad_h, pad_w, J, J32, scale, dlip_range_for(DLIP_ST_PACK));
   return dlip_launch_status();
 }
 
