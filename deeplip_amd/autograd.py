@@ -279,19 +279,21 @@ class TDNNBlockTrainFn(Function):
                   "dlip_colsum_rows_f32")
         dz = dz2.view(B, Tp, K)
         dx = None
+        from .autograd_video import pow2_lift
+        lift = pow2_lift(dz2)                                                  # one absmax pass for dgrad and wgrad alike
         if ctx.needs_input_grad[0]:
             w_csk = _permute3(weight.contiguous(), (1, 2, 0), flip_axis=2)     # [K,C,S] -> [C,S',K], taps reversed
             from .autograd_video import conv_train
             dzc = dz.contiguous()
-            dx = conv_train(dzc.view(B, 1, Tp, K), w_csk.view(Cx, 1, S, K), None, (1, 1), (0, (S - 1) * dilation), (1, dilation), lift=True)
+            dx = conv_train(dzc.view(B, 1, Tp, K), w_csk.view(Cx, 1, S, K), None, (1, 1), (0, (S - 1) * dilation), (1, dilation), lift=True, scale2=lift)
             dx = dx.view(B, dx.shape[2], Cx)
         dweight = None
         if ctx.needs_input_grad[1]:
-            dweight = _conv1d_wgrad(x, dz, S, dilation)
+            dweight = _conv1d_wgrad(x, dz, S, dilation, lift)
         return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def _conv1d_wgrad(x, dz, S, dilation):
+def _conv1d_wgrad(x, dz, S, dilation, lift=None):
     """dW[k,c,s] = sum_{b,t} dz[b,t,k] x[b,t+s*dil,c]  ->  reference layout [K,C,S]."""
     B, T, Cx = x.shape
     _, Tp, K = dz.shape
@@ -299,7 +301,7 @@ def _conv1d_wgrad(x, dz, S, dilation):
     if Cx % 4 == 0 and K % 4 == 0:
         # a "valid" 1-D convolution is the H = 1 case of the fused operand path (autograd_video.wgrad_conv_fused)
         from .autograd_video import wgrad_conv_fused
-        dwt = wgrad_conv_fused(x.contiguous().view(B, 1, T, Cx), dz.contiguous().view(B, 1, Tp, K), 1, S, (1, 1), (0, 0), (1, dilation))
+        dwt = wgrad_conv_fused(x.contiguous().view(B, 1, T, Cx), dz.contiguous().view(B, 1, Tp, K), 1, S, (1, 1), (0, 0), (1, dilation), scale2=lift)
         return _permute3(dwt, (2, 1, 0))                                       # [S,C,K] -> [K,C,S]
     dzp = torch.zeros((B, T, K), device=dev, dtype=torch.float32)              # rows t >= T' stay zero: no cross-utterance terms
     dzp[:, :Tp].copy_(dz)

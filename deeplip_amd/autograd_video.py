@@ -65,9 +65,18 @@ def wgrad_gemm(dz_rows, tap_rows, n_taps):
 # gradient after its power-of-two lift), the CURRENT weights split on the device (dlip_split_weights_rows_f32), fp32 out: 2.6x the
 # rate of the exact-fp32 MFMA kernel at fp32-grade accuracy -- or "f32", the exact kernel (what the training path used before).
 TRAIN_CONV = "f16x3"
+WGRAD_ODD_PITCH = True
 
 
-def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False):
+def pow2_lift(t):
+    """Device pair (2^e, 2^-e) that lifts a gradient tensor's largest magnitude to ~1024 (dlip_pow2_scale_f32): computed ONCE per
+    backward step and shared by the data-gradient convolution and the weight-gradient operand of the same dy."""
+    scale2 = torch.empty((2,), device=t.device, dtype=torch.float32)
+    check(lib().dlip_pow2_scale_f32(ptr(t), ptr(scale2), t.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
+    return scale2
+
+
+def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False, scale2=None):
     """One convolution of a training step on NHWC fp32 ``x`` with CURRENT weights ``w_krsc`` [K,R,S,C] -> fp32 NHWC.
     ``lift``: x is a gradient (tiny magnitudes): multiply by a power of two into fp16's normal range before the split and
     divide the result by it (the conv epilogue's post_scale) -- exact."""
@@ -82,8 +91,8 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
     check(lib().dlip_split_weights_rows_f32(ptr(w_krsc), ptr(ws), ptr(wsc), K, L, stream_handle()), "dlip_split_weights_rows_f32")
     if not lift:
         return ops.conv_nhwc(ops.split_pack(x), ws, bias, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True)
-    scale2 = torch.empty((2,), device=dev, dtype=torch.float32)
-    check(lib().dlip_pow2_scale_f32(ptr(x), ptr(scale2), x.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
+    if scale2 is None:
+        scale2 = pow2_lift(x)
     xs = torch.empty_like(x)
     check(lib().dlip_split_pack_scaled_f32(ptr(x), ptr(xs), ptr(scale2), x.numel() // Cx, Cx, stream_handle()), "dlip_split_pack_scaled_f32")
     inv = torch.empty((K,), device=dev, dtype=torch.float32)
@@ -92,7 +101,7 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
     return ops.conv_nhwc(xs, ws, None, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True, post_scale=inv, post_shift=zeros)
 
 
-def wgrad_conv_fused(x, dy, R, S, stride, pad, dil):
+def wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2=None):
     """dW[(tap, c), k] of a Conv2d / Conv1d on NHWC tensors with BOTH operands written by dlip_wgrad_operand_f32: one pass over
     x (all R*S taps, reduction-major, split) and one over dy (power-of-two lift, reduction-major, split), then the one GEMM.
     Replaces tap gather + transpose + split (three round trips of a matrix R*S times the activation; 15 of the 61 ms of a
@@ -102,14 +111,16 @@ def wgrad_conv_fused(x, dy, R, S, stride, pad, dil):
     dev = x.device
     J = N * Ho * Wo
     J32 = (J + 31) // 32 * 32
+    if WGRAD_ODD_PITCH and (J32 // 32) % 2 == 0:
+        J32 += 32            # an odd number of 128-B blocks per row: the 128 rows a slice touches spread over the memory channels
     taps = R * S
-    scale2 = torch.empty((2,), device=dev, dtype=torch.float32)
-    check(lib().dlip_pow2_scale_f32(ptr(dy), ptr(scale2), dy.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
+    if scale2 is None:
+        scale2 = pow2_lift(dy)
     dzT_s = torch.empty((K, J32), device=dev, dtype=torch.float32)
-    check(lib().dlip_wgrad_operand_f32(ptr(dy), ptr(dzT_s), N, Ho, Wo, K, K, Ho, Wo, 1, 1, 1, 1, 1, 1, 0, 0, ptr(scale2), stream_handle()),
+    check(lib().dlip_wgrad_operand_f32(ptr(dy), ptr(dzT_s), J32, N, Ho, Wo, K, K, Ho, Wo, 1, 1, 1, 1, 1, 1, 0, 0, ptr(scale2), stream_handle()),
           "dlip_wgrad_operand_f32")
     xT_s = torch.empty((taps * Cx, J32), device=dev, dtype=torch.float32)
-    check(lib().dlip_wgrad_operand_f32(ptr(x), ptr(xT_s), N, H, W, Cx, x.stride(2), Ho, Wo, stride[0], stride[1], R, S, dil[0], dil[1],
+    check(lib().dlip_wgrad_operand_f32(ptr(x), ptr(xT_s), J32, N, H, W, Cx, x.stride(2), Ho, Wo, stride[0], stride[1], R, S, dil[0], dil[1],
                                        pad[0], pad[1], None, stream_handle()), "dlip_wgrad_operand_f32")
     inv = torch.empty((K,), device=dev, dtype=torch.float32)
     check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
@@ -153,6 +164,7 @@ class ConvTrainFn(Function):
         dz_rows = dy.view(J, K)
         dbias = _colsum_rows(dz_rows) if has_bias and ctx.needs_input_grad[2] else None
         dx = None
+        lift = pow2_lift(dy) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None   # zero insertion does not change max|dy|
         if ctx.needs_input_grad[0]:
             w_crsk = _permute3(weight.contiguous().view(K, Cx, R * S), (1, 2, 0), flip_axis=2).view(Cx, R, S, K)
             src = dy
@@ -161,14 +173,14 @@ class ConvTrainFn(Function):
                 src = torch.empty((N, Hu, Wu, K), device=dev, dtype=torch.float32)
                 check(lib().dlip_upsample_zero_f32(ptr(dy), ptr(src), N, Ho, Wo, Hu, Wu, K, sh, sw, stream_handle()),
                       "dlip_upsample_zero_f32")
-            dx = conv_train(src, w_crsk, None, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), lift=True)
+            dx = conv_train(src, w_crsk, None, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), lift=True, scale2=lift)
         dweight = None
         if ctx.needs_input_grad[1]:
             # all taps side by side in ONE [J, RS*C] matrix -> one GEMM with RS*C output rows (RS times the
             # tiles of a per-tap GEMM: a 64-channel layer would otherwise be a single 64x64 tile)
             taps = R * S
             if Cx % 4 == 0 and K % 4 == 0:
-                dwt = wgrad_conv_fused(x, dy, R, S, (sh, sw), (ph, pw), (dh, dw))
+                dwt = wgrad_conv_fused(x, dy, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift)
                 return dx, _permute3(dwt, (2, 1, 0)).view(K, Cx, R, S), dbias, None, None, None
             rows = torch.empty((J, taps * Cx), device=dev, dtype=torch.float32)
             for t in range(taps):

@@ -50,37 +50,39 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict
 // One workgroup = 32 positions x 32 channels of one tap through a 32 x 33 LDS tile: coalesced 128-B reads along c, whole 128-B
 // split blocks written along j.  With R = S = 1 and no padding it is the dy operand (scale = the gradient's power-of-two lift).
 __global__ __launch_bounds__(256) void wgrad_operand_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int ldx,
-                                                            int C, int Ho, int Wo, int sh, int sw, int S, int dh, int dw, int ph, int pw,
-                                                            long long J, long long J32, const float* __restrict__ scale, DlipRange status) {
+                                                            int C, int Ho, int Wo, int sh, int sw, int R, int S, int dh, int dw, int ph, int pw,
+                                                            int J, long long ldo, const float* __restrict__ scale, DlipRange status) {
   __shared__ float tile[32][33];
-  const long long j0 = (long long)blockIdx.x * 32;
-  const int c0 = blockIdx.y * 32, tap = blockIdx.z;
-  const int r = tap / S, s_ = tap - r * S;
-  const int oh = r * dh - ph, ow = s_ * dw - pw;
+  const int j0 = blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   const float sc = scale ? scale[0] : 1.f;
+  // this thread's four positions j0 + ty + {0, 8, 16, 24}: pixel origin (tap 0, 0) and image row / column, once for all taps
+  int base[4], hi0[4], wi0[4];
 #pragma unroll
-  for (int jj = 0; jj < 32; jj += 8) {
-    const long long j = j0 + ty + jj;
-    float v = 0.f;
-    if (j < J) {
-      const int wo = (int)(j % Wo);
-      const long long t = j / Wo;
-      const int ho = (int)(t % Ho);
-      const long long n = t / Ho;
-      const int hi = ho * sh + oh, wi = wo * sw + ow;
-      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W && c0 + tx < C) v = x[((n * H + hi) * W + wi) * ldx + c0 + tx] * sc;
-    }
-    tile[ty + jj][tx] = v;
+  for (int q = 0; q < 4; ++q) {
+    const int j = j0 + ty + 8 * q;
+    const int wo = j % Wo, t = j / Wo;
+    const int ho = t % Ho, n = t / Ho;
+    hi0[q] = j < J ? ho * sh - ph : -(1 << 28);       // beyond J: every tap reads "outside the image" -> zeros
+    wi0[q] = wo * sw - pw;
+    base[q] = n * H;
   }
-  __syncthreads();
-  // write phase: a row's 128-B block = 8 sixteen-byte pieces (4 of hi halves, 4 of lo halves, 8 positions each): thread ->
-  // (channel row cr = tid >> 3, piece pq = tid & 7), one 16-B store each (2-byte stores made this kernel 5.7 ms of a step)
+  const int cr = threadIdx.x >> 3, pq = threadIdx.x & 7;    // write phase: channel row, 16-B piece of its 128-B block
+  const int jb = (pq & 3) * 8;
   float amax = 0.f;
-  {
-    const int cr = threadIdx.x >> 3, pq = threadIdx.x & 7;
-    const int c = c0 + cr;
-    const int jb = (pq & 3) * 8;
+  for (int tap = 0; tap < R * S; ++tap) {
+    const int r = tap / S, s_ = tap - r * S;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int hi = hi0[q] + r * dh, wi = wi0[q] + s_ * dw;
+      float v = 0.f;
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W && c0 + tx < C)
+        v = x[((long long)(base[q] + hi) * W + wi) * ldx + c0 + tx] * sc;
+      tile[ty + 8 * q][tx] = v;
+    }
+    __syncthreads();
+    // a row's 128-B block = 8 sixteen-byte pieces (4 of hi halves, 4 of lo halves, 8 positions each): one 16-B store per thread
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     h8 o;
 #pragma unroll
@@ -90,7 +92,9 @@ __global__ __launch_bounds__(256) void wgrad_operand_kernel(const float* __restr
       o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
       amax = fmaxf(amax, fabsf(v));
     }
-    if (c < C) *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + ((long long)tap * C + c) * J32 + j0) + (pq < 4 ? 0 : 32) + jb) = o;
+    if (c0 + cr < C)
+      *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + ((long long)tap * C + c0 + cr) * ldo + j0) + (pq < 4 ? 0 : 32) + jb) = o;
+    __syncthreads();
   }
   dlip_report_range(amax, status);
 }
@@ -249,15 +253,16 @@ extern "C" int dlip_tap_gather_f32(const float* x, float* out, int64_t N, int32_
   return dlip_launch_status();
 }
 
-extern "C" int dlip_wgrad_operand_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t Ho,
-                                      int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t R, int32_t S, int32_t dil_h, int32_t dil_w,
-                                      int32_t pad_h, int32_t pad_w, const float* scale, dlip_stream_t stream) {
+extern "C" int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                                      int32_t Ho, int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t R, int32_t S, int32_t dil_h,
+                                      int32_t dil_w, int32_t pad_h, int32_t pad_w, const float* scale, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && out && N > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && Ho > 0 && Wo > 0 && stride_h > 0 &&
-                 stride_w > 0 && R > 0 && S > 0 && R * S <= 65535 && (reinterpret_cast<uintptr_t>(out) & 127) == 0);
-  const long long J = (long long)N * Ho * Wo, J32 = (J + 31) / 32 * 32;
-  DLIP_CHECK_ARG(J32 / 32 <= 0x7FFFFFFFll && (C + 31) / 32 <= 65535);
-  hipLaunchKernelGGL(wgrad_operand_kernel, dim3((unsigned)(J32 / 32), (unsigned)((C + 31) / 32), (unsigned)(R * S)), dim3(256), 0, ST(stream), x, out, H, W,
-                     ldx, C, Ho, Wo, stride_h, stride_w, S, dil_h, dil_w, pad_h, pad_w, J, J32, scale, dlip_range_for(DLIP_ST_PACK));
+                 stride_w > 0 && R > 0 && S > 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0);
+  const long long J = (long long)N * Ho * Wo;
+  DLIP_CHECK_ARG(J < (1ll << 28) && (long long)N * H < (1ll << 30) && ld_out >= J && (ld_out & 31) == 0 && (C + 31) / 32 <= 65535);
+  hipLaunchKernelGGL(wgrad_operand_kernel, dim3((unsigned)(ld_out / 32), (unsigned)((C + 31) / 32)), dim3(256), 0, ST(stream), x, out, H, W,
+                     ldx, C, Ho, Wo, stride_h, stride_w, R, S, dil_h, dil_w, pad_h, pad_w, (int)J, (long long)ld_out, scale,
+                     dlip_range_for(DLIP_ST_PACK));
   return dlip_launch_status();
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 22
+#define DLIP_ABI_VERSION 23
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -458,14 +458,15 @@ int dlip_tap_gather_f32(const float* x, float* out, int64_t N, int32_t H, int32_
                         int32_t ldo, dlip_stream_t stream);
 
 /* One operand of the weight-gradient GEMM of a Conv2d / Conv1d in ONE pass (replaces dlip_tap_gather_f32 + dlip_nct_to_ntc_f32 +
- * dlip_split_pack*_f32 on a matrix R*S times the activation): out is [R*S*C rows][J32] floats in the split activation format ALONG
+ * dlip_split_pack*_f32 on a matrix R*S times the activation): out is [R*S*C rows][ld_out] floats in the split activation format ALONG
  * THE REDUCTION -- row (tap, c) holds scale * x[n, ho*stride_h + r*dil_h - pad_h, wo*stride_w + s*dil_w - pad_w, c] for j = (n*Ho +
- * ho)*Wo + wo = 0 .. J-1 (zeros outside the image and for j in J .. J32-1, J32 = J rounded up to 32), 32 consecutive j per 128-byte
- * block (32 hi halves | 32 lo halves).  R = S = 1, no padding, scale = the power-of-two lift of dlip_pow2_scale_f32: the dy operand.
+ * ho)*Wo + wo = 0 .. J-1 (zeros outside the image and for j in J .. ld_out-1), 32 consecutive j per 128-byte block (32 hi halves |
+ * 32 lo halves).  ld_out: row pitch in floats, a multiple of 32, >= J (an ODD number of 128-byte blocks keeps the rows of a slice
+ * off one memory channel).  R = S = 1, no padding, scale = the power-of-two lift of dlip_pow2_scale_f32: the dy operand.
  * out 128-byte aligned; scale a device scalar or NULL (1).  x is [N,H,W,ldx] NHWC (Conv1d: H = 1). */
-int dlip_wgrad_operand_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t Ho,
-                           int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t R, int32_t S, int32_t dil_h, int32_t dil_w,
-                           int32_t pad_h, int32_t pad_w, const float* scale, dlip_stream_t stream);
+int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                           int32_t Ho, int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t R, int32_t S, int32_t dil_h,
+                           int32_t dil_w, int32_t pad_h, int32_t pad_w, const float* scale, dlip_stream_t stream);
 /* out [N,Hu,Wu,C] = dz [N,Ho,Wo,C] with stride-1 zeros inserted (out[n, ho*s, wo*s] = dz[n, ho, wo]): the data
  * gradient of a strided convolution as a stride-1 convolution (resnet.py:9-16 with stride 2). */
 int dlip_upsample_zero_f32(const float* dz, float* out, int64_t N, int32_t Ho, int32_t Wo, int32_t Hu, int32_t Wu,
