@@ -448,6 +448,7 @@ def main():
                     help="development: dlip_debug_set(KEY, VALUE) before anything is launched (tile / split / window / tile-order "
                          "choices of the convolution kernels, include/deeplip_hip.h); for whole-step A/B runs on one box -- the line "
                          "then carries `debug`")
+    ap.add_argument("--no-spans", dest="spans", action="store_false", help="do not let the timed plan's conv launches time themselves in-kernel")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the H2D-inclusive leg (value_h2d_inclusive)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher rehearsal on CPU ranks (gloo): stand-in step + the real exchange, one JSON line, no measurement")
@@ -548,11 +549,13 @@ def main():
                     hook.only, hook.enabled = dominant, True
             else:
                 ops.LAUNCH_HOOK = None
-                plan = StepPlan(lambda v, a: local_step(video, audio, v, a), xv, xa, stream=run_stream)
+                plan = StepPlan(lambda v, a: local_step(video, audio, v, a), xv, xa, stream=run_stream, spans=args.spans)
                 run_step = lambda: exchange(plan.run(), world)
             for _ in range(args.warmup):
                 run_step()
             sync_all()
+            if plan is not None and args.spans:
+                plan.span_summary()             # reset: only the timed replays count
             hook.records = []
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
@@ -563,6 +566,9 @@ def main():
             sync_all()
             elapsed = time.perf_counter() - t0
             hook.enabled = False
+            # what the REPLAYED launches of the timed region measured about themselves (in-kernel 100 MHz clock, first workgroup
+            # in -> last workgroup out, per launch; dlip_span_scope_*): warm-up replays are dropped by a reset before the region
+            replayed = plan.span_summary() if (plan is not None and args.spans) else None
             gpu_ms = ev0.elapsed_time(ev1)
             my_elapsed = elapsed
             tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -636,6 +642,14 @@ def main():
                 roof["kernels_ms_sum"] = round(sum(v["ms_per_step"] for v in roof["kernels"].values()), 4)
                 roof["kernels_note"] = ("3 untimed eager single-stream steps after the timed region, every MFMA launch bracketed by HIP events; "
                                         "the timed plan overlaps the two encoders on two streams, so ms_per_step can be below kernels_ms_sum")
+            if replayed:
+                # cross-check carried by the driver's own run: the dominant instance as timed INSIDE the replayed, two-stream timed
+                # region (a launch shares the chip with the other encoder's launches there, so its span is longer than alone)
+                roof["replayed_spans"] = {"note": "in-kernel spans of the LDS-DMA conv launches of the timed plan-replay region (mean over "
+                                                  f"its {args.steps} replays; two streams overlap, so a launch's span includes time shared with the other encoder)",
+                                          "kernels": replayed}
+                if dominant in replayed:
+                    roof["replayed_dominant"] = {"kernel": dominant, **replayed[dominant], "frac": round(replayed[dominant]["tflops"] / peak, 4)}
             if plan is not None:
                 roof["plan_launches"] = plan.launches
                 plan.close()

@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _lock = threading.Lock()
 _lib = None
@@ -44,6 +44,8 @@ SIGNATURES = {
     "dlip_conv_pool_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_pool_finish_f32": [c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_stream],
     "dlip_set_status_words": [c_f],
+    "dlip_span_scope_begin": [c_f, c_f, c_i32],
+    "dlip_span_scope_end": [c_stream, C.POINTER(C.c_int32)],
     "dlip_range_scope_begin": [c_f, c_i32],
     "dlip_range_scope_end": [c_stream],
     "dlip_debug_set": [c_i32, c_i32],

@@ -86,6 +86,54 @@ extern "C" int dlip_set_status_words(int32_t* words) {
   return DLIP_OK;
 }
 
+// ---- span scope: in-kernel timing of the LDS-DMA convolution launches (include/deeplip_hip.h) ----
+namespace {
+struct SpanScope {
+  unsigned long long* pairs = nullptr;
+  unsigned long long* acc = nullptr;
+  int n = 0, cur = 0;
+};
+thread_local SpanScope g_span;
+
+// pair i = {min start, max end} of one launch in 100 MHz ticks -> acc[2 i] += end - start, acc[2 i + 1] += 1; the pair is re-armed
+__global__ __launch_bounds__(256) void span_collect_kernel(unsigned long long* pairs, unsigned long long* acc, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long t0 = pairs[2 * i], t1 = pairs[2 * i + 1];
+  if (t1 != 0ull && t1 >= t0) { acc[2 * i] += t1 - t0; acc[2 * i + 1] += 1ull; }
+  pairs[2 * i] = ~0ull;
+  pairs[2 * i + 1] = 0ull;
+}
+}  // namespace
+
+unsigned long long* dlip_span_next(void) {
+  SpanScope& sc = g_span;
+  if (sc.pairs == nullptr || sc.cur >= sc.n) return nullptr;
+  return sc.pairs + 2 * (sc.cur++);
+}
+
+extern "C" int dlip_span_scope_begin(uint64_t* pairs, uint64_t* acc, int32_t n) {
+  DLIP_CHECK_ARG(pairs && acc && n > 0 && g_span.pairs == nullptr);
+  g_span.pairs = reinterpret_cast<unsigned long long*>(pairs);
+  g_span.acc = reinterpret_cast<unsigned long long*>(acc);
+  g_span.n = n;
+  g_span.cur = 0;
+  return DLIP_OK;
+}
+
+extern "C" int dlip_span_scope_end(dlip_stream_t stream, int32_t* used) {
+  SpanScope sc = g_span;
+  g_span = SpanScope{};
+  DLIP_CHECK_ARG(sc.pairs != nullptr);
+  if (used) *used = sc.cur;
+  if (sc.cur > 0) {
+    hipLaunchKernelGGL(span_collect_kernel, dim3((unsigned)((sc.cur + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), sc.pairs, sc.acc,
+                       sc.cur);
+    return dlip_launch_status();
+  }
+  return DLIP_OK;
+}
+
 // ---- device identity (cached per device) ----
 extern "C" int dlip_device_is_gfx950(void) {
   static std::mutex mu;

@@ -61,6 +61,7 @@ struct StreamK {
   float* slabs;      // [2 * G][BM * BN] fp32
   int* counters;     // [tiles], zero between launches (the finisher resets its tile's word)
   int G;             // workgroups in the grid
+  unsigned long long* span;   // NULL, or this launch's {first workgroup start, last workgroup end} in 100 MHz ticks (dlip_span_scope_*)
 #ifdef DLIP_LAB
   unsigned long long* stamps;   // lab build only: [G][10] s_memtime values of each workgroup's first segment
 #endif
@@ -145,6 +146,10 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const int nk1 = a.nk - (DUAL ? a.nk2 : 0);   // slices of the first source
 
   const long long it_begin = (long long)g * sk.iters / sk.G, it_end = (long long)(g + 1) * sk.iters / sk.G;
+  // In-kernel span of this launch (measurement only, off unless a span scope is open: one scalar test): every workgroup folds the
+  // constant 100 MHz clock into {min at entry, max at exit}; what a replayed step plan cannot give the host (no event
+  // can be read back from a graph) the kernel notes itself.
+  if (sk.span != nullptr && threadIdx.x == 0) atomicMin(sk.span, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #ifdef DLIP_LAB
   if (threadIdx.x == 0 && sk.stamps) sk.stamps[(size_t)g * 10 + 8] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -486,16 +491,22 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         for (int p = gf; p <= gl; ++p) {
           const long long pb = (long long)p * sk.iters / sk.G;
           const __amdgpu_buffer_rsrc_t pr = dlip_make_rsrc(sk.slabs + (size_t)(2 * p + (pb < t0 ? 1 : 0)) * SLAB, SLAB * 4);
+          // a row of NI pieces in flight at a time (one wait per row instead of one per piece: a part cost ~2 us of serial
+          // latency, which capped the parts a tile could usefully have; the sums and their order are unchanged)
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+          for (int mi = 0; mi < MI; ++mi) {
+            f32x4 v[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              f32x4 v = acc[mi][ni];
-              if (p != g) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 16));
-#pragma unroll
-              for (int c = 0; c < 4; ++c) tot[mi][ni][c] = p == gf ? v[c] : tot[mi][ni][c] + v[c];
-              __builtin_amdgcn_sched_barrier(0);
+              v[ni] = acc[mi][ni];
+              if (p != g) v[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 16));
             }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) tot[mi][ni][c] = p == gf ? v[ni][c] : tot[mi][ni][c] + v[ni][c];
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -676,6 +687,10 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #endif
     it += kn;
   }
+  if (sk.span != nullptr && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's stores have left
+    atomicMax(sk.span + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
 #ifdef DLIP_LAB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0 && sk.stamps) {
@@ -745,7 +760,7 @@ struct Workspace {
 };
 constexpr int kMaxSplitTiles = 1 << 16;   // counter words per workspace
 constexpr double kSlotFlops = 0.85e12;    // algorithmic FLOP/s one resident 128x128 workgroup sustains (measured, 2 per CU)
-constexpr int kMaxPartsPerTile = 16;      // balanced split: upper bound on the workgroups sharing one tile
+constexpr int kMaxPartsPerTile = 64;      // balanced split: upper bound on the workgroups sharing one tile (16 before the finisher pipelined its slab reads)
 constexpr double kHandoffUs = 10.0;       // cost of the slab hand-off of a launch at 128x128 tiles (measured)
 constexpr int kMaxDevices = 16;
 
@@ -862,6 +877,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     }
   }
   sk.G = (int)G;
+  sk.span = dlip_span_next();
   // Tile order.  Column block INNER when the whole filter bank stays in an XCD's 4 MiB L2 beside the activation rows in
   // flight (<= 3.25 MB: the TDNN layers incl. tdnn.9's 12 column blocks, layer 3): the column blocks of one row block run
   // back to back, so its activation rows come from HBM once instead of once per column block (tdnn.9 108 -> 98 us,

@@ -116,6 +116,8 @@ struct DlipKernelState {
     return DLIP_OK;
   }
 };
+// Next {start, end} pair of the open span scope (capi.hip: dlip_span_scope_*), or NULL: in-kernel timing of replayed launches.
+__attribute__((visibility("hidden"))) unsigned long long* dlip_span_next(void);
 // 1 when the current device is gfx950 (cached per device; capi.hip).  Kernels that lean on probed gfx950 behaviour (conv_win's
 // out-of-allocation ds_read returning zeros) are only selected there.
 extern "C" __attribute__((visibility("hidden"))) int dlip_device_is_gfx950(void);

@@ -77,10 +77,24 @@ def _flatten(out):
     raise TypeError(f"StepPlan: step function returned {type(out).__name__}; expected tensors")
 
 
+class _NameHook:
+    """ops.LAUNCH_HOOK that only notes (kernel instance, algorithmic FLOPs) per launch, in order."""
+
+    def __init__(self):
+        self.seen: list = []
+
+    def begin(self, name, flops):
+        self.seen.append((name, flops))
+        return None
+
+    def end(self, tok):
+        pass
+
+
 class StepPlan:
     """``fn(*inputs)`` recorded on a private HIP stream; see the module docstring."""
 
-    def __init__(self, fn: Callable, *inputs: Tensor, stream: Optional[torch.cuda.Stream] = None):
+    def __init__(self, fn: Callable, *inputs: Tensor, stream: Optional[torch.cuda.Stream] = None, spans: bool = False):
         for i, t in enumerate(inputs):
             if not (isinstance(t, Tensor) and t.is_cuda):
                 raise DeepLipHipError(f"StepPlan: input {i} must be a CUDA (ROCm) tensor")
@@ -91,6 +105,15 @@ class StepPlan:
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
         self.arena = Arena()
         self._range_slots = scope_slots(self.device)
+        # spans=True: every launch of the LDS-DMA convolution kernel times itself in-kernel on every replay (dlip_span_scope_*);
+        # span_names = those launches in order, as ops.LAUNCH_HOOK names them (instance, algorithmic FLOPs)
+        self._spans = None
+        self.span_names: list = []
+        if spans:
+            n = 256
+            pairs = torch.zeros((n, 2), dtype=torch.int64, device=self.device)
+            pairs[:, 0] = -1                                   # {~0, 0}: armed
+            self._spans = (pairs, torch.zeros((n, 2), dtype=torch.int64, device=self.device), n)
         self._handle = C.c_void_p()
         self.outputs = None
         caller = torch.cuda.current_stream(self.device)
@@ -119,13 +142,28 @@ class StepPlan:
         self.arena.mode, self.arena.cursor = mode, 0
         prev = ops.ARENA
         ops.ARENA = self.arena
+        names = _NameHook() if self._spans is not None else None
+        prev_hook = ops.LAUNCH_HOOK
         try:
-            # one low-side range scope per pass over the plan's own evidence words: the verdict kernel is the last launch of
-            # the recorded step, so every replay reports (and re-zeroes) for itself
-            with range_scope(self._range_slots):
-                return self.fn(*self.inputs)
+            if names is not None:
+                ops.LAUNCH_HOOK = names
+                check(lib().dlip_span_scope_begin(self._spans[0].data_ptr(), self._spans[1].data_ptr(), self._spans[2]), "dlip_span_scope_begin")
+            try:
+                # one low-side range scope per pass over the plan's own evidence words: the verdict kernel is the last launch of
+                # the recorded step, so every replay reports (and re-zeroes) for itself
+                with range_scope(self._range_slots):
+                    out = self.fn(*self.inputs)
+            finally:
+                if names is not None:
+                    used = C.c_int32()
+                    lib().dlip_span_scope_end(torch.cuda.current_stream(self.device).cuda_stream, C.byref(used))
+                    self.span_names = [x for x in names.seen if "conv_igemm_f16x3_dma_kernel" in x[0]]
+                    if len(self.span_names) != used.value:
+                        raise DeepLipHipError(f"StepPlan spans: {used.value} timed launches but {len(self.span_names)} named ones")
+            return out
         finally:
             ops.ARENA = prev
+            ops.LAUNCH_HOOK = prev_hook
 
     def run(self):
         """Replay the step on the current stream (asynchronous); returns the recorded output tensor(s),
@@ -142,6 +180,31 @@ class StepPlan:
         check_range()           # f16x3 overflow reported by an earlier replay (host read, no synchronisation)
         check(lib().dlip_plan_run(self._handle, torch.cuda.current_stream(self.device).cuda_stream), "dlip_plan_run")
         return self.outputs
+
+    def span_summary(self, reset: bool = True) -> dict:
+        """Per kernel instance: launches per replay, replays seen, mean in-kernel span (first workgroup in -> last workgroup out,
+        100 MHz clock) and the algorithmic TFLOP/s over it -- measured by the replayed launches themselves.  Synchronises."""
+        if self._spans is None:
+            return {}
+        torch.cuda.synchronize(self.device)
+        acc = self._spans[1].cpu().numpy()
+        out = {}
+        for i, (name, flops) in enumerate(self.span_names):
+            ticks, cnt = int(acc[i, 0]), int(acc[i, 1])
+            if cnt == 0:
+                continue
+            e = out.setdefault(name, {"launches_per_step": 0, "replays": cnt, "us_sum": 0.0, "flops": 0.0})
+            e["launches_per_step"] += 1
+            e["us_sum"] += ticks / cnt / 100.0          # 100 MHz ticks -> us, mean over the replays
+            e["flops"] += flops
+        for e in out.values():
+            e["avg_launch_us"] = round(e["us_sum"] / e["launches_per_step"], 2)
+            e["tflops"] = round(e["flops"] / (e["us_sum"] * 1e-6) / 1e12, 2)
+            e["us_sum"] = round(e["us_sum"], 2)
+            del e["flops"]
+        if reset:
+            self._spans[1].zero_()
+        return out
 
     def __call__(self, *new_inputs: Tensor):
         if len(new_inputs) != len(self.inputs):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 23
+#define DLIP_ABI_VERSION 24
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -515,6 +515,16 @@ int dlip_set_status_words(int32_t* words);
  * zeroed once by the caller); _end launches a one-block verdict kernel on `stream` -- which must be ordered behind every launch
  * of the scope (join side streams first) -- that reports and re-zeroes the words.  Recorded into a step plan the verdict is
  * part of every replay.  Outside a scope the low side is not guarded (the high side always is). */
+/* Span scope (measurement): what a replayed step plan cannot give the host -- no event recorded into a graph can be read back --
+ * the kernel notes itself.  Between _begin and _end (thread-local, not nestable) every launch of the LDS-DMA convolution kernel
+ * (dlip_conv_nhwc_f16x3 / dlip_conv2_nhwc_f16x3 / dlip_conv_pool_f16x3 on split-format input, not the window kernel) takes the
+ * next {start, end} pair of `pairs` (device uint64[2 n], armed as {~0, 0}); its workgroups fold the constant 100 MHz clock
+ * (s_memrealtime) into it, min at entry and max at exit.  _end launches a collect kernel on `stream` (order it behind the scope's
+ * launches) that adds end - start and 1 into acc[2 i], acc[2 i + 1] (device uint64[2 n], zeroed by the caller) and re-arms the pair
+ * -- recorded into a plan, every replay accumulates; *used = pairs taken.  Outside a scope the kernels time nothing. */
+int dlip_span_scope_begin(uint64_t* pairs, uint64_t* acc, int32_t n);
+int dlip_span_scope_end(dlip_stream_t stream, int32_t* used);
+
 int dlip_range_scope_begin(int32_t* slots, int32_t n);
 int dlip_range_scope_end(dlip_stream_t stream);
 

@@ -176,3 +176,41 @@ def test_extract_pipeline_rows_equal_the_direct_step(precision):
         pipe.close()
     finally:
         packing.set_precision("f32")
+
+
+def test_plan_spans_time_the_replayed_launches():
+    """spans=True: every LDS-DMA convolution launch of the recorded step times itself in-kernel on every replay
+    (dlip_span_scope_*: first workgroup in -> last workgroup out on the constant 100 MHz clock) -- the per-kernel timing a replayed
+    hipGraph cannot give the host.  Results are bit-identical with and without; the spans add up to less than the replay's wall
+    time on one stream and each is a plausible duration."""
+    from deeplip_amd import fusion, packing, weightgen as wg
+    from deeplip_amd.plan import StepPlan
+    try:
+        video, audio = _models("f16x3")
+        xv = torch.from_numpy(wg.video_input(4, frames=29, key="span.video")).cuda()
+        xa = torch.from_numpy(wg.audio_input(4, 24, 300, key="span.audio")).cuda()
+        step = lambda v, a: fusion.embed_av(audio, video, a, v, two_streams=False)
+        ref = StepPlan(step, xv.clone(), xa.clone())
+        want = ref.run().clone()
+        plan = StepPlan(step, xv.clone(), xa.clone(), spans=True)
+        assert plan.launches == ref.launches + 1                   # + the collect kernel
+        assert len(plan.span_names) >= 10 and all("conv_igemm_f16x3_dma_kernel" in n for n, _ in plan.span_names)
+        plan.span_summary()                                        # drop the recording passes
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            out = plan.run()
+        e1.record()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        s = plan.span_summary()
+        assert s and all(v["replays"] == 5 for v in s.values())
+        assert sum(v["launches_per_step"] for v in s.values()) == len(plan.span_names)
+        total_us = sum(v["us_sum"] for v in s.values())
+        wall_us = 1e3 * e0.elapsed_time(e1) / 5
+        assert 0 < total_us < wall_us, (total_us, wall_us)         # one stream: the conv launches are a part of the replay
+        assert all(1.0 < v["avg_launch_us"] < 5e3 for v in s.values())
+        assert plan.span_summary() == {}                           # reset by the previous call
+        plan.close(); ref.close()
+    finally:
+        packing.set_precision("f32")
