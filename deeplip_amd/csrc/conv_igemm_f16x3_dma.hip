@@ -927,8 +927,8 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 // (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
 #ifdef DLIP_LAB
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {256, 128}, {256, 128}, {128, 64}, {64, 128}};   // 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
-constexpr int NUM_DMA_ALL = 10;
+                           {256, 128}, {256, 128}, {128, 64}, {64, 128}, {256, 256}};   // 10: the 256x256 experiment; 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
+constexpr int NUM_DMA_ALL = 11;
 #else
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
 constexpr int NUM_DMA_ALL = 6;
@@ -995,6 +995,7 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 7: return launch_dma<256, 128, 4, 2, 3, 1, 48>(a, st, epi);
     case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
     case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);
+    case 10: return launch_dma<256, 256, 4, 2, 2, 1, 64>(a, st, epi);   // experiment: 64 KB per slice for twice the MFMAs of 256x128 (48 KB)
 #endif
     default:
 #ifdef DLIP_LAB
