@@ -63,16 +63,19 @@ class ExtractPipeline:
         self.launches = self.plans[0].launches
         self.run_stream.synchronize()
 
-    def run(self, batches: Iterable[Sequence[Tensor]], table: Tensor, row0: int = 0) -> int:
-        """Stream ``batches`` (tuples of pinned host tensors shaped like the recorded inputs; the last one may be short) through
-        the plans; batch i's rows land in ``table[row0 + i*B : ...]``.  Asynchronous: returns the number of rows enqueued --
-        call ``finish()`` (or synchronise the device) before reading ``table``."""
+    def run(self, batches: Iterable[Sequence[Tensor]], table, row0: int = 0) -> int:
+        """Stream ``batches`` (tuples of pinned host tensors shaped like the recorded inputs; any of them may be SHORT in its
+        leading dimension -- the last batch of a list) through the plans.  ``table``: one tensor, or one per output of the step
+        function; batch i's rows land in ``table[row0 + i*B : ...]``, as many rows as the batch's FIRST tensor has.  ``batches``
+        may be a generator: the host prepares batch i+2 while the GPU works on i and i+1.  Asynchronous: returns the number of
+        rows enqueued -- call ``finish()`` (or synchronise the device) before reading the tables."""
+        tables = [table] if isinstance(table, Tensor) else list(table)
         n = 0
         for i, hb in enumerate(batches):
             k = i % self.depth
             ins = self.sets[k]
             rows = int(hb[0].shape[0])
-            if rows > self.batch or len(hb) != len(ins):
+            if rows > self.batch or len(hb) != len(ins) or any(int(h.shape[0]) > int(d.shape[0]) for h, d in zip(hb, ins)):
                 raise ValueError("ExtractPipeline: batch does not match the recorded inputs")
             if i >= self.depth:
                 # Bounded run-ahead: the HOST waits here until the replay that read this set has finished, so it is never more
@@ -82,12 +85,16 @@ class ExtractPipeline:
                 self.free[k].synchronize()
             with torch.cuda.stream(self.copy_stream):
                 for dst, src in zip(ins, hb):
-                    (dst if rows == self.batch else dst[:rows]).copy_(src, non_blocking=True)
+                    (dst if src.shape[0] == dst.shape[0] else dst[:src.shape[0]]).copy_(src, non_blocking=True)
                 self.ready[k].record(self.copy_stream)
             with torch.cuda.stream(self.run_stream):
                 self.run_stream.wait_event(self.ready[k])
                 out = self.plans[k].run()
-                table[row0 + n: row0 + n + rows].copy_(out[:rows], non_blocking=True)
+                outs = [out] if isinstance(out, Tensor) else list(out)
+                if len(outs) != len(tables):
+                    raise ValueError(f"ExtractPipeline: the step returns {len(outs)} tensors, {len(tables)} tables given")
+                for t, o in zip(tables, outs):
+                    t[row0 + n: row0 + n + rows].copy_(o[:rows], non_blocking=True)
                 self.free[k].record(self.run_stream)
             n += rows
         return n

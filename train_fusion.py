@@ -252,20 +252,46 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ test-time extraction + scoring
     def _extract(self, dataset, batch=32):
-        """Sharded over ranks; returns (EmbeddingTable of fused [N,1024], audio-only table, video-only table)."""
-        lo, hi = ddist.shard_range(len(dataset))
-        fa, fv = [], []
-        for b0 in range(lo, hi, batch):
-            idx = list(range(b0, min(hi, b0 + batch)))
-            xv_audio, em_video = self._embed_batch(dataset, idx)
-            fa.append(xv_audio); fv.append(em_video)
-        D = self.embedding_dim
-        xa = torch.cat(fa) if fa else torch.empty((0, D), device=self.device)
-        xv = torch.cat(fv) if fv else torch.empty((0, D), device=self.device)
-        em = fusion.fuse_av(xa, xv) if xa.shape[0] else torch.empty((0, 2 * D), device=self.device)  # :353-358
-        n = len(dataset)
+        """Sharded over ranks; returns (EmbeddingTable of fused [N,1024], audio-only table, video-only table).  The reference
+        walks the list one utterance at a time with a `.to(device)` in front of every forward (train_fusion.py:338-358); here
+        the rank's shard streams through deeplip_amd.pipeline.ExtractPipeline: batches of `batch` utterances, the host-to-device
+        copies of batch i+1 behind the replay of batch i (two input sets, one recorded plan each), the embeddings left in HBM."""
         from deeplip_amd import _lib
-        _lib.check_range(sync=True)       # every launch of the extraction has completed: reports of the last batch included
+        from deeplip_amd.pipeline import ExtractPipeline, pin
+        lo, hi = ddist.shard_range(len(dataset))
+        D = self.embedding_dim
+        n_loc = hi - lo
+        xa = torch.empty((n_loc, D), device=self.device)
+        xv = torch.empty((n_loc, D), device=self.device)
+        if n_loc:
+            cpu = dataset.clips                        # clips per utterance (constant over a synthetic set)
+
+            def host_batch(b0):
+                idx = list(range(b0, min(hi, b0 + batch)))
+                clips, ptr = dataset.video(idx)
+                ptr_full = np.full((batch + 1,), ptr[-1], dtype=np.int32)      # a short batch: empty groups behind its last one
+                ptr_full[:len(ptr)] = ptr
+                return (pin(torch.from_numpy(dataset.audio(idx))), pin(torch.from_numpy(clips)), pin(torch.from_numpy(ptr_full)))
+
+            def step(audio, clips, ptr):
+                xv_audio, _ = self.model_audio.extract_embedding(audio)                # train_fusion.py:338
+                em_video = ops.group_mean(self.model_video.embed(clips), ptr)          # :346-349: mean over T, then over clip files
+                return xv_audio, em_video
+
+            first = host_batch(lo)
+            full = tuple(torch.zeros((batch,) + tuple(first[0].shape[1:])) if i == 0 else
+                         torch.zeros((batch * cpu,) + tuple(first[1].shape[1:])) if i == 1 else first[2].clone() for i in range(3))
+            for dst, src in zip(full[:2], first[:2]):
+                dst[:src.shape[0]] = src                                               # the plan is recorded on representative values
+            with torch.no_grad():
+                pipe = ExtractPipeline(step, *(t.to(self.device) for t in full))
+                batches = (first if b0 == lo else host_batch(b0) for b0 in range(lo, hi, batch))
+                pipe.run(batches, (xa, xv))
+                pipe.finish()                          # synchronises; a range report of the last batch surfaces here
+                pipe.close()
+        em = fusion.fuse_av(xa, xv) if n_loc else torch.empty((0, 2 * D), device=self.device)  # :353-358
+        n = len(dataset)
+        _lib.check_range(sync=True)
         em, xa, xv = (ddist.gather_rows(t, n) for t in (em, xa, xv))
         return (scoring.EmbeddingTable(dataset.utt_ids, em), scoring.EmbeddingTable(dataset.utt_ids, xa),
                 scoring.EmbeddingTable(dataset.utt_ids, xv))
