@@ -32,7 +32,7 @@ def _hipcc() -> str:
 
 def _deps():
     return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "dlip_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv_dma_common.h"),
-                                                       os.path.join(CSRC, "conv_dma_winmode_lab.inc"), os.path.join(ROOT, "include", "deeplip_hip.h")]
+                                                       os.path.join(CSRC, "conv_dma_lab.inc"), os.path.join(ROOT, "include", "deeplip_hip.h")]
 
 
 def source_sha() -> str:

@@ -100,10 +100,10 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   constexpr int STAGE_B = (BM + BN) * ROWB;
   constexpr int LDK = 32;             // dwords per LDS row
   constexpr int PF = NSTAGE - 1;      // slices in flight ahead of the one being multiplied
-  // (window mode -- VAR bit 7, activations from a per-slice window instead of the ring -- is a lab experiment: conv_dma_winmode_lab.inc)
+  // (window mode -- VAR bit 7, activations from a per-slice window instead of the ring -- is a lab experiment: conv_dma_lab.inc)
 #ifdef DLIP_LAB
 #define DLIP_WINMODE_SECTION 1
-#include "conv_dma_winmode_lab.inc"
+#include "conv_dma_lab.inc"
 #else
   constexpr bool WIN = false;
   constexpr int RING_W = 0;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     if constexpr (WIN) {
 #ifdef DLIP_LAB
 #define DLIP_WINMODE_SECTION 2
-#include "conv_dma_winmode_lab.inc"
+#include "conv_dma_lab.inc"
 #endif
     } else {
     // Per-row gather state, branch-free: byte offset of the row's window origin and a bit per filter tap
@@ -321,6 +321,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     // ---- main loop: per slice 3 groups of MI x NI instructions.  Group order lo*hi, hi*hi, hi*lo:
     // the last group needs neither the activation-lo nor the weight-hi fragments, so the NEXT slice's first
     // group's fragments are read (behind the barrier) into registers the tail of this slice does not use. ----
+#ifdef DLIP_LAB
+    if constexpr ((VAR & 64) != 0) {   // (lab experiment: the 256x256 tile's half-column loop, conv_dma_lab.inc section 3)
+#define DLIP_WINMODE_SECTION 3
+#include "conv_dma_lab.inc"
+    } else
+#endif
     {
       f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
       auto read_first = [&](int stage) {   // what group 0 needs: activation lo, weight hi
@@ -486,15 +492,16 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // sum the parts in part order (own part from registers): the bits do not depend on who came last
-        f32x4 tot[MI][NI];
-        for (int p = gf; p <= gl; ++p) {
-          const long long pb = (long long)p * sk.iters / sk.G;
-          const __amdgpu_buffer_rsrc_t pr = dlip_make_rsrc(sk.slabs + (size_t)(2 * p + (pb < t0 ? 1 : 0)) * SLAB, SLAB * 4);
-          // a row of NI pieces in flight at a time (one wait per row instead of one per piece: a part cost ~2 us of serial
-          // latency, which capped the parts a tile could usefully have; the sums and their order are unchanged)
+        // sum the parts in part order (own part from registers): the bits do not depend on who came last.  Row block by row
+        // block, in place: one row of NI pieces in flight (one wait per row and part; a part cost ~2 us of serial latency when
+        // every piece was waited for singly), and only 2 NI quads of registers beside the accumulators (a full second copy of
+        // the tile, as before, does not fit once the accumulators are half the register file).  Same sums, same order.
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4 t[NI];
+          for (int p = gf; p <= gl; ++p) {
+            const long long pb = (long long)p * sk.iters / sk.G;
+            const __amdgpu_buffer_rsrc_t pr = dlip_make_rsrc(sk.slabs + (size_t)(2 * p + (pb < t0 ? 1 : 0)) * SLAB, SLAB * 4);
             f32x4 v[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
@@ -504,14 +511,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) tot[mi][ni][c] = p == gf ? v[ni][c] : tot[mi][ni][c] + v[ni][c];
+              for (int c = 0; c < 4; ++c) t[ni][c] = p == gf ? v[ni][c] : t[ni][c] + v[ni][c];
             __builtin_amdgcn_sched_barrier(0);
           }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = t[ni];
         }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = tot[mi][ni];
       }
     }
 
