@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _lock = threading.Lock()
 _lib = None
@@ -115,6 +115,8 @@ SIGNATURES = {
     "dlip_bn1d_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_stream],
     "dlip_bn1d_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_lrelu_bwd_f32": [c_f, c_f, c_f, c_i64, C.c_float, c_stream],
+    "dlip_l1_sum_f32": [c_f, c_f, c_i64, c_stream],
+    "dlip_l1_sign_f32": [c_f, c_f, c_f, C.c_float, c_i64, c_stream],
     "dlip_colsum_f32": [c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_margin_ce_bwd_f32": [c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_f, c_stream],
     "dlip_l2_normalize_bwd_f32": [c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_stream],

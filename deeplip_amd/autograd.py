@@ -183,6 +183,32 @@ def _ws(M: int, C_: int, device):
     return torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 2,), device=device, dtype=torch.float64)
 
 
+class L1NormFn(Function):
+    """coef * ||W||_1 (LMCL's regulariser, loss.py:49-50) and its gradient coef * sign(W): two dlip_* launches instead of
+    torch.norm(W, 1) under autograd."""
+
+    @staticmethod
+    def forward(ctx, w, coef):
+        w = w.contiguous()
+        out = torch.empty((1,), device=w.device, dtype=torch.float32)
+        check(lib().dlip_l1_sum_f32(ptr(w), ptr(out), w.numel(), stream_handle()), "dlip_l1_sum_f32")
+        ctx.save_for_backward(w)
+        ctx.coef = float(coef)
+        return out[0] * float(coef)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        dw = torch.empty_like(w)
+        gs = g.contiguous().view(1)
+        check(lib().dlip_l1_sign_f32(ptr(w), ptr(gs), ptr(dw), ctx.coef, w.numel(), stream_handle()), "dlip_l1_sign_f32")
+        return dw, None
+
+
+def l1_norm(w, coef=1.0):
+    return L1NormFn.apply(w, coef)
+
+
 def _permute3(x, perm, flip_axis=-1):
     d0, d1, d2 = x.shape
     y = torch.empty(tuple(x.shape[p] for p in perm), device=x.device, dtype=torch.float32)

@@ -85,6 +85,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   y[c] = (float)s;
 }
 
+// L1 norm of a weight matrix (the LMCL regulariser 1e-5 * ||W||_1, models/audio_models/loss.py:49-50) and its gradient
+// d(out)/dW = gscale * sign(W).  One workgroup: the tensors are the criterion's [n_spk, 512] (29 k elements); fp64 sum in a
+// fixed order (lane-strided partials, shuffle tree, wave order): deterministic.
+__global__ __launch_bounds__(256) void l1_sum_kernel(const float* __restrict__ w, float* __restrict__ out, long long n) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) s += (double)fabsf(w[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+__global__ __launch_bounds__(256) void l1_sign_kernel(const float* __restrict__ w, const float* __restrict__ gscale, float* __restrict__ dw,
+                                                      float coef, long long n) {
+  const float g = coef * (gscale ? gscale[0] : 1.f);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = w[i];
+    dw[i] = v > 0.f ? g : (v < 0.f ? -g : 0.f);
+  }
+}
+
 // d loss / d logits for loss = mean_b CE(z_b, label_b), z = scale*(logits - margin*onehot) + 1e-8:
 //   dlogits[b,k] = gscale * scale * (softmax(z_b)[k] - [k == label_b]) / B.   One wave per row.
 __global__ __launch_bounds__(256) void margin_ce_bwd_kernel(const float* __restrict__ logits,
@@ -195,6 +218,20 @@ extern "C" int dlip_lrelu_bwd_f32(const float* dy, const float* y, float* dx, in
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y, dx,
                      (long long)n, slope);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_l1_sum_f32(const float* w, float* out, int64_t n, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(w && out && n > 0);
+  hipLaunchKernelGGL(l1_sum_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), w, out, (long long)n);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_l1_sign_f32(const float* w, const float* grad_scale_dev, float* dw, float coef, int64_t n, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(w && dw && n > 0);
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(l1_sign_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                     grad_scale_dev, dw, coef, (long long)n);
   return dlip_launch_status();
 }
 

@@ -32,9 +32,7 @@ class LMCL(nn.Module):
         loss = None
         if labels is not None:
             loss = ops.margin_ce_loss(logits, labels.contiguous(), float(self.s), float(self.margin))
-            # L1 regulariser 1e-5*||W||_1 (loss.py:49-50): a 29k-element reduction, done with the
-            # z-norm kernel's sibling would be overkill -- torch glue, not on the hot path.
-            loss = loss + 0.00001 * w.abs().sum()
+            loss = loss + ops.l1_sum(w) * 0.00001      # L1 regulariser 1e-5*||W||_1 (loss.py:49-50)
         return loss, logits, amax
 
     def forward(self, embeddings, labels):
@@ -42,7 +40,7 @@ class LMCL(nn.Module):
             from . import autograd as ag       # differentiable path (training)
             logits = ag.linear(ag.l2_normalize(embeddings), ag.l2_normalize(self.weights))
             loss = ag.margin_ce_loss(logits, labels, self.s, self.margin)
-            loss = loss + 0.00001 * torch.norm(self.weights, 1)   # L1 term: torch glue (loss.py:49-50)
+            loss = loss + ag.l1_norm(self.weights, 0.00001)       # L1 term (loss.py:49-50)
             return loss, logits
         loss, logits, _ = self.predict(embeddings, labels)
         return loss, logits

@@ -387,6 +387,14 @@ def time_mean(x: Tensor, lengths: Optional[Tensor] = None) -> Tensor:
     return y
 
 
+def l1_sum(w: Tensor) -> Tensor:
+    """sum |w| as a 0-d device tensor (dlip_l1_sum_f32: fp64 accumulation, fixed order)."""
+    _req(w, "w")
+    out = torch.empty((1,), device=w.device, dtype=torch.float32)
+    check(lib().dlip_l1_sum_f32(ptr(w.contiguous()), ptr(out), w.numel(), stream_handle()), "dlip_l1_sum_f32")
+    return out[0]
+
+
 def group_mean(x: Tensor, group_ptr: Tensor) -> Tensor:
     _req(x, "x")
     _req(group_ptr, "group_ptr", torch.int32)

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import ops
+from ._lib import DeepLipHipError
 
 
 class EmbeddingTable:
@@ -66,10 +67,10 @@ class EmbeddingTable:
         if device is not None:
             emb = emb.to(device)
         if groups is not None:
-            if emb.is_cuda:
-                emb = ops.group_mean(emb, torch.tensor(gptr, dtype=torch.int32, device=emb.device))
-            else:   # host-side table (I/O tests): plain mean per group, no engine arithmetic involved
-                emb = torch.stack([emb[a:b].mean(0) for a, b in zip(gptr[:-1], gptr[1:])], 0)
+            if not emb.is_cuda:   # the clip-file mean is arithmetic of the path (utils.py:456-463): it runs on the engine or not at all
+                raise DeepLipHipError("EmbeddingTable.load_npy_tree: averaging clip files per utterance runs on the GPU "
+                                      "(group-mean kernel); pass device=")
+            emb = ops.group_mean(emb, torch.tensor(gptr, dtype=torch.int32, device=emb.device))
         return cls(utt_ids, emb)
 
 

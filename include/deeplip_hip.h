@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 24
+#define DLIP_ABI_VERSION 25
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -369,6 +369,11 @@ int dlip_lrelu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, fl
                        dlip_stream_t stream);
 /* y[c] = sum_m x[m,c]  (bias gradients). */
 int dlip_colsum_f32(const float* x, float* y, int32_t M, int32_t C, dlip_stream_t stream);
+/* out[0] = sum |w[i]| (fp64 accumulation, fixed order) -- the L1 regulariser of LMCL, 1e-5 * ||W||_1 (models/audio_models/loss.py:
+ * 49-50); dlip_l1_sign_f32: dw[i] = coef * grad_scale_dev[0] * sign(w[i]) (grad_scale_dev NULL: 1), its gradient. */
+int dlip_l1_sum_f32(const float* w, float* out, int64_t n, dlip_stream_t stream);
+int dlip_l1_sign_f32(const float* w, const float* grad_scale_dev, float* dw, float coef, int64_t n, dlip_stream_t stream);
+
 /* dlogits = grad_scale * grad_scale_dev[0] * d/dlogits mean_b CE(scale*(logits - margin*onehot) + 1e-8, labels);
  * grad_scale_dev = the upstream gradient of the scalar loss as a DEVICE scalar (NULL = 1): autograd's backward
  * does not have to read it back to the host. */

@@ -62,4 +62,6 @@ def test_without_a_gpu_the_children_fail_not_the_launcher():
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
     assert "must be launched with" not in r.stderr
-    assert r.stderr.count("needs a ROCm GPU") == 2                 # said by both RANKS, inside the job
+    assert "torch.distributed.run" in r.stderr                      # the job was started ...
+    assert r.stderr.count("needs a ROCm GPU") >= 1                 # ... and it is a RANK that says so (torchrun may stop the other
+                                                                   # rank before it gets to print the same)
