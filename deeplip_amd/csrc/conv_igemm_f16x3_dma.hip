@@ -325,6 +325,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     if constexpr ((VAR & 64) != 0) {   // (lab experiment: the 256x256 tile's half-column loop, conv_dma_lab.inc section 3)
 #define DLIP_WINMODE_SECTION 3
 #include "conv_dma_lab.inc"
+    } else if constexpr ((VAR & 256) != 0) {   // (lab experiment: ping-pong halves, conv_dma_lab.inc section 4)
+#define DLIP_WINMODE_SECTION 4
+#include "conv_dma_lab.inc"
     } else
 #endif
     {
@@ -932,8 +935,8 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 // (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
 #ifdef DLIP_LAB
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {256, 128}, {256, 128}, {128, 64}, {64, 128}, {256, 256}};   // 10: the 256x256 experiment; 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
-constexpr int NUM_DMA_ALL = 11;
+                           {256, 128}, {256, 128}, {128, 64}, {64, 128}, {256, 256}, {256, 128}, {256, 128}};   // 12: 11 with priority; 10: the 256x256 experiment; 11: ping-pong 256x128; 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
+constexpr int NUM_DMA_ALL = 13;
 #else
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
 constexpr int NUM_DMA_ALL = 6;
@@ -1000,6 +1003,8 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 7: return launch_dma<256, 128, 4, 2, 3, 1, 48>(a, st, epi);
     case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
     case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);
+    case 12: return launch_dma<256, 128, 4, 2, 3, 1, 768>(a, st, epi);   // 11 + s_setprio 2 around the matrix phase
+    case 11: return launch_dma<256, 128, 4, 2, 3, 1, 256>(a, st, epi);   // experiment: ping-pong halves (matrix beside memory on every SIMD)
     case 10: return launch_dma<256, 256, 4, 2, 2, 1, 64>(a, st, epi);   // experiment: 64 KB per slice for twice the MFMAs of 256x128 (48 KB)
 #endif
     default:
