@@ -19,7 +19,9 @@
 //   * Padding taps, rows past M and weight rows past K use the out-of-range buffer offset: an
 //     out-of-range LDS-DMA writes zeros (probed on gfx950: tools/probes/ldsdma_oob.hip).
 //   * NSTAGE-deep LDS ring, slices issued NSTAGE-1 ahead; one raw s_barrier per slice behind a
-//     COUNTED s_waitcnt vmcnt (the newest slices stay in flight across the barrier).
+//     COUNTED s_waitcnt vmcnt (the newest slices stay in flight across the barrier).  The eight-wave
+//     256x128 tile instead runs its two halves of waves half a slice apart (PING-PONG, two barriers per
+//     slice: one half multiplies while the other reads fragments, issues pieces and waits) -- see its loop.
 //   * The DMA is issued from inline asm: hipcc would otherwise order every later ds_read behind it
 //     with vmcnt(0) (it cannot tell the stages apart) and serialise the ring.
 //   * Matrix instruction: v_mfma_f32_16x16x32_f16, one per 32-channel slice and 16x16 block (the shape
@@ -111,6 +113,10 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #endif
   constexpr int RING = WIN ? RING_W : NSTAGE * STAGE_B;   // bytes; the epilogue parameter table (5 x BN floats) sits behind it
   constexpr bool ALT = (VAR & 8) != 0;     // alternating issuer halves
+  // The eight-wave 256x128 tile runs the ping-pong main loop (below); VAR bit 10 keeps the lock-step loop (lab reference),
+  // bit 9 drops the matrix phase's priority (lab).
+  constexpr bool PINGPONG = BM == 256 && BN == 128 && NW == 8 && NSTAGE == 3 && (VAR & ~512) == 0;
+  constexpr bool PP_PRIO = (VAR & 512) == 0;
   static_assert(!ALT || (NW == 8 && NSTAGE == 3), "alternating issuers: eight waves, three stages");
   constexpr int AQ = ALT ? 2 * A_PER : A_PER, BQ = ALT ? 2 * B_PER : B_PER;   // rows a lane addresses: its own passes (+ its partner wave's)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -325,11 +331,108 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     if constexpr ((VAR & 64) != 0) {   // (lab experiment: the 256x256 tile's half-column loop, conv_dma_lab.inc section 3)
 #define DLIP_WINMODE_SECTION 3
 #include "conv_dma_lab.inc"
-    } else if constexpr ((VAR & 256) != 0) {   // (lab experiment: ping-pong halves, conv_dma_lab.inc section 4)
-#define DLIP_WINMODE_SECTION 4
-#include "conv_dma_lab.inc"
     } else
 #endif
+    if constexpr (PINGPONG) {
+      // PING-PONG main loop (round 3; the eight-wave 256x128 tile).  The loop below (still what the four-wave tiles run) keeps the
+      // two waves of a SIMD in LOCK STEP: both read their
+      // fragments, both issue their 48 MFMAs (sharing the matrix pipe: 1 536 cycles for the pair), both wait at vmcnt and at the
+      // slice's barrier together -- ~650 of a slice's 2 520 cycles in which neither issues an MFMA (in-kernel stamps, DESIGN.md
+      // section 4).  Here the workgroup's two halves -- waves 0-3 ("A") and 4-7 ("B"), one wave of every SIMD in each
+      // (MI355X_MICROARCH.md, item 9: split SIMD partners by wave number >= NW/2) -- run the SAME slice half a period apart, two
+      // barriers per slice: while one half issues its 48 MFMAs alone on its SIMDs (768 cycles, nothing else in its stream), the
+      // other does everything that is not matrix work: the 16 fragment reads of its next MFMA phase, its 6 LDS-DMA pieces two
+      // slices ahead, its vmcnt wait.  Matrix beside memory in every interval (item 5: a rendezvous pays when the paired
+      // intervals are complementary).
+      //   interval between barriers   b(2s-1) .. b(2s)      |  b(2s) .. b(2s+1)
+      //   half A                      LOAD(s)               |  MFMA(s), wait slice s+1
+      //   half B                      MFMA(s-1)             |  LOAD(s), wait slice s+1
+      //   LOAD(s) = issue this wave's pieces of slice s+2 (stage (s+2) % 3 = that of slice s-1, whose last reader -- B's LOAD(s-1)
+      //             -- finished before b(2s-1)), read every fragment of slice s (stage s % 3) into registers, lgkmcnt(0).
+      //   "wait slice s+1": this wave's pieces of slice s+1 have landed (vmcnt leaves only slice s+2's NL younger ones), so that
+      //             behind the next barrier the whole stage of slice s+1 is complete for whichever half reads it first.
+      // Accumulation order per accumulator is the product's (lo*hi, hi*hi, hi*lo per slice): bit-identical results.
+      static_assert(NW == 8 && NSTAGE == 3 && !ALT, "ping-pong: eight waves, three stages");
+      const bool half_b = wave >= NW / 2;            // (wave-uniform)
+      f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
+      auto read_all = [&](int stage) {
+        const float* Aw = smem + stage * (STAGE_B / 4) + a_frag;
+        const float* Bw = smem + stage * (STAGE_B / 4) + b_frag;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fal[mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 16 * LDK + klo);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fbh[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + khi);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fah[mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 16 * LDK + khi);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + klo);
+      };
+      auto mfma_all = [&]() {
+        if constexpr (PP_PRIO) __builtin_amdgcn_s_setprio(2);   // the matrix phase outranks its SIMD partner's load phase
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const f16x8 av = grp == 0 ? fal[mi] : fah[mi];
+              const f16x8 bv = grp == 2 ? fbl[ni] : fbh[ni];
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[mi][ni], 0, 0, 0);
+            }
+          DLIP_FENCE();
+        }
+        if constexpr (PP_PRIO) __builtin_amdgcn_s_setprio(0);
+      };
+      int st_iss = (PF > 1 && kn > 1) ? 2 % NSTAGE : 1 % NSTAGE;   // stage the next issue goes to (the prologue issued slices 0, 1)
+      auto load_phase = [&](int s) {
+        read_all(s % NSTAGE);                        // the reads first: their latency passes under the piece issue below
+        DLIP_FENCE();
+        if (s + 2 < kn) {
+          advance();
+          issue_a(st_iss, own_a); issue_b(st_iss, own_b);
+          st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1;
+        }
+        DLIP_FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage may be refilled behind the next barrier: the reads are done
+        DLIP_FENCE();
+      };
+      auto wait_next = [&](int s) {                  // this wave's pieces of slice s + 1 have landed
+        if (s + 1 < kn) { if (s + 2 < kn) wait_vmcnt<NL>(); else wait_vmcnt<0>(); }
+      };
+      DLIP_STAMP(2);
+      if (PF > 1 && kn > 1) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                  // slice 0 is complete
+      DLIP_STAMP(3);
+      if (!half_b) {
+        for (int s = 0; s < kn; ++s) {
+          const int kt = s;   // (the slice stamps name the slice `kt`)
+          (void)kt;
+          DLIP_SSTAMP(0);
+          load_phase(s);
+          DLIP_SSTAMP(1);
+          __builtin_amdgcn_s_barrier();              // b(2s)
+          DLIP_SSTAMP(2);
+          mfma_all();
+          DLIP_SSTAMP(3);
+          DLIP_SSTAMP(4);
+          __builtin_amdgcn_s_barrier();              // b(2s+1)
+          DLIP_SSTAMP(5);
+          // half A is the FIRST reader of slice s + 1 (right here, in its next load phase): its own pieces of that slice need
+          // to have landed before ITS reads, not before the barrier -- the wait sits behind it (half B reads an interval later)
+          wait_next(s);
+          DLIP_SSTAMP(6);
+        }
+      } else {
+        __builtin_amdgcn_s_barrier();                // b(0): half A reads slice 0 first
+        for (int s = 0; s < kn; ++s) {
+          load_phase(s);
+          wait_next(s);
+          __builtin_amdgcn_s_barrier();              // b(2s+1)
+          mfma_all();
+          if (s + 1 < kn) __builtin_amdgcn_s_barrier();   // b(2s+2)
+        }
+      }
+    } else
     {
       f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
       auto read_first = [&](int stage) {   // what group 0 needs: activation lo, weight hi
@@ -935,7 +1038,7 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 // (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
 #ifdef DLIP_LAB
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {256, 128}, {256, 128}, {128, 64}, {64, 128}, {256, 256}, {256, 128}, {256, 128}};   // 12: 11 with priority; 10: the 256x256 experiment; 11: ping-pong 256x128; 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
+                           {256, 128}, {256, 128}, {128, 64}, {64, 128}, {256, 256}, {256, 128}, {256, 128}};   // 10: the 256x256 experiment; 11: 256x128 with the lock-step loop; 12: ping-pong without priority; 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
 constexpr int NUM_DMA_ALL = 13;
 #else
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
@@ -1003,8 +1106,8 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 7: return launch_dma<256, 128, 4, 2, 3, 1, 48>(a, st, epi);
     case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
     case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);
-    case 12: return launch_dma<256, 128, 4, 2, 3, 1, 768>(a, st, epi);   // 11 + s_setprio 2 around the matrix phase
-    case 11: return launch_dma<256, 128, 4, 2, 3, 1, 256>(a, st, epi);   // experiment: ping-pong halves (matrix beside memory on every SIMD)
+    case 12: return launch_dma<256, 128, 4, 2, 3, 1, 512>(a, st, epi);    // the product's ping-pong loop without s_setprio around the matrix phase
+    case 11: return launch_dma<256, 128, 4, 2, 3, 1, 1024>(a, st, epi);   // the LOCK-STEP loop on 256x128 (the product until round 3): the reference of the ping-pong loop
     case 10: return launch_dma<256, 256, 4, 2, 2, 1, 64>(a, st, epi);   // experiment: 64 KB per slice for twice the MFMAs of 256x128 (48 KB)
 #endif
     default:

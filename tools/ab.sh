@@ -8,6 +8,8 @@ if [ "$1" = snapshot ]; then
   for f in $T/deeplip_amd/csrc/*.hip; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$T/include -I$T/deeplip_amd/csrc -c $f -o $T/$(basename $f .hip).o &
   done; wait
+  echo 'extern "C" const char* dlip_source_sha(void) { return "snapshot"; }' > $T/stamp.cpp
+  /opt/rocm/bin/hipcc -O2 -fPIC -c -x c++ $T/stamp.cpp -o $T/stamp.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/deeplip_amd/lib/libdeeplip_hip_A.so $T/*.o && rm -rf $T
   echo built $R/deeplip_amd/lib/libdeeplip_hip_A.so from HEAD; exit 0
 fi
