@@ -73,9 +73,12 @@ struct StreamK {
 #define DLIP_STAMP(i) do { if (threadIdx.x == 0 && it == it_begin && sk.stamps) sk.stamps[(size_t)g * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 // inside ONE slice (the 9th of each workgroup's first segment): [(G + g) * 10 + i]
 #define DLIP_SSTAMP(i) do { if (threadIdx.x == 0 && it == it_begin && kt == 8 && sk.stamps) sk.stamps[((size_t)sk.G + g) * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// the same slice as seen by wave 4 (the ping-pong loop's half B): [(2 G + g) * 10 + i]
+#define DLIP_BSTAMP(i) do { if (threadIdx.x == 256 && it == it_begin && kt == 8 && sk.stamps) sk.stamps[((size_t)2 * sk.G + g) * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DLIP_STAMP(i) do { } while (0)
 #define DLIP_SSTAMP(i) do { } while (0)
+#define DLIP_BSTAMP(i) do { } while (0)
 #endif
 
 // EPI: what the epilogue does with act(acc / wscale + bias + residual) * post_scale + post_shift
@@ -425,11 +428,19 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       } else {
         __builtin_amdgcn_s_barrier();                // b(0): half A reads slice 0 first
         for (int s = 0; s < kn; ++s) {
+          const int kt = s;
+          (void)kt;
+          DLIP_BSTAMP(0);
           load_phase(s);
+          DLIP_BSTAMP(1);
           wait_next(s);
+          DLIP_BSTAMP(2);
           __builtin_amdgcn_s_barrier();              // b(2s+1)
+          DLIP_BSTAMP(3);
           mfma_all();
+          DLIP_BSTAMP(4);
           if (s + 1 < kn) __builtin_amdgcn_s_barrier();   // b(2s+2)
+          DLIP_BSTAMP(5);
         }
       }
     } else
@@ -818,12 +829,12 @@ template <typename K>
 int dlip_lab_stamped_launch(K kern, unsigned G, int threads, size_t lds, hipStream_t st, const ConvArgs& b, StreamK sk, int BM, int BN) {
   static unsigned long long* dbuf = nullptr;
   static size_t cap = 0;
-  if (cap < (size_t)G * 20) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc(reinterpret_cast<void**>(&dbuf), (size_t)G * 20 * 8); cap = (size_t)G * 20; }
-  (void)hipMemsetAsync(dbuf, 0, (size_t)G * 20 * 8, st);
+  if (cap < (size_t)G * 30) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc(reinterpret_cast<void**>(&dbuf), (size_t)G * 30 * 8); cap = (size_t)G * 30; }
+  (void)hipMemsetAsync(dbuf, 0, (size_t)G * 30 * 8, st);
   sk.stamps = dbuf;
   hipLaunchKernelGGL(kern, dim3(G), dim3(threads), lds, st, b, sk);
   (void)hipStreamSynchronize(st);
-  std::vector<unsigned long long> h((size_t)G * 20);
+  std::vector<unsigned long long> h((size_t)G * 30);
   (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
   std::vector<double> d[5], per, clk, dur;
   unsigned long long t0 = ~0ull, t1 = 0, s1 = 0;
@@ -853,6 +864,16 @@ int dlip_lab_stamped_launch(K kern, unsigned G, int threads, size_t lds, hipStre
   }
   fprintf(stderr, "[slice 8 of the first segment, wave 0] piece issue %.0f  rest reads + group 0 %.0f  group 1 + half of 2 %.0f  vmcnt wait %.0f  barrier %.0f  first reads + rest of group 2 %.0f\n",
           med(e[0]), med(e[1]), med(e[2]), med(e[3]), med(e[4]), med(e[5]));
+  {   // ping-pong loop: the same slice in half B (wave 4); for half A the line above reads: LOAD | barrier | matrix phase | - | barrier | wait
+    std::vector<double> f[5];
+    for (unsigned i = 0; i < G; ++i) {
+      const unsigned long long* r = &h[((size_t)2 * G + i) * 10];
+      if (r[5] && r[0]) for (int j = 0; j < 5; ++j) f[j].push_back((double)(r[j + 1] - r[j]));
+    }
+    if (!f[0].empty())
+      fprintf(stderr, "[ping-pong, the same slice in half B (wave 4)] LOAD %.0f  vmcnt wait %.0f  barrier %.0f  matrix phase %.0f  barrier %.0f\n",
+              med(f[0]), med(f[1]), med(f[2]), med(f[3]), med(f[4]));
+  }
   return dlip_launch_status();
 }
 #endif
