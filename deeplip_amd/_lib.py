@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 25
+ABI_VERSION = 27
 
 _lock = threading.Lock()
 _lib = None
@@ -254,7 +254,8 @@ def check_range(sync: bool = False) -> None:
 
 
 # ---- low-side range scopes: one evidence word per split-producing launch (dlip_range_scope_*) ----
-_SCOPE_SLOTS = 512           # launches per scope (a B = 64 fused step makes ~40)
+_SCOPE_SLOTS = 128           # launches per scope (a B = 64 fused step makes ~40)
+_EVID_WORDS = 1024           # int32 words of evidence per launch (32 cache lines: DLIP_EVID_WORDS)
 _RING_CHUNKS = 16
 _ring = None
 _ring_next = 0
@@ -263,7 +264,7 @@ _scope_depth = threading.local()
 
 def scope_slots(device=None):
     """A zeroed block of evidence words owned by the caller (a StepPlan keeps one for its lifetime)."""
-    return torch.zeros(_SCOPE_SLOTS, dtype=torch.int32, device=device if device is not None else "cuda")
+    return torch.zeros(_EVID_WORDS * _SCOPE_SLOTS, dtype=torch.int32, device=device if device is not None else "cuda")
 
 
 class range_scope:
@@ -289,11 +290,11 @@ class range_scope:
         if slots is None:
             with _lock:
                 if _ring is None or _ring.device.index != torch.cuda.current_device():
-                    _ring = torch.zeros(_RING_CHUNKS * _SCOPE_SLOTS, dtype=torch.int32, device="cuda")
+                    _ring = torch.zeros(_RING_CHUNKS * _EVID_WORDS * _SCOPE_SLOTS, dtype=torch.int32, device="cuda")
                     _ring_next = 0
-                slots = _ring[_ring_next * _SCOPE_SLOTS:(_ring_next + 1) * _SCOPE_SLOTS]
+                slots = _ring[_ring_next * _EVID_WORDS * _SCOPE_SLOTS:(_ring_next + 1) * _EVID_WORDS * _SCOPE_SLOTS]
                 _ring_next = (_ring_next + 1) % _RING_CHUNKS
-        check(lib().dlip_range_scope_begin(slots.data_ptr(), min(_SCOPE_SLOTS, slots.numel())), "dlip_range_scope_begin")
+        check(lib().dlip_range_scope_begin(slots.data_ptr(), min(_SCOPE_SLOTS, slots.numel() // _EVID_WORDS)), "dlip_range_scope_begin")
         return self
 
     def __exit__(self, et, ev, tb):

@@ -35,14 +35,24 @@ struct RangeScope {
 };
 thread_local RangeScope g_scope;
 
-// One thread per evidence word: bit 1 without bit 0 = the launch's whole tensor lay in (0, 2^-6) -> its kernel family + 1 into
-// the host-pinned word DLIP_ST_LOW (sticky until the host clears it); every word is reset for the scope's next use.
-__global__ __launch_bounds__(256) void range_verdict_kernel(int32_t* slots, int n, int32_t* status) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// One thread per launch of the scope, over its DLIP_EVID_LINES lines: flag 1 ("something, all below 2^-6") anywhere without flag 0
+// ("something >= 2^-6") anywhere = the launch's whole tensor lay in (0, 2^-6) -> its kernel family + 1 into the host-pinned
+// word DLIP_ST_LOW (sticky until the host clears it); raised flags are re-zeroed for the scope's next use.
+__global__ __launch_bounds__(64) void range_verdict_kernel(int32_t* slots, int n, int32_t* status) {
+  // one WAVE per launch: lane 2 l + f looks at flag f of line l (a single thread walking the 64 words took 20 us)
+  const int i = blockIdx.x;
   if (i >= n) return;
-  const int32_t v = slots[i];
-  if (v != 0) slots[i] = 0;
-  if ((v & 3) == 2 && status != nullptr) __hip_atomic_store(status + DLIP_ST_LOW, v >> 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  static_assert(DLIP_EVID_LINES == 32, "one lane per (line, flag)");
+  int32_t* w = slots + (size_t)i * DLIP_EVID_WORDS + (threadIdx.x >> 1) * 32 + (threadIdx.x & 1);
+  const int32_t v = *w;
+  if (v != 0) *w = 0;
+  const unsigned long long up = __builtin_amdgcn_ballot_w64(v != 0);
+  const bool big = (up & 0x5555555555555555ull) != 0ull, small = (up & 0xAAAAAAAAAAAAAAAAull) != 0ull;
+  if (small && !big && status != nullptr) {
+    const int lane = __builtin_ctzll(up & 0xAAAAAAAAAAAAAAAAull);       // a lane that holds the family code
+    const int32_t code = __shfl(v, lane, 64);
+    if (threadIdx.x == 0) __hip_atomic_store(status + DLIP_ST_LOW, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 }  // namespace
 
@@ -50,7 +60,7 @@ DlipRange dlip_range_for(int family) {
   DlipRange r;
   if (g_status_words != nullptr) r.status = g_status_words + family;
   RangeScope& sc = g_scope;
-  if (sc.slots != nullptr && sc.cur < sc.n) r.lo = sc.slots + sc.cur++;
+  if (sc.slots != nullptr && sc.cur < sc.n) r.lo = sc.slots + (size_t)DLIP_EVID_WORDS * (sc.cur++);
   r.code = family + 1;
   return r;
 }
@@ -74,8 +84,7 @@ extern "C" int dlip_range_scope_end(dlip_stream_t stream) {
   const int used = sc.cur;
   sc = RangeScope{};
   if (used > 0) {
-    hipLaunchKernelGGL(range_verdict_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), slots, used,
-                       g_status_words);
+    hipLaunchKernelGGL(range_verdict_kernel, dim3((unsigned)used), dim3(64), 0, static_cast<hipStream_t>(stream), slots, used, g_status_words);
     return dlip_launch_status();
   }
   return DLIP_OK;

@@ -37,20 +37,27 @@ extern "C" __attribute__((visibility("hidden"))) int32_t* dlip_status_words(void
 // exact and is not).
 #define DLIP_SPLIT_LOW 0.015625f   // 2^-6
 
-// What a producer of split-format values is handed per launch: the host-pinned overflow word of its kernel family and a
-// device word that collects the launch's low-side evidence (dlip_range_scope_*; NULL outside a scope: low side unguarded).
+// What a producer of split-format values is handed per launch: the host-pinned overflow word of its kernel family and the
+// pair of device words that collects the launch's low-side evidence (dlip_range_scope_*; NULL outside a scope: low side unguarded).
 struct DlipRange {
   int32_t* status = nullptr;
   int32_t* lo = nullptr;
-  int32_t code = 0;        // family + 1, carried in the evidence word's bits 8.. (names the kernel in the error)
+  int32_t code = 0;        // family + 1: the value of a raised evidence flag (names the kernel in the error)
 };
 __attribute__((visibility("hidden"))) DlipRange dlip_range_for(int family);
 
 // Called by every wave at the end of a producer of split-format values: amax = the largest |v| the lane converted.
 //   high side: any lane >= 65520 -> 1 into the family's host-pinned word (system scope);
-//   low side : bit 0 of the launch's evidence word = "a wave saw |v| >= 2^-6", bit 1 = "a wave saw 0 < |v| < 2^-6 and nothing
-//              larger"; the scope's verdict kernel (capi.hip) reports the launch iff bit 1 is set and bit 0 is not, i.e. iff the
-//              whole tensor's largest magnitude lies in (0, 2^-6).  One cached load per wave, an atomic only for a new bit.
+//   low side : the launch owns DLIP_EVID_LINES cache lines of evidence; in each, word 0 = "a wave saw |v| >= 2^-6", word 1 = "a wave
+//              saw 0 < |v| < 2^-6 and nothing larger"; the scope's verdict kernel (capi.hip) ORs the lines and reports the launch
+//              iff flag 1 is set and flag 0 is not, i.e. iff the whole tensor's largest magnitude lies in (0, 2^-6).
+//              FLAGS, not counters, and SPREAD: a wave picks its line by workgroup and wave index, looks at the flag with a plain
+//              (L1-cacheable: a stale 0 only costs a redundant store) load and stores the family code only while it reads 0.
+//              The first version OR-ed bits atomically into ONE word per launch: the 16 k waves of an element-wise pass (or
+//              the first round of a GEMM) finishing together queued at that word's L2 channel -- 12 ns per atomic, and
+//              plain loads of one hot line were no better: the 22 us stem pre-pass became a 100 us one.
+#define DLIP_EVID_LINES 32
+#define DLIP_EVID_WORDS (DLIP_EVID_LINES * 32)   // int32 words of evidence per launch (32 lines of 128 B)
 __device__ __forceinline__ void dlip_report_range(float amax, const DlipRange r) {
   if (r.status != nullptr && __builtin_amdgcn_ballot_w64(!(amax < DLIP_F16_OVERFLOW)) != 0ull) {
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(r.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -58,11 +65,34 @@ __device__ __forceinline__ void dlip_report_range(float amax, const DlipRange r)
   if (r.lo != nullptr) {
     const bool big = __builtin_amdgcn_ballot_w64(amax >= DLIP_SPLIT_LOW) != 0ull;
     const bool some = __builtin_amdgcn_ballot_w64(amax > 0.f) != 0ull;
-    const int32_t bits = big ? 1 : (some ? 2 : 0);
-    if ((threadIdx.x & 63) == 0 && bits != 0) {
-      const int32_t cur = __hip_atomic_load(r.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((cur & bits) != bits) __hip_atomic_fetch_or(r.lo, bits | (r.code << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0 && some) {
+      const unsigned line = (blockIdx.x * 5u + (threadIdx.x >> 6)) & (DLIP_EVID_LINES - 1);
+      volatile int32_t* w = r.lo + line * 32 + (big ? 0 : 1);
+      if (*w == 0) *w = r.code;
     }
+  }
+}
+
+// The same report for kernels whose every thread reaches the call (element-wise passes with thousands of small workgroups): the
+// waves of a workgroup meet in LDS first, so ONE lane per workgroup touches the evidence lines instead of one per wave.
+__device__ __forceinline__ void dlip_report_range_block(float amax, const DlipRange r) {
+  if (r.status != nullptr && __builtin_amdgcn_ballot_w64(!(amax < DLIP_F16_OVERFLOW)) != 0ull) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(r.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (r.lo == nullptr) return;      // (kernel-uniform)
+  __shared__ int wg_big, wg_some;
+  if (threadIdx.x == 0) { wg_big = 0; wg_some = 0; }
+  __syncthreads();
+  const bool big = __builtin_amdgcn_ballot_w64(amax >= DLIP_SPLIT_LOW) != 0ull;
+  const bool some = __builtin_amdgcn_ballot_w64(amax > 0.f) != 0ull;
+  if ((threadIdx.x & 63) == 0) {
+    if (big) wg_big = 1;
+    else if (some) wg_some = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && (wg_big | wg_some)) {
+    volatile int32_t* w = r.lo + (blockIdx.x & (DLIP_EVID_LINES - 1)) * 32 + (wg_big ? 0 : 1);
+    if (*w == 0) *w = r.code;
   }
 }
 

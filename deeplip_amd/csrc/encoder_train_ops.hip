@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void split_pack_scaled_kernel(const f32x4* __r
     *reinterpret_cast<h4*>(b + q * 2) = hi;
     *reinterpret_cast<h4*>(b + 16 + q * 2) = lo;
   }
-  dlip_report_range(amax, status);
+  dlip_report_range_block(amax, status);
 }
 
 // Weights of a training step -> the split-fp16 operand image, on the device (packing.split_weights does this once per

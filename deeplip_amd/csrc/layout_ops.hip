@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
       blk[32 + tx] = lo;
     }
   }
-  dlip_report_range(amax, status);
+  dlip_report_range_block(amax, status);
 }
 
 __global__ __launch_bounds__(256) void ingest_rgb_kernel(const uint8_t* __restrict__ x, float* __restrict__ y,
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const f32x4* __restrict
     *reinterpret_cast<h4*>(b + q * 2) = hi;        // halves 4q..4q+3 of the hi half (64 B)
     *reinterpret_cast<h4*>(b + 16 + q * 2) = lo;   // same position in the lo half
   }
-  dlip_report_range(amax, status);
+  dlip_report_range_block(amax, status);
 }
 __global__ __launch_bounds__(256) void split_unpack_kernel(const float* __restrict__ x, f32x4* __restrict__ y, long long n4) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {

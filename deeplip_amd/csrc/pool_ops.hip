@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const f32x4* __restri
       y[i] = m;
     }
   }
-  if constexpr (OSPLIT) dlip_report_range(amax, status);
+  if constexpr (OSPLIT) dlip_report_range_block(amax, status);
 }
 
 // y[n,c] = mean over hw of x[n,hw,c]   (sequential fp32 sum, then one divide: AdaptiveAvgPool2d(1))
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const double* __restri
       blk[col & 31] = (_Float16)0.f;
       blk[32 + (col & 31)] = (_Float16)0.f;
     }
-    dlip_report_range(amax, status);
+    dlip_report_range_block(amax, status);
   }
 }
 }  // namespace

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void stem_split_input_kernel(const void* __res
     }
     *reinterpret_cast<u32x4*>(xs + (size_t)c * 4) = o;
   }
-  dlip_report_range(amax, status);
+  dlip_report_range_block(amax, status);
 }
 
 __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemArgs a) {

@@ -92,11 +92,11 @@ class AudioFrontend:
         B, S = wave.shape
         NF = num_frames(S, self.frame_len, self.frame_step)
         R = B * NF
-        frames = torch.empty((R, self.nfft), device=wave.device, dtype=torch.float32)
+        frames = ops._empty((R, self.nfft), wave.device)
         check(lib().dlip_frame_preemph_f32(ptr(wave), ptr(frames), B, S, NF, self.frame_len, self.frame_step, self.nfft,
                                            self.preemph, stream_handle()), "dlip_frame_preemph_f32")
-        pw = torch.empty((R, self.nbp), device=wave.device, dtype=torch.float32)
-        energy = torch.empty((R,), device=wave.device, dtype=torch.float32)
+        pw = ops._empty((R, self.nbp), wave.device)
+        energy = ops._empty((R,), wave.device)
         if self.dft64:
             check(lib().dlip_powspec_dft64_f32(ptr(frames), ptr(pw), ptr(energy), R, self.nb, self.nbp, self.nfft, stream_handle()),
                   "dlip_powspec_dft64_f32")
@@ -109,18 +109,18 @@ class AudioFrontend:
                       out=mel.view(1, 1, R, self.nfp))                         # [R, num_bin] (+ zero pad)
         feat, C_, en = mel, self.num_bin, None
         if self.feat_type in ("mfcc", "logfbank"):
-            lg = torch.empty_like(mel)
+            lg = ops._empty(tuple(mel.shape), mel.device)
             check(lib().dlip_log_floor_f32(ptr(mel), ptr(lg), mel.numel(), stream_handle()), "dlip_log_floor_f32")
             feat = lg
         if self.feat_type == "mfcc":
             feat = ops.linear(feat, self.w_dct)                                # [R, num_cep]
             C_ = self.num_cep
             en = energy if self.energy else None                               # appendEnergy: c0 = log(energy)
-        out = torch.empty((B, C_, NF), device=wave.device, dtype=torch.float32)
+        out = ops._empty((B, C_, NF), wave.device)
         check(lib().dlip_cmvn_nct_f32(ptr(feat), ptr(en), ptr(out), B, NF, C_, feat.shape[1], int(self.normalize),
                                       stream_handle()), "dlip_cmvn_nct_f32")
         if self.delta:
-            out3 = torch.empty((B, 3 * C_, NF), device=wave.device, dtype=torch.float32)
+            out3 = ops._empty((B, 3 * C_, NF), wave.device)
             check(lib().dlip_delta_nct_f32(ptr(out), ptr(out3), B, C_, NF, 2, stream_handle()), "dlip_delta_nct_f32")
             return out3
         return out
@@ -140,7 +140,7 @@ class VideoFrontend:
         ch = 3 if frames.dim() == 5 else 1
         B, T = frames.shape[0], frames.shape[1]
         H, W = frames.shape[-2], frames.shape[-1]
-        y = torch.empty((B, 1, T, self.crop, self.crop), device=frames.device, dtype=torch.float32)
+        y = ops._empty((B, 1, T, self.crop, self.crop), frames.device)   # (arena-aware: this may run inside a recorded step plan)
         check(lib().dlip_crop_normalize_u8(ptr(frames), ptr(y), B * T, ch, H, W, self.crop, stream_handle()),
               "dlip_crop_normalize_u8")
         return y

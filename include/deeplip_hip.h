@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 25
+#define DLIP_ABI_VERSION 27
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -516,8 +516,9 @@ int dlip_set_status_words(int32_t* words);
  * status block (int32[8]: {conv, stem, split_pack, pooling, LOW, 3 reserved}) receives the kernel family + 1 -- and the host
  * raises exactly as for an overflow (same recourse: "f32" packing).
  * Per-launch evidence needs a word per launch: between dlip_range_scope_begin and dlip_range_scope_end (thread-local, may
- * nest: the outermost pair counts) every producer launched by this thread takes the next word of `slots` (device int32[n],
- * zeroed once by the caller); _end launches a one-block verdict kernel on `stream` -- which must be ordered behind every launch
+ * nest: the outermost pair counts) every producer launched by this thread takes the next 1024 words (32 cache lines: its waves
+ * spread over them, so that thousands finishing together do not queue at one line) of `slots` (device int32[1024 n], zeroed once
+ * by the caller; flags, not counters: plain stores, no read-modify-write); _end launches a one-block verdict kernel on `stream` -- which must be ordered behind every launch
  * of the scope (join side streams first) -- that reports and re-zeroes the words.  Recorded into a step plan the verdict is
  * part of every replay.  Outside a scope the low side is not guarded (the high side always is). */
 /* Span scope (measurement): what a replayed step plan cannot give the host -- no event recorded into a graph can be read back --
