@@ -117,9 +117,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   constexpr int RING = WIN ? RING_W : NSTAGE * STAGE_B;   // bytes; the epilogue parameter table (5 x BN floats) sits behind it
   constexpr bool ALT = (VAR & 8) != 0;     // alternating issuer halves
   // The eight-wave 256x128 tile runs the ping-pong main loop (below); VAR bit 10 keeps the lock-step loop (lab reference),
-  // bit 9 drops the matrix phase's priority (lab).
-  constexpr bool PINGPONG = BM == 256 && BN == 128 && NW == 8 && NSTAGE == 3 && (VAR & ~512) == 0;
+  // bit 9 drops the matrix phase's priority (lab), bit 11 keeps the group-major MFMA order inside the matrix phase (lab).
+#ifdef DLIP_NO_PINGPONG   // (A/B builds only: tools/ab.sh nopp)
+  constexpr bool PINGPONG = false;
+#else
+  constexpr bool PINGPONG = BM == 256 && BN == 128 && NW == 8 && NSTAGE == 3 && (VAR & ~(512 | 2048)) == 0;
+#endif
   constexpr bool PP_PRIO = (VAR & 512) == 0;
+  constexpr bool PP_ACC_MAJOR = (VAR & 2048) == 0;   // (bit 11: the group-major MFMA order, lab reference)
   static_assert(!ALT || (NW == 8 && NSTAGE == 3), "alternating issuers: eight waves, three stages");
   constexpr int AQ = ALT ? 2 * A_PER : A_PER, BQ = ALT ? 2 * B_PER : B_PER;   // rows a lane addresses: its own passes (+ its partner wave's)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -375,6 +380,23 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       };
       auto mfma_all = [&]() {
         if constexpr (PP_PRIO) __builtin_amdgcn_s_setprio(2);   // the matrix phase outranks its SIMD partner's load phase
+        if constexpr (PP_ACC_MAJOR) {
+          // ACCUMULATOR-MAJOR: the three products of one accumulator back to back.  A wave that is ALONE on its SIMD's matrix pipe
+          // -- as it is here -- issues v_mfma_f32_16x16x32_f16 every 16.4 cycles when consecutive instructions accumulate into the
+          // same registers, and only every 24.4 when each goes to another accumulator (tools/probes/mfma_rate.hip: 16 accumulators
+          // group by group 24.43, one chain 16.58, chains of three 16.42 cycles per MFMA; two waves per SIMD reach 16.3 either
+          // way, which is why the lock-step loop never saw it).  Per accumulator the order is still lo*hi, hi*hi, hi*lo: same bits.
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[ni], fal[mi], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[ni], fah[mi], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[ni], fah[mi], acc[mi][ni], 0, 0, 0);
+            }
+            DLIP_FENCE();
+          }
+        } else {
 #pragma unroll
         for (int grp = 0; grp < 3; ++grp) {
 #pragma unroll
@@ -386,6 +408,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[mi][ni], 0, 0, 0);
             }
           DLIP_FENCE();
+        }
         }
         if constexpr (PP_PRIO) __builtin_amdgcn_s_setprio(0);
       };
@@ -1062,8 +1085,8 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 // (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
 #ifdef DLIP_LAB
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {256, 128}, {256, 128}, {128, 64}, {64, 128}, {256, 256}, {256, 128}, {256, 128}};   // 10: the 256x256 experiment; 11: 256x128 with the lock-step loop; 12: ping-pong without priority; 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
-constexpr int NUM_DMA_ALL = 13;
+                           {256, 128}, {256, 128}, {128, 64}, {64, 128}, {256, 256}, {256, 128}, {256, 128}, {256, 128}};   // 10: the 256x256 experiment; 11: 256x128 with the lock-step loop; 12: ping-pong without priority; 13: ping-pong, group-major MFMA order; 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
+constexpr int NUM_DMA_ALL = 14;
 #else
 const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
 constexpr int NUM_DMA_ALL = 6;
@@ -1130,6 +1153,7 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 7: return launch_dma<256, 128, 4, 2, 3, 1, 48>(a, st, epi);
     case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
     case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);
+    case 13: return launch_dma<256, 128, 4, 2, 3, 1, 2048>(a, st, epi);   // the ping-pong loop with the group-major MFMA order (its first version)
     case 12: return launch_dma<256, 128, 4, 2, 3, 1, 512>(a, st, epi);    // the product's ping-pong loop without s_setprio around the matrix phase
     case 11: return launch_dma<256, 128, 4, 2, 3, 1, 1024>(a, st, epi);   // the LOCK-STEP loop on 256x128 (the product until round 3): the reference of the ping-pong loop
     case 10: return launch_dma<256, 256, 4, 2, 2, 1, 64>(a, st, epi);   // experiment: 64 KB per slice for twice the MFMAs of 256x128 (48 KB)
