@@ -374,6 +374,46 @@ def time_mean(x, lengths):
     return TimeMeanFn.apply(x, lengths)
 
 
+class ConcatChannelsFn(Function):
+    """torch.cat(branches, dim=-1) of channels-last tensors under autograd as dlip_* launches (the multibranch TCN block's
+    concatenation, tcn.py:96-108): forward copies each branch into its channel slice of one output, backward copies the
+    slices of dy back out -- the strided row copy of dlip_tap_gather_f32 (one tap, identity gather, ldx / ldo row pitches)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [x.contiguous() for x in xs]
+        lead = xs[0].shape[:-1]
+        J = xs[0].numel() // xs[0].shape[-1]
+        widths = [x.shape[-1] for x in xs]
+        Ct = sum(widths)
+        out = torch.empty(tuple(lead) + (Ct,), device=xs[0].device, dtype=torch.float32)
+        off = 0
+        for x, Cb in zip(xs, widths):
+            check(lib().dlip_tap_gather_f32(ptr(x), out.data_ptr() + 4 * off, J, 1, 1, Cb, Cb, 1, 1, 1, 1, 0, 0, Ct, stream_handle()),
+                  "dlip_tap_gather_f32")
+            off += Cb
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        Ct = dy.shape[-1]
+        J = dy.numel() // Ct
+        outs, off = [], 0
+        for Cb in ctx.widths:
+            g = torch.empty(tuple(dy.shape[:-1]) + (Cb,), device=dy.device, dtype=torch.float32)
+            check(lib().dlip_tap_gather_f32(dy.data_ptr() + 4 * off, ptr(g), J, 1, 1, Cb, Ct, 1, 1, 1, 1, 0, 0, Cb, stream_handle()),
+                  "dlip_tap_gather_f32")
+            outs.append(g)
+            off += Cb
+        return tuple(outs)
+
+
+def concat_channels(xs):
+    return ConcatChannelsFn.apply(*xs)
+
+
 def dropout(x, p: float, training: bool = True):
     if not training or p <= 0.0:
         return x

@@ -309,7 +309,7 @@ def _tcn_block_train(b: "MultibranchTemporalBlock", x: Tensor, p_drop: float) ->
             z = av.batchnorm(z, m.batchnorm)                         # [B,1,T+pad,nb]
             z = z[:, :, pad // 2: pad // 2 + T].contiguous()         # symmetric chomp
             outs.append(av.prelu(z, m.non_lin))
-        cur = av.dropout(torch.cat(outs, dim=3).view(B, T, b.n_outputs), p_drop)
+        cur = av.dropout(av.concat_channels(outs).view(B, T, b.n_outputs), p_drop)   # (a HIP row copy per branch, not torch.cat)
     if b.downsample is None:
         raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
     res = av.conv(x.reshape(B, 1, T, x.shape[2]), b.downsample.weight, b.downsample.bias).view(B, T, b.n_outputs)
