@@ -145,7 +145,7 @@ def local_step(video, audio, xv, xa, sequential=False):
 
 def exchange(fused, world):
     """The enrol/verify exchange: every rank gets every rank's fused rows (RCCL all-gather over xGMI)."""
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return fused
     out = torch.empty((world * fused.shape[0], fused.shape[1]), device=fused.device, dtype=fused.dtype)
     dist.all_gather_into_tensor(out, fused)
@@ -165,7 +165,7 @@ def step(video, audio, xv, xa, world):
         em_video = video.embed(xv)
         xv_audio, _ = audio.extract_embedding(xa)
     fused = fusion.fuse_av(xv_audio, em_video)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         out = torch.empty((world * fused.shape[0], fused.shape[1]), device=fused.device, dtype=fused.dtype)
         dist.all_gather_into_tensor(out, fused)
         return out
@@ -469,7 +469,11 @@ def main():
         sys.exit("bench.py needs a ROCm GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # Inside a torch.distributed.run job the process group is ALWAYS initialised -- a one-rank job included, so that a single-GPU
+    # box can exercise the RCCL path end to end (init with device_id, all_gather_into_tensor, barrier, MAX all-reduce):
+    # `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (tests/test_rccl_gpu.py).
+    dist_on = world > 1 or "RANK" in os.environ
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
@@ -491,7 +495,7 @@ def main():
     xa = torch.from_numpy(wg.audio_input(B, args.audio_dim, 300, speakers=spk, key=f"bench.audio.r{rank}")).unsqueeze(1).to(device)
 
     def sync_all():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -515,11 +519,11 @@ def main():
         t0 = time.perf_counter()
         pipe.run([ring[i % 3] for i in range(nb)], table)
         pipe.finish()
-        if world > 1:
+        if dist_on:
             exchange(table[:B], world)                       # one exchange of rows closes the job, as a scoring run would
         sync_all()
         el = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         pipe.close()
         mb = sum(t.numel() * t.element_size() for t in ring[0]) / B / 1e6
@@ -572,13 +576,13 @@ def main():
             gpu_ms = ev0.elapsed_time(ev1)
             my_elapsed = elapsed
             tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-            if world > 1:
+            if dist_on:
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
             value = world * B * args.steps / elapsed
             ranks = None
             n1_alone = None
-            if world > 1:
+            if dist_on:
                 # self-check of a scaling run: what every rank saw (RCCL's own world size, its wall time over the same K
                 # steps, the all-gather of [B,1024] rows timed on its own)
                 fused_probe = torch.zeros((B, 1024), device=device)
@@ -692,7 +696,7 @@ def main():
     configs = None
     if rank == 0 and not args.no_configs:
         configs = extra_configs(args, device, video, audio, xv, xa, main_fields["peak"], StepPlan)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     alt = None
     if not args.single_mode:
@@ -749,7 +753,7 @@ def main():
                 res["alt_mode"]["parity"] = parity(alt[0], alt[2], alt[3], ref, cxv, cxa)
         print(json.dumps(res), flush=True)
 
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -20,6 +20,11 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+def active() -> bool:
+    """A process group exists: collectives are issued (also in a one-rank job)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def shard_range(n: int, rank: Optional[int] = None, world_size: Optional[int] = None) -> Tuple[int, int]:
     """Contiguous block partition of n units: the first n % W ranks get one extra unit."""
     r, w = world()
@@ -35,7 +40,7 @@ def gather_rows(local: torch.Tensor, total_rows: int) -> torch.Tensor:
     every rank (shards are padded to the largest one so a single all_gather_into_tensor suffices:
     one 256 KB-1 MB message per rank, latency-bound on xGMI)."""
     rank, w = world()
-    if w == 1:
+    if not active():
         return local
     sizes = [shard_range(total_rows, r, w) for r in range(w)]
     mx = max(hi - lo for lo, hi in sizes)
@@ -60,17 +65,17 @@ def score_trials_sharded(scorer: Callable[[torch.Tensor, torch.Tensor], torch.Te
 def allreduce_metrics(values: List[float], device) -> List[float]:
     """Sum of (loss*n, correct, n)-style scalars over ranks."""
     t = torch.tensor(values, dtype=torch.float64, device=device)
-    if world()[1] > 1:
+    if active():
         dist.all_reduce(t)
     return t.tolist()
 
 
 def init_from_env(device: Optional[torch.device] = None) -> Tuple[int, int]:
     """Join the job torch.distributed.run started (RANK / WORLD_SIZE / MASTER_* in the environment): backend nccl
-    (= RCCL over xGMI) bound to ``device`` for a GPU rank, gloo for a CPU rank.  No-op for a single process.
-    Returns (rank, world size)."""
-    w = int(os.environ.get("WORLD_SIZE", "1"))
-    if w > 1 and not dist.is_initialized():
+    (= RCCL over xGMI) bound to ``device`` for a GPU rank, gloo for a CPU rank.  No-op for a plain single process; a ONE-rank
+    job (torch.distributed.run --nproc-per-node 1) does join, and every collective below then really goes through the
+    backend -- how a single-GPU box exercises the RCCL path (tests/test_rccl_gpu.py).  Returns (rank, world size)."""
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if device is not None and device.type == "cuda":
             dist.init_process_group("nccl", device_id=device)
@@ -83,7 +88,7 @@ def broadcast_params(params, src: int = 0) -> None:
     """Replicas start identical (what nn.DataParallel's per-step broadcast guarantees: train_audio.py:83).  The write goes
     through ``p.data`` (no version-counter bump), so the packed-weight cache and any recorded step plan are invalidated
     explicitly: a forward run before the broadcast must not leave stale packs on the non-source ranks."""
-    if world()[1] > 1:
+    if active():
         for p in params:
             dist.broadcast(p.data, src)
         from . import holders
@@ -101,7 +106,7 @@ def allreduce_grads(params, world_size: Optional[int] = None) -> int:
         return 0
     w = world_size or dist.get_world_size()
     params = [p for p in params if p.requires_grad]
-    if w == 1 or not params:
+    if not params:
         return 0
     has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=params[0].device)
     dist.all_reduce(has)                                       # which parameters got a gradient on ANY rank
@@ -143,6 +148,7 @@ class GradBuckets:
     def __init__(self, params, bucket_bytes: int = 32 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.world = world()[1]
+        self.active = active()     # a process group exists (a one-rank job included): the collectives are issued
         self.buckets: List[torch.Tensor] = []
         self._slot = {}            # id(param) -> bucket index
         self._pending: List[int] = []
@@ -189,7 +195,7 @@ class GradBuckets:
         if self._launched[bi]:
             return
         self._launched[bi] = True
-        if self.world > 1:
+        if self.active:
             self._works.append(dist.all_reduce(self.buckets[bi], async_op=True))
 
     def _hook(self, p):
@@ -218,9 +224,10 @@ class GradBuckets:
         for w in self._works:
             w.wait()
         n = 0
-        if self.world > 1:
+        if self.active:
             for b in self.buckets:
-                b.div_(self.world)
+                if self.world > 1:
+                    b.div_(self.world)
                 n += b.numel()
         self._reset()
         return n

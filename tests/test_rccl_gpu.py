@@ -1,0 +1,60 @@
+"""The nccl (= RCCL) backend for real, on the one GPU a test box has: ONE-rank torch.distributed.run jobs.
+
+RCCL refuses two ranks on one device, so the world size is 1 -- but everything else is the production path: the launcher of
+`deeplip_amd.launch` (a child process, never an exec), `init_process_group("nccl", device_id=...)`, all_gather_into_tensor /
+all_reduce / broadcast / barrier issued through the communicator, the bucketed gradient exchange behind a real backward, and
+bench.py's scaling-run protocol (`ranks[]`, `n1_value_rank0_alone`).  What a second GPU would add is bytes on xGMI, not code."""
+import json
+import os
+import sys
+
+import pytest
+
+from deeplip_amd import launch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(script, argv):
+    lines = []
+    rc = launch.self_launch(os.path.join(ROOT, script), argv, 1, relay=lines.append)
+    js = [json.loads(l) for l in lines if l.lstrip().startswith("{")]
+    return rc, js, lines
+
+
+def test_dist_api_on_rccl_one_rank():
+    rc, js, lines = _run("tests/rccl_rank.py", [])
+    assert rc == 0, "".join(lines)[-2000:]
+    r = js[-1]
+    assert r["backend"] == "nccl" and r["active"] and r["world"] == 1
+    assert r["gather_ok"] and r["score_err"] < 1e-6 and r["metrics"] == [1.0, 2.0]
+    assert r["buckets"] >= 2 and r["reduced_elements"] > 0 and r["flat_reduced"] > 0
+    assert r["n_grads"][0] == r["n_grads"][1] and r["grad_max_rel_diff"] < 1e-5
+    assert abs(r["loss_plain"] - r["loss_bucketed"]) < 1e-5 * abs(r["loss_plain"])
+
+
+def test_bench_scaling_protocol_on_rccl_one_rank():
+    rc, js, lines = _run("bench.py", ["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-configs", "--single-mode", "--no-h2d"])
+    assert rc == 0, "".join(lines)[-2000:]
+    assert len(js) == 1
+    r = js[0]
+    assert r["n_gpus"] == 1 and r["value"] > 1000
+    rk = r["ranks"]
+    assert len(rk) == 1 and rk[0]["rccl_world_size"] == 1 and rk[0]["allgather_us"] > 0
+    assert r["n1_value_rank0_alone"] > 1000
+
+
+def test_train_audio_dp_on_rccl_one_rank(tmp_path):
+    """BASELINE config C5's mechanism (DP training, bucketed all-reduce behind backward) as a job on the real backend."""
+    over = ["data.test_speakers=4", "data.test_utt_per_spk=3", "data.trials=200", "data.trial_targets=40", "data.audio_frames=120",
+            "data.n_spk=6", "data.utt_per_spk=3", "train.bs=8", "train.epoch=1"]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        rc, js, lines = _run("train_audio.py", ["--mode", "train", "--config", os.path.join(ROOT, "conf/audio_config.yaml"), "--set", *over])
+    finally:
+        os.chdir(cwd)
+    text = "".join(lines)
+    assert rc == 0, text[-2000:]
+    assert "Epoch 1 loss" in text and "EER" in text

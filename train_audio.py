@@ -86,7 +86,7 @@ class Trainer(object):
         self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optim, milestones=self.train_opts["lr_decay_step"], gamma=0.1)
         self.epoch, self.current_epoch = self.train_opts["epoch"], 0
         self.log_time = time.asctime(time.localtime(time.time())).replace(" ", "_")[4:]
-        if self.world > 1:          # one directory name for the job (rank 0's clock), identical replicas
+        if ddist.active():          # one directory name for the job (rank 0's clock), identical replicas
             name = [self.log_time]
             torch.distributed.broadcast_object_list(name, 0)
             self.log_time = name[0]
@@ -103,7 +103,7 @@ class Trainer(object):
         rng = np.random.Generator(np.random.PCG64([self.current_epoch, 5, self.rank]))    # every rank its own batches
         tot = n = correct = 0.0
         self.model.train(not self.freeze_encoder)
-        if self.world > 1 and self.buckets is None:
+        if ddist.active() and self.buckets is None:
             params = [p for g in self.optim.param_groups for p in g["params"]]
             self.buckets = ddist.GradBuckets(params)
         t0 = time.perf_counter()
@@ -142,7 +142,7 @@ class Trainer(object):
                                                                                      st["steps"], st["bs"]), flush=True)
             self.lr_scheduler.step()
             self.save()
-            if self.world > 1:
+            if ddist.active():
                 torch.distributed.barrier()     # rank 0's checkpoint is on disk before anybody averages / resumes
 
     def save(self, filename=None):
@@ -248,7 +248,7 @@ def main():
     eer, thr = tr.eer()
     if tr.rank == 0:
         print("EER: {:.6f}%".format(eer * 100))
-    if tr.world > 1:
+    if ddist.active():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

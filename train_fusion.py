@@ -65,7 +65,7 @@ class Trainer(object):
             raise RuntimeError("train_fusion.py needs a ROCm GPU: the deeplip_amd engine has no CPU path")
         torch.cuda.set_device(local)
         self.device = torch.device("cuda", local)
-        if self.world > 1 and not dist.is_initialized():
+        if "RANK" in os.environ and not dist.is_initialized():     # any torch.distributed.run job, a one-rank one included
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl", device_id=self.device)
 
@@ -135,7 +135,7 @@ class Trainer(object):
         self.current_epoch = 0
         self.load_finetune()
         # replicas start identical (DataParallel broadcast equivalent)
-        if self.world > 1:
+        if ddist.active():
             for p in list(self.model_fusion.parameters()) + list(self.criterion.parameters()):
                 dist.broadcast(p.data, 0)
 
@@ -178,7 +178,7 @@ class Trainer(object):
         return self.model_fusion(torch.cat([xv_audio, em_video], dim=1).contiguous())
 
     def _allreduce_grads(self):
-        if self.world == 1:
+        if not ddist.active():
             return
         ddist.allreduce_grads([p for g in self.optim.param_groups for p in g["params"]], self.world)   # one bucket (3.4 MB)
 

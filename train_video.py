@@ -135,7 +135,7 @@ def train(model, args, device):
             p.requires_grad = True
     params = [p for p in model.parameters() if p.requires_grad]
     # DP: gradients live in flat buckets whose all-reduces (RCCL) start while backward is still running
-    buckets = ddist.GradBuckets(params) if (world > 1 and device.type != "cpu") else None
+    buckets = ddist.GradBuckets(params) if (ddist.active() and device.type != "cpu") else None
     optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=1e-4)                      # (:112-113)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=5, eta_min=4e-08)      # (:114)
     last = None
@@ -198,7 +198,8 @@ def main(argv=None):
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.to(device)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and args.device == "gpu":
+    in_job = "RANK" in os.environ            # any torch.distributed.run job joins its process group, a one-rank one included
+    if in_job and args.device == "gpu":
         import torch.distributed as dist
         from deeplip_amd import dist as ddist
         torch.cuda.set_device(device)
@@ -210,7 +211,7 @@ def main(argv=None):
             np.savez(args.mouth_embedding_out_path, data=out.cpu().numpy())
         return out
     res = train(model, args, device)
-    if world > 1 and args.device == "gpu":
+    if in_job and args.device == "gpu":
         import torch.distributed as dist
         dist.barrier()
     # checkpoint round trip (bare state_dict, as the reference saves it)
@@ -218,7 +219,7 @@ def main(argv=None):
     model.load_state_dict(torch.load(ck, map_location="cpu"))
     if int(os.environ.get("RANK", "0")) == 0:
         print("done:", res, "checkpoint", ck)
-    if world > 1 and args.device == "gpu":
+    if in_job and args.device == "gpu":
         import torch.distributed as dist
         dist.destroy_process_group()
     return res
