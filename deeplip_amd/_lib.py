@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _lock = threading.Lock()
 _lib = None
@@ -68,6 +68,8 @@ SIGNATURES = {
     "dlip_maxpool3x3s2_bwd_f32": [c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_stream],
     "dlip_row_broadcast_f32": [c_f, c_f, c_f, c_i64, c_i32, c_i32, C.c_float, c_stream],
     "dlip_stem_im2col_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_stem_wgrad_operand_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_split_stem_weights_f32": [c_f, c_f, c_f, c_i32, c_stream],
     "dlip_mul_mask_f32": [c_f, c_f, c_f, c_i64, C.c_float, c_stream],
     "dlip_conv_workspace_bytes": [],
     "dlip_conv_set_workspace": [c_f, c_i64, c_stream],

@@ -19,6 +19,19 @@ from ._lib import check, lib, ptr, stream_handle
 from .autograd import BNRowsActFn, _permute3, _ws
 
 
+_CONST = {}
+
+
+def const_vec(n: int, value: float, device):
+    """A read-only [n] vector of ``value`` (unit scales, zero shifts of the conv epilogues): made once per (device, n, value) --
+    276 torch fill launches of a B = 32 training step were these."""
+    key = (str(device), int(n), float(value))
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((n,), float(value), device=device, dtype=torch.float32)
+    return t
+
+
 def _colsum_rows(x2):
     M, C_ = x2.shape
     y = torch.empty((C_,), device=x2.device, dtype=torch.float32)
@@ -43,8 +56,8 @@ def wgrad_gemm(dz_rows, tap_rows, n_taps):
     check(lib().dlip_split_pack_scaled_f32(ptr(dzT), ptr(dzT_s), ptr(scale2), K, J32, stream_handle()), "dlip_split_pack_scaled_f32")
     inv = torch.empty((K,), device=dev, dtype=torch.float32)
     check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
-    ones = torch.ones((K,), device=dev, dtype=torch.float32)
-    zeros = torch.zeros((K,), device=dev, dtype=torch.float32)
+    ones = const_vec(K, 1.0, dev)
+    zeros = const_vec(K, 0.0, dev)
     out = None
     xT = None
     for s in range(n_taps):
@@ -97,7 +110,7 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
     check(lib().dlip_split_pack_scaled_f32(ptr(x), ptr(xs), ptr(scale2), x.numel() // Cx, Cx, stream_handle()), "dlip_split_pack_scaled_f32")
     inv = torch.empty((K,), device=dev, dtype=torch.float32)
     check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
-    zeros = torch.zeros((K,), device=dev, dtype=torch.float32)
+    zeros = const_vec(K, 0.0, dev)
     return ops.conv_nhwc(xs, ws, None, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True, post_scale=inv, post_shift=zeros)
 
 
@@ -124,8 +137,8 @@ def wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2=None):
                                        pad[0], pad[1], None, stream_handle()), "dlip_wgrad_operand_f32")
     inv = torch.empty((K,), device=dev, dtype=torch.float32)
     check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
-    ones = torch.ones((K,), device=dev, dtype=torch.float32)
-    zeros = torch.zeros((K,), device=dev, dtype=torch.float32)
+    ones = const_vec(K, 1.0, dev)
+    zeros = const_vec(K, 0.0, dev)
     out = torch.empty((taps * Cx, K), device=dev, dtype=torch.float32)
     ops.conv_nhwc(xT_s.view(1, 1, taps * Cx, J32), dzT_s.view(K, 1, 1, J32), None, w_scale=ones, x_split=True, post_scale=inv,
                   post_shift=zeros, out=out.view(1, 1, taps * Cx, K))
@@ -194,19 +207,26 @@ class ConvTrainFn(Function):
 
 class StemConvTrainFn(Function):
     """Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3), bias=False) on [B,T,H,W] (model.py:82) -> [(B T),H/2,W/2,64]:
-    forward = the fp32 stem kernel with the raw weights (unit scale, zero shift), backward = weight gradient
-    only (the input is data) as one GEMM over the im2col matrix."""
+    forward = the split-fp16 stem kernel on the CURRENT weights (split on the device; unit scale, zero shift, slope 1) -- the exact
+    fp32 stem kernel with TRAIN_CONV = "f32"; backward = weight gradient only (the input is data): both GEMM operands written
+    in one pass each (dlip_stem_wgrad_operand_f32 from the clip, dlip_wgrad_operand_f32 from dy), then one GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight):
         x = x.contiguous()
         B, T, H, W = x.shape
         K = weight.shape[0]
-        wk = torch.zeros((248, K), device=x.device, dtype=torch.float32)
-        wk[:245].copy_(_permute3(weight.contiguous().view(1, K, 245), (0, 2, 1)).view(245, K))
-        zero = torch.zeros((K,), device=x.device, dtype=torch.float32)
-        one = torch.ones((K,), device=x.device, dtype=torch.float32)
-        y = ops.stem3d(x, wk, zero, one)
+        dev = x.device
+        zero, one = const_vec(K, 0.0, dev), const_vec(K, 1.0, dev)
+        if TRAIN_CONV == "f16x3" and K == 64:
+            img = torch.empty((K * 296,), device=dev, dtype=torch.float32)
+            wsc = torch.empty((K,), device=dev, dtype=torch.float32)
+            check(lib().dlip_split_stem_weights_f32(ptr(weight.contiguous()), ptr(img), ptr(wsc), K, stream_handle()), "dlip_split_stem_weights_f32")
+            y = ops.stem3d(x, img, zero, one, w_scale=wsc)
+        else:
+            wk = torch.zeros((248, K), device=dev, dtype=torch.float32)
+            wk[:245].copy_(_permute3(weight.contiguous().view(1, K, 245), (0, 2, 1)).view(245, K))
+            y = ops.stem3d(x, wk, zero, one)
         ctx.save_for_backward(x)
         ctx.K = K
         return y
@@ -216,12 +236,25 @@ class StemConvTrainFn(Function):
         (x,) = ctx.saved_tensors
         B, T, H, W = x.shape
         K = ctx.K
+        dev = x.device
         dy = dy.contiguous()
-        J = B * T * (H // 2) * (W // 2)
-        col = torch.empty((J, 248), device=x.device, dtype=torch.float32)
-        check(lib().dlip_stem_im2col_f32(ptr(x), ptr(col), B, T, H, W, stream_handle()), "dlip_stem_im2col_f32")
-        dwt = wgrad_gemm(dy.view(J, K), lambda s: col, 1)                  # [1, 248, K]
-        dweight = _permute3(dwt[:, :245].contiguous(), (0, 2, 1)).view(K, 1, 5, 7, 7)
+        Ho, Wo = H // 2, W // 2
+        J = B * T * Ho * Wo
+        J32 = (J + 31) // 32 * 32
+        if WGRAD_ODD_PITCH and (J32 // 32) % 2 == 0:
+            J32 += 32
+        scale2 = pow2_lift(dy)
+        dzT_s = torch.empty((K, J32), device=dev, dtype=torch.float32)
+        check(lib().dlip_wgrad_operand_f32(ptr(dy), ptr(dzT_s), J32, B * T, Ho, Wo, K, K, Ho, Wo, 1, 1, 1, 1, 1, 1, 0, 0, ptr(scale2), stream_handle()),
+              "dlip_wgrad_operand_f32")
+        xT_s = torch.empty((248, J32), device=dev, dtype=torch.float32)
+        check(lib().dlip_stem_wgrad_operand_f32(ptr(x), ptr(xT_s), J32, B, T, H, W, stream_handle()), "dlip_stem_wgrad_operand_f32")
+        inv = torch.empty((K,), device=dev, dtype=torch.float32)
+        check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+        out = torch.empty((248, K), device=dev, dtype=torch.float32)
+        ops.conv_nhwc(xT_s.view(1, 1, 248, J32), dzT_s.view(K, 1, 1, J32), None, w_scale=const_vec(K, 1.0, dev), x_split=True,
+                      post_scale=inv, post_shift=const_vec(K, 0.0, dev), out=out.view(1, 1, 248, K))
+        dweight = _permute3(out[:245].contiguous().view(1, 245, K), (0, 2, 1)).view(K, 1, 5, 7, 7)
         return None, dweight
 
 
@@ -356,7 +389,7 @@ def prelu(x, act):
     w = getattr(act, "weight", None)
     C_ = x.shape[-1]
     if w is None:
-        w = torch.zeros((C_,), device=x.device, dtype=torch.float32)
+        w = const_vec(C_, 0.0, x.device)
     elif w.numel() == 1:
         w = w.expand(C_)
     return PReLUFn.apply(x, w.contiguous() if not w.is_contiguous() else w)

@@ -233,6 +233,80 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
   }
 }
 
+// The stem's weight-gradient operand in ONE pass (was: im2col [J, 248] -> transpose -> split, three round trips of a 1.8 GB matrix
+// at B = 32): out[tap * ldo + j] = x[b, t + dt - 2, 2 ho + r - 3, 2 wo + s - 3] (zero outside the clip, for j >= J and for the
+// padding rows tap = 245..247), tap = (dt 7 + r) 7 + s, j = ((b T + t) Ho + ho) Wo + wo, in the GEMM's reduction-major split image
+// (per row and 32 positions one 128-B block: 32 hi halves | 32 lo halves).  C = 1: the positions ARE the contiguous axis of the
+// input (stride 2), so no LDS transposition -- a thread owns 8 consecutive positions (their clip coordinates computed once)
+// and walks the tap rows tap_sub, tap_sub + 64, ...; four neighbouring threads complete a row's 128-B block with 16-B stores.
+// The clip is read ~61 times per pixel, from L1 / L2 (29 MB at B = 32); HBM sees the 1.8 GB of the operand once.
+__global__ __launch_bounds__(256) void stem_wgrad_operand_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int H, int W,
+                                                                 int Ho, int Wo, long long J, long long ldo, DlipRange status) {
+  const long long j0 = (long long)blockIdx.x * 32;
+  const int pq = threadIdx.x & 3, tap_sub = threadIdx.x >> 2;
+  int base[8], h0[8], w0[8], tt[8];
+  {
+    long long j = j0 + pq * 8;
+    int wo = (int)(j % Wo);
+    long long q = j / Wo;
+    int ho = (int)(q % Ho);
+    long long bt = q / Ho;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool in = j + e < J;
+      base[e] = (int)(bt * H * W);
+      tt[e] = in ? (int)(bt % T) : -(1 << 20);
+      h0[e] = 2 * ho - 3;
+      w0[e] = 2 * wo - 3;
+      if (++wo == Wo) { wo = 0; if (++ho == Ho) { ho = 0; ++bt; } }
+    }
+  }
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  float amax = 0.f;
+  for (int tap = tap_sub; tap < 248; tap += 64) {
+    h8 hi, lo;
+    const int s_ = tap % 7, r = (tap / 7) % 7, dt = tap / 49;      // tap >= 245: dt = 5 -> t + 3 may be < T: masked below
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int t2 = tt[e] + dt - 2, hh = h0[e] + r, ww = w0[e] + s_;
+      float v = 0.f;
+      if (tap < 245 && (unsigned)t2 < (unsigned)T && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+        v = x[base[e] + ((dt - 2) * H + hh) * W + ww];
+      const _Float16 a = (_Float16)v;
+      hi[e] = a; lo[e] = (_Float16)(v - (float)a);
+      amax = fmaxf(amax, fabsf(v));
+    }
+    _Float16* row = reinterpret_cast<_Float16*>(out + (long long)tap * ldo + j0);
+    *reinterpret_cast<h8*>(row + pq * 8) = hi;
+    *reinterpret_cast<h8*>(row + 32 + pq * 8) = lo;
+  }
+  dlip_report_range(amax, status);
+}
+
+// The stem's CURRENT weights [K, 245] -> the split LDS image of stem3d_f16x3.hip on the device (packing.split_stem_weights does
+// this on the host once per load_state_dict; under training the weights change every step).  One 64-lane workgroup per output
+// channel: row maximum -> scale = 2^floor(log2(1023 / max)) -> per channel 1184 B: [36 kernel rows (dt 7 + r; row 35 zero) x 8 hi
+// halves (tap 7 zero)] [the same, lo halves] + 32 B of padding.
+__global__ __launch_bounds__(64) void split_stem_weights_kernel(const float* __restrict__ w, float* __restrict__ img, float* __restrict__ scale) {
+  const float* row = w + (long long)blockIdx.x * 245;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < 245; i += 64) m = fmaxf(m, fabsf(row[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  float sc = 1.f;
+  if (m > 0.f && m < 3.0e38f) sc = exp2f(floorf(log2f(1023.0f / m)));
+  if (threadIdx.x == 0) scale[blockIdx.x] = sc;
+  _Float16* out = reinterpret_cast<_Float16*>(img + (long long)blockIdx.x * (1184 / 4));
+  for (int i = threadIdx.x; i < 592; i += 64) {
+    const int q = i < 288 ? i : i - 288;               // slot (row, tap) of the hi plane / the lo plane; i >= 576: padding
+    const int kr = q >> 3, tap = q & 7;
+    float t = 0.f;
+    if (i < 576 && kr < 35 && tap < 7) t = row[kr * 7 + tap] * sc;
+    const _Float16 hi = (_Float16)t;
+    out[i] = i < 288 ? hi : (_Float16)(t - (float)hi);
+  }
+}
+
 __global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask,
                                                        float* __restrict__ y, float scale, long long n) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * mask[i] * scale;
@@ -316,6 +390,23 @@ extern "C" int dlip_stem_im2col_f32(const float* x, float* col, int32_t B, int32
   DLIP_CHECK_ARG(x && col && B > 0 && T > 0 && H > 1 && W > 1 && (H & 1) == 0 && (W & 1) == 0);
   const long long n = (long long)B * T * (H / 2) * (W / 2) * 248;
   hipLaunchKernelGGL(stem_im2col_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, col, T, H, W, H / 2, W / 2, n);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_stem_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int32_t B, int32_t T, int32_t H, int32_t W,
+                                           dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && out && B > 0 && T > 0 && H > 1 && W > 1 && (H & 1) == 0 && (W & 1) == 0 &&
+                 (reinterpret_cast<uintptr_t>(out) & 127) == 0);
+  const long long J = (long long)B * T * (H / 2) * (W / 2);
+  DLIP_CHECK_ARG(ld_out >= J && (ld_out & 31) == 0 && (long long)B * T * H * W < (1ll << 31) && ld_out / 32 < (1ll << 31));
+  hipLaunchKernelGGL(stem_wgrad_operand_kernel, dim3((unsigned)(ld_out / 32)), dim3(256), 0, ST(stream), x, out, T, H, W, H / 2, W / 2, J,
+                     (long long)ld_out, dlip_range_for(DLIP_ST_PACK));
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_split_stem_weights_f32(const float* w, float* w_img, float* w_scale, int32_t K, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(w && w_img && w_scale && K > 0);
+  hipLaunchKernelGGL(split_stem_weights_kernel, dim3((unsigned)K), dim3(64), 0, ST(stream), w, w_img, w_scale);
   return dlip_launch_status();
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 27
+#define DLIP_ABI_VERSION 28
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -493,6 +493,16 @@ int dlip_row_broadcast_f32(const float* dy, const int32_t* lengths, float* dx, i
 /* im2col of the stem Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) (model.py:82): x [B,T,H,W] -> col [B*T*(H/2)*(W/2), 248]
  * (245 taps + 3 zero columns), the operand of the stem's weight-gradient GEMM. */
 int dlip_stem_im2col_f32(const float* x, float* col, int32_t B, int32_t T, int32_t H, int32_t W, dlip_stream_t stream);
+/* The same operand WITHOUT the im2col round trip: out [248, ld_out] = the reduction-major split image the weight-gradient GEMM
+ * reads (per row and 32 positions one 128-B block: 32 hi halves | 32 lo halves; positions >= J and rows 245..247 zero), written
+ * in one pass from the clip x [B,T,H,W].  ld_out >= B*T*(H/2)*(W/2), a multiple of 32; out 128-B aligned.  Reports range like
+ * the other split producers.  (train_video.py:129-147: the stem's weight gradient.) */
+int dlip_stem_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int32_t B, int32_t T, int32_t H, int32_t W,
+                                dlip_stream_t stream);
+/* The stem's CURRENT weights w [K,245] (= [K,1,5,7,7]) -> the split-fp16 weight image of dlip_stem3d_bn_act_f16x3 /
+ * dlip_stem3d_pool_f16x3 (K x 1184 B) and its per-channel power-of-two scale [K], on the device: what a training step needs
+ * every iteration (the extraction path packs once on the host). */
+int dlip_split_stem_weights_f32(const float* w, float* w_img, float* w_scale, int32_t K, dlip_stream_t stream);
 /* y = x * mask * scale (nn.Dropout forward / backward, tcn.py:80,85). */
 int dlip_mul_mask_f32(const float* x, const float* mask, float* y, int64_t n, float scale, dlip_stream_t stream);
 

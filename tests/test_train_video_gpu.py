@@ -78,6 +78,45 @@ def test_stem_conv_train_fn():
     assert rel_err(wgp.grad.cpu().numpy(), w.grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("B,T,H,W", [(2, 6, 88, 88), (1, 3, 24, 40)])
+def test_stem_wgrad_operand_is_the_split_transposed_im2col(B, T, H, W):
+    """dlip_stem_wgrad_operand_f32 (one pass) == im2col -> transpose -> split, bit for bit: rows = taps (245 + 3 zero rows),
+    per 32 positions 32 hi halves | 32 lo halves, zero columns beyond J."""
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    x = rnd(B, T, H, W, seed=9).to(DEV)
+    J = B * T * (H // 2) * (W // 2)
+    J32 = (J + 31) // 32 * 32 + 32
+    out = torch.full((248, J32), 7.0, device=DEV)
+    check(lib().dlip_stem_wgrad_operand_f32(ptr(x), ptr(out), J32, B, T, H, W, stream_handle()), "dlip_stem_wgrad_operand_f32")
+    col = torch.empty((J, 248), device=DEV)
+    check(lib().dlip_stem_im2col_f32(ptr(x), ptr(col), B, T, H, W, stream_handle()), "dlip_stem_im2col_f32")
+    torch.cuda.synchronize()
+    ref = np.zeros((248, J32), dtype=np.float32)
+    ref[:, :J] = col.cpu().numpy().T
+    hi = ref.astype(np.float16)
+    lo = (ref - hi.astype(np.float32)).astype(np.float16)
+    blocks = np.concatenate([hi.reshape(248, J32 // 32, 32), lo.reshape(248, J32 // 32, 32)], axis=2)     # [248, nb, 64] halves
+    got = out.cpu().numpy().view(np.float16).reshape(248, J32 // 32, 64)
+    assert np.array_equal(got.view(np.uint16), blocks.view(np.uint16))
+
+
+def test_split_stem_weights_on_device_equals_host_packing():
+    from deeplip_amd import packing
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    w = rnd(64, 1, 5, 7, 7, seed=6, scale=1.0 / np.sqrt(245))
+    w[3] *= 1e-3; w[5] = 0.0
+    img_h, sc_h = packing.split_stem_weights(w.double())
+    img = torch.empty((64 * 296,), device=DEV)
+    sc = torch.empty((64,), device=DEV)
+    check(lib().dlip_split_stem_weights_f32(ptr(w.to(DEV)), ptr(img), ptr(sc), 64, stream_handle()), "dlip_split_stem_weights_f32")
+    torch.cuda.synchronize()
+    assert np.array_equal(sc.cpu().numpy()[:5], sc_h.numpy()[:5]) and np.array_equal(sc.cpu().numpy()[6:], sc_h.numpy()[6:])
+    keep = np.ones(64, bool); keep[5] = False                 # an all-zero channel: any scale, zero image
+    a = img.cpu().numpy().view(np.uint16).reshape(64, 592)[:, :576]
+    b = img_h.numpy().view(np.uint16).reshape(64, 592)[:, :576]
+    assert np.array_equal(a[keep], b[keep]) and not a[5].any()
+
+
 def test_prelu_maxpool_avgpool_timemean_dropout():
     from deeplip_amd import autograd_video as av
     # PReLU with per-channel slope
