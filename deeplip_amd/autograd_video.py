@@ -285,6 +285,38 @@ class PReLUFn(Function):
         return dx, dslope
 
 
+class BNPReLUFn(Function):
+    """prelu(bn_train(x)) on [M, C] rows with per-channel slopes in the BatchNorm kernels' own passes
+    (dlip_bn_prelu_rows_train_fwd/bwd_f32): no separate PReLU forward / backward pass and no column sum of slope terms."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, momentum, eps):
+        x = x.contiguous()
+        M, C_ = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((C_,), device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        ws = torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 4,), device=x.device, dtype=torch.float64)
+        check(lib().dlip_bn_prelu_rows_train_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(y), ptr(mean), ptr(invstd),
+                                                     ptr(running_mean), ptr(running_var), ptr(ws), M, C_, momentum, eps, stream_handle()),
+              "dlip_bn_prelu_rows_train_fwd_f32")
+        ctx.save_for_backward(x, gamma, beta, slope, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, slope, mean, invstd = ctx.saved_tensors
+        M, C_ = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg, db, ds = (torch.empty_like(mean) for _ in range(3))
+        ws = torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 4,), device=x.device, dtype=torch.float64)
+        check(lib().dlip_bn_prelu_rows_train_bwd_f32(ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(mean), ptr(invstd), ptr(dx),
+                                                     ptr(dg), ptr(db), ptr(ds), ptr(ws), M, C_, stream_handle()),
+              "dlip_bn_prelu_rows_train_bwd_f32")
+        return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None
+
+
 class MaxPoolFn(Function):
     """MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on [(B T),H,W,C] (model.py:85)."""
 
@@ -380,6 +412,21 @@ def batchnorm(x, bn):
     C_ = x.shape[-1]
     y = BNRowsActFn.apply(x.contiguous().view(-1, C_), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                           1.0, False)
+    bn.num_batches_tracked += 1
+    return y.view(x.shape)
+
+
+def batchnorm_prelu(x, bn, act):
+    """prelu(batchnorm(x)) of a channels-last tensor in train mode, fused when the activation has one slope per channel (or is a
+    ReLU marker: slope 0, no parameter); a single shared slope keeps the two-step path (its gradient is a sum over channels)."""
+    w = getattr(act, "weight", None)
+    C_ = x.shape[-1]
+    if w is not None and w.numel() != C_:
+        return prelu(batchnorm(x, bn), act)
+    if w is None:
+        w = const_vec(C_, 0.0, x.device)
+    y = BNPReLUFn.apply(x.contiguous().view(-1, C_), bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(),
+                        bn.running_mean, bn.running_var, bn.momentum, bn.eps)
     bn.num_batches_tracked += 1
     return y.view(x.shape)
 

@@ -21,23 +21,28 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ?
 // MODE 1: s0 = sum g, s1 = sum g * xhat                                          (BN backward)
 //         g = dy * (act_first ? 1 : lrelu'(bn(x))),  xhat = (a - mean) * invstd
 // MODE 2: s0 = sum x, s1 unused                                                   (bias gradient)
+// MODE 3: MODE 1 for y = prelu(bn(x)) with the per-channel slopes `slope_vec` (act_first = 0), plus
+//         s2 = sum (bn(x) < 0 ? dy * bn(x) : 0) = the slope gradient, written as {s2, 0} pairs to a SECOND partial
+//         region behind the first (part + chunks * C * 2): BatchNorm + PReLU backward sums in one pass over dy and x
 template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          double* __restrict__ part, int M, int C, float slope, int act_first) {
-  __shared__ double red[16][64][2];
+                                                          double* __restrict__ part, int M, int C, float slope, int act_first,
+                                                          const float* __restrict__ slope_vec = nullptr) {
+  __shared__ double red[16][64][MODE == 3 ? 3 : 2];
   const int c0 = blockIdx.x * 64, chunk = blockIdx.y;
   const int lx = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = c0 + lx * 4;
   const int r0 = chunk * CHUNK_ROWS, r1 = min(M, r0 + CHUNK_ROWS);
-  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   if (c < C) {   // C % 4 == 0
-    f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, ga = {0, 0, 0, 0}, be = {0, 0, 0, 0};
-    if (MODE == 1) {
+    f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, ga = {0, 0, 0, 0}, be = {0, 0, 0, 0}, sl = {0, 0, 0, 0};
+    if (MODE == 1 || MODE == 3) {
       mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c);
       ga = *reinterpret_cast<const f32x4*>(gamma + c); be = *reinterpret_cast<const f32x4*>(beta + c);
     }
+    if (MODE == 3) sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
     for (int r = r0 + rg; r < r1; r += 16) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long long)r * C + c);
       if (MODE == 0) {
@@ -56,6 +61,16 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
           if (!act_first) g *= (xh * ga[k] + be[k]) >= 0.f ? 1.f : slope;
           s0[k] += (double)g; s1[k] += (double)g * (double)xh;
         }
+      } else if (MODE == 3) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + (long long)r * C + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (xv[k] - mu[k]) * is[k];
+          const float bn = xh * ga[k] + be[k];
+          float g = gv[k];
+          if (bn < 0.f) { s2[k] += (double)g * (double)bn; g *= sl[k]; }
+          s0[k] += (double)g; s1[k] += (double)g * (double)xh;
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) s0[k] += (double)xv[k];
@@ -63,14 +78,24 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { red[rg][lx * 4 + k][0] = s0[k]; red[rg][lx * 4 + k][1] = s1[k]; }
+  for (int k = 0; k < 4; ++k) {
+    red[rg][lx * 4 + k][0] = s0[k]; red[rg][lx * 4 + k][1] = s1[k];
+    if (MODE == 3) red[rg][lx * 4 + k][2] = s2[k];
+  }
   __syncthreads();
   if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
-    double a0 = 0.0, a1 = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { a0 += red[i][threadIdx.x][0]; a1 += red[i][threadIdx.x][1]; }
+    for (int i = 0; i < 16; ++i) {
+      a0 += red[i][threadIdx.x][0]; a1 += red[i][threadIdx.x][1];
+      if (MODE == 3) a2 += red[i][threadIdx.x][2];
+    }
     double* p = part + ((long long)chunk * C + c0 + threadIdx.x) * 2;
     p[0] = a0; p[1] = a1;
+    if (MODE == 3) {
+      double* p2 = p + (long long)gridDim.y * C * 2;
+      p2[0] = a2; p2[1] = 0.0;
+    }
   }
 }
 
@@ -120,12 +145,14 @@ template <bool FIXED>
 __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, f32x4* __restrict__ y, long long n4,
-                                                           int C4, float slope, int act_first) {
+                                                           int C4, float slope, int act_first,
+                                                           const float* __restrict__ slope_vec = nullptr) {
   const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-  f32x4 mu, is, ga, be;
+  f32x4 mu, is, ga, be, sl = {slope, slope, slope, slope};
   auto load = [&](int c) {
     mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c);
     ga = *reinterpret_cast<const f32x4*>(gamma + c); be = *reinterpret_cast<const f32x4*>(beta + c);
+    if (slope_vec) sl = *reinterpret_cast<const f32x4*>(slope_vec + c);     // PReLU behind the BatchNorm (act_first = 0)
   };
   if (FIXED) load((int)(i0 % C4) * 4);
   for (long long i = i0; i < n4; i += (long long)gridDim.x * 256) {
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const f32x4* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (act_first) o[k] = (lrelu(v[k], slope) - mu[k]) * is[k] * ga[k] + be[k];
-      else o[k] = lrelu((v[k] - mu[k]) * is[k] * ga[k] + be[k], slope);
+      else o[k] = lrelu((v[k] - mu[k]) * is[k] * ga[k] + be[k], sl[k]);
     }
     y[i] = o;
   }
@@ -157,14 +184,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                            f32x4* __restrict__ dx, long long n4, int C4, int M, float slope,
-                                                           int act_first) {
+                                                           int act_first, const float* __restrict__ slope_vec = nullptr) {
   const float invM = 1.f / (float)M;
   const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-  f32x4 mu, is, ga, be, dg, db;
+  f32x4 mu, is, ga, be, dg, db, sl = {slope, slope, slope, slope};
   auto load = [&](int c) {
     mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c);
     ga = *reinterpret_cast<const f32x4*>(gamma + c); be = *reinterpret_cast<const f32x4*>(beta + c);
     dg = *reinterpret_cast<const f32x4*>(dgamma + c); db = *reinterpret_cast<const f32x4*>(dbeta + c);
+    if (slope_vec) sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
   };
   if (FIXED) load((int)(i0 % C4) * 4);
   for (long long i = i0; i < n4; i += (long long)gridDim.x * 256) {
@@ -176,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
       const float a = act_first ? lrelu(xv[k], slope) : xv[k];
       const float xh = (a - mu[k]) * is[k];
       float g = gv[k];
-      if (!act_first) g *= (xh * ga[k] + be[k]) >= 0.f ? 1.f : slope;
+      if (!act_first) g *= (xh * ga[k] + be[k]) >= 0.f ? 1.f : sl[k];
       float d = ga[k] * is[k] * (g - db[k] * invM - xh * dg[k] * invM);
       if (act_first) d *= xv[k] >= 0.f ? 1.f : slope;
       o[k] = d;
@@ -373,6 +401,55 @@ extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
                        reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_bn_prelu_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, const float* slope, float* y,
+                                                float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                                double* workspace, int32_t M, int32_t C, float momentum, float eps,
+                                                dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && gamma && beta && slope && y && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = dlip_bn_rows_chunks(M);
+  hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, workspace, M, C, 1.f, 0, nullptr);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_invstd,
+                     running_mean, running_var, M, C, chunks, momentum, eps);
+  const long long n4 = (long long)M * (C / 4);
+  if (const unsigned gf = grid_fixed(n4, C / 4))
+    hipLaunchKernelGGL(bn_fwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
+                       save_invstd, gamma, beta, reinterpret_cast<f32x4*>(y), n4, C / 4, 1.f, 0, slope);
+  else
+    hipLaunchKernelGGL(bn_fwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
+                       save_invstd, gamma, beta, reinterpret_cast<f32x4*>(y), n4, C / 4, 1.f, 0, slope);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                                                const float* slope, const float* save_mean, const float* save_invstd, float* dx,
+                                                float* dgamma, float* dbeta, float* dslope, double* workspace, int32_t M, int32_t C,
+                                                dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dy && x && gamma && beta && slope && save_mean && save_invstd && dx && dgamma && dbeta && dslope && workspace);
+  DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = dlip_bn_rows_chunks(M);
+  hipLaunchKernelGGL(col_partial_kernel<3>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd,
+                     gamma, beta, workspace, M, C, 1.f, 0, slope);
+  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
+  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace + (long long)chunks * C * 2, dslope,
+                     nullptr, C, chunks);
+  const long long n4 = (long long)M * (C / 4);
+  if (const unsigned gf = grid_fixed(n4, C / 4))
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
+                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
+                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope);
   return dlip_launch_status();
 }
 

@@ -127,7 +127,7 @@ def _basic_block_train(b: "BasicBlock", x: Tensor) -> Tensor:
     every step a differentiable dlip_* launch (deeplip_amd/autograd_video.py).  x NHWC."""
     from . import autograd_video as av
     s = (b.stride, b.stride)
-    h = av.prelu(av.batchnorm(av.conv(x, b.conv1.weight, None, stride=s, pad=(1, 1)), b.bn1), b.relu1)
+    h = av.batchnorm_prelu(av.conv(x, b.conv1.weight, None, stride=s, pad=(1, 1)), b.bn1, b.relu1)
     h = av.batchnorm(av.conv(h, b.conv2.weight, None, pad=(1, 1)), b.bn2)
     res = x if b.downsample is None else av.batchnorm(av.conv(x, b.downsample[0].weight, None, stride=s), b.downsample[1])
     return av.prelu(h + res, b.relu2)
@@ -306,9 +306,8 @@ def _tcn_block_train(b: "MultibranchTemporalBlock", x: Tensor, p_drop: float) ->
             m = getattr(b, f"cbcr{s}_{j}")
             pad = (k - 1) * b.dilation
             z = av.conv(cur.reshape(B, 1, T, cur.shape[2]), m.conv.weight, m.conv.bias, pad=(0, pad), dil=(1, b.dilation))
-            z = av.batchnorm(z, m.batchnorm)                         # [B,1,T+pad,nb]
-            z = z[:, :, pad // 2: pad // 2 + T].contiguous()         # symmetric chomp
-            outs.append(av.prelu(z, m.non_lin))
+            z = av.batchnorm_prelu(z, m.batchnorm, m.non_lin)        # [B,1,T+pad,nb]; the element-wise PReLU commutes with the chomp
+            outs.append(z[:, :, pad // 2: pad // 2 + T].contiguous())   # symmetric chomp
         cur = av.dropout(av.concat_channels(outs).view(B, T, b.n_outputs), p_drop)   # (a HIP row copy per branch, not torch.cat)
     if b.downsample is None:
         raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
@@ -442,7 +441,7 @@ class Lipreading(nn.Module):
             raise ValueError("Lipreading expects grayscale clips [B,1,T,H,W] (model.py:82)")
         stem, bn, act = self.frontend3D[0], self.frontend3D[1], self.frontend3D[2]
         y = av.stem_conv(x.contiguous().float().view(B, T, H, W), stem.weight)       # [(B T),H/2,W/2,64]
-        y = av.maxpool(av.prelu(av.batchnorm(y, bn), act))
+        y = av.maxpool(av.batchnorm_prelu(y, bn, act))
         for blk in self.trunk.blocks():
             y = _basic_block_train(blk, y)
         y = av.avgpool(y).view(B, T, self.backend_out)

@@ -410,6 +410,17 @@ int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const float* gam
                                const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                                float* dbeta, double* workspace, int32_t M, int32_t C, float slope,
                                int32_t act_first, dlip_stream_t stream);
+/* BatchNorm (batch statistics) + PReLU with PER-CHANNEL slopes in the same passes: y = prelu(bn(x)) (resnet.py:51-53 bn1 + relu1,
+ * tcn.py:42-43, model.py:83-84 under model.train()).  Forward as dlip_bn_rows_train_fwd_f32 with slope[C] applied behind the
+ * affine; backward additionally returns dslope[C] = sum over rows of (bn(x) < 0 ? dy * bn(x) : 0) from the SAME pass that
+ * forms dgamma / dbeta -- `workspace` holds 2 * dlip_bn_rows_chunks(M) * C * 2 doubles here.  Saves the separate PReLU
+ * forward / backward passes and the column sum of its slope terms. */
+int dlip_bn_prelu_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, const float* slope, float* y,
+                                     float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                     double* workspace, int32_t M, int32_t C, float momentum, float eps, dlip_stream_t stream);
+int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* slope,
+                                     const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                                     float* dslope, double* workspace, int32_t M, int32_t C, dlip_stream_t stream);
 /* y[c] = sum_m x[m,c] (bias gradients), same chunked reduction and workspace. */
 int dlip_colsum_rows_f32(const float* x, float* y, double* workspace, int32_t M, int32_t C, dlip_stream_t stream);
 

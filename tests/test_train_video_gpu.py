@@ -117,6 +117,37 @@ def test_split_stem_weights_on_device_equals_host_packing():
     assert np.array_equal(a[keep], b[keep]) and not a[5].any()
 
 
+@pytest.mark.parametrize("M,C", [(2 * 22 * 22, 64), (1300, 256), (70, 768)])
+def test_fused_batchnorm_prelu_vs_torch_autograd(M, C):
+    """prelu(bn_train(x)) with per-channel slopes in the BatchNorm passes: outputs, dx, dgamma, dbeta, dslope and the running
+    statistics against torch autograd (fp64) of BatchNorm1d + PReLU."""
+    from deeplip_amd import autograd_video as av
+    x = (rnd(M, C, seed=21) * 1.7 + 0.3).requires_grad_()
+    ga = (1.0 + 0.3 * rnd(C, seed=22)).requires_grad_()
+    be = (0.2 * rnd(C, seed=23)).requires_grad_()
+    sl = (torch.rand(C, generator=torch.Generator().manual_seed(24)) * 0.5 - 0.05).requires_grad_()     # a few negative slopes too
+    dy = rnd(M, C, seed=25)
+    bn = torch.nn.BatchNorm1d(C, momentum=0.1).double()
+    with torch.no_grad():
+        bn.weight.copy_(ga); bn.bias.copy_(be)
+    bn.train()
+    xd = x.detach().double().requires_grad_()
+    sld = sl.detach().double().requires_grad_()
+    ref = F.prelu(bn(xd), sld)
+    ref.backward(dy.double())
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    xg, gg, bg, sg = (t.detach().to(DEV).requires_grad_() for t in (x, ga, be, sl))
+    y = av.BNPReLUFn.apply(xg, gg, bg, sg, rm, rv, 0.1, 1e-5)
+    y.backward(dy.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    assert rel_err(xg.grad.cpu().numpy(), xd.grad.numpy()) < 1e-4
+    assert rel_err(gg.grad.cpu().numpy(), bn.weight.grad.numpy()) < 1e-4
+    assert rel_err(bg.grad.cpu().numpy(), bn.bias.grad.numpy()) < 1e-4
+    assert rel_err(sg.grad.cpu().numpy(), sld.grad.numpy()) < 1e-4
+    assert rel_err(rm.cpu().numpy(), bn.running_mean.numpy()) < 1e-5 and rel_err(rv.cpu().numpy(), bn.running_var.numpy()) < 1e-5
+
+
 def test_prelu_maxpool_avgpool_timemean_dropout():
     from deeplip_amd import autograd_video as av
     # PReLU with per-channel slope
