@@ -326,8 +326,8 @@ def _conv1d_wgrad(x, dz, S, dilation, lift=None):
     dev = x.device
     if Cx % 4 == 0 and K % 4 == 0:
         # a "valid" 1-D convolution is the H = 1 case of the fused operand path (autograd_video.wgrad_conv_fused)
-        from .autograd_video import wgrad_conv_fused
-        dwt = wgrad_conv_fused(x.contiguous().view(B, 1, T, Cx), dz.contiguous().view(B, 1, Tp, K), 1, S, (1, 1), (0, 0), (1, dilation), scale2=lift)
+        from .autograd_video import wgrad_conv
+        dwt = wgrad_conv(x.contiguous().view(B, 1, T, Cx), dz.contiguous().view(B, 1, Tp, K), 1, S, (1, 1), (0, 0), (1, dilation), scale2=lift)
         return _permute3(dwt, (2, 1, 0))                                       # [S,C,K] -> [K,C,S]
     dzp = torch.zeros((B, T, K), device=dev, dtype=torch.float32)              # rows t >= T' stay zero: no cross-utterance terms
     dzp[:, :Tp].copy_(dz)

@@ -145,6 +145,45 @@ def wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2=None):
     return out.view(taps, Cx, K)
 
 
+# How the convolutions' weight gradients run: "conv" = as a convolution over ONE transposed copy of x and of dy (wgrad_as_conv),
+# "gemm" = one GEMM over the R*S shifted copies of x (wgrad_conv_fused: what round 3 started with).
+WGRAD = "conv"
+
+
+def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None):
+    """dW[c, r, s, k] = sum_{n,h,w} x[n, h*sh + r*dh - ph, w*sw + s*dw - pw, c] * dy[n, h, w, k] run as a CONVOLUTION on the
+    engine's own conv kernel: input x' = x as [C][H][W][N] (the C channels play the batch, the N images the channels), filter
+    g' = dy as [K][Ho][Wo][N], convolution stride = the layer's dilation, dilation = the layer's stride, same padding; the
+    output [C, R', S', K] holds dW in its first R x S positions (R' > R when the layer's stride leaves a remainder).  Both
+    operands are ONE split copy of their tensor (dlip_wgrad_chwn_f32; dy after its power-of-two lift) -- the reduction-major
+    GEMM operand is R*S shifted copies of x: 1.03 GB written and read back per layer-1 convolution at B = 32, 0.9 ms of a
+    0.1 ms data gradient's worth of FLOPs.  The Ho*Wo filter taps (484 on layer 1) are the conv kernel's address walk
+    (its variant without the 32-bit tap mask).  Returns [R*S, C, K] like wgrad_conv_fused."""
+    N, H, W, Cx = x.shape
+    _, Ho, Wo, K = dy.shape
+    dev = x.device
+    N32 = (N + 31) // 32 * 32
+    if scale2 is None:
+        scale2 = pow2_lift(dy)
+    xT = torch.empty((Cx, H, W, N32), device=dev, dtype=torch.float32)
+    check(lib().dlip_wgrad_chwn_f32(ptr(x), ptr(xT), N, H, W, Cx, x.stride(2), N32, None, stream_handle()), "dlip_wgrad_chwn_f32")
+    gT = torch.empty((K, Ho, Wo, N32), device=dev, dtype=torch.float32)
+    check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), stream_handle()), "dlip_wgrad_chwn_f32")
+    inv = torch.empty((K,), device=dev, dtype=torch.float32)
+    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    out = ops.conv_nhwc(xT, gT, None, stride=dil, pad=pad, dil=stride, w_scale=const_vec(K, 1.0, dev), x_split=True,
+                        post_scale=inv, post_shift=const_vec(K, 0.0, dev))                 # [Cx, R', S', K]
+    if out.shape[1] != R or out.shape[2] != S:
+        out = out[:, :R, :S].contiguous()
+    return _permute3(out.view(Cx, R * S, K), (1, 0, 2))                                     # [R*S, Cx, K]
+
+
+def wgrad_conv(x, dy, R, S, stride, pad, dil, scale2=None):
+    if WGRAD == "conv" and TRAIN_CONV == "f16x3":
+        return wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2)
+    return wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2)
+
+
 class ConvTrainFn(Function):
     """nn.Conv2d / nn.Conv1d (H = 1) on NHWC activations, raw (unfolded) weights in the reference layout
     [K,C,R,S]: forward = the fp32 implicit-GEMM kernel; backward = bias column sum, DATA gradient = the same
@@ -193,7 +232,7 @@ class ConvTrainFn(Function):
             # tiles of a per-tap GEMM: a 64-channel layer would otherwise be a single 64x64 tile)
             taps = R * S
             if Cx % 4 == 0 and K % 4 == 0:
-                dwt = wgrad_conv_fused(x, dy, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift)
+                dwt = wgrad_conv(x, dy, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift)
                 return dx, _permute3(dwt, (2, 1, 0)).view(K, Cx, R, S), dbias, None, None, None
             rows = torch.empty((J, taps * Cx), device=dev, dtype=torch.float32)
             for t in range(taps):

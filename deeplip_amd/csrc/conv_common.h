@@ -67,7 +67,7 @@ struct ConvArgs {
 // the packed weight tensor (== d->C for the fp32 layout).
 inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const float* w, const float* bias,
                                const float* residual, const float* slope, const float* post_scale,
-                               const float* post_shift, float* y, int Cw, ConvArgs* out) {
+                               const float* post_shift, float* y, int Cw, ConvArgs* out, int max_taps = 32) {
   DLIP_CHECK_ARG(d && x && w && y);
   DLIP_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0);
   DLIP_CHECK_ARG(d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0 && d->pad_h >= 0 && d->pad_w >= 0);
@@ -78,7 +78,7 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
   const int Ho = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
   const int Wo = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
   DLIP_CHECK_ARG(Ho == d->Ho && Wo == d->Wo && Ho > 0 && Wo > 0);
-  DLIP_CHECK_ARG(d->R * d->S <= 32);  // per-row tap-validity mask is 32 bits
+  DLIP_CHECK_ARG(d->R * d->S <= max_taps);  // per-row tap-validity mask is 32 bits (the LDS-DMA kernel has a mask-free variant)
 
   const long long in_pix = (long long)d->N * d->H * d->W;
   const long long x_bytes = ((in_pix - 1) * d->ldx + d->C) * 4;

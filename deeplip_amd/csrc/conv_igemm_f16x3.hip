@@ -340,7 +340,7 @@ namespace {
 // Shared argument checks of the three split-fp16 entry points; fills `a`.
 int fill_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, const float* w_scale, const float* bias,
                const float* residual, const float* slope, const float* post_scale, const float* post_shift, float* y,
-               int32_t flags, ConvArgs* a) {
+               int32_t flags, ConvArgs* a, int max_taps = 32) {
   DLIP_CHECK_ARG(d && w_scale);
   // flags: DLIP_SPLIT_IN (x and residual hold (hi, lo) pairs; C, ldx, ldr multiples of 32),
   //        DLIP_SPLIT_OUT (y is written in that format; K, ldy multiples of 32)
@@ -348,7 +348,7 @@ int fill_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, con
   if (flags & 2) DLIP_CHECK_ARG((d->K & 31) == 0 && (d->ldy & 31) == 0);
   const int Cw = (d->C + 31) / 32 * 32;
   const int rc = dlip_fill_conv_args(d, x, static_cast<const float*>(w_split), bias, residual, slope, post_scale,
-                                     post_shift, y, Cw, a);
+                                     post_shift, y, Cw, a, max_taps);
   if (rc != DLIP_OK) return rc;
   a->wscale = w_scale;
   a->status = dlip_range_for(DLIP_ST_CONV);
@@ -362,7 +362,11 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
                                     const float* slope, const float* post_scale, const float* post_shift,
                                     float* y, int32_t flags, dlip_stream_t stream) {
   ConvArgs a;
-  const int rc = fill_f16x3(d, x, w_split, w_scale, bias, residual, slope, post_scale, post_shift, y, flags, &a);
+  // Filters with more than 32 taps (a weight gradient run as a convolution: the "filter" is the output-gradient map) exist on the
+  // LDS-DMA kernel only: split input, fp32 output, no residual.
+  const bool big = d && d->R > 0 && d->S > 0 && (long long)d->R * d->S > 32;
+  if (big) DLIP_CHECK_ARG((flags & 3) == 1 && residual == nullptr && (long long)d->R * d->S <= 65536);
+  const int rc = fill_f16x3(d, x, w_split, w_scale, bias, residual, slope, post_scale, post_shift, y, flags, &a, big ? 65536 : 32);
   if (rc != DLIP_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // Split-format activations go to the LDS-DMA kernel.  Its epilogue leaves in 16-byte chunks, so an fp32
@@ -376,6 +380,7 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
     if (dlip_conv_win_ok(&a)) return dlip_conv_f16x3_win_launch(&a, stream, (flags & 2) ? 1 : 0);
     return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) ? 1 : 0);
   }
+  if (big) return DLIP_EINVAL;
   switch (pick_tile(a.M, d->K, kEffF16x3)) {
     case 0: return launch<128, 128, 2, 2>(a, st, flags);
     case 1: return launch<128, 64, 2, 2>(a, st, flags);

@@ -121,8 +121,13 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #ifdef DLIP_NO_PINGPONG   // (A/B builds only: tools/ab.sh nopp)
   constexpr bool PINGPONG = false;
 #else
-  constexpr bool PINGPONG = BM == 256 && BN == 128 && NW == 8 && NSTAGE == 3 && (VAR & ~(512 | 2048)) == 0;
+  constexpr bool PINGPONG = BM == 256 && BN == 128 && NW == 8 && NSTAGE == 3 && (VAR & ~(512 | 2048 | 4096)) == 0;
 #endif
+  // VAR bit 12: filters with MORE THAN 32 TAPS.  The product's per-row validity mask has one bit per tap (R S <= 32); a weight
+  // gradient run as a convolution -- input x as [C][H][W][N], "filter" = the output gradient as [K][Ho][Wo][N], the images as the
+  // reduction's channels (deeplip_amd.autograd_video.wgrad_as_conv) -- has Ho x Wo taps (484 on layer 1).  This variant keeps each
+  // row's window origin (hi0, wi0) in registers and tests a tap's row / column against the image when the piece is issued.
+  constexpr bool BIGTAPS = (VAR & 4096) != 0;
   constexpr bool PP_PRIO = (VAR & 512) == 0;
   constexpr bool PP_ACC_MAJOR = (VAR & 2048) == 0;   // (bit 11: the group-major MFMA order, lab reference)
   static_assert(!ALT || (NW == 8 && NSTAGE == 3), "alternating issuers: eight waves, three stages");
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     // that stays inside the image (columns and rows tested separately: R + S steps, not R x S).
     int a_off[AQ];
     uint32_t a_mask[AQ];
+    int a_h0[BIGTAPS ? AQ : 1], a_w0[BIGTAPS ? AQ : 1];   // (BIGTAPS) window origin of the row; rows past M: far outside
     int a2_off[DUAL ? AQ : 1];   // second source: byte offset of the row's pixel, < 0 past M
     auto row_of = [&](int j) { return (j < A_PER ? rbase : rbase ^ (RPP / 2)) + RPP * (j % A_PER); };   // j >= A_PER: the partner wave's row
     {
@@ -223,16 +229,24 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         colbits[j] = 0u;
         a_mask[j] = 0u;
       }
-      for (int sx = 0; sx < a.S; ++sx)
+      if constexpr (BIGTAPS) {
 #pragma unroll
-        for (int j = 0; j < AQ; ++j) colbits[j] |= (uint32_t)((unsigned)(wi0[j] + sx * a.dw) < (unsigned)a.W) << sx;
-      for (int r = 0; r < a.R; ++r)
+        for (int j = 0; j < AQ; ++j) {
+          a_h0[j] = tile_m * BM + row_of(j) < a.M ? hi0[j] : -(1 << 28);
+          a_w0[j] = wi0[j];
+        }
+      } else {
+        for (int sx = 0; sx < a.S; ++sx)
+#pragma unroll
+          for (int j = 0; j < AQ; ++j) colbits[j] |= (uint32_t)((unsigned)(wi0[j] + sx * a.dw) < (unsigned)a.W) << sx;
+        for (int r = 0; r < a.R; ++r)
+#pragma unroll
+          for (int j = 0; j < AQ; ++j)
+            a_mask[j] |= ((unsigned)(hi0[j] + r * a.dh) < (unsigned)a.H ? colbits[j] : 0u) << (r * a.S);
 #pragma unroll
         for (int j = 0; j < AQ; ++j)
-          a_mask[j] |= ((unsigned)(hi0[j] + r * a.dh) < (unsigned)a.H ? colbits[j] : 0u) << (r * a.S);
-#pragma unroll
-      for (int j = 0; j < AQ; ++j)
-        if (tile_m * BM + row_of(j) >= a.M) a_mask[j] = 0u;
+          if (tile_m * BM + row_of(j) >= a.M) a_mask[j] = 0u;
+      }
     }
     int b_off[BQ];
 #pragma unroll
@@ -249,6 +263,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       if (k0 >= nk1) { c0 = a.Cw + (k0 - nk1) * BK; tap = 0; }
     }
     int s_pos = tap % a.S, x_row = (tap / a.S) * x_dr;
+    int tap_dh = (tap / a.S) * a.dh, tap_dw = s_pos * a.dw;   // (BIGTAPS) the tap's row / column offset in pixels
     int x_tap = x_row + s_pos * x_ds + c0 * 4, w_tap = (tap * a.Cw + c0) * 4;
     if constexpr (DUAL) {
       if (c0 >= a.Cw) { x_tap = (c0 - a.Cw) * 4; w_tap = (ntaps * a.Cw + c0 - a.Cw) * 4; }
@@ -258,12 +273,17 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         c0 += BK;
       } else {
         ++tap;
-        if (++s_pos == a.S) { s_pos = 0; x_row += x_dr; }
-        if (tap == ntaps) { tap = 0; s_pos = 0; x_row = 0; c0 += BK; }
+        if (++s_pos == a.S) { s_pos = 0; x_row += x_dr; if constexpr (BIGTAPS) tap_dh += a.dh; }
+        if (tap == ntaps) { tap = 0; s_pos = 0; x_row = 0; c0 += BK; if constexpr (BIGTAPS) tap_dh = 0; }
+        if constexpr (BIGTAPS) tap_dw = s_pos * a.dw;
       }
       x_tap = x_row + s_pos * x_ds + c0 * 4;
       w_tap = (tap * a.Cw + c0) * 4;
       if (DUAL && c0 >= a.Cw) { x_tap = (c0 - a.Cw) * 4; w_tap = (ntaps * a.Cw + c0 - a.Cw) * 4; }
+    };
+    auto tap_ok = [&](int j) -> bool {
+      if constexpr (BIGTAPS) return (unsigned)(a_h0[j] + tap_dh) < (unsigned)a.H && (unsigned)(a_w0[j] + tap_dw) < (unsigned)a.W;
+      else return (a_mask[j] >> tap) & 1u;
     };
     // (nj = A_PER / B_PER: this wave's own pieces; AQ / BQ: its partner's too)
     auto issue_a = [&](int stage, auto nj) {
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       }
 #pragma unroll
       for (int j = 0; j < nj(); ++j) {
-        const bool ok = (a_mask[j] >> tap) & 1u;
+        const bool ok = tap_ok(j);
         dma_piece(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + (j % A_PER) * RPP * ROWB + (j < A_PER ? 0 : pdelta));
       }
     };
@@ -290,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     auto issue_one = [&](int stage, int i) {   // piece i of this wave's NL of the slice the walk stands on: activations first
       if (i < A_PER) {
         const uint32_t base = piece0 + stage * STAGE_B;
-        const bool ok = (a_mask[i] >> tap) & 1u;
+        const bool ok = tap_ok(i);
         dma_piece(xr, ok ? (uint32_t)(a_off[i] + x_tap) : DLIP_OOB_OFFSET, base + i * RPP * ROWB);
       } else {
         const int j = i - A_PER;
@@ -1060,6 +1080,9 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
     if (epi == 2 || dual) return DLIP_EINVAL;
     return epi ? launch_one<BM, BN, WAVES_M, WAVES_N, NSTAGE, OCC, 1, false, VAR>(a, st)
                : launch_one<BM, BN, WAVES_M, WAVES_N, NSTAGE, OCC, 0, false, VAR>(a, st);
+  } else if constexpr (VAR == 4096) {   // more than 32 filter taps (the weight gradient as a convolution): fp32 output, one source
+    if (epi != 0 || dual) return DLIP_EINVAL;
+    return launch_one<BM, BN, WAVES_M, WAVES_N, NSTAGE, OCC, 0, false, VAR>(a, st);
   } else if constexpr (VAR != 0) {   // lab experiments: plain launches only
     if (epi == 2 || dual) return DLIP_EINVAL;
     return epi ? launch_one<BM, BN, WAVES_M, WAVES_N, NSTAGE, OCC, 1, false, VAR>(a, st)
@@ -1142,6 +1165,12 @@ extern "C" __attribute__((visibility("hidden"))) void dlip_conv_dma_tile(long lo
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int epi) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.R * a.S > 32) {   // the tap-mask-free variant, on the three tiles long reductions use
+    const int t = dma_pick(a.M, a.K, a.nk, epi);
+    if (a.K <= 64 || t == 1 || t == 3) return launch_dma<128, 64, 2, 2, 3, 2, 4096>(a, st, epi);
+    if (t == 5) return launch_dma<256, 128, 4, 2, 3, 1, 4096>(a, st, epi);
+    return launch_dma<128, 128, 2, 2, 2, 2, 4096>(a, st, epi);
+  }
   switch (dma_pick(a.M, a.K, a.nk, epi)) {
     case 0: return launch_dma<128, 128, 2, 2, 2, 2>(a, st, epi);
     case 1: return launch_dma<128, 64, 2, 2, 3, 2>(a, st, epi);

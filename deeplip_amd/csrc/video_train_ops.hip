@@ -99,6 +99,44 @@ __global__ __launch_bounds__(256) void wgrad_operand_kernel(const float* __restr
   dlip_report_range(amax, status);
 }
 
+// Operands of the weight gradient RUN AS A CONVOLUTION (deeplip_amd.autograd_video.wgrad_as_conv): an NHWC tensor x [N,H,W,C]
+// becomes [C][H][W][N32] in the split format -- the images are the "channels" the convolution reduces over, 32 of them per
+// 128-B block (32 hi halves | 32 lo halves), zero for n >= N:
+//   out[((c * H + h) * W + w) * N32 + n]  <-  scale * x[n, h, w, c]
+// One workgroup = 32 images x 32 channels of one pixel through a 32 x 33 LDS tile: 128-B reads along c, one 16-B store per thread
+// along n.  Unlike the reduction-major operand above this is ONE copy of the tensor, not R*S of them: the taps are the
+// convolution kernel's own address walk.
+__global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int ldx, int C,
+                                                         int N32, const float* __restrict__ scale, DlipRange status) {
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32, p = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float sc = scale ? scale[0] : 1.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = n0 + ty + 8 * q;
+    float v = 0.f;
+    if (n < N && c0 + tx < C) v = x[((long long)n * HW + p) * ldx + c0 + tx] * sc;
+    tile[ty + 8 * q][tx] = v;
+  }
+  __syncthreads();
+  const int cr = threadIdx.x >> 3, pq = threadIdx.x & 7;
+  const int jb = (pq & 3) * 8;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 o;
+  float amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = tile[jb + e][cr];
+    const _Float16 hi = (_Float16)v;
+    o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
+    amax = fmaxf(amax, fabsf(v));
+  }
+  if (c0 + cr < C)
+    *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + ((long long)(c0 + cr) * HW + p) * N32 + n0) + (pq < 4 ? 0 : 32) + jb) = o;
+  dlip_report_range(amax, status);
+}
+
 __global__ __launch_bounds__(256) void upsample_zero_kernel(const f32x4* __restrict__ dz, f32x4* __restrict__ out, int Ho, int Wo,
                                                             int Hu, int Wu, int C4, int sh, int sw, long long n4) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -337,6 +375,16 @@ extern "C" int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out
   hipLaunchKernelGGL(wgrad_operand_kernel, dim3((unsigned)(ld_out / 32), (unsigned)((C + 31) / 32)), dim3(256), 0, ST(stream), x, out, H, W,
                      ldx, C, Ho, Wo, stride_h, stride_w, R, S, dil_h, dil_w, pad_h, pad_w, (int)J, (long long)ld_out, scale,
                      dlip_range_for(DLIP_ST_PACK));
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t N32,
+                                   const float* scale, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && out && N > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && N32 >= N && (N32 & 31) == 0 &&
+                 (reinterpret_cast<uintptr_t>(out) & 127) == 0);
+  DLIP_CHECK_ARG((long long)H * W <= 65535 && (C + 31) / 32 <= 65535 && N < (1ll << 31));
+  hipLaunchKernelGGL(wgrad_chwn_kernel, dim3((unsigned)(N32 / 32), (unsigned)((C + 31) / 32), (unsigned)(H * W)), dim3(256), 0, ST(stream), x,
+                     out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK));
   return dlip_launch_status();
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 28
+#define DLIP_ABI_VERSION 29
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -483,6 +483,15 @@ int dlip_tap_gather_f32(const float* x, float* out, int64_t N, int32_t H, int32_
 int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
                            int32_t Ho, int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t R, int32_t S, int32_t dil_h,
                            int32_t dil_w, int32_t pad_h, int32_t pad_w, const float* scale, dlip_stream_t stream);
+/* Operand of a weight gradient RUN AS A CONVOLUTION: x [N,H,W,C] fp32 (row pitch ldx) -> out [C,H,W,N32] in the split format, the
+ * images as the reduction's channels (N32 >= N, a multiple of 32; images beyond N are zeros), times *scale when scale != NULL
+ * (the gradient's power-of-two lift).  With x' = this image of the layer input and g' = this image of dy,
+ *   dW[c, r, s, k] = dlip_conv_nhwc_f16x3(x' as N = C images of H x W x N32, filter g' = [K, Ho, Wo, N32], stride = the layer's
+ *                    dilation, dilation = the layer's stride, padding = the layer's) [c, r, s, k]        (r < R, s < S)
+ * -- ONE copy of each tensor instead of the R*S shifted copies of dlip_wgrad_operand_f32; dlip_conv_nhwc_f16x3 accepts filters of
+ * more than 32 taps for this (split input, fp32 output, no residual).  train_video.py:129-147 (loss.backward()). */
+int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t N32,
+                        const float* scale, dlip_stream_t stream);
 /* out [N,Hu,Wu,C] = dz [N,Ho,Wo,C] with stride-1 zeros inserted (out[n, ho*s, wo*s] = dz[n, ho, wo]): the data
  * gradient of a strided convolution as a stride-1 convolution (resnet.py:9-16 with stride 2). */
 int dlip_upsample_zero_f32(const float* dz, float* out, int64_t N, int32_t Ho, int32_t Wo, int32_t Hu, int32_t Wu,

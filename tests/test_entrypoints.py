@@ -42,6 +42,24 @@ def test_train_video_gpu_two_steps(tmp_path, mode):
 
 
 @pytest.mark.gpu
+def test_train_video_graph_step(tmp_path, capsys):
+    """--graph-step: the optimisation step recorded once and replayed as one HIP graph (deeplip_amd.train_plan): four steps = one
+    eager + recording + replays, per-iteration cosine learning rate read from a device tensor.  (That a replayed step is bit-
+    identical to the eager one is tests/test_train_video_gpu.py::test_recorded_training_step_is_bit_identical_to_eager.)"""
+    import train_video
+    loss, shape = train_video.main(["--save-path", str(tmp_path / "ck"), "--steps", "4", "--frames", "9", "--graph-step"])
+    assert np.isfinite(loss) and shape == (4, 54)
+    out = capsys.readouterr().out
+    assert out.count("(replayed)") == 3
+    lrs = [float(l.split(" lr ")[1].split()[0]) for l in out.splitlines() if l.startswith("epoch 0 it")]
+    assert lrs == sorted(lrs, reverse=True) and lrs[0] < 3e-4 and lrs[-1] > 0           # the cosine schedule advanced every iteration
+    sd = torch.load(tmp_path / "ck" / "1.pt", map_location="cpu")
+    ref = __import__("deeplip_amd.weightgen", fromlist=["x"]).fill_state_dict({"frontend3D.0.weight": (64, 1, 5, 7, 7)}, prefix="video.")
+    assert not np.array_equal(sd["frontend3D.0.weight"].numpy(), ref["frontend3D.0.weight"])
+    assert int(sd["frontend3D.1.num_batches_tracked"]) == 4
+
+
+@pytest.mark.gpu
 def test_train_audio_test_mode(tmp_path, monkeypatch):
     import train_audio
     monkeypatch.chdir(tmp_path)

@@ -297,3 +297,53 @@ def test_lipreading_train_mode_with_dropout_and_eval_roundtrip():
         out = net(x, lengths=[5, 5, 4, 3])
     torch.cuda.synchronize()
     assert out.shape == (4, 54) and bool(torch.isfinite(out).all())
+
+
+def test_recorded_training_step_is_bit_identical_to_eager():
+    """deeplip_amd.train_plan.TrainStepGraph: five optimisation steps on five different batches -- eager loop vs one eager step +
+    a recorded step replayed four times -- leave bit-identical parameters, BatchNorm statistics and losses (same Adam variant in
+    both: capturable, learning rate in a device tensor that a cosine scheduler updates every iteration; dropout off -- the
+    generator's offsets under capture are torch's business).  Two DIFFERENT Adam variants diverge by 5e-4 after two steps on this
+    model -- the biases in front of a BatchNorm have pure-rounding-noise gradients, which Adam turns into +-lr steps
+    (tools/probes/adam_variants.py) -- so only like is compared with like."""
+    from deeplip_amd import autograd as ag
+    from deeplip_amd.train_plan import TrainStepGraph
+    from models.video_models.model import Lipreading
+    B, T = 4, 9
+
+    def run(graph):
+        tcn = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.0, "dwpw": False, "width_mult": 1}
+        net = Lipreading(num_classes=54, relu_type="prelu", tcn_options=tcn, extract_feats=False)
+        sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="video.")
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.to(DEV).train()
+        opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(3e-4, device=DEV), weight_decay=1e-4, capturable=True)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=5, eta_min=4e-8)
+
+        def one(xb, lb, ln):
+            opt.zero_grad(set_to_none=True)
+            l = ag.margin_ce_loss(net(xb, lengths=ln), lb)
+            l.backward()
+            opt.step()
+            return l
+
+        plan = TrainStepGraph(one, eager_steps=1) if graph else None
+        losses = []
+        for i in range(5):
+            x = torch.from_numpy(wg.video_input(B, frames=T, key=f"tsg.v{i}")).to(DEV)
+            lab = torch.from_numpy((wg.labels(B, 54) + 7 * i) % 54).to(DEV)
+            ln = torch.tensor([T, T - 1, T - 2, T - 3][:B], dtype=torch.int32, device=DEV)
+            l = plan.step(x, lab, ln) if graph else one(x, lab, ln)
+            sched.step()
+            losses.append(float(l.detach()))
+        if graph:
+            plan.finish()
+            assert plan.recorded
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+    le, se = run(False)
+    lg, sg = run(True)
+    assert le == lg
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k

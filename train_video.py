@@ -70,6 +70,9 @@ def load_args(argv=None):
     p.add_argument("--frames", type=int, default=29)
     p.add_argument("--rgb", action="store_true", help="feed uint8 RGB [B,T,3,88,88] through the ingest kernel")
     p.add_argument("--head-only", action="store_true", help="train tcn.tcn_output on frozen eval-mode features")
+    p.add_argument("--graph-step", action="store_true",
+                   help="record the optimisation step once and replay it as one HIP graph (deeplip_amd.train_plan.TrainStepGraph: "
+                        "full-model training on one GPU; batches of one shape)")
     return p.parse_args(argv)
 
 
@@ -136,13 +139,30 @@ def train(model, args, device):
     params = [p for p in model.parameters() if p.requires_grad]
     # DP: gradients live in flat buckets whose all-reduces (RCCL) start while backward is still running
     buckets = ddist.GradBuckets(params) if (ddist.active() and device.type != "cpu") else None
-    optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=1e-4)                      # (:112-113)
+    graph_step = bool(getattr(args, "graph_step", False)) and full and buckets is None
+    if graph_step:      # a recorded step reads its learning rate from a device tensor (the scheduler updates it in place)
+        optimizer = torch.optim.Adam(params, lr=torch.tensor(float(args.lr), device=device), weight_decay=1e-4, capturable=True)
+    else:
+        optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=1e-4)                  # (:112-113)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=5, eta_min=4e-08)      # (:114)
     last = None
     if device.type == "cpu" and rank == 0:
         print("[plumbing] --device cpu exercises config / collate / optimizer / scheduler / checkpoint plumbing ONLY (BASELINE config C1): the "
               "engine has no CPU arithmetic path by design, so no forward runs and no loss or logits exist here; the same command on "
               "--device gpu computes them (C1-size run: tests/test_entrypoints.py::test_train_video_gpu_two_steps[c1-size]).")
+    plan = None
+    if graph_step:
+        from deeplip_amd.train_plan import TrainStepGraph
+
+        def one_step(xb, lb, ln):
+            optimizer.zero_grad(set_to_none=True)
+            lg = model(xb, lengths=ln)
+            ls = ag.margin_ce_loss(lg, lb, 1.0, 0.0)
+            ls.backward()
+            optimizer.step()
+            return ls, lg
+
+        plan = TrainStepGraph(one_step, eager_steps=1, device=device)
     for epoch in range(int(args.maxepoch)):
         run_loss = run_ok = run_n = 0.0
         model.train() if full else model.eval()                                                # (:129)
@@ -154,6 +174,17 @@ def train(model, args, device):
                 continue
             labels = labels.to(device)
             x = ops.ingest_rgb_u8(inputs.to(device)) if args.rgb else inputs.unsqueeze(1).to(device)   # :125
+            if plan is not None:
+                loss, logits = plan.step(x.contiguous(), labels, torch.as_tensor(lengths, dtype=torch.int32).to(device))
+                sched.step()
+                plan.finish()
+                _, pred = torch.max(torch.softmax(logits.detach(), 1), 1)
+                run_loss += float(loss.detach()) * len(labels); run_ok += float((pred == labels).sum()); run_n += len(labels)
+                last = (float(loss.detach()), tuple(logits.shape))
+                if it % args.display == 0 and rank == 0:
+                    print(f"epoch {epoch} it {it} loss {run_loss / run_n:.4f} acc {run_ok / run_n:.3f} lr {float(sched.get_last_lr()[0]):.2e}"
+                          f"{' (replayed)' if plan.recorded else ''}", flush=True)
+                continue
             optimizer.zero_grad(set_to_none=buckets is None)
             if full:
                 logits = model(x, lengths=lengths)                          # (:140) whole graph on the engine
