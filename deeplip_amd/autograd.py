@@ -276,11 +276,10 @@ class TDNNBlockTrainFn(Function):
         K, Cw, S = weight.shape
         if Cw != Cx or Cx % 4 or K % 4:
             raise ValueError(f"TDNN train path: channels must match and be multiples of 4 (x {Cx}, weight {Cw}, out {K})")
-        w_ksc = _permute3(weight.contiguous(), (0, 2, 1))                      # reference [K,C,S] -> kernel [K,S,C]
         from .autograd_video import conv_train
         B_, T_, C_in = x.shape
-        z = conv_train(x.view(B_, 1, T_, C_in), w_ksc.view(w_ksc.shape[0], 1, w_ksc.shape[1], w_ksc.shape[2]),
-                       bias.contiguous() if bias is not None else None, (1, 1), (0, 0), (1, dilation))
+        z = conv_train(x.view(B_, 1, T_, C_in), None, bias.contiguous() if bias is not None else None, (1, 1), (0, 0), (1, dilation),
+                       w_ref=weight.view(K, Cw, 1, S))                         # reference [K,C,S]: split image written straight from it
         z = z.view(B_, z.shape[2], z.shape[3])
         Tp = z.shape[1]
         y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first)
@@ -308,10 +307,10 @@ class TDNNBlockTrainFn(Function):
         from .autograd_video import pow2_lift
         lift = pow2_lift(dz2)                                                  # one absmax pass for dgrad and wgrad alike
         if ctx.needs_input_grad[0]:
-            w_csk = _permute3(weight.contiguous(), (1, 2, 0), flip_axis=2)     # [K,C,S] -> [C,S',K], taps reversed
             from .autograd_video import conv_train
             dzc = dz.contiguous()
-            dx = conv_train(dzc.view(B, 1, Tp, K), w_csk.view(Cx, 1, S, K), None, (1, 1), (0, (S - 1) * dilation), (1, dilation), lift=True, scale2=lift)
+            dx = conv_train(dzc.view(B, 1, Tp, K), None, None, (1, 1), (0, (S - 1) * dilation), (1, dilation), lift=True, scale2=lift,
+                            w_ref=weight.view(K, Cx, 1, S), transposed=True)   # [K,C,S] -> rows c of [S reversed][K]
             dx = dx.view(B, dx.shape[2], Cx)
         dweight = None
         if ctx.needs_input_grad[1]:
@@ -327,8 +326,8 @@ def _conv1d_wgrad(x, dz, S, dilation, lift=None):
     if Cx % 4 == 0 and K % 4 == 0:
         # a "valid" 1-D convolution is the H = 1 case of the fused operand path (autograd_video.wgrad_conv_fused)
         from .autograd_video import wgrad_conv
-        dwt = wgrad_conv(x.contiguous().view(B, 1, T, Cx), dz.contiguous().view(B, 1, Tp, K), 1, S, (1, 1), (0, 0), (1, dilation), scale2=lift)
-        return _permute3(dwt, (2, 1, 0))                                       # [S,C,K] -> [K,C,S]
+        return wgrad_conv(x.contiguous().view(B, 1, T, Cx), dz.contiguous().view(B, 1, Tp, K), 1, S, (1, 1), (0, 0), (1, dilation),
+                          scale2=lift).view(K, Cx, S)                         # reference layout [K,C,S]
     dzp = torch.zeros((B, T, K), device=dev, dtype=torch.float32)              # rows t >= T' stay zero: no cross-utterance terms
     dzp[:, :Tp].copy_(dz)
     J = B * T - (S - 1) * dilation                                             # rows every tap can read

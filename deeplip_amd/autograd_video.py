@@ -89,19 +89,35 @@ def pow2_lift(t):
     return scale2
 
 
-def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False, scale2=None):
-    """One convolution of a training step on NHWC fp32 ``x`` with CURRENT weights ``w_krsc`` [K,R,S,C] -> fp32 NHWC.
+def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False, scale2=None, w_ref=None, transposed=False):
+    """One convolution of a training step on NHWC fp32 ``x`` with CURRENT weights -> fp32 NHWC.  Weights: ``w_krsc`` [K,R,S,C]
+    (kernel layout), or ``w_ref`` = the parameter itself in the reference layout [Ko,Ci,R,S] -- then ``transposed`` False means
+    the forward filter bank and True the data gradient's (flipped taps, in / out channels swapped): the split-fp16 image is
+    written straight from the parameter by dlip_split_weights_perm_f32, no permuted fp32 copy in between.
     ``lift``: x is a gradient (tiny magnitudes): multiply by a power of two into fp16's normal range before the split and
     divide the result by it (the conv epilogue's post_scale) -- exact."""
     N, H, W, Cx = x.shape
-    K = w_krsc.shape[0]
-    if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or w_krsc.shape[3] != Cx:
-        return ops.conv_nhwc(x, w_krsc, bias, stride=stride, pad=pad, dil=dil)
-    dev = x.device
-    L = w_krsc.numel() // K
-    ws = torch.empty_like(w_krsc)
-    wsc = torch.empty((K,), device=dev, dtype=torch.float32)
-    check(lib().dlip_split_weights_rows_f32(ptr(w_krsc), ptr(ws), ptr(wsc), K, L, stream_handle()), "dlip_split_weights_rows_f32")
+    if w_ref is not None:
+        Ko, Ci, R_, S_ = w_ref.shape
+        K, Cw = (Ci, Ko) if transposed else (Ko, Ci)
+        if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or Cw != Cx:
+            w3 = w_ref.contiguous().view(Ko, Ci, R_ * S_)
+            w_krsc = (_permute3(w3, (1, 2, 0), flip_axis=2).view(Ci, R_, S_, Ko) if transposed else _permute3(w3, (0, 2, 1)).view(Ko, R_, S_, Ci))
+            return ops.conv_nhwc(x, w_krsc, bias, stride=stride, pad=pad, dil=dil)
+        dev = x.device
+        ws = torch.empty((K, R_, S_, Cw), device=dev, dtype=torch.float32)
+        wsc = torch.empty((K,), device=dev, dtype=torch.float32)
+        check(lib().dlip_split_weights_perm_f32(ptr(w_ref.contiguous()), ptr(ws), ptr(wsc), Ko, Ci, R_ * S_, 1 if transposed else 0, stream_handle()),
+              "dlip_split_weights_perm_f32")
+    else:
+        K = w_krsc.shape[0]
+        if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or w_krsc.shape[3] != Cx:
+            return ops.conv_nhwc(x, w_krsc, bias, stride=stride, pad=pad, dil=dil)
+        dev = x.device
+        L = w_krsc.numel() // K
+        ws = torch.empty_like(w_krsc)
+        wsc = torch.empty((K,), device=dev, dtype=torch.float32)
+        check(lib().dlip_split_weights_rows_f32(ptr(w_krsc), ptr(ws), ptr(wsc), K, L, stream_handle()), "dlip_split_weights_rows_f32")
     if not lift:
         return ops.conv_nhwc(ops.split_pack(x), ws, bias, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True)
     if scale2 is None:
@@ -158,7 +174,7 @@ def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None):
     operands are ONE split copy of their tensor (dlip_wgrad_chwn_f32; dy after its power-of-two lift) -- the reduction-major
     GEMM operand is R*S shifted copies of x: 1.03 GB written and read back per layer-1 convolution at B = 32, 0.9 ms of a
     0.1 ms data gradient's worth of FLOPs.  The Ho*Wo filter taps (484 on layer 1) are the conv kernel's address walk
-    (its variant without the 32-bit tap mask).  Returns [R*S, C, K] like wgrad_conv_fused."""
+    (its variant without the 32-bit tap mask).  Returns dW in the reference layout [K, C, R, S]."""
     N, H, W, Cx = x.shape
     _, Ho, Wo, K = dy.shape
     dev = x.device
@@ -175,13 +191,17 @@ def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None):
                         post_scale=inv, post_shift=const_vec(K, 0.0, dev))                 # [Cx, R', S', K]
     if out.shape[1] != R or out.shape[2] != S:
         out = out[:, :R, :S].contiguous()
-    return _permute3(out.view(Cx, R * S, K), (1, 0, 2))                                     # [R*S, Cx, K]
+    return _permute3(out.view(Cx, R * S, K), (2, 0, 1)).view(K, Cx, R, S)                   # the reference layout [K, C, R, S]
 
 
 def wgrad_conv(x, dy, R, S, stride, pad, dil, scale2=None):
-    if WGRAD == "conv" and TRAIN_CONV == "f16x3":
+    """dW of a Conv2d / Conv1d (H = 1) in the REFERENCE layout [K, C, R, S]."""
+    # (a 1x1 convolution has nothing to expand: its GEMM operand is one copy already, and as a convolution a strided one would
+    # compute a 2x2 output for the one position it needs -- 326 vs 160 us on layer2.0's shortcut, tools/bench_wgrad.py)
+    if WGRAD == "conv" and TRAIN_CONV == "f16x3" and R * S > 1:
         return wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2)
-    return wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2)
+    dwt = wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2)                           # [R*S, C, K]
+    return _permute3(dwt, (2, 1, 0)).view(dy.shape[3], x.shape[3], R, S)
 
 
 class ConvTrainFn(Function):
@@ -197,8 +217,7 @@ class ConvTrainFn(Function):
         K, Cw, R, S = weight.shape
         if Cw != Cx or Cx % 4 or K % 4:
             raise ValueError(f"conv train path: channels must match and be multiples of 4 (x {Cx}, weight {Cw}, out {K})")
-        w_krsc = _permute3(weight.contiguous().view(K, Cw, R * S), (0, 2, 1)).view(K, R, S, Cw)
-        y = conv_train(x, w_krsc, bias.contiguous() if bias is not None else None, stride, pad, dil)
+        y = conv_train(x, None, bias.contiguous() if bias is not None else None, stride, pad, dil, w_ref=weight)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
         return y
@@ -218,22 +237,21 @@ class ConvTrainFn(Function):
         dx = None
         lift = pow2_lift(dy) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None   # zero insertion does not change max|dy|
         if ctx.needs_input_grad[0]:
-            w_crsk = _permute3(weight.contiguous().view(K, Cx, R * S), (1, 2, 0), flip_axis=2).view(Cx, R, S, K)
             src = dy
             if sh != 1 or sw != 1:
                 Hu, Wu = H + 2 * ph - dh * (R - 1), W + 2 * pw - dw * (S - 1)
                 src = torch.empty((N, Hu, Wu, K), device=dev, dtype=torch.float32)
                 check(lib().dlip_upsample_zero_f32(ptr(dy), ptr(src), N, Ho, Wo, Hu, Wu, K, sh, sw, stream_handle()),
                       "dlip_upsample_zero_f32")
-            dx = conv_train(src, w_crsk, None, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), lift=True, scale2=lift)
+            dx = conv_train(src, None, None, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), lift=True, scale2=lift,
+                            w_ref=weight, transposed=True)
         dweight = None
         if ctx.needs_input_grad[1]:
             # all taps side by side in ONE [J, RS*C] matrix -> one GEMM with RS*C output rows (RS times the
             # tiles of a per-tap GEMM: a 64-channel layer would otherwise be a single 64x64 tile)
             taps = R * S
             if Cx % 4 == 0 and K % 4 == 0:
-                dwt = wgrad_conv(x, dy, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift)
-                return dx, _permute3(dwt, (2, 1, 0)).view(K, Cx, R, S), dbias, None, None, None
+                return dx, wgrad_conv(x, dy, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift), dbias, None, None, None
             rows = torch.empty((J, taps * Cx), device=dev, dtype=torch.float32)
             for t in range(taps):
                 r, s = divmod(t, S)

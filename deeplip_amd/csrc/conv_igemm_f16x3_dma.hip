@@ -1036,7 +1036,10 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     // few tiles with very long reductions (the weight-gradient GEMMs of training: 1..8 tiles, 10^4 slices):
     // the finisher adds the parts of a tile one after the other (~2 us each), so a tile is cut into at most
     // kMaxPartsPerTile parts -- 512 parts of one 64x64 tile cost 1 ms of serial slab reads for 90 us of MFMA
-    if (Gb > tiles * kMaxPartsPerTile) Gb = tiles * kMaxPartsPerTile;
+    // (reductions of thousands of slices -- the weight gradients run as convolutions: 5 tiles x 14 036 slices on layer 1 -- afford
+    // more parts: 64 parts of 5 tiles leave 192 of 512 slots idle)
+    const long long max_parts = a.nk >= 16384 ? 4 * kMaxPartsPerTile : a.nk >= 4096 ? 2 * kMaxPartsPerTile : kMaxPartsPerTile;
+    if (Gb > tiles * max_parts) Gb = tiles * max_parts;
     const double bal_us = (double)sk.iters / Gb / a.nk * tile_us + kHandoffUs * (BM * BN / 16384.0);
     // Short reductions on a full chip (nk <= 16 slices, at least one tile per slot: the k = 1 TDNN layers) run
     // plain: a tile's slab hand-off costs as much as a third of such a tile, and the under-filled last round of a
@@ -1131,6 +1134,9 @@ static int dma_pick(long long M, int K, int nk, int epi) {
   if (K <= 64) return 1;
   if (nk <= 8) return 4;
   if (nk >= 32 && M >= 8192) return 5;
+  // very long reductions over few tiles (the weight gradients run as convolutions: 5-36 tiles of 260-3 500 slices; no forward launch reduces over more than 144): the balanced split
+  // fills the chip whatever M is, and the 256x128 tile's loop is the faster one (7-12 % per launch, tools/bench_wgrad.py)
+  if (nk >= 256 && M >= 1024) return 5;
   // (Measured and rejected in round 2: 160-row tiles for the short plain launches -- the k = 1 TDNN layers are 592 tiles of
   // 128x128 on 512 slots, two rounds with the second 16 % full, and 476 tiles of 160x128, one round: 47.8 vs 46.8 us.  The
   // under-filled second round is cheap because these layers wait for operands, not for the matrix core.)

@@ -331,6 +331,43 @@ __global__ __launch_bounds__(256) void split_weights_rows_kernel(const float* __
   }
 }
 
+// The same from the REFERENCE layout w [K, C, T] (T = R*S taps; nn.Conv2d / nn.Conv1d weights), permutation included -- one launch
+// instead of permute + split, 94 times per training step of the lip-clip model:
+//   MODE 0 (forward):        row k = [T][C]          row[t * C + c]             = w[k, c, t]
+//   MODE 1 (data gradient):  row c = [T flipped][K]  row[(T - 1 - t) * K + k]   = w[k, c, t]
+// One workgroup per output row; the row's blocks of 32 values are (hi | lo) as above.  Rows are a few thousand values read
+// through L2 (the whole bank is at most 9.4 MB), so the strided gather of MODE 1 costs nothing measurable.
+template <int MODE>
+__global__ __launch_bounds__(256) void split_weights_perm_kernel(const float* __restrict__ w, float* __restrict__ ws, float* __restrict__ scale,
+                                                                 int K, int C, int T) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int inner = MODE == 0 ? C : K;            // channels of one tap in the output row
+  const int L = T * inner;
+  auto src = [&](int i) -> float {
+    const int t = i / inner, j = i - t * inner;
+    return MODE == 0 ? w[((long long)row * C + j) * T + t] : w[((long long)j * C + row) * T + (T - 1 - t)];
+  };
+  float m = 0.f;
+  for (int i = threadIdx.x; i < L; i += 256) m = fmaxf(m, fabsf(src(i)));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sc = 1.f;
+  if (m > 0.f && m < 3.0e38f) sc = exp2f(floorf(log2f(1023.0f / m)));
+  if (threadIdx.x == 0) scale[row] = sc;
+  _Float16* out = reinterpret_cast<_Float16*>(ws + (long long)row * L);
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const float t = src(i) * sc;
+    const _Float16 hi = (_Float16)t, lo = (_Float16)(t - (float)hi);
+    const int b = i >> 5, q = i & 31;
+    out[b * 64 + q] = hi;
+    out[b * 64 + 32 + q] = lo;
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_from_scalar_kernel(const float* __restrict__ src, float* __restrict__ y, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) y[i] = src[0];
@@ -507,6 +544,16 @@ extern "C" int dlip_split_pack_scaled_f32(const float* x, float* y, const float*
 extern "C" int dlip_split_weights_rows_f32(const float* w, float* w_split, float* w_scale, int32_t K, int32_t L, dlip_stream_t stream) {
   DLIP_CHECK_ARG(w && w_split && w_scale && K > 0 && L > 0 && (L & 31) == 0);
   hipLaunchKernelGGL(split_weights_rows_kernel, dim3((unsigned)K), dim3(256), 0, static_cast<hipStream_t>(stream), w, w_split, w_scale, L);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_split_weights_perm_f32(const float* w_kct, float* w_split, float* w_scale, int32_t K, int32_t C, int32_t T,
+                                           int32_t mode, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(w_kct && w_split && w_scale && K > 0 && C > 0 && T > 0 && (mode == 0 || mode == 1));
+  DLIP_CHECK_ARG(((mode == 0 ? C : K) & 31) == 0 && (long long)K * C * T < (1ll << 31));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mode == 0) hipLaunchKernelGGL(split_weights_perm_kernel<0>, dim3((unsigned)K), dim3(256), 0, st, w_kct, w_split, w_scale, K, C, T);
+  else hipLaunchKernelGGL(split_weights_perm_kernel<1>, dim3((unsigned)C), dim3(256), 0, st, w_kct, w_split, w_scale, K, C, T);
   return dlip_launch_status();
 }
 

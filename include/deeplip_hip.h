@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 29
+#define DLIP_ABI_VERSION 30
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -446,6 +446,11 @@ int dlip_split_pack_scaled_f32(const float* x, float* y, const float* scale, int
  * w_split [K][L] (per block 32 hi halves | 32 lo halves of w * w_scale[k]), w_scale[k] = 2^floor(log2(1023 / max|w[k,:]|))
  * (1 for a zero row) -- the w_split / w_scale pair dlip_conv_nhwc_f16x3 takes. */
 int dlip_split_weights_rows_f32(const float* w, float* w_split, float* w_scale, int32_t K, int32_t L, dlip_stream_t stream);
+/* The same straight from the reference layout w [K, C, T] (T = R*S taps: nn.Conv2d / nn.Conv1d weights), permutation included:
+ * mode 0 = the forward operand, K rows of [T][C]; mode 1 = the data-gradient operand, C rows of [T reversed][K] (the flipped,
+ * transposed filter).  w_scale has one entry per output row; the row's inner channel count (C resp. K) must be a multiple of 32. */
+int dlip_split_weights_perm_f32(const float* w_kct, float* w_split, float* w_scale, int32_t K, int32_t C, int32_t T, int32_t mode,
+                                dlip_stream_t stream);
 /* y[0:n] = src[0] (device scalar broadcast: the per-channel 1/scale vector of the weight-gradient GEMM). */
 int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream_t stream);
 

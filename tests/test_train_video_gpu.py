@@ -317,7 +317,7 @@ def test_recorded_training_step_is_bit_identical_to_eager():
         sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="video.")
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         net.to(DEV).train()
-        opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(3e-4, device=DEV), weight_decay=1e-4, capturable=True)
+        opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(3e-4, device=DEV), weight_decay=1e-4, capturable=True, fused=True)
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=5, eta_min=4e-8)
 
         def one(xb, lb, ln):

@@ -23,7 +23,7 @@ net = Lipreading(num_classes=54, relu_type="prelu", tcn_options=tcn, extract_fea
 sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="video.")
 net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
 net.cuda().train()
-opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(3e-4, device="cuda"), weight_decay=1e-4, capturable=True)
+opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(3e-4, device="cuda"), weight_decay=1e-4, capturable=True, fused=True)
 x = torch.from_numpy(wg.video_input(a.batch, frames=a.frames, key="bench.vtrain")).cuda()
 lab = torch.from_numpy(wg.labels(a.batch, 54)).cuda()
 lengths = torch.full((a.batch,), a.frames, dtype=torch.int32, device="cuda")

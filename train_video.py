@@ -141,7 +141,7 @@ def train(model, args, device):
     buckets = ddist.GradBuckets(params) if (ddist.active() and device.type != "cpu") else None
     graph_step = bool(getattr(args, "graph_step", False)) and full and buckets is None
     if graph_step:      # a recorded step reads its learning rate from a device tensor (the scheduler updates it in place)
-        optimizer = torch.optim.Adam(params, lr=torch.tensor(float(args.lr), device=device), weight_decay=1e-4, capturable=True)
+        optimizer = torch.optim.Adam(params, lr=torch.tensor(float(args.lr), device=device), weight_decay=1e-4, capturable=True, fused=True)
     else:
         optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=1e-4)                  # (:112-113)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=5, eta_min=4e-08)      # (:114)
