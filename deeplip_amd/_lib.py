@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 30
+ABI_VERSION = 32
 
 _lock = threading.Lock()
 _lib = None
@@ -51,9 +51,9 @@ SIGNATURES = {
     "dlip_debug_set": [c_i32, c_i32],
     "dlip_bn_rows_chunks": [c_i32],
     "dlip_bn_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_i32, c_stream],
-    "dlip_bn_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_stream],
+    "dlip_bn_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_f, c_stream],
     "dlip_bn_prelu_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_stream],
-    "dlip_bn_prelu_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_stream],
+    "dlip_bn_prelu_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_f, c_stream],
     "dlip_colsum_rows_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_meanstd_pool_bwd_f32": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_permute3_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
@@ -70,6 +70,8 @@ SIGNATURES = {
     "dlip_prelu_rows_fwd_f32": [c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_prelu_rows_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_maxpool3x3s2_bwd_f32": [c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_stream],
+    "dlip_maxpool3x3s2_idx_f32": [c_f, c_f, C.c_void_p, c_i64, c_i32, c_i32, c_i32, c_stream],
+    "dlip_maxpool3x3s2_bwd_idx_f32": [C.c_void_p, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_stream],
     "dlip_row_broadcast_f32": [c_f, c_f, c_f, c_i64, c_i32, c_i32, C.c_float, c_stream],
     "dlip_stem_im2col_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem_wgrad_operand_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_stream],

@@ -233,9 +233,11 @@ def _bn_rows_bwd(dy2, x2, gamma, beta, mean, invstd, slope, act_first):
     dx = torch.empty_like(x2)
     dg = torch.empty_like(mean)
     db = torch.empty_like(mean)
+    lift = torch.empty((2,), device=x2.device, dtype=torch.float32)
     check(lib().dlip_bn_rows_train_bwd_f32(ptr(dy2), ptr(x2), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx), ptr(dg),
-                                           ptr(db), ptr(_ws(M, C_, x2.device)), M, C_, slope, int(act_first), stream_handle()),
+                                           ptr(db), ptr(_ws(M, C_, x2.device)), M, C_, slope, int(act_first), ptr(lift), stream_handle()),
           "dlip_bn_rows_train_bwd_f32")
+    dx._dlip_lift = lift      # the power-of-two lift of dx, formed by the pass that wrote it (autograd_video.pow2_lift picks it up)
     return dx, dg, db
 
 
@@ -245,17 +247,20 @@ class BNRowsActFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, act_first):
-        x = x.contiguous()
+        shape = tuple(x.shape)                                 # any channels-last shape [..., C]: rows = all leading axes
+        x = x.contiguous().view(-1, shape[-1])
         y, mean, invstd = _bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, act_first)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
-        ctx.slope, ctx.act_first = slope, act_first
-        return y
+        ctx.slope, ctx.act_first, ctx.shape = slope, act_first, shape
+        return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
-        dx, dg, db = _bn_rows_bwd(dy.contiguous(), x, gamma, beta, mean, invstd, ctx.slope, ctx.act_first)
-        return dx, dg, db, None, None, None, None, None, None
+        dx, dg, db = _bn_rows_bwd(dy.contiguous().view(x.shape), x, gamma, beta, mean, invstd, ctx.slope, ctx.act_first)
+        out = dx.view(ctx.shape)
+        out._dlip_lift = dx._dlip_lift                        # travels with the tensor object the next backward receives
+        return out, dg, db, None, None, None, None, None, None
 
 
 class TDNNBlockTrainFn(Function):

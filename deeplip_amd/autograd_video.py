@@ -84,6 +84,9 @@ WGRAD_ODD_PITCH = True
 def pow2_lift(t):
     """Device pair (2^e, 2^-e) that lifts a gradient tensor's largest magnitude to ~1024 (dlip_pow2_scale_f32): computed ONCE per
     backward step and shared by the data-gradient convolution and the weight-gradient operand of the same dy."""
+    ready = getattr(t, "_dlip_lift", None)       # the producer of this gradient (a BatchNorm backward) formed it while writing t
+    if ready is not None:
+        return ready
     scale2 = torch.empty((2,), device=t.device, dtype=torch.float32)
     check(lib().dlip_pow2_scale_f32(ptr(t), ptr(scale2), t.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
     return scale2
@@ -348,7 +351,8 @@ class BNPReLUFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, slope, running_mean, running_var, momentum, eps):
-        x = x.contiguous()
+        shape = tuple(x.shape)                                 # any channels-last shape [..., C]
+        x = x.contiguous().view(-1, shape[-1])
         M, C_ = x.shape
         y = torch.empty_like(x)
         mean = torch.empty((C_,), device=x.device, dtype=torch.float32)
@@ -358,38 +362,49 @@ class BNPReLUFn(Function):
                                                      ptr(running_mean), ptr(running_var), ptr(ws), M, C_, momentum, eps, stream_handle()),
               "dlip_bn_prelu_rows_train_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, slope, mean, invstd)
-        return y
+        ctx.shape = shape
+        return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, slope, mean, invstd = ctx.saved_tensors
         M, C_ = x.shape
-        dy = dy.contiguous()
+        dy = dy.contiguous().view(M, C_)
         dx = torch.empty_like(x)
         dg, db, ds = (torch.empty_like(mean) for _ in range(3))
         ws = torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 4,), device=x.device, dtype=torch.float64)
+        lift = torch.empty((2,), device=x.device, dtype=torch.float32)
         check(lib().dlip_bn_prelu_rows_train_bwd_f32(ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(mean), ptr(invstd), ptr(dx),
-                                                     ptr(dg), ptr(db), ptr(ds), ptr(ws), M, C_, stream_handle()),
+                                                     ptr(dg), ptr(db), ptr(ds), ptr(ws), M, C_, ptr(lift), stream_handle()),
               "dlip_bn_prelu_rows_train_bwd_f32")
+        dx = dx.view(ctx.shape)
+        dx._dlip_lift = lift      # see autograd._bn_rows_bwd: travels with the tensor object the convolution backward receives
         return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None
 
 
 class MaxPoolFn(Function):
-    """MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on [(B T),H,W,C] (model.py:85)."""
+    """MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on [(B T),H,W,C] (model.py:85).  The forward records each maximum's tap as one byte, the
+    backward reads those instead of re-scanning the windows of x (and x itself is not kept alive for it)."""
 
     @staticmethod
     def forward(ctx, x):
         x = x.contiguous()
-        ctx.save_for_backward(x)
-        return ops.maxpool3x3s2(x)
+        N, H, W, C_ = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, Ho, Wo, C_), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, Ho, Wo, C_ // 4), device=x.device, dtype=torch.int32)
+        check(lib().dlip_maxpool3x3s2_idx_f32(ptr(x), ptr(y), idx.data_ptr(), N, H, W, C_, stream_handle()), "dlip_maxpool3x3s2_idx_f32")
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, H, W, C_)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        N, H, W, C_ = x.shape
-        dx = torch.empty_like(x)
-        check(lib().dlip_maxpool3x3s2_bwd_f32(ptr(x), ptr(dy.contiguous()), ptr(dx), N, H, W, C_, stream_handle()),
-              "dlip_maxpool3x3s2_bwd_f32")
+        (idx,) = ctx.saved_tensors
+        N, H, W, C_ = ctx.shape
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        check(lib().dlip_maxpool3x3s2_bwd_idx_f32(idx.data_ptr(), ptr(dy.contiguous()), ptr(dx), N, H, W, C_, stream_handle()),
+              "dlip_maxpool3x3s2_bwd_idx_f32")
         return dx
 
 
@@ -467,10 +482,9 @@ def batchnorm(x, bn):
     """Train-mode BatchNorm over all leading axes of a channels-last tensor; running stats updated in place
     (nn.BatchNorm1d/2d/3d: resnet.py:51,64,16; model.py:83; tcn.py:42)."""
     C_ = x.shape[-1]
-    y = BNRowsActFn.apply(x.contiguous().view(-1, C_), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                          1.0, False)
+    y = BNRowsActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, 1.0, False)
     bn.num_batches_tracked += 1
-    return y.view(x.shape)
+    return y
 
 
 def batchnorm_prelu(x, bn, act):
@@ -482,10 +496,10 @@ def batchnorm_prelu(x, bn, act):
         return prelu(batchnorm(x, bn), act)
     if w is None:
         w = const_vec(C_, 0.0, x.device)
-    y = BNPReLUFn.apply(x.contiguous().view(-1, C_), bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(),
+    y = BNPReLUFn.apply(x, bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(),
                         bn.running_mean, bn.running_var, bn.momentum, bn.eps)
     bn.num_batches_tracked += 1
-    return y.view(x.shape)
+    return y
 
 
 def prelu(x, act):

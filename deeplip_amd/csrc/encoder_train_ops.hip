@@ -184,8 +184,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                            f32x4* __restrict__ dx, long long n4, int C4, int M, float slope,
-                                                           int act_first, const float* __restrict__ slope_vec = nullptr) {
+                                                           int act_first, const float* __restrict__ slope_vec = nullptr,
+                                                           unsigned* __restrict__ amax_acc = nullptr) {
   const float invM = 1.f / (float)M;
+  float amax = 0.f;     // max |dx| of the launch -> amax_acc (the next convolution backward's power-of-two lift, without its own pass)
   const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
   f32x4 mu, is, ga, be, dg, db, sl = {slope, slope, slope, slope};
   auto load = [&](int c) {
@@ -208,8 +210,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
       float d = ga[k] * is[k] * (g - db[k] * invM - xh * dg[k] * invM);
       if (act_first) d *= xv[k] >= 0.f ? 1.f : slope;
       o[k] = d;
+      amax = fmaxf(amax, fabsf(d));
     }
     dx[i] = o;
+  }
+  if (amax_acc) {
+    __shared__ float amax_red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
+      if (!(m == m)) m = 3.4e38f;
+      atomicMax(amax_acc, __float_as_uint(m));
+    }
   }
 }
 
@@ -420,7 +435,7 @@ extern "C" int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, co
 extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
                                           const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                                           float* dbeta, double* workspace, int32_t M, int32_t C, float slope,
-                                          int32_t act_first, dlip_stream_t stream) {
+                                          int32_t act_first, float* dx_lift2, dlip_stream_t stream) {
   DLIP_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace);
   DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0);
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
@@ -430,14 +445,17 @@ extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const
                      gamma, beta, workspace, M, C, slope, act_first);
   hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
   const long long n4 = (long long)M * (C / 4);
+  unsigned* acc = reinterpret_cast<unsigned*>(dx_lift2);
+  if (acc && hipMemsetAsync(acc, 0, 2 * sizeof(float), st) != hipSuccess) return DLIP_EINVAL;
   if (const unsigned gf = grid_fixed(n4, C / 4))
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first);
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, nullptr, acc);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first);
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, nullptr, acc);
+  if (acc) hipLaunchKernelGGL(pow2_finalize_kernel, dim3(1), dim3(1), 0, st, dx_lift2, 1024.0f);
   return dlip_launch_status();
 }
 
@@ -467,7 +485,7 @@ extern "C" int dlip_bn_prelu_rows_train_fwd_f32(const float* x, const float* gam
 extern "C" int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
                                                 const float* slope, const float* save_mean, const float* save_invstd, float* dx,
                                                 float* dgamma, float* dbeta, float* dslope, double* workspace, int32_t M, int32_t C,
-                                                dlip_stream_t stream) {
+                                                float* dx_lift2, dlip_stream_t stream) {
   DLIP_CHECK_ARG(dy && x && gamma && beta && slope && save_mean && save_invstd && dx && dgamma && dbeta && dslope && workspace);
   DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0);
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
@@ -479,14 +497,17 @@ extern "C" int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x,
   hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace + (long long)chunks * C * 2, dslope,
                      nullptr, C, chunks);
   const long long n4 = (long long)M * (C / 4);
+  unsigned* acc = reinterpret_cast<unsigned*>(dx_lift2);
+  if (acc && hipMemsetAsync(acc, 0, 2 * sizeof(float), st) != hipSuccess) return DLIP_EINVAL;
   if (const unsigned gf = grid_fixed(n4, C / 4))
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope);
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope, acc);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope);
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope, acc);
+  if (acc) hipLaunchKernelGGL(pow2_finalize_kernel, dim3(1), dim3(1), 0, st, dx_lift2, 1024.0f);
   return dlip_launch_status();
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 30
+#define DLIP_ABI_VERSION 32
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -405,11 +405,13 @@ int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, const float* 
                                float* save_mean, float* save_invstd, float* running_mean,
                                float* running_var, double* workspace, int32_t M, int32_t C, float momentum,
                                float eps, float slope, int32_t act_first, dlip_stream_t stream);
-/* Backward of the above: dy = dL/dy -> dx = dL/dx [M,C], dgamma, dbeta [C]. */
+/* Backward of the above: dy = dL/dy -> dx = dL/dx [M,C], dgamma, dbeta [C].  dx_lift2 (nullable, 2 floats): the power-of-two
+ * lift of dx, (2^e, 2^-e) with max|dx| * 2^e in [512, 1024] -- what dlip_pow2_scale_f32(dx, ., 1024) would return, formed by the
+ * pass that writes dx: the convolution backward that consumes dx needs it and would otherwise read dx once more. */
 int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                                float* dbeta, double* workspace, int32_t M, int32_t C, float slope,
-                               int32_t act_first, dlip_stream_t stream);
+                               int32_t act_first, float* dx_lift2, dlip_stream_t stream);
 /* BatchNorm (batch statistics) + PReLU with PER-CHANNEL slopes in the same passes: y = prelu(bn(x)) (resnet.py:51-53 bn1 + relu1,
  * tcn.py:42-43, model.py:83-84 under model.train()).  Forward as dlip_bn_rows_train_fwd_f32 with slope[C] applied behind the
  * affine; backward additionally returns dslope[C] = sum over rows of (bn(x) < 0 ? dy * bn(x) : 0) from the SAME pass that
@@ -420,7 +422,7 @@ int dlip_bn_prelu_rows_train_fwd_f32(const float* x, const float* gamma, const f
                                      double* workspace, int32_t M, int32_t C, float momentum, float eps, dlip_stream_t stream);
 int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* slope,
                                      const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
-                                     float* dslope, double* workspace, int32_t M, int32_t C, dlip_stream_t stream);
+                                     float* dslope, double* workspace, int32_t M, int32_t C, float* dx_lift2, dlip_stream_t stream);
 /* y[c] = sum_m x[m,c] (bias gradients), same chunked reduction and workspace. */
 int dlip_colsum_rows_f32(const float* x, float* y, double* workspace, int32_t M, int32_t C, dlip_stream_t stream);
 
@@ -511,6 +513,12 @@ int dlip_prelu_rows_bwd_f32(const float* dy, const float* x, const float* slope,
  * dy [N,Ho,Wo,C] -> dx; first-maximum tie rule (row-major window scan), deterministic. */
 int dlip_maxpool3x3s2_bwd_f32(const float* x, const float* dy, float* dx, int64_t N, int32_t H, int32_t W, int32_t C,
                               dlip_stream_t stream);
+/* The training pair that does not re-scan x: the forward also writes, per output element, the tap (r*3+s) of its first maximum
+ * as one byte (idx: N*Ho*Wo*C bytes, 4 channels per 32-bit word), the backward reads at most four (byte, dy) pairs per input
+ * pixel.  y is bit-identical to dlip_maxpool3x3s2_f32, dx to dlip_maxpool3x3s2_bwd_f32. */
+int dlip_maxpool3x3s2_idx_f32(const float* x, float* y, uint32_t* idx, int64_t N, int32_t H, int32_t W, int32_t C, dlip_stream_t stream);
+int dlip_maxpool3x3s2_bwd_idx_f32(const uint32_t* idx, const float* dy, float* dx, int64_t N, int32_t H, int32_t W, int32_t C,
+                                  dlip_stream_t stream);
 /* dx[n, p, :] = dy[n, :] * w, p < P: w = scale (AdaptiveAvgPool2d(1) backward, resnet.py:83: scale = 1/(H W)),
  * or with lengths != NULL w = (p < len[n] ? 1/len[n] : 0) (masked temporal mean backward, model.py:16-17). */
 int dlip_row_broadcast_f32(const float* dy, const int32_t* lengths, float* dx, int64_t N, int32_t P, int32_t C,
