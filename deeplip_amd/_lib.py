@@ -13,7 +13,8 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 32
+ABI_VERSION = 33
+LIFT_WORDS = 4098
 
 _lock = threading.Lock()
 _lib = None

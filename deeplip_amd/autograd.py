@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from ._lib import check, lib, ptr, stream_handle
+from ._lib import LIFT_WORDS, check, lib, ptr, stream_handle
 
 
 def _gemm(A, B, M, N, K, ta=False, tb=False):
@@ -233,7 +233,7 @@ def _bn_rows_bwd(dy2, x2, gamma, beta, mean, invstd, slope, act_first):
     dx = torch.empty_like(x2)
     dg = torch.empty_like(mean)
     db = torch.empty_like(mean)
-    lift = torch.empty((2,), device=x2.device, dtype=torch.float32)
+    lift = torch.empty((LIFT_WORDS,), device=x2.device, dtype=torch.float32)
     check(lib().dlip_bn_rows_train_bwd_f32(ptr(dy2), ptr(x2), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx), ptr(dg),
                                            ptr(db), ptr(_ws(M, C_, x2.device)), M, C_, slope, int(act_first), ptr(lift), stream_handle()),
           "dlip_bn_rows_train_bwd_f32")

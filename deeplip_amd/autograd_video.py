@@ -15,7 +15,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from ._lib import check, lib, ptr, stream_handle
+from ._lib import LIFT_WORDS, check, lib, ptr, stream_handle
 from .autograd import BNRowsActFn, _permute3, _ws
 
 
@@ -373,7 +373,7 @@ class BNPReLUFn(Function):
         dx = torch.empty_like(x)
         dg, db, ds = (torch.empty_like(mean) for _ in range(3))
         ws = torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 4,), device=x.device, dtype=torch.float64)
-        lift = torch.empty((2,), device=x.device, dtype=torch.float32)
+        lift = torch.empty((LIFT_WORDS,), device=x.device, dtype=torch.float32)
         check(lib().dlip_bn_prelu_rows_train_bwd_f32(ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(mean), ptr(invstd), ptr(dx),
                                                      ptr(dg), ptr(db), ptr(ds), ptr(ws), M, C_, ptr(lift), stream_handle()),
               "dlip_bn_prelu_rows_train_bwd_f32")

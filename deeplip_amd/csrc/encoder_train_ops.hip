@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
     if (threadIdx.x == 0) {
       float m = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
       if (!(m == m)) m = 3.4e38f;
-      atomicMax(amax_acc, __float_as_uint(m));
-    }
+      amax_acc[blockIdx.x] = __float_as_uint(m);    // one word per workgroup, reduced by pow2_finalize_parts_kernel: thousands of
+    }                                               // workgroups meeting in ONE atomic cost 14 us per launch (the hot-line effect)
   }
 }
 
@@ -298,6 +298,26 @@ __global__ void pow2_finalize_kernel(float* __restrict__ out, float target) {
   if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
   out[0] = s;
   out[1] = 1.f / s;
+}
+
+// out[0] = 2^floor(log2(target / max(parts))), out[1] = 1 / out[0]: the per-workgroup maxima of a producer pass (non-negative floats
+// as bit patterns) reduced by one workgroup
+__global__ __launch_bounds__(256) void pow2_finalize_parts_kernel(const unsigned* __restrict__ parts, int n, float* __restrict__ out, float target) {
+  __shared__ unsigned red[4];
+  unsigned m = 0u;
+  for (int i = threadIdx.x; i < n; i += 256) m = max(m, parts[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float mx = __uint_as_float(max(max(red[0], red[1]), max(red[2], red[3])));
+    float s = 1.f;
+    if (mx > 0.f && mx < 3.0e38f) s = exp2f(floorf(log2f(target / mx)));
+    if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
+    out[0] = s;
+    out[1] = 1.f / s;
+  }
 }
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -445,17 +465,18 @@ extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const
                      gamma, beta, workspace, M, C, slope, act_first);
   hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
   const long long n4 = (long long)M * (C / 4);
-  unsigned* acc = reinterpret_cast<unsigned*>(dx_lift2);
-  if (acc && hipMemsetAsync(acc, 0, 2 * sizeof(float), st) != hipSuccess) return DLIP_EINVAL;
-  if (const unsigned gf = grid_fixed(n4, C / 4))
+  unsigned* acc = dx_lift2 ? reinterpret_cast<unsigned*>(dx_lift2) + 2 : nullptr;   // per-workgroup maxima behind the pair
+  const unsigned gf = grid_fixed(n4, C / 4);
+  const unsigned grid = gf ? gf : grid1d(n4);
+  if (gf)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
                        reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, nullptr, acc);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
                        reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, nullptr, acc);
-  if (acc) hipLaunchKernelGGL(pow2_finalize_kernel, dim3(1), dim3(1), 0, st, dx_lift2, 1024.0f);
+  if (acc) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
   return dlip_launch_status();
 }
 
@@ -497,17 +518,18 @@ extern "C" int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x,
   hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace + (long long)chunks * C * 2, dslope,
                      nullptr, C, chunks);
   const long long n4 = (long long)M * (C / 4);
-  unsigned* acc = reinterpret_cast<unsigned*>(dx_lift2);
-  if (acc && hipMemsetAsync(acc, 0, 2 * sizeof(float), st) != hipSuccess) return DLIP_EINVAL;
-  if (const unsigned gf = grid_fixed(n4, C / 4))
+  unsigned* acc = dx_lift2 ? reinterpret_cast<unsigned*>(dx_lift2) + 2 : nullptr;   // per-workgroup maxima behind the pair
+  const unsigned gf = grid_fixed(n4, C / 4);
+  const unsigned grid = gf ? gf : grid1d(n4);
+  if (gf)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
                        reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope, acc);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
                        reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope, acc);
-  if (acc) hipLaunchKernelGGL(pow2_finalize_kernel, dim3(1), dim3(1), 0, st, dx_lift2, 1024.0f);
+  if (acc) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
   return dlip_launch_status();
 }
 

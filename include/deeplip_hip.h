@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 32
+#define DLIP_ABI_VERSION 33
+#define DLIP_LIFT_WORDS 4098   /* (2^e, 2^-e) + one word per workgroup of the pass that forms them */
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -405,7 +406,7 @@ int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, const float* 
                                float* save_mean, float* save_invstd, float* running_mean,
                                float* running_var, double* workspace, int32_t M, int32_t C, float momentum,
                                float eps, float slope, int32_t act_first, dlip_stream_t stream);
-/* Backward of the above: dy = dL/dy -> dx = dL/dx [M,C], dgamma, dbeta [C].  dx_lift2 (nullable, 2 floats): the power-of-two
+/* Backward of the above: dy = dL/dy -> dx = dL/dx [M,C], dgamma, dbeta [C].  dx_lift2 (nullable, DLIP_LIFT_WORDS floats: the pair, then per-workgroup scratch): the power-of-two
  * lift of dx, (2^e, 2^-e) with max|dx| * 2^e in [512, 1024] -- what dlip_pow2_scale_f32(dx, ., 1024) would return, formed by the
  * pass that writes dx: the convolution backward that consumes dx needs it and would otherwise read dx once more. */
 int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
