@@ -299,6 +299,23 @@ class StemConvTrainFn(Function):
         dev = x.device
         dy = dy.contiguous()
         Ho, Wo = H // 2, W // 2
+        if WGRAD == "conv" and TRAIN_CONV == "f16x3" and K % 32 == 0:
+            # as ONE 2-D convolution (see wgrad_as_conv): the five temporal taps are five shifted copies of the clip playing the
+            # "images", the filter is the output gradient (44 x 44 taps, dilation 2): reads 0.6 GB where the reduction-major GEMM
+            # operands are 2.2 GB written and read back
+            N = B * T
+            N32 = (N + 31) // 32 * 32
+            scale2 = pow2_lift(dy)
+            xT = torch.empty((5, H, W, N32), device=dev, dtype=torch.float32)
+            check(lib().dlip_stem_wgrad_chwn_f32(ptr(x), ptr(xT), B, T, H, W, N32, stream_handle()), "dlip_stem_wgrad_chwn_f32")
+            gT = torch.empty((K, Ho, Wo, N32), device=dev, dtype=torch.float32)
+            check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), stream_handle()), "dlip_wgrad_chwn_f32")
+            inv = torch.empty((K,), device=dev, dtype=torch.float32)
+            check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+            out = ops.conv_nhwc(xT, gT, None, stride=(1, 1), pad=(3, 3), dil=(2, 2), w_scale=const_vec(K, 1.0, dev), x_split=True,
+                                post_scale=inv, post_shift=const_vec(K, 0.0, dev))              # [5, 8, 8, K] (even H: one spare row / column)
+            out = out[:, :7, :7].contiguous()
+            return None, _permute3(out.view(1, 245, K), (0, 2, 1)).view(K, 1, 5, 7, 7)
         J = B * T * Ho * Wo
         J32 = (J + 31) // 32 * 32
         if WGRAD_ODD_PITCH and (J32 // 32) % 2 == 0:

@@ -106,8 +106,12 @@ __global__ __launch_bounds__(256) void wgrad_operand_kernel(const float* __restr
 // One workgroup = 32 images x 32 channels of one pixel through a 32 x 33 LDS tile: 128-B reads along c, one 16-B store per thread
 // along n.  Unlike the reduction-major operand above this is ONE copy of the tensor, not R*S of them: the taps are the
 // convolution kernel's own address walk.
+// With group > 0 the images are frames of clips of `group` frames and image n reads frame n + shift of ITS clip (zeros when that
+// leaves the clip): the temporal taps of the stem's Conv3d as five shifted copies of the clip (dlip_wgrad_chwn_f32's callers pass
+// group = 0).
 __global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int ldx, int C,
-                                                         int N32, const float* __restrict__ scale, DlipRange status) {
+                                                         int N32, const float* __restrict__ scale, DlipRange status, int group = 0,
+                                                         int shift = 0) {
   __shared__ float tile[32][33];
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32, p = blockIdx.z;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict
   for (int q = 0; q < 4; ++q) {
     const int n = n0 + ty + 8 * q;
     float v = 0.f;
-    if (n < N && c0 + tx < C) v = x[((long long)n * HW + p) * ldx + c0 + tx] * sc;
+    const bool in_clip = group == 0 || (unsigned)(n % group + shift) < (unsigned)group;
+    if (n < N && c0 + tx < C && in_clip) v = x[((long long)(n + shift) * HW + p) * ldx + c0 + tx] * sc;
     tile[ty + 8 * q][tx] = v;
   }
   __syncthreads();
@@ -452,6 +457,17 @@ extern "C" int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_
   DLIP_CHECK_ARG((long long)H * W <= 65535 && (C + 31) / 32 <= 65535 && N < (1ll << 31));
   hipLaunchKernelGGL(wgrad_chwn_kernel, dim3((unsigned)(N32 / 32), (unsigned)((C + 31) / 32), (unsigned)(H * W)), dim3(256), 0, ST(stream), x,
                      out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK));
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_stem_wgrad_chwn_f32(const float* x, float* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t N32,
+                                        dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && out && B > 0 && T > 0 && H > 0 && W > 0 && N32 >= (long long)B * T && (N32 & 31) == 0 &&
+                 (reinterpret_cast<uintptr_t>(out) & 127) == 0 && (H * W + 31) / 32 <= 65535);
+  // the clip as [frames][1 pixel][H W "channels"]: out[dt][p][n] = x[n + dt - 2][p] inside the clip of frame n
+  for (int dt = 0; dt < 5; ++dt)
+    hipLaunchKernelGGL(wgrad_chwn_kernel, dim3((unsigned)(N32 / 32), (unsigned)((H * W + 31) / 32), 1u), dim3(256), 0, ST(stream), x,
+                       out + (long long)dt * H * W * N32, B * T, 1, H * W, H * W, N32, nullptr, dlip_range_for(DLIP_ST_PACK), T, dt - 2);
   return dlip_launch_status();
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 33
+#define DLIP_ABI_VERSION 34
 #define DLIP_LIFT_WORDS 4098   /* (2^e, 2^-e) + one word per workgroup of the pass that forms them */
 
 #define DLIP_OK 0
@@ -500,6 +500,11 @@ int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int64_t N
  * more than 32 taps for this (split input, fp32 output, no residual).  train_video.py:129-147 (loss.backward()). */
 int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t N32,
                         const float* scale, dlip_stream_t stream);
+/* The stem's input for its weight gradient run as a convolution: the clip x [B,T,H,W] -> out [5][H][W][N32] split format, n = b*T + t,
+ * out[dt][h][w][n] = x[b, t + dt - 2, h, w] (zero outside the clip; N32 >= B*T, a multiple of 32): the five temporal taps of
+ * Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) (model.py:82) as five "images" of ONE 2-D convolution whose filter is the output gradient
+ * (dlip_wgrad_chwn_f32 of dy: [64][H/2][W/2][N32]; stride 1, dilation 2, padding 3): dW[k, dt, r, s] = its output [dt, r, s, k]. */
+int dlip_stem_wgrad_chwn_f32(const float* x, float* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t N32, dlip_stream_t stream);
 /* out [N,Hu,Wu,C] = dz [N,Ho,Wo,C] with stride-1 zeros inserted (out[n, ho*s, wo*s] = dz[n, ho, wo]): the data
  * gradient of a strided convolution as a stride-1 convolution (resnet.py:9-16 with stride 2). */
 int dlip_upsample_zero_f32(const float* dz, float* out, int64_t N, int32_t Ho, int32_t Wo, int32_t Hu, int32_t Wu,
