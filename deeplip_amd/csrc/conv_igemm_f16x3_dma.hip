@@ -64,6 +64,7 @@ struct StreamK {
   int* counters;     // [tiles], zero between launches (the finisher resets its tile's word)
   int G;             // workgroups in the grid
   unsigned long long* span;   // NULL, or this launch's {first workgroup start, last workgroup end} in 100 MHz ticks (dlip_span_scope_*)
+  int il_tiles;      // > 0: G = il_tiles * parts and neighbours in work order take the SAME part of DIFFERENT tiles (launch_one)
 #ifdef DLIP_LAB
   unsigned long long* stamps;   // lab build only: [G][10] s_memtime values of each workgroup's first segment
 #endif
@@ -136,7 +137,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // neighbours in work order share an XCD (L2)
+  const int g_hw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // neighbours in work order share an XCD (L2)
+  // Few tiles with reductions of thousands of slices (weight gradients run as convolutions): workgroup (tile t, part p) is
+  // number t * parts + p of the split, but in WORK order the tiles of one part sit side by side -- they read the same slices of
+  // the streamed "filter" (the output-gradient map, cold in every slice) at the same time on the same XCD, once instead of
+  // once per tile.
+  const int g = sk.il_tiles > 0 ? (g_hw % sk.il_tiles) * (nwg / sk.il_tiles) + g_hw / sk.il_tiles : g_hw;
 
   const int tid = threadIdx.x;
   const int cq = tid & 7;
@@ -1056,6 +1062,11 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
       sk.slabs = w->slabs;
       sk.counters = w->counters;
     }
+  }
+  sk.il_tiles = 0;
+  if (G != tiles && a.nk >= 256 && tiles >= 2 && tiles <= 64 && G / tiles >= 2) {
+    G = G / tiles * tiles;          // whole parts: every workgroup stays inside one tile
+    sk.il_tiles = (int)tiles;
   }
   sk.G = (int)G;
   sk.span = dlip_span_next();
