@@ -13,8 +13,9 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 34
+ABI_VERSION = 35
 LIFT_WORDS = 4098
+LIFT_BCAST = 2048
 
 _lock = threading.Lock()
 _lib = None
@@ -58,6 +59,7 @@ SIGNATURES = {
     "dlip_colsum_rows_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_meanstd_pool_bwd_f32": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_permute3_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_pow2_lift_f32": [c_f, c_f, c_i64, C.c_float, c_stream],
     "dlip_pow2_scale_f32": [c_f, c_f, c_i64, C.c_float, c_stream],
     "dlip_split_pack_scaled_f32": [c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_split_weights_rows_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],

@@ -15,7 +15,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from ._lib import LIFT_WORDS, check, lib, ptr, stream_handle
+from ._lib import LIFT_BCAST, LIFT_WORDS, check, lib, ptr, stream_handle
 from .autograd import BNRowsActFn, _permute3, _ws
 
 
@@ -54,8 +54,7 @@ def wgrad_gemm(dz_rows, tap_rows, n_taps):
     check(lib().dlip_pow2_scale_f32(ptr(dzT), ptr(scale2), dzT.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
     dzT_s = torch.empty_like(dzT)
     check(lib().dlip_split_pack_scaled_f32(ptr(dzT), ptr(dzT_s), ptr(scale2), K, J32, stream_handle()), "dlip_split_pack_scaled_f32")
-    inv = torch.empty((K,), device=dev, dtype=torch.float32)
-    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    inv = lift_inv(scale2, K)
     ones = const_vec(K, 1.0, dev)
     zeros = const_vec(K, 0.0, dev)
     out = None
@@ -87,9 +86,19 @@ def pow2_lift(t):
     ready = getattr(t, "_dlip_lift", None)       # the producer of this gradient (a BatchNorm backward) formed it while writing t
     if ready is not None:
         return ready
-    scale2 = torch.empty((2,), device=t.device, dtype=torch.float32)
-    check(lib().dlip_pow2_scale_f32(ptr(t), ptr(scale2), t.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
+    scale2 = torch.empty((LIFT_WORDS,), device=t.device, dtype=torch.float32)
+    check(lib().dlip_pow2_lift_f32(ptr(t), ptr(scale2), t.numel(), 1024.0, stream_handle()), "dlip_pow2_lift_f32")
     return scale2
+
+
+def lift_inv(scale2, K):
+    """[K] copies of 2^-e: the post_scale vector of a convolution over a lifted gradient.  A DLIP_LIFT_WORDS buffer carries 2048
+    of them behind the pair (written by the kernel that finalised the lift); anything else gets a fill launch."""
+    if scale2.numel() >= 2 + K and K <= LIFT_BCAST:
+        return scale2[2:2 + K]
+    inv = torch.empty((K,), device=scale2.device, dtype=torch.float32)
+    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    return inv
 
 
 def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False, scale2=None, w_ref=None, transposed=False):
@@ -127,8 +136,7 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
         scale2 = pow2_lift(x)
     xs = torch.empty_like(x)
     check(lib().dlip_split_pack_scaled_f32(ptr(x), ptr(xs), ptr(scale2), x.numel() // Cx, Cx, stream_handle()), "dlip_split_pack_scaled_f32")
-    inv = torch.empty((K,), device=dev, dtype=torch.float32)
-    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    inv = lift_inv(scale2, K)
     zeros = const_vec(K, 0.0, dev)
     return ops.conv_nhwc(xs, ws, None, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True, post_scale=inv, post_shift=zeros)
 
@@ -154,8 +162,7 @@ def wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2=None):
     xT_s = torch.empty((taps * Cx, J32), device=dev, dtype=torch.float32)
     check(lib().dlip_wgrad_operand_f32(ptr(x), ptr(xT_s), J32, N, H, W, Cx, x.stride(2), Ho, Wo, stride[0], stride[1], R, S, dil[0], dil[1],
                                        pad[0], pad[1], None, stream_handle()), "dlip_wgrad_operand_f32")
-    inv = torch.empty((K,), device=dev, dtype=torch.float32)
-    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    inv = lift_inv(scale2, K)
     ones = const_vec(K, 1.0, dev)
     zeros = const_vec(K, 0.0, dev)
     out = torch.empty((taps * Cx, K), device=dev, dtype=torch.float32)
@@ -188,8 +195,7 @@ def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None):
     check(lib().dlip_wgrad_chwn_f32(ptr(x), ptr(xT), N, H, W, Cx, x.stride(2), N32, None, stream_handle()), "dlip_wgrad_chwn_f32")
     gT = torch.empty((K, Ho, Wo, N32), device=dev, dtype=torch.float32)
     check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), stream_handle()), "dlip_wgrad_chwn_f32")
-    inv = torch.empty((K,), device=dev, dtype=torch.float32)
-    check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+    inv = lift_inv(scale2, K)
     out = ops.conv_nhwc(xT, gT, None, stride=dil, pad=pad, dil=stride, w_scale=const_vec(K, 1.0, dev), x_split=True,
                         post_scale=inv, post_shift=const_vec(K, 0.0, dev))                 # [Cx, R', S', K]
     if out.shape[1] != R or out.shape[2] != S:
@@ -310,8 +316,7 @@ class StemConvTrainFn(Function):
             check(lib().dlip_stem_wgrad_chwn_f32(ptr(x), ptr(xT), B, T, H, W, N32, stream_handle()), "dlip_stem_wgrad_chwn_f32")
             gT = torch.empty((K, Ho, Wo, N32), device=dev, dtype=torch.float32)
             check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), stream_handle()), "dlip_wgrad_chwn_f32")
-            inv = torch.empty((K,), device=dev, dtype=torch.float32)
-            check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+            inv = lift_inv(scale2, K)
             out = ops.conv_nhwc(xT, gT, None, stride=(1, 1), pad=(3, 3), dil=(2, 2), w_scale=const_vec(K, 1.0, dev), x_split=True,
                                 post_scale=inv, post_shift=const_vec(K, 0.0, dev))              # [5, 8, 8, K] (even H: one spare row / column)
             out = out[:, :7, :7].contiguous()
@@ -326,8 +331,7 @@ class StemConvTrainFn(Function):
               "dlip_wgrad_operand_f32")
         xT_s = torch.empty((248, J32), device=dev, dtype=torch.float32)
         check(lib().dlip_stem_wgrad_operand_f32(ptr(x), ptr(xT_s), J32, B, T, H, W, stream_handle()), "dlip_stem_wgrad_operand_f32")
-        inv = torch.empty((K,), device=dev, dtype=torch.float32)
-        check(lib().dlip_fill_from_scalar_f32(scale2[1:].data_ptr(), ptr(inv), K, stream_handle()), "dlip_fill_from_scalar_f32")
+        inv = lift_inv(scale2, K)
         out = torch.empty((248, K), device=dev, dtype=torch.float32)
         ops.conv_nhwc(xT_s.view(1, 1, 248, J32), dzT_s.view(K, 1, 1, J32), None, w_scale=const_vec(K, 1.0, dev), x_split=True,
                       post_scale=inv, post_shift=const_vec(K, 0.0, dev), out=out.view(1, 1, 248, K))

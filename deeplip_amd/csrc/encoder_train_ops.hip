@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int CHUNK_ROWS = 512;
+constexpr int DLIP_LIFT_BCAST = 2048;   // include/deeplip_hip.h: DLIP_LIFT_WORDS = 2 + max(4096 workgroup maxima, this many copies of 2^-e)
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
 
@@ -177,6 +178,27 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const double* __restr
   if (out1) out1[c] = (float)q;
 }
 
+// The three column sums of the BatchNorm + PReLU backward (dbeta, dgamma from region A's pairs, dslope from region B's) in ONE launch.
+__global__ __launch_bounds__(256) void col_finalize3_kernel(const double* __restrict__ part_a, const double* __restrict__ part_b,
+                                                            float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2,
+                                                            int C, int chunks) {
+  __shared__ double red[16][16][3];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double a = 0.0, b = 0.0, d = 0.0;
+  if (c < C)
+    for (int i = g; i < chunks; i += 16) {
+      a += part_a[((long long)i * C + c) * 2]; b += part_a[((long long)i * C + c) * 2 + 1]; d += part_b[((long long)i * C + c) * 2];
+    }
+  red[g][cl][0] = a; red[g][cl][1] = b; red[g][cl][2] = d;
+  __syncthreads();
+  if (g != 0 || c >= C) return;
+  double s = 0.0, q = 0.0, r = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { s += red[i][cl][0]; q += red[i][cl][1]; r += red[i][cl][2]; }
+  out0[c] = (float)s; out1[c] = (float)q; out2[c] = (float)r;
+}
+
 // dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M), times lrelu'(x) when the activation came first
 template <bool FIXED>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
@@ -310,14 +332,14 @@ __global__ __launch_bounds__(256) void pow2_finalize_parts_kernel(const unsigned
   for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float mx = __uint_as_float(max(max(red[0], red[1]), max(red[2], red[3])));
-    float s = 1.f;
-    if (mx > 0.f && mx < 3.0e38f) s = exp2f(floorf(log2f(target / mx)));
-    if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
-    out[0] = s;
-    out[1] = 1.f / s;
-  }
+  const float mx = __uint_as_float(max(max(red[0], red[1]), max(red[2], red[3])));
+  float s = 1.f;
+  if (mx > 0.f && mx < 3.0e38f) s = exp2f(floorf(log2f(target / mx)));
+  if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
+  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; }
+  // words 2 .. 2 + DLIP_LIFT_BCAST: 1 / s repeated -- the per-output-channel post_scale vector of the convolution that consumes the
+  // lifted gradient (its epilogue takes a vector), without a fill launch per convolution.  (The maxima lived there: all read above.)
+  for (int i = threadIdx.x; i < DLIP_LIFT_BCAST; i += 256) out[2 + i] = 1.f / s;
 }
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -514,9 +536,8 @@ extern "C" int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x,
   const int chunks = dlip_bn_rows_chunks(M);
   hipLaunchKernelGGL(col_partial_kernel<3>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd,
                      gamma, beta, workspace, M, C, 1.f, 0, slope);
-  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
-  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace + (long long)chunks * C * 2, dslope,
-                     nullptr, C, chunks);
+  hipLaunchKernelGGL(col_finalize3_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, workspace + (long long)chunks * C * 2, dbeta,
+                     dgamma, dslope, C, chunks);
   const long long n4 = (long long)M * (C / 4);
   unsigned* acc = dx_lift2 ? reinterpret_cast<unsigned*>(dx_lift2) + 2 : nullptr;   // per-workgroup maxima behind the pair
   const unsigned gf = grid_fixed(n4, C / 4);
@@ -572,6 +593,17 @@ extern "C" int dlip_pow2_scale_f32(const float* x, float* scale2, int64_t n, flo
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, st, x,
                      reinterpret_cast<unsigned*>(scale2), (long long)n);
   hipLaunchKernelGGL(pow2_finalize_kernel, dim3(1), dim3(1), 0, st, scale2, target);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_pow2_lift_f32(const float* x, float* lift, int64_t n, float target, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && lift && n > 0 && target > 0.f && (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  long long blocks = (n / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  if (hipMemsetAsync(lift + 2, 0, sizeof(float), st) != hipSuccess) return DLIP_EINVAL;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, reinterpret_cast<unsigned*>(lift) + 2, (long long)n);
+  hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const unsigned*>(lift) + 2, 1, lift, target);
   return dlip_launch_status();
 }
 

@@ -28,8 +28,10 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 34
-#define DLIP_LIFT_WORDS 4098   /* (2^e, 2^-e) + one word per workgroup of the pass that forms them */
+#define DLIP_ABI_VERSION 35
+#define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
+                                  the convolution that consumes the lifted gradient); while it is formed the words behind the pair
+                                  hold one maximum per workgroup of the producing pass */
 
 #define DLIP_OK 0
 #define DLIP_EINVAL (-1)  /* inconsistent shapes / null pointers / unsupported alignment */
@@ -441,6 +443,8 @@ int dlip_permute3_f32(const float* x, float* y, int32_t d0, int32_t d1, int32_t 
 /* scale2[0] = 2^floor(log2(target / max|x|)), scale2[1] = 1 / scale2[0] (device scalars; 1 if x == 0):
  * the power-of-two that lifts a gradient tensor into fp16's normal range before it is split. */
 int dlip_pow2_scale_f32(const float* x, float* scale2, int64_t n, float target, dlip_stream_t stream);
+/* The same into a DLIP_LIFT_WORDS buffer (layout above): lift[0] = 2^e, lift[1] = 2^-e, lift[2 .. 2049] = 2^-e. */
+int dlip_pow2_lift_f32(const float* x, float* lift, int64_t n, float target, dlip_stream_t stream);
 /* dlip_split_pack_f32 of x * scale[0] (device scalar). */
 int dlip_split_pack_scaled_f32(const float* x, float* y, const float* scale, int64_t rows, int32_t C,
                                dlip_stream_t stream);
