@@ -850,3 +850,124 @@ def test_conv_window_kernel(ops, case):
     ref = ref.permute(0, 2, 3, 1)
     assert rel_err(y.cpu().numpy(), ref.numpy()) < TOL
     assert rel_err(y.cpu().numpy(), y_ring.cpu().numpy()) < 2e-6
+
+
+# ---- round 3: the weight gradient run as a convolution (filters of more than 32 taps; one-copy operands) ----
+BIG_TAP_CASES = [
+    # N, H, W, C, K, R, S, stride, pad, dil, tile (-1 = built-in choice)
+    (3, 11, 11, 64, 64, 11, 11, 1, 1, 1, -1),     # layer-2-like: the 11x11 "filter" is an output-gradient map, output 3x3
+    (2, 22, 22, 32, 64, 22, 22, 1, 1, 1, -1),     # 484 taps (layer 1)
+    (4, 22, 22, 64, 128, 11, 11, 1, 1, 2, -1),    # a strided layer's weight gradient: dilation 2, output 4x4 (one spare row / column)
+    (5, 6, 6, 96, 128, 6, 6, 1, 1, 1, 5),         # even filter size, 256x128 tile forced
+    (5, 6, 6, 96, 128, 6, 6, 1, 1, 1, 0),         # 128x128 tile forced
+    (2, 1, 40, 64, 64, 1, 36, 2, 0, 1, -1),       # 1-D: a dilated TDNN layer's weight gradient (conv stride = the layer's dilation)
+]
+
+
+@pytest.mark.parametrize("case", BIG_TAP_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_more_than_32_taps(ops, case, force_dma_tile):
+    """dlip_conv_nhwc_f16x3 with R*S > 32 (split input, fp32 output): the ring kernel's variant that tests a tap against the image
+    when the piece is issued instead of reading the 32-bit tap mask -- against F.conv2d in fp64."""
+    from deeplip_amd import packing
+    N, H, W, C, K, R, S, stride, pad, dil, tile = case
+    x = _split_ref_value(rnd(N, H, W, C, seed=31))
+    w = rnd(K, R, S, C, seed=32, scale=1.0 / np.sqrt(C * R * S))
+    sh, sw = (1, stride) if H == 1 else (stride, stride)
+    ph, pw = (0, pad) if H == 1 else (pad, pad)
+    dh, dw = (1, dil) if H == 1 else (dil, dil)
+    ws, sc = packing.split_weights(w.double())
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, (sh, sw), (ph, pw), (dh, dw))
+    force_dma_tile(tile)
+    y = ops.conv_nhwc(ops.split_pack(x.cuda()), ws.cuda(), None, stride=(sh, sw), pad=(ph, pw), dil=(dh, dw), w_scale=sc.cuda(), x_split=True)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (N, ref.shape[2], ref.shape[3], K)
+    assert rel_err(y.cpu().numpy(), ref.permute(0, 2, 3, 1).numpy()) < 2e-5
+    with pytest.raises(Exception):          # more than 32 taps exist for split input / fp32 output only
+        ops.conv_nhwc(x.cuda(), ws.cuda(), None, stride=(sh, sw), pad=(ph, pw), dil=(dh, dw), w_scale=sc.cuda())
+
+
+@pytest.mark.parametrize("N,H,W,C", [(5, 3, 4, 64), (33, 2, 2, 40), (64, 1, 7, 32)])
+def test_wgrad_chwn_operand(ops, N, H, W, C):
+    """dlip_wgrad_chwn_f32: [N,H,W,C] -> [C,H,W,N32] split blocks (32 hi halves | 32 lo halves per 32 images), zero beyond N,
+    optional scale -- bit for bit."""
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    x = rnd(N, H, W, C, seed=41) * 3.0
+    N32 = (N + 31) // 32 * 32
+    xd, scale = x.cuda(), torch.tensor([4.0, 0.25]).cuda()        # (held in variables: ptr() of a temporary would dangle)
+    for sc in (None, scale):
+        out = torch.full((C, H, W, N32), 9.0, device="cuda")
+        check(lib().dlip_wgrad_chwn_f32(ptr(xd), ptr(out), N, H, W, C, C, N32, ptr(sc) if sc is not None else None, stream_handle()),
+              "dlip_wgrad_chwn_f32")
+        torch.cuda.synchronize()
+        ref = torch.zeros(C, H, W, N32)
+        ref[..., :N] = (x * (4.0 if sc is not None else 1.0)).permute(3, 1, 2, 0)
+        assert torch.equal(out.cpu().view(torch.int32), _split_ref(ref).view(torch.int32))
+
+
+def test_stem_wgrad_chwn_operand(ops):
+    """dlip_stem_wgrad_chwn_f32: out[dt][h][w][n = b T + t] = x[b, t + dt - 2, h, w] inside the clip, zero outside."""
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    B, T, H, W = 3, 7, 6, 10
+    x = rnd(B, T, H, W, seed=43)
+    N32 = 32
+    out = torch.full((5, H, W, N32), 9.0, device="cuda")
+    xd = x.cuda()
+    check(lib().dlip_stem_wgrad_chwn_f32(ptr(xd), ptr(out), B, T, H, W, N32, stream_handle()), "dlip_stem_wgrad_chwn_f32")
+    torch.cuda.synchronize()
+    ref = torch.zeros(5, H, W, N32)
+    for dt in range(5):
+        for b in range(B):
+            for t in range(T):
+                if 0 <= t + dt - 2 < T:
+                    ref[dt, :, :, b * T + t] = x[b, t + dt - 2]
+    assert torch.equal(out.cpu().view(torch.int32), _split_ref(ref).view(torch.int32))
+
+
+@pytest.mark.parametrize("K,C,T", [(64, 64, 9), (128, 32, 3), (96, 64, 1), (32, 128, 5)])
+def test_split_weights_perm_equals_permute_then_split(ops, K, C, T):
+    """dlip_split_weights_perm_f32 (reference [K,C,T] in, split image out) == permute + dlip_split_weights_rows_f32, both modes."""
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    w = (rnd(K, C, T, seed=45) * 0.07).cuda()
+    for mode in (0, 1):
+        rows, inner = (K, C) if mode == 0 else (C, K)
+        perm = w.permute(0, 2, 1).contiguous() if mode == 0 else w.flip(2).permute(1, 2, 0).contiguous()      # [rows, T, inner]
+        a, sa = torch.empty((rows, T * inner), device="cuda"), torch.empty((rows,), device="cuda")
+        b, sb = torch.empty_like(a), torch.empty_like(sa)
+        check(lib().dlip_split_weights_rows_f32(ptr(perm), ptr(a), ptr(sa), rows, T * inner, stream_handle()), "dlip_split_weights_rows_f32")
+        check(lib().dlip_split_weights_perm_f32(ptr(w), ptr(b), ptr(sb), K, C, T, mode, stream_handle()), "dlip_split_weights_perm_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(sa, sb) and torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.parametrize("N,H,W,C", [(5, 44, 44, 64), (3, 9, 7, 8), (2, 1, 5, 4)])
+def test_maxpool_with_recorded_taps(ops, N, H, W, C):
+    """dlip_maxpool3x3s2_idx_f32 / _bwd_idx_f32 == the pooling kernel and the window-scanning backward, bit for bit (ties included)."""
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    x = torch.round(rnd(N, H, W, C, seed=47) * 2.0).cuda()            # rounded: plenty of ties inside a window
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = rnd(N, Ho, Wo, C, seed=48).cuda()
+    y = torch.empty((N, Ho, Wo, C), device="cuda")
+    idx = torch.empty((N, Ho, Wo, C // 4), device="cuda", dtype=torch.int32)
+    check(lib().dlip_maxpool3x3s2_idx_f32(ptr(x), ptr(y), idx.data_ptr(), N, H, W, C, stream_handle()), "dlip_maxpool3x3s2_idx_f32")
+    dx = torch.empty_like(x)
+    check(lib().dlip_maxpool3x3s2_bwd_idx_f32(idx.data_ptr(), ptr(dy), ptr(dx), N, H, W, C, stream_handle()), "dlip_maxpool3x3s2_bwd_idx_f32")
+    dx_ref = torch.empty_like(x)
+    check(lib().dlip_maxpool3x3s2_bwd_f32(ptr(x), ptr(dy), ptr(dx_ref), N, H, W, C, stream_handle()), "dlip_maxpool3x3s2_bwd_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(y, ops.maxpool3x3s2(x)) and torch.equal(dx, dx_ref)
+
+
+def test_pow2_lift_buffer(ops):
+    """dlip_pow2_lift_f32: (2^e, 2^-e) as dlip_pow2_scale_f32 forms them, then 2^-e repeated 2048 times."""
+    from deeplip_amd import _lib
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    for scale in (3e-7, 1.0, 5e4):
+        x = (rnd(1000, 37, seed=49) * scale).cuda()
+        lift = torch.empty((_lib.LIFT_WORDS,), device="cuda")
+        pair = torch.empty((2,), device="cuda")
+        check(lib().dlip_pow2_lift_f32(ptr(x), ptr(lift), x.numel(), 1024.0, stream_handle()), "dlip_pow2_lift_f32")
+        check(lib().dlip_pow2_scale_f32(ptr(x), ptr(pair), x.numel(), 1024.0, stream_handle()), "dlip_pow2_scale_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(lift[:2], pair) and bool((lift[2:2 + _lib.LIFT_BCAST] == pair[1]).all())
+        m = float(x.abs().max()) * float(pair[0])
+        assert 512.0 <= m <= 1024.0

@@ -108,7 +108,8 @@ def test_split_stem_weights_on_device_equals_host_packing():
     img_h, sc_h = packing.split_stem_weights(w.double())
     img = torch.empty((64 * 296,), device=DEV)
     sc = torch.empty((64,), device=DEV)
-    check(lib().dlip_split_stem_weights_f32(ptr(w.to(DEV)), ptr(img), ptr(sc), 64, stream_handle()), "dlip_split_stem_weights_f32")
+    wd = w.to(DEV)
+    check(lib().dlip_split_stem_weights_f32(ptr(wd), ptr(img), ptr(sc), 64, stream_handle()), "dlip_split_stem_weights_f32")
     torch.cuda.synchronize()
     assert np.array_equal(sc.cpu().numpy()[:5], sc_h.numpy()[:5]) and np.array_equal(sc.cpu().numpy()[6:], sc_h.numpy()[6:])
     keep = np.ones(64, bool); keep[5] = False                 # an all-zero channel: any scale, zero image
