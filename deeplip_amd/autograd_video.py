@@ -176,6 +176,22 @@ def wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2=None):
 WGRAD = "conv"
 
 
+# Operand images of the weight gradient run as a convolution: slice-major ([image][32-image slice][H][W][32]: the taps a workgroup
+# walks are adjacent 128-byte lines, dlip_wgrad_conv_f16x3) or pixel-major ([image][H][W][N32] through dlip_conv_nhwc_f16x3: every
+# piece a DRAM page of its own -- kept for A/B runs and as the second implementation the tests compare).
+WGRAD_SLICE_MAJOR = True
+
+
+def _wgrad_conv_launch(xT, gT, inv, C_, H, W, K, Ho, Wo, N32, stride, pad, dil):
+    dev = xT.device
+    Ro = (H + 2 * pad[0] - stride[0] * (Ho - 1) - 1) // dil[0] + 1
+    So = (W + 2 * pad[1] - stride[1] * (Wo - 1) - 1) // dil[1] + 1
+    out = torch.empty((C_, Ro, So, K), device=dev, dtype=torch.float32)
+    check(lib().dlip_wgrad_conv_f16x3(ptr(xT), ptr(gT), ptr(inv), ptr(const_vec(K, 0.0, dev)), ptr(const_vec(K, 1.0, dev)), ptr(out), C_, H, W, K,
+                                      Ho, Wo, N32, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], stream_handle()), "dlip_wgrad_conv_f16x3")
+    return out
+
+
 def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None):
     """dW[c, r, s, k] = sum_{n,h,w} x[n, h*sh + r*dh - ph, w*sw + s*dw - pw, c] * dy[n, h, w, k] run as a CONVOLUTION on the
     engine's own conv kernel: input x' = x as [C][H][W][N] (the C channels play the batch, the N images the channels), filter
@@ -191,13 +207,17 @@ def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None):
     N32 = (N + 31) // 32 * 32
     if scale2 is None:
         scale2 = pow2_lift(dy)
-    xT = torch.empty((Cx, H, W, N32), device=dev, dtype=torch.float32)
-    check(lib().dlip_wgrad_chwn_f32(ptr(x), ptr(xT), N, H, W, Cx, x.stride(2), N32, None, stream_handle()), "dlip_wgrad_chwn_f32")
+    sm = 1 if WGRAD_SLICE_MAJOR else 0
+    xT = torch.empty((Cx, H, W, N32), device=dev, dtype=torch.float32)          # slice-major: [Cx][N32/32][H][W][32]
+    check(lib().dlip_wgrad_chwn_f32(ptr(x), ptr(xT), N, H, W, Cx, x.stride(2), N32, None, sm, stream_handle()), "dlip_wgrad_chwn_f32")
     gT = torch.empty((K, Ho, Wo, N32), device=dev, dtype=torch.float32)
-    check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), stream_handle()), "dlip_wgrad_chwn_f32")
+    check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), sm, stream_handle()), "dlip_wgrad_chwn_f32")
     inv = lift_inv(scale2, K)
-    out = ops.conv_nhwc(xT, gT, None, stride=dil, pad=pad, dil=stride, w_scale=const_vec(K, 1.0, dev), x_split=True,
-                        post_scale=inv, post_shift=const_vec(K, 0.0, dev))                 # [Cx, R', S', K]
+    if sm:
+        out = _wgrad_conv_launch(xT, gT, inv, Cx, H, W, K, Ho, Wo, N32, stride, pad, dil)   # [Cx, R', S', K]
+    else:
+        out = ops.conv_nhwc(xT, gT, None, stride=dil, pad=pad, dil=stride, w_scale=const_vec(K, 1.0, dev), x_split=True,
+                            post_scale=inv, post_shift=const_vec(K, 0.0, dev))
     if out.shape[1] != R or out.shape[2] != S:
         out = out[:, :R, :S].contiguous()
     return _permute3(out.view(Cx, R * S, K), (2, 0, 1)).view(K, Cx, R, S)                   # the reference layout [K, C, R, S]
@@ -312,13 +332,17 @@ class StemConvTrainFn(Function):
             N = B * T
             N32 = (N + 31) // 32 * 32
             scale2 = pow2_lift(dy)
+            sm = 1 if WGRAD_SLICE_MAJOR else 0
             xT = torch.empty((5, H, W, N32), device=dev, dtype=torch.float32)
-            check(lib().dlip_stem_wgrad_chwn_f32(ptr(x), ptr(xT), B, T, H, W, N32, stream_handle()), "dlip_stem_wgrad_chwn_f32")
+            check(lib().dlip_stem_wgrad_chwn_f32(ptr(x), ptr(xT), B, T, H, W, N32, sm, stream_handle()), "dlip_stem_wgrad_chwn_f32")
             gT = torch.empty((K, Ho, Wo, N32), device=dev, dtype=torch.float32)
-            check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), stream_handle()), "dlip_wgrad_chwn_f32")
+            check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), sm, stream_handle()), "dlip_wgrad_chwn_f32")
             inv = lift_inv(scale2, K)
-            out = ops.conv_nhwc(xT, gT, None, stride=(1, 1), pad=(3, 3), dil=(2, 2), w_scale=const_vec(K, 1.0, dev), x_split=True,
-                                post_scale=inv, post_shift=const_vec(K, 0.0, dev))              # [5, 8, 8, K] (even H: one spare row / column)
+            if sm:
+                out = _wgrad_conv_launch(xT, gT, inv, 5, H, W, K, Ho, Wo, N32, (2, 2), (3, 3), (1, 1))   # [5, 8, 8, K] (even H: a spare row / column)
+            else:
+                out = ops.conv_nhwc(xT, gT, None, stride=(1, 1), pad=(3, 3), dil=(2, 2), w_scale=const_vec(K, 1.0, dev), x_split=True,
+                                    post_scale=inv, post_shift=const_vec(K, 0.0, dev))
             out = out[:, :7, :7].contiguous()
             return None, _permute3(out.view(1, 245, K), (0, 2, 1)).view(K, 1, 5, 7, 7)
         J = B * T * Ho * Wo

@@ -60,6 +60,12 @@ struct ConvArgs {
   DlipRange status;     // range reporting of a split-format output (dlip_common.h)
   FastDiv div_howo, div_wo;
   int n_inner;          // LDS-DMA kernel: tile order with the output-channel block inner
+  // ---- the LDS-DMA kernel's many-tap instances only (a weight gradient run as a convolution, dlip_wgrad_conv_f16x3): where a
+  // 32-channel slice and a filter tap sit.  Pixel-major operands (the default): slice c of a pixel / tap is 128 c bytes further,
+  // tap t of a filter row Cw * 4 t; SLICE-major operands ([image][slice][H][W][32]): a slice is a whole image plane further and
+  // consecutive taps are adjacent 128-byte lines.
+  int Hs;               // rows between two images of x (H, or slices * H)
+  int cs_x, wt, cs_w;   // bytes: slice stride of x, tap stride and slice stride of the filter rows
 };
 
 
@@ -112,6 +118,7 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
   a.div_howo = dlip_fastdiv((uint32_t)a.HoWo);
   a.div_wo = dlip_fastdiv((uint32_t)a.Wo);
   a.n_inner = 0;
+  a.Hs = d->H; a.cs_x = 128; a.wt = Cw * 4; a.cs_w = 128;
   return DLIP_OK;
 }
 

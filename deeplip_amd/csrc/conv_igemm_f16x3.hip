@@ -390,6 +390,36 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   }
 }
 
+// A convolution's weight gradient run as a convolution over SLICE-major operand images (include/deeplip_hip.h).
+extern "C" int dlip_wgrad_conv_f16x3(const float* x_img, const float* g_img, const float* post_scale, const float* post_shift,
+                                     const float* unit_scale, float* dw, int32_t C, int32_t H, int32_t W, int32_t K, int32_t Ho,
+                                     int32_t Wo, int32_t N32, int32_t stride_h, int32_t stride_w, int32_t pad_h, int32_t pad_w,
+                                     int32_t dil_h, int32_t dil_w, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x_img && g_img && dw && unit_scale && C > 0 && H > 0 && W > 0 && K > 0 && Ho > 0 && Wo > 0 && N32 > 0 && (N32 & 31) == 0);
+  DLIP_CHECK_ARG((K & 3) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 && dlip_conv_dma_enabled());
+  // the LAYER computes y[n, ho, wo] from x[n, ho * stride + r * dil - pad, ...]; its weight gradient is the convolution of x' with the
+  // filter g' whose taps are the (ho, wo): convolution stride = the layer's dilation, convolution dilation = the layer's stride
+  dlip_conv_desc d;
+  d.N = C; d.H = H; d.W = W; d.C = N32; d.K = K; d.R = Ho; d.S = Wo;
+  d.stride_h = dil_h; d.stride_w = dil_w; d.pad_h = pad_h; d.pad_w = pad_w; d.dil_h = stride_h; d.dil_w = stride_w;
+  d.Ho = (H + 2 * pad_h - stride_h * (Ho - 1) - 1) / dil_h + 1;
+  d.Wo = (W + 2 * pad_w - stride_w * (Wo - 1) - 1) / dil_w + 1;
+  d.ldx = N32; d.ldy = K; d.ldr = 0;
+  DLIP_CHECK_ARG(d.Ho > 0 && d.Wo > 0 && (long long)Ho * Wo <= 65536);
+  ConvArgs a;
+  const int rc = fill_f16x3(&d, x_img, g_img, unit_scale, nullptr, nullptr, nullptr, post_scale, post_shift, dw, 1, &a, 65536);
+  if (rc != DLIP_OK) return rc;
+  // slice-major images: [image][N32 / 32][H][W][32] -- a pixel is 128 B, a slice a whole image plane, a tap the next 128-byte line
+  const int NS = N32 / 32;
+  a.ldx = 32;
+  a.Hs = NS * H;
+  a.cs_x = H * W * 128;
+  a.wt = 128;
+  a.cs_w = Ho * Wo * 128;
+  DLIP_CHECK_ARG((long long)C * NS * H * W * 128 < (1ll << 31) && (long long)NS * Ho * Wo * 128 < (1ll << 31));
+  return dlip_conv_f16x3_dma_launch(&a, stream, 0);
+}
+
 // conv + 1x1 strided shortcut convolution in ONE reduction (include/deeplip_hip.h).
 extern "C" int dlip_conv2_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const float* x2, int32_t H2, int32_t W2,
                                      int32_t C2, int32_t ldx2, int32_t stride2_h, int32_t stride2_w, const void* w_split,

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         const int wo = rem - ho * a.Wo;
         hi0[j] = ho * a.sh - a.ph;
         wi0[j] = wo * a.sw - a.pw;
-        a_off[j] = (((n * a.H + hi0[j]) * a.W + wi0[j]) * a.ldx + csrc) * 4;
+        a_off[j] = (((n * (BIGTAPS ? a.Hs : a.H) + hi0[j]) * a.W + wi0[j]) * a.ldx + csrc) * 4;
         if constexpr (DUAL) a2_off[j] = m < a.M ? (((n * a.H2 + ho * a.s2h) * a.W2 + wo * a.s2w) * a.ldx2 + csrc) * 4 : -1;
         colbits[j] = 0u;
         a_mask[j] = 0u;
@@ -271,6 +271,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     int s_pos = tap % a.S, x_row = (tap / a.S) * x_dr;
     int tap_dh = (tap / a.S) * a.dh, tap_dw = s_pos * a.dw;   // (BIGTAPS) the tap's row / column offset in pixels
     int x_tap = x_row + s_pos * x_ds + c0 * 4, w_tap = (tap * a.Cw + c0) * 4;
+    if constexpr (BIGTAPS) { x_tap = x_row + s_pos * x_ds + (c0 / BK) * a.cs_x; w_tap = tap * a.wt + (c0 / BK) * a.cs_w; }
     if constexpr (DUAL) {
       if (c0 >= a.Cw) { x_tap = (c0 - a.Cw) * 4; w_tap = (ntaps * a.Cw + c0 - a.Cw) * 4; }
     }
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       }
       x_tap = x_row + s_pos * x_ds + c0 * 4;
       w_tap = (tap * a.Cw + c0) * 4;
+      if constexpr (BIGTAPS) { x_tap = x_row + s_pos * x_ds + (c0 / BK) * a.cs_x; w_tap = tap * a.wt + (c0 / BK) * a.cs_w; }
       if (DUAL && c0 >= a.Cw) { x_tap = (c0 - a.Cw) * 4; w_tap = (ntaps * a.Cw + c0 - a.Cw) * 4; }
     };
     auto tap_ok = [&](int j) -> bool {

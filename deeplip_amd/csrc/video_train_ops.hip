@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void wgrad_operand_kernel(const float* __restr
 // group = 0).
 __global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int ldx, int C,
                                                          int N32, const float* __restrict__ scale, DlipRange status, int group = 0,
-                                                         int shift = 0) {
+                                                         int shift = 0, int layout = 0) {
   __shared__ float tile[32][33];
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32, p = blockIdx.z;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -137,8 +137,13 @@ __global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict
     o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
     amax = fmaxf(amax, fabsf(v));
   }
-  if (c0 + cr < C)
-    *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + ((long long)(c0 + cr) * HW + p) * N32 + n0) + (pq < 4 ? 0 : 32) + jb) = o;
+  // layout 0: [c][pixel][N32] (pixel-major: a pixel's 32-image slices side by side); 1: [c][slice][pixel][32] (SLICE-major: one
+  // slice of all pixels of an image is one contiguous plane -- what dlip_wgrad_conv_f16x3 reads: consecutive filter taps are
+  // adjacent 128-byte lines); 2: the stem's clip copies, where the "channels" ARE the pixels: [slice][pixel c][32]
+  const long long blk = layout == 0 ? ((long long)(c0 + cr) * HW + p) * N32 + n0
+                      : layout == 1 ? (((long long)(c0 + cr) * (N32 / 32) + blockIdx.x) * HW + p) * 32
+                                    : ((long long)blockIdx.x * C + (c0 + cr)) * 32;
+  if (c0 + cr < C) *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + blk) + (pq < 4 ? 0 : 32) + jb) = o;
   dlip_report_range(amax, status);
 }
 
@@ -451,23 +456,24 @@ extern "C" int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out
 }
 
 extern "C" int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t N32,
-                                   const float* scale, dlip_stream_t stream) {
+                                   const float* scale, int32_t slice_major, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && out && N > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && N32 >= N && (N32 & 31) == 0 &&
                  (reinterpret_cast<uintptr_t>(out) & 127) == 0);
   DLIP_CHECK_ARG((long long)H * W <= 65535 && (C + 31) / 32 <= 65535 && N < (1ll << 31));
   hipLaunchKernelGGL(wgrad_chwn_kernel, dim3((unsigned)(N32 / 32), (unsigned)((C + 31) / 32), (unsigned)(H * W)), dim3(256), 0, ST(stream), x,
-                     out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK));
+                     out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK), 0, 0, slice_major ? 1 : 0);
   return dlip_launch_status();
 }
 
 extern "C" int dlip_stem_wgrad_chwn_f32(const float* x, float* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t N32,
-                                        dlip_stream_t stream) {
+                                        int32_t slice_major, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && out && B > 0 && T > 0 && H > 0 && W > 0 && N32 >= (long long)B * T && (N32 & 31) == 0 &&
                  (reinterpret_cast<uintptr_t>(out) & 127) == 0 && (H * W + 31) / 32 <= 65535);
   // the clip as [frames][1 pixel][H W "channels"]: out[dt][p][n] = x[n + dt - 2][p] inside the clip of frame n
   for (int dt = 0; dt < 5; ++dt)
     hipLaunchKernelGGL(wgrad_chwn_kernel, dim3((unsigned)(N32 / 32), (unsigned)((H * W + 31) / 32), 1u), dim3(256), 0, ST(stream), x,
-                       out + (long long)dt * H * W * N32, B * T, 1, H * W, H * W, N32, nullptr, dlip_range_for(DLIP_ST_PACK), T, dt - 2);
+                       out + (long long)dt * H * W * N32, B * T, 1, H * W, H * W, N32, nullptr, dlip_range_for(DLIP_ST_PACK), T, dt - 2,
+                       slice_major ? 2 : 0);
   return dlip_launch_status();
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 35
+#define DLIP_ABI_VERSION 36
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -503,12 +503,24 @@ int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int64_t N
  * -- ONE copy of each tensor instead of the R*S shifted copies of dlip_wgrad_operand_f32; dlip_conv_nhwc_f16x3 accepts filters of
  * more than 32 taps for this (split input, fp32 output, no residual).  train_video.py:129-147 (loss.backward()). */
 int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t N32,
-                        const float* scale, dlip_stream_t stream);
+                        const float* scale, int32_t slice_major, dlip_stream_t stream);
+/* slice_major != 0: the image as [C][N32/32][H][W][32] instead -- one 32-image slice of all pixels of a channel is ONE contiguous
+ * plane, so that the filter taps a convolution walks one after the other are adjacent 128-byte lines (pixel-major they are
+ * N32 * 4 bytes apart: every piece a DRAM page of its own).  That is the layout dlip_wgrad_conv_f16x3 reads:
+ *   dw [C, R', S', K] fp32 = sum over images and output positions, x_img = the layer input's image, g_img = the output gradient's
+ *   (lifted), R' = (H + 2 pad - stride (Ho - 1) - 1) / dil + 1 >= R (dW sits in [:, :R, :S, :]); post_scale / post_shift [K]: the
+ *   epilogue's affine (2^-e of the lift, 0); unit_scale [K]: ones (the "filter" carries no per-channel scale).
+ * stride / pad / dil are the LAYER's. */
+int dlip_wgrad_conv_f16x3(const float* x_img, const float* g_img, const float* post_scale, const float* post_shift,
+                          const float* unit_scale, float* dw, int32_t C, int32_t H, int32_t W, int32_t K, int32_t Ho, int32_t Wo,
+                          int32_t N32, int32_t stride_h, int32_t stride_w, int32_t pad_h, int32_t pad_w, int32_t dil_h, int32_t dil_w,
+                          dlip_stream_t stream);
 /* The stem's input for its weight gradient run as a convolution: the clip x [B,T,H,W] -> out [5][H][W][N32] split format, n = b*T + t,
  * out[dt][h][w][n] = x[b, t + dt - 2, h, w] (zero outside the clip; N32 >= B*T, a multiple of 32): the five temporal taps of
  * Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) (model.py:82) as five "images" of ONE 2-D convolution whose filter is the output gradient
  * (dlip_wgrad_chwn_f32 of dy: [64][H/2][W/2][N32]; stride 1, dilation 2, padding 3): dW[k, dt, r, s] = its output [dt, r, s, k]. */
-int dlip_stem_wgrad_chwn_f32(const float* x, float* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t N32, dlip_stream_t stream);
+int dlip_stem_wgrad_chwn_f32(const float* x, float* out, int32_t B, int32_t T, int32_t H, int32_t W, int32_t N32, int32_t slice_major,
+                             dlip_stream_t stream);
 /* out [N,Hu,Wu,C] = dz [N,Ho,Wo,C] with stride-1 zeros inserted (out[n, ho*s, wo*s] = dz[n, ho, wo]): the data
  * gradient of a strided convolution as a stride-1 convolution (resnet.py:9-16 with stride 2). */
 int dlip_upsample_zero_f32(const float* dz, float* out, int64_t N, int32_t Ho, int32_t Wo, int32_t Hu, int32_t Wu,

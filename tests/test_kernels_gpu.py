@@ -896,12 +896,18 @@ def test_wgrad_chwn_operand(ops, N, H, W, C):
     xd, scale = x.cuda(), torch.tensor([4.0, 0.25]).cuda()        # (held in variables: ptr() of a temporary would dangle)
     for sc in (None, scale):
         out = torch.full((C, H, W, N32), 9.0, device="cuda")
-        check(lib().dlip_wgrad_chwn_f32(ptr(xd), ptr(out), N, H, W, C, C, N32, ptr(sc) if sc is not None else None, stream_handle()),
+        check(lib().dlip_wgrad_chwn_f32(ptr(xd), ptr(out), N, H, W, C, C, N32, ptr(sc) if sc is not None else None, 0, stream_handle()),
+              "dlip_wgrad_chwn_f32")
+        out_sm = torch.full((C, N32 // 32, H, W, 32), 9.0, device="cuda")
+        check(lib().dlip_wgrad_chwn_f32(ptr(xd), ptr(out_sm), N, H, W, C, C, N32, ptr(sc) if sc is not None else None, 1, stream_handle()),
               "dlip_wgrad_chwn_f32")
         torch.cuda.synchronize()
         ref = torch.zeros(C, H, W, N32)
         ref[..., :N] = (x * (4.0 if sc is not None else 1.0)).permute(3, 1, 2, 0)
-        assert torch.equal(out.cpu().view(torch.int32), _split_ref(ref).view(torch.int32))
+        want = _split_ref(ref).view(torch.int32)
+        assert torch.equal(out.cpu().view(torch.int32), want)
+        # slice-major: the same 128-byte blocks, ordered [c][slice][h][w]
+        assert torch.equal(out_sm.cpu().view(torch.int32), want.view(C, H, W, N32 // 32, 32).permute(0, 3, 1, 2, 4).contiguous())
 
 
 def test_stem_wgrad_chwn_operand(ops):
@@ -912,7 +918,9 @@ def test_stem_wgrad_chwn_operand(ops):
     N32 = 32
     out = torch.full((5, H, W, N32), 9.0, device="cuda")
     xd = x.cuda()
-    check(lib().dlip_stem_wgrad_chwn_f32(ptr(xd), ptr(out), B, T, H, W, N32, stream_handle()), "dlip_stem_wgrad_chwn_f32")
+    check(lib().dlip_stem_wgrad_chwn_f32(ptr(xd), ptr(out), B, T, H, W, N32, 0, stream_handle()), "dlip_stem_wgrad_chwn_f32")
+    out_sm = torch.full((5, N32 // 32, H, W, 32), 9.0, device="cuda")
+    check(lib().dlip_stem_wgrad_chwn_f32(ptr(xd), ptr(out_sm), B, T, H, W, N32, 1, stream_handle()), "dlip_stem_wgrad_chwn_f32")
     torch.cuda.synchronize()
     ref = torch.zeros(5, H, W, N32)
     for dt in range(5):
@@ -920,7 +928,33 @@ def test_stem_wgrad_chwn_operand(ops):
             for t in range(T):
                 if 0 <= t + dt - 2 < T:
                     ref[dt, :, :, b * T + t] = x[b, t + dt - 2]
-    assert torch.equal(out.cpu().view(torch.int32), _split_ref(ref).view(torch.int32))
+    want = _split_ref(ref).view(torch.int32)
+    assert torch.equal(out.cpu().view(torch.int32), want)
+    assert torch.equal(out_sm.cpu().view(torch.int32), want.view(5, H, W, N32 // 32, 32).permute(0, 3, 1, 2, 4).contiguous())
+
+
+@pytest.mark.parametrize("slice_major", [True, False], ids=["slice-major", "pixel-major"])
+@pytest.mark.parametrize("N,H,C,K,R,stride,pad,dil", [(40, 22, 64, 64, 3, 1, 1, 1), (33, 22, 64, 128, 3, 2, 1, 1), (70, 11, 128, 128, 3, 1, 1, 1),
+                                                       (9, 11, 32, 64, 3, 2, 1, 1), (5, 6, 256, 256, 3, 1, 1, 1), (4, 12, 32, 32, 3, 1, 2, 2)])
+def test_wgrad_as_conv_both_layouts(ops, slice_major, N, H, C, K, R, stride, pad, dil):
+    """The weight gradient run as a convolution (dlip_wgrad_chwn_f32 + dlip_wgrad_conv_f16x3 on slice-major images, or
+    dlip_conv_nhwc_f16x3 on pixel-major ones) against torch autograd in fp64."""
+    from deeplip_amd import autograd_video as av
+    x = rnd(N, C, H, H, seed=51).double().requires_grad_(False)
+    w = (rnd(K, C, R, R, seed=52) * 0.05).double().requires_grad_()
+    y = torch.nn.functional.conv2d(x, w, None, stride, pad, dil)
+    dy = rnd(*y.shape, seed=53) * 1e-3
+    y.backward(dy.double())
+    old = av.WGRAD_SLICE_MAJOR
+    av.WGRAD_SLICE_MAJOR = slice_major
+    try:
+        got = av.wgrad_as_conv(x.float().permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda(), R, R,
+                               (stride, stride), (pad, pad), (dil, dil))
+        torch.cuda.synchronize()
+    finally:
+        av.WGRAD_SLICE_MAJOR = old
+    assert tuple(got.shape) == (K, C, R, R)
+    assert rel_err(got.cpu().numpy(), w.grad.numpy()) < 2e-5
 
 
 @pytest.mark.parametrize("K,C,T", [(64, 64, 9), (128, 32, 3), (96, 64, 1), (32, 128, 5)])
