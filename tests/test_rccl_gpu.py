@@ -58,3 +58,20 @@ def test_train_audio_dp_on_rccl_one_rank(tmp_path):
     text = "".join(lines)
     assert rc == 0, text[-2000:]
     assert "Epoch 1 loss" in text and "EER" in text
+
+
+def test_train_fusion_dp_on_rccl_one_rank(tmp_path):
+    """BASELINE config C5 itself -- `train_fusion.py --mode train`: the fusion head on frozen encoders, its gradients one flat
+    all-reduce (deeplip_amd.dist.allreduce_grads), epoch metrics reduced over ranks, then sharded extraction + ragged gather +
+    trial scoring -- as a one-rank job on the real backend."""
+    over = ["train.bs=16", "train.epoch=1", "train.steps_per_epoch=2", "data.n_spk=6", "data.utt_per_spk=4", "data.test_speakers=4",
+            "data.test_utt_per_spk=3", "data.trials=300", "data.trial_targets=60", "data.video_frames=9", "data.audio_frames=120"]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        rc, js, lines = _run("train_fusion.py", ["--mode", "train", "--config", os.path.join(ROOT, "conf/fusion_config.yaml"), "--set", *over])
+    finally:
+        os.chdir(cwd)
+    text = "".join(lines)
+    assert rc == 0, text[-2000:]
+    assert "EER" in text
