@@ -101,7 +101,8 @@ def lift_inv(scale2, K):
     return inv
 
 
-def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False, scale2=None, w_ref=None, transposed=False):
+def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False, scale2=None, w_ref=None, transposed=False,
+               xs_ready=None):
     """One convolution of a training step on NHWC fp32 ``x`` with CURRENT weights -> fp32 NHWC.  Weights: ``w_krsc`` [K,R,S,C]
     (kernel layout), or ``w_ref`` = the parameter itself in the reference layout [Ko,Ci,R,S] -- then ``transposed`` False means
     the forward filter bank and True the data gradient's (flipped taps, in / out channels swapped): the split-fp16 image is
@@ -131,11 +132,15 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
         wsc = torch.empty((K,), device=dev, dtype=torch.float32)
         check(lib().dlip_split_weights_rows_f32(ptr(w_krsc), ptr(ws), ptr(wsc), K, L, stream_handle()), "dlip_split_weights_rows_f32")
     if not lift:
-        return ops.conv_nhwc(ops.split_pack(x), ws, bias, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True)
+        return ops.conv_nhwc(xs_ready if xs_ready is not None else ops.split_pack(x), ws, bias, stride=stride, pad=pad, dil=dil, w_scale=wsc,
+                             x_split=True)
     if scale2 is None:
         scale2 = pow2_lift(x)
-    xs = torch.empty_like(x)
-    check(lib().dlip_split_pack_scaled_f32(ptr(x), ptr(xs), ptr(scale2), x.numel() // Cx, Cx, stream_handle()), "dlip_split_pack_scaled_f32")
+    if xs_ready is not None:        # (x in the split format, lifted by scale2, written by the pass that formed the weight gradient's image)
+        xs = xs_ready
+    else:
+        xs = torch.empty_like(x)
+        check(lib().dlip_split_pack_scaled_f32(ptr(x), ptr(xs), ptr(scale2), x.numel() // Cx, Cx, stream_handle()), "dlip_split_pack_scaled_f32")
     inv = lift_inv(scale2, K)
     zeros = const_vec(K, 0.0, dev)
     return ops.conv_nhwc(xs, ws, None, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True, post_scale=inv, post_shift=zeros)
@@ -192,7 +197,21 @@ def _wgrad_conv_launch(xT, gT, inv, C_, H, W, K, Ho, Wo, N32, stride, pad, dil):
     return out
 
 
-def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None):
+def wgrad_image(t, scale2=None, also_nhwc_split=False):
+    """The weight gradient's operand image of an NHWC tensor ``t`` [N,H,W,C] (dlip_wgrad_chwn_f32; layout per
+    WGRAD_SLICE_MAJOR; times scale2[0] when given).  ``also_nhwc_split``: the convolution kernels' split activation format of the
+    same (scaled) tensor from the same read -- the forward convolution's operand (t = x) or the data gradient's (t = dy).
+    Returns (image [C,H,W,N32], split or None)."""
+    N, H, W, C_ = t.shape
+    N32 = (N + 31) // 32 * 32
+    img = torch.empty((C_, H, W, N32), device=t.device, dtype=torch.float32)    # slice-major: [C][N32/32][H][W][32]
+    spl = torch.empty_like(t) if also_nhwc_split else None
+    check(lib().dlip_wgrad_chwn_f32(ptr(t), ptr(img), N, H, W, C_, t.stride(2), N32, ptr(scale2) if scale2 is not None else None,
+                                    1 if WGRAD_SLICE_MAJOR else 0, ptr(spl) if spl is not None else None, stream_handle()), "dlip_wgrad_chwn_f32")
+    return img, spl
+
+
+def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None, xT=None, gT=None):
     """dW[c, r, s, k] = sum_{n,h,w} x[n, h*sh + r*dh - ph, w*sw + s*dw - pw, c] * dy[n, h, w, k] run as a CONVOLUTION on the
     engine's own conv kernel: input x' = x as [C][H][W][N] (the C channels play the batch, the N images the channels), filter
     g' = dy as [K][Ho][Wo][N], convolution stride = the layer's dilation, dilation = the layer's stride, same padding; the
@@ -200,18 +219,18 @@ def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None):
     operands are ONE split copy of their tensor (dlip_wgrad_chwn_f32; dy after its power-of-two lift) -- the reduction-major
     GEMM operand is R*S shifted copies of x: 1.03 GB written and read back per layer-1 convolution at B = 32, 0.9 ms of a
     0.1 ms data gradient's worth of FLOPs.  The Ho*Wo filter taps (484 on layer 1) are the conv kernel's address walk
-    (its variant without the 32-bit tap mask).  Returns dW in the reference layout [K, C, R, S]."""
-    N, H, W, Cx = x.shape
-    _, Ho, Wo, K = dy.shape
-    dev = x.device
-    N32 = (N + 31) // 32 * 32
-    if scale2 is None:
-        scale2 = pow2_lift(dy)
+    (its variant without the 32-bit tap mask).  ``xT`` / ``gT``: operand images already formed (wgrad_image; gT with the lift
+    ``scale2``); then x / dy may be None.  Returns dW in the reference layout [K, C, R, S]."""
+    if xT is None:
+        xT, _ = wgrad_image(x)
+    if gT is None:
+        if scale2 is None:
+            scale2 = pow2_lift(dy)
+        gT, _ = wgrad_image(dy, scale2)
+    Cx, H, W, N32 = xT.shape
+    K, Ho, Wo, _ = gT.shape
+    dev = xT.device
     sm = 1 if WGRAD_SLICE_MAJOR else 0
-    xT = torch.empty((Cx, H, W, N32), device=dev, dtype=torch.float32)          # slice-major: [Cx][N32/32][H][W][32]
-    check(lib().dlip_wgrad_chwn_f32(ptr(x), ptr(xT), N, H, W, Cx, x.stride(2), N32, None, sm, stream_handle()), "dlip_wgrad_chwn_f32")
-    gT = torch.empty((K, Ho, Wo, N32), device=dev, dtype=torch.float32)
-    check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), sm, stream_handle()), "dlip_wgrad_chwn_f32")
     inv = lift_inv(scale2, K)
     if sm:
         out = _wgrad_conv_launch(xT, gT, inv, Cx, H, W, K, Ho, Wo, N32, stride, pad, dil)   # [Cx, R', S', K]
@@ -246,9 +265,16 @@ class ConvTrainFn(Function):
         K, Cw, R, S = weight.shape
         if Cw != Cx or Cx % 4 or K % 4:
             raise ValueError(f"conv train path: channels must match and be multiples of 4 (x {Cx}, weight {Cw}, out {K})")
-        y = conv_train(x, None, bias.contiguous() if bias is not None else None, stride, pad, dil, w_ref=weight)
-        ctx.save_for_backward(x, weight)
+        # One read of x writes BOTH of its split images: the forward convolution's operand and the weight gradient's (kept for the
+        # backward instead of x itself -- the data gradient does not need x).
+        fused = WGRAD == "conv" and TRAIN_CONV == "f16x3" and R * S > 1 and Cx % 32 == 0 and K % 4 == 0 and ctx.needs_input_grad[1]
+        xT = xs = None
+        if fused:
+            xT, xs = wgrad_image(x, None, also_nhwc_split=True)
+        y = conv_train(x, None, bias.contiguous() if bias is not None else None, stride, pad, dil, w_ref=weight, xs_ready=xs)
+        ctx.save_for_backward(xT if fused else x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
+        ctx.x_shape, ctx.fused = (N, H, W, Cx), fused
         return y
 
     @staticmethod
@@ -256,15 +282,33 @@ class ConvTrainFn(Function):
         x, weight = ctx.saved_tensors
         (sh, sw), (ph, pw), (dh, dw), has_bias = ctx.cfg
         dy = dy.contiguous()
-        N, H, W, Cx = x.shape
+        N, H, W, Cx = ctx.x_shape
         K, _, R, S = weight.shape
         _, Ho, Wo, _ = dy.shape
         J = N * Ho * Wo
-        dev = x.device
+        dev = dy.device
         dz_rows = dy.view(J, K)
         dbias = _colsum_rows(dz_rows) if has_bias and ctx.needs_input_grad[2] else None
         dx = None
         lift = pow2_lift(dy) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None   # zero insertion does not change max|dy|
+        if ctx.fused:
+            # (x here is the weight gradient's image of the layer input, formed in the forward.)  One read of dy writes its image AND,
+            # for a stride-1 layer, the lifted split operand of the data-gradient convolution.
+            want_w, want_x = ctx.needs_input_grad[1], ctx.needs_input_grad[0]
+            dense = sh == 1 and sw == 1 and K % 32 == 0
+            gT = dys = None
+            if want_w:
+                gT, dys = wgrad_image(dy, lift, also_nhwc_split=want_x and dense)
+            if want_x:
+                src = dy
+                if not dense:
+                    Hu, Wu = H + 2 * ph - dh * (R - 1), W + 2 * pw - dw * (S - 1)
+                    src = torch.empty((N, Hu, Wu, K), device=dev, dtype=torch.float32)
+                    check(lib().dlip_upsample_zero_f32(ptr(dy), ptr(src), N, Ho, Wo, Hu, Wu, K, sh, sw, stream_handle()), "dlip_upsample_zero_f32")
+                dx = conv_train(src, None, None, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), lift=True, scale2=lift,
+                                w_ref=weight, transposed=True, xs_ready=dys)
+            dweight = wgrad_as_conv(None, None, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift, xT=x, gT=gT) if want_w else None
+            return dx, dweight, dbias, None, None, None
         if ctx.needs_input_grad[0]:
             src = dy
             if sh != 1 or sw != 1:
@@ -336,7 +380,7 @@ class StemConvTrainFn(Function):
             xT = torch.empty((5, H, W, N32), device=dev, dtype=torch.float32)
             check(lib().dlip_stem_wgrad_chwn_f32(ptr(x), ptr(xT), B, T, H, W, N32, sm, stream_handle()), "dlip_stem_wgrad_chwn_f32")
             gT = torch.empty((K, Ho, Wo, N32), device=dev, dtype=torch.float32)
-            check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), sm, stream_handle()), "dlip_wgrad_chwn_f32")
+            check(lib().dlip_wgrad_chwn_f32(ptr(dy), ptr(gT), N, Ho, Wo, K, K, N32, ptr(scale2), sm, None, stream_handle()), "dlip_wgrad_chwn_f32")
             inv = lift_inv(scale2, K)
             if sm:
                 out = _wgrad_conv_launch(xT, gT, inv, 5, H, W, K, Ho, Wo, N32, (2, 2), (3, 3), (1, 1))   # [5, 8, 8, K] (even H: a spare row / column)

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void wgrad_operand_kernel(const float* __restr
 // group = 0).
 __global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int ldx, int C,
                                                          int N32, const float* __restrict__ scale, DlipRange status, int group = 0,
-                                                         int shift = 0, int layout = 0) {
+                                                         int shift = 0, int layout = 0, float* __restrict__ nhwc_out = nullptr) {
   __shared__ float tile[32][33];
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32, p = blockIdx.z;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -144,6 +144,20 @@ __global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict
                       : layout == 1 ? (((long long)(c0 + cr) * (N32 / 32) + blockIdx.x) * HW + p) * 32
                                     : ((long long)blockIdx.x * C + (c0 + cr)) * 32;
   if (c0 + cr < C) *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + blk) + (pq < 4 ? 0 : 32) + jb) = o;
+  // The SAME tile in the split activation format of the convolution kernels ([N,H,W,C]: per pixel and 32 channels one block of
+  // 32 hi | 32 lo halves): what the forward convolution reads of x, and the data-gradient convolution of dy -- written here,
+  // from the one read of the tensor, instead of by a split pass of its own (C % 32 == 0).
+  if (nhwc_out) {
+    const int nl = threadIdx.x >> 3, n = n0 + nl;
+    h8 q;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = tile[nl][jb + e];
+      const _Float16 hi = (_Float16)v;
+      q[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
+    }
+    if (n < N) *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(nhwc_out + ((long long)n * HW + p) * C + c0) + (pq < 4 ? 0 : 32) + jb) = q;
+  }
   dlip_report_range(amax, status);
 }
 
@@ -456,12 +470,13 @@ extern "C" int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out
 }
 
 extern "C" int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t N32,
-                                   const float* scale, int32_t slice_major, dlip_stream_t stream) {
+                                   const float* scale, int32_t slice_major, float* nhwc_split_out, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && out && N > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && N32 >= N && (N32 & 31) == 0 &&
                  (reinterpret_cast<uintptr_t>(out) & 127) == 0);
   DLIP_CHECK_ARG((long long)H * W <= 65535 && (C + 31) / 32 <= 65535 && N < (1ll << 31));
+  DLIP_CHECK_ARG(nhwc_split_out == nullptr || ((C & 31) == 0 && (reinterpret_cast<uintptr_t>(nhwc_split_out) & 127) == 0));
   hipLaunchKernelGGL(wgrad_chwn_kernel, dim3((unsigned)(N32 / 32), (unsigned)((C + 31) / 32), (unsigned)(H * W)), dim3(256), 0, ST(stream), x,
-                     out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK), 0, 0, slice_major ? 1 : 0);
+                     out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK), 0, 0, slice_major ? 1 : 0, nhwc_split_out);
   return dlip_launch_status();
 }
 

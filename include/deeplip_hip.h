@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 36
+#define DLIP_ABI_VERSION 37
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -503,7 +503,10 @@ int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int64_t N
  * -- ONE copy of each tensor instead of the R*S shifted copies of dlip_wgrad_operand_f32; dlip_conv_nhwc_f16x3 accepts filters of
  * more than 32 taps for this (split input, fp32 output, no residual).  train_video.py:129-147 (loss.backward()). */
 int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t N32,
-                        const float* scale, int32_t slice_major, dlip_stream_t stream);
+                        const float* scale, int32_t slice_major, float* nhwc_split_out, dlip_stream_t stream);
+/* nhwc_split_out (nullable; C % 32 == 0): the same tensor (scaled alike) ALSO in the convolution kernels' split activation format
+ * [N,H,W,C] -- what dlip_split_pack_f32 / dlip_split_pack_scaled_f32 would write -- from the one read: the forward convolution's
+ * operand together with the weight gradient's (x), the data gradient's together with the weight gradient's (dy). */
 /* slice_major != 0: the image as [C][N32/32][H][W][32] instead -- one 32-image slice of all pixels of a channel is ONE contiguous
  * plane, so that the filter taps a convolution walks one after the other are adjacent 128-byte lines (pixel-major they are
  * N32 * 4 bytes apart: every piece a DRAM page of its own).  That is the layout dlip_wgrad_conv_f16x3 reads:

@@ -896,16 +896,19 @@ def test_wgrad_chwn_operand(ops, N, H, W, C):
     xd, scale = x.cuda(), torch.tensor([4.0, 0.25]).cuda()        # (held in variables: ptr() of a temporary would dangle)
     for sc in (None, scale):
         out = torch.full((C, H, W, N32), 9.0, device="cuda")
-        check(lib().dlip_wgrad_chwn_f32(ptr(xd), ptr(out), N, H, W, C, C, N32, ptr(sc) if sc is not None else None, 0, stream_handle()),
+        check(lib().dlip_wgrad_chwn_f32(ptr(xd), ptr(out), N, H, W, C, C, N32, ptr(sc) if sc is not None else None, 0, None, stream_handle()),
               "dlip_wgrad_chwn_f32")
         out_sm = torch.full((C, N32 // 32, H, W, 32), 9.0, device="cuda")
-        check(lib().dlip_wgrad_chwn_f32(ptr(xd), ptr(out_sm), N, H, W, C, C, N32, ptr(sc) if sc is not None else None, 1, stream_handle()),
-              "dlip_wgrad_chwn_f32")
+        spl = torch.full((N, H, W, C), 9.0, device="cuda") if C % 32 == 0 else None      # + the NHWC split copy from the same read
+        check(lib().dlip_wgrad_chwn_f32(ptr(xd), ptr(out_sm), N, H, W, C, C, N32, ptr(sc) if sc is not None else None, 1,
+                                        ptr(spl) if spl is not None else None, stream_handle()), "dlip_wgrad_chwn_f32")
         torch.cuda.synchronize()
         ref = torch.zeros(C, H, W, N32)
         ref[..., :N] = (x * (4.0 if sc is not None else 1.0)).permute(3, 1, 2, 0)
         want = _split_ref(ref).view(torch.int32)
         assert torch.equal(out.cpu().view(torch.int32), want)
+        if spl is not None:
+            assert torch.equal(spl.cpu().view(torch.int32), _split_ref(x * (4.0 if sc is not None else 1.0)).view(torch.int32))
         # slice-major: the same 128-byte blocks, ordered [c][slice][h][w]
         assert torch.equal(out_sm.cpu().view(torch.int32), want.view(C, H, W, N32 // 32, 32).permute(0, 3, 1, 2, 4).contiguous())
 
