@@ -13,6 +13,8 @@ the autograd Functions of deeplip_amd/autograd_video.py (train_video.py:108-169)
 """
 from __future__ import annotations
 
+import contextlib
+
 import math
 from typing import Dict, List, Optional, Sequence
 
@@ -292,6 +294,18 @@ class MultibranchTemporalBlock(nn.Module):
         raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
 
 
+TCN_BRANCH_STREAMS = True
+_BRANCH_STREAMS = {}
+
+
+def _branch_streams(device, n: int):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    have = _BRANCH_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
 def _tcn_block_train(b: "MultibranchTemporalBlock", x: Tensor, p_drop: float) -> Tensor:
     """MultibranchTemporalBlock.forward under model.train() (tcn.py:89-116).  Each branch convolves with
     padding (k-1)d on both sides, normalises with the batch statistics of the FULL padded-length output,
@@ -300,14 +314,27 @@ def _tcn_block_train(b: "MultibranchTemporalBlock", x: Tensor, p_drop: float) ->
     from . import autograd_video as av
     B, T, _ = x.shape
     cur = x
+    # The branches of a stage are independent and small ([B T = 928 rows] x 256 channels: 16 tiles on a 512-slot chip, 40 us of
+    # mostly latency per launch): each runs on its OWN stream between a fork and a join, so that their launches -- and, since
+    # autograd runs an op's backward on the stream of its forward, their backward launches too -- overlap, eagerly and as parallel
+    # branches of a recorded step graph.  (A side stream's tensors return to that stream's allocator pool; every side-stream
+    # phase starts by waiting for the main stream, so a block is never rewritten while the main stream still reads it.)
+    main = torch.cuda.current_stream(x.device) if (TCN_BRANCH_STREAMS and x.is_cuda) else None
+    side = _branch_streams(x.device, len(b.kernel_sizes) - 1) if main is not None else []
     for s in (0, 1):
         outs = []
         for j, k in enumerate(b.kernel_sizes):
             m = getattr(b, f"cbcr{s}_{j}")
             pad = (k - 1) * b.dilation
-            z = av.conv(cur.reshape(B, 1, T, cur.shape[2]), m.conv.weight, m.conv.bias, pad=(0, pad), dil=(1, b.dilation))
-            z = av.batchnorm_prelu(z, m.batchnorm, m.non_lin)        # [B,1,T+pad,nb]; the element-wise PReLU commutes with the chomp
-            outs.append(z[:, :, pad // 2: pad // 2 + T].contiguous())   # symmetric chomp
+            st = side[j - 1] if (main is not None and j > 0) else None
+            if st is not None:
+                st.wait_stream(main)
+            with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+                z = av.conv(cur.reshape(B, 1, T, cur.shape[2]), m.conv.weight, m.conv.bias, pad=(0, pad), dil=(1, b.dilation))
+                z = av.batchnorm_prelu(z, m.batchnorm, m.non_lin)        # [B,1,T+pad,nb]; the element-wise PReLU commutes with the chomp
+                outs.append(z[:, :, pad // 2: pad // 2 + T].contiguous())   # symmetric chomp
+        for st in side:
+            main.wait_stream(st)
         cur = av.dropout(av.concat_channels(outs).view(B, T, b.n_outputs), p_drop)   # (a HIP row copy per branch, not torch.cat)
     if b.downsample is None:
         raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
