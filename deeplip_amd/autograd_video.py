@@ -28,7 +28,14 @@ def const_vec(n: int, value: float, device):
     key = (str(device), int(n), float(value))
     t = _CONST.get(key)
     if t is None:
-        t = _CONST[key] = torch.full((n,), float(value), device=device, dtype=torch.float32)
+        t = torch.full((n,), float(value), device=device, dtype=torch.float32)
+        # The vector is SHARED by every later launch on every stream, but its fill runs on whichever stream is current now --
+        # possibly a side stream of a forked branch (video.BRANCH_STREAMS), which nobody else waits for: the first step read
+        # garbage scales on the other streams (a range error with the default stream as main stream, silently different weights
+        # otherwise).  Created once: wait for it.
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(t.device).synchronize()
+        _CONST[key] = t
     return t
 
 

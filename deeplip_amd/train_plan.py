@@ -36,10 +36,11 @@ Tensor = torch.Tensor
 class TrainStepGraph:
     """``fn(*inputs) -> tensor or tuple of tensors`` performs one complete optimisation step on device tensors ``inputs``."""
 
-    def __init__(self, fn: Callable, eager_steps: int = 2, device: Optional[torch.device] = None):
+    def __init__(self, fn: Callable, eager_steps: int = 2, device: Optional[torch.device] = None, branch_streams: bool = True):
         if eager_steps < 1:
             raise ValueError("TrainStepGraph: at least one eager step (optimizer state and workspaces must exist before recording)")
         self.fn = fn
+        self.branch_streams = branch_streams    # independent branches of the lip-clip model's train graph on side streams (video.BRANCH_STREAMS)
         self.eager_steps = eager_steps
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(device=self.device)
@@ -59,6 +60,14 @@ class TrainStepGraph:
         self._check(inputs)
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
+        from . import video as _video
+        prev, _video.BRANCH_STREAMS = _video.BRANCH_STREAMS, self.branch_streams
+        try:
+            return self._step(inputs, cur)
+        finally:
+            _video.BRANCH_STREAMS = prev
+
+    def _step(self, inputs, cur):
         with torch.cuda.stream(self.stream):
             if self.calls < self.eager_steps:
                 out = self.fn(*inputs)

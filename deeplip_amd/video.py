@@ -129,9 +129,20 @@ def _basic_block_train(b: "BasicBlock", x: Tensor) -> Tensor:
     every step a differentiable dlip_* launch (deeplip_amd/autograd_video.py).  x NHWC."""
     from . import autograd_video as av
     s = (b.stride, b.stride)
+    res, side = x, None
+    if b.downsample is not None:
+        # the shortcut (1x1 strided convolution + BatchNorm) is independent of the main path: its own stream, forward and -- by
+        # autograd's stream rule -- backward (see _tcn_block_train)
+        main = _fork_stream(x)
+        side = _branch_streams(x.device, 1)[0] if main is not None else None
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            res = av.batchnorm(av.conv(x, b.downsample[0].weight, None, stride=s), b.downsample[1])
     h = av.batchnorm_prelu(av.conv(x, b.conv1.weight, None, stride=s, pad=(1, 1)), b.bn1, b.relu1)
     h = av.batchnorm(av.conv(h, b.conv2.weight, None, pad=(1, 1)), b.bn2)
-    res = x if b.downsample is None else av.batchnorm(av.conv(x, b.downsample[0].weight, None, stride=s), b.downsample[1])
+    if side is not None:
+        main.wait_stream(side)
     return av.prelu(h + res, b.relu2)
 
 
@@ -294,8 +305,20 @@ class MultibranchTemporalBlock(nn.Module):
         raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
 
 
-TCN_BRANCH_STREAMS = True
+# Independent branches of the train-mode graph (the three kernel sizes of a TCN stage, a block's shortcut) on side streams.
+# OFF by default (issued from Python the extra stream switches cost more host time than the overlap returns);
+# deeplip_amd.train_plan.TrainStepGraph turns it on around the step it runs / records.  Bit-identical to the single-stream step
+# (tools/probes/train_streams_identity.py at B = 32; tests/test_train_video_gpu.py).  What a forked branch must not do is CREATE a
+# tensor that other streams will read without an edge to its fill -- autograd_video.const_vec waits for the ones it makes.
+BRANCH_STREAMS = False
 _BRANCH_STREAMS = {}
+
+
+def _fork_stream(x):
+    """The stream to fork side streams from, or None: branches stay on the current stream."""
+    if not (BRANCH_STREAMS and x.is_cuda):
+        return None
+    return torch.cuda.current_stream(x.device)
 
 
 def _branch_streams(device, n: int):
@@ -319,7 +342,7 @@ def _tcn_block_train(b: "MultibranchTemporalBlock", x: Tensor, p_drop: float) ->
     # autograd runs an op's backward on the stream of its forward, their backward launches too -- overlap, eagerly and as parallel
     # branches of a recorded step graph.  (A side stream's tensors return to that stream's allocator pool; every side-stream
     # phase starts by waiting for the main stream, so a block is never rewritten while the main stream still reads it.)
-    main = torch.cuda.current_stream(x.device) if (TCN_BRANCH_STREAMS and x.is_cuda) else None
+    main = _fork_stream(x)
     side = _branch_streams(x.device, len(b.kernel_sizes) - 1) if main is not None else []
     for s in (0, 1):
         outs = []

@@ -960,7 +960,7 @@ def test_wgrad_as_conv_both_layouts(ops, slice_major, N, H, C, K, R, stride, pad
     assert rel_err(got.cpu().numpy(), w.grad.numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("K,C,T", [(64, 64, 9), (128, 32, 3), (96, 64, 1), (32, 128, 5)])
+@pytest.mark.parametrize("K,C,T", [(64, 64, 9), (128, 32, 3), (96, 64, 1), (32, 128, 5), (32, 1024, 9), (1024, 32, 9)])
 def test_split_weights_perm_equals_permute_then_split(ops, K, C, T):
     """dlip_split_weights_perm_f32 (reference [K,C,T] in, split image out) == permute + dlip_split_weights_rows_f32, both modes."""
     from deeplip_amd._lib import check, lib, ptr, stream_handle

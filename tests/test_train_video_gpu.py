@@ -344,6 +344,8 @@ def test_recorded_training_step_is_bit_identical_to_eager():
         return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}
 
     le, se = run(False)
+    av_mod = __import__("deeplip_amd.autograd_video", fromlist=["x"])
+    av_mod._CONST.clear()       # the recorded run must CREATE the shared constant vectors itself -- inside its forked branches
     lg, sg = run(True)
     assert le == lg
     for k in se:
