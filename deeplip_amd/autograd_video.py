@@ -661,6 +661,48 @@ def concat_channels(xs):
     return ConcatChannelsFn.apply(*xs)
 
 
+class ChompConcatFn(Function):
+    """The end of a multibranch TCN stage in one launch per branch: symmetric chomp (tcn.py:52-59: rows pad/2 .. pad/2 + T of the
+    padded-length branch output [B,1,T+pad,nb]) AND concatenation along channels (tcn.py:96-108) -> [B,T,sum nb].  Backward: each
+    branch's gradient is the slice of dy at its channels, placed at rows pad/2.. of a zero tensor -- the same strided row copy with
+    a negative row offset (out-of-range rows read as zeros).  Replaces slice + contiguous + concat (two copies forward; a zero
+    fill, a copy and a slice copy backward)."""
+
+    @staticmethod
+    def forward(ctx, T, *zs):
+        zs = [z.contiguous() for z in zs]
+        B = zs[0].shape[0]
+        widths = [z.shape[-1] for z in zs]
+        lens = [z.shape[2] for z in zs]                       # T + pad_j
+        Ct = sum(widths)
+        out = torch.empty((B, T, Ct), device=zs[0].device, dtype=torch.float32)
+        off = 0
+        for z, Cb, L in zip(zs, widths, lens):
+            check(lib().dlip_tap_gather_f32(ptr(z), out.data_ptr() + 4 * off, B, 1, L, Cb, Cb, 1, T, 1, 1, 0, (L - T) // 2, Ct, stream_handle()),
+                  "dlip_tap_gather_f32")
+            off += Cb
+        ctx.cfg = (T, widths, lens)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        T, widths, lens = ctx.cfg
+        dy = dy.contiguous()
+        B, _, Ct = dy.shape
+        outs, off = [], 0
+        for Cb, L in zip(widths, lens):
+            g = torch.empty((B, 1, L, Cb), device=dy.device, dtype=torch.float32)
+            check(lib().dlip_tap_gather_f32(dy.data_ptr() + 4 * off, ptr(g), B, 1, T, Cb, Ct, 1, L, 1, 1, 0, -((L - T) // 2), Cb, stream_handle()),
+                  "dlip_tap_gather_f32")
+            outs.append(g)
+            off += Cb
+        return (None,) + tuple(outs)
+
+
+def chomp_concat(zs, T):
+    return ChompConcatFn.apply(T, *zs)
+
+
 def dropout(x, p: float, training: bool = True):
     if not training or p <= 0.0:
         return x

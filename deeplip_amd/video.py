@@ -354,11 +354,10 @@ def _tcn_block_train(b: "MultibranchTemporalBlock", x: Tensor, p_drop: float) ->
                 st.wait_stream(main)
             with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
                 z = av.conv(cur.reshape(B, 1, T, cur.shape[2]), m.conv.weight, m.conv.bias, pad=(0, pad), dil=(1, b.dilation))
-                z = av.batchnorm_prelu(z, m.batchnorm, m.non_lin)        # [B,1,T+pad,nb]; the element-wise PReLU commutes with the chomp
-                outs.append(z[:, :, pad // 2: pad // 2 + T].contiguous())   # symmetric chomp
+                outs.append(av.batchnorm_prelu(z, m.batchnorm, m.non_lin))   # [B,1,T+pad,nb]; the element-wise PReLU commutes with the chomp
         for st in side:
             main.wait_stream(st)
-        cur = av.dropout(av.concat_channels(outs).view(B, T, b.n_outputs), p_drop)   # (a HIP row copy per branch, not torch.cat)
+        cur = av.dropout(av.chomp_concat(outs, T), p_drop)      # symmetric chomp + concatenation: one strided row copy per branch
     if b.downsample is None:
         raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
     res = av.conv(x.reshape(B, 1, T, x.shape[2]), b.downsample.weight, b.downsample.bias).view(B, T, b.n_outputs)
