@@ -300,9 +300,29 @@ def test_lipreading_train_mode_with_dropout_and_eval_roundtrip():
     assert out.shape == (4, 54) and bool(torch.isfinite(out).all())
 
 
-def test_recorded_training_step_is_bit_identical_to_eager():
-    """deeplip_amd.train_plan.TrainStepGraph: five optimisation steps on five different batches -- eager loop vs one eager step +
-    a recorded step replayed four times -- leave bit-identical parameters, BatchNorm statistics and losses (same Adam variant in
+def test_chomp_concat_vs_torch_slice_and_cat():
+    """ChompConcatFn (one strided row copy per branch, forward and backward) == slice + cat under torch autograd, bit for bit."""
+    from deeplip_amd import autograd_video as av
+    B, T = 3, 11
+    pads, widths = [4, 8, 12], [8, 16, 12]
+    zs = [rnd(B, 1, T + p, w, seed=60 + i).to(DEV).requires_grad_() for i, (p, w) in enumerate(zip(pads, widths))]
+    zr = [z.detach().clone().requires_grad_() for z in zs]
+    dy = rnd(B, T, sum(widths), seed=70).to(DEV)
+    y = av.chomp_concat(zs, T)
+    y.backward(dy)
+    ref = torch.cat([z[:, 0, p // 2: p // 2 + T] for z, p in zip(zr, pads)], dim=2)
+    ref.backward(dy)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    for a, b in zip(zs, zr):
+        assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("B,T", [(4, 9), (8, 29)])
+def test_recorded_training_step_is_bit_identical_to_eager(B, T):
+    """deeplip_amd.train_plan.TrainStepGraph: five optimisation steps on five different batches -- eager loop on ONE stream vs one
+    eager step + a recorded step replayed four times, both with the independent branches of the graph on SIDE streams
+    (video.BRANCH_STREAMS) -- leave bit-identical parameters, BatchNorm statistics and losses (same Adam variant in
     both: capturable, learning rate in a device tensor that a cosine scheduler updates every iteration; dropout off -- the
     generator's offsets under capture are torch's business).  Two DIFFERENT Adam variants diverge by 5e-4 after two steps on this
     model -- the biases in front of a BatchNorm have pure-rounding-noise gradients, which Adam turns into +-lr steps
@@ -310,7 +330,6 @@ def test_recorded_training_step_is_bit_identical_to_eager():
     from deeplip_amd import autograd as ag
     from deeplip_amd.train_plan import TrainStepGraph
     from models.video_models.model import Lipreading
-    B, T = 4, 9
 
     def run(graph):
         tcn = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.0, "dwpw": False, "width_mult": 1}
@@ -333,7 +352,7 @@ def test_recorded_training_step_is_bit_identical_to_eager():
         for i in range(5):
             x = torch.from_numpy(wg.video_input(B, frames=T, key=f"tsg.v{i}")).to(DEV)
             lab = torch.from_numpy((wg.labels(B, 54) + 7 * i) % 54).to(DEV)
-            ln = torch.tensor([T, T - 1, T - 2, T - 3][:B], dtype=torch.int32, device=DEV)
+            ln = torch.tensor([T - (i % 4) for i in range(B)], dtype=torch.int32, device=DEV)
             l = plan.step(x, lab, ln) if graph else one(x, lab, ln)
             sched.step()
             losses.append(float(l.detach()))
