@@ -179,6 +179,15 @@ class SpeakerEmbNet(nn.Module):
         return ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim, 32 if split else 4),
                               out_split=split)
 
+    def _to_ntc_padded(self, x: Tensor) -> Tensor:
+        from . import autograd_video as av
+        if x.dim() == 4:
+            x = x.squeeze(1)
+        if x.dim() != 3 or x.shape[1] != self.input_dim:
+            raise ValueError(f"SpeakerEmbNet expects [B,{self.input_dim},T] features, got {tuple(x.shape)}")
+        pad32 = av.TRAIN_CONV == "f16x3" and self.input_dim % 32 != 0 and self.tdnn[0].output_dim % 4 == 0
+        return ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim, 32 if pad32 else 4))
+
     def _extract_embedding_train(self, x: Tensor) -> Tuple[Tensor, Tensor]:
         """extract_embedding under model.train() (train_audio.py:167-183): batch-statistics BatchNorm, every
         layer differentiable.  Each step is a torch.autograd Function whose forward and backward are dlip_*
@@ -188,7 +197,9 @@ class SpeakerEmbNet(nn.Module):
             raise NotImplementedError("train-mode encoder: only pooling='statistic' (the shipped configs)")
         if self.input_dim % 4:
             raise ValueError("train-mode encoder: input_dim must be a multiple of 4")
-        h = self._to_ntc(x)                                   # [B,T,F] channels-last
+        # [B,T,F] channels-last; F zero-padded to a multiple of 32 when the first layer can then run on the split-fp16 kernels
+        # (24 features: the exact-fp32 kernel took 0.55 ms per launch on it, 1.1 of a 15 ms step at B = 256)
+        h = self._to_ntc_padded(x)
         for blk in self.tdnn:
             h = ag.tdnn_block_train(h, blk)
         h = ag.meanstd_pool(h)

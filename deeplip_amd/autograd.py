@@ -36,10 +36,16 @@ class LinearFn(Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         M, Cin = x.shape
-        if Cin % 4 == 0:
+        # Batch-level layers (fc1 / fc2 / the classifier: M = the batch, a long reduction) go to the small-GEMM kernel: on the
+        # convolution kernel a [256 x 3000] x [3000 x 512] product is 16 tiles walking 94 slices each -- 1.0 ms of a 15 ms
+        # speech-encoder training step -- while the backward already ran its two products here in 40 us each.
+        if Cin % 4 == 0 and M > 1024:
             return ops.linear(x, w, b.contiguous() if b is not None else None)
         y = _gemm(x, w, M, w.shape[0], Cin, tb=True)
-        return y + b if b is not None else y
+        if b is None:
+            return y
+        from .autograd_video import const_vec
+        return ops.affine_act(y, const_vec(w.shape[0], 1.0, x.device), b.contiguous(), slope=1.0)
 
     @staticmethod
     def backward(ctx, dy):
@@ -279,7 +285,8 @@ class TDNNBlockTrainFn(Function):
         x = x.contiguous()
         B, T, Cx = x.shape
         K, Cw, S = weight.shape
-        if Cw != Cx or Cx % 4 or K % 4:
+        # (a first layer on 24 features may read its input zero-padded to 32 channels: then the split-fp16 kernels serve it too)
+        if (Cw != Cx and (Cw + 31) // 32 * 32 != Cx) or Cx % 4 or K % 4:
             raise ValueError(f"TDNN train path: channels must match and be multiples of 4 (x {Cx}, weight {Cw}, out {K})")
         from .autograd_video import conv_train
         B_, T_, C_in = x.shape
@@ -320,6 +327,8 @@ class TDNNBlockTrainFn(Function):
         dweight = None
         if ctx.needs_input_grad[1]:
             dweight = _conv1d_wgrad(x, dz, S, dilation, lift)
+            if dweight.shape[1] != weight.shape[1]:          # zero-padded input channels: their gradient columns are not parameters
+                dweight = dweight[:, :weight.shape[1]].contiguous()
         return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None
 
 

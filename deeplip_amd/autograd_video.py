@@ -120,6 +120,9 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
     if w_ref is not None:
         Ko, Ci, R_, S_ = w_ref.shape
         K, Cw = (Ci, Ko) if transposed else (Ko, Ci)
+        padded = (not transposed) and Cw < Cx and (Cw + 31) // 32 * 32 == Cx     # x carries zero channels up to the next 32 (a 24-feature input)
+        if padded and TRAIN_CONV == "f16x3" and K % 4 == 0:
+            Cw = Cx
         if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or Cw != Cx:
             w3 = w_ref.contiguous().view(Ko, Ci, R_ * S_)
             w_krsc = (_permute3(w3, (1, 2, 0), flip_axis=2).view(Ci, R_, S_, Ko) if transposed else _permute3(w3, (0, 2, 1)).view(Ko, R_, S_, Ci))
@@ -127,8 +130,8 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
         dev = x.device
         ws = torch.empty((K, R_, S_, Cw), device=dev, dtype=torch.float32)
         wsc = torch.empty((K,), device=dev, dtype=torch.float32)
-        check(lib().dlip_split_weights_perm_f32(ptr(w_ref.contiguous()), ptr(ws), ptr(wsc), Ko, Ci, R_ * S_, 1 if transposed else 0, stream_handle()),
-              "dlip_split_weights_perm_f32")
+        check(lib().dlip_split_weights_perm_f32(ptr(w_ref.contiguous()), ptr(ws), ptr(wsc), Ko, Ci, R_ * S_, 1 if transposed else 0,
+                                                Cw if not transposed else 0, stream_handle()), "dlip_split_weights_perm_f32")
     else:
         K = w_krsc.shape[0]
         if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or w_krsc.shape[3] != Cx:

@@ -396,17 +396,21 @@ __global__ __launch_bounds__(256) void split_weights_rows_kernel(const float* __
 // through L2 (the whole bank is at most 9.4 MB), so the strided gather of MODE 1 costs nothing measurable.
 template <int MODE>
 __global__ __launch_bounds__(256) void split_weights_perm_kernel(const float* __restrict__ w, float* __restrict__ ws, float* __restrict__ scale,
-                                                                 int K, int C, int T) {
+                                                                 int K, int C, int T, int Cp) {
   __shared__ float red[4];
   __shared__ float stage[8192];                   // the row's source values in OUTPUT order (rows of up to 8192 values: else from memory)
   const int row = blockIdx.x;
-  const int inner = MODE == 0 ? C : K;            // channels of one tap in the output row
+  const int inner = MODE == 0 ? Cp : K;           // channels of one tap in the output row (MODE 0: C padded with zeros to Cp)
   const int L = T * inner;
   const bool staged = L <= 8192;
   if (staged) {
+    if (MODE == 0 && Cp != C) {
+      for (int i = threadIdx.x; i < L; i += 256) stage[i] = 0.f;
+      __syncthreads();
+    }
     // read in SOURCE order -- the T taps of one (k, c) pair are contiguous, MODE 0's whole row is -- and scatter into LDS: MODE 1
     // read in output order touches one 4-byte word per 128-byte line (12 us per call, 0.6 ms per training step)
-    for (int s_ = threadIdx.x; s_ < L; s_ += 256) {
+    for (int s_ = threadIdx.x; s_ < T * (MODE == 0 ? C : K); s_ += 256) {
       const int j = s_ / T, t = s_ - j * T;       // j: the other channel index (c for MODE 0, k for MODE 1)
       const float v = MODE == 0 ? w[(long long)row * C * T + s_] : w[((long long)j * C + row) * T + t];
       stage[(MODE == 0 ? t : T - 1 - t) * inner + j] = v;
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(256) void split_weights_perm_kernel(const float* __
   auto src = [&](int i) -> float {
     if (staged) return stage[i];
     const int t = i / inner, j = i - t * inner;
+    if (MODE == 0 && j >= C) return 0.f;
     return MODE == 0 ? w[((long long)row * C + j) * T + t] : w[((long long)j * C + row) * T + (T - 1 - t)];
   };
   float m = 0.f;
@@ -636,12 +641,14 @@ extern "C" int dlip_split_weights_rows_f32(const float* w, float* w_split, float
 }
 
 extern "C" int dlip_split_weights_perm_f32(const float* w_kct, float* w_split, float* w_scale, int32_t K, int32_t C, int32_t T,
-                                           int32_t mode, dlip_stream_t stream) {
+                                           int32_t mode, int32_t C_pad, dlip_stream_t stream) {
   DLIP_CHECK_ARG(w_kct && w_split && w_scale && K > 0 && C > 0 && T > 0 && (mode == 0 || mode == 1));
-  DLIP_CHECK_ARG(((mode == 0 ? C : K) & 31) == 0 && (long long)K * C * T < (1ll << 31));
+  if (C_pad <= 0) C_pad = C;
+  DLIP_CHECK_ARG(C_pad >= C && (mode == 0 || C_pad == C));
+  DLIP_CHECK_ARG(((mode == 0 ? C_pad : K) & 31) == 0 && (long long)K * C_pad * T < (1ll << 31));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (mode == 0) hipLaunchKernelGGL(split_weights_perm_kernel<0>, dim3((unsigned)K), dim3(256), 0, st, w_kct, w_split, w_scale, K, C, T);
-  else hipLaunchKernelGGL(split_weights_perm_kernel<1>, dim3((unsigned)C), dim3(256), 0, st, w_kct, w_split, w_scale, K, C, T);
+  if (mode == 0) hipLaunchKernelGGL(split_weights_perm_kernel<0>, dim3((unsigned)K), dim3(256), 0, st, w_kct, w_split, w_scale, K, C, T, C_pad);
+  else hipLaunchKernelGGL(split_weights_perm_kernel<1>, dim3((unsigned)C), dim3(256), 0, st, w_kct, w_split, w_scale, K, C, T, C);
   return dlip_launch_status();
 }
 

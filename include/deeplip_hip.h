@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 37
+#define DLIP_ABI_VERSION 38
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -457,7 +457,9 @@ int dlip_split_weights_rows_f32(const float* w, float* w_split, float* w_scale, 
  * mode 0 = the forward operand, K rows of [T][C]; mode 1 = the data-gradient operand, C rows of [T reversed][K] (the flipped,
  * transposed filter).  w_scale has one entry per output row; the row's inner channel count (C resp. K) must be a multiple of 32. */
 int dlip_split_weights_perm_f32(const float* w_kct, float* w_split, float* w_scale, int32_t K, int32_t C, int32_t T, int32_t mode,
-                                dlip_stream_t stream);
+                                int32_t C_pad, dlip_stream_t stream);
+/* C_pad (mode 0; 0 = C): the rows are [T][C_pad] with zeros for c >= C -- a first layer whose input has 24 feature channels reads
+ * its activations padded to 32 (tdnn.py:52-62 on conf/audio_config.yaml's input_dim). */
 /* y[0:n] = src[0] (device scalar broadcast: the per-channel 1/scale vector of the weight-gradient GEMM). */
 int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream_t stream);
 

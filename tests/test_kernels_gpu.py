@@ -971,9 +971,19 @@ def test_split_weights_perm_equals_permute_then_split(ops, K, C, T):
         a, sa = torch.empty((rows, T * inner), device="cuda"), torch.empty((rows,), device="cuda")
         b, sb = torch.empty_like(a), torch.empty_like(sa)
         check(lib().dlip_split_weights_rows_f32(ptr(perm), ptr(a), ptr(sa), rows, T * inner, stream_handle()), "dlip_split_weights_rows_f32")
-        check(lib().dlip_split_weights_perm_f32(ptr(w), ptr(b), ptr(sb), K, C, T, mode, stream_handle()), "dlip_split_weights_perm_f32")
+        check(lib().dlip_split_weights_perm_f32(ptr(w), ptr(b), ptr(sb), K, C, T, mode, 0, stream_handle()), "dlip_split_weights_perm_f32")
         torch.cuda.synchronize()
         assert torch.equal(sa, sb) and torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # mode 0 with the channels zero-padded to the next 32 (a 24-feature first layer)
+    Cs = C - 8
+    w2 = w[:, :Cs].contiguous()
+    perm = torch.zeros((K, T, C), device="cuda"); perm[:, :, :Cs] = w2.permute(0, 2, 1)
+    a, sa = torch.empty((K, T * C), device="cuda"), torch.empty((K,), device="cuda")
+    b, sb = torch.empty_like(a), torch.empty_like(sa)
+    check(lib().dlip_split_weights_rows_f32(ptr(perm), ptr(a), ptr(sa), K, T * C, stream_handle()), "dlip_split_weights_rows_f32")
+    check(lib().dlip_split_weights_perm_f32(ptr(w2), ptr(b), ptr(sb), K, Cs, T, 0, C, stream_handle()), "dlip_split_weights_perm_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(sa, sb) and torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
 @pytest.mark.parametrize("N,H,W,C", [(5, 44, 44, 64), (3, 9, 7, 8), (2, 1, 5, 4)])
