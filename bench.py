@@ -129,10 +129,10 @@ SINGLE_STREAM = False
 
 
 def kernel_source_sha():
-    """sha256 (16 hex digits) of the dominant kernel's source: what profiles/traffic_latest.json is stamped with."""
-    import hashlib
-    with open(os.path.join(ROOT, "deeplip_amd", "csrc", "conv_igemm_f16x3_dma.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    """sha256 (16 hex digits) over the sources the dominant kernel is compiled from (its .hip file and the headers it includes):
+    what profiles/traffic_latest.json is stamped with."""
+    from deeplip_amd import build
+    return build.dominant_kernel_sha()
 
 
 def local_step(video, audio, xv, xa, sequential=False):
@@ -663,14 +663,14 @@ def main():
         ops.LAUNCH_HOOK = None
         # HBM traffic per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot be collected from
         # inside this process, so it comes from the committed PMC passes of this same command (tools/collect_profiles.sh
-        # -> profiles/traffic_latest.json) -- and only if that file was produced by THIS kernel source (sha of
-        # conv_igemm_f16x3_dma.hip + library ABI stamped into it); otherwise null rather than a stale number.
+        # -> profiles/traffic_latest.json) -- and only if that file was produced by THIS kernel source (sha over
+        # conv_igemm_f16x3_dma.hip and the headers it includes, stamped into it); otherwise null rather than a stale number.
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
             meta = tr.get("_meta", {})
             key = roof.get("kernel", "")
-            if meta.get("kernel_sha") != kernel_source_sha() or meta.get("abi") != _lib.ABI_VERSION:
-                roof["traffic_source"] = "profiles/traffic_latest.json is from another kernel build (sha / ABI mismatch): ignored"
+            if meta.get("kernel_sha") != kernel_source_sha():
+                roof["traffic_source"] = "profiles/traffic_latest.json is from another build of the kernel (source sha mismatch): ignored"
             elif key in tr and "hbm_read_bytes_per_launch" in tr[key]:
                 roof["traffic"] = round(tr[key]["hbm_read_bytes_per_launch"] + tr[key]["hbm_write_bytes_per_launch"])
                 roof["traffic_source"] = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per "

@@ -129,3 +129,18 @@ def prove_compile(source: str = "capi.hip", verbose: bool = True) -> float:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, lab="--lab" in sys.argv))
+
+
+# What profiles/traffic_latest.json (PMC bytes per launch of the dominant kernel) is stamped with, and what bench.py compares the
+# stamp to: the sources the dominant kernel's translation unit is compiled from.  Entry points added elsewhere (an ABI bump) do not
+# change that kernel; an edit of a header it includes does.
+DOMINANT_KERNEL_SOURCES = ("conv_igemm_f16x3_dma.hip", "conv_dma_common.h", "conv_common.h", "dlip_common.h")
+
+
+def dominant_kernel_sha() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for name in DOMINANT_KERNEL_SOURCES:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]

@@ -58,9 +58,11 @@ def main():
     # stamp: which kernel build these counters belong to (bench.py ignores the file on a mismatch)
     import hashlib, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = os.path.join(root, "deeplip_amd", "csrc", "conv_igemm_f16x3_dma.hip")
+    import sys
+    sys.path.insert(0, root)
+    from deeplip_amd import build
     abi = int(re.search(r"#define DLIP_ABI_VERSION (\d+)", open(os.path.join(root, "include", "deeplip_hip.h")).read()).group(1))
-    res["_meta"] = {"kernel_sha": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16], "abi": abi, "steps": steps}
+    res["_meta"] = {"kernel_sha": build.dominant_kernel_sha(), "kernel_sources": list(build.DOMINANT_KERNEL_SOURCES), "abi": abi, "steps": steps}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
 
