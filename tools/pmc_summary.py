@@ -58,7 +58,6 @@ def main():
     # stamp: which kernel build these counters belong to (bench.py ignores the file on a mismatch)
     import hashlib, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import sys
     sys.path.insert(0, root)
     from deeplip_amd import build
     abi = int(re.search(r"#define DLIP_ABI_VERSION (\d+)", open(os.path.join(root, "include", "deeplip_hip.h")).read()).group(1))
