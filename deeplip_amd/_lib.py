@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 38
+ABI_VERSION = 39
 LIFT_WORDS = 4098
 LIFT_BCAST = 2048
 
@@ -73,6 +73,7 @@ SIGNATURES = {
     "dlip_tap_gather_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_upsample_zero_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_prelu_rows_fwd_f32": [c_f, c_f, c_f, c_i64, c_i32, c_stream],
+    "dlip_add_prelu_rows_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_prelu_rows_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_maxpool3x3s2_bwd_f32": [c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_stream],
     "dlip_maxpool3x3s2_idx_f32": [c_f, c_f, C.c_void_p, c_i64, c_i32, c_i32, c_i32, c_stream],

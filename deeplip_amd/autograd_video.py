@@ -481,6 +481,34 @@ class BNPReLUFn(Function):
         return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None
 
 
+class AddPReLUFn(Function):
+    """prelu(a + b) with per-channel slopes in one launch (the end of a residual block); the sum is kept for the backward, which is
+    PReLU's (the same gradient flows to a and to b)."""
+
+    @staticmethod
+    def forward(ctx, a, b, slope):
+        a, b = a.contiguous(), b.contiguous()
+        C_ = a.shape[-1]
+        M = a.numel() // C_
+        s_ = torch.empty_like(a)
+        y = torch.empty_like(a)
+        check(lib().dlip_add_prelu_rows_fwd_f32(ptr(a), ptr(b), ptr(slope), ptr(s_), ptr(y), M, C_, stream_handle()), "dlip_add_prelu_rows_fwd_f32")
+        ctx.save_for_backward(s_, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s_, slope = ctx.saved_tensors
+        dy = dy.contiguous()
+        C_ = s_.shape[-1]
+        M = s_.numel() // C_
+        dx = torch.empty_like(s_)
+        terms = torch.empty_like(s_)
+        check(lib().dlip_prelu_rows_bwd_f32(ptr(dy), ptr(s_), ptr(slope), ptr(dx), ptr(terms), M, C_, stream_handle()), "dlip_prelu_rows_bwd_f32")
+        dslope = _colsum_rows(terms.view(M, C_)) if ctx.needs_input_grad[2] else None
+        return dx, dx, dslope
+
+
 class MaxPoolFn(Function):
     """MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on [(B T),H,W,C] (model.py:85).  The forward records each maximum's tap as one byte, the
     backward reads those instead of re-scanning the windows of x (and x itself is not kept alive for it)."""
@@ -610,6 +638,19 @@ def prelu(x, act):
     elif w.numel() == 1:
         w = w.expand(C_)
     return PReLUFn.apply(x, w.contiguous() if not w.is_contiguous() else w)
+
+
+def add_prelu(a, b, act):
+    """prelu(a + b); act as in prelu()."""
+    w = getattr(act, "weight", None)
+    C_ = a.shape[-1]
+    if w is None:
+        w = const_vec(C_, 0.0, a.device)
+    elif w.numel() == 1:
+        w = w.expand(C_)
+    if a.shape != b.shape:
+        return prelu(a + b, act)
+    return AddPReLUFn.apply(a, b, w.contiguous() if not w.is_contiguous() else w)
 
 
 def maxpool(x):

@@ -188,6 +188,24 @@ __global__ __launch_bounds__(256) void prelu_fwd_kernel(const f32x4* __restrict_
   }
 }
 
+// The end of a residual block in one pass: s = a + b (kept: the backward needs the pre-activation), y = prelu(s)
+// (resnet.py:66-68 `out += residual; out = relu2(out)`; tcn.py:114 `relu_final(out + res)`).
+__global__ __launch_bounds__(256) void add_prelu_fwd_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, const float* __restrict__ slope,
+                                                            f32x4* __restrict__ s_out, f32x4* __restrict__ y, int C4, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const f32x4 u = a[i], v = b[i];
+    f32x4 sv, o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sv[k] = u[k] + v[k];
+      o[k] = sv[k] >= 0.f ? sv[k] : sv[k] * slope[c + k];
+    }
+    s_out[i] = sv;
+    y[i] = o;
+  }
+}
+
 // dx = dy * (x >= 0 ? 1 : slope);  t = (x >= 0 ? 0 : dy * x)  (column sums of t = the slope gradient)
 __global__ __launch_bounds__(256) void prelu_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
                                                         const float* __restrict__ slope, f32x4* __restrict__ dx,
@@ -516,6 +534,15 @@ extern "C" int dlip_prelu_rows_bwd_f32(const float* dy, const float* x, const fl
   hipLaunchKernelGGL(prelu_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), reinterpret_cast<const f32x4*>(dy),
                      reinterpret_cast<const f32x4*>(x), slope, reinterpret_cast<f32x4*>(dx), reinterpret_cast<f32x4*>(dslope_terms),
                      C / 4, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_add_prelu_rows_fwd_f32(const float* a, const float* b, const float* slope, float* sum, float* y, int64_t M, int32_t C,
+                                           dlip_stream_t stream) {
+  DLIP_CHECK_ARG(a && b && slope && sum && y && M > 0 && C > 0 && (C & 3) == 0);
+  const long long n4 = (long long)M * (C / 4);
+  hipLaunchKernelGGL(add_prelu_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, ST(stream), reinterpret_cast<const f32x4*>(a),
+                     reinterpret_cast<const f32x4*>(b), slope, reinterpret_cast<f32x4*>(sum), reinterpret_cast<f32x4*>(y), C / 4, n4);
   return dlip_launch_status();
 }
 

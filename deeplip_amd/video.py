@@ -143,7 +143,7 @@ def _basic_block_train(b: "BasicBlock", x: Tensor) -> Tensor:
     h = av.batchnorm(av.conv(h, b.conv2.weight, None, pad=(1, 1)), b.bn2)
     if side is not None:
         main.wait_stream(side)
-    return av.prelu(h + res, b.relu2)
+    return av.add_prelu(h, res, b.relu2)
 
 
 class ResNet(nn.Module):
@@ -361,7 +361,7 @@ def _tcn_block_train(b: "MultibranchTemporalBlock", x: Tensor, p_drop: float) ->
     if b.downsample is None:
         raise NotImplementedError("identity-residual multibranch block never occurs (tcn.py:87)")
     res = av.conv(x.reshape(B, 1, T, x.shape[2]), b.downsample.weight, b.downsample.bias).view(B, T, b.n_outputs)
-    return av.prelu(cur + res, b.relu_final)
+    return av.add_prelu(cur, res, b.relu_final)
 
 
 class MultibranchTemporalConvNet(nn.Module):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 38
+#define DLIP_ABI_VERSION 39
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -536,6 +536,10 @@ int dlip_prelu_rows_fwd_f32(const float* x, const float* slope, float* y, int64_
  * the slope gradient. */
 int dlip_prelu_rows_bwd_f32(const float* dy, const float* x, const float* slope, float* dx, float* dslope_terms,
                             int64_t M, int32_t C, dlip_stream_t stream);
+/* The end of a residual block in one pass (resnet.py:66-68, tcn.py:114): sum = a + b (the pre-activation dlip_prelu_rows_bwd_f32
+ * needs), y = prelu(sum) with per-channel slopes; a, b, sum, y [M,C]. */
+int dlip_add_prelu_rows_fwd_f32(const float* a, const float* b, const float* slope, float* sum, float* y, int64_t M, int32_t C,
+                                dlip_stream_t stream);
 /* MaxPool3d((1,3,3),(1,2,2),(0,1,1)) backward (model.py:85): x [N,H,W,C] = the pooled tensor's input,
  * dy [N,Ho,Wo,C] -> dx; first-maximum tie rule (row-major window scan), deterministic. */
 int dlip_maxpool3x3s2_bwd_f32(const float* x, const float* dy, float* dx, int64_t N, int32_t H, int32_t W, int32_t C,

@@ -300,6 +300,24 @@ def test_lipreading_train_mode_with_dropout_and_eval_roundtrip():
     assert out.shape == (4, 54) and bool(torch.isfinite(out).all())
 
 
+def test_add_prelu_vs_torch():
+    """AddPReLUFn (the end of a residual block in one launch) == F.prelu(a + b) under torch autograd (fp64)."""
+    from deeplip_amd import autograd_video as av
+    from deeplip_amd.holders import PReLUParams
+    a, b = rnd(5, 6, 7, 64, seed=80).requires_grad_(), rnd(5, 6, 7, 64, seed=81).requires_grad_()
+    sl = (torch.rand(64, generator=torch.Generator().manual_seed(82)) * 0.5 - 0.05).requires_grad_()
+    dy = rnd(5, 6, 7, 64, seed=83)
+    ref = F.prelu((a.double() + b.double()).permute(0, 3, 1, 2), sl.double()).permute(0, 2, 3, 1)
+    ref.backward(dy.double())
+    ag_, bg, sg = (t.detach().to(DEV).requires_grad_() for t in (a, b, sl))
+    y = av.AddPReLUFn.apply(ag_, bg, sg)
+    y.backward(dy.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 1e-6
+    assert rel_err(ag_.grad.cpu().numpy(), a.grad.numpy()) < 1e-6 and torch.equal(ag_.grad, bg.grad)
+    assert rel_err(sg.grad.cpu().numpy(), sl.grad.numpy()) < 1e-5
+
+
 def test_chomp_concat_vs_torch_slice_and_cat():
     """ChompConcatFn (one strided row copy per branch, forward and backward) == slice + cat under torch autograd, bit for bit."""
     from deeplip_amd import autograd_video as av
