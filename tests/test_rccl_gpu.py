@@ -75,3 +75,12 @@ def test_train_fusion_dp_on_rccl_one_rank(tmp_path):
     text = "".join(lines)
     assert rc == 0, text[-2000:]
     assert "EER" in text
+
+
+def test_train_video_dp_on_rccl_one_rank(tmp_path):
+    """`train_video.py` (full lip-clip model training) as a one-rank job: parameters broadcast, gradients in flat buckets whose
+    all-reduces start from autograd hooks while the backward still runs (deeplip_amd.dist.GradBuckets on RCCL's stream)."""
+    rc, js, lines = _run("train_video.py", ["--save-path", str(tmp_path / "ck"), "--steps", "2", "--frames", "9"])
+    text = "".join(lines)
+    assert rc == 0, text[-2000:]
+    assert "done:" in text and os.path.exists(tmp_path / "ck" / "1.pt")
