@@ -84,3 +84,12 @@ def test_train_video_dp_on_rccl_one_rank(tmp_path):
     text = "".join(lines)
     assert rc == 0, text[-2000:]
     assert "done:" in text and os.path.exists(tmp_path / "ck" / "1.pt")
+
+
+def test_train_video_dp_recorded_step_on_rccl_one_rank(tmp_path):
+    """The same with --graph-step: the bucket all-reduces are RCCL collectives captured INTO the recorded step graph (launched from
+    autograd hooks during the captured backward) and replayed with it."""
+    rc, js, lines = _run("train_video.py", ["--save-path", str(tmp_path / "ck"), "--steps", "4", "--frames", "9", "--graph-step"])
+    text = "".join(lines)
+    assert rc == 0, text[-3000:]
+    assert text.count("(replayed)") == 3 and "done:" in text

@@ -139,7 +139,9 @@ def train(model, args, device):
     params = [p for p in model.parameters() if p.requires_grad]
     # DP: gradients live in flat buckets whose all-reduces (RCCL) start while backward is still running
     buckets = ddist.GradBuckets(params) if (ddist.active() and device.type != "cpu") else None
-    graph_step = bool(getattr(args, "graph_step", False)) and full and buckets is None
+    # (with GradBuckets the recorded step contains the bucket all-reduces -- RCCL collectives captured into the graph: exercised at one
+    # rank by tests/test_rccl_gpu.py; DLIP_GRAPH_WITH_BUCKETS=0 keeps data-parallel runs on the eager loop)
+    graph_step = bool(getattr(args, "graph_step", False)) and full and (buckets is None or os.environ.get("DLIP_GRAPH_WITH_BUCKETS", "1") != "0")
     if graph_step:      # a recorded step reads its learning rate from a device tensor (the scheduler updates it in place)
         optimizer = torch.optim.Adam(params, lr=torch.tensor(float(args.lr), device=device), weight_decay=1e-4, capturable=True, fused=True)
     else:
@@ -155,10 +157,15 @@ def train(model, args, device):
         from deeplip_amd.train_plan import TrainStepGraph
 
         def one_step(xb, lb, ln):
-            optimizer.zero_grad(set_to_none=True)
+            if buckets is None:
+                optimizer.zero_grad(set_to_none=True)
+            else:
+                buckets.zero()                       # the gradients are views into the buckets: cleared in place
             lg = model(xb, lengths=ln)
             ls = ag.margin_ce_loss(lg, lb, 1.0, 0.0)
-            ls.backward()
+            ls.backward()                            # bucket all-reduces start from the hooks as the gradients land
+            if buckets is not None:
+                buckets.finish()
             optimizer.step()
             return ls, lg
 
