@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 39
+ABI_VERSION = 40
 LIFT_WORDS = 4098
 LIFT_BCAST = 2048
 
@@ -61,6 +61,7 @@ SIGNATURES = {
     "dlip_permute3_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_pow2_lift_f32": [c_f, c_f, c_i64, C.c_float, c_stream],
     "dlip_pow2_scale_f32": [c_f, c_f, c_i64, C.c_float, c_stream],
+    "dlip_split_pack_scaled_pad_f32": [c_f, c_f, c_f, c_i64, c_i32, c_i32, c_stream],
     "dlip_split_pack_scaled_f32": [c_f, c_f, c_f, c_i64, c_i32, c_stream],
     "dlip_split_weights_rows_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_split_weights_perm_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],

@@ -36,16 +36,10 @@ class LinearFn(Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         M, Cin = x.shape
-        # Batch-level layers (fc1 / fc2 / the classifier: M = the batch, a long reduction) go to the small-GEMM kernel: on the
-        # convolution kernel a [256 x 3000] x [3000 x 512] product is 16 tiles walking 94 slices each -- 1.0 ms of a 15 ms
-        # speech-encoder training step -- while the backward already ran its two products here in 40 us each.
-        if Cin % 4 == 0 and M > 1024:
+        if Cin % 4 == 0:
             return ops.linear(x, w, b.contiguous() if b is not None else None)
         y = _gemm(x, w, M, w.shape[0], Cin, tb=True)
-        if b is None:
-            return y
-        from .autograd_video import const_vec
-        return ops.affine_act(y, const_vec(w.shape[0], 1.0, x.device), b.contiguous(), slope=1.0)
+        return y + b if b is not None else y
 
     @staticmethod
     def backward(ctx, dy):

@@ -123,6 +123,21 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
         padded = (not transposed) and Cw < Cx and (Cw + 31) // 32 * 32 == Cx     # x carries zero channels up to the next 32 (a 24-feature input)
         if padded and TRAIN_CONV == "f16x3" and K % 4 == 0:
             Cw = Cx
+        # a lifted gradient whose channel count is a multiple of 4 but not of 32 (1500): split with its rows zero-padded to the next 32
+        pad_x = Cx
+        if transposed and lift and TRAIN_CONV == "f16x3" and Cx % 32 and Cx % 4 == 0 and K % 4 == 0 and Cw == Cx and xs_ready is None:
+            pad_x = (Cx + 31) // 32 * 32
+            dev = x.device
+            if scale2 is None:
+                scale2 = pow2_lift(x)
+            ws = torch.empty((K, R_, S_, pad_x), device=dev, dtype=torch.float32)
+            wsc = torch.empty((K,), device=dev, dtype=torch.float32)
+            check(lib().dlip_split_weights_perm_f32(ptr(w_ref.contiguous()), ptr(ws), ptr(wsc), Ko, Ci, R_ * S_, 1, pad_x, stream_handle()),
+                  "dlip_split_weights_perm_f32")
+            xs = torch.empty((N, H, W, pad_x), device=dev, dtype=torch.float32)
+            check(lib().dlip_split_pack_scaled_pad_f32(ptr(x), ptr(xs), ptr(scale2), N * H * W, Cx, pad_x, stream_handle()), "dlip_split_pack_scaled_pad_f32")
+            return ops.conv_nhwc(xs, ws, None, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True, post_scale=lift_inv(scale2, K),
+                                 post_shift=const_vec(K, 0.0, dev))
         if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or Cw != Cx:
             w3 = w_ref.contiguous().view(Ko, Ci, R_ * S_)
             w_krsc = (_permute3(w3, (1, 2, 0), flip_axis=2).view(Ci, R_, S_, Ko) if transposed else _permute3(w3, (0, 2, 1)).view(Ko, R_, S_, Ci))
@@ -130,8 +145,8 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
         dev = x.device
         ws = torch.empty((K, R_, S_, Cw), device=dev, dtype=torch.float32)
         wsc = torch.empty((K,), device=dev, dtype=torch.float32)
-        check(lib().dlip_split_weights_perm_f32(ptr(w_ref.contiguous()), ptr(ws), ptr(wsc), Ko, Ci, R_ * S_, 1 if transposed else 0,
-                                                Cw if not transposed else 0, stream_handle()), "dlip_split_weights_perm_f32")
+        check(lib().dlip_split_weights_perm_f32(ptr(w_ref.contiguous()), ptr(ws), ptr(wsc), Ko, Ci, R_ * S_, 1 if transposed else 0, Cw,
+                                                stream_handle()), "dlip_split_weights_perm_f32")
     else:
         K = w_krsc.shape[0]
         if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or w_krsc.shape[3] != Cx:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 39
+#define DLIP_ABI_VERSION 40
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -448,6 +448,9 @@ int dlip_pow2_lift_f32(const float* x, float* lift, int64_t n, float target, dli
 /* dlip_split_pack_f32 of x * scale[0] (device scalar). */
 int dlip_split_pack_scaled_f32(const float* x, float* y, const float* scale, int64_t rows, int32_t C,
                                dlip_stream_t stream);
+/* The same with each row zero-padded from C (a multiple of 4) to C_pad (a multiple of 32) channels: y [rows, C_pad]. */
+int dlip_split_pack_scaled_pad_f32(const float* x, float* y, const float* scale, int64_t rows, int32_t C, int32_t C_pad,
+                                   dlip_stream_t stream);
 /* Split-fp16 operand image of a weight matrix on the device (what deeplip_amd.packing.split_weights builds on the host at load
  * time; a training step needs it from the CURRENT weights): w [K rows][L], L % 32 == 0 with every 32-channel block intact ->
  * w_split [K][L] (per block 32 hi halves | 32 lo halves of w * w_scale[k]), w_scale[k] = 2^floor(log2(1023 / max|w[k,:]|))
@@ -458,8 +461,9 @@ int dlip_split_weights_rows_f32(const float* w, float* w_split, float* w_scale, 
  * transposed filter).  w_scale has one entry per output row; the row's inner channel count (C resp. K) must be a multiple of 32. */
 int dlip_split_weights_perm_f32(const float* w_kct, float* w_split, float* w_scale, int32_t K, int32_t C, int32_t T, int32_t mode,
                                 int32_t C_pad, dlip_stream_t stream);
-/* C_pad (mode 0; 0 = C): the rows are [T][C_pad] with zeros for c >= C -- a first layer whose input has 24 feature channels reads
- * its activations padded to 32 (tdnn.py:52-62 on conf/audio_config.yaml's input_dim). */
+/* C_pad (0 = none): the rows' inner channel count (C in mode 0, K in mode 1) zero-padded to C_pad -- a first layer whose input has
+ * 24 feature channels reads its activations padded to 32; the data gradient of a 1500-channel layer reads its gradient padded
+ * to 1504 (tdnn.py:52-62 on conf/audio_config.yaml's input_dim / hidden_dim). */
 /* y[0:n] = src[0] (device scalar broadcast: the per-channel 1/scale vector of the weight-gradient GEMM). */
 int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream_t stream);
 
