@@ -78,7 +78,13 @@ class TrainStepGraph:
                         d.copy_(s, non_blocking=True)
                     self.stream.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self.stream):
+                    # Inside a torch.distributed job the process group's watchdog THREAD polls the events of earlier collectives;
+                    # under the default ("global") capture mode such a call from another thread aborts the capture ("operation not
+                    # permitted when stream is capturing" -- seen in one run of two).  "thread_local" confines the check to this
+                    # thread; the launches of the autograd worker threads are captured either way (they go to the capturing stream).
+                    import torch.distributed as _dist
+                    mode = "thread_local" if (_dist.is_available() and _dist.is_initialized()) else "global"
+                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
                         self.outputs = self.fn(*self.static)
                     self.graph = g
                 else:
