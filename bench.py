@@ -240,8 +240,10 @@ def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan):
     plan replay over inputs resident in HBM, HIP-event timed; failures are recorded, never fatal to the headline.
       C2 video-only clip embed [B,1,29,88,88]; C3 speech-encoder embed [256,1,F,300] (configs[2]);
       C4 fused extraction of a 256-utterance test list + 20 000 cosine trials shaped like trial_grid_v1.txt + EER;
-      C5 one rank's DP training step of the fusion head (frozen encoders, bs 60): where its time goes."""
-    from deeplip_amd import fusion, ops, scoring, weightgen as wg
+      C5 one rank's DP training step of the fusion head (frozen encoders, bs 60): where its time goes;
+      F2 (not a BASELINE configuration): one optimisation step of the FULL lip-clip model (B = 32, replayed
+      HIP graph) and of the full speech encoder (B = 256) -- the trainers' throughput where the driver measures it."""
+    from deeplip_amd import _lib, fusion, ops, scoring, weightgen as wg
     from deeplip_amd.synthetic import SyntheticAVSet, synthetic_trials
     out = {}
     sync = torch.cuda.synchronize
@@ -367,10 +369,95 @@ def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan):
                                                                    "head_backward": round(b, 4), "optimizer": round(o, 4)},
                 "loss": round(float(loss.detach()), 4)}
 
+    def f2_video():
+        """one optimisation step of the FULL lip-clip model (ResNet-18 + MS-TCN, Adam) at the reference's shapes,
+        B = 32 clips x 29 frames, recorded once and replayed as one HIP graph (deeplip_amd.train_plan)."""
+        import gc
+        from deeplip_amd import autograd as ag
+        from deeplip_amd.train_plan import TrainStepGraph
+        from models.video_models.model import Lipreading
+        Bt = 32
+        tcn = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
+        net = Lipreading(num_classes=54, relu_type="prelu", tcn_options=tcn, extract_feats=False)
+        sdv = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="video.")
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sdv.items()})
+        net.to(device).train()
+        opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(3e-4, device=device), weight_decay=1e-4, capturable=True, fused=True)
+        xb = torch.from_numpy(wg.video_input(Bt, frames=29, key="bench.vtrain")).to(device)
+        lb = torch.from_numpy(wg.labels(Bt, 54)).to(device)
+        ln = torch.full((Bt,), 29, dtype=torch.int32, device=device)
+
+        def one(x_, l_, n_):
+            opt.zero_grad(set_to_none=True)
+            ls = ag.margin_ce_loss(net(x_, lengths=n_), l_)
+            ls.backward()
+            opt.step()
+            return ls
+
+        plan = TrainStepGraph(one, eager_steps=1, device=device)
+        for _ in range(3):
+            plan.step(xb, lb, ln)
+        plan.finish()
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ls = plan.step(xb, lb, ln)
+        plan.finish()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        res = {"workload": f"full Lipreading training step (forward + backward + Adam), {Bt} clips x 29 frames, replayed HIP graph",
+               "clips_per_s": round(1e3 * Bt / ms, 1), "ms_per_step": round(ms, 3), "loss": round(float(ls.detach()), 4),
+               "tflops_at_3x_forward": round(3 * 20.567 * Bt / ms, 1)}
+        del plan, net, opt
+        gc.collect(); torch.cuda.empty_cache()
+        return res
+
+    def f2_audio():
+        """one optimisation step of the full speech encoder (E-TDNN, LMCL, SGD), B = 256 x 300 frames."""
+        import gc
+        from models.audio_models.loss import LMCL
+        from models.audio_models.tdnn import SpeakerEmbNet
+        Bt = 256
+        ctx = [[-2, -1, 0, 1, 2], [0], [-2, 0, 2], [0], [-3, 0, 3], [0], [-4, 0, 4], [0], [0], [0]]
+        et = {"input_dim": 24, "hidden_dim": [512] * 9 + [1500], "context": ctx, "tdnn_layers": 10, "embedding_dim": 512,
+              "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+        net = SpeakerEmbNet({"arch": "etdnn", "etdnn": et})
+        sda = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="audio.")
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sda.items()})
+        net.to(device).train()
+        crit = LMCL(512, 57, 30, 0.2).to(device)
+        opt = torch.optim.SGD([{"params": net.parameters()}, {"params": crit.parameters()}], 0.01, momentum=0.9, weight_decay=1e-5)
+        xb = torch.from_numpy(wg.audio_input(Bt, 24, 300, key="bench.atrain")).to(device)
+        lb = torch.from_numpy(wg.labels(Bt, 57)).to(device)
+
+        def one():
+            opt.zero_grad()
+            ls, _ = crit(net(xb), lb)
+            ls.backward()
+            opt.step()
+            return ls
+
+        for _ in range(2):
+            one()
+        sync()
+        n = 8
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ls = one()
+        sync()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        _lib.check_range(sync=True)
+        res = {"workload": f"full E-TDNN training step (forward + backward + SGD, LMCL), {Bt} utterances x 300 frames x 24 features",
+               "utt_per_s": round(1e3 * Bt / ms, 1), "ms_per_step": round(ms, 3), "loss": round(float(ls.detach()), 4)}
+        del net, opt, crit
+        gc.collect(); torch.cuda.empty_cache()
+        return res
+
     guarded("C2_video_embed", c2)
     guarded("C3_audio_embed", c3)
     guarded("C4_fusion_scoring", c4)
     guarded("C5_fusion_train_step", c5)
+    guarded("F2_train_video_step", f2_video)
+    guarded("F2_train_audio_step", f2_audio)
     return out
 
 
