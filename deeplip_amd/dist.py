@@ -140,6 +140,10 @@ class GradBuckets:
     a few hundred microseconds each (default 32 MB ~ 0.5 ms at 8 ranks) -- large enough to be bandwidth- rather than
     latency-bound, small enough that the last one does not stick out behind backward.
 
+    Stream rule: a bucket's all-reduce waits for the stream that is current when its last gradient lands.  Gradients written on
+    OTHER streams (deeplip_amd.video.BRANCH_STREAMS: forked branches of the train graph) are not covered -- keep the branches on
+    one stream with GradBuckets (train_video.py does).
+
     One difference from a single-GPU run to know about: a parameter that NO rank's batch reached keeps an all-zero gradient here
     (its ``.grad`` is a bucket view, never None), so an optimizer with momentum or weight decay still updates it, where the
     single-process run -- ``.grad is None`` -- skips it.  The shipped models touch every trainable parameter in every step, so

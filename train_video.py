@@ -169,7 +169,9 @@ def train(model, args, device):
             optimizer.step()
             return ls, lg
 
-        plan = TrainStepGraph(one_step, eager_steps=1, device=device)
+        # (with GradBuckets the branches stay on one stream: a bucket's all-reduce is enqueued behind the CURRENT stream of the hook
+        # that completes it, and would not wait for gradients another branch stream is still writing)
+        plan = TrainStepGraph(one_step, eager_steps=1, device=device, branch_streams=buckets is None)
     for epoch in range(int(args.maxepoch)):
         run_loss = run_ok = run_n = 0.0
         model.train() if full else model.eval()                                                # (:129)
