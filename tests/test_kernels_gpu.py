@@ -1018,3 +1018,17 @@ def test_pow2_lift_buffer(ops):
         assert torch.equal(lift[:2], pair) and bool((lift[2:2 + _lib.LIFT_BCAST] == pair[1]).all())
         m = float(x.abs().max()) * float(pair[0])
         assert 512.0 <= m <= 1024.0
+
+
+def test_split_pack_scaled_with_padded_rows(ops):
+    """dlip_split_pack_scaled_pad_f32 ([rows, 1500] -> [rows, 1504], zero columns) == pad, then dlip_split_pack_scaled_f32."""
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    rows, C, Cp = 77, 1500, 1504
+    x = (rnd(rows, C, seed=91) * 1e-3).cuda()
+    sc = torch.tensor([2048.0, 1.0 / 2048.0]).cuda()
+    xp = torch.zeros((rows, Cp), device="cuda"); xp[:, :C] = x
+    a, b = torch.empty((rows, Cp), device="cuda"), torch.full((rows, Cp), 9.0, device="cuda")
+    check(lib().dlip_split_pack_scaled_f32(ptr(xp), ptr(a), ptr(sc), rows, Cp, stream_handle()), "dlip_split_pack_scaled_f32")
+    check(lib().dlip_split_pack_scaled_pad_f32(ptr(x), ptr(b), ptr(sc), rows, C, Cp, stream_handle()), "dlip_split_pack_scaled_pad_f32")
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
