@@ -272,8 +272,7 @@ def check_range(sync: bool = False) -> None:
 _SCOPE_SLOTS = 128           # launches per scope (a B = 64 fused step makes ~40)
 _EVID_WORDS = 1024           # int32 words of evidence per launch (32 cache lines: DLIP_EVID_WORDS)
 _RING_CHUNKS = 16
-_ring = None
-_ring_next = 0
+_rings = {}                  # (device index, stream handle) -> [ring tensor, next chunk]
 _scope_depth = threading.local()
 
 
@@ -285,31 +284,35 @@ def scope_slots(device=None):
 class range_scope:
     """``with range_scope():`` around the launches of one forward pass; the verdict kernel goes out on the current stream at
     exit (join side streams first).  Nested scopes fold into the outermost one of the thread.  Eager scopes draw their words from
-    a ring of chunks (a scope's verdict re-zeroes its chunk, so a chunk is clean again long before the ring comes round); a
-    StepPlan passes its own block, which the recorded launches then address for the plan's lifetime."""
+    a ring of chunks OF THE STREAM THEY OPEN ON (a scope's verdict kernel re-zeroes its chunk on that stream, and the next user of
+    the chunk launches on the same stream: in order, so a chunk is clean before it is written again -- one ring shared by all
+    streams had no such order between, say, an ExtractPipeline's run stream and the caller's); a StepPlan passes its own block,
+    which the recorded launches then address for the plan's lifetime."""
 
     def __init__(self, slots=None):
         self.slots = slots
         self.outer = False
 
     def __enter__(self):
-        global _ring, _ring_next
         d = getattr(_scope_depth, "n", 0)
-        _scope_depth.n = d + 1
         self.outer = d == 0
         if not self.outer:
+            _scope_depth.n = d + 1
             return self
         if _status is None:
             status_words()
         slots = self.slots
         if slots is None:
+            key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
             with _lock:
-                if _ring is None or _ring.device.index != torch.cuda.current_device():
-                    _ring = torch.zeros(_RING_CHUNKS * _EVID_WORDS * _SCOPE_SLOTS, dtype=torch.int32, device="cuda")
-                    _ring_next = 0
-                slots = _ring[_ring_next * _EVID_WORDS * _SCOPE_SLOTS:(_ring_next + 1) * _EVID_WORDS * _SCOPE_SLOTS]
-                _ring_next = (_ring_next + 1) % _RING_CHUNKS
+                ring = _rings.get(key)
+                if ring is None:
+                    # zeroed on the current stream = the stream of every later user of this ring
+                    ring = _rings[key] = [torch.zeros(_RING_CHUNKS * _EVID_WORDS * _SCOPE_SLOTS, dtype=torch.int32, device="cuda"), 0]
+                slots = ring[0][ring[1] * _EVID_WORDS * _SCOPE_SLOTS:(ring[1] + 1) * _EVID_WORDS * _SCOPE_SLOTS]
+                ring[1] = (ring[1] + 1) % _RING_CHUNKS
         check(lib().dlip_range_scope_begin(slots.data_ptr(), min(_SCOPE_SLOTS, slots.numel() // _EVID_WORDS)), "dlip_range_scope_begin")
+        _scope_depth.n = d + 1          # only once the scope is really open: a failed begin leaves the thread's depth as it was
         return self
 
     def __exit__(self, et, ev, tb):

@@ -17,9 +17,11 @@ and so does the parent.  Nothing here imports torch: the decision is taken befor
 from __future__ import annotations
 
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 from typing import List, Optional, Sequence
 
 
@@ -39,6 +41,19 @@ def launch_command(script: str, argv: Sequence[str], nproc: int, port: Optional[
             "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), script, *argv]
 
 
+class _Terminated(BaseException):
+    def __init__(self, signum):
+        super().__init__(signum)
+        self.signum = signum
+
+
+def _kill_group(p, sig) -> None:
+    try:
+        os.killpg(p.pid, sig)          # start_new_session: the child's pid is its group id
+    except (ProcessLookupError, PermissionError):
+        pass
+
+
 def self_launch(script: str, argv: Sequence[str], nproc: int, relay=None, env=None) -> int:
     """Run ``script argv`` as an ``nproc``-rank job and return its exit code.  ``relay(line)`` receives every stdout line
     of the job (default: print it)."""
@@ -48,7 +63,17 @@ def self_launch(script: str, argv: Sequence[str], nproc: int, relay=None, env=No
     e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or nproc) // nproc)))
     e["DLIP_LAUNCHED_BY"] = str(os.getpid())
     print(f"[launch] {nproc} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=e)
+    # The job gets its own session (= process group): the launcher can then end exactly the processes it started -- the
+    # torch.distributed.run child AND its N ranks -- by group id, also when it is itself told to stop.
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=e, start_new_session=True)
+
+    def _stop(signum, _frame):
+        raise _Terminated(signum)
+
+    old = {}
+    if threading.current_thread() is threading.main_thread():        # signal.signal is main-thread only
+        for sig in (signal.SIGTERM, signal.SIGHUP):
+            old[sig] = signal.signal(sig, _stop)
     try:
         for line in p.stdout:
             if relay is None:
@@ -57,13 +82,22 @@ def self_launch(script: str, argv: Sequence[str], nproc: int, relay=None, env=No
             else:
                 relay(line)
         rc = p.wait()
-    except BaseException:
-        p.terminate()           # the exact child we started, nothing by pattern
+    except BaseException as ex:
+        # a harness timeout / scheduler preemption (SIGTERM, SIGHUP), Ctrl-C, or an error in relay(): the job must not outlive
+        # its launcher holding the GPUs.  The exact process group we started, nothing by pattern.
+        _kill_group(p, signal.SIGTERM)
         try:
             p.wait(timeout=30)
         except subprocess.TimeoutExpired:
-            p.kill()
+            _kill_group(p, signal.SIGKILL)
+            p.wait()
+        if isinstance(ex, _Terminated):
+            print(f"[launch] signal {ex.signum}: job stopped", file=sys.stderr, flush=True)
+            return 128 + ex.signum
         raise
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
     if rc != 0:
         print(f"[launch] job failed: exit code {rc}", file=sys.stderr, flush=True)
     return rc

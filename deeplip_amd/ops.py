@@ -310,8 +310,11 @@ def stem3d_pool(x_bthw: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Ten
 
 
 def center_crop_origin(size: int, crop: int) -> int:
-    """CenterCrop's offset (models/video_models/preprocess.py): int(round((size - crop) / 2.)) with Python's round."""
-    return int(round((size - crop) / 2.0))
+    """CenterCrop's offset (models/video_models/preprocess.py:89-90): ``int(round(w - tw) / 2.)`` -- the round() is of the
+    integer margin (a no-op), the division's result is truncated: FLOOR of half the margin, as dlip_crop_normalize_u8 does.
+    (Round 3 had int(round(margin / 2)), Python's round-half-even: one pixel off for margins of 3, 7, 11 ... -- 91- or
+    95-pixel frames.)"""
+    return (size - crop) // 2
 
 
 def stem3d_pool_u8(frames: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Tensor], w_scale: Tensor, crop: int = 88) -> Tensor:

@@ -59,6 +59,7 @@ class ExtractPipeline:
                 self.plans.append(StepPlan(fn, *ins, stream=self.run_stream))
         self.ready = [torch.cuda.Event() for _ in range(depth)]
         self.free = [torch.cuda.Event() for _ in range(depth)]
+        self._replayed = [False] * depth     # set k has a replay in flight (or finished) whose FREE event must be awaited before refilling it
         self.batch = int(example_inputs[0].shape[0])
         self.launches = self.plans[0].launches
         self.run_stream.synchronize()
@@ -77,7 +78,9 @@ class ExtractPipeline:
             rows = int(hb[0].shape[0])
             if rows > self.batch or len(hb) != len(ins) or any(int(h.shape[0]) > int(d.shape[0]) for h, d in zip(hb, ins)):
                 raise ValueError("ExtractPipeline: batch does not match the recorded inputs")
-            if i >= self.depth:
+            if self._replayed[k]:
+                # (Also across calls: a second run() without finish() in between refills sets the previous call's last replays may
+                # still be reading -- the copy stream is ordered behind nothing but this wait.)
                 # Bounded run-ahead: the HOST waits here until the replay that read this set has finished, so it is never more
                 # than `depth` batches ahead of the GPU.  Measured (tools/probes/h2d_timeline.py, B = 64, uint8 RGB): with the
                 # host free to enqueue all 40 batches at once the replays behind the enqueue burst take 5.2-6.2 ms instead of
@@ -96,11 +99,13 @@ class ExtractPipeline:
                 for t, o in zip(tables, outs):
                     t[row0 + n: row0 + n + rows].copy_(o[:rows], non_blocking=True)
                 self.free[k].record(self.run_stream)
+            self._replayed[k] = True
             n += rows
         return n
 
     def finish(self) -> None:
         self.run_stream.synchronize()
+        self._replayed = [False] * self.depth
         check_range(sync=False)       # an f16x3 overflow of the LAST batch surfaces here, not one call late
 
     def close(self) -> None:

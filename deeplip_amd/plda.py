@@ -69,6 +69,36 @@ class PLDA:
         relevant = order[: int((psi > 0).sum())]
         return cls(m, np.linalg.inv(A), psi, relevant, pca_mean, pca_comp)
 
+    # ---- exp/plda.pkl (train_audio.py:339-341: joblib.dump(classifier, 'exp/plda.pkl')) ----
+    def save(self, path: str) -> None:
+        """A joblib file holding a plain dict of arrays (no pickled classes: loading it executes nothing)."""
+        import os
+        import joblib
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        joblib.dump({"format": "deeplip_amd.plda/1", "m": self.m, "inv_A": self.inv_A, "psi": self.psi, "relevant": self.relevant,
+                     "pca_mean": self.pca_mean, "pca_components": self.pca_components}, path)
+
+    @classmethod
+    def load(cls, path: str) -> "PLDA":
+        """This build's file, or the reference's: there the object is a ``plda.Classifier`` (RaviSoji/plda), which joblib can
+        only rebuild where that package is installed; its fitted model's parameters are then taken over (``model.m``,
+        ``model.inv_A``, ``model.Psi`` (diagonal), ``model.relevant_U_dims``, ``model.pca``)."""
+        import joblib
+        try:
+            obj = joblib.load(path)
+        except ModuleNotFoundError as ex:
+            raise RuntimeError(f"{path} pickles a classifier of the third-party `plda` package, which is not installed here; "
+                               "re-fit with Trainer.train_plda() (writes a plain-array file) or install the package") from ex
+        if isinstance(obj, dict) and str(obj.get("format", "")).startswith("deeplip_amd.plda/"):
+            return cls(obj["m"], obj["inv_A"], obj["psi"], obj["relevant"], obj.get("pca_mean"), obj.get("pca_components"))
+        model = getattr(obj, "model", obj)
+        psi = np.asarray(model.Psi, dtype=np.float64)
+        psi = np.diag(psi) if psi.ndim == 2 else psi
+        pca = getattr(model, "pca", None)
+        return cls(np.asarray(model.m, dtype=np.float64), np.asarray(model.inv_A, dtype=np.float64), psi,
+                   np.asarray(model.relevant_U_dims), None if pca is None else np.asarray(pca.mean_, dtype=np.float64),
+                   None if pca is None else np.asarray(pca.components_, dtype=np.float64))
+
     # ---- affine map D -> U_model as (weight [Dr, D], bias [Dr]) ----
     def affine(self) -> Tuple[np.ndarray, np.ndarray]:
         Wt = self.inv_A[self.relevant]                          # u = inv_A (x - m)

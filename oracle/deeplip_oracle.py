@@ -619,6 +619,6 @@ def video_preprocess_u8(frames_u8: np.ndarray, crop: int = 88) -> np.ndarray:
     if x.ndim == 4:
         x = np.float32(0.299) * x[:, 0] + np.float32(0.587) * x[:, 1] + np.float32(0.114) * x[:, 2]
     h, w = x.shape[-2:]
-    dh, dw = int(round((h - crop) / 2.0)), int(round((w - crop) / 2.0))       # preprocess.py CenterCrop
+    dh, dw = int(round((h - crop)) / 2.), int(round((w - crop)) / 2.)         # preprocess.py:89-90 CenterCrop, verbatim: floor(margin / 2)
     x = x[:, dh:dh + crop, dw:dw + crop] / np.float32(255.0)
     return ((x - np.float32(0.421)) / np.float32(0.165)).astype(np.float32)

@@ -150,3 +150,47 @@ def test_train_audio_loads_reference_style_checkpoints(tmp_path, monkeypatch):
     # (3) this trainer's own epoch file
     tr3.load("exp/{}/net_2.pth".format(tr.log_time))
     assert tr3.current_epoch == 2
+
+
+@pytest.mark.gpu
+def test_train_audio_reference_method_names_and_av_test_flow(tmp_path, monkeypatch):
+    """The Trainer surface of train_audio.py:234-483 -- ``__call__``, ``extract_train_xv``, ``train_plda``,
+    ``extract_test_xv_lomgrid`` / ``_grid``, ``load_finetune`` -- and its ``__main__`` scoring (``utils.eer(log_time)``,
+    ``utils.eer_cos_lomgrid(log_time)``, ``utils.eer_plda_lomgrid(log_time)``: one argument, the store on disk)."""
+    import train_audio
+    from deeplip_amd import scoring_entry as se
+    from models.audio_models import utils
+    monkeypatch.chdir(tmp_path)
+    ov = {"data.test_speakers": 5, "data.test_utt_per_spk": 4, "data.trials": 200, "data.trial_targets": 40, "data.audio_frames": 120,
+          "data.n_spk": 6, "data.utt_per_spk": 3, "train.bs": 8, "train.epoch": 1}
+    tr = train_audio.Trainer(overrides=ov)
+    try:
+        tr()                                                              # :473-483
+        root = "exp/{}".format(tr.log_time)
+        assert os.path.exists(root + "/net_1.pth")
+        t = tr.extract_train_xv()                                          # :234-258: not normalised
+        assert t.emb.shape == (18, 512) and np.abs(t.emb.norm(dim=1).cpu().numpy() - 1).max() > 1e-3
+        assert np.load(root + "/train_xv/s0/s0_u0.npy").shape == (1, 512)
+        tr.extract_test_xv()
+        e, thr = utils.eer(tr.log_time)                                    # :499-503
+        assert (e, thr) == tuple(tr.eer())
+        tr.train_plda()                                                    # :298-341
+        assert os.path.exists("exp/plda.pkl") and os.path.exists(root + "/dev_xv_lomgrid/s0_u0.npy")
+        for name in ("lomgrid", "grid"):
+            tab = getattr(tr, "extract_test_xv_" + name)()                 # :375-437
+            assert np.abs(tab.emb.norm(dim=1).cpu().numpy() - 1).max() < 1e-5
+            assert np.load(root + "/test_xv_{}/s0/s0_u0.npy".format(name)).shape == (1, 512)
+            e, _ = getattr(utils, "eer_cos_" + name)(tr.log_time)
+            ep, _ = getattr(utils, "eer_plda_" + name)(tr.log_time)
+            assert 0 <= e <= 1 and 0 <= ep <= 1
+        # load_finetune (:276-296): encoder frozen, optimizer over the criterion alone
+        tr.train_opts["type"] = "sgd"
+        tr.load_finetune(root + "/net_1.pth", None)
+        assert tr.log_time == root.split("/")[1] and not any(p.requires_grad for p in tr.model.parameters())
+        assert sum(len(g["params"]) for g in tr.optim.param_groups) == len(list(tr.criterion.parameters()))
+        w0 = tr.model.tdnn[0].context_layer.weight.detach().clone(); c0 = tr.criterion.weights.detach().clone()
+        tr.current_epoch = 0
+        tr._train()
+        assert torch.equal(w0, tr.model.tdnn[0].context_layer.weight.detach()) and not torch.equal(c0, tr.criterion.weights.detach())
+    finally:
+        se._process_paths.clear()

@@ -91,6 +91,11 @@ def test_video_frontend_vs_oracle():
         assert np.abs(yr[b, 0].cpu().numpy() - O.video_preprocess_u8(rgb[b].numpy())).max() < 1e-4
     clips = [gray[0, :3].cuda(), gray[1].cuda()]
     batch, lengths = vf.collate(clips)
+    odd = torch.randint(0, 256, (1, 2, 3, 91, 95), dtype=torch.uint8, generator=g)      # margins 3 and 7: CenterCrop takes 1 and 3
+    yo = vf(odd.cuda())
+    assert np.array_equal(yo[0, 0].cpu().numpy(), O.video_preprocess_u8(odd[0].numpy()))
+    ref = ((0.299 * odd[0, :, 0].float() + 0.587 * odd[0, :, 1].float() + 0.114 * odd[0, :, 2].float())[:, 1:89, 3:91] / 255.0 - 0.421) / 0.165
+    assert np.abs(yo[0, 0].cpu().numpy() - ref.numpy()).max() < 1e-4
     assert lengths == [5, 3] and batch.shape == (2, 1, 5, 88, 88)
     assert np.abs(batch[1, 0, 3:].cpu().numpy() - (0.0 - 0.421) / 0.165).max() < 1e-5   # zero-padded RAW frames
 

@@ -195,14 +195,16 @@ def test_ingest_rgb(ops):
     assert np.array_equal(ops.ingest_rgb_u8(full.cuda()).cpu().numpy(), O.ingest_rgb_u8(full.numpy()))
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 3, 88, 88), (2, 5, 88, 88), (1, 3, 96, 96), (1, 2, 3, 100, 97), (3, 29, 3, 88, 88)],
-                         ids=["rgb88", "gray88", "gray96-crop", "rgb100x97-crop", "rgb-clip29"])
+@pytest.mark.parametrize("shape", [(2, 5, 3, 88, 88), (2, 5, 88, 88), (1, 3, 96, 96), (1, 2, 3, 100, 97), (1, 2, 3, 91, 95), (1, 2, 99, 91),
+                                   (3, 29, 3, 88, 88)],
+                         ids=["rgb88", "gray88", "gray96-crop", "rgb100x97-crop", "rgb91x95-crop", "gray99x91-crop", "rgb-clip29"])
 def test_stem3d_pool_u8_prepass_bit_identical(ops, shape):
     """uint8 frames straight into the stem's pre-pass (dlip_stem3d_pool_u8_f16x3): centre crop + BT.601 gray +
     (x/255 - 0.421)/0.165 while the split clip is written.  Three statements, all exact:
       * the normalised clip the pre-pass splits == the oracle's ingest_rgb_u8 / video_preprocess_u8 (bit for bit);
       * the stem + pool output == ingest kernel -> fp32 clip -> dlip_stem3d_pool_f16x3 (bit for bit);
-      * gray and RGB sources, frames larger than the crop (even and odd margins), a whole 29-frame clip."""
+      * gray and RGB sources, frames larger than the crop (even and odd margins; margins of 3, 7 and 11 -- 91, 95, 99 pixels --
+        where CenterCrop's floor (preprocess.py:89-90) and a round-half-even of margin / 2 differ by one pixel), a whole 29-frame clip."""
     from deeplip_amd import packing
     from deeplip_amd.frontend import VideoFrontend
     from oracle import deeplip_oracle as O

@@ -65,3 +65,65 @@ def test_without_a_gpu_the_children_fail_not_the_launcher():
     assert "torch.distributed.run" in r.stderr                      # the job was started ...
     assert r.stderr.count("needs a ROCm GPU") >= 1                 # ... and it is a RANK that says so (torchrun may stop the other
                                                                    # rank before it gets to print the same)
+
+
+def test_sigterm_to_the_launcher_ends_the_job():
+    """A harness timeout or a preemption sends SIGTERM to the LAUNCHER: the N-rank job it started (own session = own process
+    group) must go with it instead of staying behind holding the GPUs; the launcher returns 128 + SIGTERM."""
+    import signal
+    import time
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    code = ("import sys; sys.path.insert(0, %r); from deeplip_amd import launch; "
+            "sys.exit(launch.self_launch(%r, ['300'], 2))" % (ROOT, os.path.join(ROOT, "tests", "launch_sleeper.py")))
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
+    pids = []
+    t0 = time.time()
+    while len(pids) < 2 and time.time() - t0 < 120:
+        line = p.stdout.readline()
+        if line.startswith("rank-pid"):
+            pids.append(int(line.split()[1]))
+    assert len(pids) == 2, "the two ranks never started"
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    for _ in range(50):                                   # the ranks are gone (reaped by their own parent, which is gone too)
+        alive = [q for q in pids if os.path.exists(f"/proc/{q}") and open(f"/proc/{q}/stat").read().split()[2] != "Z"]
+        if not alive:
+            break
+        time.sleep(0.2)
+    assert not alive, alive
+
+
+def test_train_fusion_dry_two_ranks_end_to_end(tmp_path):
+    """`python train_fusion.py --mode train --dry --gpus 2`: the trainer launches its own 2-rank job (CPU ranks, gloo) and runs the
+    data-parallel protocol of BASELINE config C5 around stand-in arithmetic (train_fusion.py:88-93,241-315): one job name for all
+    ranks, replicas broadcast from rank 0 (they are seeded differently on purpose), each rank its own slice of the global batch,
+    flat gradient all-reduce, metric reduction, checkpoints written by rank 0 ALONE, and after two epochs of two steps the head
+    weights of both ranks bit-identical -- and different from where rank 0 started."""
+    import glob
+    import torch
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_fusion.py"), "--mode", "train", "--dry", "--gpus", "2", "--set",
+                        "train.bs=6", "train.epoch=2", "train.steps_per_epoch=2", "data.n_spk=5", "data.utt_per_spk=4",
+                        "train.sgd.init_lr=0.05"],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "--nproc-per-node 2" in r.stderr and "DRY (stand-in arithmetic" in r.stdout and "2 rank(s)" in r.stdout
+    assert r.stdout.count("Epoch 1 ") == 1 and r.stdout.count("Epoch 2 ") == 1        # rank 0 alone reports, over the GLOBAL batch
+    assert "on 2 GPU(s)" in r.stdout
+    runs = glob.glob(str(tmp_path / "exp" / "*"))
+    assert len(runs) == 1, runs                                                        # one run directory: rank 0's clock
+    files = sorted(os.path.basename(f) for f in glob.glob(runs[0] + "/*"))
+    assert files == ["dry_rank0.pt", "dry_rank1.pt", "net_1.pth", "net_2.pth"], files
+    for e in (1, 2):
+        ck = torch.load(os.path.join(runs[0], f"net_{e}.pth"), map_location="cpu")
+        assert ck["writer_rank"] == 0 and ck["epoch"] == e
+    a, b = (torch.load(os.path.join(runs[0], f"dry_rank{i}.pt")) for i in (0, 1))
+    assert all(torch.equal(a[k], b[k]) for k in a) and set(a) == set(b)
+    assert all(torch.equal(a[k], ck["state_dict"][k]) for k in a)                       # = rank 0's last checkpoint
+    torch.manual_seed(1234)                                                            # rank 0's initial head (train_fusion._init_dry)
+    w0 = torch.nn.Linear(1024, 5).weight
+    assert not torch.equal(a["fc.weight"], w0.detach())

@@ -55,3 +55,47 @@ def test_av_test_flow_matches_oracle(tmp_path, monkeypatch):
         ref = O.fuse_av(xva, emv)
     err = float((table.emb.cpu() - ref).abs().max() / ref.abs().max())
     assert err < 1e-4, err
+
+
+def test_main_flow_scores_through_the_reference_entry_points(tmp_path, monkeypatch):
+    """train_fusion.py:430-469: extract, then ``utils.eer_cos_*(trainer.log_time)`` -- one argument, the store on disk.  The
+    store the trainer leaves is the reference's (fused rows under exp/<run>/test_em/test_em_<set>/, x-vectors, lip clip
+    files, trial lists); every entry point over it gives what the in-memory scoring of the same tables gives."""
+    import os
+    import train_fusion
+    from models.fusion_models import utils
+    monkeypatch.chdir(tmp_path)
+    tr = train_fusion.Trainer("av_test", overrides=dict(SMALL, **{"data.clips_per_utt": 2}))
+    try:
+        for name, ds_name in (("lomgrid", "lomgridtestset"), ("grid", "gridtestset")):
+            getattr(tr, "extract_test_xv_" + name)()
+            tables = getattr(tr, name + "_tables")
+            root = "exp/{}".format(tr.log_time)
+            u0 = getattr(tr, ds_name).utt_ids[0].replace(".wav", ".npy")
+            assert np.load(os.path.join(root, "test_em", "test_em_" + name, u0)).shape == (1, 1024)      # train_fusion.py:362-364
+            assert np.load(os.path.join(root, "test_xv_" + name, u0)).shape == (1, 512)
+            for fn, mode in (("eer_cos_{}", "cos"), ("eer_cos_{}_scorefusion", "scorefusion"), ("eer_cos_{}_featurefusion", "featurefusion")):
+                got = getattr(utils, fn.format(name))(tr.log_time)
+                want = tr.eer_cos(getattr(tr, ds_name), tables, mode)
+                assert abs(got[0] - want[0]) < 1e-6 and abs(got[1] - want[1]) < 1e-5, (fn, name, got, want)
+    finally:
+        from deeplip_amd import scoring_entry as se
+        se._process_paths.clear()
+
+
+def test_model_average_is_the_mean_of_the_last_checkpoints(tmp_path, monkeypatch):
+    """train_fusion.py:158-175."""
+    import train_fusion
+    monkeypatch.chdir(tmp_path)
+    tr = train_fusion.Trainer("train", overrides=dict(SMALL, **{"train.sgd.init_lr": 0.05}))
+    tr()                                                 # two epochs -> net_1.pth, net_2.pth
+    a = torch.load("exp/{}/net_1.pth".format(tr.log_time), map_location="cpu")["state_dict"]
+    b = torch.load("exp/{}/net_2.pth".format(tr.log_time), map_location="cpu")["state_dict"]
+    avg = tr.model_average(2)
+    ck = torch.load("exp/{}/net_avg.pth".format(tr.log_time), map_location="cpu")
+    assert ck["epoch"] == 0 and "optimizer" in ck
+    for k, v in tr.model_fusion.state_dict().items():
+        if v.dtype.is_floating_point:
+            want = ((a[k].double() + b[k].double()) / 2).float()
+            assert torch.equal(v.cpu(), want) and torch.equal(ck["state_dict"][k], want), k
+    assert any(not torch.equal(a[k], b[k]) for k in a)

@@ -2,10 +2,12 @@
 """train_audio.py -- x-vector (TDNN / E-TDNN) entry point on the MI355X engine.
 
 Re-creation of the reference's train_audio.py surface that the A+V hot path uses: config schema
-(conf/audio_config.yaml: data / model / train / test), ``Trainer`` with ``extract_test_xv`` (x-vector
-extraction + F.normalize, train_audio.py:343-373), ``model_average`` (checkpoint averaging,
-:216-232), ``_adjust_margin`` (:141-145), ``save`` / ``load``; modes ``test`` (extract + cosine EER)
-and ``train``.  ``train`` is the reference's loop (train_audio.py:167-199): ``model.train()``, forward
+(conf/audio_config.yaml: data / model / train / test), ``Trainer`` with the reference's method names --
+``__call__`` (:473-483), ``_train`` / ``_train_epoch``, ``_adjust_margin`` (:141-145), ``model_average`` (checkpoint averaging,
+:216-232), ``extract_train_xv`` (:234-258), ``save`` / ``load`` / ``load_finetune`` (:260-296), ``train_plda`` (:298-341),
+``extract_test_xv`` (x-vector extraction + F.normalize, :343-373), ``extract_test_xv_lomgrid`` / ``_grid`` (:375-437) -- each
+extraction leaving the reference's ``exp/<run>/<set>/<utt>.npy`` store, and ``__main__`` scoring it through
+``models.audio_models.utils.eer*(log_time)`` as the reference's does (:485-543); modes ``train``, ``test``, ``av_test``, ``av_fusion``.  ``train`` is the reference's loop (train_audio.py:167-199): ``model.train()``, forward
 through every TDNN layer with batch-statistics BatchNorm, LMCL / CrossEntropy, ``loss.backward()`` through the
 whole encoder (conv dgrad / wgrad, BN and pooling backward as dlip_* launches -- deeplip_amd/autograd.py),
 SGD over model + criterion parameters, MultiStepLR, margin schedule, per-epoch checkpoints and checkpoint
@@ -66,6 +68,11 @@ class Trainer(object):
         F_ = self.model_opts[arch]["input_dim"] if arch != "resnet" else int(d.get("feat_dim", 40))
         self.trainset = SyntheticAVSet(d["n_spk"], d["utt_per_spk"], 0, 1, F_, d["audio_frames"], key="atrain")
         self.voxtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="atest")
+        # the reference's three A+V evaluation lists (train_audio.py:119-139: lomgriddevloader / lomgridtestloader / gridtestloader)
+        self.lomgriddevset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="alomdev")
+        self.lomgridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="alomgrid")
+        self.gridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="agrid")
+        self.resume = self.train_opts.get("resume", "exp/none/net_avg.pth")
         sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in self.model.state_dict().items()}, prefix="audio.")
         self.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         self.model.eval().to(self.device)
@@ -159,9 +166,10 @@ class Trainer(object):
         """Resume from one of this trainer's checkpoints or from a reference one (train_audio.py:234-296): there
         ``criterion`` is the pickled criterion MODULE (train_audio.py:264), and ``net_avg.pth`` (written by
         model_average, :229-232) has neither ``criterion`` nor ``epoch``."""
+        import pickle
         try:
             ck = torch.load(resume, map_location="cpu", weights_only=True)       # tensors and plain containers only
-        except Exception as ex:   # noqa: BLE001 -- torch raises UnpicklingError for anything beyond that
+        except pickle.UnpicklingError as ex:   # what torch raises for anything beyond that; a missing / truncated file propagates as itself
             # a reference checkpoint pickles the criterion MODULE: loading it executes the pickle, i.e. arbitrary code.
             # Allowed only on request (train.allow_pickled_checkpoints: True / DLIP_ALLOW_PICKLED_CHECKPOINTS=1).
             if not (self.train_opts.get("allow_pickled_checkpoints") or os.environ.get("DLIP_ALLOW_PICKLED_CHECKPOINTS") == "1"):
@@ -192,17 +200,134 @@ class Trainer(object):
             torch.save({"state_dict": {"module." + k: v for k, v in avg.items()}}, "exp/{}/net_avg.pth".format(self.log_time))
         return len(paths)
 
-    def extract_test_xv(self, batch=64):
-        """x-vectors of the test set, L2-normalised (train_audio.py:343-373) -> EmbeddingTable."""
+    def _xvectors(self, dataset, batch=64, normalize=True):
+        """The embedding the reference extracts (train_audio.py:362-366): CrossEntropy -> the 1st fc layer's output; LMCL (and
+        the ArcFace stand-in) -> the 2nd fc layer's, L2-normalised (``F.normalize``) for the test lists."""
         rows = []
+        ce = self.train_opts["loss"] == "CrossEntropy"
+        self.model.eval()
         with torch.no_grad():
-            for b0 in range(0, len(self.voxtestset), batch):
-                idx = list(range(b0, min(len(self.voxtestset), b0 + batch)))
-                xv, _ = self.model.extract_embedding(torch.from_numpy(self.voxtestset.audio(idx)).to(self.device))
-                rows.append(ops.l2_normalize(xv))
-        self.table = scoring.EmbeddingTable(self.voxtestset.utt_ids, torch.cat(rows))
+            for b0 in range(0, len(dataset), batch):
+                idx = list(range(b0, min(len(dataset), b0 + batch)))
+                xv, x_a = self.model.extract_embedding(torch.from_numpy(dataset.audio(idx)).to(self.device))
+                rows.append(x_a if ce else ops.l2_normalize(xv) if normalize else xv)
+        table = scoring.EmbeddingTable(dataset.utt_ids, torch.cat(rows))
         _lib.check_range(sync=True)       # a range report of the LAST batch must surface here, not at some later call
+        return table
+
+    def _load_for_extract(self, avg_only=False):
+        """train_audio.py:235-236,300-301 (net_avg.pth if the run has one) / :345-347,377-379 (``resume`` unless fine-tuning)."""
+        avg = "exp/{}/net_avg.pth".format(self.log_time)
+        if avg_only:
+            if os.path.exists(avg):
+                self.load(avg)
+        elif os.path.exists(self.resume) and self.train_opts.get("train_type") != "finetune":
+            self.load(self.resume)
+
+    def _store(self, sub, table, flat=False):
+        """One ``[1, D]`` .npy per utterance under exp/<run>/<sub>/ (train_audio.py:367-369); rank 0 writes."""
+        if self.rank == 0 and self.test_opts.get("write_store", True):
+            root = "exp/{}/{}".format(self.log_time, sub)
+            if flat:                      # train_plda stores by basename (train_audio.py:320-322)
+                scoring.EmbeddingTable([os.path.basename(u) for u in table.utt_ids], table.emb).save_npy_tree(root)
+            else:
+                table.save_npy_tree(root)
+        if ddist.active():
+            torch.distributed.barrier()
+
+    def extract_test_xv(self, batch=64):
+        """x-vectors of the test set, L2-normalised (train_audio.py:343-373) -> EmbeddingTable (+ exp/<run>/test_xv/)."""
+        self._load_for_extract()
+        self.table = self._xvectors(self.voxtestset, batch)
+        self._store("test_xv", self.table)
+        self._point_scoring("eer", self.voxtestset, "task")
         return self.table
+
+    def extract_train_xv(self, batch=64):
+        """train_audio.py:234-258: embeddings of the training list, NOT normalised, under exp/<run>/train_xv/."""
+        self._load_for_extract(avg_only=True)
+        self.train_table = self._xvectors(self.trainset, batch, normalize=False)
+        self._store("train_xv", self.train_table)
+        return self.train_table
+
+    def extract_test_xv_lomgrid(self, batch=64):
+        """train_audio.py:375-405 -> exp/<run>/test_xv_lomgrid/."""
+        self._load_for_extract()
+        self.lomgrid_table = self._xvectors(self.lomgridtestset, batch)
+        self._store("test_xv_lomgrid", self.lomgrid_table)
+        self._point_scoring("lomgrid", self.lomgridtestset, "trial_lomgrid")
+        return self.lomgrid_table
+
+    def extract_test_xv_grid(self, batch=64):
+        """train_audio.py:407-437 -> exp/<run>/test_xv_grid/."""
+        self._load_for_extract()
+        self.grid_table = self._xvectors(self.gridtestset, batch)
+        self._store("test_xv_grid", self.grid_table)
+        self._point_scoring("grid", self.gridtestset, "trial_grid")
+        return self.grid_table
+
+    def _point_scoring(self, name, dataset, fname):
+        """The synthetic trial list of a test set, written in the reference's format, and this run's scoring calls pointed at
+        it (the reference hard-codes ``task.txt`` / ``data/trial/A_*_trial_2w``: models/audio_models/utils.py:237,254,271)."""
+        from deeplip_amd import scoring_entry as se
+        if not self.test_opts.get("write_store", True):
+            return
+        path = "exp/{}/{}.txt".format(self.log_time, fname)
+        if self.rank == 0:
+            y, pairs = synthetic_trials(dataset, self.data_opts["trials"], self.data_opts["trial_targets"])
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as fh:
+                fh.writelines("{} {} {}\n".format(int(l), a, b) for l, (a, b) in zip(y, pairs))
+        if ddist.active():
+            torch.distributed.barrier()
+        for fn in (("eer",) if name == "eer" else ("eer_cos_" + name, "eer_plda_" + name)):
+            se.set_paths(fn, trial=path)
+
+    def train_plda(self, n_principal_components=20):
+        """train_audio.py:298-341: x-vectors of the LombardGRID development list -> exp/<run>/dev_xv_lomgrid/<basename>.npy, labels
+        from the speaker id in the file name (``s<k>_...``), a PLDA model with ``n_principal_components=20`` fitted on them
+        (host: the `plda` package's algorithm, deeplip_amd/plda.py) -> ``exp/plda.pkl``."""
+        from deeplip_amd.plda import PLDA
+        self._load_for_extract(avg_only=True)
+        dev = self._xvectors(self.lomgriddevset)
+        self._store("dev_xv_lomgrid", dev, flat=True)
+        labels = [int(os.path.basename(u).split("_")[0].replace("s", "")) for u in dev.utt_ids]      # :334
+        X = dev.emb.cpu().numpy()
+        self.plda = PLDA.fit(X, labels, n_principal_components=min(n_principal_components, X.shape[1], max(2, len(set(labels)) - 1)))
+        if self.rank == 0:
+            self.plda.save("exp/plda.pkl")
+        if ddist.active():
+            torch.distributed.barrier()
+        return self.plda
+
+    def load_finetune(self, resume, param_groups=None):
+        """train_audio.py:276-296: load an encoder checkpoint, freeze the encoder and rebuild optimizer + schedule over the
+        criterion's parameters alone (``param_groups`` is overwritten there too)."""
+        print("loading model from {}".format(resume))
+        self.log_time = resume.split("/")[1]
+        self.load(resume)
+        for p in self.model.parameters():
+            p.requires_grad = False
+        self.freeze_encoder = True
+        param_groups = [{"params": self.criterion.parameters()}]
+        kind = self.train_opts.get("type", "sgd")
+        if kind == "sgd":
+            o = self.train_opts["sgd"]
+            self.optim = torch.optim.SGD(param_groups, o["init_lr"], momentum=o["momentum"], weight_decay=o["weight_decay"])
+        elif kind == "adam":
+            o = self.train_opts["adam"]
+            self.optim = torch.optim.Adam(param_groups, o["init_lr"], weight_decay=o["weight_decay"])
+        else:
+            raise NotImplementedError(kind)
+        self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optim, milestones=self.train_opts["lr_decay_step"], gamma=0.1)
+        self.buckets = None
+
+    def __call__(self):
+        """train_audio.py:473-483."""
+        if self.rank == 0:
+            print("[LOG Time: {}]".format(self.log_time))
+            os.makedirs("exp/{}".format(self.log_time), exist_ok=True)
+        self._train()
 
     def eer(self):
         y, pairs = synthetic_trials(self.voxtestset, self.data_opts["trials"], self.data_opts["trial_targets"])
@@ -230,9 +355,10 @@ def _self_launch(gpus, config, overrides, key="train.gpus_id"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="test", choices=["train", "test"])    # reference: hard-coded at :485
+    ap.add_argument("--mode", default="test", choices=["train", "test", "av_test", "av_fusion"])    # reference: hard-coded at :486
     ap.add_argument("--config", default="conf/audio_config.yaml")
     ap.add_argument("--set", nargs="*", default=[])
+    ap.add_argument("--run", default=None, help="name of an existing exp/<run>/ directory to score (av_fusion; the reference edits log_time by hand)")
     ap.add_argument("--gpus", type=int, default=None,
                     help="GPUs of this node, one process each (default: len(train.gpus_id), as the reference sizes nn.DataParallel: "
                          "train_audio.py:80-83)")
@@ -241,13 +367,35 @@ def main():
     if rc is not None:
         sys.exit(rc)
     tr = Trainer(a.config, {k: yaml.safe_load(v) for k, v in (kv.split("=", 1) for kv in a.set)})
+    from models.audio_models import utils           # the scoring entry points, called as train_audio.py:499-543 calls them
+
+    def report(fn):
+        if tr.rank == 0:            # the store is on disk and complete (barrier in _store): one rank scores and prints
+            eer, threshold = fn(tr.log_time)
+            print("EER: {:.6f}%".format(eer * 100))
+
     if a.mode == "train":
-        tr._train()
+        tr()
         tr.model_average(min(4, tr.epoch))
-    tr.extract_test_xv()
-    eer, thr = tr.eer()
-    if tr.rank == 0:
-        print("EER: {:.6f}%".format(eer * 100))
+        tr.extract_test_xv()
+        report(utils.eer)
+    elif a.mode == "test":
+        tr.extract_test_xv()
+        report(utils.eer)
+    else:                           # av_test: cosine / PLDA on the x-vectors (train_audio.py:504-520)
+        if a.run:
+            tr.log_time = a.run     # av_fusion scores the stores an earlier run left under exp/<run>/ (:521-543: extraction commented out)
+        if a.mode == "av_test" and tr.test_opts.get("train_plda"):
+            tr.train_plda()
+        for name in ("lomgrid", "grid"):
+            if not tr.test_opts.get("eval_" + name, True):
+                continue
+            if a.mode == "av_test":
+                getattr(tr, "extract_test_xv_" + name)()
+            if tr.test_opts.get("use_cos", True):
+                report(getattr(utils, "eer_cos_" + name + ("_featurefusion" if a.mode == "av_fusion" else "")))
+            if tr.test_opts.get("use_plda"):
+                report(getattr(utils, "eer_plda_" + name))
     if ddist.active():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

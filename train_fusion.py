@@ -3,14 +3,16 @@
 
 Entry point of the reference (train_fusion.py) re-created runnable: same config schema
 (conf/fusion_config.yaml: data / model / train / test), same ``Trainer`` method names
-(``__call__/_train/_train_epoch/feature_normalize/extract_test_xv_lomgrid/extract_test_xv_grid/
+(``__call__/_train/_train_epoch/model_average/feature_normalize/extract_test_xv_lomgrid/extract_test_xv_grid/
 save/load/load_finetune``) and the same flow -- frozen audio + video encoders, trainable fusion
 head + criterion (train_fusion.py:120,198-201), test-time fusion = z-norm + concat
 (:353-358), cosine EER over a trial list -- with the upstream breakages fixed and
 three structural changes:
   * batched: the reference's per-utterance / per-clip Python loops (:267-281,:346-349) become one
     encoder launch set per batch + a segmented clip-group mean on the device;
-  * embeddings stay in HBM (``EmbeddingTable``) instead of one .npy per utterance (:361-364);
+  * embeddings stay in HBM (``EmbeddingTable``) through extraction; rank 0 then writes the reference's on-disk store
+    (one .npy per utterance, :361-364) once, and ``__main__`` scores it through ``models.fusion_models.utils.eer_*(log_time)``
+    exactly as the reference's does (:430-469);
   * data parallel = one process per GPU over RCCL (gradient all-reduce of the trainable tail, one
     all-gather of test embeddings), replacing nn.DataParallel (:91-93).
 
@@ -46,7 +48,7 @@ from models.video_models.model import Lipreading  # noqa: E402
 
 
 class Trainer(object):
-    def __init__(self, mode, config="conf/fusion_config.yaml", overrides=None):
+    def __init__(self, mode, config="conf/fusion_config.yaml", overrides=None, dry=False):
         with open(os.path.join(ROOT, config) if not os.path.isabs(config) else config) as f:
             opts = yaml.safe_load(f)
         for k, v in (overrides or {}).items():      # e.g. {"train.bs": 8}
@@ -61,13 +63,23 @@ class Trainer(object):
 
         self.rank, self.world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
         local = int(os.environ.get("LOCAL_RANK", 0))
-        if not torch.cuda.is_available():
-            raise RuntimeError("train_fusion.py needs a ROCm GPU: the deeplip_amd engine has no CPU path")
-        torch.cuda.set_device(local)
-        self.device = torch.device("cuda", local)
-        if "RANK" in os.environ and not dist.is_initialized():     # any torch.distributed.run job, a one-rank one included
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=self.device)
+        self.dry = bool(dry)
+        if self.dry:
+            # --dry: a REHEARSAL of the data-parallel protocol on CPU ranks over gloo (tests/test_launch_cpu.py), like bench.py's
+            # --dry-launch.  Nothing of the engine runs and nothing is measured: the frozen encoders are replaced by seeded rows,
+            # the head and criterion by stand-ins (_DryHead); what is real is everything AROUND the arithmetic -- the launcher,
+            # the job name broadcast, per-rank sampling, the flat gradient all-reduce, the optimizer / scheduler, metric
+            # reduction, rank 0's checkpoints.
+            self.device = torch.device("cpu")
+            ddist.init_from_env(None)
+        else:
+            if not torch.cuda.is_available():
+                raise RuntimeError("train_fusion.py needs a ROCm GPU: the deeplip_amd engine has no CPU path")
+            torch.cuda.set_device(local)
+            self.device = torch.device("cuda", local)
+            if "RANK" in os.environ and not dist.is_initialized():     # any torch.distributed.run job, a one-rank one included
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                dist.init_process_group("nccl", device_id=self.device)
 
         d = self.data_opts
         acfg = self.model_opts["audio_config"]
@@ -79,6 +91,8 @@ class Trainer(object):
         self.gridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], d["clips_per_utt"],
                                           d["video_frames"], feat_dim, d["audio_frames"], key="grid")
         n_spk = self.trainset.n_spk
+        if self.dry:
+            return self._init_dry(acfg, n_spk)
 
         if acfg["arch"] in ("tdnn", "etdnn"):
             self.model_audio = tdnn.SpeakerEmbNet(acfg)
@@ -120,6 +134,18 @@ class Trainer(object):
         else:
             raise NotImplementedError("Other loss function has not been implemented yet!")
 
+        self._init_optim()
+
+    def _init_dry(self, acfg, n_spk):
+        self.embedding_dim = acfg[acfg["arch"]]["embedding_dim"]
+        self.model_audio = self.model_video = None
+        self.fusion_kind = "dry"
+        torch.manual_seed(1234 + self.rank)              # ranks start DIFFERENT: the broadcast below has something to do
+        self.model_fusion = _DryHead(2 * self.embedding_dim, n_spk)
+        self.criterion = _DryCriterion()
+        self._init_optim()
+
+    def _init_optim(self):
         param_groups = [{"params": list(self.model_fusion.parameters())}, {"params": self.criterion.parameters()}]
         if self.train_opts["optimizer"] == "sgd":
             o = self.train_opts["sgd"]
@@ -131,9 +157,14 @@ class Trainer(object):
         self.resume_video = self.train_opts["video_config"]["resume"]
         self.resume_fusion = self.train_opts["resume"]
         self.log_time = time.asctime(time.localtime(time.time())).replace(" ", "_")[4:]
+        if ddist.active():          # one run directory for the job: rank 0's clock
+            name = [self.log_time]
+            dist.broadcast_object_list(name, 0)
+            self.log_time = name[0]
         self.lr_scheduler = lr_scheduler.MultiStepLR(self.optim, milestones=self.train_opts["lr_decay_step"], gamma=0.1)
         self.current_epoch = 0
-        self.load_finetune()
+        if not self.dry:
+            self.load_finetune()
         # replicas start identical (DataParallel broadcast equivalent)
         if ddist.active():
             for p in list(self.model_fusion.parameters()) + list(self.criterion.parameters()):
@@ -164,6 +195,12 @@ class Trainer(object):
 
     def _embed_batch(self, dataset, idx):
         """Frozen encoders on a batch of utterances -> (xv_audio [B,512], em_video [B,512])."""
+        if self.dry:                                     # seeded rows shaped like the encoders' outputs (speaker centre + noise)
+            rows = np.stack([np.random.Generator(np.random.PCG64([int(i), 99])).normal(size=2 * self.embedding_dim) * 0.5
+                             + np.random.Generator(np.random.PCG64([int(dataset.utts[i][0]), 7])).normal(size=2 * self.embedding_dim)
+                             for i in idx]).astype(np.float32)
+            t = torch.from_numpy(rows)
+            return t[:, :self.embedding_dim].contiguous(), t[:, self.embedding_dim:].contiguous()
         with torch.no_grad():
             audio = torch.from_numpy(dataset.audio(idx)).to(self.device)
             xv_audio, _ = self.model_audio.extract_embedding(audio)      # train_fusion.py:262,338
@@ -184,8 +221,9 @@ class Trainer(object):
 
     def _train_epoch(self):
         self.model_fusion.train()
-        self.model_audio.eval()
-        self.model_video.eval()
+        if not self.dry:
+            self.model_audio.eval()
+            self.model_video.eval()
         bs = self.train_opts["bs"]
         steps = self.train_opts.get("steps_per_epoch", max(1, len(self.trainset) // (bs * self.world)))
         rng = np.random.Generator(np.random.PCG64([self.current_epoch, 17]))
@@ -220,7 +258,7 @@ class Trainer(object):
         path = "exp/{}/{}".format(self.log_time, filename or "net_{}.pth".format(self.current_epoch))
         os.makedirs(os.path.dirname(path), exist_ok=True)
         torch.save({"epoch": self.current_epoch, "state_dict": self.model_fusion.state_dict(),
-                    "criterion": self.criterion.state_dict(), "optimizer": self.optim.state_dict()}, path)
+                    "criterion": self.criterion.state_dict(), "optimizer": self.optim.state_dict(), "writer_rank": self.rank}, path)
         return path
 
     def load(self, resume):
@@ -228,6 +266,25 @@ class Trainer(object):
         self.model_fusion.load_state_dict(ckpt["state_dict"])
         self.criterion.load_state_dict(ckpt["criterion"])
         self.current_epoch = ckpt["epoch"]
+
+    def model_average(self, avg_num=2):
+        """train_fusion.py:158-175: average the fusion head's state dicts of the last ``avg_num`` epoch checkpoints
+        (``net_<epoch - i>.pth``), write ``net_avg.pth`` (``epoch 0``, the last checkpoint's optimizer state) and load the
+        average into the head.  Sums in fp64, rounded once (the reference adds fp32 tensors in place, which also mutates the
+        first checkpoint's tensors); integer buffers (BatchNorm's ``num_batches_tracked``) are averaged with integer
+        division as ``v / avg_num`` on a LongTensor did when the reference was written."""
+        sums, ckpt = {}, None
+        for i in range(avg_num):
+            ckpt = torch.load("exp/{}/net_{}.pth".format(self.log_time, self.epoch - i), map_location="cpu")
+            for k, v in ckpt["state_dict"].items():
+                sums[k] = sums[k] + v.double() if k in sums else v.double().clone()
+        own = self.model_fusion.state_dict()
+        avg = {k: (torch.div(v, avg_num, rounding_mode="floor") if not own[k].dtype.is_floating_point else v / avg_num).to(own[k].dtype)
+               for k, v in sums.items()}
+        if self.rank == 0:
+            torch.save({"epoch": 0, "state_dict": avg, "optimizer": ckpt["optimizer"]}, "exp/{}/net_avg.pth".format(self.log_time))
+        self.model_fusion.load_state_dict(avg)
+        return avg
 
     def load_finetune(self):
         """train_fusion.py:191-215: load pretrained audio (keys carry DataParallel's 'module.' prefix) and
@@ -296,12 +353,47 @@ class Trainer(object):
         return (scoring.EmbeddingTable(dataset.utt_ids, em), scoring.EmbeddingTable(dataset.utt_ids, xa),
                 scoring.EmbeddingTable(dataset.utt_ids, xv))
 
+    def _write_store(self, name, dataset, tables):
+        """What the reference leaves on disk for its ``utils.eer_*`` functions, so that they can be called with the run's
+        name alone as its ``__main__`` does (train_fusion.py:430-469):
+          exp/<run>/test_em/test_em_<name>/<utt>.npy   fused [1,1024] rows (train_fusion.py:362-364)
+          exp/<run>/test_xv_<name>/<utt>.npy           speech x-vectors [1,512] (train_audio.py:375-405 writes these)
+          exp/<run>/embedding_<name>/<pattern>_c<k>.npz  lip embeddings, ``data`` [1,T,512] per clip file (train_video.py:212);
+                                                       T = 1 here: the clip's frame mean, which is all the readers use
+          exp/<run>/trial_<name>.txt, video_trial_<name>.txt   the synthetic trial list in both of the reference's formats
+        and the default paths of this run's scoring calls pointed at them (the reference hard-codes its site's)."""
+        from deeplip_amd import scoring_entry as se
+        if not self.test_opts.get("write_store", True):
+            return
+        root = "exp/{}".format(self.log_time)
+        trial, vtrial = os.path.join(root, "trial_{}.txt".format(name)), os.path.join(root, "video_trial_{}.txt".format(name))
+        vdir = os.path.join(root, "datasets_{}".format(name)) + "/"
+        kind = "spk/utt" if name == "lomgrid" else "utt"
+        if self.rank == 0:
+            tables[0].save_npy_tree(os.path.join(root, "test_em", "test_em_" + name))
+            tables[1].save_npy_tree(os.path.join(root, "test_xv_" + name))
+            for u, row in zip(dataset.utt_ids, tables[2].emb.cpu().numpy()):
+                f = (vdir + se._pattern(kind, u) + "_c0.npz").replace("datasets", "embedding")
+                os.makedirs(os.path.dirname(f), exist_ok=True)
+                np.savez_compressed(f, data=row[None, None, :])
+            y, pairs = synthetic_trials(dataset, self.data_opts["trials"], self.data_opts["trial_targets"])
+            with open(trial, "w") as fh:
+                fh.writelines("{} {} {}\n".format(int(l), a, b) for l, (a, b) in zip(y, pairs))
+            with open(vtrial, "w") as fh:
+                fh.writelines("{}\t{}\n".format(se._pattern(kind, a), se._pattern(kind, b)) for a, b in pairs)
+        if ddist.active():
+            dist.barrier()
+        for fn in ("eer_cos_{}", "eer_plda_{}", "eer_cos_{}_scorefusion", "eer_cos_{}_featurefusion"):
+            se.set_paths(fn.format(name), trial=trial, video_dir=vdir, video_trial=vtrial)
+
     def extract_test_xv_lomgrid(self):
         self.lomgrid_tables = self._extract(self.lomgridtestset)
+        self._write_store("lomgrid", self.lomgridtestset, self.lomgrid_tables)
         return self.lomgrid_tables[0]
 
     def extract_test_xv_grid(self):
         self.grid_tables = self._extract(self.gridtestset)
+        self._write_store("grid", self.gridtestset, self.grid_tables)
         return self.grid_tables[0]
 
     def eer_cos(self, dataset, tables, mode="cos"):
@@ -314,6 +406,22 @@ class Trainer(object):
         else:                          # utils.eer_cos_*_featurefusion (:433-521)
             s = scoring.feature_fusion_scores(tables[1].emb, tables[2].emb, ia, ib)
         return scoring.eer_from_scores(y, s.cpu().numpy())
+
+
+class _DryHead(torch.nn.Module):
+    """--dry only: a stock-torch stand-in for the fusion head (the engine's head needs the GPU).  Never built otherwise."""
+
+    def __init__(self, d, n):
+        super().__init__()
+        self.fc = torch.nn.Linear(d, n)
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+class _DryCriterion(torch.nn.Module):
+    def forward(self, output, labels):
+        return torch.nn.functional.cross_entropy(output, labels), output
 
 
 def _self_launch(gpus, config, overrides, key):
@@ -340,6 +448,9 @@ def main():
     ap.add_argument("--mode", default="av_test", choices=["train", "av_test", "av_fusion"])   # reference: hard-coded at :424
     ap.add_argument("--config", default="conf/fusion_config.yaml")
     ap.add_argument("--set", nargs="*", default=[], help="overrides, e.g. train.bs=8 data.trials=2000")
+    ap.add_argument("--dry", action="store_true",
+                    help="rehearse the data-parallel protocol of --mode train on CPU ranks over gloo: stand-in arithmetic, nothing of the "
+                         "engine runs, nothing is measured (tests)")
     ap.add_argument("--gpus", type=int, default=None,
                     help="GPUs of this node to use, one process each (default: len(train.gpus_id) of the config, as the "
                          "reference sizes nn.DataParallel: train_fusion.py:88-93)")
@@ -351,28 +462,45 @@ def main():
     rc = _self_launch(args.gpus, args.config, ov, "train.gpus_id")
     if rc is not None:
         sys.exit(rc)
+    if args.dry:
+        if args.mode != "train":
+            ap.error("--dry rehearses --mode train only")
+        trainer = Trainer("train", args.config, ov, dry=True)
+        trainer()
+        # every rank leaves what it holds after the last step: replicas must be bit-identical (the test compares the files)
+        torch.save({k: v.clone() for k, v in trainer.model_fusion.state_dict().items()},
+                   "exp/{}/dry_rank{}.pt".format(trainer.log_time, trainer.rank))
+        if trainer.rank == 0:
+            print("DRY (stand-in arithmetic, nothing of the engine ran): {} rank(s), run {}".format(trainer.world, trainer.log_time), flush=True)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     trainer = Trainer(args.mode, args.config, ov)
-    rank0 = trainer.rank == 0
+    from models.fusion_models import utils          # the scoring entry points, called as train_fusion.py:430-469 calls them
+
+    def report(fn):
+        # every rank extracted its shard and holds the gathered tables; the store is on disk: rank 0 scores and prints
+        if trainer.rank == 0:
+            eer, threshold = fn(trainer.log_time)
+            print("EER: {:.6f}%".format(eer * 100))
+
     if args.mode == "train":
         trainer()
+        if trainer.test_opts.get("model_average", False):      # commented out upstream (train_fusion.py:428)
+            if ddist.active():
+                dist.barrier()
+            trainer.model_average(min(2, trainer.epoch))
         trainer.extract_test_xv_lomgrid()
-        eer, thr = trainer.eer_cos(trainer.lomgridtestset, trainer.lomgrid_tables, "featurefusion")
-        if rank0:
-            print("EER: {:.6f}%".format(eer * 100))
+        report(utils.eer_cos_lomgrid_featurefusion)
     else:
-        kind = "cos" if args.mode == "av_test" else "scorefusion"
-        if trainer.test_opts["eval_lomgrid"]:
-            trainer.extract_test_xv_lomgrid()
+        sets = [(s, getattr(trainer, "extract_test_xv_" + s)) for s in ("lomgrid", "grid") if trainer.test_opts["eval_" + s]]
+        for name, extract in sets:
+            extract()
             if trainer.test_opts["use_cos"]:
-                eer, thr = trainer.eer_cos(trainer.lomgridtestset, trainer.lomgrid_tables, kind)
-                if rank0:
-                    print("EER: {:.6f}%".format(eer * 100))
-        if trainer.test_opts["eval_grid"]:
-            trainer.extract_test_xv_grid()
-            if trainer.test_opts["use_cos"]:
-                eer, thr = trainer.eer_cos(trainer.gridtestset, trainer.grid_tables, kind)
-                if rank0:
-                    print("EER: {:.6f}%".format(eer * 100))
+                report(getattr(utils, "eer_cos_" + name + ("" if args.mode == "av_test" else "_scorefusion")))
+            if trainer.test_opts["use_plda"]:
+                report(getattr(utils, "eer_plda_" + name))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
