@@ -1,0 +1,466 @@
+// Split-fp16 convolution, ROWS variant: convolutions whose every tap is a plain row offset of the activation matrix --
+// the 1-D "valid" convolutions of the speech encoder (models/audio_models/tdnn.py:23-43: Conv1d over time, no padding,
+// dilation from the context list) and, with one tap, its k = 1 layers: plain [M x C] . [C x K] GEMMs over the B * T' frames.
+//
+// Why a third kernel.  On the ring kernel (conv_igemm_f16x3_dma.hip) the k = 1 layers -- 16 slices of 32 channels per
+// tile -- ran at 0.21 of the split-fp16 ceiling for three rounds: a third of every 128 x 128 tile was set-up, first fills
+// and epilogue around a 16-slice loop (in-kernel stamps: 7.8 k + 9.9 k of 52 k cycles), and 592 tiles on 512 slots made a
+// second round that was 16 % full.  What such a layer needs is (1) more matrix work behind every barrier and every byte,
+// (2) one round, (3) nothing between two tiles.  So:
+//   * tile = (32 MI) x 256, MI = 5 | 4 | 3: eight waves (2 x 4), a wave owns 16 MI x 64 outputs = 4 MI accumulator quads
+//     (80 registers at MI = 5).  Per 32-channel slice a workgroup moves (160 + 256) x 128 B = 52 KB for 60 MFMAs per
+//     wave (the 256 x 128 ring tile: 48 KB for 48); the host picks MI so that rows x column blocks fill ONE round of the
+//     chip's CUs where it can (B = 64, T' = 296: 119 x 2 = 238 tiles of 160 x 256 on 256 CUs).
+//   * ONE persistent workgroup per CU walks its tiles with a CONTINUOUS slice stream: "two slices ahead" of a tile's last
+//     slices are the next tile's first ones, the LDS ring never drains, and no barrier joins the waves between tiles.
+//   * the epilogue goes from the accumulator registers straight to memory -- no LDS image, so the ring is not touched
+//     (that is what let the stream run on; the ring kernel stages its output tile in the ring).  A split-format output
+//     needs 16-B pieces: v_permlane16_swap_b32 exchanges the odd 16-lane rows of one accumulator with the even rows of
+//     its neighbour in the channel direction, after which a lane holds 8 consecutive channels of its pixel = one 16-B
+//     piece of hi halves and one of lo halves.  Each half of the waves runs a tile's epilogue at the head of its next LOAD
+//     interval, i.e. beside its SIMD partner's matrix phase.
+//   * main loop: the ring kernel's PING-PONG (its 256 x 128 instance): waves 0-3 and 4-7 -- one wave of every SIMD in each
+//     half -- work on the same slice half a period apart, two barriers per slice; one half multiplies (60 MFMAs, nothing
+//     else in its stream) while the other reads the 18 fragments of its next matrix phase, issues its LDS-DMA pieces
+//     two slices ahead and waits for the pieces of the next slice.
+// Arithmetic, slice order (channel slice outer, tap inner), product order per accumulator (lo*hi, hi*hi, hi*lo) and
+// epilogue formula are the ring kernel's: a launch that the ring kernel runs as a plain (un-split) launch gives the
+// same bits here (tests/test_kernels_gpu.py::test_conv_rows_*).
+#include "conv_common.h"
+#include "conv_dma_common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+struct RowsSched {
+  int items;      // tiles of the launch: tiles_m * tiles_n, row block major (the column blocks of a row block are neighbours)
+  int tiles_n;
+  unsigned long long* span;   // NULL, or this launch's {first start, last end} in 100 MHz ticks (dlip_span_scope_*)
+#ifdef DLIP_LAB
+  unsigned long long* stamps;
+#endif
+};
+
+constexpr int ROWS_BN = 256;
+
+// EPI: 0 fp32 rows of y; 1 split-format rows of y (reports range)
+template <int MI, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs a, const RowsSched sc) {
+  constexpr int NW = 8, BN = ROWS_BN, BM = 32 * MI, NI = 4;
+  constexpr int WM = BM / 2;                       // rows of a wave's tile (16 MI); WN = 64
+  constexpr int A_PIECES = BM / 8, B_PER = 4;      // 1-KiB pieces of a slice's activation rows; weight pieces per wave
+  constexpr int NA_A = (A_PIECES + 7) / 8, NA_B = A_PIECES / 8;   // activation pieces of a wave of half A (waves 0-3) / B (4-7)
+  static_assert(A_PIECES % 8 == 0 || A_PIECES % 8 == 4, "waves 0-3 take one activation piece more than waves 4-7, or the same");
+  constexpr int STAGE_B = (BM + BN) * ROWB, NSTAGE = 3;
+  constexpr int LDK = 32;
+  constexpr int NST = EPI == 1 ? MI * 4 : MI * NI;   // 16-B output stores per lane and tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // neighbours in tile order share an XCD (L2)
+  if (g >= sc.items) return;
+  const int n_my = (sc.items - g + nwg - 1) / nwg;        // this workgroup's tiles: g, g + nwg, ...
+  const int nk = a.nk;
+  const int total = n_my * nk;                            // slices of its stream
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const bool half_b = wave >= NW / 2;                     // (wave-uniform)
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lrow = lane & 15, hq = lane >> 4;
+  // DMA side: piece q = wave + 8 j covers tile rows 8 q .. 8 q + 7; lane -> (row lane >> 3, chunk position lane & 7); the XOR
+  // swizzle of the LDS image (chunk p of row r at position p ^ ((r >> 1) & 7)) goes on the SOURCE chunk, and since
+  // 4 q mod 8 is the same for every piece of a wave the key is a per-lane constant.
+  const int prow = lane >> 3;
+  const int key_st = (4 * (wave & 1) + (lane >> 4)) & 7;
+  const int csrc = ((lane & 7) ^ key_st) << 2;            // first channel (dword) of the chunk this lane fetches
+  const u32x4 xr = make_rsrc_words(a.x, a.x_bytes);
+  const u32x4 wr = make_rsrc_words(a.w, a.w_bytes);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t piece0 = lds0 + wave * 1024;
+  // fragment side (v_mfma_f32_16x16x32_f16; the weight fragment is the A operand: accumulators hold the transposed tile)
+  const int a_frag = (wm * WM + lrow) * LDK;
+  const int b_frag = BM * LDK + (wn * 64 + lrow) * LDK;
+  const int key_rd = (lrow >> 1) & 7;
+  const int khi = (hq ^ key_rd) << 2, klo = ((4 + hq) ^ key_rd) << 2;
+  const int x_ds = a.dw * a.ldx * 4;                      // bytes between two taps of a row
+
+  const bool span_me = sc.span != nullptr && tid == 0 && (g & 15) == 0;
+  if (span_me) atomicMin(sc.span, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#ifdef DLIP_LAB
+#define ROWS_STAMP(i) do { if (sc.stamps && tid == 0) sc.stamps[(size_t)g * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ROWS_SSTAMP(i) do { if (sc.stamps && tid == 0 && s == 8) sc.stamps[(size_t)g * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  if (sc.stamps && tid == 0) sc.stamps[(size_t)g * 16 + 7] = __builtin_amdgcn_s_memrealtime();
+#else
+#define ROWS_STAMP(i) do { } while (0)
+#define ROWS_SSTAMP(i) do { } while (0)
+#endif
+
+  // ---- issue cursor: the slice the NEXT pieces belong to (two slices ahead of the one being multiplied) ----
+  int a_off[NA_A], b_off[B_PER];
+  int c_item = g, c_k = 0, s_pos = 0, c0 = 0, x_tap = 0, w_tap = 0;
+  auto set_item = [&](int item) {
+    const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
+#pragma unroll
+    for (int j = 0; j < NA_A; ++j) {
+      const int m = tile_m * BM + 8 * (wave + 8 * j) + prow;
+      const int mc = m < a.M ? m : 0;
+      const int n = dlip_div(mc, a.div_howo);
+      const int t = mc - n * a.HoWo;                       // H = 1: the row's first input pixel is n * W + t
+      a_off[j] = m < a.M ? ((n * a.W + t) * a.ldx + csrc) * 4 : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+      const int n = tile_n * BN + 8 * (wave + 8 * j) + prow;
+      b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
+    }
+  };
+  auto advance = [&]() {   // channel slice outer, tap inner (the ring kernel's reduction order)
+    if (++c_k == nk) {
+      c_k = 0; s_pos = 0; c0 = 0;
+      c_item += nwg;
+      set_item(c_item);
+    } else if (++s_pos == a.S) {
+      s_pos = 0; c0 += BK;
+    }
+    x_tap = s_pos * x_ds + c0 * 4;
+    w_tap = (s_pos * a.Cw + c0) * 4;
+  };
+  auto issue = [&](int stage, auto na) {
+    const uint32_t base = piece0 + stage * STAGE_B;
+#pragma unroll
+    for (int j = 0; j < na(); ++j)
+      dma_piece(xr, a_off[j] >= 0 ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * 8192);
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j)
+      dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + BM * ROWB + j * 8192);
+  };
+
+  f32x4 acc[MI][NI];
+  f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
+#define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
+  };
+  auto read_all = [&](int stage) {
+    const float* Aw = smem + stage * (STAGE_B / 4) + a_frag;
+    const float* Bw = smem + stage * (STAGE_B / 4) + b_frag;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) fal[mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 16 * LDK + klo);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) fbh[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + khi);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) fah[mi] = *reinterpret_cast<const f16x8*>(Aw + mi * 16 * LDK + khi);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + klo);
+  };
+  auto mfma_all = [&]() {
+    __builtin_amdgcn_s_setprio(2);   // the matrix phase outranks its SIMD partner's load phase
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {   // accumulator-major: the three products of one accumulator back to back (ring kernel)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[ni], fal[mi], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[ni], fah[mi], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[ni], fah[mi], acc[mi][ni], 0, 0, 0);
+      }
+      DLIP_FENCE();
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- epilogue of one tile, from this wave's accumulators straight to memory:
+  //      y = act(acc / wscale + bias) * post_scale + post_shift   (no residual on this path) ----
+  const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
+  const uint32_t kbytes = (uint32_t)a.K * 4u;
+  const __amdgpu_buffer_rsrc_t scr = dlip_make_rsrc(a.wscale, kbytes);
+  const __amdgpu_buffer_rsrc_t bir = dlip_make_rsrc(a.bias, a.bias ? kbytes : 0u);
+  const __amdgpu_buffer_rsrc_t slr = dlip_make_rsrc(a.slope, a.slope ? kbytes : 0u);
+  const __amdgpu_buffer_rsrc_t psr = dlip_make_rsrc(a.pscale, a.pscale ? kbytes : 0u);
+  const __amdgpu_buffer_rsrc_t ptr_ = dlip_make_rsrc(a.pshift, a.pshift ? kbytes : 0u);
+  const bool has_slope = a.slope != nullptr, post = a.pscale != nullptr;
+  float amax = 0.f;
+  auto epilogue = [&](int item) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
+    const int row0 = tile_m * BM + wm * WM + lrow;
+    const int col0 = tile_n * BN + wn * 64;
+    if constexpr (EPI == 1) {
+      // after the swap, 16-lane row hq of the pair (2 p, 2 p + 1) holds channels 32 p + {0, 16, 8, 24}[hq] + 0..7 of its pixel
+      const int cs = ((hq & 1) << 4) | ((hq & 2) << 2);
+#pragma unroll
+      for (int p = 0; p < NI / 2; ++p) {
+        const int kb = col0 + 32 * p;                    // first channel of the 32-channel block
+        const int k0 = kb + cs;                          // first of this lane's 8 channels
+        float inv[8], bi[8], sl[8], ps[8], pt[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 s4 = dlip_buffer_load_f4(scr, (uint32_t)(k0 + 4 * q) * 4u);
+          const f32x4 b4 = dlip_buffer_load_f4(bir, (uint32_t)(k0 + 4 * q) * 4u);
+          f32x4 l4 = {1.f, 1.f, 1.f, 1.f}, p4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+          if (has_slope) l4 = dlip_buffer_load_f4(slr, (uint32_t)(k0 + 4 * q) * 4u);
+          if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)(k0 + 4 * q) * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)(k0 + 4 * q) * 4u); }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            inv[4 * q + c] = k0 + 4 * q + c < a.K ? 1.f / s4[c] : 0.f;   // power of two: exact
+            bi[4 * q + c] = b4[c]; sl[4 * q + c] = l4[c]; ps[4 * q + c] = p4[c]; pt[4 * q + c] = t4[c];
+          }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          float v[8];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[mi][2 * p][c]),
+                                                            __builtin_bit_cast(unsigned, acc[mi][2 * p + 1][c]), false, false);
+            v[c] = __builtin_bit_cast(float, r[0]);
+            v[4 + c] = __builtin_bit_cast(float, r[1]);
+          }
+          h8 hi, lo;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            float t = v[c] * inv[c] + bi[c];
+            t = t >= 0.f ? t : t * sl[c];
+            if (post) t = t * ps[c] + pt[c];
+            hi[c] = (_Float16)t;
+            lo[c] = (_Float16)(t - (float)hi[c]);
+            amax = fmaxf(amax, fabsf(t));
+          }
+          const int m = row0 + mi * 16;
+          const bool ok = m < a.M && k0 < a.K;           // K % 32 == 0 for a split output: a block is whole or absent
+          const uint32_t off = ok ? (uint32_t)((m * a.ldy + kb) * 4 + cs * 2) : DLIP_OOB_OFFSET;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), yr, (int)off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), yr, (int)(ok ? off + 64u : DLIP_OOB_OFFSET), 0, 0);
+        }
+        DLIP_FENCE();
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int k0 = col0 + 16 * ni + 4 * hq;
+        const f32x4 s4 = dlip_buffer_load_f4(scr, (uint32_t)k0 * 4u);
+        const f32x4 b4 = dlip_buffer_load_f4(bir, (uint32_t)k0 * 4u);
+        f32x4 l4 = {1.f, 1.f, 1.f, 1.f}, p4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+        if (has_slope) l4 = dlip_buffer_load_f4(slr, (uint32_t)k0 * 4u);
+        if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)k0 * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)k0 * 4u); }
+        f32x4 inv4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) inv4[c] = k0 + c < a.K ? 1.f / s4[c] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float t = acc[mi][ni][c] * inv4[c] + b4[c];
+            t = t >= 0.f ? t : t * l4[c];
+            if (post) t = t * p4[c] + t4[c];
+            v[c] = t;
+          }
+          const int m = row0 + mi * 16;
+          const uint32_t off = (m < a.M && k0 < a.K) ? (uint32_t)((m * a.ldy + k0) * 4) : DLIP_OOB_OFFSET;   // K % 4 == 0
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, (int)off, 0, 0);
+        }
+        DLIP_FENCE();
+      }
+    }
+  };
+
+  // ---- prologue: the first two slices of the stream in flight ----
+  constexpr std::integral_constant<int, NA_A> na_a{};
+  constexpr std::integral_constant<int, NA_B> na_b{};
+  set_item(c_item);
+  ROWS_STAMP(0);
+  if (!half_b) issue(0, na_a); else issue(0, na_b);
+  if (total > 1) {
+    advance();
+    if (!half_b) issue(1, na_a); else issue(1, na_b);
+  }
+  zero_acc();
+
+  // One half of the ping-pong loop; NL = this half's pieces per slice, FIRST = half A (reads a slice first).
+  //   interval between barriers   b(2s-1) .. b(2s)      |  b(2s) .. b(2s+1)
+  //   half A                      [EPI] LOAD(s)         |  MFMA(s), wait slice s+1
+  //   half B                      MFMA(s-1)             |  [EPI] LOAD(s), wait slice s+1
+  // LOAD(s): read every fragment of slice s (stage s % 3), issue this wave's pieces of slice s+2 into the stage of slice s-1
+  // (whose last reader finished before b(2s-1)), lgkmcnt(0).  [EPI]: when the previous matrix phase finished a tile, its
+  // epilogue runs first -- beside the partner's matrix phase -- and its NST stores are then the only vector-memory
+  // operations younger than slice s+1's pieces besides slice s+2's: the counted wait leaves them in flight too.
+  auto run_half = [&](auto na, auto first_c) {
+    constexpr int NL = decltype(na)::value + B_PER;
+    constexpr bool FIRST = decltype(first_c)::value;
+    static_assert(NL + NST < 64, "vmcnt is a 6-bit counter");
+    int st_iss = total > 1 ? 2 : 1;                        // stage the next issue goes to (the prologue issued slices 0, 1)
+    int kleft = nk, e_item = g, done_item = -1;
+    if (total > 1) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                          // slice 0 is complete
+    ROWS_STAMP(1);
+    if (!FIRST) __builtin_amdgcn_s_barrier();              // b(0): half A reads slice 0 first
+    for (int s = 0; s < total; ++s) {
+      bool did_epi = false;                                // (wave-uniform)
+      ROWS_SSTAMP(0);
+      if (done_item >= 0) { epilogue(done_item); zero_acc(); done_item = -1; did_epi = true; }
+      DLIP_FENCE();
+      const int stage = s - (s / 3) * 3;
+      read_all(stage);                                     // the reads first: their latency passes under the piece issue below
+      DLIP_FENCE();
+      const bool more2 = s + 2 < total;
+      if (more2) {
+        advance();
+        issue(st_iss, na);
+        st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1;
+      }
+      DLIP_FENCE();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage may be refilled behind the next barrier: the reads are done
+      DLIP_FENCE();
+      ROWS_SSTAMP(1);
+      auto wait_next = [&]() {                             // this wave's pieces of slice s + 1 have landed
+        if (s + 1 >= total) return;
+        if (more2) { if (did_epi) wait_vmcnt<NL + NST>(); else wait_vmcnt<NL>(); }
+        else       { if (did_epi) wait_vmcnt<NST>(); else wait_vmcnt<0>(); }
+      };
+      if (!FIRST) wait_next();                             // half B waits in front of the barrier that opens its matrix phase
+      ROWS_SSTAMP(2);
+      __builtin_amdgcn_s_barrier();                        // A: b(2s)      B: b(2s+1)
+      ROWS_SSTAMP(3);
+      mfma_all();
+      ROWS_SSTAMP(4);
+      if (--kleft == 0) { kleft = nk; done_item = e_item; e_item += nwg; }
+      if (FIRST) {
+        __builtin_amdgcn_s_barrier();                      // b(2s+1)
+        ROWS_SSTAMP(5);
+        // half A is the FIRST reader of slice s + 1 (its next load phase): its own pieces must have landed before ITS reads
+        wait_next();
+        ROWS_SSTAMP(6);
+      } else if (s + 1 < total) {
+        __builtin_amdgcn_s_barrier();                      // b(2s+2)
+        ROWS_SSTAMP(5);
+      }
+    }
+    ROWS_STAMP(2);
+    epilogue(done_item);                                   // the last tile's (total = n_my * nk: the stream ends on a tile's last slice)
+  };
+  if (!half_b) run_half(na_a, std::true_type{}); else run_half(na_b, std::false_type{});
+#undef DLIP_FENCE
+  if constexpr (EPI == 1) dlip_report_range(amax, a.status);
+  ROWS_STAMP(3);
+  if (span_me) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's stores have left
+    atomicMax(sc.span + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
+#ifdef DLIP_LAB
+  if (sc.stamps && tid == 0) sc.stamps[(size_t)g * 16 + 6] = __builtin_amdgcn_s_memrealtime() - sc.stamps[(size_t)g * 16 + 7];
+#endif
+}
+
+template <int MI, int EPI>
+int launch_rows(const ConvArgs& a, hipStream_t st) {
+  constexpr int BM = 32 * MI;
+  constexpr size_t lds = (size_t)3 * (BM + ROWS_BN) * ROWB;
+  static_assert(lds <= 160 * 1024, "LDS ring exceeds a CU");
+  ConvArgs b = a;
+  b.tiles_n = (a.K + ROWS_BN - 1) / ROWS_BN;
+  const long long tiles_m = ((long long)a.M + BM - 1) / BM;
+  const long long items = tiles_m * b.tiles_n;
+  if (items <= 0 || items > 0x3FFFFFFFll) return DLIP_EINVAL;
+  auto kern = conv_rows_f16x3_kernel<MI, EPI>;
+  static DlipKernelState ks;
+  int e = ks.ensure_lds(reinterpret_cast<const void*>(kern), lds);
+  if (e != DLIP_OK) return e;
+  int slots = 0;
+  e = ks.resident(reinterpret_cast<const void*>(kern), 512, lds, &slots);   // one workgroup per CU
+  if (e != DLIP_OK) return e;
+  RowsSched sc;
+  sc.items = (int)items;
+  sc.tiles_n = b.tiles_n;
+  sc.span = dlip_span_next();
+  const long long grid = items < slots ? items : slots;
+#ifdef DLIP_LAB
+  sc.stamps = nullptr;
+  if (getenv("DLIP_STAMP_PRINT")) {
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), 4096 * 16 * 8);
+    (void)hipMemsetAsync(dbuf, 0, 4096 * 16 * 8, st);
+    sc.stamps = dbuf;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, b, sc);
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> h((size_t)grid * 16);
+    (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
+    auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    std::vector<double> d[3], sl[6], clk;
+    for (long long i = 0; i < grid; ++i) {
+      const unsigned long long* r = &h[(size_t)i * 16];
+      if (!r[3]) continue;
+      for (int j = 0; j < 3; ++j) d[j].push_back((double)(r[j + 1] - r[j]));
+      if (r[6]) clk.push_back((double)(r[3] - r[0]) / (double)r[6] * 100.0);
+      if (r[14]) for (int j = 0; j < 6; ++j) sl[j].push_back((double)(r[9 + j] - r[8 + j]));
+    }
+    fprintf(stderr, "[rows stamps %dx%d M=%d K=%d nk=%d grid=%lld] first fill %.0f  stream %.0f (%.0f / slice)  last epilogue %.0f  clock %.0f MHz\n",
+            BM, ROWS_BN, b.M, b.K, b.nk, grid, med(d[0]), med(d[1]), med(d[1]) / (double)(((items + grid - 1) / grid) * b.nk), med(d[2]), med(clk));
+    fprintf(stderr, "[rows slice 8, wave 0 (half A)] epi+reads+issue %.0f  (wait) %.0f  barrier %.0f  matrix phase %.0f  barrier %.0f  wait next %.0f\n",
+            med(sl[0]), med(sl[1]), med(sl[2]), med(sl[3]), med(sl[4]), med(sl[5]));
+    return dlip_launch_status();
+  }
+#endif
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, b, sc);
+  return dlip_launch_status();
+}
+
+// Tile height.  A launch takes ceil(items / CUs) rounds of one tile-time ~ MI (+ a fixed part per round: first fill and the
+// exposed half of the last epilogue, about a slice and a half of a 16-slice tile); the fewest "row units" wins, the taller
+// tile on a tie (fewer bytes per MFMA).
+int rows_pick_mi(long long M, int K, int nk, int cus) {
+  const int tiles_n = (K + ROWS_BN - 1) / ROWS_BN;
+  int best = 5;
+  double best_cost = 1e300;
+  for (int mi = 5; mi >= 3; --mi) {
+    const long long items = ((M + 32 * mi - 1) / (32 * mi)) * tiles_n;
+    const long long rounds = (items + cus - 1) / cus;
+    const double cost = (double)rounds * (mi * (double)nk + 1.5 * 5.0) * (mi == 5 ? 1.0 : mi == 4 ? 1.04 : 1.10);
+    if (cost < best_cost * 0.999) { best_cost = cost; best = mi; }
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" int dlip_conv_dma_enabled(void);   // conv_igemm_f16x3.hip
+
+// Which launches the rows kernel serves: H = 1, one filter row, stride 1, no padding (every tap of every output row exists: a
+// plain row offset), whole 32-channel slices, no residual / second source / pooled epilogue, and enough rows and columns for its
+// 256-column tiles to be the right shape (the fully connected layers on a batch of utterances stay on the ring kernel's split).
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_ok(const void* args) {
+  const ConvArgs& a = *static_cast<const ConvArgs*>(args);
+  const int v = dlip_dbg_value[DLIP_DBG_ROWS];
+  if (v == 0) return 0;
+  const bool shape = a.H == 1 && a.R == 1 && a.sw == 1 && a.sh == 1 && a.ph == 0 && a.pw == 0 && (a.C & 31) == 0 && a.Cw == a.C &&
+                     a.res == nullptr && a.x2 == nullptr && a.pool == nullptr && a.S <= 32 && a.wscale != nullptr;
+  if (!shape) return 0;
+  if (v > 0) return 1;                                     // forced (tests)
+  return a.K >= 192 && a.M >= 4096;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_rows_launch(const void* args, void* stream, int epi) {
+  const ConvArgs& a = *static_cast<const ConvArgs*>(args);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return DLIP_EINVAL;
+  int mi = rows_pick_mi(a.M, a.K, a.nk, cus);
+  if (const int v = dlip_dbg_value[DLIP_DBG_ROWS]; v >= 3 && v <= 5) mi = v;   // dlip_debug_set: a forced tile height (tests, A/B)
+  switch (mi) {
+    case 3: return epi ? launch_rows<3, 1>(a, st) : launch_rows<3, 0>(a, st);
+    case 4: return epi ? launch_rows<4, 1>(a, st) : launch_rows<4, 0>(a, st);
+    default: return epi ? launch_rows<5, 1>(a, st) : launch_rows<5, 0>(a, st);
+  }
+}

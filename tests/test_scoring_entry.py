@@ -121,12 +121,13 @@ def _store(tmp_path, r, n_spk=9, per=5, D=512, trials=1500):
     spk = np.repeat(np.arange(n_spk), per)
     utts = [f"s{s}_l_u{i}.wav" for i, s in enumerate(spk)]                       # flat names like the A+V trial lists'
     ca, cv = r.normal(size=(n_spk, D)), r.normal(size=(n_spk, D))
-    audio = (ca[spk] + 2.5 * r.normal(size=(len(spk), D)) + 0.7).astype(np.float32)
-    fused = np.concatenate([audio, (cv[spk] + 2.5 * r.normal(size=(len(spk), D))).astype(np.float32)], 1)
+    audio = (ca[spk] + 3.0 * r.normal(size=(len(spk), D)) + 0.7).astype(np.float32)
+    fused = np.concatenate([audio, (cv[spk] + 3.0 * r.normal(size=(len(spk), D))).astype(np.float32)], 1)
     # lip store: 1-3 clip files per utterance, ragged frame counts, data [1, T, D]
     clips = {}
-    for u, s in zip(utts, spk):
-        clips[u] = [(cv[s] + 3.0 * r.normal(size=(1, int(r.integers(3, 40)), D)) - 0.3).astype(np.float32) for _ in range(int(r.integers(1, 4)))]
+    for u, s in zip(utts, spk):       # utterance-level scatter (frame noise averages out over the clip files; this does not)
+        off = 3.0 * r.normal(size=D)
+        clips[u] = [(cv[s] + off + 3.0 * r.normal(size=(1, int(r.integers(3, 40)), D)) - 0.3).astype(np.float32) for _ in range(int(r.integers(1, 4)))]
     pairs, y = [], []
     for _ in range(trials):
         a, b = r.integers(0, len(utts), 2)
