@@ -219,7 +219,7 @@ def ensure_conv_workspace() -> None:
 
 
 # ---- diagnostic overrides (tests, tools): dlip_debug_set ----
-DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK, DBG_WIN = 0, 1, 2, 3, 4
+DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK, DBG_WIN, DBG_NINNER, DBG_ROWS = 0, 1, 2, 3, 4, 5, 6
 
 
 def debug_set(key: int, value: int = -1) -> None:

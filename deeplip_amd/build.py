@@ -19,7 +19,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libdeeplip_hip.so")
-SOURCES = ["capi.hip", "plan.hip", "conv_igemm.hip", "conv_igemm_f16x3.hip", "conv_igemm_f16x3_dma.hip", "conv_win_f16x3.hip", "stem3d.hip", "stem3d_f16x3.hip", "pool_ops.hip", "score_ops.hip", "layout_ops.hip", "train_ops.hip", "encoder_train_ops.hip", "video_train_ops.hip", "frontend_ops.hip"]
+SOURCES = ["capi.hip", "plan.hip", "conv_igemm.hip", "conv_igemm_f16x3.hip", "conv_igemm_f16x3_dma.hip", "conv_win_f16x3.hip", "conv_rows_f16x3.hip", "stem3d.hip", "stem3d_f16x3.hip", "pool_ops.hip", "score_ops.hip", "layout_ops.hip", "train_ops.hip", "encoder_train_ops.hip", "video_train_ops.hip", "frontend_ops.hip"]
 ARCH = "gfx950"
 
 

@@ -331,6 +331,8 @@ extern "C" int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int ep
 extern "C" void dlip_conv_dma_tile(long long M, int K, int nk, int epi, int* bm, int* bn);
 extern "C" int dlip_conv_win_ok(const void* args);                                          // conv_win_f16x3.hip
 extern "C" int dlip_conv_f16x3_win_launch(const void* args, void* stream, int out_split);
+extern "C" int dlip_conv_rows_ok(const void* args);                                         // conv_rows_f16x3.hip
+extern "C" int dlip_conv_f16x3_rows_launch(const void* args, void* stream, int epi);
 
 // Diagnostic switch (dlip_debug_set DLIP_DBG_DMA_ENABLE = 0): keeps split-format launches on the register-staged kernel.
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_dma_enabled(void) { return dlip_dbg_value[DLIP_DBG_DMA_ENABLE] != 0; }
@@ -378,6 +380,8 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   if ((flags & 1) && dma_ok && res_ok && dlip_conv_dma_enabled()) {
     // narrow same-size 3x3 layers (layer 1: 64 -> 64): one activation window per channel slice instead of nine tap fetches
     if (dlip_conv_win_ok(&a)) return dlip_conv_f16x3_win_launch(&a, stream, (flags & 2) ? 1 : 0);
+    // the speech encoder's 1-D "valid" convolutions and k = 1 GEMMs over all frames: persistent 160 x 256 tiles, continuous slice stream
+    if (dlip_conv_rows_ok(&a)) return dlip_conv_f16x3_rows_launch(&a, stream, (flags & 2) ? 1 : 0);
     return dlip_conv_f16x3_dma_launch(&a, stream, (flags & 2) ? 1 : 0);
   }
   if (big) return DLIP_EINVAL;

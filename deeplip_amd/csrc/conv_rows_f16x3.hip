@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   // ---- issue cursor: the slice the NEXT pieces belong to (two slices ahead of the one being multiplied) ----
   int a_off[NA_A], b_off[B_PER];
   int c_item = g, c_k = 0, s_pos = 0, c0 = 0, x_tap = 0, w_tap = 0;
-  auto set_item = [&](int item) {
+  auto set_item = [&](int item) __attribute__((always_inline)) {
     const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
 #pragma unroll
     for (int j = 0; j < NA_A; ++j) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
     }
   };
-  auto advance = [&]() {   // channel slice outer, tap inner (the ring kernel's reduction order)
+  auto advance = [&]() __attribute__((always_inline)) {   // channel slice outer, tap inner (the ring kernel's reduction order)
     if (++c_k == nk) {
       c_k = 0; s_pos = 0; c0 = 0;
       c_item += nwg;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
     x_tap = s_pos * x_ds + c0 * 4;
     w_tap = (s_pos * a.Cw + c0) * 4;
   };
-  auto issue = [&](int stage, auto na) {
+  auto issue = [&](int stage, auto na) __attribute__((always_inline)) {
     const uint32_t base = piece0 + stage * STAGE_B;
 #pragma unroll
     for (int j = 0; j < na(); ++j)
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   f32x4 acc[MI][NI];
   f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
 #define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
-  auto zero_acc = [&]() {
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[mi][ni][e] = 0.f;
   };
-  auto read_all = [&](int stage) {
+  auto read_all = [&](int stage) __attribute__((always_inline)) {
     const float* Aw = smem + stage * (STAGE_B / 4) + a_frag;
     const float* Bw = smem + stage * (STAGE_B / 4) + b_frag;
 #pragma unroll
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + klo);
   };
-  auto mfma_all = [&]() {
+  auto mfma_all = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_s_setprio(2);   // the matrix phase outranks its SIMD partner's load phase
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   const __amdgpu_buffer_rsrc_t ptr_ = dlip_make_rsrc(a.pshift, a.pshift ? kbytes : 0u);
   const bool has_slope = a.slope != nullptr, post = a.pscale != nullptr;
   float amax = 0.f;
-  auto epilogue = [&](int item) {
+  auto epilogue = [&](int item) __attribute__((always_inline)) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
     const int row0 = tile_m * BM + wm * WM + lrow;
@@ -222,10 +222,12 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
           float v[8];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[mi][2 * p][c]),
-                                                            __builtin_bit_cast(unsigned, acc[mi][2 * p + 1][c]), false, false);
-            v[c] = __builtin_bit_cast(float, r[0]);
-            v[4 + c] = __builtin_bit_cast(float, r[1]);
+            // (__float_as_uint of a scalar copy: __builtin_bit_cast applied to the vector ELEMENT expression acc[..][c] makes this
+            // clang read element 0 for every c -- tools/probes/permlane16_swap.hip)
+            const float xc = acc[mi][2 * p][c], yc = acc[mi][2 * p + 1][c];
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(xc), __float_as_uint(yc), false, false);
+            v[c] = __uint_as_float(r[0]);
+            v[4 + c] = __uint_as_float(r[1]);
           }
           h8 hi, lo;
 #pragma unroll
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   // (whose last reader finished before b(2s-1)), lgkmcnt(0).  [EPI]: when the previous matrix phase finished a tile, its
   // epilogue runs first -- beside the partner's matrix phase -- and its NST stores are then the only vector-memory
   // operations younger than slice s+1's pieces besides slice s+2's: the counted wait leaves them in flight too.
-  auto run_half = [&](auto na, auto first_c) {
+  auto run_half = [&](auto na, auto first_c) __attribute__((always_inline)) {
     constexpr int NL = decltype(na)::value + B_PER;
     constexpr bool FIRST = decltype(first_c)::value;
     static_assert(NL + NST < 64, "vmcnt is a 6-bit counter");
@@ -306,13 +308,18 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
     __builtin_amdgcn_s_barrier();                          // slice 0 is complete
     ROWS_STAMP(1);
     if (!FIRST) __builtin_amdgcn_s_barrier();              // b(0): half A reads slice 0 first
-    for (int s = 0; s < total; ++s) {
+    int st_cur = 0;
+    for (int s = 0;; ++s) {
       bool did_epi = false;                                // (wave-uniform)
       ROWS_SSTAMP(0);
-      if (done_item >= 0) { epilogue(done_item); zero_acc(); done_item = -1; did_epi = true; }
+      if (done_item >= 0) {
+        epilogue(done_item);
+        if (s == total) break;                             // the stream ends on a tile's last slice (total = n_my * nk)
+        zero_acc(); done_item = -1; did_epi = true;
+      }
       DLIP_FENCE();
-      const int stage = s - (s / 3) * 3;
-      read_all(stage);                                     // the reads first: their latency passes under the piece issue below
+      read_all(st_cur);                                    // the reads first: their latency passes under the piece issue below
+      st_cur = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
       DLIP_FENCE();
       const bool more2 = s + 2 < total;
       if (more2) {
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage may be refilled behind the next barrier: the reads are done
       DLIP_FENCE();
       ROWS_SSTAMP(1);
-      auto wait_next = [&]() {                             // this wave's pieces of slice s + 1 have landed
+      auto wait_next = [&]() __attribute__((always_inline)) {   // this wave's pieces of slice s + 1 have landed
         if (s + 1 >= total) return;
         if (more2) { if (did_epi) wait_vmcnt<NL + NST>(); else wait_vmcnt<NL>(); }
         else       { if (did_epi) wait_vmcnt<NST>(); else wait_vmcnt<0>(); }
@@ -348,7 +355,6 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       }
     }
     ROWS_STAMP(2);
-    epilogue(done_item);                                   // the last tile's (total = n_my * nk: the stream ends on a tile's last slice)
   };
   if (!half_b) run_half(na_a, std::true_type{}); else run_half(na_b, std::false_type{});
 #undef DLIP_FENCE
@@ -439,15 +445,31 @@ extern "C" int dlip_conv_dma_enabled(void);   // conv_igemm_f16x3.hip
 // Which launches the rows kernel serves: H = 1, one filter row, stride 1, no padding (every tap of every output row exists: a
 // plain row offset), whole 32-channel slices, no residual / second source / pooled epilogue, and enough rows and columns for its
 // 256-column tiles to be the right shape (the fully connected layers on a batch of utterances stay on the ring kernel's split).
+static bool rows_shape_ok(int H, int R, int S, int sh, int sw, int ph, int pw, int C, int K, long long M) {
+  const int v = dlip_dbg_value[DLIP_DBG_ROWS];
+  if (v == 0 || !dlip_conv_dma_enabled()) return false;
+  if (!(H == 1 && R == 1 && sw == 1 && sh == 1 && ph == 0 && pw == 0 && (C & 31) == 0 && S <= 32)) return false;
+  if (v > 0) return true;                                  // forced (tests)
+  return K >= 192 && M >= 4096;
+}
+
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_ok(const void* args) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
-  const int v = dlip_dbg_value[DLIP_DBG_ROWS];
-  if (v == 0) return 0;
-  const bool shape = a.H == 1 && a.R == 1 && a.sw == 1 && a.sh == 1 && a.ph == 0 && a.pw == 0 && (a.C & 31) == 0 && a.Cw == a.C &&
-                     a.res == nullptr && a.x2 == nullptr && a.pool == nullptr && a.S <= 32 && a.wscale != nullptr;
-  if (!shape) return 0;
-  if (v > 0) return 1;                                     // forced (tests)
-  return a.K >= 192 && a.M >= 4096;
+  return a.Cw == a.C && a.res == nullptr && a.x2 == nullptr && a.pool == nullptr && a.wscale != nullptr &&
+         rows_shape_ok(a.H, a.R, a.S, a.sh, a.sw, a.ph, a.pw, a.C, a.K, a.M);
+}
+
+// The same decision from a descriptor (dlip_conv_kernel_kind / dlip_conv_plan: which kernel and tile a profiler will show for a
+// split-format launch of `d` without a residual); *bm = the tile height the launch will use.
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_plan(const dlip_conv_desc* d, int* bm) {
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  if (d->ldr != 0 || !rows_shape_ok(d->H, d->R, d->S, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->C, d->K, M)) return 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int mi = rows_pick_mi(M, d->K, d->S * (d->C / 32), cus > 0 ? cus : 256);
+  if (const int v = dlip_dbg_value[DLIP_DBG_ROWS]; v >= 3 && v <= 5) mi = v;
+  if (bm) *bm = 32 * mi;
+  return 1;
 }
 
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_rows_launch(const void* args, void* stream, int epi) {

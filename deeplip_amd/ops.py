@@ -105,8 +105,11 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
         mode = 0 if w_scale is None else (3 if x_split else 1)
         check(lib().dlip_conv_plan(C.byref(d), mode, C.byref(bm), C.byref(bn)), "dlip_conv_plan")
         kname = ("conv_igemm_f32_kernel", "conv_igemm_f16x3_kernel", "", "conv_igemm_f16x3_dma_kernel")[mode]
-        if mode == 3 and lib().dlip_conv_kernel_kind(C.byref(d)) == 1:
+        kind = lib().dlip_conv_kernel_kind(C.byref(d)) if mode == 3 else 0
+        if kind == 1:
             kname, bm.value, bn.value = "conv_win_f16x3_kernel", 128, (128 if K > 64 else 64)
+        elif kind == 2:      # (d.ldr == 0 there: the rows kernel takes no residual)
+            kname = "conv_rows_f16x3_kernel"
         tok = hook.begin(f"{kname}<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
     if w_scale is not None:
         if x_split:

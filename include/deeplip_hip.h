@@ -156,7 +156,9 @@ int dlip_split_unpack_f32(const float* x, float* y, int64_t rows, int32_t C, dli
 int dlip_conv_plan(const dlip_conv_desc* d, int32_t split_f16, int32_t* bm, int32_t* bn);
 /* 1 if a split-format (DLIP_SPLIT_IN) launch of `d` runs on the window kernel (conv_win_f16x3_kernel<128,64> for K <= 64, <128,128> above: same-size
  * stride-1 3x3 convolutions with K <= 128 -- one activation window per channel slice in LDS instead of one fetch per
- * tap), 0 if on the LDS-DMA ring kernel dlip_conv_plan describes.  Host-only. */
+ * tap), 2 if (without a residual) on the rows kernel (conv_rows_f16x3_kernel: the speech encoder's 1-D valid convolutions and
+ * k = 1 GEMMs over all frames; dlip_conv_plan then reports its BM x 256 tile), 0 if on the LDS-DMA ring kernel dlip_conv_plan
+ * describes.  Host-only. */
 int dlip_conv_kernel_kind(const dlip_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------
@@ -615,7 +617,8 @@ int dlip_range_scope_end(dlip_stream_t stream);
 /* Diagnostic overrides for tests and A/B runs (the launch path reads no environment variable):
  * key 0 tile of dlip_conv_nhwc_f32 / the register-staged f16x3 kernel, 1 tile of the LDS-DMA kernel,
  * 2 LDS-DMA kernel on/off (0 = off), 3 balanced split (0 never, 2 always), 4 window kernel on/off (0 = off),
- * 5 tile order of the LDS-DMA kernel (0 column block outer, 1 inner);
+ * 5 tile order of the LDS-DMA kernel (0 column block outer, 1 inner), 6 rows kernel (conv_rows_f16x3.hip: 0 = off, 1 = on for
+ * every launch of its shape class whatever the size, 3 | 4 | 5 = on with that tile height in units of 32 rows);
  * value -1 restores the built-in choice. */
 int dlip_debug_set(int32_t key, int32_t value);
 

@@ -1034,3 +1034,111 @@ def test_split_pack_scaled_with_padded_rows(ops):
     check(lib().dlip_split_pack_scaled_pad_f32(ptr(x), ptr(b), ptr(sc), rows, C, Cp, stream_handle()), "dlip_split_pack_scaled_pad_f32")
     torch.cuda.synchronize()
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+# ---- round 4: the rows kernel (conv_rows_f16x3.hip): 1-D valid convolutions / k = 1 GEMMs over all frames ----
+ROWS_CASES = [  # B, T, C, K, S (taps), dilation, post-affine (conv -> LReLU -> BN order), what it stands for
+    (3, 300, 512, 512, 1, 1, False),     # k = 1 TDNN layer, ragged last row tile
+    (2, 292, 512, 512, 3, 2, False),     # dilated TDNN layer: rows shift by 2 * dil per utterance (T' = T - 4)
+    (2, 150, 96, 512, 5, 1, True),       # tdnn.0 with 80 features padded to 96: 3 slices x 5 taps, post-affine order
+    (2, 278, 512, 1500, 1, 1, False),    # tdnn.9's shape: K tail (1500 = 5 x 256 + 220)
+    (1, 40, 64, 256, 1, 1, False),       # one partial tile, K = one column block
+    (1, 700, 32, 288, 2, 3, True),       # a single channel slice, two taps, K tail of one 32-channel block
+    (5, 200, 128, 512, 1, 1, False),     # several tiles per workgroup when the grid is capped (see the persistent test)
+]
+
+
+@pytest.fixture
+def force_rows():
+    from deeplip_amd import _lib
+    yield lambda v: _lib.debug_set(_lib.DBG_ROWS, v)
+    _lib.debug_set(_lib.DBG_ROWS, -1)
+    _lib.debug_set(_lib.DBG_STREAMK, -1)
+
+
+def _rows_inputs(case, seed=0):
+    from deeplip_amd import packing
+    B, T, C, K, S, dil, post = case
+    x = _split_ref_value(rnd(B, T, C, seed=71 + seed) * 2.0)
+    w = rnd(K, S, C, seed=72 + seed, scale=1.0 / np.sqrt(C * S))
+    b = rnd(K, seed=73 + seed, scale=0.1)
+    slope = torch.rand(K, generator=torch.Generator().manual_seed(11)) * 0.3
+    ws, sc = packing.split_weights(w.double())
+    kw = dict(dilation=dil, slope=slope.cuda(), w_scale=sc.cuda(), x_split=True)
+    ps = pt = None
+    if post:
+        ps = 0.5 + torch.rand(K, generator=torch.Generator().manual_seed(12))
+        pt = rnd(K, seed=13, scale=0.1)
+        kw.update(post_scale=ps.cuda(), post_shift=pt.cuda())
+    ref = F.conv1d(x.permute(0, 2, 1).double(), w.permute(0, 2, 1).double(), b.double(), dilation=dil)
+    ref = torch.where(ref >= 0, ref, ref * slope.double().view(1, K, 1))
+    if post:
+        ref = ref * ps.double().view(1, K, 1) + pt.double().view(1, K, 1)
+    return x, ws, b, kw, ref.permute(0, 2, 1)
+
+
+@pytest.mark.parametrize("mi", [3, 4, 5])
+@pytest.mark.parametrize("case", ROWS_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_conv_rows_kernel(ops, case, mi, force_rows):
+    """conv_rows_f16x3_kernel<MI, split | fp32 output> forced onto 1-D valid convolutions: (1) against an fp64 statement of
+    Conv1d + bias + LeakyReLU (+ BatchNorm behind it) of tdnn.py:35-43; (2) BIT FOR BIT the ring kernel's plain launch of
+    the same convolution -- same slice order, same product order per accumulator, same epilogue arithmetic -- for the split
+    output (v_permlane16_swap pieces) and the fp32 output alike."""
+    from deeplip_amd import _lib
+    x, ws, b, kw, ref = _rows_inputs(case)
+    xs = ops.split_pack(x.cuda())
+    K = case[3]
+    outs = {}
+    for which in ("ring", "rows"):
+        force_rows(0 if which == "ring" else mi)
+        _lib.debug_set(_lib.DBG_STREAMK, 0)                      # the ring kernel as a plain launch: one workgroup per tile
+        for out_split in ((True, False) if K % 32 == 0 else (False,)):
+            y = ops.conv1d_ntc(xs, ws.cuda(), b.cuda(), out_split=out_split, **kw)
+            outs[which, out_split] = y.clone()
+    torch.cuda.synchronize()
+    for (which, out_split), y in outs.items():
+        yv = ops.split_unpack(y) if out_split else y
+        assert yv.shape == ref.shape
+        assert rel_err(yv.cpu().numpy(), ref.numpy()) < TOL, (which, out_split)
+    for out_split in ((True, False) if K % 32 == 0 else (False,)):
+        assert torch.equal(outs["rows", out_split].view(torch.int32), outs["ring", out_split].view(torch.int32)), out_split
+
+
+def test_conv_rows_kernel_is_chosen_for_the_speech_encoder_shapes(ops):
+    """dlip_conv_kernel_kind / dlip_conv_plan: at the bench's batch the TDNN layers go to the rows kernel with a one-round tile
+    (B = 64, T' = 296: 119 row tiles of 160 x 2 column blocks on 256 CUs), a fully connected layer on a batch does not."""
+    import ctypes as C
+    from deeplip_amd import _lib
+    from deeplip_amd.ops import ConvDesc
+
+    def kind(N, W, Cin, K, S, dil, ldr=0):
+        Wo = W - dil * (S - 1)
+        d = ConvDesc(N, 1, W, Cin, K, 1, S, 1, 1, 0, 0, 1, dil, 1, Wo, Cin, K, ldr)
+        bm, bn = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().dlip_conv_plan(C.byref(d), 3, C.byref(bm), C.byref(bn)), "dlip_conv_plan")
+        return _lib.lib().dlip_conv_kernel_kind(C.byref(d)), bm.value, bn.value
+
+    assert kind(64, 296, 512, 512, 1, 1) == (2, 160, 256)
+    assert kind(64, 300, 512, 512, 3, 2)[0] == 2
+    assert kind(256, 278, 512, 1500, 1, 1)[0] == 2
+    assert kind(64, 1, 3008, 512, 1, 1)[0] == 0            # fc1 on 64 utterances: M = 64
+    assert kind(64, 296, 512, 512, 1, 1, ldr=512)[0] == 0  # a residual: the ring kernel
+
+
+def test_conv_rows_persistent_stream_across_tiles(ops, force_rows):
+    """More tiles than CUs: every workgroup walks several tiles with one continuous slice stream (a tile's last slices have
+    the next tile's first ones in flight; the epilogue's stores are counted in the vmcnt waits behind it).  B x T' rows far
+    beyond 256 tiles of 96 rows; bit-identical to the ring kernel, repeatable."""
+    from deeplip_amd import _lib
+    case = (40, 300, 128, 512, 3, 1, False)                  # M = 11 920 -> 125 x 2 = 250 tiles at MI = 3 ... use more rows:
+    case = (130, 300, 128, 512, 3, 1, False)                 # M = 38 740 -> 404 x 2 = 808 tiles of 96 x 256: 3.2 per CU
+    x, ws, b, kw, ref = _rows_inputs(case, seed=5)
+    xs = ops.split_pack(x.cuda())
+    force_rows(0)
+    _lib.debug_set(_lib.DBG_STREAMK, 0)
+    want = ops.conv1d_ntc(xs, ws.cuda(), b.cuda(), out_split=True, **kw).clone()
+    force_rows(3)
+    got = [ops.conv1d_ntc(xs, ws.cuda(), b.cuda(), out_split=True, **kw).clone() for _ in range(2)]
+    torch.cuda.synchronize()
+    assert torch.equal(got[0].view(torch.int32), want.view(torch.int32)) and torch.equal(got[0], got[1])
+    assert rel_err(ops.split_unpack(got[0]).cpu().numpy(), ref.numpy()) < TOL
