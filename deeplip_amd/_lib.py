@@ -222,8 +222,12 @@ def ensure_conv_workspace() -> None:
 DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK, DBG_WIN, DBG_NINNER, DBG_ROWS = 0, 1, 2, 3, 4, 5, 6
 
 
+DEBUG = {}          # what this process set through debug_set (key -> value; -1 / absent = the built-in choice)
+
+
 def debug_set(key: int, value: int = -1) -> None:
     check(lib().dlip_debug_set(key, value), "dlip_debug_set")
+    DEBUG[key] = value
 
 
 # ---- range status of the f16x3 arithmetic: eight words in host-pinned, device-visible memory ----

@@ -333,6 +333,8 @@ extern "C" int dlip_conv_win_ok(const void* args);                              
 extern "C" int dlip_conv_f16x3_win_launch(const void* args, void* stream, int out_split);
 extern "C" int dlip_conv_rows_ok(const void* args);                                         // conv_rows_f16x3.hip
 extern "C" int dlip_conv_f16x3_rows_launch(const void* args, void* stream, int epi);
+extern "C" int dlip_conv_rows_plan(const dlip_conv_desc* d, int* bm);
+extern "C" int dlip_conv_rows_pool_plan(const dlip_conv_desc* d, int* bm);
 
 // Diagnostic switch (dlip_debug_set DLIP_DBG_DMA_ENABLE = 0): keeps split-format launches on the register-staged kernel.
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_dma_enabled(void) { return dlip_dbg_value[DLIP_DBG_DMA_ENABLE] != 0; }
@@ -457,6 +459,9 @@ extern "C" int64_t dlip_conv_pool_partial_bytes(const dlip_conv_desc* d, int32_t
   int bm = 0, bn = 0;
   const long long M = (long long)d->N * d->Ho * d->Wo;
   dlip_conv_dma_tile(M, d->K, d->R * d->S * ((d->C + 31) / 32), 2, &bm, &bn);
+  // the rows kernel's pooled epilogue (conv_rows_f16x3.hip): one partial row set per WAVE ROW = half of its BM x 256 tile; columns
+  // rounded up to 128 like the ring kernel's, so both feed the same finishers
+  if (int rbm = 0; dlip_conv_rows_pool_plan(d, &rbm)) { bm = rbm / 2; bn = 128; }
   if (tile_rows) *tile_rows = bm;
   const long long tiles_m = (M + bm - 1) / bm, Kp = (long long)(d->K + bn - 1) / bn * bn;
   return tiles_m * 4 * Kp * 8;
@@ -480,6 +485,7 @@ extern "C" int dlip_conv_pool_f16x3(const dlip_conv_desc* d, const float* x, con
   a.y = nullptr; a.y_bytes = 0;
   a.pool = partials;
   a.pool_group = group_rows;
+  if (residual == nullptr && dlip_conv_rows_pool_plan(d, nullptr) && dlip_conv_rows_ok(&a)) return dlip_conv_f16x3_rows_launch(&a, stream, 2);
   return dlip_conv_f16x3_dma_launch(&a, stream, 2);
 }
 

@@ -47,7 +47,8 @@ struct RowsSched {
 
 constexpr int ROWS_BN = 256;
 
-// EPI: 0 fp32 rows of y; 1 split-format rows of y (reports range)
+// EPI: 0 fp32 rows of y; 1 split-format rows of y (reports range); 2 no y: per HALF tile (the 16 MI rows of a wave row) and
+// row-group segment the fp64 column sums of v and v^2 (a.pool, the ring kernel's pooled epilogue with tile rows = 16 MI)
 template <int MI, int EPI>
 __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs a, const RowsSched sc) {
   constexpr int NW = 8, BN = ROWS_BN, BM = 32 * MI, NI = 4;
@@ -57,7 +58,10 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   static_assert(A_PIECES % 8 == 0 || A_PIECES % 8 == 4, "waves 0-3 take one activation piece more than waves 4-7, or the same");
   constexpr int STAGE_B = (BM + BN) * ROWB, NSTAGE = 3;
   constexpr int LDK = 32;
-  constexpr int NST = EPI == 1 ? MI * 4 : MI * NI;   // 16-B output stores per lane and tile
+  // output stores per lane and tile that the counted waits behind an epilogue may leave in flight: a LOWER bound of what the
+  // epilogue issues (a larger number would let the wait return before the next slice's pieces have landed).  The pooled
+  // epilogue's few stores are issued under lane masks: not counted, i.e. waited for.
+  constexpr int NST = EPI == 1 ? MI * 4 : EPI == 0 ? MI * NI : 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -244,6 +248,60 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
           const uint32_t off = ok ? (uint32_t)((m * a.ldy + kb) * 4 + cs * 2) : DLIP_OOB_OFFSET;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), yr, (int)off, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), yr, (int)(ok ? off + 64u : DLIP_OOB_OFFSET), 0, 0);
+        }
+        DLIP_FENCE();
+      }
+    } else if constexpr (EPI == 2) {
+      // Pooled: nothing is written but, per wave ROW (its 16 MI rows are one "tile" of the partials: tile index 2 tile_m + wm) and
+      // row-group segment, the column sums of v and v^2 -- fp64, fixed order: a lane adds its MI pixels, the 16 lanes of a
+      // channel quad meet by butterfly, lane 0 of each quad stores.  Rows before the half tile's one possible group boundary
+      // are segment 0, the rest segment 1 (pool_group >= 16 MI); dlip_pool_finish_f32 / znorm_cat_pooled add the tiles in row order.
+      const int m0 = tile_m * BM + wm * WM;
+      const int rb = (m0 / a.pool_group + 1) * a.pool_group - m0;
+      const int Kp = (a.K + 127) / 128 * 128;
+      double* prow = a.pool + (size_t)(2 * tile_m + wm) * 4 * Kp;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int k0 = col0 + 16 * ni + 4 * hq;
+        const f32x4 s4 = dlip_buffer_load_f4(scr, (uint32_t)k0 * 4u);
+        const f32x4 b4 = dlip_buffer_load_f4(bir, (uint32_t)k0 * 4u);
+        f32x4 l4 = {1.f, 1.f, 1.f, 1.f}, p4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+        if (has_slope) l4 = dlip_buffer_load_f4(slr, (uint32_t)k0 * 4u);
+        if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)k0 * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)k0 * 4u); }
+        f32x4 inv4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) inv4[c] = k0 + c < a.K ? 1.f / s4[c] : 0.f;
+        double st[4][4];   // [sum0, sumsq0, sum1, sumsq1][channel]
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) st[q][c] = 0.0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int r = mi * 16 + lrow;
+          const bool in = m0 + r < a.M, seg1 = r >= rb;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float t = acc[mi][ni][c] * inv4[c] + b4[c];
+            t = t >= 0.f ? t : t * l4[c];
+            if (post) t = t * p4[c] + t4[c];
+            const double d = in ? (double)t : 0.0;
+            st[0][c] += seg1 ? 0.0 : d; st[1][c] += seg1 ? 0.0 : d * d;
+            st[2][c] += seg1 ? d : 0.0; st[3][c] += seg1 ? d * d : 0.0;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) st[q][c] += __shfl_xor(st[q][c], o, 64);
+        if (lrow == 0 && m0 < a.M) {   // (a last tile's second half may lie wholly beyond M: it has no partial row set)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (k0 + c < Kp) prow[(size_t)q * Kp + k0 + c] = st[q][c];
         }
         DLIP_FENCE();
       }
@@ -455,7 +513,7 @@ static bool rows_shape_ok(int H, int R, int S, int sh, int sw, int ph, int pw, i
 
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_ok(const void* args) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
-  return a.Cw == a.C && a.res == nullptr && a.x2 == nullptr && a.pool == nullptr && a.wscale != nullptr &&
+  return a.Cw == a.C && a.res == nullptr && a.x2 == nullptr && a.wscale != nullptr &&
          rows_shape_ok(a.H, a.R, a.S, a.sh, a.sw, a.ph, a.pw, a.C, a.K, a.M);
 }
 
@@ -472,6 +530,15 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_plan(const d
   return 1;
 }
 
+// The pooled epilogue on this kernel is correct and tested, and slower than the ring kernel's LDS-staged one: the fp64 column
+// sums taken straight from the accumulators cost ~13 us per tile in cross-lane work (64 doubles x 4 butterfly steps per channel
+// quad), tdnn.9 at B = 64: 130 us against 96 us on the ring kernel's <128,128,pool> instance (tools/bench_rows.py).  So a
+// pooled launch comes here only when the rows kernel is FORCED (dlip_debug_set(6, 1 | 3 | 4 | 5): tests, A/B runs).
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_pool_plan(const dlip_conv_desc* d, int* bm) {
+  if (dlip_dbg_value[DLIP_DBG_ROWS] <= 0) return 0;
+  return dlip_conv_rows_plan(d, bm);
+}
+
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_rows_launch(const void* args, void* stream, int epi) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -480,6 +547,14 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_rows_launch
     return DLIP_EINVAL;
   int mi = rows_pick_mi(a.M, a.K, a.nk, cus);
   if (const int v = dlip_dbg_value[DLIP_DBG_ROWS]; v >= 3 && v <= 5) mi = v;   // dlip_debug_set: a forced tile height (tests, A/B)
+  if (epi == 2) {   // pooled: a half tile (16 mi rows) may contain at most one row-group boundary
+    if (a.pool == nullptr || a.pool_group < 16 * mi) return DLIP_EINVAL;
+    switch (mi) {
+      case 3: return launch_rows<3, 2>(a, st);
+      case 4: return launch_rows<4, 2>(a, st);
+      default: return launch_rows<5, 2>(a, st);
+    }
+  }
   switch (mi) {
     case 3: return epi ? launch_rows<3, 1>(a, st) : launch_rows<3, 0>(a, st);
     case 4: return epi ? launch_rows<4, 1>(a, st) : launch_rows<4, 0>(a, st);

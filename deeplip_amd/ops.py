@@ -215,7 +215,10 @@ def conv_pool(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor], w_scale: Tensor
     part = _empty((nbytes // 8,), x.device, torch.float64)
     hook = LAUNCH_HOOK
     if hook is not None:
-        tok = hook.begin(f"conv_igemm_f16x3_dma_kernel<{bm.value},128,pool>", 2.0 * N * Ho * Wo * K * R * S * Cx)
+        # the rows kernel (pooled launches go there only when it is forced: dlip_debug_set) reports HALF its tile as partial rows
+        rows = residual is None and _lib.DEBUG.get(_lib.DBG_ROWS, -1) > 0 and lib().dlip_conv_kernel_kind(C.byref(d)) == 2
+        tok = hook.begin(f"conv_rows_f16x3_kernel<{2 * bm.value},256,pool>" if rows else f"conv_igemm_f16x3_dma_kernel<{bm.value},128,pool>",
+                         2.0 * N * Ho * Wo * K * R * S * Cx)
     _lib.ensure_conv_workspace()
     check(lib().dlip_conv_pool_f16x3(C.byref(d), ptr(x), ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(residual), ptr(slope),
                                      ptr(post_scale), ptr(post_shift), ptr(part), nbytes, group_rows, stream_handle()),

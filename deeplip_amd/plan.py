@@ -91,6 +91,10 @@ class _NameHook:
         pass
 
 
+# kernels that time themselves inside a span scope (dlip_span_next in their launch path), as ops.LAUNCH_HOOK names them
+SPAN_KERNELS = ("conv_igemm_f16x3_dma_kernel", "conv_rows_f16x3_kernel")
+
+
 class StepPlan:
     """``fn(*inputs)`` recorded on a private HIP stream; see the module docstring."""
 
@@ -157,7 +161,7 @@ class StepPlan:
                 if names is not None:
                     used = C.c_int32()
                     lib().dlip_span_scope_end(torch.cuda.current_stream(self.device).cuda_stream, C.byref(used))
-                    self.span_names = [x for x in names.seen if "conv_igemm_f16x3_dma_kernel" in x[0]]
+                    self.span_names = [x for x in names.seen if any(k in x[0] for k in SPAN_KERNELS)]
                     if len(self.span_names) != used.value:
                         raise DeepLipHipError(f"StepPlan spans: {used.value} timed launches but {len(self.span_names)} named ones")
             return out

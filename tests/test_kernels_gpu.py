@@ -1142,3 +1142,46 @@ def test_conv_rows_persistent_stream_across_tiles(ops, force_rows):
     torch.cuda.synchronize()
     assert torch.equal(got[0].view(torch.int32), want.view(torch.int32)) and torch.equal(got[0], got[1])
     assert rel_err(ops.split_unpack(got[0]).cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("mi", [3, 5])
+@pytest.mark.parametrize("case", [c for c in POOL_CASES if c[1] == 1], ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_rows_pooled_epilogue(ops, case, mi, force_rows):
+    """The rows kernel's pooled epilogue (per wave row and row-group segment the fp64 column sums, straight from the
+    accumulators) feeds the same finishers as the ring kernel's: group mean, mean | unbiased std (pooling.py:24-26), and the
+    two agree to fp32 rounding; repeatable bits."""
+    from deeplip_amd import packing
+    N, H, W, C, K, R, S, pad, dil, group, use_res, post = case
+    x = _split_ref_value(rnd(N, H, W, C, seed=61) * 2.0)
+    w = rnd(K, R, S, C, seed=62, scale=1.0 / np.sqrt(C * R * S))
+    b = rnd(K, seed=63, scale=0.1)
+    slope = (torch.rand(K, generator=torch.Generator().manual_seed(7)) * 0.3).cuda()
+    ws, sc = packing.split_weights(w.double())
+    kw = dict(pad=(0, pad), dil=(1, dil), slope=slope)
+    if post:
+        kw["post_scale"] = (0.5 + torch.rand(K, generator=torch.Generator().manual_seed(8))).cuda()
+        kw["post_shift"] = rnd(K, seed=9, scale=0.1).cuda()
+    xs = ops.split_pack(x.cuda())
+    force_rows(0)
+    full = ops.conv_nhwc(xs, ws.cuda(), b.cuda(), w_scale=sc.cuda(), x_split=True, **kw)
+    ring = ops.conv_pool(xs, ws.cuda(), b.cuda(), sc.cuda(), group, **kw)
+    ring_ms = ops.pool_finish(ring, "meanstd")
+    force_rows(mi)
+    if group < 16 * mi:
+        with pytest.raises(ValueError):
+            ops.conv_pool(xs, ws.cuda(), b.cuda(), sc.cuda(), group, **kw)
+        return
+    pooled = ops.conv_pool(xs, ws.cuda(), b.cuda(), sc.cuda(), group, **kw)
+    assert pooled.tile_rows == 16 * mi
+    ms = ops.pool_finish(pooled, "meanstd")
+    mean = ops.pool_finish(pooled, "mean")
+    again = ops.pool_finish(ops.conv_pool(xs, ws.cuda(), b.cuda(), sc.cuda(), group, **kw), "meanstd")
+    torch.cuda.synchronize()
+    rows = full.reshape(-1, K).double().cpu()
+    G = (rows.shape[0] + group - 1) // group
+    ref_mean = torch.stack([rows[g * group:(g + 1) * group].mean(0) for g in range(G)])
+    ref_std = torch.stack([rows[g * group:(g + 1) * group].std(0) for g in range(G)])
+    assert rel_err(mean.cpu().numpy(), ref_mean.numpy()) < 1e-6
+    assert rel_err(ms[:, :K].cpu().numpy(), ref_mean.numpy()) < 1e-6 and rel_err(ms[:, K:].cpu().numpy(), ref_std.numpy()) < 1e-6
+    assert rel_err(ms.cpu().numpy(), ring_ms.cpu().numpy()) < 1e-6      # (the ring launch may split its reduction: another summation order)
+    assert torch.equal(again, ms)
