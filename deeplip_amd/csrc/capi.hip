@@ -104,21 +104,25 @@ struct SpanScope {
 };
 thread_local SpanScope g_span;
 
-// pair i = {min start, max end} of one launch in 100 MHz ticks -> acc[2 i] += end - start, acc[2 i + 1] += 1; the pair is re-armed
+// record i = {min start, -, .., 8 x max end by workgroup shard} of one launch in 100 MHz ticks -> acc[2 i] += max end - start,
+// acc[2 i + 1] += 1; the record is re-armed
 __global__ __launch_bounds__(256) void span_collect_kernel(unsigned long long* pairs, unsigned long long* acc, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const unsigned long long t0 = pairs[2 * i], t1 = pairs[2 * i + 1];
+  unsigned long long* r = pairs + (size_t)DLIP_SPAN_WORDS * i;
+  const unsigned long long t0 = r[0];
+  unsigned long long t1 = 0ull;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { t1 = r[8 + k] > t1 ? r[8 + k] : t1; r[8 + k] = 0ull; }
   if (t1 != 0ull && t1 >= t0) { acc[2 * i] += t1 - t0; acc[2 * i + 1] += 1ull; }
-  pairs[2 * i] = ~0ull;
-  pairs[2 * i + 1] = 0ull;
+  r[0] = ~0ull;
 }
 }  // namespace
 
 unsigned long long* dlip_span_next(void) {
   SpanScope& sc = g_span;
   if (sc.pairs == nullptr || sc.cur >= sc.n) return nullptr;
-  return sc.pairs + 2 * (sc.cur++);
+  return sc.pairs + (size_t)DLIP_SPAN_WORDS * (sc.cur++);
 }
 
 extern "C" int dlip_span_scope_begin(uint64_t* pairs, uint64_t* acc, int32_t n) {

@@ -66,6 +66,9 @@ struct ConvArgs {
   // consecutive taps are adjacent 128-byte lines.
   int Hs;               // rows between two images of x (H, or slices * H)
   int cs_x, wt, cs_w;   // bytes: slice stride of x, tap stride and slice stride of the filter rows
+  // ---- the window kernel (conv_win_f16x3.hip): NULL, or this launch's {first start, last end} pair in 100 MHz ticks (dlip_span_scope_*;
+  // the ring and rows kernels carry theirs in their schedule blocks)
+  unsigned long long* span;
 };
 
 
@@ -119,6 +122,7 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
   a.div_wo = dlip_fastdiv((uint32_t)a.Wo);
   a.n_inner = 0;
   a.Hs = d->H; a.cs_x = 128; a.wt = Cw * 4; a.cs_w = 128;
+  a.span = nullptr;
   return DLIP_OK;
 }
 

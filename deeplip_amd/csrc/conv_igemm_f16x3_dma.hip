@@ -171,13 +171,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const int nk1 = a.nk - (DUAL ? a.nk2 : 0);   // slices of the first source
 
   const long long it_begin = (long long)g * sk.iters / sk.G, it_end = (long long)(g + 1) * sk.iters / sk.G;
-  // In-kernel span of this launch (measurement only, off unless a span scope is open: one scalar test): every workgroup folds the
-  // constant 100 MHz clock into {min at entry, max at exit}; what a replayed step plan cannot give the host (no event
-  // can be read back from a graph) the kernel notes itself.
-  // (every 16th workgroup: they start within half a microsecond of each other and a range's length is the same for all, so
-  // the sample spans the launch; 500+ workgroups at one atomic word would add microseconds to the launch they time)
-  const bool span_me = sk.span != nullptr && threadIdx.x == 0 && (g & 15) == 0;
-  if (span_me) atomicMin(sk.span, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  // In-kernel span of this launch (measurement only, off unless a span scope is open: one scalar test; dlip_common.h): what a
+  // replayed step plan cannot give the host (no event can be read back from a graph) the kernel notes itself.
+  dlip_span_enter(sk.span, g);
 #ifdef DLIP_LAB
   if (threadIdx.x == 0 && sk.stamps) sk.stamps[(size_t)g * 10 + 8] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -863,10 +859,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #endif
     it += kn;
   }
-  if (span_me) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's stores have left
-    atomicMax(sk.span + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  }
+  dlip_span_exit(sk.span);
 #ifdef DLIP_LAB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (threadIdx.x == 0 && sk.stamps) {

@@ -95,8 +95,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   const int khi = (hq ^ key_rd) << 2, klo = ((4 + hq) ^ key_rd) << 2;
   const int x_ds = a.dw * a.ldx * 4;                      // bytes between two taps of a row
 
-  const bool span_me = sc.span != nullptr && tid == 0 && (g & 15) == 0;
-  if (span_me) atomicMin(sc.span, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  dlip_span_enter(sc.span, g);
 #ifdef DLIP_LAB
 #define ROWS_STAMP(i) do { if (sc.stamps && tid == 0) sc.stamps[(size_t)g * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define ROWS_SSTAMP(i) do { if (sc.stamps && tid == 0 && s == 8) sc.stamps[(size_t)g * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -193,10 +192,11 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   const __amdgpu_buffer_rsrc_t slr = dlip_make_rsrc(a.slope, a.slope ? kbytes : 0u);
   const __amdgpu_buffer_rsrc_t psr = dlip_make_rsrc(a.pscale, a.pscale ? kbytes : 0u);
   const __amdgpu_buffer_rsrc_t ptr_ = dlip_make_rsrc(a.pshift, a.pshift ? kbytes : 0u);
-  const bool has_slope = a.slope != nullptr, post = a.pscale != nullptr;
+  const bool has_slope = a.slope != nullptr, has_post = a.pscale != nullptr;
   float amax = 0.f;
-  auto epilogue = [&](int item) __attribute__((always_inline)) {
+  auto epilogue_p = [&](int item, auto post_c) __attribute__((always_inline)) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr bool post = decltype(post_c)::value;   // (compile-time inside: the runtime flag selected and computed both forms per value)
     const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
     const int row0 = tile_m * BM + wm * WM + lrow;
     const int col0 = tile_n * BN + wn * 64;
@@ -335,6 +335,9 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       }
     }
   };
+  auto epilogue = [&](int item) __attribute__((always_inline)) {
+    if (has_post) epilogue_p(item, std::true_type{}); else epilogue_p(item, std::false_type{});
+  };
 
   // ---- prologue: the first two slices of the stream in flight ----
   constexpr std::integral_constant<int, NA_A> na_a{};
@@ -418,10 +421,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #undef DLIP_FENCE
   if constexpr (EPI == 1) dlip_report_range(amax, a.status);
   ROWS_STAMP(3);
-  if (span_me) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's stores have left
-    atomicMax(sc.span + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  }
+  dlip_span_exit(sc.span);
 #ifdef DLIP_LAB
   if (sc.stamps && tid == 0) sc.stamps[(size_t)g * 16 + 6] = __builtin_amdgcn_s_memrealtime() - sc.stamps[(size_t)g * 16 + 7];
 #endif

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   const int tiles_m = (a.M + BM - 1) / BM;                                                     // (one column block: K <= BN)
   const int t_begin = (int)((long long)g * tiles_m / nwg), t_end = (int)((long long)(g + 1) * tiles_m / nwg);
   if (t_begin >= t_end) return;
+  dlip_span_enter(a.span, g);
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
     }
   }
   if constexpr (OSPLIT) dlip_report_range(amax, a.status);
+  dlip_span_exit(a.span);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OCC>
@@ -464,6 +466,7 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
     if (e != DLIP_OK) return e;
   }
   const long long grid = tiles < slots ? tiles : slots;
+  b.span = dlip_span_next();
 #ifdef DLIP_LAB
   if (getenv("DLIP_STAMP_PRINT")) {   // median cycles between the phase stamps of every workgroup's second tile
     static unsigned long long* dbuf = nullptr;

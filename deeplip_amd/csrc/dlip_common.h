@@ -146,8 +146,24 @@ struct DlipKernelState {
     return DLIP_OK;
   }
 };
-// Next {start, end} pair of the open span scope (capi.hip: dlip_span_scope_*), or NULL: in-kernel timing of replayed launches.
+// Next record of the open span scope (capi.hip: dlip_span_scope_*), or NULL: in-kernel timing of replayed launches.  A record is
+// DLIP_SPAN_WORDS uint64 (one 128-byte line): word 0 = start (min), words 8..15 = end (max) per workgroup shard.
+#define DLIP_SPAN_WORDS 16
 __attribute__((visibility("hidden"))) unsigned long long* dlip_span_next(void);
+// Measurement only; one scalar test when no scope is open.  `wg` = the workgroup's index in whatever order the kernel walks.
+// Entry: every 16th workgroup folds the clock into the start (they start within half a microsecond of each other; 500 workgroups
+// at one word would add microseconds to the launch they time).  Exit: EVERY workgroup folds it into the end word of its shard --
+// the last one out is what ends a launch, and under a second stream's load it is not a predictable one (a sampled end read up to
+// 10 % short of the kernel trace) -- behind a drain of its own stores.
+__device__ __forceinline__ void dlip_span_enter(unsigned long long* span, int wg) {
+  if (span != nullptr && threadIdx.x == 0 && (wg & 15) == 0) atomicMin(span, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void dlip_span_exit(unsigned long long* span) {
+  if (span != nullptr && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left
+    atomicMax(span + 8 + (blockIdx.x & 7), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
+}
 // 1 when the current device is gfx950 (cached per device; capi.hip).  Kernels that lean on probed gfx950 behaviour (conv_win's
 // out-of-allocation ds_read returning zeros) are only selected there.
 extern "C" __attribute__((visibility("hidden"))) int dlip_device_is_gfx950(void);

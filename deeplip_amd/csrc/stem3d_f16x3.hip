@@ -64,6 +64,7 @@ struct StemArgs {
   int Hp, Wp;          // pooled output size (stem + pool kernel)
   int n_frames;        // B*T
   DlipRange status;    // range reporting of the split-format output (dlip_common.h)
+  unsigned long long* span;     // NULL, or {first start, last end} of this launch in 100 MHz ticks (dlip_span_scope_*): the pre-pass notes the start
 #ifdef DLIP_LAB
   unsigned long long* stamps;   // lab build: [grid][8] s_memtime of each workgroup's second tile
 #endif
@@ -331,7 +332,10 @@ __device__ __forceinline__ float dpp_from_right(float v, float edge) {   // lane
 //          ingest_rgb_kernel / crop_norm_kernel (dlip_common.h): bit-identical to ingest -> fp32 -> SRC 0.
 template <int SRC>
 __global__ __launch_bounds__(256) void stem_split_input_kernel(const void* __restrict__ xin, uint32_t* __restrict__ xs, int rows, int H, int W,
-                                                               int pwp, int CH, int Hs, int Ws, int oy, int ox, DlipRange status) {
+                                                               int pwp, int CH, int Hs, int Ws, int oy, int ox, DlipRange status,
+                                                               unsigned long long* span) {
+  // (measurement only, one scalar test when no span scope is open: the stem's span starts with its pre-pass and ends with the pool kernel)
+  if (span != nullptr && threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicMin(span, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int cpr = pwp >> 2;                            // 16-B chunks per row
   const long long total = (long long)rows * cpr;
   float amax = 0.f;
@@ -631,6 +635,7 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last tile's refills -- zeros -- have landed before the LDS is released)
   dlip_report_range(amax, a.status);
+  dlip_span_exit(a.span);
 }
 
 }  // namespace
@@ -656,6 +661,7 @@ extern "C" int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, con
   if (xb > DLIP_MAX_BUFFER_BYTES || yb > DLIP_MAX_BUFFER_BYTES) return DLIP_ERANGE;
   a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
   a.Hp = a.Wp = 0; a.n_frames = B * T;
+  a.span = nullptr;
   const long long grid = tiles < 256 ? tiles : 256;   // persistent: one workgroup per CU (154 KB of LDS each)
   const size_t ldsb = (size_t)WBYTES + 2 * (size_t)KT * PR * a.pwp * 4;
   auto kern = stem3d_f16x3_kernel;
@@ -719,6 +725,7 @@ static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws,
   if (xb > DLIP_MAX_BUFFER_BYTES || yb > DLIP_MAX_BUFFER_BYTES) return DLIP_ERANGE;
   a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
   a.status = dlip_range_for(DLIP_ST_STEM);
+  a.span = dlip_span_next();
   hipStream_t st = static_cast<hipStream_t>(stream);
   {   // pre-pass: the clip as (hi, lo) pairs at the window's row pitch
     const long long chunks = frames * H * (a.pwp / 4);
@@ -726,10 +733,10 @@ static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws,
     if (frames * H > 0x7FFFFFFFll) return DLIP_ERANGE;
     if (src_kind == 0)
       hipLaunchKernelGGL(stem_split_input_kernel<0>, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), H, W, a.pwp,
-                         1, H, W, 0, 0, a.status);
+                         1, H, W, 0, 0, a.status, a.span);
     else
       hipLaunchKernelGGL(stem_split_input_kernel<1>, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), H, W, a.pwp,
-                         CH, Hs, Ws, oy, ox, a.status);
+                         CH, Hs, Ws, oy, ox, a.status, a.span);
   }
   const long long grid = frames < 256 ? frames : 256;   // persistent: a workgroup walks whole frames
   const size_t ldsb = (size_t)WBYTES + (size_t)KT * (np * 256 + 32) * 4 + (size_t)CARRY_SLOTS * CARRY_B + 3 * 64 * 4 + 128;

@@ -84,7 +84,7 @@ class _NameHook:
         self.seen: list = []
 
     def begin(self, name, flops):
-        self.seen.append((name, flops))
+        self.seen.append((name, flops, torch.cuda.current_stream().cuda_stream))   # + the stream the launch goes to (a step forks)
         return None
 
     def end(self, tok):
@@ -92,7 +92,7 @@ class _NameHook:
 
 
 # kernels that time themselves inside a span scope (dlip_span_next in their launch path), as ops.LAUNCH_HOOK names them
-SPAN_KERNELS = ("conv_igemm_f16x3_dma_kernel", "conv_rows_f16x3_kernel")
+SPAN_KERNELS = ("conv_igemm_f16x3_dma_kernel", "conv_rows_f16x3_kernel", "conv_win_f16x3_kernel", "stem3d_pool_f16x3_kernel")
 
 
 class StepPlan:
@@ -113,10 +113,11 @@ class StepPlan:
         # span_names = those launches in order, as ops.LAUNCH_HOOK names them (instance, algorithmic FLOPs)
         self._spans = None
         self.span_names: list = []
+        self.last_stream_us: dict = {}
         if spans:
             n = 256
-            pairs = torch.zeros((n, 2), dtype=torch.int64, device=self.device)
-            pairs[:, 0] = -1                                   # {~0, 0}: armed
+            pairs = torch.zeros((n, 16), dtype=torch.int64, device=self.device)   # one 128-byte record per launch (include/deeplip_hip.h)
+            pairs[:, 0] = -1                                   # start ~0, the eight end words 0: armed
             self._spans = (pairs, torch.zeros((n, 2), dtype=torch.int64, device=self.device), n)
         self._handle = C.c_void_p()
         self.outputs = None
@@ -193,7 +194,9 @@ class StepPlan:
         torch.cuda.synchronize(self.device)
         acc = self._spans[1].cpu().numpy()
         out = {}
-        for i, (name, flops) in enumerate(self.span_names):
+        streams: dict = {}
+        self.last_stream_us = {}                        # "stream0" (the first stream a timed launch went to), "stream1", ... -> sum of spans per replay
+        for i, (name, flops, stream) in enumerate(self.span_names):
             ticks, cnt = int(acc[i, 0]), int(acc[i, 1])
             if cnt == 0:
                 continue
@@ -201,6 +204,8 @@ class StepPlan:
             e["launches_per_step"] += 1
             e["us_sum"] += ticks / cnt / 100.0          # 100 MHz ticks -> us, mean over the replays
             e["flops"] += flops
+            key = "stream%d" % streams.setdefault(stream, len(streams))
+            self.last_stream_us[key] = self.last_stream_us.get(key, 0.0) + ticks / cnt / 100.0
         for e in out.values():
             e["avg_launch_us"] = round(e["us_sum"] / e["launches_per_step"], 2)
             e["tflops"] = round(e["flops"] / (e["us_sum"] * 1e-6) / 1e12, 2)

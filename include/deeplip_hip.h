@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 40
+#define DLIP_ABI_VERSION 41
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -602,12 +602,15 @@ int dlip_set_status_words(int32_t* words);
  * of the scope (join side streams first) -- that reports and re-zeroes the words.  Recorded into a step plan the verdict is
  * part of every replay.  Outside a scope the low side is not guarded (the high side always is). */
 /* Span scope (measurement): what a replayed step plan cannot give the host -- no event recorded into a graph can be read back --
- * the kernel notes itself.  Between _begin and _end (thread-local, not nestable) every launch of the LDS-DMA convolution kernel
- * (dlip_conv_nhwc_f16x3 / dlip_conv2_nhwc_f16x3 / dlip_conv_pool_f16x3 on split-format input, not the window kernel) takes the
- * next {start, end} pair of `pairs` (device uint64[2 n], armed as {~0, 0}); its workgroups fold the constant 100 MHz clock
- * (s_memrealtime) into it, min at entry and max at exit.  _end launches a collect kernel on `stream` (order it behind the scope's
- * launches) that adds end - start and 1 into acc[2 i], acc[2 i + 1] (device uint64[2 n], zeroed by the caller) and re-arms the pair
- * -- recorded into a plan, every replay accumulates; *used = pairs taken.  Outside a scope the kernels time nothing. */
+ * the kernel notes itself.  Between _begin and _end (thread-local, not nestable) every launch of an MFMA kernel on split-format
+ * input (the LDS-DMA ring kernel behind dlip_conv_nhwc_f16x3 / dlip_conv2_nhwc_f16x3 / dlip_conv_pool_f16x3, the window kernel, the
+ * rows kernel, the stem + pool kernel together with its pre-pass) takes the next RECORD of `pairs` (device uint64[16 n]: word 0 =
+ * start, armed as ~0; words 8..15 = end, armed as 0, one per blockIdx.x % 8 so that a grid's workgroups do not queue at one word;
+ * a record is one 128-byte line); its workgroups fold the constant 100 MHz clock (s_memrealtime) into it -- every 16th the minimum at
+ * entry (a grid starts within a microsecond), EVERY one the maximum at exit.  _end launches a collect kernel on `stream` (order it
+ * behind the scope's launches) that adds max(end) - start and 1 into acc[2 i], acc[2 i + 1] (device uint64[2 n], zeroed by the
+ * caller) and re-arms the record -- recorded into a plan, every replay accumulates; *used = records taken.  Outside a scope the
+ * kernels time nothing. */
 int dlip_span_scope_begin(uint64_t* pairs, uint64_t* acc, int32_t n);
 int dlip_span_scope_end(dlip_stream_t stream, int32_t* used);
 

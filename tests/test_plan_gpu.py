@@ -179,7 +179,7 @@ def test_extract_pipeline_rows_equal_the_direct_step(precision):
 
 
 def test_plan_spans_time_the_replayed_launches():
-    """spans=True: every LDS-DMA convolution launch of the recorded step times itself in-kernel on every replay
+    """spans=True: every MFMA launch of the recorded step (stem + pool with its pre-pass, window, ring and rows kernels) times itself in-kernel on every replay
     (dlip_span_scope_*: first workgroup in -> last workgroup out on the constant 100 MHz clock) -- the per-kernel timing a replayed
     hipGraph cannot give the host.  Results are bit-identical with and without; the spans add up to less than the replay's wall
     time on one stream and each is a plausible duration."""
@@ -194,7 +194,10 @@ def test_plan_spans_time_the_replayed_launches():
         want = ref.run().clone()
         plan = StepPlan(step, xv.clone(), xa.clone(), spans=True)
         assert plan.launches == ref.launches + 1                   # + the collect kernel
-        assert len(plan.span_names) >= 10 and all("conv_igemm_f16x3_dma_kernel" in n for n, _ in plan.span_names)
+        from deeplip_amd.plan import SPAN_KERNELS
+        kinds = {k for n, _, _ in plan.span_names for k in SPAN_KERNELS if k in n}
+        assert len(plan.span_names) >= 20 and {"conv_igemm_f16x3_dma_kernel", "conv_win_f16x3_kernel", "stem3d_pool_f16x3_kernel"} <= kinds
+        assert len({st for _, _, st in plan.span_names}) == 1      # two_streams=False: one stream
         plan.span_summary()                                        # drop the recording passes
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -208,7 +211,8 @@ def test_plan_spans_time_the_replayed_launches():
         assert sum(v["launches_per_step"] for v in s.values()) == len(plan.span_names)
         total_us = sum(v["us_sum"] for v in s.values())
         wall_us = 1e3 * e0.elapsed_time(e1) / 5
-        assert 0 < total_us < wall_us, (total_us, wall_us)         # one stream: the conv launches are a part of the replay
+        assert 0 < total_us < wall_us, (total_us, wall_us)         # one stream: the MFMA launches are a part of the replay, never more
+        assert abs(sum(plan.last_stream_us.values()) - total_us) < 1e-6 * total_us and list(plan.last_stream_us) == ["stream0"]
         assert all(1.0 < v["avg_launch_us"] < 5e3 for v in s.values())
         assert plan.span_summary() == {}                           # reset by the previous call
         plan.close(); ref.close()
