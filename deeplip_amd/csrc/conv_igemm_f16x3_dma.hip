@@ -1140,6 +1140,10 @@ static int dma_pick(long long M, int K, int nk, int epi) {
   if (K <= 64) return 1;
   if (nk <= 8) return 4;
   if (nk >= 32 && M >= 8192) return 5;
+  // (round 4) 18..31 slices over many rows -- layer 2's stride-2 3x3 convolution, 64 -> 128 channels on 22x22 maps: M = 224 576,
+  // 18 slices -- took 152 us on 128x128 and takes 137 on 256x128 with the balanced split (same box, tools/bench_dma.py); the
+  // k = 1 TDNN layers, where 256x128 had been no better at 16 slices, are on the rows kernel now
+  if (nk >= 18 && M >= 65536) return 5;
   // very long reductions over few tiles (the weight gradients run as convolutions: 5-36 tiles of 260-3 500 slices; no forward launch reduces over more than 144): the balanced split
   // fills the chip whatever M is, and the 256x128 tile's loop is the faster one (7-12 % per launch, tools/bench_wgrad.py)
   if (nk >= 256 && M >= 1024) return 5;

@@ -23,9 +23,9 @@
 //
 // With the operand traffic gone, what a 18-slice tile costs is its fixed part: set-up, the latency of its first
 // fetches, the epilogue.  So the workgroups are PERSISTENT (two per CU, each walking a contiguous range of row blocks)
-// and pipeline consecutive tiles: a tile's epilogue issues the next tile's window 0 and first weight slices -- into LDS
-// regions its own output image does not touch -- behind its residual fetch, and computes the next tile's tap masks
-// while it waits for the residual (LDS map in the kernel).
+// and pipeline consecutive tiles: a tile's last slices issue the next tile's window 0 and first weight slices, and its
+// epilogue -- from the accumulator registers straight to memory since round 4, the residual by two 16-B loads per pixel
+// block -- runs with that head in flight (LDS map in the kernel).
 #include "conv_common.h"
 #include "conv_dma_common.h"
 
@@ -52,27 +52,20 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   constexpr int WPER = 2 * WBLK / NW;                                // window pieces per wave
   constexpr int SLOT_B = WBLK * 2048;
   constexpr int BSTAGE_B = BN * ROWB;
-  // LDS map.  The workgroup is PERSISTENT and pipelines consecutive tiles: while a tile's epilogue stages its image in
-  // [0, IMG), the next tile's window 0 and first two weight slices are already landing in regions the image does not touch.
-  //   [0, SLOT_B)                      window slot 1 (odd channel slices)        } epilogue image [0, IMG_B); with 128 output
-  //   [SLOT_B, +BSTAGE_B)              weight ring stage 2                       } columns it is longer than these two: padding
-  //   [HEAD_OFF, +2 BSTAGE_B)          weight ring stages 0, 1 (the next tile's arrive during the epilogue)
+  // LDS map.  The workgroup is PERSISTENT and pipelines consecutive tiles: while a tile's epilogue runs (from registers: it
+  // touches no LDS but the parameter table), the next tile's window 0 and first two weight slices are landing.
+  //   [0, SLOT_B)                      window slot 1 (odd channel slices)
+  //   [SLOT_B, +BSTAGE_B)              weight ring stage 2
+  //   [HEAD_OFF, +2 BSTAGE_B)          weight ring stages 0, 1 (the next tile's arrive during the last two slices)
   //   then window slot 0 (even channel slices; the next tile's arrives during the last slices), the table
   constexpr int W1_OFF = 0;
-  constexpr int IMG_B = BM * BN * 4;                                                  // the epilogue's output image [0, IMG_B)
-  constexpr int HEAD_OFF = IMG_B > SLOT_B + BSTAGE_B ? IMG_B : SLOT_B + BSTAGE_B;    // stages 0, 1 start behind the image
+  constexpr int HEAD_OFF = SLOT_B + BSTAGE_B;      // (until round 3 the epilogue's output image lay over [0, BM BN 4) and pushed stages 0, 1 behind it)
   constexpr int W0_OFF = HEAD_OFF + 2 * BSTAGE_B;
   constexpr int TAB_OFF = W0_OFF + SLOT_B;
   constexpr int LDK = 32;
-  constexpr int PITCH = BN * 4;                    // bytes per image row
-  constexpr int CPR = BN / 4;                      // 16-B chunks per image row
-  constexpr int NSTORE = BM * CPR / NT;            // 16-B output stores per thread
-  constexpr int RES_PIECES = BM * PITCH / 1024 / NW;
-  constexpr int RPQ = 1024 / PITCH;
-  static_assert(BN % RPP == 0 && WM % 16 == 0 && 2 * WBLK % NW == 0, "tile / window layout");
+  constexpr int NSTORE = OSPLIT ? MI * NI : MI * NI;   // 16-B output stores per lane and tile (split: 2 per channel-block pair and pixel block)
+  static_assert(BN % RPP == 0 && WM % 16 == 0 && 2 * WBLK % NW == 0 && NI % 2 == 0, "tile / window layout");
   static_assert(WPER <= 7, "the last window piece of a channel slice goes out at least two slices before the slice ends");
-  static_assert(BM * PITCH == IMG_B && IMG_B <= HEAD_OFF, "the epilogue image must not reach the prefetched weight stages");
-  static_assert((BM * PITCH) % (NW * 1024) == 0 && (BM * CPR) % NT == 0, "the tile image is whole DMA pieces / stores per wave");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds_c = reinterpret_cast<char*>(smem);
   auto stage_off = [](int st) { return st == 2 ? SLOT_B : HEAD_OFF + st * BSTAGE_B; };   // stages 0, 1 outside the image
@@ -178,7 +171,6 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   const int b_frag = (wn * WN + lrow) * LDK;
   const int key_rd = (lrow >> 1) & 7;
   const int khi = (half ^ key_rd) << 2, klo = ((4 + half) ^ key_rd) << 2;
-  const u32x4 rrw = make_rsrc_words(a.res, a.res ? a.r_bytes : 0u);
   const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
   const bool post = a.pscale != nullptr;
   float amax = 0.f;
@@ -329,102 +321,119 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
 #undef DLIP_FENCE
     WIN_STAMP(2);
 
-    // ---- epilogue through LDS (the ring kernel's, fp32 / split rows): y = act(acc / wscale + bias + residual) * ps + pt,
-    // with the NEXT tile's head (window 0, weights of slices 0 and 1) in flight underneath it ----
+    // ---- epilogue straight from the accumulators (round 4; the rows kernel's): y = act(acc / wscale + bias + residual) * ps + pt.
+    // Until round 3 the output tile was staged in LDS as its memory image (the ring kernel's epilogue): three workgroup barriers, the
+    // residual tile fetched by LDS-DMA into that image -- 1.7-3 k cycles of exposed latency on the two residual launches of every
+    // BasicBlock, since no LDS was free for it before the ring and the windows were done -- 16 LDS reads per lane to add it, and the
+    // image pinned where the next tile's head could not go.  Now a lane exchanges the odd 16-lane rows of one accumulator with the
+    // even rows of its neighbour in the channel direction (v_permlane16_swap_b32), holds 8 consecutive channels of its pixel and
+    // stores one 16-B piece of hi halves and one of lo halves; the residual arrives in the same shape by two 16-B loads per pixel
+    // block, issued FIRST, so that their latency passes under the parameter reads and the other blocks' arithmetic; no barrier,
+    // no LDS traffic, and the next tile's head (in flight since the last slices) is not touched.  Arithmetic and order per value are
+    // the old epilogue's: same bits. ----
     {
       typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-      char* img = lds_c;
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
       const f32x4* tab = reinterpret_cast<const f32x4*>(smem + TAB_OFF / 4);
-      __syncthreads();   // every wave is done with the windows and the weight ring
-      if (a.res) {       // the residual tile first (the epilogue waits for it alone), then the next tile's head
-#pragma unroll
-        for (int i = 0; i < RES_PIECES; ++i) {
-          const int piece = i * NW + wave;
-          const int r = piece * RPQ + lane / CPR;
-          const int pp = lane % CPR;
-          const int c = (pp & ~15) | ((pp ^ r) & 15);
-          const int m = m0 + r;
-          const bool ok = m < a.M && (c >> 3) * 32 < a.K;
-          dma_piece(rrw, ok ? (uint32_t)(m * a.ldr * 4 + c * 16) : DLIP_OOB_OFFSET, lds0 + piece * 1024);
-        }
-      }
+      const __amdgpu_buffer_rsrc_t rr = dlip_make_rsrc(a.res, a.res ? a.r_bytes : 0u);
       const bool head_here = has_next && (cchunks & 1) != 0;   // odd channel-slice count: window 0 could not be streamed
       if (head_here) {
+        __syncthreads();   // (workgroup-uniform) slot 0 held the last channel slice: every wave is done reading it
 #pragma unroll
         for (int j = 0; j < WPER; ++j) issue_win(0, 0, wave + NW * j, m0n - halo_lo);
       }
       WIN_STAMP(3);
-      if (a.res) {
-        if (head_here) wait_vmcnt<WPER>(); else wait_vmcnt<0>();
-        __syncthreads();
-      }
-      WIN_STAMP(4);
+      const int row0 = m0 + wm * WM + lrow;
+      if constexpr (OSPLIT) {
+        const int cs = ((half & 1) << 4) | ((half & 2) << 2);   // after the swap: channels 32 p + {0, 16, 8, 24}[half] + 0..7
+        h8 rh[NI / 2][MI], rl[NI / 2][MI];
+        if (a.res) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int kl = wn * WN + ni * FR + 4 * half;
-        const f32x4 inv4 = tab[kl >> 2], bi4 = tab[(BN + kl) >> 2], sl4 = tab[(2 * BN + kl) >> 2];
-        f32x4 ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
-        if (post) { ps4 = tab[(3 * BN + kl) >> 2]; pt4 = tab[(4 * BN + kl) >> 2]; }
-        const int ch = (kl >> 5) * 8 + ((kl >> 3) & 3);
+          for (int p = 0; p < NI / 2; ++p)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int r = wm * WM + mi * FR + lrow;
-          char* row = img + r * PITCH + 2 * (kl & 4);
-          const int phi = (ch & ~15) | ((ch ^ r) & 15), plo = ((ch + 4) & ~15) | (((ch + 4) ^ r) & 15);
-          float v[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = acc[mi][ni][c] * inv4[c] + bi4[c];
-          if (a.res) {
-            const h4 rh = *reinterpret_cast<const h4*>(row + phi * 16), rl = *reinterpret_cast<const h4*>(row + plo * 16);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += (float)rh[c] + (float)rl[c];
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            v[c] = v[c] >= 0.f ? v[c] : v[c] * sl4[c];
-            if (post) v[c] = v[c] * ps4[c] + pt4[c];
-          }
-          if constexpr (OSPLIT) {
-            h4 hi, lo;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); }
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-            *reinterpret_cast<h4*>(row + phi * 16) = hi;
-            *reinterpret_cast<h4*>(row + plo * 16) = lo;
-          } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[mi][ni][c] = v[c];
-          }
+            for (int mi = 0; mi < MI; ++mi) {
+              const int m = row0 + mi * FR, kb = wn * WN + 32 * p;
+              const uint32_t off = (m < a.M && kb < a.K) ? (uint32_t)((m * a.ldr + kb) * 4 + cs * 2) : DLIP_OOB_OFFSET;
+              rh[p][mi] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)off, 0, 0));
+              rl[p][mi] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(off == DLIP_OOB_OFFSET ? off : off + 64u), 0, 0));
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (!OSPLIT) {
-        if (a.res) __syncthreads();
+        WIN_STAMP(4);
+#pragma unroll
+        for (int p = 0; p < NI / 2; ++p) {
+          const int kb = wn * WN + 32 * p, k0 = kb + cs;
+          float inv[8], bi[8], sl[8], ps[8], pt[8];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x4 i4 = tab[(k0 >> 2) + q], b4 = tab[((BN + k0) >> 2) + q], l4 = tab[((2 * BN + k0) >> 2) + q];
+            f32x4 p4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+            if (post) { p4 = tab[((3 * BN + k0) >> 2) + q]; t4 = tab[((4 * BN + k0) >> 2) + q]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { inv[4 * q + c] = i4[c]; bi[4 * q + c] = b4[c]; sl[4 * q + c] = l4[c]; ps[4 * q + c] = p4[c]; pt[4 * q + c] = t4[c]; }
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {   // (scalar copies: see conv_rows_f16x3.hip on __builtin_bit_cast of a vector element)
+              const float xc = acc[mi][2 * p][c], yc = acc[mi][2 * p + 1][c];
+              const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(xc), __float_as_uint(yc), false, false);
+              v[c] = __uint_as_float(r[0]);
+              v[4 + c] = __uint_as_float(r[1]);
+            }
+            h8 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              float t = v[c] * inv[c] + bi[c];
+              if (a.res) t += (float)rh[p][mi][c] + (float)rl[p][mi][c];
+              t = t >= 0.f ? t : t * sl[c];
+              if (post) t = t * ps[c] + pt[c];
+              hi[c] = (_Float16)t;
+              lo[c] = (_Float16)(t - (float)hi[c]);
+              amax = fmaxf(amax, fabsf(t));
+            }
+            const int m = row0 + mi * FR;
+            const bool ok = m < a.M && kb < a.K;
+            const uint32_t off = ok ? (uint32_t)((m * a.ldy + kb) * 4 + cs * 2) : DLIP_OOB_OFFSET;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), yr, (int)off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), yr, (int)(ok ? off + 64u : DLIP_OOB_OFFSET), 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        WIN_STAMP(4);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int kl = wn * WN + ni * FR + 4 * half;
-          const int ch = kl >> 2;
+          const f32x4 inv4 = tab[kl >> 2], bi4 = tab[(BN + kl) >> 2], sl4 = tab[(2 * BN + kl) >> 2];
+          f32x4 ps4 = {1.f, 1.f, 1.f, 1.f}, pt4 = {0.f, 0.f, 0.f, 0.f};
+          if (post) { ps4 = tab[(3 * BN + kl) >> 2]; pt4 = tab[(4 * BN + kl) >> 2]; }
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
-            const int r = wm * WM + mi * FR + lrow;
-            const int pc = (ch & ~15) | ((ch ^ r) & 15);
-            *reinterpret_cast<f32x4*>(img + r * PITCH + pc * 16) = acc[mi][ni];
+            const int m = row0 + mi * FR;
+            const bool ok = m < a.M && kl < a.K;
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = acc[mi][ni][c] * inv4[c] + bi4[c];
+            if (a.res) {   // the residual is in the split format: 4 hi halves, 4 lo halves of this lane's channels
+              const uint32_t ro = ok ? (uint32_t)((m * a.ldr + (kl & ~31)) * 4 + (kl & 31) * 2) : DLIP_OOB_OFFSET;
+              const h4 rh = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rr, (int)ro, 0, 0));
+              const h4 rl = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rr, (int)(ok ? ro + 64u : DLIP_OOB_OFFSET), 0, 0));
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] += (float)rh[c] + (float)rl[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[c] = v[c] >= 0.f ? v[c] : v[c] * sl4[c];
+              if (post) v[c] = v[c] * ps4[c] + pt4[c];
+            }
+            const uint32_t off = ok ? (uint32_t)((m * a.ldy + kl) * 4) : DLIP_OOB_OFFSET;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, (int)off, 0, 0);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __syncthreads();
       WIN_STAMP(5);
-#pragma unroll
-      for (int i = 0; i < NSTORE; ++i) {   // exactly NSTORE stores per thread (out-of-range ones included): the next tile counts them
-        const int idx = i * NT + tid;
-        const int r = idx / CPR, pp = idx % CPR;
-        const int c = (pp & ~15) | ((pp ^ r) & 15);
-        const int m = m0 + r;
-        const int kfirst = OSPLIT ? (c >> 3) * 32 : c * 4;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(img + r * PITCH + pp * 16);
-        const uint32_t off = (m < a.M && kfirst < a.K) ? (uint32_t)(m * a.ldy * 4 + c * 16) : DLIP_OOB_OFFSET;
-        __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)off, 0, 0);
-      }
       WIN_STAMP(6);
       if (has_next) {
 #pragma unroll
@@ -447,8 +456,8 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WBLK0 = (BM + WIN_SLACK + 15) / 16;
   constexpr int WBLK = (WBLK0 + NW / 2 - 1) / (NW / 2) * (NW / 2);
-  constexpr size_t slot_b = (size_t)WBLK * 2048, bst = (size_t)BN * ROWB, img = (size_t)BM * BN * 4;
-  constexpr size_t head = img > slot_b + bst ? img : slot_b + bst;
+  constexpr size_t slot_b = (size_t)WBLK * 2048, bst = (size_t)BN * ROWB;
+  constexpr size_t head = slot_b + bst;
   constexpr size_t lds = head + 2 * bst + slot_b + 5 * BN * sizeof(float);
   if (b.tiles_n != 1) return DLIP_EINVAL;   // one column block (K <= BN): the kernel's tile index is the row block
   static_assert(lds <= 160 * 1024, "LDS exceeds a CU");
