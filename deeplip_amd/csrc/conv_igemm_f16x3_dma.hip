@@ -1137,6 +1137,11 @@ static int dma_pick(long long M, int K, int nk, int epi) {
   if (const int v = dlip_dbg_value[DLIP_DBG_DMA_TILE]; v >= 0 && v < NUM_DMA_ALL && epi != 2) return v;
   if (epi == 2) return (nk >= 32 && M >= 8192) ? 5 : 0;
   if (M <= 64) return K <= 64 ? 3 : 2;
+  // (round 4) up to 2 048 rows with a reduction of 16 slices or more -- the MS-TCN head's convolutions of a training step: 928 + padding
+  // rows, 512 | 768 -> 256 channels, 48-168 slices -- are a handful of row tiles split many ways: on 64-row tiles there are twice as
+  // many tiles to split and half as many parts per tile for the finisher to add (tools/bench_tcn.py, same box: 41.8 -> 27.9 us,
+  // 45.9 -> 32.7, 60.7 -> 45.6 against 128 x 128; 128 x 64 and 256 x 128 in between)
+  if (M <= 2048 && nk >= 16) return K <= 64 ? 3 : 2;
   if (K <= 64) return 1;
   if (nk <= 8) return 4;
   if (nk >= 32 && M >= 8192) return 5;
@@ -1181,7 +1186,13 @@ extern "C" __attribute__((visibility("hidden"))) void dlip_conv_dma_tile(long lo
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int epi) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (a.R * a.S > 32) {   // the tap-mask-free variant, on the three tiles long reductions use
+  // The many-tap instances are also the ONLY ones that honour the slice / tap strides of slice-major operand images
+  // (dlip_wgrad_conv_f16x3: cs_x, wt, cs_w, Hs); a weight gradient with 32 taps or fewer -- layer 4's 3x3 output-gradient maps: 9 taps --
+  // used to fall through to the pixel-major instances below and read its slice-major images as if they were pixel-major: wrong
+  // layer-4 weight gradients whenever the batch had more than 32 images (round 3's default layout; the 2-clip golden has one
+  // slice, where the two layouts coincide; found by tests/test_train_video_gpu.py's full-size gradient test in round 4).
+  const bool slice_major = a.cs_x != 128 || a.cs_w != 128 || a.wt != a.Cw * 4 || a.Hs != a.H;
+  if (a.R * a.S > 32 || slice_major) {   // the tap-mask-free variant, on the three tiles long reductions use
     const int t = dma_pick(a.M, a.K, a.nk, epi);
     if (a.K <= 64 || t == 1 || t == 3) return launch_dma<128, 64, 2, 2, 3, 2, 4096>(a, st, epi);
     if (t == 5) return launch_dma<256, 128, 4, 2, 3, 1, 4096>(a, st, epi);

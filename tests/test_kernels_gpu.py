@@ -940,7 +940,10 @@ def test_stem_wgrad_chwn_operand(ops):
 
 @pytest.mark.parametrize("slice_major", [True, False], ids=["slice-major", "pixel-major"])
 @pytest.mark.parametrize("N,H,C,K,R,stride,pad,dil", [(40, 22, 64, 64, 3, 1, 1, 1), (33, 22, 64, 128, 3, 2, 1, 1), (70, 11, 128, 128, 3, 1, 1, 1),
-                                                       (9, 11, 32, 64, 3, 2, 1, 1), (5, 6, 256, 256, 3, 1, 1, 1), (4, 12, 32, 32, 3, 1, 2, 2)])
+                                                       (9, 11, 32, 64, 3, 2, 1, 1), (5, 6, 256, 256, 3, 1, 1, 1), (4, 12, 32, 32, 3, 1, 2, 2),
+                                                       # layer 4: 3x3 maps -> a "filter" of 9 taps (<= 32: not the many-tap walk) over MORE than one
+                                                       # 32-image slice -- the case round 3's slice-major default got wrong
+                                                       (70, 3, 512, 512, 3, 1, 1, 1), (40, 6, 256, 512, 3, 2, 1, 1), (33, 4, 64, 96, 3, 1, 1, 1)])
 def test_wgrad_as_conv_both_layouts(ops, slice_major, N, H, C, K, R, stride, pad, dil):
     """The weight gradient run as a convolution (dlip_wgrad_chwn_f32 + dlip_wgrad_conv_f16x3 on slice-major images, or
     dlip_conv_nhwc_f16x3 on pixel-major ones) against torch autograd in fp64."""

@@ -387,3 +387,67 @@ def test_recorded_training_step_is_bit_identical_to_eager(B, T):
     assert le == lg
     for k in se:
         assert torch.equal(se[k], sg[k]), k
+
+
+def test_full_size_training_step_loss_and_gradients_vs_fp64_oracle():
+    """The optimisation step at the size bench.py times it (configs.F2_train_video_step: B = 32 clips x 29 frames, 54 classes,
+    ragged lengths): loss, logits, argmax and EVERY parameter's gradient against the oracle's train-mode restatement
+    (oracle.lipreading_logits_train: batch-statistics BatchNorm, tcn.py:52-59 statistics over the padded length) evaluated in
+    fp64 with torch autograd on the host cores (~1.8 TFLOP, a quarter of a minute on 16 cores).
+
+    What the bar can be.  The network is piecewise linear (PReLU kinks, max-pool choices): a rounding difference that moves one
+    pre-activation across zero changes the gradient by a finite amount, so ANY fp32 evaluation sits 1e-3 .. 3e-2 (largest element
+    error over largest element, per tensor) from the fp64 gradient -- measured here with the same oracle run in fp32, which is what
+    the reference itself computes in.  Loss and logits hold the plain 1e-4; the gradients are held to the fp32 noise floor: the
+    worst tensor no further from fp64 than twice the fp32 oracle's worst, and the average over tensors no more than twice its
+    average.  (This test found a real bug: with more than 32 images per batch the weight gradients of layer 4 -- 3x3 maps, a
+    nine-tap "filter" -- read their slice-major operand images with pixel-major strides and were off by 130-200 %;
+    conv_igemm_f16x3_dma.hip, dlip_conv_f16x3_dma_launch.  The 2-clip golden has a single 32-image slice, where the layouts coincide.)"""
+    from deeplip_amd import autograd as ag
+    from oracle import deeplip_oracle as O
+    B, T = 32, 29
+    net = _build(0.0)
+    net.train()
+    x = torch.from_numpy(wg.video_input(B, frames=T, key="vtrain.full"))
+    lab = torch.from_numpy(wg.labels(B, 54))
+    lengths = [T - (i % 5) for i in range(B)]
+    lengths[0] = T
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    logits = net(x.to(DEV), lengths=lengths)
+    loss = ag.margin_ce_loss(logits, lab.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: v.grad.detach().cpu().double() for k, v in net.named_parameters()}
+    names = [k for k, _ in net.named_parameters()]
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))     # (a GPU box grants 16 cores; more threads than that thrash)
+
+    def oracle(dtype):
+        p = {k: (v.to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in sd0.items()}
+        for k in names:
+            p[k].requires_grad_(True)
+        lo = O.lipreading_logits_train(p, x.to(dtype), lengths)
+        ls = F.cross_entropy(lo, lab)
+        ls.backward()
+        return lo.detach(), float(ls.detach()), {k: p[k].grad.double() for k in names}
+
+    ref_logits, ref_loss, g64 = oracle(torch.float64)
+    _, _, g32 = oracle(torch.float32)
+    assert abs(float(loss.detach()) - ref_loss) < 1e-4 * abs(ref_loss)
+    assert rel_err(logits.detach().cpu().numpy(), ref_logits.numpy()) < 1e-4
+    assert np.array_equal(torch.max(logits, 1)[1].cpu().numpy(), torch.max(ref_logits, 1)[1].numpy())
+    ours, floor = [], []
+    for k in names:
+        scale = float(g64[k].abs().max())
+        if scale < 1e-9:           # conv biases in front of a BatchNorm: the exact gradient is zero
+            assert float(grads[k].abs().max()) < 1e-6, k
+            continue
+        ours.append((float((grads[k] - g64[k]).abs().max()) / scale, k))
+        floor.append(float((g32[k] - g64[k]).abs().max()) / scale)
+    worst, who = max(ours)
+    assert worst < max(1e-4, 2.0 * max(floor)), (who, worst, max(floor))
+    assert np.mean([e for e, _ in ours]) < max(1e-4, 2.0 * np.mean(floor)), (np.mean([e for e, _ in ours]), np.mean(floor))
+    # gradient norms: well conditioned (a flipped kink moves single elements, not a tensor's norm)
+    for k in names:
+        n64 = float(g64[k].norm())
+        if n64 > 1e-7:
+            assert abs(float(grads[k].norm()) - n64) < 5e-3 * n64, (k, float(grads[k].norm()), n64)
