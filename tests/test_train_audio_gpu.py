@@ -156,3 +156,58 @@ def test_speaker_encoder_two_sgd_steps_vs_reference_golden(golden):
     for k, v in net.state_dict().items():
         ref = g[f"after2_{k}_sum"]
         assert abs(float(v.detach().double().abs().sum()) - ref[1]) < 1e-4 * max(ref[1], 1e-6), k
+
+
+def test_full_size_training_step_vs_fp64_oracle():
+    """The speech encoder's optimisation step at the size bench.py times it (configs.F2_train_audio_step: B = 256 utterances x 300
+    frames x 24 features, E-TDNN, LMCL): loss and EVERY parameter's gradient against the oracle's train-mode restatement
+    (oracle.speaker_forward_train + oracle.lmcl) in fp64 with torch autograd on the host cores.  The LeakyReLU kinks make any
+    fp32 evaluation sit 1e-3 .. 6e-3 (per tensor: largest element error over largest element) from the fp64 gradient -- measured
+    with the same oracle in fp32 -- so the gradients are held to that floor (worst tensor and average within twice the fp32
+    oracle's), the loss to 1e-5."""
+    import os
+    import torch.nn.functional as F  # noqa: F401
+    from deeplip_amd import weightgen as wg
+    from models.audio_models.loss import LMCL
+    from models.audio_models.tdnn import SpeakerEmbNet
+    from oracle import deeplip_oracle as O
+    B = 256
+    et = {"input_dim": 24, "hidden_dim": [512] * 9 + [1500], "context": O.ETDNN_CONTEXT, "tdnn_layers": 10, "embedding_dim": 512,
+          "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
+    net = SpeakerEmbNet({"arch": "etdnn", "etdnn": et})
+    sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="audio.")
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.cuda().train()
+    crit = LMCL(512, 57, 30, 0.2).cuda()
+    x = torch.from_numpy(wg.audio_input(B, 24, 300, key="full.atrain"))
+    lab = torch.from_numpy(wg.labels(B, 57))
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    cw = crit.weights.detach().cpu().clone()
+    loss, _ = crit(net(x.cuda()), lab.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [k for k, _ in net.named_parameters()]
+    grads = {k: v.grad.detach().cpu().double() for k, v in net.named_parameters()}
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+
+    def oracle(dt):
+        p = {k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd0.items()}
+        for k in names:
+            p[k].requires_grad_(True)
+        l, _ = O.lmcl(O.speaker_forward_train(p, x.to(dt), O.ETDNN_CONTEXT), lab, cw.to(dt), 30, 0.2)
+        l.backward()
+        return float(l.detach()), {k: p[k].grad.double() for k in names}
+
+    l64, g64 = oracle(torch.float64)
+    _, g32 = oracle(torch.float32)
+    assert abs(float(loss.detach()) - l64) < 1e-5 * abs(l64)
+    ours, floor = [], []
+    for k in names:
+        sc = float(g64[k].abs().max())
+        if sc < 1e-12:
+            continue
+        ours.append((float((grads[k] - g64[k]).abs().max()) / sc, k))
+        floor.append(float((g32[k] - g64[k]).abs().max()) / sc)
+    worst, who = max(ours)
+    assert worst < max(1e-4, 2.0 * max(floor)), (who, worst, max(floor))
+    assert np.mean([e for e, _ in ours]) < max(1e-4, 2.0 * np.mean(floor))
