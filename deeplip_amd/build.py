@@ -32,7 +32,9 @@ def _hipcc() -> str:
 
 def _deps():
     return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "dlip_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv_dma_common.h"),
-                                                       os.path.join(CSRC, "conv_dma_lab.inc"), os.path.join(ROOT, "include", "deeplip_hip.h")]
+                                                       os.path.join(CSRC, "conv_dma_lab.inc"), os.path.join(CSRC, "conv_dma_hooks.h"), os.path.join(CSRC, "conv_dma_hook_consts.inc"),
+                                                       os.path.join(CSRC, "conv_dma_hook_window.inc"), os.path.join(CSRC, "conv_dma_hook_tile256.inc"),
+                                                       os.path.join(CSRC, "conv_dma_lab_menu.inc"), os.path.join(ROOT, "include", "deeplip_hip.h")]
 
 
 def source_sha() -> str:
@@ -134,7 +136,7 @@ if __name__ == "__main__":
 # What profiles/traffic_latest.json (PMC bytes per launch of the dominant kernel) is stamped with, and what bench.py compares the
 # stamp to: the sources the dominant kernel's translation unit is compiled from.  Entry points added elsewhere (an ABI bump) do not
 # change that kernel; an edit of a header it includes does.
-DOMINANT_KERNEL_SOURCES = ("conv_igemm_f16x3_dma.hip", "conv_dma_common.h", "conv_common.h", "dlip_common.h")
+DOMINANT_KERNEL_SOURCES = ("conv_igemm_f16x3_dma.hip", "conv_dma_common.h", "conv_dma_hooks.h", "conv_dma_hook_consts.inc", "conv_common.h", "dlip_common.h")
 
 
 def dominant_kernel_sha() -> str:

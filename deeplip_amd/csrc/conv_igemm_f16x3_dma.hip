@@ -30,6 +30,7 @@
 // Fragment layout, accumulator initialisation and the LDS image are those of conv_igemm_f16x3.hip.
 #include "conv_common.h"
 #include "conv_dma_common.h"
+#include "conv_dma_hooks.h"
 #include <algorithm>
 #include <cstdio>
 #include <map>
@@ -65,32 +66,19 @@ struct StreamK {
   int G;             // workgroups in the grid
   unsigned long long* span;   // NULL, or this launch's {first workgroup start, last workgroup end} in 100 MHz ticks (dlip_span_scope_*)
   int il_tiles;      // > 0: G = il_tiles * parts and neighbours in work order take the SAME part of DIFFERENT tiles (launch_one)
-#ifdef DLIP_LAB
-  unsigned long long* stamps;   // lab build only: [G][10] s_memtime values of each workgroup's first segment
-#endif
+  DLIP_LAB_STREAMK_FIELDS   // (conv_dma_hooks.h: nothing in the product build)
 };
-
-#ifdef DLIP_LAB
-#define DLIP_STAMP(i) do { if (threadIdx.x == 0 && it == it_begin && sk.stamps) sk.stamps[(size_t)g * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-// inside ONE slice (the 9th of each workgroup's first segment): [(G + g) * 10 + i]
-#define DLIP_SSTAMP(i) do { if (threadIdx.x == 0 && it == it_begin && kt == 8 && sk.stamps) sk.stamps[((size_t)sk.G + g) * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-// the same slice as seen by wave 4 (the ping-pong loop's half B): [(2 G + g) * 10 + i]
-#define DLIP_BSTAMP(i) do { if (threadIdx.x == 256 && it == it_begin && kt == 8 && sk.stamps) sk.stamps[((size_t)2 * sk.G + g) * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define DLIP_STAMP(i) do { } while (0)
-#define DLIP_SSTAMP(i) do { } while (0)
-#define DLIP_BSTAMP(i) do { } while (0)
-#endif
 
 // EPI: what the epilogue does with act(acc / wscale + bias + residual) * post_scale + post_shift
 //   0  fp32 rows of y;  1  split-format rows of y (reports |v| >= 65520 to the range-status word);
 //   2  no y: per tile and row-group segment, the column sums of v and v^2 in fp64 (a.pool)
 // DUAL: the reduction continues over a second source x2 (1x1, strided) after the taps of x.
-// VAR (lab build experiments on the 8-wave tiles, bit 0: s_setprio 1 for the second-dispatched half of the waves;
-// bit 1: that half issues its LDS-DMA pieces half a slice later than the first half -- measured 15 % slower: the
-// pieces need their full two slices of lead; bit 2: every wave issues them at the top of the slice; bit 3: the two halves
-// of the waves -- one wave of each SIMD in either -- take turns as the slice's issuer: the half whose turn it is moves the
-// WHOLE slice (its own rows and its partner's) while the other half goes straight to its matrix work): 0 in the product.
+// VAR: 0 in the product except bit 12 (filters of more than 32 taps: below).  The lab build (conv_dma_hooks.h) uses bit 2 (every
+// wave issues its pieces at the top of the slice), 6 (256x256 tile), 7 (window mode), 9 / 11 (ping-pong without priority / with the
+// group-major MFMA order), 10 (the lock-step loop on 256x128: the ping-pong loop's reference).  The experiments of rounds 2 / 3 that
+// lost -- a static priority for the second half of the waves, that half issuing half a slice late, the halves taking turns as a
+// slice's issuer, the pieces spread one by one behind MFMA quarter-groups -- are in DESIGN.md section 4 with their numbers and in
+// the history of this file, no longer in its text.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, int OCC, bool DUAL, int VAR = 0>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_dma_kernel(const ConvArgs a, const StreamK sk) {
   constexpr bool OSPLIT = EPI == 1;
@@ -106,24 +94,11 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   constexpr int STAGE_B = (BM + BN) * ROWB;
   constexpr int LDK = 32;             // dwords per LDS row
   constexpr int PF = NSTAGE - 1;      // slices in flight ahead of the one being multiplied
-  // (window mode -- VAR bit 7, activations from a per-slice window instead of the ring -- is a lab experiment: conv_dma_lab.inc)
-#ifdef DLIP_LAB
-#define DLIP_WINMODE_SECTION 1
-#include "conv_dma_lab.inc"
-#else
-  constexpr bool WIN = false;
-  constexpr int RING_W = 0;
-  static_assert((VAR & 128) == 0, "window mode exists in the lab build only");
-#endif
+#include "conv_dma_hook_consts.inc"   // product: `constexpr bool WIN = false; constexpr int RING_W = 0;`
   constexpr int RING = WIN ? RING_W : NSTAGE * STAGE_B;   // bytes; the epilogue parameter table (5 x BN floats) sits behind it
-  constexpr bool ALT = (VAR & 8) != 0;     // alternating issuer halves
   // The eight-wave 256x128 tile runs the ping-pong main loop (below); VAR bit 10 keeps the lock-step loop (lab reference),
   // bit 9 drops the matrix phase's priority (lab), bit 11 keeps the group-major MFMA order inside the matrix phase (lab).
-#ifdef DLIP_NO_PINGPONG   // (A/B builds only: tools/ab.sh nopp)
-  constexpr bool PINGPONG = false;
-#else
   constexpr bool PINGPONG = BM == 256 && BN == 128 && NW == 8 && NSTAGE == 3 && (VAR & ~(512 | 2048 | 4096)) == 0;
-#endif
   // VAR bit 12: filters with MORE THAN 32 TAPS.  The product's per-row validity mask has one bit per tap (R S <= 32); a weight
   // gradient run as a convolution -- input x as [C][H][W][N], "filter" = the output gradient as [K][Ho][Wo][N], the images as the
   // reduction's channels (deeplip_amd.autograd_video.wgrad_as_conv) -- has Ho x Wo taps (484 on layer 1).  This variant keeps each
@@ -131,8 +106,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   constexpr bool BIGTAPS = (VAR & 4096) != 0;
   constexpr bool PP_PRIO = (VAR & 512) == 0;
   constexpr bool PP_ACC_MAJOR = (VAR & 2048) == 0;   // (bit 11: the group-major MFMA order, lab reference)
-  static_assert(!ALT || (NW == 8 && NSTAGE == 3), "alternating issuers: eight waves, three stages");
-  constexpr int AQ = ALT ? 2 * A_PER : A_PER, BQ = ALT ? 2 * B_PER : B_PER;   // rows a lane addresses: its own passes (+ its partner wave's)
+  constexpr int AQ = A_PER, BQ = B_PER;   // rows a lane addresses: its own passes
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -157,7 +131,6 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t piece0 = lds0 + wave * 8 * ROWB;   // this wave's 8 rows of pass 0, stage 0, operand A
-  const int pdelta = ((wave ^ (NW / 2)) - wave) * 8 * ROWB;   // (ALT) from there to the partner wave's rows
   const int lane = tid & 63;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   // lane = (row 0..15, k group 0..3); the one step of a slice reads hi chunk kgroup, lo chunk 4 + kgroup
@@ -174,9 +147,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   // In-kernel span of this launch (measurement only, off unless a span scope is open: one scalar test; dlip_common.h): what a
   // replayed step plan cannot give the host (no event can be read back from a graph) the kernel notes itself.
   dlip_span_enter(sk.span, g);
-#ifdef DLIP_LAB
-  if (threadIdx.x == 0 && sk.stamps) sk.stamps[(size_t)g * 10 + 8] = __builtin_amdgcn_s_memrealtime();
-#endif
+  DLIP_LAB_WG_STAMP(8, true);
   for (long long it = it_begin; it < it_end;) {
     const int tile = (int)(it / a.nk);
     const int k0 = (int)(it - (long long)tile * a.nk);
@@ -194,17 +165,12 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     // every wave is done reading the previous segment's last stage (and the ticket word) before the ring is refilled
     if (it != it_begin) __syncthreads();
     DLIP_STAMP(0);
-#ifdef DLIP_LAB
-    if (threadIdx.x == 0 && it == it_begin && sk.stamps) sk.stamps[(size_t)g * 10 + 7] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-#endif
+    DLIP_LAB_WG_STAMP(7, it == it_begin);
 
     f32x4 acc[MI][NI];
 #define DLIP_FENCE() __builtin_amdgcn_sched_barrier(0)
     if constexpr (WIN) {
-#ifdef DLIP_LAB
-#define DLIP_WINMODE_SECTION 2
-#include "conv_dma_lab.inc"
-#endif
+#include "conv_dma_hook_window.inc"
     } else {
     // Per-row gather state, branch-free: byte offset of the row's window origin and a bit per filter tap
     // that stays inside the image (columns and rows tested separately: R + S steps, not R x S).
@@ -212,7 +178,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     uint32_t a_mask[AQ];
     int a_h0[BIGTAPS ? AQ : 1], a_w0[BIGTAPS ? AQ : 1];   // (BIGTAPS) window origin of the row; rows past M: far outside
     int a2_off[DUAL ? AQ : 1];   // second source: byte offset of the row's pixel, < 0 past M
-    auto row_of = [&](int j) { return (j < A_PER ? rbase : rbase ^ (RPP / 2)) + RPP * (j % A_PER); };   // j >= A_PER: the partner wave's row
+    auto row_of = [&](int j) { return rbase + RPP * j; };
     {
       int hi0[AQ], wi0[AQ];
       uint32_t colbits[AQ];
@@ -253,7 +219,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     int b_off[BQ];
 #pragma unroll
     for (int j = 0; j < BQ; ++j) {
-      const int n = tile_n * BN + (j < B_PER ? rbase : rbase ^ (RPP / 2)) + RPP * (j % B_PER);
+      const int n = tile_n * BN + rbase + RPP * j;
       b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
     }
 
@@ -289,52 +255,36 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       if constexpr (BIGTAPS) return (unsigned)(a_h0[j] + tap_dh) < (unsigned)a.H && (unsigned)(a_w0[j] + tap_dw) < (unsigned)a.W;
       else return (a_mask[j] >> tap) & 1u;
     };
-    // (nj = A_PER / B_PER: this wave's own pieces; AQ / BQ: its partner's too)
-    auto issue_a = [&](int stage, auto nj) {
+    // this wave's A_PER + B_PER pieces of the slice the walk stands on -> ring stage `stage`
+    auto issue_a = [&](int stage) {
       const uint32_t base = piece0 + stage * STAGE_B;
       if (DUAL && c0 >= a.Cw) {          // (wave-uniform)
 #pragma unroll
-        for (int j = 0; j < nj(); ++j)
-          dma_piece(x2r, a2_off[DUAL ? j : 0] >= 0 ? (uint32_t)(a2_off[DUAL ? j : 0] + x_tap) : DLIP_OOB_OFFSET,
-                    base + (j % A_PER) * RPP * ROWB + (j < A_PER ? 0 : pdelta));
+        for (int j = 0; j < A_PER; ++j)
+          dma_piece(x2r, a2_off[DUAL ? j : 0] >= 0 ? (uint32_t)(a2_off[DUAL ? j : 0] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
         return;
       }
 #pragma unroll
-      for (int j = 0; j < nj(); ++j) {
+      for (int j = 0; j < A_PER; ++j) {
         const bool ok = tap_ok(j);
-        dma_piece(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + (j % A_PER) * RPP * ROWB + (j < A_PER ? 0 : pdelta));
+        dma_piece(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
       }
     };
-    auto issue_b = [&](int stage, auto nj) {
+    auto issue_b = [&](int stage) {
       const uint32_t base = piece0 + stage * STAGE_B + BM * ROWB;
 #pragma unroll
-      for (int j = 0; j < nj(); ++j)
-        dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + (j % B_PER) * RPP * ROWB + (j < B_PER ? 0 : pdelta));
-    };
-    auto issue_one = [&](int stage, int i) {   // piece i of this wave's NL of the slice the walk stands on: activations first
-      if (i < A_PER) {
-        const uint32_t base = piece0 + stage * STAGE_B;
-        const bool ok = tap_ok(i);
-        dma_piece(xr, ok ? (uint32_t)(a_off[i] + x_tap) : DLIP_OOB_OFFSET, base + i * RPP * ROWB);
-      } else {
-        const int j = i - A_PER;
-        const uint32_t base = piece0 + stage * STAGE_B + BM * ROWB;
+      for (int j = 0; j < B_PER; ++j)
         dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
-      }
     };
-    constexpr std::integral_constant<int, A_PER> own_a{};
-    constexpr std::integral_constant<int, B_PER> own_b{};
-    constexpr std::integral_constant<int, AQ> all_a{};
-    constexpr std::integral_constant<int, BQ> all_b{};
 
     // ---- prologue: put the first NSTAGE-1 slices in flight, then initialise the accumulators ----
     DLIP_STAMP(1);
-    issue_a(0, own_a);
-    issue_b(0, own_b);
+    issue_a(0);
+    issue_b(0);
     if (PF > 1 && kn > 1) {
       advance();
-      issue_a(1, own_a);
-      issue_b(1, own_b);
+      issue_a(1);
+      issue_b(1);
     }
 
     // Accumulators hold the TRANSPOSED tile (rows = output channels, columns = pixels: the weight
@@ -362,12 +312,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     // ---- main loop: per slice 3 groups of MI x NI instructions.  Group order lo*hi, hi*hi, hi*lo:
     // the last group needs neither the activation-lo nor the weight-hi fragments, so the NEXT slice's first
     // group's fragments are read (behind the barrier) into registers the tail of this slice does not use. ----
-#ifdef DLIP_LAB
-    if constexpr ((VAR & 64) != 0) {   // (lab experiment: the 256x256 tile's half-column loop, conv_dma_lab.inc section 3)
-#define DLIP_WINMODE_SECTION 3
-#include "conv_dma_lab.inc"
-    } else
-#endif
+#include "conv_dma_hook_tile256.inc"   // product: nothing
     if constexpr (PINGPONG) {
       // PING-PONG main loop (round 3; the eight-wave 256x128 tile).  The loop below (still what the four-wave tiles run) keeps the
       // two waves of a SIMD in LOCK STEP: both read their
@@ -387,7 +332,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       //   "wait slice s+1": this wave's pieces of slice s+1 have landed (vmcnt leaves only slice s+2's NL younger ones), so that
       //             behind the next barrier the whole stage of slice s+1 is complete for whichever half reads it first.
       // Accumulation order per accumulator is the product's (lo*hi, hi*hi, hi*lo per slice): bit-identical results.
-      static_assert(NW == 8 && NSTAGE == 3 && !ALT, "ping-pong: eight waves, three stages");
+      static_assert(NW == 8 && NSTAGE == 3, "ping-pong: eight waves, three stages");
       const bool half_b = wave >= NW / 2;            // (wave-uniform)
       f16x8 fal[MI], fah[MI], fbh[NI], fbl[NI];
       auto read_all = [&](int stage) {
@@ -442,7 +387,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         DLIP_FENCE();
         if (s + 2 < kn) {
           advance();
-          issue_a(st_iss, own_a); issue_b(st_iss, own_b);
+          issue_a(st_iss); issue_b(st_iss);
           st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1;
         }
         DLIP_FENCE();
@@ -532,84 +477,48 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       read_first(0);
 
       int st_cur = 0, st_iss = (PF > 1 && kn > 1) ? 2 % NSTAGE : 1 % NSTAGE;   // stage the next issue goes to
-      const bool late = (VAR & 2) && wave >= NW / 2;    // (wave-uniform)
-      if ((VAR & 1) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
       for (int kt = 0; kt < kn; ++kt) {
         const bool more1 = (kt + 1) < kn, moreP = (kt + PF) < kn;
         const int st_nxt = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
         // WHERE the slice's LDS-DMA pieces go out.  At the very top of the slice, right behind the barrier that frees their stage
-        // (`early`), a layer that runs back to back takes 3-4 % less time on 256x128 and 2-3 % less on 128x128 and the two-stage
-        // 128x64 than with the pieces in the MFMA shadow of groups 0 / 1 (tools/bench_dma.py; issued half a slice LATER: +15 %).
-        // On the STEP, at the board's power limit, the 256x128 tile is the other way round (tools/ab_step.sh, three rounds, same
-        // box): shadow issue 15 225 vs 15 033 clips/s, this kernel 339 vs 326 TFLOP/s -- the burst leaves the matrix core idle and
-        // then runs it flat out, the interleaved issue draws less power for the same work.  128x128 keeps the early issue (-6.5 %
-        // in the step without it); the three-stage 128x64 never had it.
+        // (`early`), a layer that runs back to back takes 2-3 % less time on 128x128 and the two-stage 128x64 than with the pieces in
+        // the MFMA shadow of groups 0 / 1 (tools/bench_dma.py; -6.5 % on 128x128's launches in the step); the three-stage 128x64
+        // never had it (+1 %).  (The 256x128 tile runs the ping-pong loop above; its lock-step form, the lab build's reference,
+        // keeps its pieces in the shadow: at the board's power limit the burst at the top cost the step 1.3 %.)
         constexpr bool early = (VAR & 4) != 0 || (BM == 128 && BN == 128) || (BM == 128 && BN == 64 && NSTAGE == 2);
-        const bool my_turn = !ALT || (kt & 1) == (wave >= NW / 2 ? 1 : 0);   // (wave-uniform)
         DLIP_SSTAMP(0);
-        constexpr bool SPREAD = (VAR & 16) != 0 && NW == 8 && early && NL == 6 && MI == 4 && !ALT;   // (lab: the 256x128 tile)
-        bool spread = false;                       // (wave-uniform)
-        const int st_now = st_iss;
         if (early && moreP) {
           advance();
-          // a slice whose activation rows were fetched by an earlier tap of the same channel slice: every piece is an L2 hit
-          if constexpr (SPREAD) spread = tap != 0 && !(DUAL && c0 >= a.Cw);
-          if (spread) { if (!((VAR & 32) != 0 && wave >= NW / 2)) issue_one(st_now, 0); }
-          else if (my_turn) { issue_a(st_iss, all_a); issue_b(st_iss, all_b); }
+          issue_a(st_iss); issue_b(st_iss);
           st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1;
         }
         DLIP_FENCE();
         DLIP_SSTAMP(1);
         read_rest(st_cur); DLIP_FENCE();
-        if constexpr (SPREAD) {
-          // Twelve quarter-groups of NI MFMAs; a spread slice's six pieces go out one at a time behind quarters -1 (the
-          // advance above), 1, 3, 5, 7, 9 -- or, in the waves that share their SIMDs with those (VAR bit 5), behind quarters
-          // 0, 2, 4, 6, 8, 9: the two waves of a SIMD then never stand in the address unit's queue at the same time.
-          const bool odd = (VAR & 32) != 0 && wave >= NW / 2;   // (wave-uniform)
-          auto slot = [&](int q) {                               // q: compile-time
-            if (!spread) return;
-            if (q == 9) { issue_one(st_now, 5); return; }
-            if (!odd && (q & 1) && q > 0) issue_one(st_now, (q + 1) / 2);
-            if (odd && !(q & 1) && q >= 0) issue_one(st_now, q / 2);
-          };
-#pragma unroll
-          for (int q = 0; q < 10; ++q) {
-            mfma_p(q / 4 == 0 ? 0 : q / 4 == 1 ? 1 : 2, q % 4, q % 4 + 1); DLIP_FENCE();
-            slot(q); DLIP_FENCE();
-          }
-        } else {
         mfma_p(0, 0, MI); DLIP_FENCE();
         DLIP_SSTAMP(2);
-        if (moreP && !late && !early) { advance(); issue_a(st_iss, own_a); } DLIP_FENCE();
+        if (moreP && !early) { advance(); issue_a(st_iss); } DLIP_FENCE();
         mfma_p(1, 0, MH); DLIP_FENCE();
-        if (moreP && !late && !early) { issue_b(st_iss, own_b); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
+        if (moreP && !early) { issue_b(st_iss); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
         if (MH < MI) mfma_p(1, MH, MI);
         DLIP_FENCE();
-        if (moreP && late) { advance(); issue_a(st_iss, own_a); } DLIP_FENCE();
         // (the barrier one half-group earlier, behind group 1 -- what the window kernel does -- measured 1-7 % SLOWER here)
         mfma_p(2, 0, MH); DLIP_FENCE();
-        if (moreP && late) { issue_b(st_iss, own_b); st_iss = st_iss + 1 == NSTAGE ? 0 : st_iss + 1; } DLIP_FENCE();
-        }
         DLIP_SSTAMP(3);
         if (more1) {
           // slice kt+1 must have landed (every wave's share: wait, then barrier); slices beyond it stay in flight
-          if constexpr (ALT) {   // the issuer of this slice keeps its 2 NL newest pieces (slice kt + 2) in flight; its partner has none younger than kt + 1's
-            if (my_turn && moreP) wait_vmcnt<2 * NL>(); else wait_vmcnt<0>();
-          } else {
-            if (PF > 1 && (kt + 2) < kn) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-          }
+          if (PF > 1 && (kt + 2) < kn) wait_vmcnt<NL>(); else wait_vmcnt<0>();
           DLIP_SSTAMP(4);
           __builtin_amdgcn_s_barrier();
           DLIP_SSTAMP(5);
           read_first(st_nxt);
         }
         DLIP_FENCE();
-        if (MH < MI) mfma_p(2, MH, MI);   // (quarters 10, 11 of a SPREAD build)
+        if (MH < MI) mfma_p(2, MH, MI);
         DLIP_FENCE();
         DLIP_SSTAMP(6);
         st_cur = st_nxt;
       }
-      if (VAR & 1) __builtin_amdgcn_s_setprio(0);
     }
     }
 #undef DLIP_FENCE
@@ -849,81 +758,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       }
       if constexpr (OSPLIT) dlip_report_range(amax, a.status);
     }
-#ifdef DLIP_LAB
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0 && it == it_begin && sk.stamps) {
-      sk.stamps[(size_t)g * 10 + 5] = __builtin_amdgcn_s_memtime();
-      sk.stamps[(size_t)g * 10 + 6] = (unsigned long long)kn;
-      sk.stamps[(size_t)g * 10 + 7] = __builtin_amdgcn_s_memrealtime() - sk.stamps[(size_t)g * 10 + 7];
-    }
-#endif
+    DLIP_LAB_SEGMENT_END_STAMPS();
     it += kn;
   }
   dlip_span_exit(sk.span);
-#ifdef DLIP_LAB
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (threadIdx.x == 0 && sk.stamps) {
-    sk.stamps[(size_t)g * 10 + 9] = __builtin_amdgcn_s_memrealtime();
-    sk.stamps[(size_t)g * 10 + 6] |= (unsigned long long)(blockIdx.x & 7) << 32;
-  }
-#endif
+  DLIP_LAB_WG_END_STAMPS();
 }
 
-#ifdef DLIP_LAB
-// Lab build only (DLIP_STAMP_PRINT set): launch with the s_memtime stamps buffer, wait, print the median cycles
-// between the stamps of each workgroup's first segment (tools/probes/stamps.sh).
-template <typename K>
-int dlip_lab_stamped_launch(K kern, unsigned G, int threads, size_t lds, hipStream_t st, const ConvArgs& b, StreamK sk, int BM, int BN) {
-  static unsigned long long* dbuf = nullptr;
-  static size_t cap = 0;
-  if (cap < (size_t)G * 30) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc(reinterpret_cast<void**>(&dbuf), (size_t)G * 30 * 8); cap = (size_t)G * 30; }
-  (void)hipMemsetAsync(dbuf, 0, (size_t)G * 30 * 8, st);
-  sk.stamps = dbuf;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(threads), lds, st, b, sk);
-  (void)hipStreamSynchronize(st);
-  std::vector<unsigned long long> h((size_t)G * 30);
-  (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
-  std::vector<double> d[5], per, clk, dur;
-  unsigned long long t0 = ~0ull, t1 = 0, s1 = 0;
-  for (unsigned i = 0; i < G; ++i) {
-    const unsigned long long* r = &h[(size_t)i * 10];
-    if (r[5]) {
-      for (int j = 0; j < 5; ++j) d[j].push_back((double)(r[j + 1] - r[j]));
-      per.push_back((double)(r[4] - r[3]) / (double)((r[6] & 0xffffffffull) ? (r[6] & 0xffffffffull) : 1));
-      if (r[7]) clk.push_back((double)(r[5] - r[0]) / (double)r[7] * 100.0);   // MHz: s_memtime ticks per 100 MHz s_memrealtime tick
-    }
-    if (r[9]) {
-      t0 = r[8] < t0 ? r[8] : t0; s1 = r[8] > s1 ? r[8] : s1; t1 = r[9] > t1 ? r[9] : t1;
-      dur.push_back((double)(r[9] - r[8]) / 100.0);
-    }
-  }
-  auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
-  std::sort(dur.begin(), dur.end());
-  if (!dur.empty())
-    fprintf(stderr, "[stamps wall] kernel span %.1f us; workgroup starts spread %.1f us; workgroup busy min %.1f med %.1f max %.1f us\n",
-            (double)(t1 - t0) / 100.0, (double)(s1 - t0) / 100.0, dur.front(), dur[dur.size() / 2], dur.back());
-  fprintf(stderr, "[stamps %dx%d M=%d K=%d nk=%d G=%u] setup %.0f  issue+init %.0f  first-wait %.0f  loop %.0f (%.0f/slice)  tail %.0f  clock %.0f MHz\n",
-          BM, BN, b.M, b.K, b.nk, G, med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(per), med(d[4]), med(clk));
-  std::vector<double> e[6];
-  for (unsigned i = 0; i < G; ++i) {
-    const unsigned long long* r = &h[((size_t)G + i) * 10];
-    if (r[6] && r[0]) for (int j = 0; j < 6; ++j) e[j].push_back((double)(r[j + 1] - r[j]));
-  }
-  fprintf(stderr, "[slice 8 of the first segment, wave 0] piece issue %.0f  rest reads + group 0 %.0f  group 1 + half of 2 %.0f  vmcnt wait %.0f  barrier %.0f  first reads + rest of group 2 %.0f\n",
-          med(e[0]), med(e[1]), med(e[2]), med(e[3]), med(e[4]), med(e[5]));
-  {   // ping-pong loop: the same slice in half B (wave 4); for half A the line above reads: LOAD | barrier | matrix phase | - | barrier | wait
-    std::vector<double> f[5];
-    for (unsigned i = 0; i < G; ++i) {
-      const unsigned long long* r = &h[((size_t)2 * G + i) * 10];
-      if (r[5] && r[0]) for (int j = 0; j < 5; ++j) f[j].push_back((double)(r[j + 1] - r[j]));
-    }
-    if (!f[0].empty())
-      fprintf(stderr, "[ping-pong, the same slice in half B (wave 4)] LOAD %.0f  vmcnt wait %.0f  barrier %.0f  matrix phase %.0f  barrier %.0f\n",
-              med(f[0]), med(f[1]), med(f[2]), med(f[3]), med(f[4]));
-  }
-  return dlip_launch_status();
-}
-#endif
+#include "conv_dma_lab_menu.inc"   // lab build: the stamped launch path (nothing in the product build)
 
 // Per-stream workspace of the balanced split: ticket counters (zeroed once; every launch leaves them
 // zero) + slabs.  Launches on one stream are ordered, so they can share it; another stream needs its own.
@@ -1072,10 +914,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
   // stays on one 128-channel weight block and re-streams the (L2-sized) activations instead (+4 % if forced inner).
   b.n_inner = (b.tiles_n > 1 && (size_t)a.K * a.rsc * 4 <= (size_t)3407872) ? 1 : 0;
   if (dlip_dbg_value[DLIP_DBG_NINNER] >= 0) b.n_inner = dlip_dbg_value[DLIP_DBG_NINNER] > 0 ? 1 : 0;
-#ifdef DLIP_LAB
-  sk.stamps = nullptr;
-  if (getenv("DLIP_STAMP_PRINT")) return dlip_lab_stamped_launch(kern, (unsigned)G, threads, lds, st, b, sk, BM, BN);
-#endif
+  DLIP_LAB_LAUNCH_HOOK();   // (lab build: DLIP_STAMP_PRINT -> stamped launch + printed medians)
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(threads), lds, st, b, sk);
   return dlip_launch_status();
 }
@@ -1114,15 +953,9 @@ int launch_dma(const ConvArgs& a, hipStream_t st, int epi) {
 
 // Tile menu of the DMA kernel (index = what dlip_conv_plan reports via dlip_conv_dma_tile; dlip_debug_set
 // (DLIP_DBG_DMA_TILE) forces one for tests and A/B runs).  0..5 are the product instances; a lab build
-// (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) adds the experiments 6..9.
-#ifdef DLIP_LAB
-const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128},
-                           {256, 128}, {256, 128}, {128, 64}, {64, 128}, {256, 256}, {256, 128}, {256, 128}, {256, 128}};   // 10: the 256x256 experiment; 11: 256x128 with the lock-step loop; 12: ping-pong without priority; 13: ping-pong, group-major MFMA order; 6, 7: tile 5 with VAR 16 / 48 (the pieces spread behind MFMA quarter-groups; the SIMD partners out of phase); 8, 9: tiles 4, 2 with VAR 4
-constexpr int NUM_DMA_ALL = 14;
-#else
-const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128}};
-constexpr int NUM_DMA_ALL = 6;
-#endif
+// (python -m deeplip_amd.build --lab: -DDLIP_LAB, libdeeplip_hip_lab.so) appends its experiments (conv_dma_hooks.h).
+const TileCfg kDmaCfg[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {256, 128} DLIP_LAB_TILE_CFGS};
+constexpr int NUM_DMA_ALL = (int)(sizeof(kDmaCfg) / sizeof(kDmaCfg[0]));
 
 // Tile choice (measured per layer with tools/bench_dma.py, MI355X, balanced split on).  The cost of a slice
 // is set by the bytes it pulls from L2 (ablations: pieces issued out of range cost nothing, pieces that fetch
@@ -1166,21 +999,6 @@ extern "C" __attribute__((visibility("hidden"))) void dlip_conv_dma_tile(long lo
   *bn = c.bn;
 }
 
-// Window mode of the 256x128 tile: stride-1 convolutions with more than one tap whose output pixel m reads the input pixels
-// m + const (same-size convolutions of any dilation; 1-D "valid" convolutions, where the constant grows by W - Wo per
-// image), no second source, fp32 / split output; the taps' halo (+ the image shifts inside one tile) within the window's slack.
-[[maybe_unused]] static bool win_mode_ok(const ConvArgs& a, int epi) {
-  if (dlip_dbg_value[DLIP_DBG_WIN] == 0 || epi == 2 || a.x2 != nullptr) return false;
-  const int taps = a.R * a.S, Ho = a.HoWo / a.Wo;
-  if (a.sh != 1 || a.sw != 1 || taps < 2 || taps > 25 || (a.C & 31)) return false;
-  const bool same = Ho == a.H && a.Wo == a.W;
-  const bool valid1d = a.H == 1 && a.R == 1 && a.ph == 0 && a.pw == 0 && Ho == 1;
-  if (!same && !valid1d) return false;
-  const int D = a.H * a.W - a.HoWo;
-  const int span = (a.R - 1) * a.dh * a.W + (a.S - 1) * a.dw + (D ? ((256 + a.HoWo - 1) / a.HoWo) * D : 0);
-  return span <= 48 && a.ph * a.W + a.pw <= 48;
-}
-
 // Called by dlip_conv_nhwc_f16x3 / dlip_conv2_nhwc_f16x3 / dlip_conv_pool_f16x3 for DLIP_SPLIT_IN launches
 // (argument checks done there).  epi: 0 fp32 y, 1 split y, 2 pooled partials (a.pool, a.pool_group).
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int epi) {
@@ -1204,20 +1022,8 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(
     case 2: return launch_dma<64, 128, 2, 2, 3, 2>(a, st, epi);
     case 3: return launch_dma<64, 64, 2, 2, 3, 2>(a, st, epi);
     case 4: return launch_dma<128, 64, 2, 2, 2, 3>(a, st, epi);
-#ifdef DLIP_LAB
-    case 6: return launch_dma<256, 128, 4, 2, 3, 1, 16>(a, st, epi);
-    case 7: return launch_dma<256, 128, 4, 2, 3, 1, 48>(a, st, epi);
-    case 8: return launch_dma<128, 64, 2, 2, 2, 3, 4>(a, st, epi);
-    case 9: return launch_dma<64, 128, 2, 2, 3, 2, 4>(a, st, epi);
-    case 13: return launch_dma<256, 128, 4, 2, 3, 1, 2048>(a, st, epi);   // the ping-pong loop with the group-major MFMA order (its first version)
-    case 12: return launch_dma<256, 128, 4, 2, 3, 1, 512>(a, st, epi);    // the product's ping-pong loop without s_setprio around the matrix phase
-    case 11: return launch_dma<256, 128, 4, 2, 3, 1, 1024>(a, st, epi);   // the LOCK-STEP loop on 256x128 (the product until round 3): the reference of the ping-pong loop
-    case 10: return launch_dma<256, 256, 4, 2, 2, 1, 64>(a, st, epi);   // experiment: 64 KB per slice for twice the MFMAs of 256x128 (48 KB)
-#endif
+    DLIP_LAB_DISPATCH_CASES   // (lab build: tiles 6.. of its menu; nothing in the product build)
     default:
-#ifdef DLIP_LAB
-      if (dlip_dbg_value[DLIP_DBG_WIN] == 2 && win_mode_ok(a, epi)) return launch_dma<256, 128, 4, 2, 3, 1, 128>(a, st, epi);   // experiment
-#endif
       return launch_dma<256, 128, 4, 2, 3, 1, 0>(a, st, epi);
   }
 }

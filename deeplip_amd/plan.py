@@ -95,6 +95,20 @@ class _NameHook:
 SPAN_KERNELS = ("conv_igemm_f16x3_dma_kernel", "conv_rows_f16x3_kernel", "conv_win_f16x3_kernel", "stem3d_pool_f16x3_kernel")
 
 
+def _quiesce_collectives(device) -> None:
+    """Inside a torch.distributed job on RCCL: let the process group's watchdog thread finish with every collective issued so
+    far before a stream capture starts.  The watchdog polls the events of un-reaped work every ~100 ms from its own thread; a poll
+    that fell INTO the capture of a plan ended the job with `hipErrorCapturedEvent` ("operation not permitted on an event last
+    recorded in a capturing stream") about one run in four (tests/test_rccl_gpu.py::test_bench_scaling_protocol_on_rccl_one_rank,
+    round 4: torch's own graph capture tells the watchdog, a raw hipStreamBeginCapture cannot).  With the device idle and two
+    poll periods gone, nothing is left for it to query while the plan records."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        import time
+        torch.cuda.synchronize(device)
+        time.sleep(0.25)
+
+
 class StepPlan:
     """``fn(*inputs)`` recorded on a private HIP stream; see the module docstring."""
 
@@ -126,6 +140,7 @@ class StepPlan:
         with torch.cuda.stream(self.stream), torch.no_grad():
             self._pass("collect")                 # warm-up: packs weights, registers the workspace, fills the arena
             self.stream.synchronize()
+            _quiesce_collectives(self.device)
             check(lib().dlip_plan_begin(self.stream.cuda_stream), "dlip_plan_begin")
             try:
                 out = self._pass("replay")
