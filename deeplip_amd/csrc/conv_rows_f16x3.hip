@@ -106,7 +106,9 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #endif
 
   // ---- issue cursor: the slice the NEXT pieces belong to (two slices ahead of the one being multiplied) ----
-  int a_off[NA_A], b_off[B_PER];
+  // (rows past M / weight rows past K carry the out-of-range offset itself: 2^31 plus any in-range tap offset is still beyond every
+  // buffer, so a piece's address is ONE add -- the select per piece was two of every three vector instructions of a slice)
+  uint32_t a_off[NA_A], b_off[B_PER];
   int c_item = g, c_k = 0, s_pos = 0, c0 = 0, x_tap = 0, w_tap = 0;
   auto set_item = [&](int item) __attribute__((always_inline)) {
     const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
@@ -116,12 +118,12 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       const int mc = m < a.M ? m : 0;
       const int n = dlip_div(mc, a.div_howo);
       const int t = mc - n * a.HoWo;                       // H = 1: the row's first input pixel is n * W + t
-      a_off[j] = m < a.M ? ((n * a.W + t) * a.ldx + csrc) * 4 : -1;
+      a_off[j] = m < a.M ? (uint32_t)(((n * a.W + t) * a.ldx + csrc) * 4) : DLIP_OOB_OFFSET;
     }
 #pragma unroll
     for (int j = 0; j < B_PER; ++j) {
       const int n = tile_n * BN + 8 * (wave + 8 * j) + prow;
-      b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
+      b_off[j] = n < a.K ? (uint32_t)((n * a.rsc + csrc) * 4) : DLIP_OOB_OFFSET;
     }
   };
   auto advance = [&]() __attribute__((always_inline)) {   // channel slice outer, tap inner (the ring kernel's reduction order)
@@ -139,10 +141,10 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
     const uint32_t base = piece0 + stage * STAGE_B;
 #pragma unroll
     for (int j = 0; j < na(); ++j)
-      dma_piece(xr, a_off[j] >= 0 ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * 8192);
+      dma_piece(xr, a_off[j] + (uint32_t)x_tap, base + j * 8192);
 #pragma unroll
     for (int j = 0; j < B_PER; ++j)
-      dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + BM * ROWB + j * 8192);
+      dma_piece(wr, b_off[j] + (uint32_t)w_tap, base + BM * ROWB + j * 8192);
   };
 
   f32x4 acc[MI][NI];
