@@ -175,9 +175,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     // Per-row gather state, branch-free: byte offset of the row's window origin and a bit per filter tap
     // that stays inside the image (columns and rows tested separately: R + S steps, not R x S).
     int a_off[AQ];
-    uint32_t a_mask[AQ];
+    uint32_t a_mask[AQ];         // after set-up: INVERTED (bit tap set = that tap falls outside the image, or the row is past M)
     int a_h0[BIGTAPS ? AQ : 1], a_w0[BIGTAPS ? AQ : 1];   // (BIGTAPS) window origin of the row; rows past M: far outside
-    int a2_off[DUAL ? AQ : 1];   // second source: byte offset of the row's pixel, < 0 past M
+    uint32_t a2_off[DUAL ? AQ : 1];   // second source: byte offset of the row's pixel; the out-of-range offset itself past M
     auto row_of = [&](int j) { return rbase + RPP * j; };
     {
       int hi0[AQ], wi0[AQ];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         hi0[j] = ho * a.sh - a.ph;
         wi0[j] = wo * a.sw - a.pw;
         a_off[j] = (((n * (BIGTAPS ? a.Hs : a.H) + hi0[j]) * a.W + wi0[j]) * a.ldx + csrc) * 4;
-        if constexpr (DUAL) a2_off[j] = m < a.M ? (((n * a.H2 + ho * a.s2h) * a.W2 + wo * a.s2w) * a.ldx2 + csrc) * 4 : -1;
+        if constexpr (DUAL) a2_off[j] = m < a.M ? (uint32_t)((((n * a.H2 + ho * a.s2h) * a.W2 + wo * a.s2w) * a.ldx2 + csrc) * 4) : DLIP_OOB_OFFSET;
         colbits[j] = 0u;
         a_mask[j] = 0u;
       }
@@ -213,14 +213,15 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
             a_mask[j] |= ((unsigned)(hi0[j] + r * a.dh) < (unsigned)a.H ? colbits[j] : 0u) << (r * a.S);
 #pragma unroll
         for (int j = 0; j < AQ; ++j)
-          if (tile_m * BM + row_of(j) >= a.M) a_mask[j] = 0u;
+          a_mask[j] = tile_m * BM + row_of(j) >= a.M ? ~0u : ~a_mask[j];
       }
     }
-    int b_off[BQ];
+    // (a weight row past K carries the out-of-range offset itself: 2^31 plus any tap offset stays out of range -- one add per piece)
+    uint32_t b_off[BQ];
 #pragma unroll
     for (int j = 0; j < BQ; ++j) {
       const int n = tile_n * BN + rbase + RPP * j;
-      b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
+      b_off[j] = n < a.K ? (uint32_t)((n * a.rsc + csrc) * 4) : DLIP_OOB_OFFSET;
     }
 
     // Reduction walk: 32-channel slice OUTER, filter tap INNER (conv_igemm_f16x3.hip), entered at slice k0.
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     };
     auto tap_ok = [&](int j) -> bool {
       if constexpr (BIGTAPS) return (unsigned)(a_h0[j] + tap_dh) < (unsigned)a.H && (unsigned)(a_w0[j] + tap_dw) < (unsigned)a.W;
-      else return (a_mask[j] >> tap) & 1u;
+      else return ((a_mask[j] >> tap) & 1u) == 0u;
     };
     // this wave's A_PER + B_PER pieces of the slice the walk stands on -> ring stage `stage`
     auto issue_a = [&](int stage) {
@@ -261,20 +262,27 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       if (DUAL && c0 >= a.Cw) {          // (wave-uniform)
 #pragma unroll
         for (int j = 0; j < A_PER; ++j)
-          dma_piece(x2r, a2_off[DUAL ? j : 0] >= 0 ? (uint32_t)(a2_off[DUAL ? j : 0] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+          dma_piece(x2r, a2_off[DUAL ? j : 0] + (uint32_t)x_tap, base + j * RPP * ROWB);
         return;
       }
 #pragma unroll
       for (int j = 0; j < A_PER; ++j) {
-        const bool ok = tap_ok(j);
-        dma_piece(xr, ok ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+        if constexpr (BIGTAPS) {
+          dma_piece(xr, tap_ok(j) ? (uint32_t)(a_off[j] + x_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+        } else {
+          // a tap outside the image: its bit of the inverted mask, shifted to bit 31, ORed into the offset -- beyond every buffer
+          // whatever the sum was (add, shift, and-or: the compare + select form was five vector instructions per piece in the
+          // load phase, which is the long pole of a ping-pong slice)
+          const uint32_t oob = (a_mask[j] << (31 - tap)) & 0x80000000u;
+          dma_piece(xr, (uint32_t)(a_off[j] + x_tap) | oob, base + j * RPP * ROWB);
+        }
       }
     };
     auto issue_b = [&](int stage) {
       const uint32_t base = piece0 + stage * STAGE_B + BM * ROWB;
 #pragma unroll
       for (int j = 0; j < B_PER; ++j)
-        dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, base + j * RPP * ROWB);
+        dma_piece(wr, b_off[j] + (uint32_t)w_tap, base + j * RPP * ROWB);
     };
 
     // ---- prologue: put the first NSTAGE-1 slices in flight, then initialise the accumulators ----

@@ -122,17 +122,17 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   const int cq = tid & 7, rbase = tid >> 3;
   const int key_st = (rbase >> 1) & 7;
   const int csrc = ((cq ^ key_st) << 2);
-  int b_off[B_PER];
+  uint32_t b_off[B_PER];   // (a weight row past K carries the out-of-range offset itself: one add per piece, no select)
 #pragma unroll
   for (int j = 0; j < B_PER; ++j) {
     const int n = rbase + RPP * j;
-    b_off[j] = n < a.K ? (n * a.rsc + csrc) * 4 : -1;
+    b_off[j] = n < a.K ? (uint32_t)((n * a.rsc + csrc) * 4) : DLIP_OOB_OFFSET;
   }
   const uint32_t bpiece0 = lds0 + wave * 8 * ROWB;
   auto issue_b = [&](int stage, int w_tap) {
 #pragma unroll
     for (int j = 0; j < B_PER; ++j)
-      dma_piece(wr, b_off[j] >= 0 ? (uint32_t)(b_off[j] + w_tap) : DLIP_OOB_OFFSET, bpiece0 + stage_off(stage) + j * RPP * ROWB);
+      dma_piece(wr, b_off[j] + (uint32_t)w_tap, bpiece0 + stage_off(stage) + j * RPP * ROWB);
   };
   // window piece q (= 2 block + half) of channel slice cc of the tile whose window starts at input pixel p0 -> slot
   auto issue_win = [&](int slot, int cc, int q, int p0) {
