@@ -96,12 +96,17 @@ SPAN_KERNELS = ("conv_igemm_f16x3_dma_kernel", "conv_rows_f16x3_kernel", "conv_w
 
 
 def _quiesce_collectives(device) -> None:
-    """Inside a torch.distributed job on RCCL: let the process group's watchdog thread finish with every collective issued so
-    far before a stream capture starts.  The watchdog polls the events of un-reaped work every ~100 ms from its own thread; a poll
-    that fell INTO the capture of a plan ended the job with `hipErrorCapturedEvent` ("operation not permitted on an event last
-    recorded in a capturing stream") about one run in four (tests/test_rccl_gpu.py::test_bench_scaling_protocol_on_rccl_one_rank,
-    round 4: torch's own graph capture tells the watchdog, a raw hipStreamBeginCapture cannot).  With the device idle and two
-    poll periods gone, nothing is left for it to query while the plan records."""
+    """Precaution, NOT a verified fix.  tests/test_rccl_gpu.py::test_bench_scaling_protocol_on_rccl_one_rank (a plan recorded
+    inside a one-rank RCCL job) ended once in ~5 full-suite runs of round 4 with `hipErrorCapturedEvent` ("operation not permitted
+    on an event last recorded in a capturing stream") and passed 3 of 3 re-runs before this function existed, so its passing
+    afterwards shows nothing.  The guess this acts on -- the process group's watchdog thread polling an event while the raw
+    stream capture is open -- is untested, and the capture is already thread-local (csrc/plan.hip); the caching allocator's
+    event queries are an equally untested candidate.  What it does: with the nccl backend up, idle the
+    device and wait two watchdog poll periods before the capture starts.  `DLIP_PLAN_QUIESCE=0` turns it off (for the A/B
+    that would settle whether it matters)."""
+    import os
+    if os.environ.get("DLIP_PLAN_QUIESCE", "1") == "0":
+        return
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
         import time
