@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 41
+ABI_VERSION = 42
 LIFT_WORDS = 4098
 LIFT_BCAST = 2048
 
@@ -219,7 +219,7 @@ def ensure_conv_workspace() -> None:
 
 
 # ---- diagnostic overrides (tests, tools): dlip_debug_set ----
-DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK, DBG_WIN, DBG_NINNER, DBG_ROWS = 0, 1, 2, 3, 4, 5, 6
+DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK, DBG_WIN, DBG_NINNER, DBG_ROWS, DBG_ROWS2D = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 DEBUG = {}          # what this process set through debug_set (key -> value; -1 / absent = the built-in choice)

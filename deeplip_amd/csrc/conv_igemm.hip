@@ -316,11 +316,13 @@ extern "C" void dlip_conv_dma_tile(long long M, int K, int nk, int epi, int* bm,
 extern "C" int dlip_conv_dma_enabled(void);                                  // conv_igemm_f16x3.hip
 
 extern "C" int dlip_conv_rows_plan(const dlip_conv_desc* d, int* bm);   // conv_rows_f16x3.hip
+extern "C" int dlip_conv_rows2d_plan(const dlip_conv_desc* d, int c2, int* bm);
 extern "C" int dlip_conv_plan(const dlip_conv_desc* d, int32_t split_f16, int32_t* bm, int32_t* bn) {
   DLIP_CHECK_ARG(d && bm && bn && d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0);
   if ((split_f16 & 3) == 3 && dlip_conv_dma_enabled()) {   // split-format activations: the LDS-DMA kernel's menu
     int rbm = 0;
     if (dlip_conv_rows_plan(d, &rbm)) { *bm = rbm; *bn = 256; return DLIP_OK; }   // conv_rows_f16x3_kernel<BM / 32, ..>: BM x 256
+    if (dlip_conv_rows2d_plan(d, 0, &rbm)) { *bm = rbm; *bn = 256; return DLIP_OK; }   // its general mode (2-D filters, residual, second source)
     dlip_conv_dma_tile((long long)d->N * d->Ho * d->Wo, d->K, d->R * d->S * ((d->C + 31) / 32), 0, bm, bn);
     return DLIP_OK;
   }

@@ -999,6 +999,24 @@ static int dma_pick(long long M, int K, int nk, int epi) {
   return 0;
 }
 
+// The split workspace of `stream` for another kernel of the library (conv_rows_f16x3.hip's general mode): 1 and the block, or 0
+// when there is none of that size (same rules as for this kernel's own launches: never allocated inside a stream capture).
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_split_workspace(void* stream, size_t slab_floats, float** slabs, int** counters,
+                                                                               int* counter_words) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  Workspace* w = workspace_for(dev, static_cast<hipStream_t>(stream), slab_floats);
+  if (w == nullptr) return 0;
+  *slabs = w->slabs;
+  *counters = w->counters;
+  *counter_words = kMaxSplitTiles;
+  return 1;
+}
+
+extern "C" int dlip_conv_rows2d_ok(const void* args, int epi);                                // conv_rows_f16x3.hip
+extern "C" int dlip_conv_f16x3_rows2d_launch(const void* args, void* stream, int epi);
+extern "C" int dlip_conv_rows_declined(void);
+
 // Library-internal entry points (hidden): ConvArgs lives in an unnamed namespace, so it crosses the
 // translation-unit boundary as an opaque pointer.
 extern "C" __attribute__((visibility("hidden"))) void dlip_conv_dma_tile(long long M, int K, int nk, int epi, int* bm, int* bn) {
@@ -1012,6 +1030,13 @@ extern "C" __attribute__((visibility("hidden"))) void dlip_conv_dma_tile(long lo
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_dma_launch(const void* args, void* stream, int epi) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // (round 4) the rows kernel's general mode (160 x 256 tiles, continuous slice stream, epilogue from registers, the same balanced
+  // split), when FORCED (dlip_debug_set(7, 1); measured slower than this kernel on the trunk: conv_rows_f16x3.hip); it declines when
+  // the stream has no split workspace for it
+  if (dlip_conv_rows2d_ok(args, epi)) {
+    const int rc = dlip_conv_f16x3_rows2d_launch(args, stream, epi);
+    if (rc != dlip_conv_rows_declined()) return rc;
+  }
   // The many-tap instances are also the ONLY ones that honour the slice / tap strides of slice-major operand images
   // (dlip_wgrad_conv_f16x3: cs_x, wt, cs_w, Hs); a weight gradient with 32 taps or fewer -- layer 4's 3x3 output-gradient maps: 9 taps --
   // used to fall through to the pixel-major instances below and read its slice-major images as if they were pixel-major: wrong
@@ -1041,8 +1066,9 @@ extern "C" int64_t dlip_conv_workspace_bytes(void) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return -1;
-  // counters + two slabs per resident workgroup: 2 per CU x 128x128 fp32 is the largest product on the menu
-  return (int64_t)kMaxSplitTiles * 4 + (int64_t)2 * (2 * cus) * 128 * 128 * 4;
+  // counters + two slabs per resident workgroup: one per CU x 160x256 fp32 (the rows kernel's general mode) is the largest product on
+  // the menu (this kernel's own: 2 per CU x 128x128)
+  return (int64_t)kMaxSplitTiles * 4 + (int64_t)2 * cus * 160 * 256 * 4;
 }
 
 extern "C" int dlip_conv_set_workspace(void* ptr, int64_t bytes, dlip_stream_t stream) {

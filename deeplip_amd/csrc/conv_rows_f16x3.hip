@@ -34,12 +34,23 @@
 #include <cstdlib>
 #include <vector>
 
+// conv_igemm_f16x3_dma.hip: the per-stream workspace of the balanced split (slabs + ticket words); 0 = none / too small
+extern "C" int dlip_conv_split_workspace(void* stream, size_t slab_floats, float** slabs, int** counters, int* counter_words);
+
 namespace {
 
 struct RowsSched {
   int items;      // tiles of the launch: tiles_m * tiles_n, row block major (the column blocks of a row block are neighbours)
   int tiles_n;
   unsigned long long* span;   // NULL, or this launch's {first start, last end} in 100 MHz ticks (dlip_span_scope_*)
+  // MODE 1 (balanced split, the ring kernel's stream-K): the items * nk slices of the launch cut into G equal ranges, one per
+  // workgroup; a tile shared by several ranges goes through fp32 slabs (two per workgroup: its first and its last segment) and
+  // ticket words (8 per tile: one per wave position) in the ring kernel's per-stream workspace
+  int iters;      // items * nk; iters * G < 2^31 (32-bit arithmetic and magic-number division throughout: the 64-bit quotients'
+  int G;          // expansion left the cursor state in vector registers and on the stack)
+  FastDiv div_G, div_iters, div_nk;
+  float* slabs;
+  int* counters;
 #ifdef DLIP_LAB
   unsigned long long* stamps;
 #endif
@@ -47,10 +58,32 @@ struct RowsSched {
 
 constexpr int ROWS_BN = 256;
 
+// The kernel's ConvArgs as the kernarg segment holds it (first explicit argument: offset 0), behind an opaque asm: what is read
+// through this pointer is (re)loaded where it is used -- scalar loads, once per tile -- instead of being kept in scalar registers
+// for the whole kernel.  The general mode's tile set-up and epilogue need ~45 argument words and seven buffer descriptors between
+// them; held across the main loop they spilled ~300 scalar registers into vector lanes and, from there, loop state into scratch.
+typedef const ConvArgs __attribute__((address_space(4))) RowsKArgs;
+__device__ __forceinline__ RowsKArgs* rows_kargs() {
+  RowsKArgs* p = (RowsKArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 // EPI: 0 fp32 rows of y; 1 split-format rows of y (reports range); 2 no y: per HALF tile (the 16 MI rows of a wave row) and
 // row-group segment the fp64 column sums of v and v^2 (a.pool, the ring kernel's pooled epilogue with tile rows = 16 MI)
-template <int MI, int EPI>
+// MODE: 0 the speech encoder's form (file comment): every tap a plain row offset, whole tiles per workgroup, tiles g, g + G, ...
+//       1 (round 4) the trunk's deep layers on the same loop: 2-D filters with padding / stride / dilation (a bit per tap and row,
+//         ORed into the piece's offset as bit 31 -- the ring kernel's), an optional residual in the split format (two 16-B loads
+//         per pixel block, the window kernel's), the ring kernel's BALANCED SPLIT -- every workgroup one contiguous range of the
+//         launch's tiles x slices -- and, DUAL, its second reduction source (dlip_conv2_nhwc_f16x3).  The hand-off of a shared
+//         tile is PER WAVE: the ping-pong halves never meet at a common barrier, and wave w of the finisher needs exactly the
+//         accumulators of wave w of the other parts -- so each wave publishes its own quads (sc1 stores, vmcnt(0), one relaxed
+//         ticket on the tile's word for its position) and the wave that finds its position complete adds the others' in part
+//         order and runs the epilogue; different waves of a tile may finish in different workgroups, the bits do not depend on it.
+template <int MI, int EPI, int MODE = 0, bool DUAL = false>
 __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs a, const RowsSched sc) {
+  static_assert(MODE == 1 || !DUAL, "the second source exists in the general mode only");
+  static_assert(MODE == 0 || EPI != 2, "no pooled epilogue in the general mode");
   constexpr int NW = 8, BN = ROWS_BN, BM = 32 * MI, NI = 4;
   constexpr int WM = BM / 2;                       // rows of a wave's tile (16 MI); WN = 64
   constexpr int A_PIECES = BM / 8, B_PER = 4;      // 1-KiB pieces of a slice's activation rows; weight pieces per wave
@@ -67,10 +100,18 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // neighbours in tile order share an XCD (L2)
-  if (g >= sc.items) return;
-  const int n_my = (sc.items - g + nwg - 1) / nwg;        // this workgroup's tiles: g, g + nwg, ...
   const int nk = a.nk;
-  const int total = n_my * nk;                            // slices of its stream
+  int total, item0 = g, k0 = 0;                           // slices of this workgroup's stream; its first tile and slice
+  if constexpr (MODE == 1) {
+    const int it_begin = dlip_div(g * sc.iters, sc.div_G);
+    total = __builtin_amdgcn_readfirstlane(dlip_div((g + 1) * sc.iters, sc.div_G) - it_begin);
+    if (total <= 0) return;
+    item0 = __builtin_amdgcn_readfirstlane(dlip_div(it_begin, sc.div_nk));
+    k0 = __builtin_amdgcn_readfirstlane(it_begin - item0 * nk);
+  } else {
+    if (g >= sc.items) return;
+    total = ((sc.items - g + nwg - 1) / nwg) * nk;        // this workgroup's tiles: g, g + nwg, ...
+  }
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,6 +127,8 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   const int csrc = ((lane & 7) ^ key_st) << 2;            // first channel (dword) of the chunk this lane fetches
   const u32x4 xr = make_rsrc_words(a.x, a.x_bytes);
   const u32x4 wr = make_rsrc_words(a.w, a.w_bytes);
+  u32x4 x2r = xr;
+  if constexpr (DUAL) x2r = make_rsrc_words(a.x2, a.x2_bytes);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t piece0 = lds0 + wave * 1024;
   // fragment side (v_mfma_f32_16x16x32_f16; the weight fragment is the A operand: accumulators hold the transposed tile)
@@ -94,6 +137,9 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   const int key_rd = (lrow >> 1) & 7;
   const int khi = (hq ^ key_rd) << 2, klo = ((4 + hq) ^ key_rd) << 2;
   const int x_ds = a.dw * a.ldx * 4;                      // bytes between two taps of a row
+  const int x_dr = a.dh * a.W * a.ldx * 4;                // (MODE 1) ... between two filter rows
+  const int ntaps = a.R * a.S;
+  const int nk1 = nk - (DUAL ? a.nk2 : 0);                // slices of the first source
 
   dlip_span_enter(sc.span, g);
 #ifdef DLIP_LAB
@@ -109,16 +155,36 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   // (rows past M / weight rows past K carry the out-of-range offset itself: 2^31 plus any in-range tap offset is still beyond every
   // buffer, so a piece's address is ONE add -- the select per piece was two of every three vector instructions of a slice)
   uint32_t a_off[NA_A], b_off[B_PER];
-  int c_item = g, c_k = 0, s_pos = 0, c0 = 0, x_tap = 0, w_tap = 0;
+  uint32_t a_mask[MODE == 1 ? NA_A : 1];                  // (MODE 1) INVERTED: bit t set = tap t of that row is outside the image, or the row past M
+  uint32_t a2_off[DUAL ? NA_A : 1];                       // (DUAL) the row's pixel of the second source; out of range past M
+  int c_item = item0, c_k = k0, s_pos = 0, c0 = 0, x_tap = 0, w_tap = 0;
+  int tap = 0, x_row = 0;                                 // (MODE 1) tap index r S + s and the byte offset of filter row r
   auto set_item = [&](int item) __attribute__((always_inline)) {
     const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
+    [[maybe_unused]] RowsKArgs* ap = nullptr;
+    if constexpr (MODE == 1) ap = rows_kargs();
 #pragma unroll
     for (int j = 0; j < NA_A; ++j) {
       const int m = tile_m * BM + 8 * (wave + 8 * j) + prow;
-      const int mc = m < a.M ? m : 0;
-      const int n = dlip_div(mc, a.div_howo);
-      const int t = mc - n * a.HoWo;                       // H = 1: the row's first input pixel is n * W + t
-      a_off[j] = m < a.M ? (uint32_t)(((n * a.W + t) * a.ldx + csrc) * 4) : DLIP_OOB_OFFSET;
+      if constexpr (MODE == 1) {
+        const int mc = m < ap->M ? m : ap->M - 1;
+        const int n = dlip_div(mc, FastDiv{ap->div_howo.mul, ap->div_howo.shift});
+        const int rem = mc - n * ap->HoWo;
+        const int ho = dlip_div(rem, FastDiv{ap->div_wo.mul, ap->div_wo.shift});
+        const int wo = rem - ho * ap->Wo;
+        const int hi0 = ho * ap->sh - ap->ph, wi0 = wo * ap->sw - ap->pw;   // window origin (may lie in the padding: the sum with a valid tap does not)
+        a_off[j] = (uint32_t)((((n * ap->H + hi0) * ap->W + wi0) * ap->ldx + csrc) * 4);
+        if constexpr (DUAL) a2_off[j] = m < ap->M ? (uint32_t)((((n * ap->H2 + ho * ap->s2h) * ap->W2 + wo * ap->s2w) * ap->ldx2 + csrc) * 4) : DLIP_OOB_OFFSET;
+        uint32_t colbits = 0u, ok = 0u;                   // columns and rows tested separately: R + S steps, not R x S
+        for (int sx = 0; sx < ap->S; ++sx) colbits |= (uint32_t)((unsigned)(wi0 + sx * ap->dw) < (unsigned)ap->W) << sx;
+        for (int r = 0; r < ap->R; ++r) ok |= ((unsigned)(hi0 + r * ap->dh) < (unsigned)ap->H ? colbits : 0u) << (r * ap->S);
+        a_mask[j] = m < ap->M ? ~ok : ~0u;
+      } else {
+        const int mc = m < a.M ? m : 0;
+        const int n = dlip_div(mc, a.div_howo);
+        const int t = mc - n * a.HoWo;                       // H = 1: the row's first input pixel is n * W + t
+        a_off[j] = m < a.M ? (uint32_t)(((n * a.W + t) * a.ldx + csrc) * 4) : DLIP_OOB_OFFSET;
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_PER; ++j) {
@@ -126,22 +192,62 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       b_off[j] = n < a.K ? (uint32_t)((n * a.rsc + csrc) * 4) : DLIP_OOB_OFFSET;
     }
   };
-  auto advance = [&]() __attribute__((always_inline)) {   // channel slice outer, tap inner (the ring kernel's reduction order)
-    if (++c_k == nk) {
-      c_k = 0; s_pos = 0; c0 = 0;
-      c_item += nwg;
-      set_item(c_item);
-    } else if (++s_pos == a.S) {
-      s_pos = 0; c0 += BK;
+  auto place = [&]() __attribute__((always_inline)) {     // byte offsets of the slice the cursor stands on
+    if constexpr (MODE == 1) {
+      x_tap = x_row + s_pos * x_ds + c0 * 4;
+      w_tap = (tap * a.Cw + c0) * 4;
+      if (DUAL && c0 >= a.Cw) { x_tap = (c0 - a.Cw) * 4; w_tap = (ntaps * a.Cw + c0 - a.Cw) * 4; }   // behind the taps of each weight row
+    } else {
+      x_tap = s_pos * x_ds + c0 * 4;
+      w_tap = (s_pos * a.Cw + c0) * 4;
     }
-    x_tap = s_pos * x_ds + c0 * 4;
-    w_tap = (s_pos * a.Cw + c0) * 4;
+  };
+  auto advance = [&]() __attribute__((always_inline)) {   // channel slice outer, tap inner (the ring kernel's reduction order)
+    if constexpr (MODE == 1) {
+      // (value selects on local copies, one store per variable: as an if / else chain storing to the cursor variables, the
+      // optimiser merged the branches' stores into stores through a pointer phi and the whole cursor stayed on the stack)
+      const bool second = DUAL && c0 >= a.Cw;            // second source: one slice per 32 channels
+      int ntap = tap + 1, nsp = s_pos + 1, nrow = x_row, nc0 = c0, nk_ = c_k + 1, nitem = c_item;
+      if (nsp == a.S) { nsp = 0; nrow += x_dr; }
+      if (ntap == ntaps) { ntap = 0; nsp = 0; nrow = 0; nc0 += BK; }
+      if (second) { ntap = tap; nsp = s_pos; nrow = x_row; nc0 = c0 + BK; }
+      if (nk_ == nk) { nk_ = 0; ntap = 0; nsp = 0; nrow = 0; nc0 = 0; ++nitem; }   // (the caller has run set_item for the next tile: enter_next)
+      c_k = nk_; tap = ntap; s_pos = nsp; x_row = nrow; c0 = nc0; c_item = nitem;
+    } else {
+      if (++c_k == nk) {
+        c_k = 0; s_pos = 0; c0 = 0;
+        c_item += nwg;
+        set_item(c_item);
+      } else if (++s_pos == a.S) {
+        s_pos = 0; c0 += BK;
+      }
+    }
+    place();
+  };
+  // MODE 1: the row set-up of the NEXT tile (two divisions and R + S mask steps per row) is done apart from advance(), at a point
+  // of the caller's choosing -- in the loop BEFORE the slice's fragment reads: behind them it sat on top of 72 live fragment
+  // registers and pushed loop state into scratch
+  auto enter_next = [&]() __attribute__((always_inline)) {
+    if constexpr (MODE == 1) { if (c_k + 1 == nk) set_item(c_item + 1); }
   };
   auto issue = [&](int stage, auto na) __attribute__((always_inline)) {
     const uint32_t base = piece0 + stage * STAGE_B;
+    if (DUAL && c0 >= a.Cw) {                              // (wave-uniform)
 #pragma unroll
-    for (int j = 0; j < na(); ++j)
-      dma_piece(xr, a_off[j] + (uint32_t)x_tap, base + j * 8192);
+      for (int j = 0; j < na(); ++j)
+        dma_piece(x2r, a2_off[DUAL ? j : 0] + (uint32_t)x_tap, base + j * 8192);
+    } else {
+#pragma unroll
+      for (int j = 0; j < na(); ++j) {
+        if constexpr (MODE == 1) {
+          // a tap outside the image: its bit of the inverted mask, shifted to bit 31, ORed into the offset -- beyond every buffer
+          const uint32_t oob = (a_mask[j] << (31 - tap)) & 0x80000000u;
+          dma_piece(xr, (a_off[j] + (uint32_t)x_tap) | oob, base + j * 8192);
+        } else {
+          dma_piece(xr, a_off[j] + (uint32_t)x_tap, base + j * 8192);
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < B_PER; ++j)
       dma_piece(wr, b_off[j] + (uint32_t)w_tap, base + BM * ROWB + j * 8192);
@@ -186,29 +292,69 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   };
 
   // ---- epilogue of one tile, from this wave's accumulators straight to memory:
-  //      y = act(acc / wscale + bias) * post_scale + post_shift   (no residual on this path) ----
-  const __amdgpu_buffer_rsrc_t yr = dlip_make_rsrc(a.y, a.y_bytes);
-  const uint32_t kbytes = (uint32_t)a.K * 4u;
-  const __amdgpu_buffer_rsrc_t scr = dlip_make_rsrc(a.wscale, kbytes);
-  const __amdgpu_buffer_rsrc_t bir = dlip_make_rsrc(a.bias, a.bias ? kbytes : 0u);
-  const __amdgpu_buffer_rsrc_t slr = dlip_make_rsrc(a.slope, a.slope ? kbytes : 0u);
-  const __amdgpu_buffer_rsrc_t psr = dlip_make_rsrc(a.pscale, a.pscale ? kbytes : 0u);
-  const __amdgpu_buffer_rsrc_t ptr_ = dlip_make_rsrc(a.pshift, a.pshift ? kbytes : 0u);
-  const bool has_slope = a.slope != nullptr, has_post = a.pscale != nullptr;
+  //      y = act(acc / wscale + bias [+ residual]) * post_scale + post_shift   (a residual in MODE 1 only; split format) ----
+  // (MODE 0: the descriptors are built once, here; MODE 1: inside the epilogue, from rows_kargs())
+  struct EpiCtx {
+    __amdgpu_buffer_rsrc_t yr, rr, scr, bir, slr, psr, ptr_;
+    bool has_res, has_slope;
+    int M, K, ldy, ldr;
+  };
+  auto make_epi = [&](auto&& A) __attribute__((always_inline)) {
+    EpiCtx e;
+    const uint32_t kbytes = (uint32_t)A.K * 4u;
+    e.yr = dlip_make_rsrc(A.y, A.y_bytes);
+    e.has_res = MODE == 1 && A.res != nullptr;
+    e.rr = dlip_make_rsrc(A.res, e.has_res ? A.r_bytes : 0u);
+    e.scr = dlip_make_rsrc(A.wscale, kbytes);
+    e.bir = dlip_make_rsrc(A.bias, A.bias ? kbytes : 0u);
+    e.slr = dlip_make_rsrc(A.slope, A.slope ? kbytes : 0u);
+    e.psr = dlip_make_rsrc(A.pscale, A.pscale ? kbytes : 0u);
+    e.ptr_ = dlip_make_rsrc(A.pshift, A.pshift ? kbytes : 0u);
+    e.has_slope = A.slope != nullptr;
+    e.M = A.M; e.K = A.K; e.ldy = A.ldy; e.ldr = A.ldr;
+    return e;
+  };
+  EpiCtx epi0;
+  if constexpr (MODE == 0) epi0 = make_epi(a);
+  const bool has_post0 = a.pscale != nullptr;
   float amax = 0.f;
   auto epilogue_p = [&](int item, auto post_c) __attribute__((always_inline)) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     constexpr bool post = decltype(post_c)::value;   // (compile-time inside: the runtime flag selected and computed both forms per value)
+    EpiCtx ec;
+    if constexpr (MODE == 1) ec = make_epi(*rows_kargs()); else ec = epi0;
+    const __amdgpu_buffer_rsrc_t yr = ec.yr, rr = ec.rr, scr = ec.scr, bir = ec.bir, slr = ec.slr, psr = ec.psr, ptr_ = ec.ptr_;
+    const bool has_res = ec.has_res, has_slope = ec.has_slope;
+    const int eM = ec.M, eK = ec.K, eldy = ec.ldy, eldr = ec.ldr;
     const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
     const int row0 = tile_m * BM + wm * WM + lrow;
     const int col0 = tile_n * BN + wn * 64;
     if constexpr (EPI == 1) {
       // after the swap, 16-lane row hq of the pair (2 p, 2 p + 1) holds channels 32 p + {0, 16, 8, 24}[hq] + 0..7 of its pixel
       const int cs = ((hq & 1) << 4) | ((hq & 2) << 2);
+      // the residual arrives in the shape the values leave in: per pixel block one 16-B piece of hi halves and one of lo halves,
+      // issued first thing for each 32-channel pair -- their latency passes under the parameter loads and the exchange (all
+      // NI / 2 pairs at once, as the window kernel does, is 80 registers at MI = 5: spills)
 #pragma unroll
       for (int p = 0; p < NI / 2; ++p) {
         const int kb = col0 + 32 * p;                    // first channel of the 32-channel block
         const int k0 = kb + cs;                          // first of this lane's 8 channels
+        // (MODE 1, no post-affine -- a launch with both stays on the ring kernel) residual pieces, RD pixel blocks ahead of their use
+        constexpr bool RES = MODE == 1 && !post;
+        constexpr int RD = 3;
+        h8 rh[RES ? RD : 1], rl[RES ? RD : 1];
+        auto load_res = [&](int mi) __attribute__((always_inline)) {
+          const int m = row0 + mi * 16;
+          const uint32_t off = (m < eM && kb < eK) ? (uint32_t)((m * eldr + kb) * 4 + cs * 2) : DLIP_OOB_OFFSET;
+          rh[mi % RD] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)off, 0, 0));
+          rl[mi % RD] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(off == DLIP_OOB_OFFSET ? off : off + 64u), 0, 0));
+        };
+        if constexpr (RES) {
+          if (has_res) {
+#pragma unroll
+            for (int mi = 0; mi < RD && mi < MI; ++mi) load_res(mi);
+          }
+        }
         float inv[8], bi[8], sl[8], ps[8], pt[8];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -219,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
           if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)(k0 + 4 * q) * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)(k0 + 4 * q) * 4u); }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            inv[4 * q + c] = k0 + 4 * q + c < a.K ? 1.f / s4[c] : 0.f;   // power of two: exact
+            inv[4 * q + c] = k0 + 4 * q + c < eK ? 1.f / s4[c] : 0.f;   // power of two: exact
             bi[4 * q + c] = b4[c]; sl[4 * q + c] = l4[c]; ps[4 * q + c] = p4[c]; pt[4 * q + c] = t4[c];
           }
         }
@@ -239,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             float t = v[c] * inv[c] + bi[c];
+            if constexpr (RES) { if (has_res) t += (float)rh[mi % RD][c] + (float)rl[mi % RD][c]; }
             t = t >= 0.f ? t : t * sl[c];
             if (post) t = t * ps[c] + pt[c];
             hi[c] = (_Float16)t;
@@ -246,10 +393,14 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
             amax = fmaxf(amax, fabsf(t));
           }
           const int m = row0 + mi * 16;
-          const bool ok = m < a.M && k0 < a.K;           // K % 32 == 0 for a split output: a block is whole or absent
-          const uint32_t off = ok ? (uint32_t)((m * a.ldy + kb) * 4 + cs * 2) : DLIP_OOB_OFFSET;
+          const bool ok = m < eM && k0 < eK;           // K % 32 == 0 for a split output: a block is whole or absent
+          const uint32_t off = ok ? (uint32_t)((m * eldy + kb) * 4 + cs * 2) : DLIP_OOB_OFFSET;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), yr, (int)off, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), yr, (int)(ok ? off + 64u : DLIP_OOB_OFFSET), 0, 0);
+          if constexpr (RES) {
+            DLIP_FENCE();
+            if (has_res && mi + RD < MI) load_res(mi + RD);
+          }
         }
         DLIP_FENCE();
       }
@@ -260,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       // are segment 0, the rest segment 1 (pool_group >= 16 MI); dlip_pool_finish_f32 / znorm_cat_pooled add the tiles in row order.
       const int m0 = tile_m * BM + wm * WM;
       const int rb = (m0 / a.pool_group + 1) * a.pool_group - m0;
-      const int Kp = (a.K + 127) / 128 * 128;
+      const int Kp = (eK + 127) / 128 * 128;
       double* prow = a.pool + (size_t)(2 * tile_m + wm) * 4 * Kp;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -272,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
         if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)k0 * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)k0 * 4u); }
         f32x4 inv4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) inv4[c] = k0 + c < a.K ? 1.f / s4[c] : 0.f;
+        for (int c = 0; c < 4; ++c) inv4[c] = k0 + c < eK ? 1.f / s4[c] : 0.f;
         double st[4][4];   // [sum0, sumsq0, sum1, sumsq1][channel]
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -281,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const int r = mi * 16 + lrow;
-          const bool in = m0 + r < a.M, seg1 = r >= rb;
+          const bool in = m0 + r < eM, seg1 = r >= rb;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             float t = acc[mi][ni][c] * inv4[c] + b4[c];
@@ -298,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
           for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) st[q][c] += __shfl_xor(st[q][c], o, 64);
-        if (lrow == 0 && m0 < a.M) {   // (a last tile's second half may lie wholly beyond M: it has no partial row set)
+        if (lrow == 0 && m0 < eM) {   // (a last tile's second half may lie wholly beyond M: it has no partial row set)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -318,19 +469,32 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
         if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)k0 * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)k0 * 4u); }
         f32x4 inv4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) inv4[c] = k0 + c < a.K ? 1.f / s4[c] : 0.f;
+        for (int c = 0; c < 4; ++c) inv4[c] = k0 + c < eK ? 1.f / s4[c] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           f32x4 v;
+          const int m = row0 + mi * 16;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = acc[mi][ni][c] * inv4[c] + b4[c];
+          if constexpr (MODE == 1) {
+            if (has_res) {   // the residual is in the split format: 4 hi halves, 4 lo halves of this lane's channels
+              typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+              const bool rok = m < eM && k0 < eK;
+              const uint32_t ro = rok ? (uint32_t)((m * eldr + (k0 & ~31)) * 4 + (k0 & 31) * 2) : DLIP_OOB_OFFSET;
+              const h4 r_hi = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rr, (int)ro, 0, 0));
+              const h4 r_lo = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rr, (int)(rok ? ro + 64u : DLIP_OOB_OFFSET), 0, 0));
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] += (float)r_hi[c] + (float)r_lo[c];
+            }
+          }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            float t = acc[mi][ni][c] * inv4[c] + b4[c];
+            float t = v[c];
             t = t >= 0.f ? t : t * l4[c];
             if (post) t = t * p4[c] + t4[c];
             v[c] = t;
           }
-          const int m = row0 + mi * 16;
-          const uint32_t off = (m < a.M && k0 < a.K) ? (uint32_t)((m * a.ldy + k0) * 4) : DLIP_OOB_OFFSET;   // K % 4 == 0
+          const uint32_t off = (m < eM && k0 < eK) ? (uint32_t)((m * eldy + k0) * 4) : DLIP_OOB_OFFSET;   // K % 4 == 0
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, (int)off, 0, 0);
         }
         DLIP_FENCE();
@@ -338,16 +502,88 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
     }
   };
   auto epilogue = [&](int item) __attribute__((always_inline)) {
+    bool has_post = has_post0;
+    if constexpr (MODE == 1) has_post = rows_kargs()->pscale != nullptr;
     if (has_post) epilogue_p(item, std::true_type{}); else epilogue_p(item, std::false_type{});
+  };
+  // End of a segment (this wave's view).  A whole tile: its epilogue.  MODE 1, a tile this range shares with others (`part`): the
+  // hand-off in the kernel comment -- peek at the tile's ticket word for this wave position; everybody else has published: this
+  // wave is the finisher and keeps its part in registers; otherwise publish (write-through stores, drained, then ONE relaxed
+  // ticket) and finish only if the ticket says the others arrived meanwhile.  The finisher acquires (agent scope: this CU's L1
+  // drops stale slab lines), adds the parts IN PART ORDER (its own from registers) one row of NI quads at a time, and runs the
+  // epilogue.  Returns whether the epilogue's stores were issued (the counted waits behind it leave NST of them in flight); on the
+  // publishing path everything this wave had in flight has been waited for.
+  auto finish_tile = [&](int item, bool part, bool first) __attribute__((always_inline)) -> bool {
+    if constexpr (MODE == 1) {
+      if (part) {                                          // (wave-uniform)
+        constexpr int WSLAB = BM * BN / NW;                // floats of one wave's share of a slab = MI NI 64 quads
+        const int t0 = item * nk;
+        const int gf = __builtin_amdgcn_readfirstlane(dlip_div((t0 + 1) * sc.G - 1, sc.div_iters));    // owner of the tile's first slice
+        const int gl = __builtin_amdgcn_readfirstlane(dlip_div((t0 + nk) * sc.G - 1, sc.div_iters));   // owner of its last slice
+        const int others = gl - gf;
+        // which of part p's two slabs holds this tile: only the first part's range can have begun before the tile
+        const int gf_slot = dlip_div(gf * sc.iters, sc.div_G) < t0 ? 1 : 0;
+        int* ctr = sc.counters + (size_t)item * NW + wave;
+        int seen = 0;
+        if (lane == 0) seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool fin = __builtin_amdgcn_readfirstlane(seen) == others;
+        if (!fin) {
+          const __amdgpu_buffer_rsrc_t sr = dlip_make_rsrc(sc.slabs + ((size_t)(2 * g + (first ? 0 : 1)) * NW + wave) * WSLAB, WSLAB * 4);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mi][ni]), sr, ((mi * NI + ni) * 64 + lane) * 16, 0, 16);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          int tk = 0;
+          if (lane == 0) tk = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fin = __builtin_amdgcn_readfirstlane(tk) == others;   // the other parts arrived between the peek and the ticket
+          if (!fin) return false;
+        }
+        if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4 t[NI];
+          for (int p = gf; p <= gl; ++p) {
+            const __amdgpu_buffer_rsrc_t pr =
+                dlip_make_rsrc(sc.slabs + ((size_t)(2 * p + (p == gf ? gf_slot : 0)) * NW + wave) * WSLAB, WSLAB * 4);
+            f32x4 v[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              v[ni] = acc[mi][ni];
+              if (p != g) v[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, ((mi * NI + ni) * 64 + lane) * 16, 0, 16));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) t[ni][c] = p == gf ? v[ni][c] : t[ni][c] + v[ni][c];
+            DLIP_FENCE();
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = t[ni];
+        }
+      }
+    }
+    epilogue(item);
+    return true;
   };
 
   // ---- prologue: the first two slices of the stream in flight ----
   constexpr std::integral_constant<int, NA_A> na_a{};
   constexpr std::integral_constant<int, NA_B> na_b{};
   set_item(c_item);
+  if constexpr (MODE == 1) {                               // the range may begin inside a tile: stand the cursor on slice k0
+    if (DUAL && k0 >= nk1) { c0 = a.Cw + (k0 - nk1) * BK; tap = 0; } else { c0 = (k0 / ntaps) * BK; tap = k0 % ntaps; }
+    s_pos = tap % a.S;
+    x_row = (tap / a.S) * x_dr;
+    place();
+  }
   ROWS_STAMP(0);
   if (!half_b) issue(0, na_a); else issue(0, na_b);
   if (total > 1) {
+    enter_next();
     advance();
     if (!half_b) issue(1, na_a); else issue(1, na_b);
   }
@@ -366,7 +602,14 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
     constexpr bool FIRST = decltype(first_c)::value;
     static_assert(NL + NST < 64, "vmcnt is a 6-bit counter");
     int st_iss = total > 1 ? 2 : 1;                        // stage the next issue goes to (the prologue issued slices 0, 1)
-    int kleft = nk, e_item = g, done_item = -1;
+    // consumer side: the segment being multiplied (MODE 0: always a whole tile)
+    int kleft = nk, e_item = item0, done_item = -1, rem = 0;
+    bool e_part = false, e_first = true, done_part = false, done_first = false;   // (wave-uniform)
+    if constexpr (MODE == 1) {
+      kleft = nk - k0 < total ? nk - k0 : total;
+      rem = total - kleft;
+      e_part = kleft != nk;
+    }
     if (total > 1) wait_vmcnt<NL>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                          // slice 0 is complete
     ROWS_STAMP(1);
@@ -376,15 +619,16 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       bool did_epi = false;                                // (wave-uniform)
       ROWS_SSTAMP(0);
       if (done_item >= 0) {
-        epilogue(done_item);
-        if (s == total) break;                             // the stream ends on a tile's last slice (total = n_my * nk)
-        zero_acc(); done_item = -1; did_epi = true;
+        const bool wrote = finish_tile(done_item, done_part, done_first);
+        if (s == total) break;                             // the stream ends on a segment's last slice
+        zero_acc(); done_item = -1; did_epi = wrote;
       }
+      const bool more2 = s + 2 < total;
+      if (more2) enter_next();
       DLIP_FENCE();
       read_all(st_cur);                                    // the reads first: their latency passes under the piece issue below
       st_cur = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
       DLIP_FENCE();
-      const bool more2 = s + 2 < total;
       if (more2) {
         advance();
         issue(st_iss, na);
@@ -405,7 +649,18 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       ROWS_SSTAMP(3);
       mfma_all();
       ROWS_SSTAMP(4);
-      if (--kleft == 0) { kleft = nk; done_item = e_item; e_item += nwg; }
+      if (--kleft == 0) {
+        done_item = e_item; done_part = e_part; done_first = e_first;
+        if constexpr (MODE == 1) {
+          ++e_item;
+          kleft = nk < rem ? nk : rem;
+          rem -= kleft;
+          e_part = kleft != nk;
+          e_first = false;
+        } else {
+          kleft = nk; e_item += nwg;
+        }
+      }
       if (FIRST) {
         __builtin_amdgcn_s_barrier();                      // b(2s+1)
         ROWS_SSTAMP(5);
@@ -429,7 +684,9 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #endif
 }
 
-template <int MI, int EPI>
+constexpr int kRowsDeclined = -1000;   // (internal) a MODE 1 launch that found no split workspace: the caller takes the ring kernel
+
+template <int MI, int EPI, int MODE = 0, bool DUAL = false>
 int launch_rows(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = 32 * MI;
   constexpr size_t lds = (size_t)3 * (BM + ROWS_BN) * ROWB;
@@ -439,7 +696,7 @@ int launch_rows(const ConvArgs& a, hipStream_t st) {
   const long long tiles_m = ((long long)a.M + BM - 1) / BM;
   const long long items = tiles_m * b.tiles_n;
   if (items <= 0 || items > 0x3FFFFFFFll) return DLIP_EINVAL;
-  auto kern = conv_rows_f16x3_kernel<MI, EPI>;
+  auto kern = conv_rows_f16x3_kernel<MI, EPI, MODE, DUAL>;
   static DlipKernelState ks;
   int e = ks.ensure_lds(reinterpret_cast<const void*>(kern), lds);
   if (e != DLIP_OK) return e;
@@ -449,8 +706,29 @@ int launch_rows(const ConvArgs& a, hipStream_t st) {
   RowsSched sc;
   sc.items = (int)items;
   sc.tiles_n = b.tiles_n;
+  sc.iters = 0; sc.G = 0; sc.slabs = nullptr; sc.counters = nullptr;
+  sc.div_G = sc.div_iters = sc.div_nk = FastDiv{0u, 0u};
+  long long grid = items < slots ? items : slots;
+  if constexpr (MODE == 1) {
+    // The ring kernel's balanced split: items x nk slices in G equal ranges, G = the resident workgroups (at least 16 slices
+    // each).  Ranges that end inside a tile need the split workspace (two slabs per workgroup, 8 ticket words per tile).
+    const long long iters = items * (long long)a.nk;
+    long long G = slots;
+    if (iters < 16 * G) G = iters / 16 > 0 ? iters / 16 : 1;
+    if ((iters + a.nk) * (G + 1) >= 0x7FFFFFFFll) return kRowsDeclined;   // the kernel's 32-bit range arithmetic
+    sc.iters = (int)iters;
+    sc.div_G = dlip_fastdiv((uint32_t)G);
+    sc.div_iters = dlip_fastdiv((uint32_t)iters);
+    sc.div_nk = dlip_fastdiv((uint32_t)a.nk);
+    if (items % G != 0) {
+      int max_words = 0;
+      if (!dlip_conv_split_workspace(st, (size_t)2 * G * BM * ROWS_BN, &sc.slabs, &sc.counters, &max_words) || items * 8 > max_words)
+        return kRowsDeclined;
+    }
+    sc.G = (int)G;
+    grid = G;
+  }
   sc.span = dlip_span_next();
-  const long long grid = items < slots ? items : slots;
 #ifdef DLIP_LAB
   sc.stamps = nullptr;
   if (getenv("DLIP_STAMP_PRINT")) {
@@ -531,6 +809,57 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_plan(const d
   if (bm) *bm = 32 * mi;
   return 1;
 }
+
+// MODE 1: which launches of the LDS-DMA path (split input; dlip_conv_f16x3_dma_launch asks first) CAN take the rows kernel's general
+// mode: pixel-major operands, whole 32-channel slices, at most 32 taps, fp32 or split output (no pooled epilogue).
+// NOT CHOSEN BY THE LIBRARY: it runs only when forced (dlip_debug_set(7, 1): tests, A/B runs).  Built in round 4 to carry the
+// trunk's layers 3 and 4 (the ring kernel's 256 x 128 launches) on the 160 x 256 tile / continuous stream / register epilogue that
+// made the speech encoder's layers 25 % faster; measured on one box at B = 64 (tools/probes/rows2d_layers.py,
+// profiles/r4/rows2d_layers.txt): layer 3's convolutions 2 - 4 % SLOWER than the ring kernel (200 vs 196 us, with residual 214
+// vs 207), its stride-2 and two-source launches 4 - 11 % slower, layer 4's 6 - 18 % slower.  Why (tools/probes/rows_trunk_proxy.py):
+// on rows that fill whole rounds of tiles -- no split -- this mode does 436 - 450 TFLOP/s against the ring kernel's 410 - 423,
+// but the trunk's row counts need the balanced split (418 tiles on 256 CUs), and here a shared tile's hand-off costs 25 - 32 us per
+// launch against the ring kernel's ~10: each ping-pong half publishes / finishes in its own interval (store acknowledgements, a
+// ticket round trip, MI x parts serial slab reads), the other half waiting at the next barrier; and every workgroup enters the
+// reduction at its own slice, so layer 4's 4.7 MB of weights per 256-column block no longer stay in an XCD's 4 MiB L2 (the ring
+// kernel keeps an XCD on one 128-column block: 2.35 MB).  What would change it is in DESIGN.md section 9.
+static bool rows2d_ok(const ConvArgs& a, int epi) {
+  const int v = dlip_dbg_value[DLIP_DBG_ROWS2D];
+  if (v <= 0 || !dlip_conv_dma_enabled() || epi < 0 || epi > 1) return false;
+  if (a.Cw != a.C || (a.C & 31) != 0 || a.R * a.S > 32 || a.wscale == nullptr || a.pool != nullptr) return false;
+  if (a.cs_x != 128 || a.cs_w != 128 || a.wt != a.Cw * 4 || a.Hs != a.H) return false;       // slice-major images: ring kernel only
+  if (a.x2 != nullptr && (a.nk2 <= 0)) return false;
+  if (a.res != nullptr && a.pscale != nullptr) return false;                                    // (not compiled: registers)
+  const long long items = (((long long)a.M + 159) / 160) * ((a.K + ROWS_BN - 1) / ROWS_BN);
+  if (items * 8 > 65536) return false;
+  return true;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows2d_ok(const void* args, int epi) {
+  return rows2d_ok(*static_cast<const ConvArgs*>(args), epi) ? 1 : 0;
+}
+
+// Descriptor form (dlip_conv_plan / dlip_conv_kernel_kind, `dual` = a second source of c2 channels): 1 if a split-format launch of `d`
+// (with or without a residual) runs the general mode; *bm = its tile height.
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows2d_plan(const dlip_conv_desc* d, int c2, int* bm) {
+  const int v = dlip_dbg_value[DLIP_DBG_ROWS2D];
+  if (v <= 0 || !dlip_conv_dma_enabled() || (d->C & 31) != 0 || d->R * d->S > 32 || (c2 & 31) != 0) return 0;
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const long long items = ((M + 159) / 160) * ((d->K + ROWS_BN - 1) / ROWS_BN);
+  if (items * 8 > 65536) return 0;
+  if (bm) *bm = 160;
+  return 1;
+}
+
+// returns kRowsDeclined when the split workspace is missing (stream capture before any eager launch, or an external block that
+// is too small): the caller then runs the ring kernel
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_rows2d_launch(const void* args, void* stream, int epi) {
+  const ConvArgs& a = *static_cast<const ConvArgs*>(args);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.x2 != nullptr) return epi ? launch_rows<5, 1, 1, true>(a, st) : launch_rows<5, 0, 1, true>(a, st);
+  return epi ? launch_rows<5, 1, 1, false>(a, st) : launch_rows<5, 0, 1, false>(a, st);
+}
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_declined(void) { return kRowsDeclined; }
 
 // The pooled epilogue on this kernel is correct and tested, and slower than the ring kernel's LDS-staged one: the fp64 column
 // sums taken straight from the accumulators cost ~13 us per tile in cross-lane work (64 doubles x 4 butterfly steps per channel

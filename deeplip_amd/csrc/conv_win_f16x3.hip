@@ -564,12 +564,13 @@ extern "C" int dlip_conv_dma_enabled(void);   // conv_igemm_f16x3.hip
 
 // Which kernel a split-format launch of `d` goes to (include/deeplip_hip.h): 1 = this one.
 extern "C" int dlip_conv_rows_plan(const dlip_conv_desc* d, int* bm);   // conv_rows_f16x3.hip
+extern "C" int dlip_conv_rows2d_plan(const dlip_conv_desc* d, int c2, int* bm);
 extern "C" int dlip_conv_kernel_kind(const dlip_conv_desc* d) {
   if (!d) return DLIP_EINVAL;
   if (d->C % 32 == 0 && dlip_conv_dma_enabled() &&
       win_shape_ok(d->stride_h, d->stride_w, d->H, d->W, d->Ho, d->Wo, d->R, d->S, d->dil_h, d->dil_w, d->pad_h, d->pad_w, d->K))
     return 1;
-  return dlip_conv_rows_plan(d, nullptr) ? 2 : 0;
+  return (dlip_conv_rows_plan(d, nullptr) || dlip_conv_rows2d_plan(d, 0, nullptr)) ? 2 : 0;
 }
 
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_win_launch(const void* args, void* stream, int out_split) {

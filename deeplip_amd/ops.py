@@ -108,7 +108,7 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
         kind = lib().dlip_conv_kernel_kind(C.byref(d)) if mode == 3 else 0
         if kind == 1:
             kname, bm.value, bn.value = "conv_win_f16x3_kernel", 128, (128 if K > 64 else 64)
-        elif kind == 2:      # (d.ldr == 0 there: the rows kernel takes no residual)
+        elif kind == 2:      # the rows kernel (its speech-encoder mode, or the general mode: 2-D filters / residual)
             kname = "conv_rows_f16x3_kernel"
         tok = hook.begin(f"{kname}<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
     if w_scale is not None:
@@ -155,7 +155,8 @@ def conv2_nhwc(x: Tensor, x2: Tensor, w_split: Tensor, bias: Tensor, w_scale: Te
     if hook is not None:
         bm, bn = C.c_int32(), C.c_int32()
         check(lib().dlip_conv_plan(C.byref(d), 3, C.byref(bm), C.byref(bn)), "dlip_conv_plan")
-        tok = hook.begin(f"conv_igemm_f16x3_dma_kernel<{bm.value},{bn.value},dual>", 2.0 * N * Ho * Wo * K * (R * S * Cx + C2))
+        kname = "conv_rows_f16x3_kernel" if lib().dlip_conv_kernel_kind(C.byref(d)) == 2 else "conv_igemm_f16x3_dma_kernel"
+        tok = hook.begin(f"{kname}<{bm.value},{bn.value},dual>", 2.0 * N * Ho * Wo * K * (R * S * Cx + C2))
     _lib.ensure_conv_workspace()
     check(lib().dlip_conv2_nhwc_f16x3(C.byref(d), ptr(x), ptr(x2), H2, W2, C2, C2, stride2[0], stride2[1], ptr(w_split),
                                       ptr(w_scale), ptr(bias), ptr(residual), ptr(slope), None, None, ptr(out),

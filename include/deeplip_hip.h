@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 41
+#define DLIP_ABI_VERSION 42
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -156,9 +156,11 @@ int dlip_split_unpack_f32(const float* x, float* y, int64_t rows, int32_t C, dli
 int dlip_conv_plan(const dlip_conv_desc* d, int32_t split_f16, int32_t* bm, int32_t* bn);
 /* 1 if a split-format (DLIP_SPLIT_IN) launch of `d` runs on the window kernel (conv_win_f16x3_kernel<128,64> for K <= 64, <128,128> above: same-size
  * stride-1 3x3 convolutions with K <= 128 -- one activation window per channel slice in LDS instead of one fetch per
- * tap), 2 if (without a residual) on the rows kernel (conv_rows_f16x3_kernel: the speech encoder's 1-D valid convolutions and
- * k = 1 GEMMs over all frames; dlip_conv_plan then reports its BM x 256 tile), 0 if on the LDS-DMA ring kernel dlip_conv_plan
- * describes.  Host-only. */
+ * tap), 2 if on the rows kernel (conv_rows_f16x3_kernel; dlip_conv_plan then reports its BM x 256 tile): without a residual the
+ * speech encoder's 1-D valid convolutions and k = 1 GEMMs over all frames; also, only while dlip_debug_set(7, 1) forces its
+ * general mode, any convolution of whole 32-channel slices and <= 32 taps (such a launch still falls back to the ring kernel when
+ * its stream has no split workspace of dlip_conv_workspace_bytes()), 0 if on the LDS-DMA ring kernel dlip_conv_plan describes.
+ * Host-only. */
 int dlip_conv_kernel_kind(const dlip_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------
@@ -621,7 +623,9 @@ int dlip_range_scope_end(dlip_stream_t stream);
  * key 0 tile of dlip_conv_nhwc_f32 / the register-staged f16x3 kernel, 1 tile of the LDS-DMA kernel,
  * 2 LDS-DMA kernel on/off (0 = off), 3 balanced split (0 never, 2 always), 4 window kernel on/off (0 = off),
  * 5 tile order of the LDS-DMA kernel (0 column block outer, 1 inner), 6 rows kernel (conv_rows_f16x3.hip: 0 = off, 1 = on for
- * every launch of its shape class whatever the size, 3 | 4 | 5 = on with that tile height in units of 32 rows);
+ * every launch of its shape class whatever the size, 3 | 4 | 5 = on with that tile height in units of 32 rows),
+ * 7 the rows kernel's general mode for 2-D filters / residual / second source (1 = on for every eligible launch; anything else:
+ * off -- the library never chooses it, see conv_rows_f16x3.hip);
  * value -1 restores the built-in choice. */
 int dlip_debug_set(int32_t key, int32_t value);
 

@@ -212,7 +212,8 @@ def test_plan_spans_time_the_replayed_launches():
         total_us = sum(v["us_sum"] for v in s.values())
         wall_us = 1e3 * e0.elapsed_time(e1) / 5
         assert 0 < total_us < wall_us, (total_us, wall_us)         # one stream: the MFMA launches are a part of the replay, never more
-        assert abs(sum(plan.last_stream_us.values()) - total_us) < 1e-6 * total_us and list(plan.last_stream_us) == ["stream0"]
+        # (the summary rounds every kernel's sum to 0.01 us and the per-stream total to 0.001 us)
+        assert abs(sum(plan.last_stream_us.values()) - total_us) < 0.01 * len(s) + 1e-6 * total_us and list(plan.last_stream_us) == ["stream0"]
         assert all(1.0 < v["avg_launch_us"] < 5e3 for v in s.values())
         assert plan.span_summary() == {}                           # reset by the previous call
         plan.close(); ref.close()
