@@ -66,6 +66,7 @@ struct StreamK {
   int G;             // workgroups in the grid
   unsigned long long* span;   // NULL, or this launch's {first workgroup start, last workgroup end} in 100 MHz ticks (dlip_span_scope_*)
   int il_tiles;      // > 0: G = il_tiles * parts and neighbours in work order take the SAME part of DIFFERENT tiles (launch_one)
+  int l2_local;      // experiment (dlip_debug_set(3, 3)): a tile whose parts all sit on ONE XCD hands its slabs over through that XCD's L2
   DLIP_LAB_STREAMK_FIELDS   // (conv_dma_hooks.h: nothing in the product build)
 };
 
@@ -547,6 +548,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       const int gf = (int)(((t0 + 1) * sk.G - 1) / sk.iters);            // owner of the tile's first slice
       const int gl = (int)(((t0 + a.nk) * sk.G - 1) / sk.iters);         // owner of its last slice
       const int others = gl - gf;                                        // parts besides this one
+      // (experiment, round 4, off in the product: VERDICT item "slab traffic") parts on one XCD -- neighbours in work order are,
+      // except across the 8 XCD boundaries -- share an L2: plain stores (they stop in L2) and sc0 loads (past this CU's L1) would do
+      bool l2_local = false;
+      if (sk.l2_local && sk.il_tiles == 0 && q8 > 0) {
+        const int big = r8 * (q8 + 1);
+        const int xf = gf < big ? gf / (q8 + 1) : r8 + (gf - big) / q8, xl = gl < big ? gl / (q8 + 1) : r8 + (gl - big) / q8;
+        l2_local = xf == xl;
+      }
       // 1. peek: if every other part has already published, this workgroup is the finisher and keeps its
       //    part in registers (the usual case for a range's final, head-of-tile segment: the neighbour
       //    computed the rest of that tile first thing).
@@ -557,11 +566,19 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       if (!finish) {
         // 2. publish: write-through (sc1) slab stores, drained by every storing wave, barrier, then ONE ticket
         const __amdgpu_buffer_rsrc_t sr = dlip_make_rsrc(sk.slabs + (size_t)(2 * g + (it != it_begin ? 1 : 0)) * SLAB, SLAB * 4);
+        if (l2_local) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mi][ni]), sr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 16);
+            for (int ni = 0; ni < NI; ++ni)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mi][ni]), sr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 0);
+        } else {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mi][ni]), sr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 16);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid_e == 0) bcast[0] = __hip_atomic_fetch_add(sk.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -590,7 +607,10 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
               v[ni] = acc[mi][ni];
-              if (p != g) v[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 16));
+              if (p != g) {
+                if (l2_local) v[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 1));
+                else v[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 16));
+              }
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
@@ -909,6 +929,7 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     }
   }
   sk.il_tiles = 0;
+  sk.l2_local = dlip_dbg_value[DLIP_DBG_STREAMK] == 3 ? 1 : 0;
   if (G != tiles && a.nk >= 256 && tiles >= 2 && tiles <= 64 && G / tiles >= 2) {
     G = G / tiles * tiles;          // whole parts: every workgroup stays inside one tile
     sk.il_tiles = (int)tiles;

@@ -95,25 +95,6 @@ class _NameHook:
 SPAN_KERNELS = ("conv_igemm_f16x3_dma_kernel", "conv_rows_f16x3_kernel", "conv_win_f16x3_kernel", "stem3d_pool_f16x3_kernel")
 
 
-def _quiesce_collectives(device) -> None:
-    """Precaution, NOT a verified fix.  tests/test_rccl_gpu.py::test_bench_scaling_protocol_on_rccl_one_rank (a plan recorded
-    inside a one-rank RCCL job) ended once in ~5 full-suite runs of round 4 with `hipErrorCapturedEvent` ("operation not permitted
-    on an event last recorded in a capturing stream") and passed 3 of 3 re-runs before this function existed, so its passing
-    afterwards shows nothing.  The guess this acts on -- the process group's watchdog thread polling an event while the raw
-    stream capture is open -- is untested, and the capture is already thread-local (csrc/plan.hip); the caching allocator's
-    event queries are an equally untested candidate.  What it does: with the nccl backend up, idle the
-    device and wait two watchdog poll periods before the capture starts.  `DLIP_PLAN_QUIESCE=0` turns it off (for the A/B
-    that would settle whether it matters)."""
-    import os
-    if os.environ.get("DLIP_PLAN_QUIESCE", "1") == "0":
-        return
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-        import time
-        torch.cuda.synchronize(device)
-        time.sleep(0.25)
-
-
 class StepPlan:
     """``fn(*inputs)`` recorded on a private HIP stream; see the module docstring."""
 
@@ -125,7 +106,17 @@ class StepPlan:
         self.fn = fn
         self.inputs: Tuple[Tensor, ...] = tuple(t.contiguous() for t in inputs)   # the recorded input buffers
         self.device = self.inputs[0].device if self.inputs else torch.device("cuda", torch.cuda.current_device())
-        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        # The recording stream is ALWAYS a private one (`stream`, if given, is only ordered in front of and behind the recording).
+        # Round 4: a plan recorded on a stream that had carried torch.distributed collectives killed the job about one time in
+        # five -- "Process group watchdog thread terminated with exception: HIP error: operation not permitted on an event last
+        # recorded in a capturing stream".  Established by tools/probes/capture_race.py --long (a capture held open across three polls
+        # of the process group's watchdog; profiles/r4/capture_race_probe.txt): collectives issued on the recording stream -> the
+        # abort at the first plan; collectives on any other stream -> 12 of 12 plans fine.  The mechanism that fits (inferred, not
+        # read in torch's or HIP's source): the events the watchdog polls sit on the stream that was current when a synchronous
+        # collective was issued, and HIP refuses a query while THAT STREAM is capturing, although the record predates the capture
+        # and the capture is thread-local (csrc/plan.hip).  A stream no collective ever ran on cannot be hit, whatever the timing.
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._order_with = stream
         self.arena = Arena()
         self._range_slots = scope_slots(self.device)
         # spans=True: every launch of the LDS-DMA convolution kernel times itself in-kernel on every replay (dlip_span_scope_*);
@@ -142,10 +133,11 @@ class StepPlan:
         self.outputs = None
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)
+        if self._order_with is not None:
+            self.stream.wait_stream(self._order_with)
         with torch.cuda.stream(self.stream), torch.no_grad():
             self._pass("collect")                 # warm-up: packs weights, registers the workspace, fills the arena
             self.stream.synchronize()
-            _quiesce_collectives(self.device)
             check(lib().dlip_plan_begin(self.stream.cuda_stream), "dlip_plan_begin")
             try:
                 out = self._pass("replay")
@@ -162,6 +154,8 @@ class StepPlan:
         self.launches = int(lib().dlip_plan_launches(self._handle))
         self._gen = holders.PACK_GEN[0]
         caller.wait_stream(self.stream)
+        if self._order_with is not None:
+            self._order_with.wait_stream(self.stream)
 
     def _pass(self, mode: str):
         self.arena.mode, self.arena.cursor = mode, 0

@@ -93,3 +93,15 @@ def test_train_video_dp_recorded_step_on_rccl_one_rank(tmp_path):
     text = "".join(lines)
     assert rc == 0, text[-3000:]
     assert text.count("(replayed)") == 3 and "done:" in text
+
+
+def test_step_plan_recorded_behind_collectives_on_the_same_stream_survives_the_watchdog():
+    """Regression test of round 4's intermittent: "Process group watchdog thread terminated with exception: HIP error: operation
+    not permitted on an event last recorded in a capturing stream" (one full-suite run in five, test_bench_scaling_protocol_...).
+    The probe issues collectives with the stream it hands to StepPlan current, then records a plan whose capture stays open for
+    0.3 s -- three polls of the process group's watchdog.  Recorded on that stream (StepPlan until round 4) the job aborts at the
+    first plan; StepPlan records on a private stream now (deeplip_amd/plan.py)."""
+    rc, js, lines = _run("tools/probes/capture_race.py", ["--child", "4", "long", "same"])
+    text = "".join(lines)
+    assert rc == 0, text[-2000:]
+    assert "RESULT survived=4 of 4 error=none" in text, text[-2000:]

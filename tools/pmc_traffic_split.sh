@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 LAYERS=${1:-l3.conv}
 cd /tmp && export TMPDIR=/tmp
 for L in $LAYERS; do
- for SK in -1 0; do
+ for SK in ${SKS:--1 0}; do   # SKS="-1 3": the L2-local hand-off experiment (dlip_debug_set(3, 3))
   for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     N=$(echo $C | cut -d" " -f1)
     O=$R/gpurun_out/tsplit_${L}_sk${SK}_$N
