@@ -36,7 +36,8 @@
     } } while (0)
 // host side (launch_one / the tile menu / the dispatch switch of conv_igemm_f16x3_dma.hip)
 #define DLIP_LAB_LAUNCH_HOOK() do { sk.stamps = nullptr; \
-    if (getenv("DLIP_STAMP_PRINT")) return dlip_lab_stamped_launch(kern, (unsigned)G, threads, lds, st, b, sk, BM, BN); } while (0)
+    if (getenv("DLIP_STAMP_PRINT")) { if (!getenv("DLIP_STAMP_REDUCE_LATER")) sk.reduce_later = 0;   /* (stamped launches skip the reduce launch) */ \
+      return dlip_lab_stamped_launch(kern, (unsigned)G, threads, lds, st, b, sk, BM, BN); } } while (0)
 // tiles 6.. of the lab menu: 6, 7 retired (the spread-piece variants of round 2); 8, 9: tiles 4, 2 with every wave issuing at the top
 // of the slice; 10: the 256x256 experiment; 11: 256x128 with the LOCK-STEP loop (the product until round 3: the ping-pong loop's
 // reference); 12: ping-pong without s_setprio around the matrix phase; 13: ping-pong with the group-major MFMA order; window mode

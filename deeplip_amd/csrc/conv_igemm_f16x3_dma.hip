@@ -67,6 +67,8 @@ struct StreamK {
   unsigned long long* span;   // NULL, or this launch's {first workgroup start, last workgroup end} in 100 MHz ticks (dlip_span_scope_*)
   int il_tiles;      // > 0: G = il_tiles * parts and neighbours in work order take the SAME part of DIFFERENT tiles (launch_one)
   int l2_local;      // experiment (dlip_debug_set(3, 3)): a tile whose parts all sit on ONE XCD hands its slabs over through that XCD's L2
+  int reduce_later;  // every workgroup is one part of one tile (il_tiles mode) and only PUBLISHES it: slab_reduce_kernel, launched behind
+                     // this kernel, adds a tile's parts in part order and runs the epilogue (launch_one: few tiles cut many ways)
   DLIP_LAB_STREAMK_FIELDS   // (conv_dma_hooks.h: nothing in the product build)
 };
 
@@ -556,6 +558,15 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         const int xf = gf < big ? gf / (q8 + 1) : r8 + (gf - big) / q8, xl = gl < big ? gl / (q8 + 1) : r8 + (gl - big) / q8;
         l2_local = xf == xl;
       }
+      if (sk.reduce_later) {   // (workgroup-uniform) publish and leave: the kernel boundary makes the slab visible to the reduce launch
+        const __amdgpu_buffer_rsrc_t sr = dlip_make_rsrc(sk.slabs + (size_t)(2 * g) * SLAB, SLAB * 4);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mi][ni]), sr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 0);
+        finish = false;
+      } else {
       // 1. peek: if every other part has already published, this workgroup is the finisher and keeps its
       //    part in registers (the usual case for a range's final, head-of-tile segment: the neighbour
       //    computed the rest of that tile first thing).
@@ -622,6 +633,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
           for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = t[ni];
         }
       }
+      }   // (!reduce_later)
     }
 
     if (finish) {
@@ -793,6 +805,48 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   DLIP_LAB_WG_END_STAMPS();
 }
 
+// Second launch of a "publish only" split (StreamK::reduce_later): one thread per accumulator quad of a tile adds that quad over
+// the tile's parts IN PART ORDER -- the same sums in the same order as the in-kernel finisher, so the same bits -- and runs the
+// fp32 epilogue y = act(v / wscale + bias) * post_scale + post_shift.  Why: a weight gradient run as a convolution is 1 - 36 tiles
+// cut 14 - 100 ways (5 tiles x 14 036 slices on layer 1); the finisher -- ONE workgroup per tile reading its parts' slabs one
+// after the other -- then ran 230 of a launch's 370 us alone on the chip (in-kernel stamps, round 4: workgroups busy 136 us in the
+// median, 369 us the slowest).  Here the parts' loads are independent and every quad has its own thread: microseconds.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const ConvArgs a, const float* __restrict__ slabs, int parts) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N, WM = BM / WAVES_M, WN = BN / WAVES_N, FR = 16;
+  constexpr int MI = WM / FR, NI = WN / FR, QUADS = MI * NI * NT;   // = BM * BN / 4
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= QUADS) return;
+  const int tile = blockIdx.y;
+  const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + (size_t)2 * tile * parts * QUADS + q;   // part p of tile t: slab 2 (t parts + p)
+  f32x4 t = src[0];
+#pragma unroll 8
+  for (int p = 1; p < parts; ++p) {
+    const f32x4 v = src[(size_t)2 * p * QUADS];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = t[c] + v[c];
+  }
+  // the quad's place in the tile: the main kernel's accumulator map (acc[mi][ni] of thread tid: pixel row wm WM + 16 mi + lrow,
+  // channels wn WN + 16 ni + 4 half ..+3)
+  const int tid = q % NT, blk = q / NT, ni = blk % NI, mi = blk / NI;
+  const int wave = tid >> 6, wm = wave / WAVES_N, wn = wave % WAVES_N, lrow = tid & (FR - 1), half = (tid & 63) / FR;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  int tile_n = tile / tiles_m, tile_m = tile - tile_n * tiles_m;
+  if (a.n_inner) { tile_m = tile / a.tiles_n; tile_n = tile - tile_m * a.tiles_n; }
+  const int m = tile_m * BM + wm * WM + mi * FR + lrow;
+  const int k = tile_n * BN + wn * WN + ni * FR + 4 * half;
+  if (m >= a.M || k >= a.K) return;                      // K % 4 == 0: a quad is whole or absent
+  f32x4 y;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v = t[c] * (1.f / a.wscale[k + c]) + (a.bias ? a.bias[k + c] : 0.f);   // power of two: exact
+    v = v >= 0.f ? v : v * (a.slope ? a.slope[k + c] : 1.f);
+    if (a.pscale) v = v * a.pscale[k + c] + a.pshift[k + c];
+    y[c] = v;
+  }
+  *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.ldy + k) = y;
+}
+
 #include "conv_dma_lab_menu.inc"   // lab build: the stamped launch path (nothing in the product build)
 
 // Per-stream workspace of the balanced split: ticket counters (zeroed once; every launch leaves them
@@ -930,9 +984,16 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
   }
   sk.il_tiles = 0;
   sk.l2_local = dlip_dbg_value[DLIP_DBG_STREAMK] == 3 ? 1 : 0;
-  if (G != tiles && a.nk >= 256 && tiles >= 2 && tiles <= 64 && G / tiles >= 2) {
+  if (G != tiles && a.nk >= 256 && tiles >= 1 && tiles <= 64 && G / tiles >= 2) {
     G = G / tiles * tiles;          // whole parts: every workgroup stays inside one tile
     sk.il_tiles = (int)tiles;
+  }
+  // Few tiles cut many ways, plain fp32 output: the parts are only published and a second, fully parallel launch adds them and runs
+  // the epilogue (slab_reduce_kernel) -- from 4 parts per tile on (below that the in-kernel finisher's one or two slab reads cost
+  // less than a launch); dlip_debug_set(3, 4) keeps the in-kernel finisher (A/B runs, tests)
+  sk.reduce_later = 0;
+  if constexpr (EPI == 0 && !DUAL) {
+    if (sk.il_tiles > 0 && a.res == nullptr && G / tiles >= 4 && dlip_dbg_value[DLIP_DBG_STREAMK] != 4) sk.reduce_later = 1;
   }
   sk.G = (int)G;
   sk.span = dlip_span_next();
@@ -945,6 +1006,11 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
   if (dlip_dbg_value[DLIP_DBG_NINNER] >= 0) b.n_inner = dlip_dbg_value[DLIP_DBG_NINNER] > 0 ? 1 : 0;
   DLIP_LAB_LAUNCH_HOOK();   // (lab build: DLIP_STAMP_PRINT -> stamped launch + printed medians)
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(threads), lds, st, b, sk);
+  if (sk.reduce_later) {
+    constexpr int quads = BM * BN / 4;
+    hipLaunchKernelGGL((slab_reduce_kernel<BM, BN, WAVES_M, WAVES_N>), dim3((quads + 255) / 256, (unsigned)tiles), dim3(256), 0, st, b,
+                       static_cast<const float*>(sk.slabs), (int)(G / tiles));
+  }
   return dlip_launch_status();
 }
 

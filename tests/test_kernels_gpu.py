@@ -965,6 +965,28 @@ def test_wgrad_as_conv_both_layouts(ops, slice_major, N, H, C, K, R, stride, pad
     assert rel_err(got.cpu().numpy(), w.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("N,H,C,K,stride", [(64, 22, 64, 64, 1), (40, 11, 128, 128, 1), (33, 22, 64, 128, 2), (70, 3, 512, 512, 1)])
+def test_split_reduce_launch_is_bit_identical_to_the_in_kernel_finisher(ops, N, H, C, K, stride):
+    """Few tiles cut many ways (weight gradients run as convolutions: 1 - 36 tiles, 14 - 100 parts each): the parts are only
+    published and slab_reduce_kernel -- a second, fully parallel launch -- adds them in part order and runs the epilogue.  Same sums
+    in the same order as the in-kernel finisher (dlip_debug_set(3, 4) brings it back): the same bits; repeatable."""
+    from deeplip_amd import _lib, autograd_video as av
+    x = rnd(N, H, H, C, seed=61).cuda()
+    Ho = (H + 2 - 3) // stride + 1
+    dy = (rnd(N, Ho, Ho, K, seed=62) * 1e-3).cuda()
+    outs = {}
+    try:
+        for mode in (4, -1, -1):
+            _lib.debug_set(_lib.DBG_STREAMK, mode)
+            outs.setdefault(mode, []).append(av.wgrad_as_conv(x, dy, 3, 3, (stride, stride), (1, 1), (1, 1)).clone())
+        torch.cuda.synchronize()
+    finally:
+        _lib.debug_set(_lib.DBG_STREAMK, -1)
+    assert torch.equal(outs[-1][0].view(torch.int32), outs[4][0].view(torch.int32))
+    assert torch.equal(outs[-1][0].view(torch.int32), outs[-1][1].view(torch.int32))
+    assert float(outs[-1][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("K,C,T", [(64, 64, 9), (128, 32, 3), (96, 64, 1), (32, 128, 5), (32, 1024, 9), (1024, 32, 9)])
 def test_split_weights_perm_equals_permute_then_split(ops, K, C, T):
     """dlip_split_weights_perm_f32 (reference [K,C,T] in, split image out) == permute + dlip_split_weights_rows_f32, both modes."""

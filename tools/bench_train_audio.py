@@ -17,7 +17,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--dim", type=int, default=24)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--dbg", action="append", default=[], metavar="KEY=VALUE", help="dlip_debug_set(KEY, VALUE) before anything is launched (A/B runs)")
 a = ap.parse_args()
+for _kv in a.dbg:
+    from deeplip_amd import _lib as _dl
+    _dl.debug_set(int(_kv.split("=")[0]), int(_kv.split("=")[1]))
 et = {"input_dim": a.dim, "hidden_dim": [512] * 9 + [1500], "context": ETDNN_CONTEXT, "tdnn_layers": 10, "embedding_dim": 512,
       "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}
 net = SpeakerEmbNet({"arch": "etdnn", "etdnn": et})

@@ -17,7 +17,11 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--frames", type=int, default=29)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--eager", action="store_true", help="issue every launch of every step from Python (no recorded step graph)")
+ap.add_argument("--dbg", action="append", default=[], metavar="KEY=VALUE", help="dlip_debug_set(KEY, VALUE) before anything is launched (A/B runs)")
 a = ap.parse_args()
+for _kv in a.dbg:
+    from deeplip_amd import _lib as _dl
+    _dl.debug_set(int(_kv.split("=")[0]), int(_kv.split("=")[1]))
 tcn = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
 net = Lipreading(num_classes=54, relu_type="prelu", tcn_options=tcn, extract_feats=False)
 sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="video.")

@@ -7,8 +7,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-tail -c 2500 $O/bench.json
 STEPS=5
 SSTEPS=40   # the kernel-trace runs: long enough to sit at the chip's steady (power-capped) clocks like bench.py's own timed region
 ARGS="$R/bench.py --steps $SSTEPS --warmup 5 --no-cpu-baseline --single-mode"
@@ -26,4 +24,9 @@ done
 python3 $R/tools/pmc_summary.py $O/pmc_summary.json $((STEPS + 2)) $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $O/pmc_TCC_HIT_sum > /dev/null
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 rm -rf $O/stats/*/*kernel_trace.csv   # large; the stats csv is what gets committed
+# the judged bench line LAST, with this very collection's counters as `roofline.traffic` (bench.py reads profiles/traffic_latest.json
+# and ignores it unless its kernel_sha matches the library's dominant-kernel sources)
+cp $O/pmc_summary.json $R/profiles/traffic_latest.json
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+tail -c 2500 $O/bench.json
 ls $O
