@@ -625,7 +625,8 @@ int dlip_range_scope_end(dlip_stream_t stream);
  * 5 tile order of the LDS-DMA kernel (0 column block outer, 1 inner), 6 rows kernel (conv_rows_f16x3.hip: 0 = off, 1 = on for
  * every launch of its shape class whatever the size, 3 | 4 | 5 = on with that tile height in units of 32 rows),
  * 7 the rows kernel's general mode for 2-D filters / residual / second source (1 = on for every eligible launch; anything else:
- * off -- the library never chooses it, see conv_rows_f16x3.hip);
+ * off -- the library never chooses it, see conv_rows_f16x3.hip); key 3 also takes 3 (experiment: slabs of same-XCD tiles through
+ * that XCD's L2) and 4 (the in-kernel finisher where the built-in choice is the reduce launch);
  * value -1 restores the built-in choice. */
 int dlip_debug_set(int32_t key, int32_t value);
 
