@@ -964,7 +964,10 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
     // (reductions of thousands of slices -- the weight gradients run as convolutions: 5 tiles x 14 036 slices on layer 1 -- afford
     // more parts: 64 parts of 5 tiles leave 192 of 512 slots idle)
     const long long max_parts = a.nk >= 16384 ? 4 * kMaxPartsPerTile : a.nk >= 4096 ? 2 * kMaxPartsPerTile : kMaxPartsPerTile;
-    if (Gb > tiles * max_parts) Gb = tiles * max_parts;
+    // (no such bound where the parts go to the parallel reduce launch below: a 1 x 1 shortcut's weight gradient -- ONE 64 x 128
+    // tile of 3 509 slices -- used 64 of the chip's 512 slots)
+    const bool reduce_ok = EPI == 0 && !DUAL && a.res == nullptr && a.nk >= 256 && tiles <= 64 && dlip_dbg_value[DLIP_DBG_STREAMK] != 4;
+    if (Gb > tiles * max_parts && !reduce_ok) Gb = tiles * max_parts;   // (same-box A/B of this rule alone: no change on either training step)
     const double bal_us = (double)sk.iters / Gb / a.nk * tile_us + kHandoffUs * (BM * BN / 16384.0);
     // Short reductions on a full chip (nk <= 16 slices, at least one tile per slot: the k = 1 TDNN layers) run
     // plain: a tile's slab hand-off costs as much as a third of such a tile, and the under-filled last round of a
