@@ -99,6 +99,64 @@ __global__ __launch_bounds__(256) void wgrad_operand_kernel(const float* __restr
   dlip_report_range(amax, status);
 }
 
+// The same operand from WIDER tiles (round 4; see wgrad_chwn_wide_kernel): 32 positions x CT channels (64 | 128) of one tap, read
+// as 16-B quads and written as CT / 32 sixteen-byte pieces per thread.  C % CT == 0, ldx % 4 == 0, x 16-byte aligned.
+template <int CT>
+__global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int ldx,
+                                                                 int C, int Ho, int Wo, int sh, int sw, int R, int S, int dh, int dw, int ph,
+                                                                 int pw, int J, long long ldo, const float* __restrict__ scale,
+                                                                 DlipRange status) {
+  constexpr int PITCH = CT + 4, Q = CT / 32;
+  __shared__ __attribute__((aligned(16))) float tile[32 * PITCH];
+  const int j0 = blockIdx.x * 32, c0 = blockIdx.y * CT;
+  const float sc = scale ? scale[0] : 1.f;
+  // this thread's Q quads: position row (i / (CT / 4)) -- pixel origin of tap (0, 0), once for all taps -- and channel quad
+  int base[Q], hi0[Q], wi0[Q], col[Q], row_[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int i = threadIdx.x + 256 * q, row = i / (CT / 4);
+    const int j = j0 + row;
+    const int wo = j % Wo, t = j / Wo;
+    const int ho = t % Ho, n = t / Ho;
+    hi0[q] = j < J ? ho * sh - ph : -(1 << 28);        // beyond J: every tap reads "outside the image" -> zeros
+    wi0[q] = wo * sw - pw;
+    base[q] = n * H;
+    col[q] = (i - row * (CT / 4)) * 4;
+    row_[q] = row;
+  }
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  float amax = 0.f;
+  for (int tap = 0; tap < R * S; ++tap) {
+    const int r = tap / S, s_ = tap - r * S;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int hi = hi0[q] + r * dh, wi = wi0[q] + s_ * dw;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+        v = *reinterpret_cast<const f32x4*>(x + ((long long)(base[q] + hi) * W + wi) * ldx + c0 + col[q]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= sc;
+      *reinterpret_cast<f32x4*>(tile + row_[q] * PITCH + col[q]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = threadIdx.x + 256 * q, cr = i >> 3, pq = i & 7, jb = (pq & 3) * 8;
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = tile[(jb + e) * PITCH + cr];
+        const _Float16 hi = (_Float16)v;
+        o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
+        amax = fmaxf(amax, fabsf(v));
+      }
+      *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + ((long long)tap * C + c0 + cr) * ldo + j0) + (pq < 4 ? 0 : 32) + jb) = o;
+    }
+    __syncthreads();
+  }
+  dlip_report_range(amax, status);
+}
+
 // Operands of the weight gradient RUN AS A CONVOLUTION (deeplip_amd.autograd_video.wgrad_as_conv): an NHWC tensor x [N,H,W,C]
 // becomes [C][H][W][N32] in the split format -- the images are the "channels" the convolution reduces over, 32 of them per
 // 128-B block (32 hi halves | 32 lo halves), zero for n >= N:
@@ -157,6 +215,63 @@ __global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict
       q[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
     }
     if (n < N) *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(nhwc_out + ((long long)n * HW + p) * C + c0) + (pq < 4 ? 0 : 32) + jb) = q;
+  }
+  dlip_report_range(amax, status);
+}
+
+// The same images from WIDER tiles (round 4): one workgroup = 32 images x CT channels (64 | 128) of one pixel, read as 16-B
+// quads (CT / 32 per thread in flight instead of four 4-B loads) and written as CT / 32 sixteen-byte pieces per thread -- the
+// 32 x 32 version moved 4 KB per workgroup between two barriers and held 2.8 TB/s.  group = 0, layouts 0 / 1, C % CT == 0.
+template <int CT>
+__global__ __launch_bounds__(256) void wgrad_chwn_wide_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int ldx, int C,
+                                                              int N32, const float* __restrict__ scale, DlipRange status, int layout,
+                                                              float* __restrict__ nhwc_out) {
+  constexpr int PITCH = CT + 4, Q = CT / 32;              // floats per LDS row (16-B aligned rows); quads / pieces per thread
+  __shared__ __attribute__((aligned(16))) float tile[32 * PITCH];
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * CT, p = blockIdx.z;
+  const float sc = scale ? scale[0] : 1.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int i = threadIdx.x + 256 * q, row = i / (CT / 4), col4 = i - row * (CT / 4);
+    const int n = n0 + row;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) v = *reinterpret_cast<const f32x4*>(x + ((long long)n * HW + p) * ldx + c0 + col4 * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] *= sc;
+    *reinterpret_cast<f32x4*>(tile + row * PITCH + col4 * 4) = v;
+  }
+  __syncthreads();
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  float amax = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int i = threadIdx.x + 256 * q, cr = i >> 3, pq = i & 7, jb = (pq & 3) * 8;
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = tile[(jb + e) * PITCH + cr];
+      const _Float16 hi = (_Float16)v;
+      o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
+      amax = fmaxf(amax, fabsf(v));
+    }
+    const long long blk = layout == 0 ? ((long long)(c0 + cr) * HW + p) * N32 + n0
+                                      : (((long long)(c0 + cr) * (N32 / 32) + blockIdx.x) * HW + p) * 32;
+    *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + blk) + (pq < 4 ? 0 : 32) + jb) = o;
+  }
+  if (nhwc_out) {   // the same tile as split NHWC rows: image nl, 32-channel block cb: 8 pieces of 16 B
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = threadIdx.x + 256 * q, pq = i & 7, t = i >> 3, cb = t % (CT / 32), nl = t / (CT / 32), jb = (pq & 3) * 8;
+      const int n = n0 + nl;
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = tile[nl * PITCH + cb * 32 + jb + e];
+        const _Float16 hi = (_Float16)v;
+        o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
+      }
+      if (n < N) *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(nhwc_out + ((long long)n * HW + p) * C + c0 + cb * 32) + (pq < 4 ? 0 : 32) + jb) = o;
+    }
   }
   dlip_report_range(amax, status);
 }
@@ -481,9 +596,19 @@ extern "C" int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out
                  stride_w > 0 && R > 0 && S > 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0);
   const long long J = (long long)N * Ho * Wo;
   DLIP_CHECK_ARG(J < (1ll << 28) && (long long)N * H < (1ll << 30) && ld_out >= J && (ld_out & 31) == 0 && (C + 31) / 32 <= 65535);
-  hipLaunchKernelGGL(wgrad_operand_kernel, dim3((unsigned)(ld_out / 32), (unsigned)((C + 31) / 32)), dim3(256), 0, ST(stream), x, out, H, W,
-                     ldx, C, Ho, Wo, stride_h, stride_w, R, S, dil_h, dil_w, pad_h, pad_w, (int)J, (long long)ld_out, scale,
-                     dlip_range_for(DLIP_ST_PACK));
+  const bool quads = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  if (quads && C % 128 == 0)
+    hipLaunchKernelGGL(wgrad_operand_wide_kernel<128>, dim3((unsigned)(ld_out / 32), (unsigned)(C / 128)), dim3(256), 0, ST(stream), x, out, H, W,
+                       ldx, C, Ho, Wo, stride_h, stride_w, R, S, dil_h, dil_w, pad_h, pad_w, (int)J, (long long)ld_out, scale,
+                       dlip_range_for(DLIP_ST_PACK));
+  else if (quads && C % 64 == 0)
+    hipLaunchKernelGGL(wgrad_operand_wide_kernel<64>, dim3((unsigned)(ld_out / 32), (unsigned)(C / 64)), dim3(256), 0, ST(stream), x, out, H, W,
+                       ldx, C, Ho, Wo, stride_h, stride_w, R, S, dil_h, dil_w, pad_h, pad_w, (int)J, (long long)ld_out, scale,
+                       dlip_range_for(DLIP_ST_PACK));
+  else
+    hipLaunchKernelGGL(wgrad_operand_kernel, dim3((unsigned)(ld_out / 32), (unsigned)((C + 31) / 32)), dim3(256), 0, ST(stream), x, out, H, W,
+                       ldx, C, Ho, Wo, stride_h, stride_w, R, S, dil_h, dil_w, pad_h, pad_w, (int)J, (long long)ld_out, scale,
+                       dlip_range_for(DLIP_ST_PACK));
   return dlip_launch_status();
 }
 
@@ -493,8 +618,16 @@ extern "C" int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_
                  (reinterpret_cast<uintptr_t>(out) & 127) == 0);
   DLIP_CHECK_ARG((long long)H * W <= 65535 && (C + 31) / 32 <= 65535 && N < (1ll << 31));
   DLIP_CHECK_ARG(nhwc_split_out == nullptr || ((C & 31) == 0 && (reinterpret_cast<uintptr_t>(nhwc_split_out) & 127) == 0));
-  hipLaunchKernelGGL(wgrad_chwn_kernel, dim3((unsigned)(N32 / 32), (unsigned)((C + 31) / 32), (unsigned)(H * W)), dim3(256), 0, ST(stream), x,
-                     out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK), 0, 0, slice_major ? 1 : 0, nhwc_split_out);
+  const bool quads = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  if (quads && C % 128 == 0)
+    hipLaunchKernelGGL(wgrad_chwn_wide_kernel<128>, dim3((unsigned)(N32 / 32), (unsigned)(C / 128), (unsigned)(H * W)), dim3(256), 0, ST(stream),
+                       x, out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK), slice_major ? 1 : 0, nhwc_split_out);
+  else if (quads && C % 64 == 0)
+    hipLaunchKernelGGL(wgrad_chwn_wide_kernel<64>, dim3((unsigned)(N32 / 32), (unsigned)(C / 64), (unsigned)(H * W)), dim3(256), 0, ST(stream),
+                       x, out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK), slice_major ? 1 : 0, nhwc_split_out);
+  else
+    hipLaunchKernelGGL(wgrad_chwn_kernel, dim3((unsigned)(N32 / 32), (unsigned)((C + 31) / 32), (unsigned)(H * W)), dim3(256), 0, ST(stream), x,
+                       out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK), 0, 0, slice_major ? 1 : 0, nhwc_split_out);
   return dlip_launch_status();
 }
 

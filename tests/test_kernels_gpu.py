@@ -888,7 +888,7 @@ def test_conv_more_than_32_taps(ops, case, force_dma_tile):
         ops.conv_nhwc(x.cuda(), ws.cuda(), None, stride=(sh, sw), pad=(ph, pw), dil=(dh, dw), w_scale=sc.cuda())
 
 
-@pytest.mark.parametrize("N,H,W,C", [(5, 3, 4, 64), (33, 2, 2, 40), (64, 1, 7, 32)])
+@pytest.mark.parametrize("N,H,W,C", [(5, 3, 4, 64), (33, 2, 2, 40), (64, 1, 7, 32), (70, 2, 3, 128), (40, 3, 3, 256), (33, 1, 5, 192)])
 def test_wgrad_chwn_operand(ops, N, H, W, C):
     """dlip_wgrad_chwn_f32: [N,H,W,C] -> [C,H,W,N32] split blocks (32 hi halves | 32 lo halves per 32 images), zero beyond N,
     optional scale -- bit for bit."""
@@ -1347,3 +1347,35 @@ def test_conv_rows_general_mode_is_never_chosen_unforced(ops, force_rows2d):
     assert kind(B, 6, 256, 256, ldr=256) == (2, 160, 256)
     assert kind(B, 3, 512, 512, ldr=512) == (2, 160, 256)
     assert kind(B, 11, 128, 128)[0] == 1                         # (the window kernel is asked first)
+
+
+@pytest.mark.parametrize("N,H,W,C,R,S,stride,pad,dil", [(3, 5, 6, 64, 3, 3, 1, 1, 1), (2, 1, 40, 128, 1, 3, 1, 0, 2), (2, 4, 4, 192, 3, 3, 2, 1, 1),
+                                                         (5, 3, 3, 40, 3, 3, 1, 1, 1), (1, 1, 70, 256, 1, 5, 1, 0, 1)])
+def test_wgrad_reduction_major_operand(ops, N, H, W, C, R, S, stride, pad, dil):
+    """dlip_wgrad_operand_f32: out[(tap C + c) J32 + j] = scale * x[n, ho s + r d - p, wo s + s' d - p, c] in 128-byte split blocks of 32
+    positions (zero outside the image and for j >= J) -- bit for bit, on the 32-channel tiles (C = 40) and the wide ones (round 4:
+    C % 64 == 0 / C % 128 == 0)."""
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    sh = (1, stride) if H == 1 else (stride, stride)
+    ph = (0, pad) if H == 1 else (pad, pad)
+    dh = (1, dil) if H == 1 else (dil, dil)
+    Ho = (H + 2 * ph[0] - dh[0] * (R - 1) - 1) // sh[0] + 1
+    Wo = (W + 2 * ph[1] - dh[1] * (S - 1) - 1) // sh[1] + 1
+    J = N * Ho * Wo
+    J32 = (J + 31) // 32 * 32
+    x = rnd(N, H, W, C, seed=91) * 3.0
+    xd, scale = x.cuda(), torch.tensor([0.5, 2.0]).cuda()
+    for sc in (None, scale):
+        out = torch.full((R * S * C, J32), 9.0, device="cuda")
+        check(lib().dlip_wgrad_operand_f32(ptr(xd), ptr(out), J32, N, H, W, C, C, Ho, Wo, sh[0], sh[1], R, S, dh[0], dh[1], ph[0], ph[1],
+                                           ptr(sc) if sc is not None else None, stream_handle()), "dlip_wgrad_operand_f32")
+        torch.cuda.synchronize()
+        ref = torch.zeros(R * S, C, J32)
+        xs = x * (0.5 if sc is not None else 1.0)
+        xp = torch.zeros(N, H + 2 * ph[0], W + 2 * ph[1], C)
+        xp[:, ph[0]:ph[0] + H, ph[1]:ph[1] + W] = xs
+        for r in range(R):
+            for s_ in range(S):
+                win = xp[:, r * dh[0]: r * dh[0] + (Ho - 1) * sh[0] + 1: sh[0], s_ * dh[1]: s_ * dh[1] + (Wo - 1) * sh[1] + 1: sh[1]]   # [N,Ho,Wo,C]
+                ref[r * S + s_, :, :J] = win.reshape(J, C).t()
+        assert torch.equal(out.cpu().view(torch.int32), _split_ref(ref.view(R * S * C, J32)).view(torch.int32))

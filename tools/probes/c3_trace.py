@@ -1,7 +1,7 @@
 """C3 (speech encoder, B = 256 x 80 x 300) eager, for a kernel trace:
    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3 -- python3 tools/probes/c3_trace.py"""
-import sys
-sys.path.insert(0, ".")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from deeplip_amd import packing
