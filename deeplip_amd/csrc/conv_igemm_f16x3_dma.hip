@@ -1072,7 +1072,7 @@ static int dma_pick(long long M, int K, int nk, int epi) {
   // rows, 512 | 768 -> 256 channels, 48-168 slices -- are a handful of row tiles split many ways: on 64-row tiles there are twice as
   // many tiles to split and half as many parts per tile for the finisher to add (tools/bench_tcn.py, same box: 41.8 -> 27.9 us,
   // 45.9 -> 32.7, 60.7 -> 45.6 against 128 x 128; 128 x 64 and 256 x 128 in between)
-  if (M <= 2048 && nk >= 16) return K <= 64 ? 3 : 2;
+  if (M <= 2048 && nk >= 16 && nk < 256) return K <= 64 ? 3 : 2;
   if (K <= 64) return 1;
   if (nk <= 8) return 4;
   if (nk >= 32 && M >= 8192) return 5;
@@ -1082,7 +1082,9 @@ static int dma_pick(long long M, int K, int nk, int epi) {
   if (nk >= 18 && M >= 65536) return 5;
   // very long reductions over few tiles (the weight gradients run as convolutions: 5-36 tiles of 260-3 500 slices; no forward launch reduces over more than 144): the balanced split
   // fills the chip whatever M is, and the 256x128 tile's loop is the faster one (7-12 % per launch, tools/bench_wgrad.py)
-  if (nk >= 256 && M >= 1024) return 5;
+  // (round 4, with the reduce launch in place: from M = 256 -- the speech encoder's 512 x 512 weight gradients, 2 400 slices, had
+  // fallen to the 64-row rule above: 13.23 ms per training step on 64 x 128, 12.72 on 128 x 128, 12.60 on 256 x 128, same box)
+  if (nk >= 256 && M >= 256) return 5;
   // (Measured and rejected in round 2: 160-row tiles for the short plain launches -- the k = 1 TDNN layers are 592 tiles of
   // 128x128 on 512 slots, two rounds with the second 16 % full, and 476 tiles of 160x128, one round: 47.8 vs 46.8 us.  The
   // under-filled second round is cheap because these layers wait for operands, not for the matrix core.)
