@@ -282,22 +282,35 @@ class TDNNBlockTrainFn(Function):
         # (a first layer on 24 features may read its input zero-padded to 32 channels: then the split-fp16 kernels serve it too)
         if (Cw != Cx and (Cw + 31) // 32 * 32 != Cx) or Cx % 4 or K % 4:
             raise ValueError(f"TDNN train path: channels must match and be multiples of 4 (x {Cx}, weight {Cw}, out {K})")
-        from .autograd_video import conv_train
+        from . import autograd_video as av
         B_, T_, C_in = x.shape
-        z = conv_train(x.view(B_, 1, T_, C_in), None, bias.contiguous() if bias is not None else None, (1, 1), (0, 0), (1, dilation),
-                       w_ref=weight.view(K, Cw, 1, S))                         # reference [K,C,S]: split image written straight from it
+        # (round 4) ONE read of x writes both of its split images: the forward convolution's operand and the weight gradient's (kept
+        # for the backward instead of x): the reduction-major GEMM operand of a k = 1 layer (mode 1), the [C][T][B32] image of the
+        # weight gradient run as a convolution otherwise (mode 2) -- what ConvTrainFn does for the lip-clip encoder
+        mode, xT, xs = 0, None, None
+        if ctx.needs_input_grad[1] and av.TRAIN_CONV == "f16x3" and K % 4 == 0 and (Cw == Cx or (Cw + 31) // 32 * 32 == Cx):
+            if S == 1 and Cx % 64 == 0:
+                xT, xs = av.operand_and_split(x.view(B_ * T_, C_in))
+                mode, xs = 1, xs.view(B_, 1, T_, C_in)
+            elif S > 1 and Cx % 32 == 0 and av.WGRAD == "conv":
+                xT, xs = av.wgrad_image(x.view(B_, 1, T_, C_in), None, also_nhwc_split=True)
+                mode = 2
+        z = av.conv_train(x.view(B_, 1, T_, C_in), None, bias.contiguous() if bias is not None else None, (1, 1), (0, 0), (1, dilation),
+                          w_ref=weight.view(K, Cw, 1, S), xs_ready=xs)         # reference [K,C,S]: split image written straight from it
         z = z.view(B_, z.shape[2], z.shape[3])
         Tp = z.shape[1]
         y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first)
-        ctx.save_for_backward(x, weight, z, gamma, beta, mean, invstd)
+        ctx.save_for_backward(xT if mode else x, weight, z, gamma, beta, mean, invstd)
         ctx.cfg = (dilation, slope, act_first, bias is not None)
+        ctx.x_shape, ctx.mode = (B, T, Cx), mode
         return y2.view(B, Tp, K)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, z, gamma, beta, mean, invstd = ctx.saved_tensors
         dilation, slope, act_first, has_bias = ctx.cfg
-        B, T, Cx = x.shape
+        B, T, Cx = ctx.x_shape
+        mode = ctx.mode
         K, _, S = weight.shape
         Tp = z.shape[1]
         dev = x.device
@@ -310,17 +323,34 @@ class TDNNBlockTrainFn(Function):
                   "dlip_colsum_rows_f32")
         dz = dz2.view(B, Tp, K)
         dx = None
-        from .autograd_video import pow2_lift
-        lift = pow2_lift(dz2)                                                  # one absmax pass for dgrad and wgrad alike
+        from . import autograd_video as av
+        lift = av.pow2_lift(dz2)                                               # one absmax pass for dgrad and wgrad alike
+        # one read of dz writes its weight-gradient image AND the data gradient's lifted split operand (when its channels allow)
+        gT = dzs = None
+        if mode == 1 and ctx.needs_input_grad[1]:
+            if K % 64 == 0 and ctx.needs_input_grad[0]:
+                gT, dzs = av.operand_and_split(dz2, lift)
+                dzs = dzs.view(B, 1, Tp, K)
+            else:
+                J32 = x.shape[1]
+                gT = torch.empty((K, J32), device=dev, dtype=torch.float32)
+                check(lib().dlip_wgrad_operand_f32(ptr(dz2), ptr(gT), J32, B, 1, Tp, K, K, 1, Tp, 1, 1, 1, 1, 1, 1, 0, 0, ptr(lift), stream_handle()),
+                      "dlip_wgrad_operand_f32")
+        elif mode == 2 and ctx.needs_input_grad[1]:
+            gT, dzs = av.wgrad_image(dz2.view(B, 1, Tp, K), lift, also_nhwc_split=ctx.needs_input_grad[0] and K % 32 == 0)
         if ctx.needs_input_grad[0]:
-            from .autograd_video import conv_train
             dzc = dz.contiguous()
-            dx = conv_train(dzc.view(B, 1, Tp, K), None, None, (1, 1), (0, (S - 1) * dilation), (1, dilation), lift=True, scale2=lift,
-                            w_ref=weight.view(K, Cx, 1, S), transposed=True)   # [K,C,S] -> rows c of [S reversed][K]
+            dx = av.conv_train(dzc.view(B, 1, Tp, K), None, None, (1, 1), (0, (S - 1) * dilation), (1, dilation), lift=True, scale2=lift,
+                               w_ref=weight.view(K, Cx, 1, S), transposed=True, xs_ready=dzs)   # [K,C,S] -> rows c of [S reversed][K]
             dx = dx.view(B, dx.shape[2], Cx)
         dweight = None
         if ctx.needs_input_grad[1]:
-            dweight = _conv1d_wgrad(x, dz, S, dilation, lift)
+            if mode == 1:
+                dweight = _permute3(av.wgrad_gemm_operands(x, gT, lift).view(1, Cx, K), (2, 1, 0)).view(K, Cx, 1)
+            elif mode == 2:
+                dweight = av.wgrad_as_conv(None, None, 1, S, (1, 1), (0, 0), (1, dilation), scale2=lift, xT=x, gT=gT).view(K, Cx, S)
+            else:
+                dweight = _conv1d_wgrad(x, dz, S, dilation, lift)
             if dweight.shape[1] != weight.shape[1]:          # zero-padded input channels: their gradient columns are not parameters
                 dweight = dweight[:, :weight.shape[1]].contiguous()
         return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None

@@ -201,6 +201,32 @@ def wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2=None):
     return out.view(taps, Cx, K)
 
 
+def operand_and_split(t2, scale2=None):
+    """A [J, C] row matrix (C % 64 == 0) -> (its reduction-major weight-gradient GEMM operand [C, J32], its split NHWC copy [J, C]) from
+    ONE read (dlip_wgrad_operand_split_f32): the forward convolution's operand of a k = 1 layer's input beside its weight-gradient
+    image, or -- with the lift ``scale2`` -- the data gradient's operand of dy beside dy's."""
+    J, C_ = t2.shape
+    J32 = (J + 31) // 32 * 32
+    if WGRAD_ODD_PITCH and (J32 // 32) % 2 == 0:
+        J32 += 32
+    opT = torch.empty((C_, J32), device=t2.device, dtype=torch.float32)
+    spl = torch.empty((J, C_), device=t2.device, dtype=torch.float32)
+    check(lib().dlip_wgrad_operand_split_f32(ptr(t2), ptr(opT), J32, J, C_, ptr(scale2) if scale2 is not None else None, ptr(spl), stream_handle()),
+          "dlip_wgrad_operand_split_f32")
+    return opT, spl
+
+
+def wgrad_gemm_operands(xT_s, dzT_s, scale2):
+    """[rows of x^T, J32] x [K, J32] (both reduction-major, split; dz lifted by ``scale2``) -> [rows, K]: the weight-gradient GEMM."""
+    rows, J32 = xT_s.shape
+    K = dzT_s.shape[0]
+    dev = xT_s.device
+    out = torch.empty((rows, K), device=dev, dtype=torch.float32)
+    ops.conv_nhwc(xT_s.view(1, 1, rows, J32), dzT_s.view(K, 1, 1, J32), None, w_scale=const_vec(K, 1.0, dev), x_split=True,
+                  post_scale=lift_inv(scale2, K), post_shift=const_vec(K, 0.0, dev), out=out.view(1, 1, rows, K))
+    return out
+
+
 # How the convolutions' weight gradients run: "conv" = as a convolution over ONE transposed copy of x and of dy (wgrad_as_conv),
 # "gemm" = one GEMM over the R*S shifted copies of x (wgrad_conv_fused: what round 3 started with).
 WGRAD = "conv"

@@ -105,7 +105,7 @@ template <int CT>
 __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int ldx,
                                                                  int C, int Ho, int Wo, int sh, int sw, int R, int S, int dh, int dw, int ph,
                                                                  int pw, int J, long long ldo, const float* __restrict__ scale,
-                                                                 DlipRange status) {
+                                                                 DlipRange status, float* __restrict__ nhwc_out = nullptr) {
   constexpr int PITCH = CT + 4, Q = CT / 32;
   __shared__ __attribute__((aligned(16))) float tile[32 * PITCH];
   const int j0 = blockIdx.x * 32, c0 = blockIdx.y * CT;
@@ -151,6 +151,21 @@ __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __
         amax = fmaxf(amax, fabsf(v));
       }
       *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + ((long long)tap * C + c0 + cr) * ldo + j0) + (pq < 4 ? 0 : 32) + jb) = o;
+    }
+    if (nhwc_out) {   // (one tap, stride 1, no padding: position j IS row j of x) the same tile as split NHWC rows, from the one read
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int i = threadIdx.x + 256 * q, pq = i & 7, t = i >> 3, cb = t % (CT / 32), nl = t / (CT / 32), jb = (pq & 3) * 8;
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = tile[nl * PITCH + cb * 32 + jb + e];
+          const _Float16 hi = (_Float16)v;
+          o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
+        }
+        if (j0 + nl < J)
+          *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(nhwc_out + (long long)(j0 + nl) * C + c0 + cb * 32) + (pq < 4 ? 0 : 32) + jb) = o;
+      }
     }
     __syncthreads();
   }
@@ -609,6 +624,21 @@ extern "C" int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out
     hipLaunchKernelGGL(wgrad_operand_kernel, dim3((unsigned)(ld_out / 32), (unsigned)((C + 31) / 32)), dim3(256), 0, ST(stream), x, out, H, W,
                        ldx, C, Ho, Wo, stride_h, stride_w, R, S, dil_h, dil_w, pad_h, pad_w, (int)J, (long long)ld_out, scale,
                        dlip_range_for(DLIP_ST_PACK));
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_wgrad_operand_split_f32(const float* x, float* out, int64_t ld_out, int64_t J, int32_t C, const float* scale,
+                                            float* nhwc_split_out, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && out && nhwc_split_out && J > 0 && J < (1ll << 28) && C > 0 && (C & 63) == 0 && ld_out >= J && (ld_out & 31) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(nhwc_split_out)) & 127) == 0 &&
+                 (reinterpret_cast<uintptr_t>(x) & 15) == 0 && C / 64 <= 65535);
+  // x as [J, 1, 1, C]: one "image" per position, one tap
+  if (C % 128 == 0)
+    hipLaunchKernelGGL(wgrad_operand_wide_kernel<128>, dim3((unsigned)(ld_out / 32), (unsigned)(C / 128)), dim3(256), 0, ST(stream), x, out, 1, 1, C,
+                       C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, scale, dlip_range_for(DLIP_ST_PACK), nhwc_split_out);
+  else
+    hipLaunchKernelGGL(wgrad_operand_wide_kernel<64>, dim3((unsigned)(ld_out / 32), (unsigned)(C / 64)), dim3(256), 0, ST(stream), x, out, 1, 1, C,
+                       C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, scale, dlip_range_for(DLIP_ST_PACK), nhwc_split_out);
   return dlip_launch_status();
 }
 

@@ -502,6 +502,12 @@ int dlip_tap_gather_f32(const float* x, float* out, int64_t N, int32_t H, int32_
  * 32 lo halves).  ld_out: row pitch in floats, a multiple of 32, >= J (an ODD number of 128-byte blocks keeps the rows of a slice
  * off one memory channel).  R = S = 1, no padding, scale = the power-of-two lift of dlip_pow2_scale_f32: the dy operand.
  * out 128-byte aligned; scale a device scalar or NULL (1).  x is [N,H,W,ldx] NHWC (Conv1d: H = 1). */
+/* (round 4) The one-tap case with BOTH images of a [J, C] row matrix from ONE read: `out` as above (rows c, positions j along the
+ * reduction) and `nhwc_split_out` [J, C] = the same values in the convolution kernels' split activation format (per row and 32
+ * channels one 128-byte block) -- the forward convolution's operand of x, or (scale = the lift) the data gradient's of dy, which
+ * dlip_split_pack*_f32 formed in a pass of its own.  C % 64 == 0; x 16-byte, both outputs 128-byte aligned. */
+int dlip_wgrad_operand_split_f32(const float* x, float* out, int64_t ld_out, int64_t J, int32_t C, const float* scale,
+                                 float* nhwc_split_out, dlip_stream_t stream);
 int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx,
                            int32_t Ho, int32_t Wo, int32_t stride_h, int32_t stride_w, int32_t R, int32_t S, int32_t dil_h,
                            int32_t dil_w, int32_t pad_h, int32_t pad_w, const float* scale, dlip_stream_t stream);

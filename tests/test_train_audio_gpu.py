@@ -68,7 +68,10 @@ def test_permute3():
 
 
 @pytest.mark.parametrize("B,T,C,K,S,dil,act_first", [(4, 60, 24, 64, 5, 1, False), (3, 50, 128, 256, 3, 2, False),
-                                                     (2, 47, 64, 128, 3, 3, True), (5, 33, 256, 512, 1, 1, False)])
+                                                     (2, 47, 64, 128, 3, 3, True), (5, 33, 256, 512, 1, 1, False),
+                                                     # (round 4: the fused operand flow's fall-backs -- an output width that is no multiple of
+                                                     # 64 / 32 (tdnn.9's 1 500) on a k = 1 and on a k = 3 layer, 64 input channels)
+                                                     (2, 40, 64, 100, 1, 1, False), (2, 40, 64, 100, 3, 1, True), (3, 45, 64, 64, 1, 1, True)])
 def test_tdnn_block_train_fn_gradients(B, T, C, K, S, dil, act_first):
     """Conv1d + train-mode BN + LeakyReLU: output and d/dx, d/dW, d/db, d/dgamma, d/dbeta vs torch autograd (fp64)."""
     from deeplip_amd import autograd as ag
