@@ -451,3 +451,20 @@ def test_full_size_training_step_loss_and_gradients_vs_fp64_oracle():
         n64 = float(g64[k].norm())
         if n64 > 1e-7:
             assert abs(float(grads[k].norm()) - n64) < 5e-3 * n64, (k, float(grads[k].norm()), n64)
+
+
+@pytest.mark.parametrize("N,Ho,Wo,Hu,Wu,C,sh,sw", [(3, 11, 11, 22, 22, 128, 2, 2), (2, 6, 6, 12, 11, 256, 2, 2), (5, 1, 20, 1, 40, 64, 1, 2),
+                                                   (2, 3, 3, 7, 6, 8, 2, 2), (1, 4, 5, 10, 13, 4, 3, 3)])
+def test_upsample_zero(N, Ho, Wo, Hu, Wu, C, sh, sw):
+    """dlip_upsample_zero_f32 (the zero insertion in front of a strided layer's data-gradient convolution): out[n, hu, wu] =
+    dz[n, hu / sh, wu / sw] where both divide and the quotient exists, zero elsewhere -- bit for bit."""
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    dz = rnd(N, Ho, Wo, C, seed=71)
+    out = torch.full((N, Hu, Wu, C), 9.0, device=DEV)
+    dzd = dz.to(DEV)
+    check(lib().dlip_upsample_zero_f32(ptr(dzd), ptr(out), N, Ho, Wo, Hu, Wu, C, sh, sw, stream_handle()), "dlip_upsample_zero_f32")
+    torch.cuda.synchronize()
+    ref = torch.zeros(N, Hu, Wu, C)
+    hs, ws = min(Ho, (Hu + sh - 1) // sh), min(Wo, (Wu + sw - 1) // sw)
+    ref[:, ::sh, ::sw][:, :hs, :ws] = dz[:, :hs, :ws]
+    assert torch.equal(out.cpu(), ref)
