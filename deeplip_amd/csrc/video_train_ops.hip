@@ -684,9 +684,11 @@ extern "C" int dlip_upsample_zero_f32(const float* dz, float* out, int64_t N, in
   const long long rows = (long long)N * Hu;
   DLIP_CHECK_ARG(rows < (1ll << 31) && (long long)Wu * (C / 4) < (1ll << 30));
   const int rowlen = Wu * (C / 4);
-  hipLaunchKernelGGL(upsample_zero_kernel, dim3((unsigned)((rowlen + 255) / 256 > 16 ? 16 : (rowlen + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535)),
-                     dim3(256), 0, ST(stream), reinterpret_cast<const f32x4*>(dz), reinterpret_cast<f32x4*>(out), Ho, Wo, Hu, Wu, C / 4,
-                     stride_h, stride_w, (int)rows);
+  const unsigned gx = (unsigned)((rowlen + 255) / 256 > 16 ? 16 : (rowlen + 255) / 256);
+  long long gy = 4096 / gx;                              // ~4 096 workgroups, each walking rows / gy output rows
+  if (gy > rows) gy = rows;
+  hipLaunchKernelGGL(upsample_zero_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, ST(stream), reinterpret_cast<const f32x4*>(dz),
+                     reinterpret_cast<f32x4*>(out), Ho, Wo, Hu, Wu, C / 4, stride_h, stride_w, (int)rows);
   return dlip_launch_status();
 }
 
