@@ -213,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       if (second) { ntap = tap; nsp = s_pos; nrow = x_row; nc0 = c0 + BK; }
       if (nk_ == nk) { nk_ = 0; ntap = 0; nsp = 0; nrow = 0; nc0 = 0; ++nitem; }   // (the caller has run set_item for the next tile: enter_next)
       c_k = nk_; tap = ntap; s_pos = nsp; x_row = nrow; c0 = nc0; c_item = nitem;
+      place();
     } else {
       if (++c_k == nk) {
         c_k = 0; s_pos = 0; c0 = 0;
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       } else if (++s_pos == a.S) {
         s_pos = 0; c0 += BK;
       }
+      x_tap = s_pos * x_ds + c0 * 4;
+      w_tap = (s_pos * a.Cw + c0) * 4;
     }
-    place();
   };
   // MODE 1: the row set-up of the NEXT tile (two divisions and R + S mask steps per row) is done apart from advance(), at a point
   // of the caller's choosing -- in the loop BEFORE the slice's fragment reads: behind them it sat on top of 72 live fragment
@@ -293,39 +295,39 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 
   // ---- epilogue of one tile, from this wave's accumulators straight to memory:
   //      y = act(acc / wscale + bias [+ residual]) * post_scale + post_shift   (a residual in MODE 1 only; split format) ----
-  // (MODE 0: the descriptors are built once, here; MODE 1: inside the epilogue, from rows_kargs())
-  struct EpiCtx {
-    __amdgpu_buffer_rsrc_t yr, rr, scr, bir, slr, psr, ptr_;
-    bool has_res, has_slope;
-    int M, K, ldy, ldr;
-  };
-  auto make_epi = [&](auto&& A) __attribute__((always_inline)) {
-    EpiCtx e;
-    const uint32_t kbytes = (uint32_t)A.K * 4u;
-    e.yr = dlip_make_rsrc(A.y, A.y_bytes);
-    e.has_res = MODE == 1 && A.res != nullptr;
-    e.rr = dlip_make_rsrc(A.res, e.has_res ? A.r_bytes : 0u);
-    e.scr = dlip_make_rsrc(A.wscale, kbytes);
-    e.bir = dlip_make_rsrc(A.bias, A.bias ? kbytes : 0u);
-    e.slr = dlip_make_rsrc(A.slope, A.slope ? kbytes : 0u);
-    e.psr = dlip_make_rsrc(A.pscale, A.pscale ? kbytes : 0u);
-    e.ptr_ = dlip_make_rsrc(A.pshift, A.pshift ? kbytes : 0u);
-    e.has_slope = A.slope != nullptr;
-    e.M = A.M; e.K = A.K; e.ldy = A.ldy; e.ldr = A.ldr;
-    return e;
-  };
-  EpiCtx epi0;
-  if constexpr (MODE == 0) epi0 = make_epi(a);
+  // (MODE 0: the descriptors are built once, here -- plain scalars, as the compiler keeps them best; MODE 1: inside the epilogue,
+  // re-read through rows_kargs().  An aggregate carrying the seven descriptors into the epilogue cost the speech-encoder layers
+  // 2 - 4 %: it lived in vector registers and came back through v_readfirstlane + hazard s_nops, same-box A/B at B = 256.)
+  const uint32_t kbytes0 = (uint32_t)a.K * 4u;
+  const __amdgpu_buffer_rsrc_t yr0 = dlip_make_rsrc(a.y, a.y_bytes);
+  const __amdgpu_buffer_rsrc_t scr0 = dlip_make_rsrc(a.wscale, kbytes0);
+  const __amdgpu_buffer_rsrc_t bir0 = dlip_make_rsrc(a.bias, a.bias ? kbytes0 : 0u);
+  const __amdgpu_buffer_rsrc_t slr0 = dlip_make_rsrc(a.slope, a.slope ? kbytes0 : 0u);
+  const __amdgpu_buffer_rsrc_t psr0 = dlip_make_rsrc(a.pscale, a.pscale ? kbytes0 : 0u);
+  const __amdgpu_buffer_rsrc_t ptr0 = dlip_make_rsrc(a.pshift, a.pshift ? kbytes0 : 0u);
+  const bool has_slope0 = a.slope != nullptr;
   const bool has_post0 = a.pscale != nullptr;
   float amax = 0.f;
   auto epilogue_p = [&](int item, auto post_c) __attribute__((always_inline)) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     constexpr bool post = decltype(post_c)::value;   // (compile-time inside: the runtime flag selected and computed both forms per value)
-    EpiCtx ec;
-    if constexpr (MODE == 1) ec = make_epi(*rows_kargs()); else ec = epi0;
-    const __amdgpu_buffer_rsrc_t yr = ec.yr, rr = ec.rr, scr = ec.scr, bir = ec.bir, slr = ec.slr, psr = ec.psr, ptr_ = ec.ptr_;
-    const bool has_res = ec.has_res, has_slope = ec.has_slope;
-    const int eM = ec.M, eK = ec.K, eldy = ec.ldy, eldr = ec.ldr;
+    __amdgpu_buffer_rsrc_t yr = yr0, rr = yr0, scr = scr0, bir = bir0, slr = slr0, psr = psr0, ptr_ = ptr0;
+    bool has_res = false, has_slope = has_slope0;
+    int eM = a.M, eK = a.K, eldy = a.ldy, eldr = 0;
+    if constexpr (MODE == 1) {
+      RowsKArgs* ap = rows_kargs();
+      const uint32_t kbytes = (uint32_t)ap->K * 4u;
+      yr = dlip_make_rsrc(ap->y, ap->y_bytes);
+      has_res = ap->res != nullptr;
+      rr = dlip_make_rsrc(ap->res, has_res ? ap->r_bytes : 0u);
+      scr = dlip_make_rsrc(ap->wscale, kbytes);
+      bir = dlip_make_rsrc(ap->bias, ap->bias ? kbytes : 0u);
+      slr = dlip_make_rsrc(ap->slope, ap->slope ? kbytes : 0u);
+      psr = dlip_make_rsrc(ap->pscale, ap->pscale ? kbytes : 0u);
+      ptr_ = dlip_make_rsrc(ap->pshift, ap->pshift ? kbytes : 0u);
+      has_slope = ap->slope != nullptr;
+      eM = ap->M; eK = ap->K; eldy = ap->ldy; eldr = ap->ldr;
+    }
     const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
     const int row0 = tile_m * BM + wm * WM + lrow;
     const int col0 = tile_n * BN + wn * 64;
@@ -603,8 +605,9 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
     static_assert(NL + NST < 64, "vmcnt is a 6-bit counter");
     int st_iss = total > 1 ? 2 : 1;                        // stage the next issue goes to (the prologue issued slices 0, 1)
     // consumer side: the segment being multiplied (MODE 0: always a whole tile)
-    int kleft = nk, e_item = item0, done_item = -1, rem = 0;
-    bool e_part = false, e_first = true, done_part = false, done_first = false;   // (wave-uniform)
+    int kleft = nk, e_item = item0, done_item = -1;
+    [[maybe_unused]] int rem = 0;
+    [[maybe_unused]] bool e_part = false, e_first = true, done_part = false, done_first = false;   // (wave-uniform; MODE 1)
     if constexpr (MODE == 1) {
       kleft = nk - k0 < total ? nk - k0 : total;
       rem = total - kleft;
@@ -619,9 +622,14 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       bool did_epi = false;                                // (wave-uniform)
       ROWS_SSTAMP(0);
       if (done_item >= 0) {
-        const bool wrote = finish_tile(done_item, done_part, done_first);
+        if constexpr (MODE == 1) {
+          did_epi = finish_tile(done_item, done_part, done_first);
+        } else {
+          epilogue(done_item);
+          did_epi = true;
+        }
         if (s == total) break;                             // the stream ends on a segment's last slice
-        zero_acc(); done_item = -1; did_epi = wrote;
+        zero_acc(); done_item = -1;
       }
       const bool more2 = s + 2 < total;
       if (more2) enter_next();
@@ -649,17 +657,17 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       ROWS_SSTAMP(3);
       mfma_all();
       ROWS_SSTAMP(4);
-      if (--kleft == 0) {
-        done_item = e_item; done_part = e_part; done_first = e_first;
-        if constexpr (MODE == 1) {
+      if constexpr (MODE == 1) {
+        if (--kleft == 0) {
+          done_item = e_item; done_part = e_part; done_first = e_first;
           ++e_item;
           kleft = nk < rem ? nk : rem;
           rem -= kleft;
           e_part = kleft != nk;
           e_first = false;
-        } else {
-          kleft = nk; e_item += nwg;
         }
+      } else {
+        if (--kleft == 0) { kleft = nk; done_item = e_item; e_item += nwg; }
       }
       if (FIRST) {
         __builtin_amdgcn_s_barrier();                      // b(2s+1)
