@@ -200,6 +200,8 @@ class SpeakerEmbNet(nn.Module):
         # [B,T,F] channels-last; F zero-padded to a multiple of 32 when the first layer can then run on the split-fp16 kernels
         # (24 features: the exact-fp32 kernel took 0.55 ms per launch on it, 1.1 of a 15 ms step at B = 256)
         h = self._to_ntc_padded(x)
+        from . import autograd_video as av
+        av.prepare_weights()                               # the step's split weight images (forward and data-gradient banks): one launch
         for blk in self.tdnn:
             h = ag.tdnn_block_train(h, blk)
         h = ag.meanstd_pool(h)

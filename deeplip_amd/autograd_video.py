@@ -108,6 +108,113 @@ def lift_inv(scale2, K):
     return inv
 
 
+# ---- the step's weight images in ONE launch (round 4) ----------------------------------------------------------------------------
+# Every convolution of a training step needs the split-fp16 image of its CURRENT weights twice: the forward bank and the flipped /
+# transposed data-gradient bank (conv_train below: dlip_split_weights_perm_f32, 94 launches of 8 - 10 us per lip-clip step, each in front
+# of the convolution that waits for it).  The first step REGISTERS each (weight, bank) it meets together with persistent output
+# buffers; from then on `prepare_weights()` -- called at the start of a train-mode forward -- writes all of them in one launch
+# (dlip_split_weights_multi_f32) and conv_train takes the prepared image when the weight has not been modified in place since (tensor
+# version counters: an optimizer step between forward and backward simply falls back to the per-convolution launch).
+class _WeightPrep:
+    def __init__(self):
+        self.entries = {}          # (data_ptr, shape, transposed, Cw) -> dict
+        self.order = []
+        self.table = None          # (descs_dev, blocks_dev, n_blocks) for len(order) entries
+        self.table_len = 0
+        self.stats = {"hit": 0, "miss": 0, "stale": 0, "launch": 0, "skipped": 0}   # (Python-side counts: a replayed graph adds none)
+        # the one launch runs on a stream of its own, beside the stem (whose weights have their own image kernel) and the first
+        # BatchNorm passes: the first convolution that takes a prepared image is ~0.6 ms into the forward.  A consumer's stream
+        # waits for the launch's event the first time it takes an image in a step.
+        self.side = None
+        self.event = None
+        self.joined = set()
+
+    def lookup(self, key, w_ref):
+        e = self.entries.get(key)
+        if e is not None and e["ver"] == w_ref._version and e["ver"] >= 0:
+            self.stats["hit"] += 1
+            st = torch.cuda.current_stream()
+            if st.cuda_stream not in self.joined:
+                st.wait_event(self.event)
+                self.joined.add(st.cuda_stream)
+            return e["ws"], e["wsc"]
+        self.stats["stale" if e is not None else "miss"] += 1
+        return None
+
+    def register(self, key, w_ref, Ko, Ci, T, mode, Cw, ws, wsc):
+        if key not in self.entries and not torch.cuda.is_current_stream_capturing():
+            rows = Ko if mode == 0 else Ci
+            # persistent buffers of the registry (the caller's ws / wsc are step-local temporaries)
+            # (a DETACHED alias: it shares storage and version counter with the parameter, and keeps no autograd node alive --
+            # holding the view the forward made, grad_fn and all, across steps crashed the end of a later step-graph capture)
+            self.entries[key] = dict(t=w_ref.detach(), Ko=Ko, Ci=Ci, T=T, mode=mode, Cw=Cw, rows=rows, ver=-1,
+                                     ws=torch.empty_like(ws), wsc=torch.empty_like(wsc))
+            self.order.append(key)
+
+    def _build(self, device):
+        import numpy as np
+        dt = np.dtype([("w", "<u8"), ("ws", "<u8"), ("sc", "<u8"), ("K", "<i4"), ("C", "<i4"), ("T", "<i4"), ("Cp", "<i4"), ("mode", "<i4"), ("row0", "<i4")])
+        assert dt.itemsize == 48
+        descs = np.zeros(len(self.order), dtype=dt)
+        blocks = []
+        row0 = 0
+        for i, k in enumerate(self.order):
+            e = self.entries[k]
+            descs[i] = (e["t"].data_ptr(), e["ws"].data_ptr(), e["wsc"].data_ptr(), e["Ko"], e["Ci"], e["T"], e["Cw"], e["mode"], row0)
+            blocks.append(np.full(e["rows"], i, dtype=np.int32))
+            row0 += e["rows"]
+        blocks = np.concatenate(blocks)
+        d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(device)
+        b_dev = torch.from_numpy(blocks).to(device)
+        self.table, self.table_len = (d_dev, b_dev, int(blocks.size)), len(self.order)
+
+    def prepare(self):
+        if not self.order:
+            return
+        import os
+        if os.environ.get("DLIP_WEIGHT_PREP", "1") == "0":   # A/B switch: every convolution splits its own weights, as until round 4
+            for k in self.order:
+                self.entries[k]["ver"] = -1
+            return
+        # (a moved / reallocated parameter would leave a dangling address in the table: such entries are dropped)
+        dead = [k for k in self.order if self.entries[k]["t"].data_ptr() != k[0]]
+        if dead and not torch.cuda.is_current_stream_capturing():
+            for k in dead:
+                del self.entries[k]
+            self.order = [k for k in self.order if k in self.entries]
+            self.table_len = -1
+            if not self.order:
+                return
+        if self.table_len != len(self.order):
+            if torch.cuda.is_current_stream_capturing():
+                self.stats["skipped"] += 1
+                return                                   # (no host-to-device copy inside a capture: this step splits per convolution)
+            self._build(self.entries[self.order[0]]["ws"].device)
+        d_dev, b_dev, n = self.table
+        cur = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=d_dev.device)
+        self.side.wait_stream(cur)                       # the previous step's last readers of the images are behind us
+        with torch.cuda.stream(self.side):
+            check(lib().dlip_split_weights_multi_f32(ptr(d_dev), ptr(b_dev), n, stream_handle()), "dlip_split_weights_multi_f32")
+            self.event = torch.cuda.Event()
+            self.event.record(self.side)
+        self.joined = set()
+        self.stats["launch"] += 1
+        for k in self.order[:self.table_len]:
+            e = self.entries[k]
+            e["ver"] = e["t"]._version
+
+
+WEIGHT_PREP = _WeightPrep()
+
+
+def prepare_weights():
+    """Start of a train-mode forward: all registered weight images of the step in one launch (see _WeightPrep)."""
+    if TRAIN_CONV == "f16x3":
+        WEIGHT_PREP.prepare()
+
+
 def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False, scale2=None, w_ref=None, transposed=False,
                xs_ready=None):
     """One convolution of a training step on NHWC fp32 ``x`` with CURRENT weights -> fp32 NHWC.  Weights: ``w_krsc`` [K,R,S,C]
@@ -143,10 +250,17 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
             w_krsc = (_permute3(w3, (1, 2, 0), flip_axis=2).view(Ci, R_, S_, Ko) if transposed else _permute3(w3, (0, 2, 1)).view(Ko, R_, S_, Ci))
             return ops.conv_nhwc(x, w_krsc, bias, stride=stride, pad=pad, dil=dil)
         dev = x.device
-        ws = torch.empty((K, R_, S_, Cw), device=dev, dtype=torch.float32)
-        wsc = torch.empty((K,), device=dev, dtype=torch.float32)
-        check(lib().dlip_split_weights_perm_f32(ptr(w_ref.contiguous()), ptr(ws), ptr(wsc), Ko, Ci, R_ * S_, 1 if transposed else 0, Cw,
-                                                stream_handle()), "dlip_split_weights_perm_f32")
+        key = (w_ref.data_ptr(), tuple(w_ref.shape), bool(transposed), Cw)
+        hit = WEIGHT_PREP.lookup(key, w_ref) if w_ref.is_contiguous() else None
+        if hit is not None:
+            ws, wsc = hit                                   # written by prepare_weights() at the start of this step
+        else:
+            ws = torch.empty((K, R_, S_, Cw), device=dev, dtype=torch.float32)
+            wsc = torch.empty((K,), device=dev, dtype=torch.float32)
+            check(lib().dlip_split_weights_perm_f32(ptr(w_ref.contiguous()), ptr(ws), ptr(wsc), Ko, Ci, R_ * S_, 1 if transposed else 0, Cw,
+                                                    stream_handle()), "dlip_split_weights_perm_f32")
+            if w_ref.is_contiguous():
+                WEIGHT_PREP.register(key, w_ref, Ko, Ci, R_ * S_, 1 if transposed else 0, Cw, ws, wsc)
     else:
         K = w_krsc.shape[0]
         if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or w_krsc.shape[3] != Cx:

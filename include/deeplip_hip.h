@@ -468,6 +468,17 @@ int dlip_split_weights_perm_f32(const float* w_kct, float* w_split, float* w_sca
 /* C_pad (0 = none): the rows' inner channel count (C in mode 0, K in mode 1) zero-padded to C_pad -- a first layer whose input has
  * 24 feature channels reads its activations padded to 32; the data gradient of a 1500-channel layer reads its gradient padded
  * to 1504 (tdnn.py:52-62 on conf/audio_config.yaml's input_dim / hidden_dim). */
+/* (round 4) dlip_split_weights_perm_f32 for MANY weight tensors in ONE launch -- a training step splits the current weights of every
+ * convolution twice (forward and data-gradient operand): `descs` is a DEVICE array of dlip_wsplit_desc (one per output tensor),
+ * `block_desc` a device int32[n_blocks] naming, for each output row of each tensor in order, its descriptor (row r of descriptor d is
+ * block d.row0 + r).  Same result per row as the single-tensor call (mode, C_pad as there). */
+typedef struct dlip_wsplit_desc {
+  const float* w;       /* [K, C, T] reference layout */
+  float* w_split;       /* mode 0: [K][T][C_pad]; mode 1: [C][T reversed][C_pad = K padded] */
+  float* w_scale;       /* one per output row */
+  int32_t K, C, T, C_pad, mode, row0;
+} dlip_wsplit_desc;
+int dlip_split_weights_multi_f32(const void* descs, const int32_t* block_desc, int32_t n_blocks, dlip_stream_t stream);
 /* y[0:n] = src[0] (device scalar broadcast: the per-channel 1/scale vector of the weight-gradient GEMM). */
 int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream_t stream);
 

@@ -468,3 +468,46 @@ def test_upsample_zero(N, Ho, Wo, Hu, Wu, C, sh, sw):
     hs, ws = min(Ho, (Hu + sh - 1) // sh), min(Wo, (Wu + sw - 1) // sw)
     ref[:, ::sh, ::sw][:, :hs, :ws] = dz[:, :hs, :ws]
     assert torch.equal(out.cpu(), ref)
+
+
+def test_prepared_weight_images_equal_the_per_convolution_ones_and_follow_the_weights():
+    """Round 4: after the first step registered them, `prepare_weights()` writes every (weight, bank) split image of the step in ONE
+    launch.  (1) Bit for bit the images dlip_split_weights_perm_f32 writes one by one (forward bank, data-gradient bank, padded
+    rows); (2) conv_train takes a prepared image only while the weight is unmodified: an in-place update in between falls back to
+    the per-convolution launch, so a stale image is never used."""
+    from deeplip_amd import autograd_video as av
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    av.WEIGHT_PREP.__init__()
+    ws_ = [(rnd(64, 32, 3, 3, seed=1) * 0.1).to(DEV), (rnd(96, 64, 1, 5, seed=2) * 0.1).to(DEV), (rnd(128, 64, 1, 1, seed=3) * 0.1).to(DEV)]
+    xs = [rnd(2, 6, 6, 32, seed=4).to(DEV), rnd(2, 1, 20, 64, seed=5).to(DEV), rnd(2, 1, 9, 64, seed=6).to(DEV)]
+    pads = [(1, 1), (0, 2), (0, 0)]
+
+    def run():
+        outs = []
+        for w, x, p in zip(ws_, xs, pads):
+            y = av.conv_train(x, None, None, (1, 1), p, (1, 1), w_ref=w)
+            g = av.conv_train(y, None, None, (1, 1), (w.shape[2] - 1 - p[0], w.shape[3] - 1 - p[1]), (1, 1), lift=True, w_ref=w, transposed=True)
+            outs += [y.clone(), g.clone()]
+        return outs
+
+    first = run()                                         # registers six images
+    assert len(av.WEIGHT_PREP.order) == 6
+    av.prepare_weights()
+    for k in av.WEIGHT_PREP.order:
+        e = av.WEIGHT_PREP.entries[k]
+        ws1, sc1 = torch.empty_like(e["ws"]), torch.empty_like(e["wsc"])
+        check(lib().dlip_split_weights_perm_f32(ptr(e["t"]), ptr(ws1), ptr(sc1), e["Ko"], e["Ci"], e["T"], e["mode"], e["Cw"], stream_handle()), "split")
+        torch.cuda.synchronize()
+        assert torch.equal(e["ws"].view(torch.int32), ws1.view(torch.int32)) and torch.equal(e["wsc"], sc1)
+    second = run()                                        # from the prepared images
+    for a, b in zip(first, second):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        ws_[0].mul_(2.0)                                  # an in-place update: the prepared image of weight 0 is stale now
+    third = run()
+    assert torch.allclose(third[0], 2.0 * first[0], rtol=1e-5, atol=1e-6) and torch.equal(third[2], first[2])
+    av.prepare_weights()
+    fourth = run()
+    for a, b in zip(third, fourth):
+        assert torch.equal(a, b)
+    av.WEIGHT_PREP.__init__()

@@ -88,3 +88,5 @@ if not a.eager:
     ms = (time.perf_counter() - t0) / n * 1e3
     print(f"the same step recorded once and replayed as one HIP graph (deeplip_amd.train_plan): {ms:.1f} ms/step = {a.batch / ms * 1e3:.1f} clips/s "
           f"(~{3 * fwd_gflop / ms:.1f} TFLOP/s at 3x forward FLOPs); loss {float(l.detach()):.4f}")
+from deeplip_amd import autograd_video as _av
+print("weight images:", len(_av.WEIGHT_PREP.order), "registered;", _av.WEIGHT_PREP.stats)
