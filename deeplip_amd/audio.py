@@ -201,7 +201,7 @@ class SpeakerEmbNet(nn.Module):
         # (24 features: the exact-fp32 kernel took 0.55 ms per launch on it, 1.1 of a 15 ms step at B = 256)
         h = self._to_ntc_padded(x)
         from . import autograd_video as av
-        av.prepare_weights()                               # the step's split weight images (forward and data-gradient banks): one launch
+        av.prepare_weights(self)                           # the step's split weight images (forward and data-gradient banks): one launch
         for blk in self.tdnn:
             h = ag.tdnn_block_train(h, blk)
         h = ag.meanstd_pool(h)

@@ -129,6 +129,12 @@ class _WeightPrep:
         self.event = None
         self.joined = set()
 
+    def __deepcopy__(self, memo):     # (a copied / pickled model starts with an empty registry: addresses, streams and events are this one's)
+        return _WeightPrep()
+
+    def __reduce__(self):
+        return (_WeightPrep, ())
+
     def lookup(self, key, w_ref):
         e = self.entries.get(key)
         if e is not None and e["ver"] == w_ref._version and e["ver"] >= 0:
@@ -206,11 +212,20 @@ class _WeightPrep:
             e["ver"] = e["t"]._version
 
 
-WEIGHT_PREP = _WeightPrep()
+WEIGHT_PREP = _WeightPrep()     # the registry in use: the one of the model whose train-mode forward ran last (or this anonymous one)
 
 
-def prepare_weights():
-    """Start of a train-mode forward: all registered weight images of the step in one launch (see _WeightPrep)."""
+def prepare_weights(owner=None):
+    """Start of a train-mode forward: all registered weight images of the step in one launch (see _WeightPrep).  ``owner`` (the
+    model): its registry -- images, descriptor table, side stream -- lives on the model object and goes with it; what the step's
+    convolutions register and take is the registry of the forward that ran last."""
+    global WEIGHT_PREP
+    if owner is not None:
+        reg = owner.__dict__.get("_dlip_weight_prep")
+        if reg is None:
+            reg = _WeightPrep()
+            owner.__dict__["_dlip_weight_prep"] = reg
+        WEIGHT_PREP = reg
     if TRAIN_CONV == "f16x3":
         WEIGHT_PREP.prepare()
 

@@ -489,7 +489,7 @@ class Lipreading(nn.Module):
         if C != 1:
             raise ValueError("Lipreading expects grayscale clips [B,1,T,H,W] (model.py:82)")
         stem, bn, act = self.frontend3D[0], self.frontend3D[1], self.frontend3D[2]
-        av.prepare_weights()                               # the step's split weight images (forward and data-gradient banks): one launch
+        av.prepare_weights(self)                           # the step's split weight images (forward and data-gradient banks): one launch
         y = av.stem_conv(x.contiguous().float().view(B, T, H, W), stem.weight)       # [(B T),H/2,W/2,64]
         y = av.maxpool(av.batchnorm_prelu(y, bn, act))
         for blk in self.trunk.blocks():
