@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 42
+ABI_VERSION = 43
 LIFT_WORDS = 4098
 LIFT_BCAST = 2048
 
@@ -43,8 +43,8 @@ SIGNATURES = {
     "dlip_conv2_nhwc_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                               c_i32, c_stream],
     "dlip_conv_pool_partial_bytes": [C.POINTER(ConvDesc), C.POINTER(C.c_int32)],
-    "dlip_conv_pool_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_stream],
-    "dlip_pool_finish_f32": [c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_stream],
+    "dlip_conv_pool_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_f, c_i32, c_i32, c_stream],
+    "dlip_pool_finish_f32": [c_f, c_i64, c_i32, c_i32, c_i32, c_f, c_i32, c_i32, c_i32, c_i32, c_f, c_stream],
     "dlip_set_status_words": [c_f],
     "dlip_span_scope_begin": [c_f, c_f, c_i32],
     "dlip_span_scope_end": [c_stream, C.POINTER(C.c_int32)],
@@ -99,23 +99,24 @@ SIGNATURES = {
     "dlip_plan_destroy": [C.c_void_p],
     "dlip_stem3d_bn_act_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem3d_bn_act_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
-    "dlip_stem3d_pool_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
-    "dlip_stem3d_pool_u8_f16x3": [c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_stem3d_pool_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_stem3d_pool_u8_f16x3": [c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_stem3d_pool_workspace_bytes": [c_i32, c_i32, c_i32, c_i32],
     "dlip_selftest_lds_oob": [c_f, c_i32, c_stream],
     "dlip_maxpool3x3s2_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_avgpool_nhwc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
-    "dlip_time_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_time_mean_f32": [c_f, c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_group_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
-    "dlip_meanstd_pool_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
-    "dlip_attentive_stat_pool_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_mask_frames_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_stream],
+    "dlip_meanstd_pool_f32": [c_f, c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_attentive_stat_pool_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_nct_to_ntc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_ntc_to_nct_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_nct_to_ntc_split_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_ingest_rgb_u8": [c_f, c_f, c_i64, c_i32, c_i32, c_stream],
     "dlip_affine_act_f32": [c_f, c_f, c_f, c_f, c_i64, c_i32, C.c_float, c_i32, c_stream],
     "dlip_znorm_cat_f32": [c_f, c_i32, c_f, c_i32, c_f, c_i32, c_i32, c_stream],
-    "dlip_znorm_cat_pooled_f32": [c_f, c_i32, c_f, c_i64, c_i32, c_i32, c_i32, c_f, c_i32, c_i32, c_stream],
+    "dlip_znorm_cat_pooled_f32": [c_f, c_i32, c_f, c_i64, c_i32, c_i32, c_i32, c_f, c_i32, c_i32, c_f, c_i32, c_i32, c_stream],
     "dlip_l2_normalize_f32": [c_f, c_f, c_i32, c_i32, C.c_float, c_stream],
     "dlip_pair_cosine_f32": [c_f, c_i32, c_i32, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_i32, c_stream],
     "dlip_plda_llr_f32": [c_f, c_i32, c_i32, c_f, c_f, c_f, c_f, c_i32, c_stream],

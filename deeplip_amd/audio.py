@@ -50,15 +50,15 @@ class AttentiveStatPooling(nn.Module):
         for p in self.parameters():
             nn.init.xavier_normal_(p)
 
-    def run_ntc(self, x_ntc: Tensor) -> Tensor:
-        """x [B,T,C] -> [B,2C]."""
+    def run_ntc(self, x_ntc: Tensor, lengths: Optional[Tensor] = None, len_add: int = 0) -> Tensor:
+        """x [B,T,C] -> [B,2C]; ``lengths`` (int32 CUDA [B]): attention and statistics over the first lengths[b] + len_add frames."""
         from ._lib import check, lib, ptr, stream_handle
         B, T, C_ = x_ntc.shape
         hidden = ops.linear(x_ntc.reshape(B * T, C_), self.W.detach().contiguous(), self.b.detach().reshape(-1).contiguous())
         y = ops._empty((B, 2 * C_), x_ntc.device)
         check(lib().dlip_attentive_stat_pool_f32(ptr(x_ntc), ptr(hidden), ptr(self.v.detach().contiguous()),
-                                                 ptr(self.k.detach().contiguous()), ptr(y), B, T, C_, self.hidden_size,
-                                                 stream_handle()), "dlip_attentive_stat_pool_f32")
+                                                 ptr(self.k.detach().contiguous()), ptr(lengths), len_add, ptr(y), B, T, C_,
+                                                 self.hidden_size, stream_handle()), "dlip_attentive_stat_pool_f32")
         return y
 
     def forward(self, x):
@@ -101,9 +101,10 @@ class TDNN_Block(nn.Module):
                               post_scale=p.post_scale, post_shift=p.post_shift, w_scale=p.wscale,
                               x_split=x_split, out_split=out_split)
 
-    def run_pooled(self, x: Tensor, p: packing.Packed):
+    def run_pooled(self, x: Tensor, p: packing.Packed, lengths: Optional[Tensor] = None, len_add: int = 0):
         """x [B,T,C] split format -> ops.Pooled column sums of the layer's output over each utterance's T' frames (the
-        input of statistics pooling), or None when T' is shorter than the workgroup tile the launch would use."""
+        input of statistics pooling), or None when T' is shorter than the workgroup tile the launch would use.  ``lengths``
+        (int32 CUDA [B]): ragged batch -- only the first lengths[b] + len_add output frames of utterance b are pooled."""
         B, T, Cx = x.shape
         Tp = ops.conv_out_size(T, self.kernel_size, 1, self.padding, self.dilation)
         xv = x.view(B, 1, T, Cx)
@@ -111,7 +112,8 @@ class TDNN_Block(nn.Module):
         kw = dict(pad=(0, self.padding), dil=(1, self.dilation))
         if Tp < ops.conv_pool_tile_rows(xv, wv, **kw):
             return None
-        return ops.conv_pool(xv, wv, p.b, p.wscale, Tp, slope=p.slope, post_scale=p.post_scale, post_shift=p.post_shift, **kw)
+        return ops.conv_pool(xv, wv, p.b, p.wscale, Tp, slope=p.slope, post_scale=p.post_scale, post_shift=p.post_shift,
+                             lengths=lengths, len_add=len_add, **kw)
 
     def forward(self, x: Tensor) -> Tensor:
         """[B,C,T] -> [B,K,T'] (reference layout, standalone use)."""
@@ -210,13 +212,28 @@ class SpeakerEmbNet(nn.Module):
         xv = ag.linear(h, self.fc2.weight, self.fc2.bias)
         return xv, x_a
 
+    def frames_consumed(self) -> int:
+        """Frames the stack's valid convolutions take off an utterance: T' = T - frames_consumed() (22 for the E-TDNN)."""
+        return sum(b.dilation * (b.kernel_size - 1) - 2 * b.padding for b in self.tdnn)
+
     @_lib.scoped_eval
-    def extract_embedding(self, x: Tensor, taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
-        """[B,F,T] -> (xv [B,E] = fc2 output, x_a [B,E] = fc1 output)   (tdnn.py:89-101)."""
+    def extract_embedding(self, x: Tensor, lengths=None, taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+        """[B,F,T] -> (xv [B,E] = fc2 output, x_a [B,E] = fc1 output)   (tdnn.py:89-101).
+
+        ``lengths`` (list / int32 tensor [B]; build-owned): a RAGGED batch -- x is zero-padded to the longest utterance and
+        utterance b has lengths[b] frames.  Row b then equals ``extract_embedding(x[b:b+1, :, :lengths[b]])``, the reference's
+        one-utterance-at-a-time test loop (train_fusion.py:334-338, train_audio.py:343-373): the convolutions are valid ones, so
+        an output frame t < lengths[b] - frames_consumed() never reads the padding, and the statistics pooling covers exactly
+        those frames.  A device tensor is read by the kernels directly (a recorded plan replays with new lengths)."""
         if self.training:
+            if lengths is not None:
+                raise NotImplementedError("train mode crops every utterance of a batch to one length (datasets.py:112-115)")
             return self._extract_embedding_train(x)
         _lib.check_range()      # an overflow reported by an earlier f16x3 launch surfaces here (host read, no sync)
         p = _cached_pack(self, x.device, self._pack)
+        shrink = self.frames_consumed()
+        lens = ops.lengths_i32(lengths, x.device, n=x.shape[0], lo=shrink + 2, hi=x.shape[-1])   # >= 2 pooled frames (unbiased std)
+        len_add = -shrink
         # f16x3 packing: frame-level activations travel between layers as (hi, lo) fp16 pairs, written
         # by the producing layer's epilogue; the last layer hands fp32 to the pooling kernel, which
         # writes the utterance statistics in that format again for fc1.
@@ -228,7 +245,7 @@ class SpeakerEmbNet(nn.Module):
             nxt = bp.wscale is not None and i + 1 < n and blk.output_dim % 32 == 0
             if (i + 1 == n and split and FUSE_POOL and taps is None and self.pooling_type == "statistic"
                     and blk.output_dim % 4 == 0):
-                pooled = blk.run_pooled(h, bp)       # None when an utterance is shorter than a workgroup tile
+                pooled = blk.run_pooled(h, bp, lens, len_add)       # None when an utterance is shorter than a workgroup tile
                 if pooled is not None:
                     break
             h = blk.run_ntc(h, bp, x_split=split, out_split=nxt)
@@ -241,11 +258,11 @@ class SpeakerEmbNet(nn.Module):
             h = ops.pool_finish(pooled, "meanstd", out_split=True)
         elif self.pooling_type == "statistic":
             pooled_split = f16x3 and h.shape[2] % 4 == 0
-            h = ops.meanstd_pool(h, out_split=pooled_split)
+            h = ops.meanstd_pool(h, out_split=pooled_split, lengths=lens, len_add=len_add)
         elif self.pooling_type == "average":
-            h = ops.time_mean(h)
+            h = ops.time_mean(h, lens, len_add)
         else:
-            h = self.pooling.run_ntc(h)
+            h = self.pooling.run_ntc(h, lens, len_add)
         if taps is not None:
             taps["pooled"] = ops.split_unpack(h)[:, :self.fc1.in_features].contiguous() if pooled_split else h
         x_a = ops.linear(h, p["fc1"].w, p["fc1"].b, w_scale=p["fc1"].wscale, x_split=pooled_split)

@@ -96,9 +96,12 @@ class SpeakerEmbNet(nn.Module):
             h = _basic_block_train(b, h)
         return ag.linear(av.avgpool(h), self.fc.weight, self.fc.bias)
 
-    def extract_embedding(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+    def extract_embedding(self, x: Tensor, lengths=None) -> Tuple[Tensor, Tensor]:
         """[B,1,F,T] (or [B,F,T]) -> (embedding [B,E], the same tensor): the TDNN encoder's (xv, x_a) interface with
         a single fully connected layer."""
+        if lengths is not None:
+            raise NotImplementedError("the resnet speech encoder's padded convolutions read across an utterance's end: ragged "
+                                      "batches (lengths) exist for the TDNN / E-TDNN encoders only")
         if self.training:
             e = self._embed_train(x)
             return e, e

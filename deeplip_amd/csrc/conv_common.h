@@ -57,6 +57,7 @@ struct ConvArgs {
   // pooled epilogue (dlip_conv_pool_f16x3): per tile row band and row-group segment, column sums of y and y^2
   double* pool;
   int pool_group;       // rows per group (>= the tile's BM)
+  DlipLen pool_len;     // ragged batches: valid rows of each group, counted from the group's first row (len == NULL: all)
   DlipRange status;     // range reporting of a split-format output (dlip_common.h)
   FastDiv div_howo, div_wo;
   int n_inner;          // LDS-DMA kernel: tile order with the output-channel block inner
@@ -116,7 +117,7 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
   a.wscale = nullptr;
   a.Cw = Cw;
   a.x2 = nullptr; a.x2_bytes = 0; a.H2 = a.W2 = a.ldx2 = a.s2h = a.s2w = a.nk2 = 0;
-  a.pool = nullptr; a.pool_group = 0;
+  a.pool = nullptr; a.pool_group = 0; a.pool_len = DlipLen{};
   a.status = DlipRange{};
   a.div_howo = dlip_fastdiv((uint32_t)a.HoWo);
   a.div_wo = dlip_fastdiv((uint32_t)a.Wo);

@@ -470,7 +470,7 @@ extern "C" int64_t dlip_conv_pool_partial_bytes(const dlip_conv_desc* d, int32_t
 extern "C" int dlip_conv_pool_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, const float* w_scale,
                                     const float* bias, const float* residual, const float* slope, const float* post_scale,
                                     const float* post_shift, double* partials, int64_t partial_bytes, int32_t group_rows,
-                                    dlip_stream_t stream) {
+                                    const int32_t* group_len, int32_t len_mul, int32_t len_add, dlip_stream_t stream) {
   DLIP_CHECK_ARG(d && partials && group_rows > 0 && (reinterpret_cast<uintptr_t>(partials) & 7) == 0);
   ConvArgs a;
   dlip_conv_desc dd = *d;
@@ -485,6 +485,7 @@ extern "C" int dlip_conv_pool_f16x3(const dlip_conv_desc* d, const float* x, con
   a.y = nullptr; a.y_bytes = 0;
   a.pool = partials;
   a.pool_group = group_rows;
+  a.pool_len.len = group_len; a.pool_len.mul = len_mul; a.pool_len.add = len_add;
   if (residual == nullptr && dlip_conv_rows_pool_plan(d, nullptr) && dlip_conv_rows_ok(&a)) return dlip_conv_f16x3_rows_launch(&a, stream, 2);
   return dlip_conv_f16x3_dma_launch(&a, stream, 2);
 }

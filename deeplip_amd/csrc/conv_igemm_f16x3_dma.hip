@@ -747,7 +747,16 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
           static_assert(NT % CPR == 0 && BM % NG == 0 && 4 * NG * BN * 8 <= RING, "pooled epilogue layout");
           const int cqd = tid_e % CPR, rg = tid_e / CPR;
           const int m0 = tile_m * BM;
-          const int rb = (m0 / a.pool_group + 1) * a.pool_group - m0;   // first tile row of the next group
+          const int g0 = m0 / a.pool_group;
+          const int rb = (g0 + 1) * a.pool_group - m0;   // first tile row of the next group
+          // ragged batches (a.pool_len): a group's rows past its valid length are padding and stay out of both sums; e0 / e1 = the
+          // tile-relative ends of the valid rows of segment 0 (group g0) and segment 1 (group g0 + 1)
+          int e0 = rb, e1 = BM;
+          if (a.pool_len.len != nullptr) {
+            const int G = (a.M + a.pool_group - 1) / a.pool_group;
+            e0 = min(rb, g0 * a.pool_group + dlip_valid_rows(a.pool_len, g0, a.pool_group) - m0);
+            e1 = g0 + 1 < G ? rb + dlip_valid_rows(a.pool_len, g0 + 1, a.pool_group) : rb;
+          }
           double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
           for (int i = 0; i < RPG; ++i) {
             const int r = rg * RPG + i;
@@ -755,9 +764,11 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
             const int pc = (cqd & ~15) | ((cqd ^ r) & 15);
             const f32x4 v = *reinterpret_cast<const f32x4*>(img + r * PITCH + pc * 16);
             if (r < rb) {
+              if (r < e0) {
 #pragma unroll
-              for (int c = 0; c < 4; ++c) { const double d = (double)v[c]; s0[c] += d; q0[c] += d * d; }
-            } else {
+                for (int c = 0; c < 4; ++c) { const double d = (double)v[c]; s0[c] += d; q0[c] += d * d; }
+              }
+            } else if (r < e1) {
 #pragma unroll
               for (int c = 0; c < 4; ++c) { const double d = (double)v[c]; s1[c] += d; q1[c] += d * d; }
             }

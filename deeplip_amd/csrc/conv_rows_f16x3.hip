@@ -412,7 +412,14 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       // channel quad meet by butterfly, lane 0 of each quad stores.  Rows before the half tile's one possible group boundary
       // are segment 0, the rest segment 1 (pool_group >= 16 MI); dlip_pool_finish_f32 / znorm_cat_pooled add the tiles in row order.
       const int m0 = tile_m * BM + wm * WM;
-      const int rb = (m0 / a.pool_group + 1) * a.pool_group - m0;
+      const int g0 = m0 / a.pool_group;
+      const int rb = (g0 + 1) * a.pool_group - m0;
+      int e0 = rb, e1 = WM;                           // ragged batches: tile-relative ends of the valid rows of the two segments
+      if (a.pool_len.len != nullptr) {
+        const int G = (eM + a.pool_group - 1) / a.pool_group;
+        e0 = min(rb, g0 * a.pool_group + dlip_valid_rows(a.pool_len, g0, a.pool_group) - m0);
+        e1 = g0 + 1 < G ? rb + dlip_valid_rows(a.pool_len, g0 + 1, a.pool_group) : rb;
+      }
       const int Kp = (eK + 127) / 128 * 128;
       double* prow = a.pool + (size_t)(2 * tile_m + wm) * 4 * Kp;
 #pragma unroll
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const int r = mi * 16 + lrow;
-          const bool in = m0 + r < eM, seg1 = r >= rb;
+          const bool seg1 = r >= rb, in = m0 + r < eM && r < (seg1 ? e1 : e0);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             float t = acc[mi][ni][c] * inv4[c] + b4[c];

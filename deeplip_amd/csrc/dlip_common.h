@@ -110,6 +110,20 @@ __device__ __forceinline__ float dlip_pixel_norm(float gray_0_255) {
   return (gray_0_255 / 255.0f - 0.421f) / 0.165f;
 }
 
+// Ragged batches (zero-padded [B, Tmax, ...] + a length vector, as models/video_models/dataset.py:123-139 collates them): how many of
+// group g's `cap` rows are valid = clamp(len[g] * mul + add, 0, cap); len == NULL: all of them.  `mul` / `add` turn the caller's unit
+// (frames of the INPUT clip / utterance) into rows of the pooled tensor: lip clips mul = Ho Wo of the last convolution, utterances
+// add = -(frames the valid convolutions consume).
+struct DlipLen {
+  const int32_t* len = nullptr;
+  int32_t mul = 1, add = 0;
+};
+__device__ __forceinline__ int dlip_valid_rows(const DlipLen l, long long g, int cap) {
+  if (l.len == nullptr) return cap;
+  const long long v = (long long)l.len[g] * l.mul + l.add;
+  return v < 0 ? 0 : (v > cap ? cap : (int)v);
+}
+
 // Launch-side state that HIP keeps PER DEVICE: the MaxDynamicSharedMemorySize attribute of a kernel and how many of its
 // workgroups the device holds at once.  One instance per kernel instantiation (a function-local static); a process that
 // drives several GPUs (one thread per device, or hipSetDevice in a loop) gets the attribute set and the grid sized on each.

@@ -185,3 +185,29 @@ extern "C" int dlip_split_unpack_f32(const float* x, float* y, int64_t rows, int
                      reinterpret_cast<f32x4*>(y), n4);
   return dlip_launch_status();
 }
+
+namespace {
+// y[b, t, :] = t < len[b] ? x[b, t, :] : 0 -- the padding frames of a ragged batch made zeros of the normalised clip (what
+// pad_packed_collate puts there, models/video_models/dataset.py:123-139) on the paths that have no pre-pass to do it in
+// (exact-fp32 packing, taps).  E % 4 == 0; one float4 per thread.
+__global__ __launch_bounds__(256) void mask_frames_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, const int32_t* __restrict__ len,
+                                                          int T, int E4, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long f = i / E4;
+    const int b = (int)(f / T), t = (int)(f - (long long)b * T);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t < len[b]) v = x[i];
+    y[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int dlip_mask_frames_f32(const float* x, const int32_t* len, float* y, int32_t B, int32_t T, int32_t E, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && len && y && B > 0 && T > 0 && E > 0 && (E & 3) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+  const long long n4 = (long long)B * T * (E / 4);
+  long long g = (n4 + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(mask_frames_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), len, T, E / 4, n4);
+  return dlip_launch_status();
+}

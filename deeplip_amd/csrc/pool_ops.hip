@@ -62,14 +62,13 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void time_mean_kernel(const float* __restrict__ x, const int32_t* __restrict__ len,
+__global__ __launch_bounds__(256) void time_mean_kernel(const float* __restrict__ x, const DlipLen len,
                                                         float* __restrict__ y, int B, int T, int C, int ldx) {
   const long long total = (long long)B * C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const int b = (int)(i / C);
-    int L = len ? len[b] : T;
-    L = L < 0 ? 0 : (L > T ? T : L);
+    const int L = dlip_valid_rows(len, b, T);
     const float* p = x + (long long)b * T * ldx + c;
     double s = 0.0;
     for (int t = 0; t < L; ++t) s += (double)p[(long long)t * ldx];
@@ -96,17 +95,20 @@ __global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict
 // in fp64 (the inputs are fp32, so sum x^2 - (sum x)^2 / T loses nothing a two-pass fp32 result has)
 // and the 16 partial rows meet in LDS.  SPLIT writes the [B, ldy] result as (hi, lo) fp16 pairs (the
 // split activation format; ldy = 2C rounded up to 32, padding zeroed) for the LDS-DMA GEMM behind it.
+// `len` (ragged batches: utterance b is valid for its first len[b] + len_add of the T frames, the rest is padding): the
+// statistics cover the valid frames only, as the reference's one-utterance-at-a-time loop computes them (train_fusion.py:334-338).
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      int T, int C, int ldy, DlipRange status) {
+                                                      int Tpad, int C, int ldy, const DlipLen len, DlipRange status) {
   __shared__ double part[16][64][2];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int T = dlip_valid_rows(len, b, Tpad);
   const int lx = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int c = c0 + lx * 4;
   float amax = 0.f;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (c < C) {   // C % 4 == 0: a float4 is all inside or all outside
-    const float* p = x + (long long)b * T * C + c;
+    const float* p = x + (long long)b * Tpad * C + c;
     for (int t = g; t < T; t += 16) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(p + (long long)t * C);
 #pragma unroll
@@ -181,11 +183,12 @@ extern "C" int dlip_avgpool_nhwc_f32(const float* x, float* y, int32_t N, int32_
   return dlip_launch_status();
 }
 
-extern "C" int dlip_time_mean_f32(const float* x, const int32_t* len, float* y, int32_t B, int32_t T, int32_t C,
+extern "C" int dlip_time_mean_f32(const float* x, const int32_t* len, int32_t len_add, float* y, int32_t B, int32_t T, int32_t C,
                                   int32_t ldx, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && y && B > 0 && T > 0 && C > 0 && ldx >= C);
+  DlipLen l; l.len = len; l.mul = 1; l.add = len_add;
   hipLaunchKernelGGL(time_mean_kernel, dim3(grid_for((long long)B * C)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, len, y, B, T, C, ldx);
+                     static_cast<hipStream_t>(stream), x, l, y, B, T, C, ldx);
   return dlip_launch_status();
 }
 
@@ -197,16 +200,17 @@ extern "C" int dlip_group_mean_f32(const float* x, const int32_t* group_ptr, flo
   return dlip_launch_status();
 }
 
-extern "C" int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
+extern "C" int dlip_meanstd_pool_f32(const float* x, const int32_t* len, int32_t len_add, float* y, int32_t B, int32_t T, int32_t C,
                                      int32_t out_split, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && y && B > 0 && B <= 65535 && T > 0 && C > 0 && (C & 3) == 0);
   DLIP_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   const dim3 grid((C + 63) / 64, B);
+  DlipLen l; l.len = len; l.mul = 1; l.add = len_add;
   if (out_split)
     hipLaunchKernelGGL(meanstd_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C,
-                       (2 * C + 31) / 32 * 32, dlip_range_for(DLIP_ST_POOL));
+                       (2 * C + 31) / 32 * 32, l, dlip_range_for(DLIP_ST_POOL));
   else
-    hipLaunchKernelGGL(meanstd_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C, 2 * C,
+    hipLaunchKernelGGL(meanstd_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C, 2 * C, l,
                        DlipRange{});
   return dlip_launch_status();
 }
@@ -220,12 +224,13 @@ namespace {
 // phase 3 one thread per channel (coalesced) with fp64 accumulation.
 __global__ __launch_bounds__(256) void attentive_stat_kernel(const float* __restrict__ x, const float* __restrict__ hidden,
                                                              const float* __restrict__ v, const float* __restrict__ kk,
-                                                             float* __restrict__ y, int T, int C, int Hd) {
+                                                             float* __restrict__ y, int Tpad, int C, int Hd, const DlipLen len) {
   extern __shared__ float alpha[];   // [T]
   __shared__ float red[2];
   const int b = blockIdx.x;
+  const int T = dlip_valid_rows(len, b, Tpad);          // ragged batches: attention and statistics over the valid frames only
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* hb = hidden + (long long)b * T * Hd;
+  const float* hb = hidden + (long long)b * Tpad * Hd;
   for (int t = wave; t < T; t += 4) {
     double s = 0.0;
     for (int h = lane; h < Hd; h += 64) s += (double)fmaxf(hb[(long long)t * Hd + h], 0.f) * (double)v[h];
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) void attentive_stat_kernel(const float* __rest
   const double se = red[1];
   for (int t = threadIdx.x; t < T; t += 256) alpha[t] = (float)(exp((double)(alpha[t] - mx)) / se);
   __syncthreads();
-  const float* xb = x + (long long)b * T * C;
+  const float* xb = x + (long long)b * Tpad * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     double m = 0.0, q = 0.0;
     for (int t = 0; t < T; ++t) {
@@ -261,11 +266,12 @@ __global__ __launch_bounds__(256) void attentive_stat_kernel(const float* __rest
 }  // namespace
 
 extern "C" int dlip_attentive_stat_pool_f32(const float* x, const float* hidden, const float* v, const float* k,
-                                            float* y, int32_t B, int32_t T, int32_t C, int32_t Hd,
-                                            dlip_stream_t stream) {
+                                            const int32_t* len, int32_t len_add, float* y, int32_t B, int32_t T, int32_t C,
+                                            int32_t Hd, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && hidden && v && k && y && B > 0 && T > 0 && C > 0 && Hd > 0 && T <= 16000);
+  DlipLen l; l.len = len; l.mul = 1; l.add = len_add;
   hipLaunchKernelGGL(attentive_stat_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float),
-                     static_cast<hipStream_t>(stream), x, hidden, v, k, y, T, C, Hd);
+                     static_cast<hipStream_t>(stream), x, hidden, v, k, y, T, C, Hd, l);
   return dlip_launch_status();
 }
 
@@ -276,7 +282,8 @@ namespace {
 // segment 0 if the tile's first row belongs to g, else segment 1.  Tiles are added in row order.
 template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(256) void pool_finish_kernel(const double* __restrict__ part, float* __restrict__ y, long long M,
-                                                          int K, int Kp, int BM, int Gs, int G, int ldy, DlipRange status) {
+                                                          int K, int Kp, int BM, int Gs, int G, int ldy, const DlipLen len,
+                                                          DlipRange status) {
   const long long total = (long long)G * K;
   float amax = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const double* __restri
       s += p[0];
       q += p[Kp];
     }
-    const double n = (double)(r1 - r0);
+    const double n = (double)dlip_valid_rows(len, g, (int)(r1 - r0));   // ragged: the epilogue summed the group's valid rows only
     const double mean = s / n;
     if (MODE == 0) {
       y[g * ldy + k] = (float)mean;
@@ -330,6 +337,7 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const double* __restri
 }  // namespace
 
 extern "C" int dlip_pool_finish_f32(const double* partials, int64_t M, int32_t K, int32_t tile_rows, int32_t group_rows,
+                                    const int32_t* group_len, int32_t len_mul, int32_t len_add,
                                     int32_t mode, int32_t out_split, float* y, dlip_stream_t stream) {
   DLIP_CHECK_ARG(partials && y && M > 0 && K > 0 && tile_rows > 0 && group_rows >= tile_rows && (mode == 0 || mode == 1));
   DLIP_CHECK_ARG(!(out_split && mode == 0));
@@ -339,14 +347,15 @@ extern "C" int dlip_pool_finish_f32(const double* partials, int64_t M, int32_t K
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned grid = grid_for(G * K);
   const DlipRange status = (mode == 1 && out_split) ? dlip_range_for(DLIP_ST_POOL) : DlipRange{};   // only a split output is a producer
+  DlipLen l; l.len = group_len; l.mul = len_mul; l.add = len_add;
   if (mode == 0)
     hipLaunchKernelGGL((pool_finish_kernel<0, false>), dim3(grid), dim3(256), 0, st, partials, y, (long long)M, K, Kp, tile_rows,
-                       group_rows, (int)G, K, status);
+                       group_rows, (int)G, K, l, status);
   else if (out_split)
     hipLaunchKernelGGL((pool_finish_kernel<1, true>), dim3(grid), dim3(256), 0, st, partials, y, (long long)M, K, Kp, tile_rows,
-                       group_rows, (int)G, (2 * K + 31) / 32 * 32, status);
+                       group_rows, (int)G, (2 * K + 31) / 32 * 32, l, status);
   else
     hipLaunchKernelGGL((pool_finish_kernel<1, false>), dim3(grid), dim3(256), 0, st, partials, y, (long long)M, K, Kp, tile_rows,
-                       group_rows, (int)G, 2 * K, status);
+                       group_rows, (int)G, 2 * K, l, status);
   return dlip_launch_status();
 }

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void znorm_cat_kernel(const float* __restrict_
 // rounded to fp32 once), into its own slice of the output row, then z-normalises that slice in place.
 __global__ __launch_bounds__(256) void znorm_cat_pooled_kernel(const float* __restrict__ a, int Da,
                                                                const double* __restrict__ part, long long M, int K, int Kp,
-                                                               int BM, int Gs, float* __restrict__ y, int U, int biased) {
+                                                               int BM, int Gs, const DlipLen len, float* __restrict__ y, int U,
+                                                               int biased) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= U) return;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void znorm_cat_pooled_kernel(const float* __re
   const long long r0 = (long long)row * Gs;
   long long r1 = r0 + Gs;
   if (r1 > M) r1 = M;
-  const double n = (double)(r1 - r0);
+  const double n = (double)dlip_valid_rows(len, row, (int)(r1 - r0));   // ragged batches: the clip's valid rows (pool_finish's count)
   for (int i = lane; i < K; i += 64) {
     double s = 0.0;
     for (long long tm = r0 / BM; tm <= (r1 - 1) / BM; ++tm) {
@@ -248,13 +249,14 @@ extern "C" int dlip_znorm_cat_f32(const float* a, int32_t Da, const float* v, in
 }
 
 extern "C" int dlip_znorm_cat_pooled_f32(const float* a, int32_t Da, const double* partials, int64_t M, int32_t K,
-                                         int32_t tile_rows, int32_t group_rows, float* y, int32_t U, int32_t biased,
-                                         dlip_stream_t stream) {
+                                         int32_t tile_rows, int32_t group_rows, const int32_t* group_len, int32_t len_mul,
+                                         int32_t len_add, float* y, int32_t U, int32_t biased, dlip_stream_t stream) {
   DLIP_CHECK_ARG(y && partials && U > 0 && Da >= 0 && K > 0 && M > 0 && tile_rows > 0 && group_rows >= tile_rows);
   DLIP_CHECK_ARG((Da == 0 || a) && (M + group_rows - 1) / group_rows == U);
+  DlipLen l; l.len = group_len; l.mul = len_mul; l.add = len_add;
   hipLaunchKernelGGL(znorm_cat_pooled_kernel, dim3((U + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a, Da, partials, (long long)M, K, (K + 127) / 128 * 128, tile_rows,
-                     group_rows, y, U, biased);
+                     group_rows, l, y, U, biased);
   return dlip_launch_status();
 }
 

@@ -330,10 +330,17 @@ __device__ __forceinline__ float dpp_from_right(float v, float edge) {   // lane
 //          gray (dataloaders.py:11-22, preprocess.py:32-46): the fp32 clip (4 B per pixel written by an ingest kernel and
 //          read back by this pre-pass, 4 B per pixel over PCIe) never exists.  Same arithmetic, same order as
 //          ingest_rgb_kernel / crop_norm_kernel (dlip_common.h): bit-identical to ingest -> fp32 -> SRC 0.
+//   lengths (ragged batches; NULL = every clip has T frames): frame t >= lengths[b] of clip b is PADDING and is written as zeros --
+//          what pad_packed_collate puts there (models/video_models/dataset.py:123-139) and, for the frames t < lengths[b], exactly the
+//          Conv3d's own zero padding behind the clip's last frame: their stem outputs equal the clip run alone at its own length
+//          (train_fusion.py:346-348).  For uint8 frames the padding must be made HERE: a zero BYTE is not a zero of the normalised clip.
+//   clip_params (SRC 1; NULL = one centre crop for the batch): int32 [B][4] = (oy, ox, flip, 0) per clip -- RandomCrop's origin and
+//          HorizontalFlip's coin (models/video_models/preprocess.py:95-138, dataloaders.py:13-17: one draw per CLIP, all its frames alike).
 template <int SRC>
 __global__ __launch_bounds__(256) void stem_split_input_kernel(const void* __restrict__ xin, uint32_t* __restrict__ xs, int rows, int H, int W,
-                                                               int pwp, int CH, int Hs, int Ws, int oy, int ox, DlipRange status,
-                                                               unsigned long long* span) {
+                                                               int pwp, int CH, int Hs, int Ws, int oy, int ox, int T,
+                                                               const int32_t* __restrict__ lengths, const int32_t* __restrict__ clip_params,
+                                                               DlipRange status, unsigned long long* span) {
   // (measurement only, one scalar test when no span scope is open: the stem's span starts with its pre-pass and ends with the pool kernel)
   if (span != nullptr && threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicMin(span, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int cpr = pwp >> 2;                            // 16-B chunks per row
@@ -341,7 +348,16 @@ __global__ __launch_bounds__(256) void stem_split_input_kernel(const void* __res
   float amax = 0.f;
   for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < total; c += (long long)gridDim.x * 256) {
     const int row = (int)(c / cpr), ch = (int)(c - (long long)row * cpr);
-    u32x4 o;
+    u32x4 o = {0u, 0u, 0u, 0u};
+    int f = 0, h = 0, b = 0;
+    if (SRC == 1 || lengths != nullptr) {
+      f = row / H; h = row - f * H;
+      b = f / T;
+      if (lengths != nullptr && f - b * T >= lengths[b]) {   // a padding frame: zeros of the normalised clip
+        *reinterpret_cast<u32x4*>(xs + (size_t)c * 4) = o;
+        continue;
+      }
+    }
     if constexpr (SRC == 0) {
       const float* src = static_cast<const float*>(xin) + (size_t)row * W;
 #pragma unroll
@@ -352,25 +368,36 @@ __global__ __launch_bounds__(256) void stem_split_input_kernel(const void* __res
         o[e] = split_pair(v);
       }
     } else {
-      const int f = row / H, h = row - f * H;
+      int coy = oy, cox = ox, flip = 0;
+      if (clip_params != nullptr) {                    // per-clip crop origin (clamped into the frame) and flip
+        coy = min(max(clip_params[4 * b], 0), Hs - H);
+        cox = min(max(clip_params[4 * b + 1], 0), Ws - W);
+        flip = clip_params[4 * b + 2];
+      }
       const size_t plane = (size_t)Hs * Ws;
-      const uint8_t* src = static_cast<const uint8_t*>(xin) + ((size_t)f * CH * Hs + (size_t)(oy + h)) * Ws + ox;
+      const uint8_t* src = static_cast<const uint8_t*>(xin) + ((size_t)f * CH * Hs + (size_t)(coy + h)) * Ws + cox;
       // a chunk's four pixels are four consecutive bytes per colour plane: one (unaligned) dword load each where the chunk
       // lies inside the row, byte loads at the row's two ends (12 byte loads per 16-B store made this pre-pass 88 us
-      // against the fp32 one's 22 at the bench's batch)
+      // against the fp32 one's 22 at the bench's batch).  Flipped clips: pixel w of the crop is source column W - 1 - w, so
+      // the chunk's four source bytes are again consecutive, in reverse order: the same dword load + a byte swap.
       const int w0 = 4 * ch - 3;
       uint32_t px[3] = {0u, 0u, 0u};
       if (w0 >= 0 && w0 + 3 < W) {
+        const int s0 = flip ? W - 4 - w0 : w0;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          if (c < CH) __builtin_memcpy(&px[c], src + (size_t)c * plane + w0, 4);
+          if (c < CH) {
+            __builtin_memcpy(&px[c], src + (size_t)c * plane + s0, 4);
+            if (flip) px[c] = __builtin_bswap32(px[c]);
+          }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if ((unsigned)(w0 + e) < (unsigned)W) {
+            const int sc = flip ? W - 1 - (w0 + e) : w0 + e;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-              if (c < CH) px[c] |= (uint32_t)src[(size_t)c * plane + w0 + e] << (8 * e);
+              if (c < CH) px[c] |= (uint32_t)src[(size_t)c * plane + sc] << (8 * e);
           }
       }
 #pragma unroll
@@ -702,7 +729,8 @@ extern "C" int64_t dlip_stem3d_pool_workspace_bytes(int32_t B, int32_t T, int32_
 }
 
 // src_kind 0: x = fp32 [B,T,H,W]; 1: x = uint8 [B,T,CH,Hs,Ws] cropped to H x W at (oy, ox)
-static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws, int oy, int ox, void* x_split, const void* w_split,
+static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws, int oy, int ox, const int32_t* clip_params,
+                            const int32_t* lengths, void* x_split, const void* w_split,
                             const float* w_scale, const float* bias, const float* slope, float* y, int32_t B, int32_t T, int32_t H,
                             int32_t W, int32_t K, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && x_split && w_split && w_scale && y && B > 0 && T > 0 && H > 0 && W > 0);
@@ -733,10 +761,10 @@ static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws,
     if (frames * H > 0x7FFFFFFFll) return DLIP_ERANGE;
     if (src_kind == 0)
       hipLaunchKernelGGL(stem_split_input_kernel<0>, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), H, W, a.pwp,
-                         1, H, W, 0, 0, a.status, a.span);
+                         1, H, W, 0, 0, (int)T, lengths, static_cast<const int32_t*>(nullptr), a.status, a.span);
     else
       hipLaunchKernelGGL(stem_split_input_kernel<1>, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), H, W, a.pwp,
-                         CH, Hs, Ws, oy, ox, a.status, a.span);
+                         CH, Hs, Ws, oy, ox, (int)T, lengths, clip_params, a.status, a.span);
   }
   const long long grid = frames < 256 ? frames : 256;   // persistent: a workgroup walks whole frames
   const size_t ldsb = (size_t)WBYTES + (size_t)KT * (np * 256 + 32) * 4 + (size_t)CARRY_SLOTS * CARRY_B + 3 * 64 * 4 + 128;
@@ -778,15 +806,16 @@ static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws,
   return dlip_launch_status();
 }
 
-extern "C" int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void* w_split, const float* w_scale, const float* bias,
-                                      const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
+extern "C" int dlip_stem3d_pool_f16x3(const float* x, const int32_t* lengths, void* x_split, const void* w_split, const float* w_scale,
+                                      const float* bias, const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W,
                                       int32_t K, dlip_stream_t stream) {
-  return stem_pool_launch(x, 0, 1, H, W, 0, 0, x_split, w_split, w_scale, bias, slope, y, B, T, H, W, K, stream);
+  return stem_pool_launch(x, 0, 1, H, W, 0, 0, nullptr, lengths, x_split, w_split, w_scale, bias, slope, y, B, T, H, W, K, stream);
 }
 
 extern "C" int dlip_stem3d_pool_u8_f16x3(const uint8_t* frames, int32_t channels, int32_t Hs, int32_t Ws, int32_t oy, int32_t ox,
-                                         void* x_split, const void* w_split, const float* w_scale, const float* bias,
-                                         const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W, int32_t K,
-                                         dlip_stream_t stream) {
-  return stem_pool_launch(frames, 1, channels, Hs, Ws, oy, ox, x_split, w_split, w_scale, bias, slope, y, B, T, H, W, K, stream);
+                                         const int32_t* clip_params, const int32_t* lengths, void* x_split, const void* w_split,
+                                         const float* w_scale, const float* bias, const float* slope, float* y, int32_t B, int32_t T,
+                                         int32_t H, int32_t W, int32_t K, dlip_stream_t stream) {
+  return stem_pool_launch(frames, 1, channels, Hs, Ws, oy, ox, clip_params, lengths, x_split, w_split, w_scale, bias, slope, y, B, T,
+                          H, W, K, stream);
 }

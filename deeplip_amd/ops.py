@@ -167,11 +167,33 @@ def conv2_nhwc(x: Tensor, x2: Tensor, w_split: Tensor, bias: Tensor, w_scale: Te
 
 
 class Pooled:
-    """Partial column sums of a pooled convolution (conv_pool) + what pool_finish needs to read them."""
-    __slots__ = ("partials", "M", "K", "tile_rows", "group_rows")
+    """Partial column sums of a pooled convolution (conv_pool) + what pool_finish needs to read them.  ``lengths`` (int32 CUDA
+    [G] or None) with ``len_mul`` / ``len_add``: a ragged batch -- group g is valid for its first lengths[g] * len_mul + len_add rows."""
+    __slots__ = ("partials", "M", "K", "tile_rows", "group_rows", "lengths", "len_mul", "len_add")
 
-    def __init__(self, partials, M, K, tile_rows, group_rows):
+    def __init__(self, partials, M, K, tile_rows, group_rows, lengths=None, len_mul=1, len_add=0):
         self.partials, self.M, self.K, self.tile_rows, self.group_rows = partials, M, K, tile_rows, group_rows
+        self.lengths, self.len_mul, self.len_add = lengths, len_mul, len_add
+
+
+def lengths_i32(lengths, device, n: Optional[int] = None, lo: int = 1, hi: Optional[int] = None) -> Optional[Tensor]:
+    """The length vector of a ragged batch as the int32 device tensor the kernels read.  A CUDA int32 tensor passes through
+    untouched (what a recorded step plan needs: no host->device copy inside the step; its values are clamped on the device and
+    are the caller's responsibility); host lists / arrays / CPU tensors are validated here -- ``n`` entries in [lo, hi]."""
+    if lengths is None:
+        return None
+    if isinstance(lengths, Tensor) and lengths.is_cuda:
+        if lengths.dtype != torch.int32:
+            raise TypeError("lengths: a device tensor must be int32")
+        if n is not None and lengths.numel() != n:
+            raise ValueError(f"lengths: {lengths.numel()} entries for a batch of {n}")
+        return lengths.contiguous()
+    vals = [int(l) for l in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)]
+    if n is not None and len(vals) != n:
+        raise ValueError(f"lengths: {len(vals)} entries for a batch of {n}")
+    if vals and (min(vals) < lo or (hi is not None and max(vals) > hi)):
+        raise ValueError(f"lengths: values must lie in [{lo}, {hi}] (got {min(vals)} .. {max(vals)})")
+    return torch.tensor(vals, dtype=torch.int32).to(device)
 
 
 def conv_pool_tile_rows(x: Tensor, w_krsc: Tensor, *, stride=(1, 1), pad=(0, 0), dil=(1, 1)) -> int:
@@ -189,14 +211,17 @@ def conv_pool_tile_rows(x: Tensor, w_krsc: Tensor, *, stride=(1, 1), pad=(0, 0),
 
 def conv_pool(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor], w_scale: Tensor, group_rows: int, *, stride=(1, 1),
               pad=(0, 0), dil=(1, 1), residual: Optional[Tensor] = None, slope: Optional[Tensor] = None,
-              post_scale: Optional[Tensor] = None, post_shift: Optional[Tensor] = None) -> Pooled:
+              post_scale: Optional[Tensor] = None, post_shift: Optional[Tensor] = None,
+              lengths: Optional[Tensor] = None, len_mul: int = 1, len_add: int = 0) -> Pooled:
     """dlip_conv_pool_f16x3: the convolution of conv_nhwc (split-format x / residual) whose output is never written --
     per workgroup tile only the fp64 column sums of y and y^2, cut at the boundaries of consecutive ``group_rows``-row
     groups.  pool_finish turns them into group means (AdaptiveAvgPool + temporal mean, resnet.py:125-126 +
-    train_fusion.py:348) or mean | std (MeanStdPooling, pooling.py:24-26)."""
+    train_fusion.py:348) or mean | std (MeanStdPooling, pooling.py:24-26).  ``lengths`` (int32 CUDA, one per group): a
+    ragged batch -- only the first lengths[g] * len_mul + len_add rows of group g are summed (and counted by pool_finish)."""
     for t, n in ((x, "x"), (w_krsc, "w"), (bias, "bias"), (w_scale, "w_scale"), (residual, "residual"), (slope, "slope"),
                  (post_scale, "post_scale"), (post_shift, "post_shift")):
         _req(t, n)
+    _req(lengths, "lengths", torch.int32)
     N, H, W, Cx = x.shape
     K, R, S, Cw = w_krsc.shape
     if Cx % 32 or Cw != Cx:
@@ -222,11 +247,14 @@ def conv_pool(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor], w_scale: Tensor
                          2.0 * N * Ho * Wo * K * R * S * Cx)
     _lib.ensure_conv_workspace()
     check(lib().dlip_conv_pool_f16x3(C.byref(d), ptr(x), ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(residual), ptr(slope),
-                                     ptr(post_scale), ptr(post_shift), ptr(part), nbytes, group_rows, stream_handle()),
-          "dlip_conv_pool_f16x3")
+                                     ptr(post_scale), ptr(post_shift), ptr(part), nbytes, group_rows, ptr(lengths), len_mul, len_add,
+                                     stream_handle()), "dlip_conv_pool_f16x3")
     if hook is not None:
         hook.end(tok)
-    return Pooled(part, N * Ho * Wo, K, bm.value, group_rows)
+    M = N * Ho * Wo
+    if lengths is not None and lengths.numel() != (M + group_rows - 1) // group_rows:
+        raise ValueError(f"conv_pool: {lengths.numel()} lengths for {(M + group_rows - 1) // group_rows} groups")
+    return Pooled(part, M, K, bm.value, group_rows, lengths, len_mul, len_add)
 
 
 def pool_finish(p: Pooled, mode: str = "mean", out_split: bool = False) -> Tensor:
@@ -237,8 +265,8 @@ def pool_finish(p: Pooled, mode: str = "mean", out_split: bool = False) -> Tenso
         y = _empty((G, p.K), p.partials.device)
     else:
         y = _empty((G, (2 * p.K + 31) // 32 * 32 if out_split else 2 * p.K), p.partials.device)
-    check(lib().dlip_pool_finish_f32(ptr(p.partials), p.M, p.K, p.tile_rows, p.group_rows, 0 if mode == "mean" else 1,
-                                     int(out_split), ptr(y), stream_handle()), "dlip_pool_finish_f32")
+    check(lib().dlip_pool_finish_f32(ptr(p.partials), p.M, p.K, p.tile_rows, p.group_rows, ptr(p.lengths), p.len_mul, p.len_add,
+                                     0 if mode == "mean" else 1, int(out_split), ptr(y), stream_handle()), "dlip_pool_finish_f32")
     return y
 
 
@@ -297,19 +325,24 @@ def stem3d(x_bthw: Tensor, w_248xk: Tensor, bias: Tensor, slope: Optional[Tensor
     return y
 
 
-def stem3d_pool(x_bthw: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Tensor], w_scale: Tensor) -> Tensor:
+def stem3d_pool(x_bthw: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Tensor], w_scale: Tensor,
+                lengths: Optional[Tensor] = None) -> Tensor:
     """x [B,T,H,W] -> [(B*T), Hp, Wp, 64] in the split activation format: Conv3d 5x7x7 + folded BN +
-    PReLU/ReLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) in one kernel (split-fp16 weights image only)."""
+    PReLU/ReLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) in one kernel (split-fp16 weights image only).  ``lengths`` (int32 CUDA [B]):
+    a zero-padded ragged batch (dataset.py:123-139) -- frames t >= lengths[b] are read as zeros whatever x holds there."""
     for t, n in ((x_bthw, "x"), (w_img, "w"), (bias, "bias"), (slope, "slope"), (w_scale, "w_scale")):
         _req(t, n)
+    _req(lengths, "lengths", torch.int32)
     B, T, H, W = x_bthw.shape
+    if lengths is not None and lengths.numel() != B:
+        raise ValueError(f"stem3d_pool: {lengths.numel()} lengths for {B} clips")
     Ho, Wo = H // 2, W // 2
     y = _empty((B * T, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), x_bthw.device)
     ws = _empty((int(lib().dlip_stem3d_pool_workspace_bytes(B, T, H, W)) // 4,), x_bthw.device)   # the clip as (hi, lo) pairs
     hook = LAUNCH_HOOK
     if hook is not None:
         tok = hook.begin("stem3d_pool_f16x3_kernel", 2.0 * B * T * Ho * Wo * 64 * 245)
-    check(lib().dlip_stem3d_pool_f16x3(ptr(x_bthw), ptr(ws), ptr(w_img), ptr(w_scale), ptr(bias), ptr(slope), ptr(y),
+    check(lib().dlip_stem3d_pool_f16x3(ptr(x_bthw), ptr(lengths), ptr(ws), ptr(w_img), ptr(w_scale), ptr(bias), ptr(slope), ptr(y),
                                        B, T, H, W, 64, stream_handle()), "dlip_stem3d_pool_f16x3")
     if hook is not None:
         hook.end(tok)
@@ -324,12 +357,38 @@ def center_crop_origin(size: int, crop: int) -> int:
     return (size - crop) // 2
 
 
-def stem3d_pool_u8(frames: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Tensor], w_scale: Tensor, crop: int = 88) -> Tensor:
+def draw_clip_params(n_clips: int, Hs: int, Ws: int, crop: int = 88, flip_ratio: float = 0.5, rng=None):
+    """One (oy, ox, flip, 0) row per clip as the reference's train pipeline draws them (dataloaders.py:13-17): RandomCrop's
+    ``random.randint(0, w - tw)`` then ``randint(0, h - th)`` (preprocess.py:110-111, inclusive bounds), then HorizontalFlip's
+    ``random.random() < flip_ratio`` (:134), per clip, from ``rng`` (a ``random.Random``; the module-level generator when None --
+    what the reference uses, seeded by the trainer).  Returns an int32 numpy array [n_clips, 4] (host; ``.to(device)`` it)."""
+    import random as _random
+    import numpy as _np
+    r = rng if rng is not None else _random
+    out = _np.zeros((n_clips, 4), dtype=_np.int32)
+    for i in range(n_clips):
+        ox = r.randint(0, Ws - crop)
+        oy = r.randint(0, Hs - crop)
+        out[i, 0], out[i, 1], out[i, 2] = oy, ox, int(r.random() < flip_ratio)
+    return out
+
+
+def stem3d_pool_u8(frames: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[Tensor], w_scale: Tensor, crop: int = 88,
+                   lengths: Optional[Tensor] = None, clip_params: Optional[Tensor] = None) -> Tensor:
     """uint8 frames [B,T,Hs,Ws] (gray) or [B,T,3,Hs,Ws] (RGB) -> [(B*T), Hp, Wp, 64] split format: centre crop + gray +
-    (x/255 - 0.421)/0.165 inside the stem's pre-pass (dlip_stem3d_pool_u8_f16x3) -- no fp32 clip in HBM or over PCIe."""
+    (x/255 - 0.421)/0.165 inside the stem's pre-pass (dlip_stem3d_pool_u8_f16x3) -- no fp32 clip in HBM or over PCIe.
+    ``lengths`` (int32 CUDA [B]): ragged batch, frames t >= lengths[b] become zeros of the normalised clip.  ``clip_params``
+    (int32 CUDA [B,4] = (oy, ox, flip, 0) per clip): the train pipeline's RandomCrop + HorizontalFlip (preprocess.py:95-138)
+    instead of the centre crop -- see draw_clip_params."""
     _req(frames, "frames", torch.uint8)
     for t, n in ((w_img, "w"), (bias, "bias"), (slope, "slope"), (w_scale, "w_scale")):
         _req(t, n)
+    _req(lengths, "lengths", torch.int32)
+    _req(clip_params, "clip_params", torch.int32)
+    if lengths is not None and lengths.numel() != frames.shape[0]:
+        raise ValueError(f"stem3d_pool_u8: {lengths.numel()} lengths for {frames.shape[0]} clips")
+    if clip_params is not None and tuple(clip_params.shape) != (frames.shape[0], 4):
+        raise ValueError(f"stem3d_pool_u8: clip_params must be [B,4] = (oy, ox, flip, 0), got {tuple(clip_params.shape)}")
     if frames.dim() not in (4, 5) or (frames.dim() == 5 and frames.shape[2] != 3):
         raise ValueError("stem3d_pool_u8: expected uint8 [B,T,H,W] or [B,T,3,H,W]")
     ch = 3 if frames.dim() == 5 else 1
@@ -345,7 +404,7 @@ def stem3d_pool_u8(frames: Tensor, w_img: Tensor, bias: Tensor, slope: Optional[
     hook = LAUNCH_HOOK
     if hook is not None:
         tok = hook.begin("stem3d_pool_f16x3_kernel", 2.0 * B * T * Ho * Wo * 64 * 245)
-    check(lib().dlip_stem3d_pool_u8_f16x3(ptr(frames), ch, Hs, Ws, oy, ox, ptr(ws), ptr(w_img), ptr(w_scale), ptr(bias), ptr(slope),
+    check(lib().dlip_stem3d_pool_u8_f16x3(ptr(frames), ch, Hs, Ws, oy, ox, ptr(clip_params), ptr(lengths), ptr(ws), ptr(w_img), ptr(w_scale), ptr(bias), ptr(slope),
                                           ptr(y), B, T, H, W, 64, stream_handle()), "dlip_stem3d_pool_u8_f16x3")
     if hook is not None:
         hook.end(tok)
@@ -387,13 +446,25 @@ def avgpool(x: Tensor) -> Tensor:
     return y
 
 
-def time_mean(x: Tensor, lengths: Optional[Tensor] = None) -> Tensor:
-    """x [B,T,C] -> [B,C]; ``lengths`` int32 [B] masks the mean to t < len (model.py:16-17)."""
+def time_mean(x: Tensor, lengths: Optional[Tensor] = None, len_add: int = 0) -> Tensor:
+    """x [B,T,C] -> [B,C]; ``lengths`` int32 [B] masks the mean to t < len + len_add (model.py:16-17)."""
     _req(x, "x")
     _req(lengths, "lengths", torch.int32)
     B, T, Cc = x.shape
     y = _empty((B, Cc), x.device)
-    check(lib().dlip_time_mean_f32(ptr(x), ptr(lengths), ptr(y), B, T, Cc, Cc, stream_handle()), "dlip_time_mean_f32")
+    check(lib().dlip_time_mean_f32(ptr(x), ptr(lengths), len_add, ptr(y), B, T, Cc, Cc, stream_handle()), "dlip_time_mean_f32")
+    return y
+
+
+def mask_frames(x: Tensor, lengths: Tensor) -> Tensor:
+    """x [B,T,E] -> same with frames t >= lengths[b] zeroed (the padding of a ragged batch; dlip_mask_frames_f32)."""
+    _req(x, "x")
+    _req(lengths, "lengths", torch.int32)
+    B, T, E = x.shape
+    if lengths.numel() != B or E % 4:
+        raise ValueError("mask_frames: one length per row of x [B,T,E], E % 4 == 0")
+    y = _empty(x.shape, x.device)
+    check(lib().dlip_mask_frames_f32(ptr(x), ptr(lengths), ptr(y), B, T, E, stream_handle()), "dlip_mask_frames_f32")
     return y
 
 
@@ -414,16 +485,20 @@ def group_mean(x: Tensor, group_ptr: Tensor) -> Tensor:
     return y
 
 
-def meanstd_pool(x: Tensor, out_split: bool = False) -> Tensor:
+def meanstd_pool(x: Tensor, out_split: bool = False, lengths: Optional[Tensor] = None, len_add: int = 0) -> Tensor:
     """x [B,T,C] -> [B,2C] = cat(mean_t, unbiased std_t)  (pooling.py:24-26).  ``out_split``: the
-    result is [B, 2C rounded up to 32] in the split activation format (zero padded)."""
+    result is [B, 2C rounded up to 32] in the split activation format (zero padded).  ``lengths`` (int32 CUDA [B]): ragged
+    batch, utterance b's statistics cover its first lengths[b] + len_add frames."""
     _req(x, "x")
+    _req(lengths, "lengths", torch.int32)
     B, T, Cc = x.shape
+    if lengths is not None and lengths.numel() != B:
+        raise ValueError(f"meanstd_pool: {lengths.numel()} lengths for {B} utterances")
     if Cc % 4:
         raise ValueError("meanstd_pool: C must be a multiple of 4")
     width = (2 * Cc + 31) // 32 * 32 if out_split else 2 * Cc
     y = _empty((B, width), x.device)
-    check(lib().dlip_meanstd_pool_f32(ptr(x), ptr(y), B, T, Cc, int(out_split), stream_handle()), "dlip_meanstd_pool_f32")
+    check(lib().dlip_meanstd_pool_f32(ptr(x), ptr(lengths), len_add, ptr(y), B, T, Cc, int(out_split), stream_handle()), "dlip_meanstd_pool_f32")
     return y
 
 
@@ -486,8 +561,8 @@ def znorm_cat_pooled(a: Optional[Tensor], p: "Pooled", biased: bool = False) -> 
     if a is not None and a.shape[0] != U:
         raise ValueError(f"znorm_cat_pooled: {a.shape[0]} rows of a, {U} pooled groups")
     y = _empty((U, Da + p.K), p.partials.device)
-    check(lib().dlip_znorm_cat_pooled_f32(ptr(a), Da, ptr(p.partials), p.M, p.K, p.tile_rows, p.group_rows, ptr(y), U,
-                                          int(biased), stream_handle()), "dlip_znorm_cat_pooled_f32")
+    check(lib().dlip_znorm_cat_pooled_f32(ptr(a), Da, ptr(p.partials), p.M, p.K, p.tile_rows, p.group_rows, ptr(p.lengths), p.len_mul,
+                                          p.len_add, ptr(y), U, int(biased), stream_handle()), "dlip_znorm_cat_pooled_f32")
     return y
 
 

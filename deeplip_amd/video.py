@@ -104,7 +104,7 @@ class BasicBlock(nn.Module):
         return p
 
     def run(self, x: Tensor, p: Dict[str, packing.Packed], split: bool = False, out_split: bool = False,
-            pool_group: Optional[int] = None):
+            pool_group: Optional[int] = None, pool_lengths: Optional[Tensor] = None, pool_len_mul: int = 1):
         """x NHWC.  conv1+bn1+relu1 | (1x1 s2 conv + bn) | conv2+bn2 + residual + relu2.
         ``split``: x is in the split activation format (f16x3 packing only) and so are the block's
         internal tensors; ``out_split`` keeps the result in it for the next block; ``pool_group`` (split only):
@@ -119,7 +119,7 @@ class BasicBlock(nn.Module):
                             x_split=split, out_split=split) if "down" in p else x
         if pool_group is not None:   # the block's output leaves as pooled partial sums only
             return ops.conv_pool(h, p["conv2"].w, p["conv2"].b, p["conv2"].wscale, pool_group, pad=(1, 1), residual=res,
-                                 slope=p["conv2"].slope)
+                                 slope=p["conv2"].slope, lengths=pool_lengths, len_mul=pool_len_mul)
         return ops.conv_nhwc(h, p["conv2"].w, p["conv2"].b, pad=(1, 1), residual=res, slope=p["conv2"].slope,
                              w_scale=p["conv2"].wscale, x_split=split, out_split=out_split)
 
@@ -193,10 +193,12 @@ class ResNet(nn.Module):
         split activation format, so each one is split once by its producer."""
         return packed[0]["conv1"].wscale is not None
 
-    def run(self, x: Tensor, packed, taps: Optional[dict] = None, x_split: bool = False, pool_frames: Optional[int] = None):
+    def run(self, x: Tensor, packed, taps: Optional[dict] = None, x_split: bool = False, pool_frames: Optional[int] = None,
+            pool_lengths: Optional[Tensor] = None):
         """x [N,H,W,64] NHWC (in the split activation format if ``x_split``) -> [N,512]; with ``pool_frames`` = T
         (f16x3 packing): ops.Pooled sums over each clip's T*Ho*Wo output pixels of the last convolution instead
-        (finish with ops.pool_finish(..., 'mean') = AdaptiveAvgPool + temporal mean)."""
+        (finish with ops.pool_finish(..., 'mean') = AdaptiveAvgPool + temporal mean); ``pool_lengths`` (int32 CUDA [B]):
+        ragged batch, clip b's sums cover its first pool_lengths[b] frames."""
         split = self.wants_split(packed)
         if split and not x_split:
             x = ops.split_pack(x)
@@ -209,7 +211,7 @@ class ResNet(nn.Module):
                 if not split:
                     raise ValueError("ResNet.run: pooled output needs the f16x3 packing")
                 hw = ops.conv_out_size(x.shape[1], 3, b.stride, 1, 1) * ops.conv_out_size(x.shape[2], 3, b.stride, 1, 1)
-                return b.run(x, p, split=True, pool_group=pool_frames * hw)
+                return b.run(x, p, split=True, pool_group=pool_frames * hw, pool_lengths=pool_lengths, pool_len_mul=hw)
             x = b.run(x, p, split=split, out_split=split and not last)   # avgpool reads fp32
             if taps is not None and i % 2 == 1:
                 taps[f"layer{i // 2 + 1}"] = ops.split_unpack(x) if (split and not last) else x
@@ -502,14 +504,19 @@ class Lipreading(nn.Module):
         return ag.linear(av.time_mean(y, _lengths_i32(lengths, x.device)), self.tcn.tcn_output.weight, self.tcn.tcn_output.bias)
 
     @_lib.scoped_eval
-    def forward(self, x: Tensor, lengths, taps: Optional[dict] = None, pooled: bool = False):
+    def forward(self, x: Tensor, lengths, taps: Optional[dict] = None, pooled: bool = False, ragged: Optional[Tensor] = None,
+                clip_params: Optional[Tensor] = None):
         """``pooled`` (eval, f16x3 packing, extract path): return the ops.Pooled sums of the last convolution over each
-        clip instead of the [B,T,512] features -- what embed() finishes into the per-clip mean."""
+        clip instead of the [B,T,512] features -- what embed() finishes into the per-clip mean.  ``ragged`` (int32 CUDA [B];
+        embed()'s): the clip lengths of a zero-padded batch whose padding frames are to be READ AS ZEROS (and left out of the
+        pooled sums) so that every clip comes out as if run alone at its own length -- the reference's classifier path
+        (``lengths``, model.py:16-17) instead feeds the padding frames through the net as they are and only masks the
+        consensus mean, and so does this method without ``ragged``.  ``clip_params``: per-clip crop / flip of uint8 frames."""
         if self.training:
             return self._forward_train(x, lengths)
         _lib.check_range()      # an overflow reported by an earlier f16x3 launch surfaces here (host read, no sync)
         if x.dtype == torch.uint8:
-            return self._forward_u8(x, lengths, taps, pooled)
+            return self._forward_u8(x, lengths, taps, pooled, ragged, clip_params)
         B, C, T, H, W = x.size()
         if C != 1:
             raise ValueError("Lipreading expects grayscale clips [B,1,T,H,W] (model.py:82); use "
@@ -519,8 +526,10 @@ class Lipreading(nn.Module):
         split = self.trunk.wants_split(p["trunk"])
         if split and taps is None and p["stem"].wscale is not None and W <= 88 and W % 8 == 0:
             # stem + max pooling in one kernel: the pre-pool activations (4x the pooled bytes) stay on chip
-            y = ops.stem3d_pool(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope, p["stem"].wscale)
+            y = ops.stem3d_pool(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope, p["stem"].wscale, lengths=ragged)
         else:
+            if ragged is not None:
+                x = ops.mask_frames(x.view(B, T, H * W), ragged).view(B, 1, T, H, W)     # padding frames -> zeros
             y = ops.stem3d(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope,
                            w_scale=p["stem"].wscale if W <= 88 else None)   # [(B*T),H/2,W/2,64]
             if taps is not None:
@@ -529,11 +538,12 @@ class Lipreading(nn.Module):
             if taps is not None:
                 taps["stem"] = ops.split_unpack(y) if split else y
         if pooled:
-            return self.trunk.run(y, p["trunk"], None, x_split=split, pool_frames=T)
+            return self.trunk.run(y, p["trunk"], None, x_split=split, pool_frames=T, pool_lengths=ragged)
         y = self.trunk.run(y, p["trunk"], taps, x_split=split).view(B, T, self.backend_out)
         return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
 
-    def _forward_u8(self, frames: Tensor, lengths, taps, pooled: bool):
+    def _forward_u8(self, frames: Tensor, lengths, taps, pooled: bool, ragged: Optional[Tensor] = None,
+                    clip_params: Optional[Tensor] = None):
         """forward() for uint8 frames as a loader hands them over -- [B,T,Hs,Ws] gray (the reference's npz mouth crops) or
         [B,T,3,Hs,Ws] RGB (BASELINE.json's input) -- instead of the normalised float clip [B,1,T,88,88].  On the split-format
         path the centre crop, the gray conversion and (x/255 - 0.421)/0.165 (dataloaders.py:11-22) happen inside the stem's
@@ -547,10 +557,13 @@ class Lipreading(nn.Module):
         B, T = frames.shape[0], frames.shape[1]
         if not (split and taps is None and p["stem"].wscale is not None):
             from .frontend import VideoFrontend
-            return self.forward(VideoFrontend(88)(frames), lengths, taps, pooled)
-        y = ops.stem3d_pool_u8(frames, p["stem"].w, p["stem"].b, p["stem"].slope, p["stem"].wscale, crop=88)
+            if clip_params is not None:
+                raise NotImplementedError("per-clip crop / flip of uint8 frames lives in the f16x3 stem's pre-pass")
+            return self.forward(VideoFrontend(88)(frames), lengths, taps, pooled, ragged)
+        y = ops.stem3d_pool_u8(frames, p["stem"].w, p["stem"].b, p["stem"].slope, p["stem"].wscale, crop=88, lengths=ragged,
+                               clip_params=clip_params)
         if pooled:
-            return self.trunk.run(y, p["trunk"], None, x_split=True, pool_frames=T)
+            return self.trunk.run(y, p["trunk"], None, x_split=True, pool_frames=T, pool_lengths=ragged)
         y = self.trunk.run(y, p["trunk"], None, x_split=True).view(B, T, self.backend_out)
         return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
 
@@ -565,16 +578,27 @@ class Lipreading(nn.Module):
         return self.tcn.pooled(feats, lengths, _cached_pack(self, x.device, self._pack)["tcn"])
 
     @_lib.scoped_eval
-    def embed(self, x: Tensor, finish: bool = True):
+    def embed(self, x: Tensor, lengths=None, finish: bool = True):
         """[B,1,T,H,W] -> [B,512]: per-clip temporal mean of the features, the quantity the fusion
         pipeline consumes (train_fusion.py:274,348).  ``finish=False`` may return the means as pooled partial sums
-        (ops.Pooled) for deeplip_amd.fusion.fuse_av to finish inside its own launch."""
+        (ops.Pooled) for deeplip_amd.fusion.fuse_av to finish inside its own launch.
+
+        ``lengths`` (list / int32 tensor [B]; build-owned): a RAGGED batch as pad_packed_collate yields it (dataset.py:123-139:
+        clips zero-padded to the longest + their lengths).  Row b then equals ``embed(x[b:b+1, :, :lengths[b]])`` -- the
+        reference's test loop, one clip at a time at its own length (train_fusion.py:346-348): the padding frames are read as
+        zeros (= the Conv3d's own padding behind the clip's last frame; the trunk is per frame) and stay out of the mean.  A
+        device tensor is read by the kernels directly, so a recorded plan replays with new lengths."""
+        lens = None
+        if lengths is not None:
+            if self.training:
+                raise NotImplementedError("embed(lengths=...) is the eval-mode extraction path")
+            lens = ops.lengths_i32(lengths, x.device, n=x.shape[0], lo=1, hi=x.shape[1] if x.dtype == torch.uint8 else x.shape[2])
         if not self.training and FUSE_POOL and self._can_pool(x):
-            pooled = self.forward(x, None, pooled=True)
+            pooled = self.forward(x, None, pooled=True, ragged=lens)
             return ops.pool_finish(pooled, "mean") if finish else pooled
         ef, self.extract_feats = self.extract_feats, True
         try:
-            return ops.time_mean(self.forward(x, lengths=None))
+            return ops.time_mean(self.forward(x, lengths=None, ragged=lens), lens)
         finally:
             self.extract_feats = ef
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 42
+#define DLIP_ABI_VERSION 43
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -122,15 +122,27 @@ int dlip_conv2_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const float* 
  *           split activation format ([G, 2K rounded up to 32], what fc1's kernel reads).
  * partials: caller-owned, dlip_conv_pool_partial_bytes(d, &tile_rows) bytes (8-byte aligned); group_rows must be
  * >= tile_rows (a tile then holds at most one group boundary) -- callers fall back to the unfused kernels
- * otherwise.  Sums are formed in a fixed order: results do not depend on scheduling. */
+ * otherwise.  Sums are formed in a fixed order: results do not depend on scheduling.
+ * RAGGED BATCHES (ABI 43).  The reference extracts one utterance / one clip at a time at its own length
+ * (train_fusion.py:334-349: audio [1,24,T_i], clips [1,1,T_j,88,88]); a batch of them is the zero-padded tensor +
+ * length vector of pad_packed_collate (models/video_models/dataset.py:123-139).  group_len (device int32 [G], NULL =
+ * every group is whole): group g is valid for its first clamp(group_len[g] * len_mul + len_add, 0, group_rows) rows, the
+ * rest is padding and enters neither sum nor count -- len_mul / len_add turn the caller's unit into pooled rows (lip
+ * clips: frames * Ho*Wo of the last convolution; utterances: input frames - the frames the valid convolutions consume),
+ * so one length vector in HBM serves the whole step and a recorded plan replays with new lengths.  The valid rows'
+ * values equal the unpadded run's (a valid convolution / a per-frame trunk never reads past them; the stem's pre-pass
+ * zeroes the padding frames, dlip_stem3d_pool_f16x3). */
 int64_t dlip_conv_pool_partial_bytes(const dlip_conv_desc* d, int32_t* tile_rows);
 int dlip_conv_pool_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, const float* w_scale,
                          const float* bias, const float* residual, const float* slope, const float* post_scale,
                          const float* post_shift, double* partials, int64_t partial_bytes, int32_t group_rows,
-                         dlip_stream_t stream);
-/* M = rows of the pooled convolution, K its channels, tile_rows as reported by dlip_conv_pool_partial_bytes.
+                         const int32_t* group_len, int32_t len_mul, int32_t len_add, dlip_stream_t stream);
+/* M = rows of the pooled convolution, K its channels, tile_rows as reported by dlip_conv_pool_partial_bytes; group_len /
+ * len_mul / len_add as given to dlip_conv_pool_f16x3 (the divisor of group g is its valid row count: the masked mean of
+ * models/video_models/model.py:16-17, the statistics of one utterance at its own length).
  * y: mode 0 [G,K]; mode 1 [G,2K] or, with out_split != 0, [G, 2K rounded up to 32] split format (padding zeroed). */
 int dlip_pool_finish_f32(const double* partials, int64_t M, int32_t K, int32_t tile_rows, int32_t group_rows,
+                         const int32_t* group_len, int32_t len_mul, int32_t len_add,
                          int32_t mode, int32_t out_split, float* y, dlip_stream_t stream);
 
 /* Workspace of dlip_conv_nhwc_f16x3's balanced ("stream-K") work split on split-format activations:
@@ -188,21 +200,31 @@ int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, const float* w
  * dlip_conv_nhwc_f16x3 (what the trunk's first layers read).  H, W even, W <= 88.
  * x_split: caller-owned scratch of dlip_stem3d_pool_workspace_bytes(B, T, H, W) bytes, 16-B aligned -- a
  * pre-pass writes the clip there once as (hi, lo) fp16 pairs at the kernel's window row pitch, and the
- * kernel fetches its windows from it by LDS-DMA (two launches on `stream`). */
+ * kernel fetches its windows from it by LDS-DMA (two launches on `stream`).
+ * lengths (device int32 [B], NULL = every clip has T frames; ABI 43): clip b's frames t >= lengths[b] are padding
+ * (pad_packed_collate, models/video_models/dataset.py:123-139) and the pre-pass writes them as ZEROS of the normalised clip
+ * whatever x holds there -- for the frames t < lengths[b] that is the Conv3d's own zero padding behind the clip's last frame,
+ * so their outputs equal the clip run alone at its own length (train_fusion.py:346-348). */
 int64_t dlip_stem3d_pool_workspace_bytes(int32_t B, int32_t T, int32_t H, int32_t W);
-int dlip_stem3d_pool_f16x3(const float* x, void* x_split, const void* w_split, const float* w_scale,
+int dlip_stem3d_pool_f16x3(const float* x, const int32_t* lengths, void* x_split, const void* w_split, const float* w_scale,
                            const float* bias, const float* slope, float* y, int32_t B, int32_t T, int32_t H,
                            int32_t W, int32_t K, dlip_stream_t stream);
 
 /* dlip_stem3d_pool_f16x3 fed with the frames as a loader hands them over: uint8, `channels` = 1 (gray [B,T,Hs,Ws], what the
  * reference's npz mouth crops hold: models/video_models/dataset.py) or 3 (RGB [B,T,3,Hs,Ws], BASELINE.json's input shape).
- * The pre-pass centre-crops H x W at row oy, column ox (CenterCrop: preprocess.py; oy = int(round((Hs - H) / 2.))) and
+ * The pre-pass crops H x W at row oy, column ox (CenterCrop, preprocess.py:89-90: oy = (Hs - H) / 2 rounded DOWN) and
  * normalises while it writes the split clip: gray = 0.299 R + 0.587 G + 0.114 B kept in float (preprocess.py:32-46),
  * (gray / 255 - 0.421) / 0.165 (dataloaders.py:11-22), mul / add / IEEE divide in that order, uncontracted -- bit-identical
  * to dlip_ingest_rgb_u8 (or dlip_crop_normalize_u8) followed by dlip_stem3d_pool_f16x3, without the fp32 clip: a quarter of
  * the host-to-device bytes, one HBM write and one read of 4 B per pixel less.  Replaces train_fusion.py:346-348's
- * `.to(device)` of a float clip + model.py:81-85. */
+ * `.to(device)` of a float clip + model.py:81-85.
+ * clip_params (device int32 [B][4], NULL = (oy, ox) for every clip, no flip; ABI 43): per clip (oy_b, ox_b, flip_b, 0) -- the
+ * train pipeline's RandomCrop origin and HorizontalFlip coin (preprocess.py:95-138, dataloaders.py:13-17: ONE draw per clip, all
+ * of its frames alike; the host draws them from its seeded generator); flip_b != 0 mirrors the cropped frame left-right
+ * (pixel w <- column ox_b + W - 1 - w).  Origins are clamped into the frame.  lengths: as dlip_stem3d_pool_f16x3 (here the
+ * only way to pad: a zero byte is not a zero of the normalised clip). */
 int dlip_stem3d_pool_u8_f16x3(const uint8_t* frames, int32_t channels, int32_t Hs, int32_t Ws, int32_t oy, int32_t ox,
+                              const int32_t* clip_params, const int32_t* lengths,
                               void* x_split, const void* w_split, const float* w_scale, const float* bias,
                               const float* slope, float* y, int32_t B, int32_t T, int32_t H, int32_t W, int32_t K,
                               dlip_stream_t stream);
@@ -225,11 +247,16 @@ int dlip_maxpool3x3s2_nhwc_f32(const float* x, float* y, int32_t N, int32_t H, i
 int dlip_avgpool_nhwc_f32(const float* x, float* y, int32_t N, int32_t HW, int32_t C,
                           dlip_stream_t stream);
 
-/* Masked temporal mean: y[b,c] = mean_{t < len[b]} x[b,t,c]; len == NULL means T for every b.
+/* Masked temporal mean: y[b,c] = mean_{t < len[b] + len_add} x[b,t,c]; len == NULL means T for every b.
  * Replaces torch.mean(..., dim=0) over frames (train_fusion.py:274,348) and _average_batch
  * (models/video_models/model.py:16-17).  x [B,T,C] with row stride ldx floats. */
-int dlip_time_mean_f32(const float* x, const int32_t* len, float* y, int32_t B, int32_t T, int32_t C,
+int dlip_time_mean_f32(const float* x, const int32_t* len, int32_t len_add, float* y, int32_t B, int32_t T, int32_t C,
                        int32_t ldx, dlip_stream_t stream);
+
+/* Ragged batches on the paths without a stem pre-pass (exact-fp32 packing, taps): y[b,t,:] = t < len[b] ? x[b,t,:] : 0 for x
+ * [B,T,E] -- the padding frames of pad_packed_collate (models/video_models/dataset.py:123-139) as zeros of the normalised
+ * clip.  E % 4 == 0, x and y 16-byte aligned (y may be x). */
+int dlip_mask_frames_f32(const float* x, const int32_t* len, float* y, int32_t B, int32_t T, int32_t E, dlip_stream_t stream);
 
 /* Segmented mean over clip groups (CSR offsets, G+1 entries): y[u] = sum(x[ptr[u]:ptr[u+1]]) / count.
  * Replaces the per-utterance clip-file average (train_fusion.py:272-275,346-349). */
@@ -238,15 +265,18 @@ int dlip_group_mean_f32(const float* x, const int32_t* group_ptr, float* y, int3
 
 /* MeanStdPooling on N-T-C: y[b, 0:C] = mean_t, y[b, C:2C] = unbiased std_t (N-1); sums of x and x^2
  * in fp64.  Replaces models/audio_models/pooling.py:24-26.  C % 4 == 0.  out_split != 0 writes y as
- * [B, 2C rounded up to 32] in the split activation format of dlip_conv_nhwc_f16x3 (padding zeroed). */
-int dlip_meanstd_pool_f32(const float* x, float* y, int32_t B, int32_t T, int32_t C,
+ * [B, 2C rounded up to 32] in the split activation format of dlip_conv_nhwc_f16x3 (padding zeroed).
+ * len (device int32 [B], NULL = T for every b; ABI 43): utterance b's statistics cover its first
+ * clamp(len[b] + len_add, 0, T) frames -- a zero-padded batch pooled as the reference pools each utterance at its own
+ * length (train_fusion.py:334-338); len_add = -(frames the valid convolutions in front consumed) when len counts input frames. */
+int dlip_meanstd_pool_f32(const float* x, const int32_t* len, int32_t len_add, float* y, int32_t B, int32_t T, int32_t C,
                           int32_t out_split, dlip_stream_t stream);
 
 /* AttentiveStatPooling tail (models/audio_models/pooling.py:87-107) on N-T-C: hidden [B,T,Hd] = x W^T + b
  * (from dlip_conv_nhwc_f32), e = relu(hidden).v + k, alpha = softmax over T, y [B,2C] = weighted mean |
- * sqrt(weighted E[x^2] - mean^2). */
-int dlip_attentive_stat_pool_f32(const float* x, const float* hidden, const float* v, const float* k, float* y,
-                                 int32_t B, int32_t T, int32_t C, int32_t Hd, dlip_stream_t stream);
+ * sqrt(weighted E[x^2] - mean^2).  len / len_add: as dlip_meanstd_pool_f32 (softmax and statistics over the valid frames). */
+int dlip_attentive_stat_pool_f32(const float* x, const float* hidden, const float* v, const float* k, const int32_t* len,
+                                 int32_t len_add, float* y, int32_t B, int32_t T, int32_t C, int32_t Hd, dlip_stream_t stream);
 
 /* Layout adapters at the API boundary.
  *   dlip_nct_to_ntc_f32: x [B,C,T] (reference layout, tdnn.py:89) -> y [B,T,Cp] zero-padded to Cp>=C.
@@ -279,10 +309,10 @@ int dlip_znorm_cat_f32(const float* a, int32_t Da, const float* v, int32_t Dv, f
 /* dlip_znorm_cat_f32 whose second table is the per-clip mean still held as pooled partial sums (dlip_conv_pool_f16x3
  * over groups of T*Ho*Wo rows; M, K, tile_rows, group_rows as for dlip_pool_finish_f32, U = number of groups): the
  * temporal mean of train_fusion.py:348 and the fusion of :353-358 in one launch; bit-identical to
- * dlip_pool_finish_f32 (mode 0) followed by dlip_znorm_cat_f32. */
+ * dlip_pool_finish_f32 (mode 0) followed by dlip_znorm_cat_f32 (group_len / len_mul / len_add as there). */
 int dlip_znorm_cat_pooled_f32(const float* a, int32_t Da, const double* partials, int64_t M, int32_t K,
-                              int32_t tile_rows, int32_t group_rows, float* y, int32_t U, int32_t biased,
-                              dlip_stream_t stream);
+                              int32_t tile_rows, int32_t group_rows, const int32_t* group_len, int32_t len_mul,
+                              int32_t len_add, float* y, int32_t U, int32_t biased, dlip_stream_t stream);
 
 /* y[u,:] = x[u,:] / max(||x[u,:]||_2, eps)   (F.normalize; loss.py:44, train_audio.py:355). */
 int dlip_l2_normalize_f32(const float* x, float* y, int32_t U, int32_t D, float eps,

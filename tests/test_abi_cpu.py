@@ -45,3 +45,19 @@ def test_ops_refuse_cpu_tensors():
         ops.meanstd_pool(torch.zeros(1, 4, 8))
     with pytest.raises(DeepLipHipError):
         ops.conv_nhwc(torch.zeros(1, 2, 2, 4), torch.zeros(4, 1, 1, 4))
+
+
+def test_binding_arity_matches_header():
+    """Every ctypes signature has as many arguments as the header's prototype (ctypes would push a short or long list without
+    complaint; the kernel would then read garbage pointers)."""
+    from deeplip_amd import _lib
+    text = open(os.path.join(ROOT, "include", "deeplip_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    seen = 0
+    for m in re.finditer(r"\b(dlip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        if name in _lib.SIGNATURES:
+            assert len(_lib.SIGNATURES[name]) == n, f"{name}: header has {n} arguments, binding {len(_lib.SIGNATURES[name])}"
+            seen += 1
+    assert seen == len(_lib.SIGNATURES)
