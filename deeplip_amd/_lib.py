@@ -129,7 +129,7 @@ SIGNATURES = {
     "dlip_log_floor_f32": [c_f, c_f, c_i64, c_stream],
     "dlip_cmvn_nct_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_delta_nct_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
-    "dlip_crop_normalize_u8": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_crop_normalize_u8": [c_f, c_f, c_f, c_i32, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_bn1d_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_stream],
     "dlip_bn1d_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_lrelu_bwd_f32": [c_f, c_f, c_f, c_i64, C.c_float, c_stream],

@@ -155,15 +155,28 @@ __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ x,
   }
 }
 
-// uint8 frames [N, CH, H, W] (CH = 1 gray or 3 RGB) -> centre crop [N, CS, CS] float, normalised.
+// uint8 frames [N, CH, H, W] (CH = 1 gray or 3 RGB; N = B clips of T frames) -> crop [N, CS, CS] float, normalised.
+//   clip_params == NULL: the "val" pipeline's CenterCrop (preprocess.py:89-90: the margin halved and rounded DOWN);
+//   clip_params [B][4] = (oy, ox, flip, 0): the "train" pipeline's RandomCrop origin + HorizontalFlip coin of each clip
+//     (preprocess.py:95-138, dataloaders.py:13-17), drawn by the host; a flipped clip reads column ox + CS - 1 - cx;
+//   lengths [B]: frames t >= lengths[b] are the zero padding of pad_packed_collate -- zeros of the NORMALISED clip
+//     (dataset.py:117,130-134: the clip is normalised first, padded second).
 __global__ __launch_bounds__(256) void crop_norm_kernel(const uint8_t* __restrict__ x, float* __restrict__ y,
-                                                        long long N, int CH, int H, int W, int CS) {
+                                                        long long N, int CH, int H, int W, int CS, int T,
+                                                        const int32_t* __restrict__ clip_params, const int32_t* __restrict__ lengths) {
   const long long total = N * CS * CS;
-  const int oy = (H - CS) / 2, ox = (W - CS) / 2;     // CenterCrop: int(round((h - th)/2.)) for even margins
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int cx = (int)(i % CS);
+    int cx = (int)(i % CS);
     const int cy = (int)((i / CS) % CS);
     const long long n = i / ((long long)CS * CS);
+    const int b = (int)(n / T);
+    if (lengths != nullptr && (int)(n - (long long)b * T) >= lengths[b]) { y[i] = 0.f; continue; }
+    int oy = (H - CS) / 2, ox = (W - CS) / 2;
+    if (clip_params != nullptr) {
+      oy = min(max(clip_params[4 * b], 0), H - CS);
+      ox = min(max(clip_params[4 * b + 1], 0), W - CS);
+      if (clip_params[4 * b + 2] != 0) cx = CS - 1 - cx;
+    }
     const uint8_t* p = x + (n * CH * H + (oy + cy)) * W + ox + cx;
     float g;
     if (CH == 3) g = dlip_gray601((float)p[0], (float)p[(long long)H * W], (float)p[2LL * H * W]);
@@ -229,10 +242,11 @@ extern "C" int dlip_delta_nct_f32(const float* x, float* y, int32_t B, int32_t C
   return dlip_launch_status();
 }
 
-extern "C" int dlip_crop_normalize_u8(const uint8_t* x, float* y, int64_t n_frames, int32_t channels, int32_t H,
-                                      int32_t W, int32_t crop, dlip_stream_t stream) {
+extern "C" int dlip_crop_normalize_u8(const uint8_t* x, const int32_t* clip_params, const int32_t* lengths, int32_t T, float* y,
+                                      int64_t n_frames, int32_t channels, int32_t H, int32_t W, int32_t crop, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && y && n_frames > 0 && (channels == 1 || channels == 3) && crop > 0 && H >= crop && W >= crop);
+  DLIP_CHECK_ARG(T > 0 && n_frames % T == 0);
   hipLaunchKernelGGL(crop_norm_kernel, dim3(grid_for(n_frames * crop * crop)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, y, (long long)n_frames, channels, H, W, crop);
+                     static_cast<hipStream_t>(stream), x, y, (long long)n_frames, channels, H, W, crop, T, clip_params, lengths);
   return dlip_launch_status();
 }

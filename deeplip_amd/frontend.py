@@ -132,27 +132,35 @@ class VideoFrontend:
     def __init__(self, crop: int = 88):
         self.crop = crop
 
-    def __call__(self, frames: torch.Tensor) -> torch.Tensor:
-        """frames [B,T,H,W] (gray) or [B,T,3,H,W] (RGB) uint8 cuda."""
+    def __call__(self, frames: torch.Tensor, clip_params: Optional[torch.Tensor] = None,
+                 lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """frames [B,T,H,W] (gray) or [B,T,3,H,W] (RGB) uint8 cuda.  Default: the "val" pipeline (CenterCrop).  ``clip_params``
+        (int32 cuda [B,4] = (oy, ox, flip, 0), see ops.draw_clip_params): the "train" pipeline's RandomCrop + HorizontalFlip per
+        clip (preprocess.py:95-138).  ``lengths`` (int32 cuda [B]): frames t >= lengths[b] become zeros of the NORMALISED clip,
+        the padding of pad_packed_collate."""
         if frames.dtype != torch.uint8 or not frames.is_cuda:
             raise TypeError("VideoFrontend expects uint8 CUDA frames")
         frames = frames.contiguous()
         ch = 3 if frames.dim() == 5 else 1
         B, T = frames.shape[0], frames.shape[1]
         H, W = frames.shape[-2], frames.shape[-1]
+        for t, n, shape in ((clip_params, "clip_params", (B, 4)), (lengths, "lengths", (B,))):
+            if t is not None and (t.dtype != torch.int32 or not t.is_cuda or tuple(t.shape) != shape or not t.is_contiguous()):
+                raise ValueError(f"VideoFrontend: {n} must be a contiguous int32 CUDA tensor of shape {shape}")
         y = ops._empty((B, 1, T, self.crop, self.crop), frames.device)   # (arena-aware: this may run inside a recorded step plan)
-        check(lib().dlip_crop_normalize_u8(ptr(frames), ptr(y), B * T, ch, H, W, self.crop, stream_handle()),
-              "dlip_crop_normalize_u8")
+        check(lib().dlip_crop_normalize_u8(ptr(frames), ptr(clip_params), ptr(lengths), T, ptr(y), B * T, ch, H, W, self.crop,
+                                           stream_handle()), "dlip_crop_normalize_u8")
         return y
 
     def collate(self, clips: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, List[int]]:
-        """pad_packed_collate (dataset.py:123-139): clips [T_i,H,W] (or [T_i,3,H,W]) uint8 cuda, sorted by
-        length (desc) and zero-padded AFTER normalisation is what the reference does NOT do -- it pads the
-        raw frames with zeros; so pad first (uint8 zeros), then normalise."""
+        """pad_packed_collate (dataset.py:123-139): clips [T_i,H,W] (or [T_i,3,H,W]) uint8 cuda, sorted by length (desc),
+        normalised, and zero-padded to the longest AFTER the normalisation, as the reference does (its dataset normalises in
+        __getitem__, dataset.py:117, and the collate pads the normalised clips with zeros, :130-134).  Round 4 padded the raw
+        bytes and normalised the padding along: (0 / 255 - 0.421) / 0.165 = -2.55 in every padding pixel instead of 0."""
         order = sorted(range(len(clips)), key=lambda i: clips[i].shape[0], reverse=True)
         lengths = [int(clips[i].shape[0]) for i in order]
         shape = (len(clips), lengths[0]) + tuple(clips[0].shape[1:])
         buf = torch.zeros(shape, dtype=torch.uint8, device=clips[0].device)
         for j, i in enumerate(order):
             buf[j, :lengths[j]] = clips[i]
-        return self(buf), lengths
+        return self(buf, lengths=torch.tensor(lengths, dtype=torch.int32).to(buf.device)), lengths

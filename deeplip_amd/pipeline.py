@@ -60,9 +60,44 @@ class ExtractPipeline:
         self.ready = [torch.cuda.Event() for _ in range(depth)]
         self.free = [torch.cuda.Event() for _ in range(depth)]
         self._replayed = [False] * depth     # set k has a replay in flight (or finished) whose FREE event must be awaited before refilling it
+        self._next = 0                       # batches submitted so far: batch i uses input set i % depth
         self.batch = int(example_inputs[0].shape[0])
         self.launches = self.plans[0].launches
         self.run_stream.synchronize()
+
+    def submit(self, hb: Sequence[Tensor], tables: Sequence[Tensor], row: int) -> int:
+        """One batch: ``hb`` (pinned host tensors shaped like the recorded inputs; any of them may be SHORT in its leading
+        dimension) -> copies on the copy stream, one plan replay on the run stream, the first ``rows = hb[0].shape[0]`` output rows
+        into ``tables[j][row : row + rows]``.  Asynchronous; returns ``rows``."""
+        k = self._next % self.depth
+        self._next += 1
+        ins = self.sets[k]
+        rows = int(hb[0].shape[0])
+        if rows > self.batch or len(hb) != len(ins) or any(int(h.shape[0]) > int(d.shape[0]) for h, d in zip(hb, ins)):
+            raise ValueError("ExtractPipeline: batch does not match the recorded inputs")
+        if self._replayed[k]:
+            # (Also across calls: a second run() without finish() in between refills sets the previous call's last replays may
+            # still be reading -- the copy stream is ordered behind nothing but this wait.)
+            # Bounded run-ahead: the HOST waits here until the replay that read this set has finished, so it is never more
+            # than `depth` batches ahead of the GPU.  Measured (tools/probes/h2d_timeline.py, B = 64, uint8 RGB): with the
+            # host free to enqueue all 40 batches at once the replays behind the enqueue burst take 5.2-6.2 ms instead of
+            # 4.2 (and the enqueue itself 2.3 ms per batch); throttled, every batch takes 4.23 ms -- the resident rate.
+            self.free[k].synchronize()
+        with torch.cuda.stream(self.copy_stream):
+            for dst, src in zip(ins, hb):
+                (dst if src.shape[0] == dst.shape[0] else dst[:src.shape[0]]).copy_(src, non_blocking=True)
+            self.ready[k].record(self.copy_stream)
+        with torch.cuda.stream(self.run_stream):
+            self.run_stream.wait_event(self.ready[k])
+            out = self.plans[k].run()
+            outs = [out] if isinstance(out, Tensor) else list(out)
+            if len(outs) != len(tables):
+                raise ValueError(f"ExtractPipeline: the step returns {len(outs)} tensors, {len(tables)} tables given")
+            for t, o in zip(tables, outs):
+                t[row: row + rows].copy_(o[:rows], non_blocking=True)
+            self.free[k].record(self.run_stream)
+        self._replayed[k] = True
+        return rows
 
     def run(self, batches: Iterable[Sequence[Tensor]], table, row0: int = 0) -> int:
         """Stream ``batches`` (tuples of pinned host tensors shaped like the recorded inputs; any of them may be SHORT in its
@@ -72,35 +107,8 @@ class ExtractPipeline:
         rows enqueued -- call ``finish()`` (or synchronise the device) before reading the tables."""
         tables = [table] if isinstance(table, Tensor) else list(table)
         n = 0
-        for i, hb in enumerate(batches):
-            k = i % self.depth
-            ins = self.sets[k]
-            rows = int(hb[0].shape[0])
-            if rows > self.batch or len(hb) != len(ins) or any(int(h.shape[0]) > int(d.shape[0]) for h, d in zip(hb, ins)):
-                raise ValueError("ExtractPipeline: batch does not match the recorded inputs")
-            if self._replayed[k]:
-                # (Also across calls: a second run() without finish() in between refills sets the previous call's last replays may
-                # still be reading -- the copy stream is ordered behind nothing but this wait.)
-                # Bounded run-ahead: the HOST waits here until the replay that read this set has finished, so it is never more
-                # than `depth` batches ahead of the GPU.  Measured (tools/probes/h2d_timeline.py, B = 64, uint8 RGB): with the
-                # host free to enqueue all 40 batches at once the replays behind the enqueue burst take 5.2-6.2 ms instead of
-                # 4.2 (and the enqueue itself 2.3 ms per batch); throttled, every batch takes 4.23 ms -- the resident rate.
-                self.free[k].synchronize()
-            with torch.cuda.stream(self.copy_stream):
-                for dst, src in zip(ins, hb):
-                    (dst if src.shape[0] == dst.shape[0] else dst[:src.shape[0]]).copy_(src, non_blocking=True)
-                self.ready[k].record(self.copy_stream)
-            with torch.cuda.stream(self.run_stream):
-                self.run_stream.wait_event(self.ready[k])
-                out = self.plans[k].run()
-                outs = [out] if isinstance(out, Tensor) else list(out)
-                if len(outs) != len(tables):
-                    raise ValueError(f"ExtractPipeline: the step returns {len(outs)} tensors, {len(tables)} tables given")
-                for t, o in zip(tables, outs):
-                    t[row0 + n: row0 + n + rows].copy_(o[:rows], non_blocking=True)
-                self.free[k].record(self.run_stream)
-            self._replayed[k] = True
-            n += rows
+        for hb in batches:
+            n += self.submit(hb, tables, row0 + n)
         return n
 
     def finish(self) -> None:
@@ -112,3 +120,58 @@ class ExtractPipeline:
         for p in self.plans:
             p.close()
         self.plans = []
+
+
+class BucketedExtract:
+    """ExtractPipeline for RAGGED lists: one pipeline (= ``depth`` input sets + recorded plans) per padded batch shape.
+
+    A length-sorted list cut by deeplip_amd.ragged.plan_batches reaches the GPU as batches of a dozen distinct padded shapes
+    (the rungs of the length ladder); the lengths themselves travel as an int32 input tensor, so every batch of a rung replays
+    the rung's plan.  Pipelines are created on first use from the batch that needs them (a plan is recorded on representative
+    values) and kept up to ``max_arena_bytes`` of plan arenas, least recently used first out -- a second pass over the list
+    (the bench, an epoch of evaluation) records nothing.  Rows are written in SUBMISSION order; the caller un-sorts once at the
+    end (``table[order] = rows``)."""
+
+    def __init__(self, fn: Callable, depth: int = 2, device: Optional[torch.device] = None, max_arena_bytes: int = 96 << 30):
+        self.fn, self.depth, self.device, self.max_arena_bytes = fn, depth, device, max_arena_bytes
+        self.pipes: dict = {}        # shape key -> ExtractPipeline, in LRU order (dicts keep insertion order)
+        self.recorded = 0            # pipelines recorded so far (tests, the bench's report)
+
+    @staticmethod
+    def _key(hb: Sequence[Tensor]):
+        return tuple((tuple(t.shape[1:]), t.dtype) for t in hb)
+
+    def _arena_bytes(self) -> int:
+        return sum(pl.arena.nbytes() for p in self.pipes.values() for pl in p.plans)
+
+    def pipe_for(self, hb: Sequence[Tensor], batch: int) -> ExtractPipeline:
+        key = (batch,) + self._key(hb)
+        p = self.pipes.pop(key, None)
+        if p is None:
+            full = []
+            for t in hb:           # a short first batch still records the plan at the full batch size (rows repeated)
+                reps = -(-batch // int(t.shape[0]))
+                full.append(torch.cat([t] * reps)[:batch] if int(t.shape[0]) != batch else t)
+            dev = self.device or torch.device("cuda", torch.cuda.current_device())
+            with torch.no_grad():
+                p = ExtractPipeline(self.fn, *(t.to(dev) for t in full), depth=self.depth, device=dev)
+            self.recorded += 1
+        self.pipes[key] = p        # most recently used last
+        while len(self.pipes) > 1 and self._arena_bytes() > self.max_arena_bytes:
+            old_key = next(iter(self.pipes))
+            old = self.pipes.pop(old_key)
+            old.finish()
+            old.close()
+        return p
+
+    def submit(self, hb: Sequence[Tensor], tables: Sequence[Tensor], row: int, batch: int) -> int:
+        return self.pipe_for(hb, batch).submit(hb, tables, row)
+
+    def finish(self) -> None:
+        for p in self.pipes.values():
+            p.finish()
+
+    def close(self) -> None:
+        for p in self.pipes.values():
+            p.close()
+        self.pipes = {}

@@ -86,7 +86,8 @@ def fill_state_dict(shapes: Mapping[str, Tuple[int, ...]], seed: int = DEFAULT_S
 
 
 def video_input(batch: int, frames: int = 29, size: int = 88, seed: int = DEFAULT_SEED,
-                key: str = "input.video", speakers: Sequence[int] | None = None) -> np.ndarray:
+                key: str = "input.video", speakers: Sequence[int] | None = None, utt_ids: Sequence | None = None,
+                jitter: float = 0.3) -> np.ndarray:
     """Synthetic normalised grayscale lip clips ``[B, 1, T, H, W]``.
 
     Each clip is a speaker-specific sum of three drifting low-frequency gratings plus a small
@@ -96,19 +97,23 @@ def video_input(batch: int, frames: int = 29, size: int = 88, seed: int = DEFAUL
     (models/video_models/dataloaders.py:11-22).  White noise alone gives embeddings that are
     0.9997-correlated across clips (bias dominated), which would make cosine / argmax parity
     tests vacuous; the speaker structure makes target trials score higher than non-target ones.
-    ``speakers[i]`` defaults to ``i`` (every clip its own speaker)."""
+    ``speakers[i]`` defaults to ``i`` (every clip its own speaker).  ``utt_ids[i]`` (default ``i``) names the utterance-level
+    generator: a dataset that draws its clips ONE PER CALL passes its own utterance / clip id here and one shared ``key``, so that
+    clips of one speaker share the speaker's gratings and differ only by the utterance jitter (``jitter`` radians of phase) and
+    noise -- with the utterance folded into ``key`` instead (as deeplip_amd.synthetic did until round 5) every utterance was its
+    own "speaker" and trial scores carried no speaker information: EER 0.50 by construction."""
     out = np.empty((batch, 1, frames, size, size), dtype=np.float32)
     u = (np.arange(size, dtype=np.float64) / size)
     tt = (np.arange(frames, dtype=np.float64) / max(frames, 1))
     for i in range(batch):
         s = i if speakers is None else int(speakers[i])
         rs = _rng(f"{key}.spk{s}", seed)
-        ru = _rng(f"{key}.utt{i}", seed)
+        ru = _rng(f"{key}.utt{i if utt_ids is None else utt_ids[i]}", seed)
         img = np.full((frames, size, size), 0.45, dtype=np.float64)
         for _ in range(3):
             fx, fy = rs.uniform(0.5, 4.0, 2)
             ft = rs.uniform(0.0, 2.0)
-            ph = rs.uniform(0.0, 2 * np.pi) + 0.3 * ru.standard_normal()
+            ph = rs.uniform(0.0, 2 * np.pi) + jitter * ru.standard_normal()
             amp = rs.uniform(0.08, 0.2)
             img += amp * np.sin(2 * np.pi * (fx * u[None, None, :] + fy * u[None, :, None]
                                              + ft * tt[:, None, None]) + ph)
@@ -119,20 +124,25 @@ def video_input(batch: int, frames: int = 29, size: int = 88, seed: int = DEFAUL
 
 
 def audio_input(batch: int, feat_dim: int = 24, frames: int = 300, seed: int = DEFAULT_SEED,
-                key: str = "input.audio", speakers: Sequence[int] | None = None) -> np.ndarray:
+                key: str = "input.audio", speakers: Sequence[int] | None = None, utt_ids: Sequence | None = None,
+                session: float = 0.0) -> np.ndarray:
     """Synthetic acoustic features ``[B, F, T]``: speaker-specific spectral envelope +
-    slow per-channel modulation + unit-ish noise (same rationale as ``video_input``)."""
+    slow per-channel modulation + unit-ish noise (same rationale as ``video_input``; ``utt_ids`` as there).  ``session``: the
+    standard deviation of a per-UTTERANCE envelope offset (channel / session variability) beside the speaker's 0.8-sigma envelope
+    -- what keeps a trial list's EER away from zero."""
     out = np.empty((batch, feat_dim, frames), dtype=np.float32)
     tt = np.arange(frames, dtype=np.float64) / 100.0
     for i in range(batch):
         s = i if speakers is None else int(speakers[i])
         rs = _rng(f"{key}.spk{s}", seed)
-        ru = _rng(f"{key}.utt{i}", seed)
+        ru = _rng(f"{key}.utt{i if utt_ids is None else utt_ids[i]}", seed)
         env = rs.standard_normal(feat_dim)
         fm = rs.uniform(0.2, 3.0, feat_dim)
         ph = rs.uniform(0, 2 * np.pi, feat_dim) + 0.3 * ru.standard_normal(feat_dim)
         x = (0.8 * env[:, None] + 0.5 * np.sin(2 * np.pi * fm[:, None] * tt[None, :] + ph[:, None])
              + 0.6 * ru.standard_normal((feat_dim, frames)))
+        if session:
+            x = x + session * _rng(f"{key}.sess{i if utt_ids is None else utt_ids[i]}", seed).standard_normal(feat_dim)[:, None]
         out[i] = x.astype(np.float32)
     return out
 

@@ -380,10 +380,14 @@ int dlip_cmvn_nct_f32(const float* feat, const float* energy, float* y, int32_t 
  * x [B,C,NF] -> y [B,(1+order)C,NF] = [x | delta(x, N=1) | delta(x, N=2)], python_speech_features.delta with edge
  * padding; order 1 or 2. */
 int dlip_delta_nct_f32(const float* x, float* y, int32_t B, int32_t C, int32_t NF, int32_t order, dlip_stream_t stream);
-/* uint8 frames [n, channels(1|3), H, W] -> centre crop [n, crop, crop] float = ((gray)/255 - 0.421)/0.165
- * (models/video_models/dataloaders.py:11-22; RGB -> gray with the BT.601 weights). */
-int dlip_crop_normalize_u8(const uint8_t* x, float* y, int64_t n_frames, int32_t channels, int32_t H,
-                           int32_t W, int32_t crop, dlip_stream_t stream);
+/* uint8 frames [n, channels(1|3), H, W] (n = B clips of T frames) -> crop [n, crop, crop] float = ((gray)/255 - 0.421)/0.165
+ * (models/video_models/dataloaders.py:11-22; RGB -> gray with the BT.601 weights).  clip_params NULL: the "val" / "test"
+ * pipeline's CenterCrop (preprocess.py:89-90); clip_params (device int32 [B][4] = (oy, ox, flip, 0); ABI 43): the "train"
+ * pipeline's RandomCrop + HorizontalFlip (preprocess.py:95-138, dataloaders.py:13-17), one host draw per clip.  lengths
+ * (device int32 [B], NULL = whole clips): frames t >= lengths[b] are written as zeros of the normalised clip -- the padding
+ * of pad_packed_collate, which pads AFTER the normalisation (dataset.py:117,130-134). */
+int dlip_crop_normalize_u8(const uint8_t* x, const int32_t* clip_params, const int32_t* lengths, int32_t T, float* y,
+                           int64_t n_frames, int32_t channels, int32_t H, int32_t W, int32_t crop, dlip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Train-mode / backward kernels for the trainable fusion head and criterion (config C5; the

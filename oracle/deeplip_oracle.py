@@ -622,3 +622,23 @@ def video_preprocess_u8(frames_u8: np.ndarray, crop: int = 88) -> np.ndarray:
     dh, dw = int(round((h - crop)) / 2.), int(round((w - crop)) / 2.)         # preprocess.py:89-90 CenterCrop, verbatim: floor(margin / 2)
     x = x[:, dh:dh + crop, dw:dw + crop] / np.float32(255.0)
     return ((x - np.float32(0.421)) / np.float32(0.165)).astype(np.float32)
+
+
+def video_preprocess_train_u8(frames_u8: np.ndarray, rng, crop: int = 88, flip_ratio: float = 0.5):
+    """dataloaders.py:13-17 'train' pipeline: Normalize(0,255) -> RandomCrop(crop) -> HorizontalFlip(0.5) -> Normalize(0.421,0.165)
+    on [T,H,W] gray (or [T,3,H,W] RGB through the BT.601 gray).  ``rng``: a ``random.Random`` standing for the module-level generator
+    the reference draws from -- RandomCrop takes ``randint(0, w - tw)`` THEN ``randint(0, h - th)`` (preprocess.py:110-111, both ends
+    inclusive), HorizontalFlip flips every frame of the clip iff ``random() < flip_ratio`` (:134-136, cv2.flip(frame, 1) = left-right).
+    Returns (clip [T,crop,crop] float32, (delta_h, delta_w, flipped))."""
+    x = frames_u8.astype(np.float32)
+    if x.ndim == 4:
+        x = np.float32(0.299) * x[:, 0] + np.float32(0.587) * x[:, 1] + np.float32(0.114) * x[:, 2]
+    x = x / np.float32(255.0)                                            # Normalize(0.0, 255.0)
+    h, w = x.shape[-2:]
+    dw = rng.randint(0, w - crop)
+    dh = rng.randint(0, h - crop)
+    x = x[:, dh:dh + crop, dw:dw + crop]                                 # RandomCrop
+    flipped = rng.random() < flip_ratio
+    if flipped:
+        x = x[:, :, ::-1]                                                # HorizontalFlip: cv2.flip(frame, 1)
+    return ((x - np.float32(0.421)) / np.float32(0.165)).astype(np.float32), (dh, dw, int(flipped))

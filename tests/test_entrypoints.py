@@ -17,7 +17,7 @@ def test_train_video_cpu_plumbing(tmp_path):
     assert data.shape == (4, 29, 88, 88) and lengths == sorted(lengths, reverse=True) and lengths[0] == 29
     assert float(data[-1, lengths[-1]:].abs().max()) == 0.0 if lengths[-1] < 29 else True
     rgb, _, _ = train_video.synthetic_batch(args, 0, rgb=True)
-    assert rgb.shape == (4, 29, 3, 88, 88) and rgb.dtype == torch.uint8
+    assert rgb.shape == (4, 29, 3, 96, 96) and rgb.dtype == torch.uint8      # --frame-size mouth crops: cropped to 88 on the GPU
     res = train_video.main(["--device", "cpu", "--save-path", str(tmp_path / "ck"), "--steps", "2"])
     assert res is None and os.path.exists(tmp_path / "ck" / "1.pt")
 
@@ -170,16 +170,16 @@ def test_train_audio_reference_method_names_and_av_test_flow(tmp_path, monkeypat
         assert os.path.exists(root + "/net_1.pth")
         t = tr.extract_train_xv()                                          # :234-258: not normalised
         assert t.emb.shape == (18, 512) and np.abs(t.emb.norm(dim=1).cpu().numpy() - 1).max() > 1e-3
-        assert np.load(root + "/train_xv/s0/s0_u0.npy").shape == (1, 512)
+        assert np.load(root + "/train_xv/s0/s0_u00.npy").shape == (1, 512)
         tr.extract_test_xv()
         e, thr = utils.eer(tr.log_time)                                    # :499-503
         assert (e, thr) == tuple(tr.eer())
         tr.train_plda()                                                    # :298-341
-        assert os.path.exists("exp/plda.pkl") and os.path.exists(root + "/dev_xv_lomgrid/s0_u0.npy")
+        assert os.path.exists("exp/plda.pkl") and os.path.exists(root + "/dev_xv_lomgrid/s0_u00.npy")
         for name in ("lomgrid", "grid"):
             tab = getattr(tr, "extract_test_xv_" + name)()                 # :375-437
             assert np.abs(tab.emb.norm(dim=1).cpu().numpy() - 1).max() < 1e-5
-            assert np.load(root + "/test_xv_{}/s0/s0_u0.npy".format(name)).shape == (1, 512)
+            assert np.load(root + "/test_xv_{}/s0/s0_u00.npy".format(name)).shape == (1, 512)
             e, _ = getattr(utils, "eer_cos_" + name)(tr.log_time)
             ep, _ = getattr(utils, "eer_plda_" + name)(tr.log_time)
             assert 0 <= e <= 1 and 0 <= ep <= 1

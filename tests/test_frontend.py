@@ -97,7 +97,35 @@ def test_video_frontend_vs_oracle():
     ref = ((0.299 * odd[0, :, 0].float() + 0.587 * odd[0, :, 1].float() + 0.114 * odd[0, :, 2].float())[:, 1:89, 3:91] / 255.0 - 0.421) / 0.165
     assert np.abs(yo[0, 0].cpu().numpy() - ref.numpy()).max() < 1e-4
     assert lengths == [5, 3] and batch.shape == (2, 1, 5, 88, 88)
-    assert np.abs(batch[1, 0, 3:].cpu().numpy() - (0.0 - 0.421) / 0.165).max() < 1e-5   # zero-padded RAW frames
+    assert float(batch[1, 0, 3:].abs().max()) == 0.0      # padded AFTER the normalisation (dataset.py:117,130-134): zeros
+    assert np.abs(batch[1, 0, :3].cpu().numpy() - O.video_preprocess_u8(gray[0, :3].numpy())).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_video_frontend_train_pipeline_bit_exact():
+    """The 'train' pipeline (dataloaders.py:13-17: RandomCrop(88) + HorizontalFlip(0.5) per clip, preprocess.py:95-138) on 91 x 95
+    frames: the crop origins and flips the host draws (ops.draw_clip_params, the reference's draw order) applied by the ingest
+    kernel == the oracle's restatement driven by the same generator state, BIT FOR BIT; gray and RGB; with a ragged batch's
+    padding frames zeroed."""
+    import random
+    from deeplip_amd import ops
+    from deeplip_amd.frontend import VideoFrontend
+    g = torch.Generator().manual_seed(9)
+    vf = VideoFrontend(88)
+    for shape in ((5, 4, 91, 95), (5, 4, 3, 91, 95)):
+        fr = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+        params = ops.draw_clip_params(5, 91, 95, crop=88, rng=random.Random(1))
+        lengths = torch.tensor([4, 2, 4, 1, 3], dtype=torch.int32)
+        y = vf(fr.cuda(), clip_params=torch.from_numpy(params).cuda(), lengths=lengths.cuda())
+        torch.cuda.synchronize()
+        rng = random.Random(1)
+        for b in range(5):
+            want, drawn = O.video_preprocess_train_u8(fr[b].numpy(), rng)
+            assert tuple(params[b, :3]) == drawn
+            T = int(lengths[b])
+            assert np.array_equal(y[b, 0, :T].cpu().numpy(), want[:T]), (shape, b)
+            assert float(y[b, 0, T:].abs().max()) == 0.0 if T < 4 else True
+    assert params[:, 2].min() == 0 and params[:, 2].max() == 1       # both coin faces were exercised
 
 
 def test_oracle_delta_known_answers():

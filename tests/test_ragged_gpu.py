@@ -300,3 +300,38 @@ def test_stem_prepass_zeroes_padding_frames_and_flips():
             assert torch.equal(yp[b], yb[0]), b
     finally:
         packing.set_precision("f32")
+
+
+# ------------------------------------------------------------------------------------------ the extraction flow
+def test_ragged_extractor_equals_one_at_a_time(video_net):
+    """deeplip_amd.extract.RaggedExtractor over a ragged synthetic list (1-2 clips per utterance, short batches, several length
+    rungs, uint8 RGB frames): every row of both tables == the engine run on that utterance's audio / clips alone, in LIST order;
+    a second pass over the list records no further plan."""
+    from deeplip_amd import ops, packing
+    from deeplip_amd.extract import RaggedExtractor
+    from deeplip_amd.synthetic import SyntheticAVSet, frames_u8_from_clips
+    from models.audio_models.tdnn import SpeakerEmbNet
+    packing.set_precision("f16x3")
+    try:
+        vnet, _ = video_net
+        anet, _ = load(SpeakerEmbNet(etdnn_opts(24)), "ragged.ex.")
+        ds = SyntheticAVSet(3, 5, 2, audio_dim=24, key="ragged.ex", ragged=True, audio_range=(60, 140), video_range=(6, 16))
+        n = len(ds)
+        ex = RaggedExtractor(lambda a, l: anet.extract_embedding(a, lengths=l)[0], lambda v, l: vnet.embed(v, lengths=l),
+                             torch.device(DEV), batch=4, clip_batch=6, waste=0.25)
+        xa, xv = ex.run(ds, 2, n, 512, u8=True)                       # utterances 2 .. n: a shard, as a rank would take
+        first = ex.stats["plans_recorded"]
+        xa2, xv2 = ex.run(ds, 2, n, 512, u8=True)
+        assert ex.stats["plans_recorded"] == first and torch.equal(xa, xa2) and torch.equal(xv, xv2)
+        assert ex.stats["audio_shapes"] >= 2 and ex.stats["video_shapes"] >= 2
+        ex.close()
+        for j, i in enumerate(range(2, n)):
+            want_a = anet.extract_embedding(torch.from_numpy(ds.audio_item(i)[None]).to(DEV))[0]
+            cm = [vnet.embed(torch.from_numpy(frames_u8_from_clips(ds.clip_item(c)[None, None], rgb=True)).to(DEV))
+                  for c in range(int(ds.clip_ptr[i]), int(ds.clip_ptr[i + 1]))]
+            want_v = torch.stack(cm).mean(0)
+            torch.cuda.synchronize()
+            assert rel_err(xa[j:j + 1].cpu().numpy(), want_a.cpu().numpy()) < 1e-6, i
+            assert rel_err(xv[j:j + 1].cpu().numpy(), want_v.cpu().numpy()) < 2e-6, i
+    finally:
+        packing.set_precision("f32")

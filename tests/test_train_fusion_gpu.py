@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 SMALL = {"train.bs": 16, "train.epoch": 2, "train.steps_per_epoch": 3, "data.n_spk": 6, "data.utt_per_spk": 4,
          "data.test_speakers": 4, "data.test_utt_per_spk": 3, "data.trials": 300, "data.trial_targets": 60,
-         "data.video_frames": 9, "data.audio_frames": 120}
+         "data.video_frames": 9, "data.audio_frames": 120, "data.test_audio_frames": [60, 120], "data.test_video_frames": [5, 12],
+         "data.test_clips_per_utt": 2}
 
 
 @pytest.mark.parametrize("loss,fus", [("CrossEntropy", "linear"), ("LMCL", "concat")])
@@ -34,7 +35,7 @@ def test_av_test_flow_matches_oracle(tmp_path, monkeypatch):
     from deeplip_amd import weightgen as wg
     from oracle import deeplip_oracle as O
     monkeypatch.chdir(tmp_path)
-    tr = train_fusion.Trainer("av_test", overrides=dict(SMALL, **{"data.clips_per_utt": 2}))
+    tr = train_fusion.Trainer("av_test", overrides=dict(SMALL, **{"data.clips_per_utt": 2, "data.test_ragged": False}))
     table = tr.extract_test_xv_lomgrid()
     assert table.emb.shape == (12, 1024)
     eer, thr = tr.eer_cos(tr.lomgridtestset, tr.lomgrid_tables, "cos")
@@ -55,6 +56,43 @@ def test_av_test_flow_matches_oracle(tmp_path, monkeypatch):
         ref = O.fuse_av(xva, emv)
     err = float((table.emb.cpu() - ref).abs().max() / ref.abs().max())
     assert err < 1e-4, err
+
+
+def test_av_test_flow_on_a_ragged_list_matches_the_reference_loop(tmp_path, monkeypatch):
+    """The shipped configuration: test utterances of differing duration, 1-2 clip files each (data.test_ragged).  The trainer
+    extracts them in length-bucketed batches (deeplip_amd/extract.py); the oracle walks the list as the reference does --
+    one utterance at a time, its audio and each of its clips at their own lengths, the clips' frame means averaged
+    (train_fusion.py:334-358)."""
+    import train_fusion
+    from deeplip_amd import weightgen as wg
+    from oracle import deeplip_oracle as O
+    monkeypatch.chdir(tmp_path)
+    tr = train_fusion.Trainer("av_test", overrides=dict(SMALL))
+    ds = tr.lomgridtestset
+    assert ds.ragged and len(set(ds.audio_len.tolist())) > 3 and len(set(ds.clip_len.tolist())) > 3
+    table = tr.extract_test_xv_lomgrid()
+    assert table.emb.shape == (12, 1024)
+    st = tr.extract_stats
+    assert st["valid_audio_frames"] == int(ds.audio_len.sum()) and st["valid_video_frames"] == int(ds.clip_len.sum())
+    vsd = O.to_torch_sd(wg.fill_state_dict({k: tuple(v.shape) for k, v in tr.model_video.state_dict().items()}, prefix="video."))
+    asd = O.to_torch_sd(wg.fill_state_dict({k: tuple(v.shape) for k, v in tr.model_audio.state_dict().items()}, prefix="audio."))
+    rows = []
+    with torch.no_grad():
+        for i in range(len(ds)):
+            xva, _ = O.speaker_extract_embedding(asd, torch.from_numpy(ds.audio_item(i)[None]), O.ETDNN_CONTEXT)          # :338
+            em = torch.zeros(1, 512)
+            cl = range(int(ds.clip_ptr[i]), int(ds.clip_ptr[i + 1]))
+            for c in cl:                                                                                                   # :346-348
+                em = em + O.video_time_mean(O.lipreading_features(vsd, torch.from_numpy(ds.clip_item(c)[None, None])))
+            rows.append(O.fuse_av(xva, em / len(cl)))                                                                      # :349-358
+    ref = torch.cat(rows)
+    err = float((table.emb.cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
+    from conftest import assert_close_rel
+    assert_close_rel(table.emb.cpu().numpy(), ref.numpy(), rtol=1e-4, what="ragged fused rows")
+    for mode in ("cos", "scorefusion", "featurefusion"):
+        e, _ = tr.eer_cos(ds, tr.lomgrid_tables, mode)
+        assert 0.0 <= e <= 1.0
 
 
 def test_main_flow_scores_through_the_reference_entry_points(tmp_path, monkeypatch):

@@ -67,11 +67,14 @@ class Trainer(object):
         # the resnet takes [B,1,F,T] with F = the feature dimension of the data section (train_audio.py:183-184)
         F_ = self.model_opts[arch]["input_dim"] if arch != "resnet" else int(d.get("feat_dim", 40))
         self.trainset = SyntheticAVSet(d["n_spk"], d["utt_per_spk"], 0, 1, F_, d["audio_frames"], key="atrain")
-        self.voxtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="atest")
+        # test lists hold utterances of differing duration, as the reference's do (data.test_ragged; train_audio.py:343-373 feeds them
+        # one at a time at their own lengths); the resnet's padded convolutions have no ragged batch
+        rag = dict(ragged=bool(d.get("test_ragged", False)) and arch != "resnet", audio_range=tuple(d.get("test_audio_frames", (137, 412))))
+        self.voxtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="atest", **rag)
         # the reference's three A+V evaluation lists (train_audio.py:119-139: lomgriddevloader / lomgridtestloader / gridtestloader)
-        self.lomgriddevset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="alomdev")
-        self.lomgridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="alomgrid")
-        self.gridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="agrid")
+        self.lomgriddevset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="alomdev", **rag)
+        self.lomgridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="alomgrid", **rag)
+        self.gridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], 0, 1, F_, d["audio_frames"], key="agrid", **rag)
         self.resume = self.train_opts.get("resume", "exp/none/net_avg.pth")
         sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in self.model.state_dict().items()}, prefix="audio.")
         self.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -207,10 +210,24 @@ class Trainer(object):
         ce = self.train_opts["loss"] == "CrossEntropy"
         self.model.eval()
         with torch.no_grad():
-            for b0 in range(0, len(dataset), batch):
-                idx = list(range(b0, min(len(dataset), b0 + batch)))
-                xv, x_a = self.model.extract_embedding(torch.from_numpy(dataset.audio(idx)).to(self.device))
+            if dataset.ragged:
+                # utterances at their own lengths (train_audio.py:343-373 feeds them one by one): length-bucketed batches,
+                # every row equal to the one-at-a-time result (deeplip_amd/extract.py)
+                from deeplip_amd.extract import RaggedExtractor
+                D = self.model.embedding_dim
+                both = torch.empty((0, 2 * D), device=self.device)
+                ex = RaggedExtractor(lambda a, l: torch.cat(self.model.extract_embedding(a, lengths=l), dim=1), None, self.device, batch=batch)
+                try:
+                    both, _ = ex.run(dataset, 0, len(dataset), 2 * D)
+                finally:
+                    ex.close()
+                xv, x_a = both[:, :D].contiguous(), both[:, D:].contiguous()
                 rows.append(x_a if ce else ops.l2_normalize(xv) if normalize else xv)
+            else:
+                for b0 in range(0, len(dataset), batch):
+                    idx = list(range(b0, min(len(dataset), b0 + batch)))
+                    xv, x_a = self.model.extract_embedding(torch.from_numpy(dataset.audio(idx)).to(self.device))
+                    rows.append(x_a if ce else ops.l2_normalize(xv) if normalize else xv)
         table = scoring.EmbeddingTable(dataset.utt_ids, torch.cat(rows))
         _lib.check_range(sync=True)       # a range report of the LAST batch must surface here, not at some later call
         return table

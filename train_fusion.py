@@ -86,10 +86,15 @@ class Trainer(object):
         feat_dim = acfg[acfg["arch"]]["input_dim"]
         self.trainset = SyntheticAVSet(d["n_spk"], d["utt_per_spk"], d["clips_per_utt"], d["video_frames"], feat_dim,
                                        d["audio_frames"], key="train")
-        self.lomgridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], d["clips_per_utt"],
-                                             d["video_frames"], feat_dim, d["audio_frames"], key="lomgrid")
-        self.gridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], d["clips_per_utt"],
-                                          d["video_frames"], feat_dim, d["audio_frames"], key="grid")
+        # test lists: utterances and clips of differing duration, as the reference's are (data.test_ragged; its loop takes each
+        # at its own length, train_fusion.py:334-349) -- 1 .. test_clips_per_utt clip files per utterance
+        rag = dict(ragged=bool(d.get("test_ragged", False)), audio_range=tuple(d.get("test_audio_frames", (137, 412))),
+                   video_range=tuple(d.get("test_video_frames", (11, 75))))
+        tclips = d.get("test_clips_per_utt", d["clips_per_utt"]) if rag["ragged"] else d["clips_per_utt"]
+        self.lomgridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], tclips,
+                                             d["video_frames"], feat_dim, d["audio_frames"], key="lomgrid", **rag)
+        self.gridtestset = SyntheticAVSet(d["test_speakers"], d["test_utt_per_spk"], tclips,
+                                          d["video_frames"], feat_dim, d["audio_frames"], key="grid", **rag)
         n_spk = self.trainset.n_spk
         if self.dry:
             return self._init_dry(acfg, n_spk)
@@ -320,7 +325,19 @@ class Trainer(object):
         n_loc = hi - lo
         xa = torch.empty((n_loc, D), device=self.device)
         xv = torch.empty((n_loc, D), device=self.device)
-        if n_loc:
+        if n_loc and dataset.ragged:
+            # utterances / clips of differing length: length-bucketed batches, one recorded plan per padded shape, every row
+            # equal to the reference's one-at-a-time result (deeplip_amd/extract.py, tests/test_ragged_gpu.py)
+            from deeplip_amd.extract import RaggedExtractor
+            ex = RaggedExtractor(lambda a, l: self.model_audio.extract_embedding(a, lengths=l)[0],          # train_fusion.py:338
+                                 lambda v, l: self.model_video.embed(v, lengths=l),                        # :346-348 (mean over T)
+                                 self.device, batch=batch)
+            try:
+                xa, xv = ex.run(dataset, lo, hi, D)                                                        # :349 inside (clip-group mean)
+            finally:
+                ex.close()
+            self.extract_stats = ex.stats
+        elif n_loc:
             cpu = dataset.clips                        # clips per utterance (constant over a synthetic set)
 
             def host_batch(b0):

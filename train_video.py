@@ -25,6 +25,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import random
 import sys
 
 import numpy as np
@@ -68,7 +69,11 @@ def load_args(argv=None):
                    "nn.DataParallel over every visible GPU, train_video.py:206-207); N > 1 starts its own N-rank job")
     p.add_argument("--steps", type=int, default=2, help="synthetic iterations per epoch")
     p.add_argument("--frames", type=int, default=29)
-    p.add_argument("--rgb", action="store_true", help="feed uint8 RGB [B,T,3,88,88] through the ingest kernel")
+    p.add_argument("--rgb", action="store_true",
+                   help="feed uint8 RGB frames [B,T,3,S,S] (S = --frame-size) through the ingest kernel: model.train() batches get the "
+                        "reference's train pipeline -- RandomCrop(88) + HorizontalFlip(0.5) per clip, dataloaders.py:13-17 -- everything "
+                        "else the val pipeline's CenterCrop(88)")
+    p.add_argument("--frame-size", type=int, default=96, help="side of the synthetic uint8 mouth crops (LRW ROIs are 96 x 96)")
     p.add_argument("--head-only", action="store_true", help="train tcn.tcn_output on frozen eval-mode features")
     p.add_argument("--graph-step", action="store_true",
                    help="record the optimisation step once and replay it as one HIP graph (deeplip_amd.train_plan.TrainStepGraph: "
@@ -107,10 +112,11 @@ def synthetic_batch(args, it, rgb=False):
     for i in range(args.batch_size):
         spk = int(r.integers(args.num_classes))
         T = args.frames if i == 0 else int(r.integers(max(2, args.frames // 3), args.frames + 1))
-        clip = wg.video_input(1, T, 88, key=f"tv.{it}.{i}", speakers=[spk])[0, 0]            # [T,88,88] normalised gray
+        size = args.frame_size if rgb else 88
+        clip = wg.video_input(1, T, size, key=f"tv.{it}.{i}", speakers=[spk])[0, 0]          # [T,S,S] normalised gray
         if rgb:
             g = np.clip((clip * 0.165 + 0.421) * 255.0, 0, 255).astype(np.uint8)
-            clip = np.repeat(g[:, None], 3, axis=1)                                            # [T,3,88,88] uint8
+            clip = np.repeat(g[:, None], 3, axis=1)                                            # [T,3,S,S] uint8: the loader's frames
         items.append((clip, spk))
     return pad_packed_collate(items)
 
@@ -148,6 +154,8 @@ def train(model, args, device):
         optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=1e-4)                  # (:112-113)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=5, eta_min=4e-08)      # (:114)
     last = None
+    aug_rng = random.Random(SEED + rank)      # the train pipeline's crop / flip draws (the reference: the `random` module, preprocess.py)
+    frontend = None
     if device.type == "cpu" and rank == 0:
         print("[plumbing] --device cpu exercises config / collate / optimizer / scheduler / checkpoint plumbing ONLY (BASELINE config C1): the "
               "engine has no CPU arithmetic path by design, so no forward runs and no loss or logits exist here; the same command on "
@@ -182,7 +190,17 @@ def train(model, args, device):
                 optimizer.step(); sched.step()
                 continue
             labels = labels.to(device)
-            x = ops.ingest_rgb_u8(inputs.to(device)) if args.rgb else inputs.unsqueeze(1).to(device)   # :125
+            if args.rgb:
+                # uint8 frames -> normalised 88 x 88 gray clips on the GPU: RandomCrop + HorizontalFlip per clip while the model
+                # trains (dataloaders.py:13-17), CenterCrop otherwise (:19-24); padding frames = zeros of the normalised clip
+                from deeplip_amd.frontend import VideoFrontend
+                frontend = frontend or VideoFrontend(88)
+                cp = None
+                if full:
+                    cp = torch.from_numpy(ops.draw_clip_params(inputs.shape[0], inputs.shape[-2], inputs.shape[-1], 88, rng=aug_rng)).to(device)
+                x = frontend(inputs.to(device), clip_params=cp, lengths=torch.as_tensor(lengths, dtype=torch.int32).to(device))
+            else:
+                x = inputs.unsqueeze(1).to(device)                                                      # :125
             if plan is not None:
                 loss, logits = plan.step(x.contiguous(), labels, torch.as_tensor(lengths, dtype=torch.int32).to(device))
                 sched.step()
