@@ -328,7 +328,9 @@ def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan):
                 "extract_utt_per_s": round(passes * n / extract_s, 1), "h2d_mb_per_pair": round(h2d_mb, 3),
                 "h2d_gb_per_s": round(passes * n / extract_s * h2d_mb / 1e3, 2),
                 "trials_per_s": round(20000 / (ms * 1e-3), 0), "scoring_ms": round(ms, 4), "eer": round(float(eer), 6),
-                "eer_note": "random-init weights do not separate speakers: the EER value carries no meaning, its agreement with the oracle does",
+                "eer_note": "random-init weights, but the synthetic list's speakers share their generators across utterances and carry "
+                            "session variability beside them (SyntheticAVSet session / jitter = 1): the EER sits mid-range, so its agreement "
+                            "with the oracle's EER on the same table is a real check of the scoring path",
                 "threshold": round(float(thr), 6), "_table": table, "_trials": (y, ia.cpu().numpy(), ib.cpu().numpy(), scores)}
 
     def c4_ragged(rect):

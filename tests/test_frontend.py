@@ -114,11 +114,11 @@ def test_video_frontend_train_pipeline_bit_exact():
     vf = VideoFrontend(88)
     for shape in ((5, 4, 91, 95), (5, 4, 3, 91, 95)):
         fr = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
-        params = ops.draw_clip_params(5, 91, 95, crop=88, rng=random.Random(1))
+        params = ops.draw_clip_params(5, 91, 95, crop=88, rng=random.Random(7))
         lengths = torch.tensor([4, 2, 4, 1, 3], dtype=torch.int32)
         y = vf(fr.cuda(), clip_params=torch.from_numpy(params).cuda(), lengths=lengths.cuda())
         torch.cuda.synchronize()
-        rng = random.Random(1)
+        rng = random.Random(7)
         for b in range(5):
             want, drawn = O.video_preprocess_train_u8(fr[b].numpy(), rng)
             assert tuple(params[b, :3]) == drawn
