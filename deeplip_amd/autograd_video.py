@@ -11,6 +11,8 @@ parameters keep the reference layouts, so the state dict is the reference's.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -128,6 +130,8 @@ class _WeightPrep:
         self.side = None
         self.event = None
         self.joined = set()
+        self.step = 0              # prepare() calls so far (Python-side: a replayed graph adds none)
+        self.pinned = False        # a stream capture has seen this registry: a recorded graph may address its buffers -> nothing is dropped
 
     def __deepcopy__(self, memo):     # (a copied / pickled model starts with an empty registry: addresses, streams and events are this one's)
         return _WeightPrep()
@@ -137,6 +141,8 @@ class _WeightPrep:
 
     def lookup(self, key, w_ref):
         e = self.entries.get(key)
+        if e is not None:
+            e["seen"] = self.step
         if e is not None and e["ver"] == w_ref._version and e["ver"] >= 0:
             self.stats["hit"] += 1
             st = torch.cuda.current_stream()
@@ -153,8 +159,12 @@ class _WeightPrep:
             # persistent buffers of the registry (the caller's ws / wsc are step-local temporaries)
             # (a DETACHED alias: it shares storage and version counter with the parameter, and keeps no autograd node alive --
             # holding the view the forward made, grad_fn and all, across steps crashed the end of a later step-graph capture)
-            self.entries[key] = dict(t=w_ref.detach(), Ko=Ko, Ci=Ci, T=T, mode=mode, Cw=Cw, rows=rows, ver=-1,
-                                     ws=torch.empty_like(ws), wsc=torch.empty_like(wsc))
+            # ... and a WEAK reference to the tensor that owns the storage (the nn.Parameter; for `weight.view(...)` its base):
+            # the alias alone pins the old storage for ever, so `param.data = ...` / `model.to()` / a deleted model could never be
+            # noticed by comparing the alias's address with the key -- the owner's current address is what tells
+            base = w_ref._base if w_ref._base is not None else w_ref
+            self.entries[key] = dict(t=w_ref.detach(), base=weakref.ref(base), off=key[0] - base.data_ptr(), Ko=Ko, Ci=Ci, T=T, mode=mode,
+                                     Cw=Cw, rows=rows, ver=-1, seen=self.step, ws=torch.empty_like(ws), wsc=torch.empty_like(wsc))
             self.order.append(key)
 
     def _build(self, device):
@@ -182,9 +192,20 @@ class _WeightPrep:
             for k in self.order:
                 self.entries[k]["ver"] = -1
             return
-        # (a moved / reallocated parameter would leave a dangling address in the table: such entries are dropped)
-        dead = [k for k in self.order if self.entries[k]["t"].data_ptr() != k[0]]
-        if dead and not torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        self.pinned = self.pinned or capturing
+        self.step += 1
+
+        # Dropped: entries whose owner is gone or holds other storage now (`param.data = ...`, `.to()`, `.float()`, a deleted
+        # model) -- their images would be re-split every step for nobody and pin the old weights plus two image buffers each --
+        # and entries no convolution asked for during the last 8 steps (direct conv_train calls on weights that are not
+        # this model's: the anonymous registry).  Never under a capture, never once a recorded graph may address the buffers.
+        def _dead(k):
+            e = self.entries[k]
+            b = e["base"]()
+            return b is None or b.data_ptr() + e["off"] != k[0] or self.step - e["seen"] > 8
+        dead = [k for k in self.order if _dead(k)] if not self.pinned else []
+        if dead and not capturing:
             for k in dead:
                 del self.entries[k]
             self.order = [k for k in self.order if k in self.entries]

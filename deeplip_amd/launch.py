@@ -63,18 +63,21 @@ def self_launch(script: str, argv: Sequence[str], nproc: int, relay=None, env=No
     e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or nproc) // nproc)))
     e["DLIP_LAUNCHED_BY"] = str(os.getpid())
     print(f"[launch] {nproc} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    # The job gets its own session (= process group): the launcher can then end exactly the processes it started -- the
-    # torch.distributed.run child AND its N ranks -- by group id, also when it is itself told to stop.
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=e, start_new_session=True)
-
     def _stop(signum, _frame):
         raise _Terminated(signum)
 
+    # Handlers FIRST, the job second: the job runs in its own session and no longer receives the terminal's SIGINT / SIGHUP, so a
+    # signal that found the launcher between Popen and signal.signal() would kill it by the default action and orphan all N ranks.
     old = {}
-    if threading.current_thread() is threading.main_thread():        # signal.signal is main-thread only
+    main = threading.current_thread() is threading.main_thread()    # signal.signal / pthread_sigmask of this thread: main thread only
+    if main:
         for sig in (signal.SIGTERM, signal.SIGHUP):
             old[sig] = signal.signal(sig, _stop)
+    p = None
     try:
+        # The job gets its own session (= process group): the launcher can then end exactly the processes it started -- the
+        # torch.distributed.run child AND its N ranks -- by group id, also when it is itself told to stop.
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=e, start_new_session=True)
         for line in p.stdout:
             if relay is None:
                 sys.stdout.write(line)
@@ -84,13 +87,25 @@ def self_launch(script: str, argv: Sequence[str], nproc: int, relay=None, env=No
         rc = p.wait()
     except BaseException as ex:
         # a harness timeout / scheduler preemption (SIGTERM, SIGHUP), Ctrl-C, or an error in relay(): the job must not outlive
-        # its launcher holding the GPUs.  The exact process group we started, nothing by pattern.
-        _kill_group(p, signal.SIGTERM)
+        # its launcher holding the GPUs.  The exact process group we started, nothing by pattern.  The teardown itself runs with
+        # the stop signals BLOCKED: a second SIGTERM during the grace wait used to raise inside this handler and skip the
+        # escalation to SIGKILL.
+        if main:
+            signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM, signal.SIGHUP, signal.SIGINT})
         try:
-            p.wait(timeout=30)
-        except subprocess.TimeoutExpired:
-            _kill_group(p, signal.SIGKILL)
-            p.wait()
+            if p is not None:
+                _kill_group(p, signal.SIGTERM)
+                try:
+                    p.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    _kill_group(p, signal.SIGKILL)
+                    p.wait()
+        finally:
+            if main:
+                for sig, h in old.items():          # (restored before unblocking: a pending stop signal then takes its old course)
+                    signal.signal(sig, h)
+                old = {}
+                signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM, signal.SIGHUP, signal.SIGINT})
         if isinstance(ex, _Terminated):
             print(f"[launch] signal {ex.signum}: job stopped", file=sys.stderr, flush=True)
             return 128 + ex.signum

@@ -70,26 +70,47 @@ class PLDA:
         return cls(m, np.linalg.inv(A), psi, relevant, pca_mean, pca_comp)
 
     # ---- exp/plda.pkl (train_audio.py:339-341: joblib.dump(classifier, 'exp/plda.pkl')) ----
+    FORMAT = "deeplip_amd.plda/2"
+
     def save(self, path: str) -> None:
-        """A joblib file holding a plain dict of arrays (no pickled classes: loading it executes nothing)."""
+        """This build's file: a numpy ``.npz`` archive of plain arrays written under the reference's file NAME (no pickle inside:
+        ``load`` reads it with ``allow_pickle=False``, so loading it executes nothing)."""
         import os
-        import joblib
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        joblib.dump({"format": "deeplip_amd.plda/1", "m": self.m, "inv_A": self.inv_A, "psi": self.psi, "relevant": self.relevant,
-                     "pca_mean": self.pca_mean, "pca_components": self.pca_components}, path)
+        arrays = {"format": np.array(self.FORMAT), "m": self.m, "inv_A": self.inv_A, "psi": self.psi, "relevant": np.asarray(self.relevant)}
+        if self.pca_components is not None:
+            arrays.update(pca_mean=self.pca_mean, pca_components=self.pca_components)
+        with open(path, "wb") as f:           # (a file object: np.savez would append ".npz" to a path)
+            np.savez(f, **arrays)
 
     @classmethod
-    def load(cls, path: str) -> "PLDA":
-        """This build's file, or the reference's: there the object is a ``plda.Classifier`` (RaviSoji/plda), which joblib can
-        only rebuild where that package is installed; its fitted model's parameters are then taken over (``model.m``,
+    def load(cls, path: str, allow_pickle: bool = None) -> "PLDA":
+        """This build's archive (arrays only, nothing is executed), or -- ONLY ON REQUEST -- the reference's file: there the object is
+        a pickled ``plda.Classifier`` (RaviSoji/plda), and unpickling runs whatever code the file names.  ``allow_pickle`` (default:
+        the environment's DLIP_ALLOW_PICKLED_CHECKPOINTS=1, the same switch as pickled checkpoints, train_audio.py) lets joblib
+        rebuild it where that package is installed; its fitted model's parameters are then taken over (``model.m``,
         ``model.inv_A``, ``model.Psi`` (diagonal), ``model.relevant_U_dims``, ``model.pca``)."""
+        import os
+        import zipfile
+        if os.path.exists(path) and zipfile.is_zipfile(path):
+            with np.load(path, allow_pickle=False) as z:
+                if not str(z["format"]).startswith("deeplip_amd.plda/"):
+                    raise RuntimeError(f"{path}: not a deeplip_amd PLDA archive")
+                pca = "pca_components" in z.files
+                return cls(z["m"], z["inv_A"], z["psi"], z["relevant"], z["pca_mean"] if pca else None, z["pca_components"] if pca else None)
+        if allow_pickle is None:
+            allow_pickle = os.environ.get("DLIP_ALLOW_PICKLED_CHECKPOINTS") == "1"
+        if not allow_pickle:
+            raise RuntimeError(f"{path} is not this build's PLDA archive; if it is the reference's joblib pickle of a `plda.Classifier`, "
+                               "loading it runs code from the file: pass allow_pickle=True (or set DLIP_ALLOW_PICKLED_CHECKPOINTS=1) "
+                               "if you trust it, or re-fit with Trainer.train_plda()")
         import joblib
         try:
             obj = joblib.load(path)
         except ModuleNotFoundError as ex:
             raise RuntimeError(f"{path} pickles a classifier of the third-party `plda` package, which is not installed here; "
                                "re-fit with Trainer.train_plda() (writes a plain-array file) or install the package") from ex
-        if isinstance(obj, dict) and str(obj.get("format", "")).startswith("deeplip_amd.plda/"):
+        if isinstance(obj, dict) and str(obj.get("format", "")).startswith("deeplip_amd.plda/"):      # round 4's joblib dict of arrays
             return cls(obj["m"], obj["inv_A"], obj["psi"], obj["relevant"], obj.get("pca_mean"), obj.get("pca_components"))
         model = getattr(obj, "model", obj)
         psi = np.asarray(model.Psi, dtype=np.float64)

@@ -77,20 +77,28 @@ def test_path_resolution_order(tmp_path, monkeypatch):
         se.set_paths("eer_cos_lomgrid"); se.set_paths()
 
 
-def test_plda_file_round_trip_and_foreign_pickle(tmp_path):
-    """exp/plda.pkl written by this build is a joblib dict of arrays; a file that pickles a class of a package that is not
-    installed (the reference's `plda.Classifier`) is refused with an explanation, not a bare ModuleNotFoundError."""
-    import joblib
+def test_plda_file_round_trip_and_foreign_pickle(tmp_path, monkeypatch):
+    """exp/plda.pkl written by this build is a numpy archive of arrays read with allow_pickle=False (loading it executes nothing);
+    anything else -- the reference's joblib pickle of a `plda.Classifier` -- is loaded only on request (allow_pickle / the
+    pickled-checkpoint switch), and a pickle of a package that is not installed is refused with an explanation."""
+    import zipfile
     from deeplip_amd.plda import PLDA
+    monkeypatch.delenv("DLIP_ALLOW_PICKLED_CHECKPOINTS", raising=False)
     r = np.random.default_rng(3)
     X = np.concatenate([c + 0.5 * r.normal(size=(8, 12)) for c in r.normal(size=(6, 12))])
     m = PLDA.fit(X, np.repeat(np.arange(6), 8), n_principal_components=5)
     p = str(tmp_path / "exp" / "plda.pkl")
     m.save(p)
-    assert isinstance(joblib.load(p), dict)
+    assert zipfile.is_zipfile(p) and all(v.dtype != object for v in np.load(p, allow_pickle=False).values())
     m2 = PLDA.load(p)
     np.testing.assert_array_equal(m.transform_np(X), m2.transform_np(X))
     np.testing.assert_array_equal(m.psi, m2.psi)
+    # a foreign file: refused unless asked for
+    foreign = str(tmp_path / "foreign.pkl")
+    import joblib
+    joblib.dump({"anything": 1}, foreign)
+    with pytest.raises(RuntimeError, match="allow_pickle=True"):
+        PLDA.load(foreign)
     # a stand-in for the reference's classifier object: taken over attribute by attribute (m, inv_A, Psi diagonal MATRIX, pca)
     class _Pca:  # noqa: E306
         mean_, components_ = m.pca_mean, m.pca_components
@@ -98,11 +106,12 @@ def test_plda_file_round_trip_and_foreign_pickle(tmp_path):
     fake = types.SimpleNamespace(model=types.SimpleNamespace(m=m.m, inv_A=m.inv_A, Psi=np.diag(m.psi), relevant_U_dims=m.relevant, pca=_Pca))
     import unittest.mock as mock
     with mock.patch("joblib.load", return_value=fake):
-        m3 = PLDA.load("whatever")
+        m3 = PLDA.load(foreign, allow_pickle=True)
     np.testing.assert_allclose(m3.transform_np(X), m.transform_np(X), rtol=0, atol=0)
+    monkeypatch.setenv("DLIP_ALLOW_PICKLED_CHECKPOINTS", "1")
     with mock.patch("joblib.load", side_effect=ModuleNotFoundError("No module named 'plda'")):
         with pytest.raises(RuntimeError, match="third-party `plda` package"):
-            PLDA.load("whatever")
+            PLDA.load(foreign)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU box only")

@@ -511,3 +511,37 @@ def test_prepared_weight_images_equal_the_per_convolution_ones_and_follow_the_we
     for a, b in zip(third, fourth):
         assert torch.equal(a, b)
     av.WEIGHT_PREP.__init__()
+
+
+def test_weight_registry_drops_entries_whose_owner_moved_or_died():
+    """Round 5 (advisor): the registry's entries held a detached alias of the weight, which pins the OLD storage -- so neither
+    `param.data = ...` nor `model.to()` nor a deleted model could ever be noticed by comparing addresses, and stale entries were
+    re-split every step for nobody.  Now every entry knows its owner weakly: reassigned storage / a dead owner drops the entry at the
+    next prepare, entries nobody asks for age out, and results follow the new weights."""
+    import gc
+    from deeplip_amd import autograd_video as av
+    av.WEIGHT_PREP.__init__()
+    w = torch.nn.Parameter((rnd(64, 32, 3, 3, seed=11) * 0.1).to(DEV))
+    w2 = torch.nn.Parameter((rnd(64, 32, 1, 1, seed=12) * 0.1).to(DEV))
+    x = rnd(2, 6, 6, 32, seed=13).to(DEV)
+    run = lambda: (av.conv_train(x, None, None, (1, 1), (1, 1), (1, 1), w_ref=w).clone(),
+                   av.conv_train(x, None, None, (1, 1), (0, 0), (1, 1), w_ref=w2.view(64, 32, 1, 1)).clone())      # a view: owner = its base
+    first = run()
+    assert len(av.WEIGHT_PREP.order) == 2
+    av.prepare_weights()
+    h0 = av.WEIGHT_PREP.stats["hit"]
+    second = run()
+    assert av.WEIGHT_PREP.stats["hit"] == h0 + 2 and torch.equal(first[0], second[0]) and torch.equal(first[1], second[1])
+    w.data = (w.data * 2.0).clone()                         # new storage: the registered address is the old one
+    av.prepare_weights()
+    assert len(av.WEIGHT_PREP.order) == 1                   # the stale entry is gone (and with it the pinned old weights)
+    third = run()                                           # re-registers at the new address, computes with the new values
+    assert len(av.WEIGHT_PREP.order) == 2 and torch.allclose(third[0], 2.0 * first[0], rtol=1e-5, atol=1e-6)
+    del w2, run
+    gc.collect()
+    av.prepare_weights()
+    assert len(av.WEIGHT_PREP.order) == 1                   # owner deleted
+    for _ in range(10):                                     # nobody asks for the remaining image: it ages out
+        av.prepare_weights()
+    assert len(av.WEIGHT_PREP.order) == 0
+    av.WEIGHT_PREP.__init__()

@@ -485,6 +485,7 @@ def main():
         trainer = Trainer("train", args.config, ov, dry=True)
         trainer()
         # every rank leaves what it holds after the last step: replicas must be bit-identical (the test compares the files)
+        os.makedirs("exp/{}".format(trainer.log_time), exist_ok=True)     # every rank: rank 0's save() may not have run yet / here
         torch.save({k: v.clone() for k, v in trainer.model_fusion.state_dict().items()},
                    "exp/{}/dry_rank{}.pt".format(trainer.log_time, trainer.rank))
         if trainer.rank == 0:
