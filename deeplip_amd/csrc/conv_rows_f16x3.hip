@@ -838,6 +838,11 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_plan(const d
 // ticket round trip, MI x parts serial slab reads), the other half waiting at the next barrier; and every workgroup enters the
 // reduction at its own slice, so layer 4's 4.7 MB of weights per 256-column block no longer stay in an XCD's 4 MiB L2 (the ring
 // kernel keeps an XCD on one 128-column block: 2.35 MB).  What would change it is in DESIGN.md section 9.
+// ROUND 5: a measured negative result belongs in the lab, not in the product library: the general mode's four instances (220-256
+// VGPRs, 65-83 SGPR spills) are compiled ONLY under -DDLIP_LAB (python -m deeplip_amd.build --lab; tests/test_kernels_gpu.py's
+// general-mode tests and tools/probes/rows2d_layers.py load that library through DLIP_LIB_PATH).  In libdeeplip_hip.so the three entry
+// points below decline every launch and dlip_debug_set refuses key 7.
+#ifdef DLIP_LAB
 static bool rows2d_ok(const ConvArgs& a, int epi) {
   const int v = dlip_dbg_value[DLIP_DBG_ROWS2D];
   if (v <= 0 || !dlip_conv_dma_enabled() || epi < 0 || epi > 1) return false;
@@ -874,6 +879,11 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_rows2d_laun
   if (a.x2 != nullptr) return epi ? launch_rows<5, 1, 1, true>(a, st) : launch_rows<5, 0, 1, true>(a, st);
   return epi ? launch_rows<5, 1, 1, false>(a, st) : launch_rows<5, 0, 1, false>(a, st);
 }
+#else
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows2d_ok(const void*, int) { return 0; }
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows2d_plan(const dlip_conv_desc*, int, int*) { return 0; }
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_rows2d_launch(const void*, void*, int) { return DLIP_EINVAL; }
+#endif
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_declined(void) { return kRowsDeclined; }
 
 // The pooled epilogue on this kernel is correct and tested, and slower than the ring kernel's LDS-staged one: the fp64 column

@@ -169,8 +169,8 @@ int dlip_conv_plan(const dlip_conv_desc* d, int32_t split_f16, int32_t* bm, int3
 /* 1 if a split-format (DLIP_SPLIT_IN) launch of `d` runs on the window kernel (conv_win_f16x3_kernel<128,64> for K <= 64, <128,128> above: same-size
  * stride-1 3x3 convolutions with K <= 128 -- one activation window per channel slice in LDS instead of one fetch per
  * tap), 2 if on the rows kernel (conv_rows_f16x3_kernel; dlip_conv_plan then reports its BM x 256 tile): without a residual the
- * speech encoder's 1-D valid convolutions and k = 1 GEMMs over all frames; also, only while dlip_debug_set(7, 1) forces its
- * general mode, any convolution of whole 32-channel slices and <= 32 taps (such a launch still falls back to the ring kernel when
+ * speech encoder's 1-D valid convolutions and k = 1 GEMMs over all frames; also, in the lab library only and only while
+ * dlip_debug_set(7, 1) forces its general mode, any convolution of whole 32-channel slices and <= 32 taps (such a launch still falls back to the ring kernel when
  * its stream has no split workspace of dlip_conv_workspace_bytes()), 0 if on the LDS-DMA ring kernel dlip_conv_plan describes.
  * Host-only. */
 int dlip_conv_kernel_kind(const dlip_conv_desc* d);
@@ -676,7 +676,8 @@ int dlip_range_scope_end(dlip_stream_t stream);
  * 5 tile order of the LDS-DMA kernel (0 column block outer, 1 inner), 6 rows kernel (conv_rows_f16x3.hip: 0 = off, 1 = on for
  * every launch of its shape class whatever the size, 3 | 4 | 5 = on with that tile height in units of 32 rows),
  * 7 the rows kernel's general mode for 2-D filters / residual / second source (1 = on for every eligible launch; anything else:
- * off -- the library never chooses it, see conv_rows_f16x3.hip); key 3 also takes 3 (experiment: slabs of same-XCD tiles through
+ * off -- measured slower than the ring kernel on the trunk, so since ABI 43 it is compiled into the LAB library only
+ * (deeplip_amd.build --lab): the product library returns DLIP_EINVAL for a value > 0); key 3 also takes 3 (experiment: slabs of same-XCD tiles through
  * that XCD's L2) and 4 (the in-kernel finisher where the built-in choice is the reduce launch);
  * value -1 restores the built-in choice. */
 int dlip_debug_set(int32_t key, int32_t value);

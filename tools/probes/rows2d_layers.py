@@ -1,5 +1,7 @@
-"""The trunk's layers 3 / 4 at the bench's batch on the rows kernel's general mode vs the ring kernel (dlip_debug_set(7, 1 | 0)),
+"""(needs the LAB library: DLIP_LIB_PATH=deeplip_amd/lib/libdeeplip_hip_lab.so -- the general mode is not in the product build)
+The trunk's layers 3 / 4 at the bench's batch on the rows kernel's general mode vs the ring kernel (dlip_debug_set(7, 1 | 0)),
 interleaved on one box.     python tools/probes/rows2d_layers.py [B]"""
+
 import sys
 import torch
 sys.path.insert(0, ".")
