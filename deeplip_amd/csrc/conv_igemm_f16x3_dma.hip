@@ -146,7 +146,16 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   const int ntaps = a.R * a.S;
   const int nk1 = a.nk - (DUAL ? a.nk2 : 0);   // slices of the first source
 
-  const long long it_begin = (long long)g * sk.iters / sk.G, it_end = (long long)(g + 1) * sk.iters / sk.G;
+  // PAIRED column blocks (a.n_inner == 2; round 5): the launch's P = tiles_n column blocks are P LANES of the split -- workgroup g
+  // works on column block g % P only, and the (row tile, slice) space of that lane is cut into G / P equal ranges, range g / P.  The P
+  // workgroups of a range are neighbours in work order (one XCD), walk the SAME activation rows at the same time, and so fetch them
+  // into that XCD's L2 once; with the column block merely INNER (n_inner == 1) one workgroup ran a row block's column tiles one after
+  // the other, ~80 us apart, and the rows had left L2 in between (rocprofv3 FETCH_SIZE: the activations of layer 3 read twice).
+  // gv / Gv / itv = workgroup index, grid and slice space of ONE lane (== g, sk.G, sk.iters when P == 1).
+  const int P = a.n_inner == 2 ? a.tiles_n : 1;
+  const int gv = P > 1 ? g / P : g, lane_n = P > 1 ? g - gv * P : 0, Gv = P > 1 ? sk.G / P : sk.G;
+  const long long itv = P > 1 ? sk.iters / P : sk.iters;
+  const long long it_begin = (long long)gv * itv / Gv, it_end = (long long)(gv + 1) * itv / Gv;
   // In-kernel span of this launch (measurement only, off unless a span scope is open: one scalar test; dlip_common.h): what a
   // replayed step plan cannot give the host (no event can be read back from a graph) the kernel notes itself.
   dlip_span_enter(sk.span, g);
@@ -161,10 +170,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     const int tiles_m = (a.M + BM - 1) / BM;
     int tile_n = tile / tiles_m;
     int tile_m = tile - tile_n * tiles_m;
-    if (a.n_inner) {   // column block INNER: consecutive tiles (one workgroup's range, one XCD's eighth) share their activation rows
+    if (a.n_inner == 2) {   // paired lanes: `tile` counts the row tiles of this workgroup's column block
+      tile_m = tile;
+      tile_n = lane_n;
+    } else if (a.n_inner) {   // column block INNER: consecutive tiles (one workgroup's range, one XCD's eighth) share their activation rows
       tile_m = tile / a.tiles_n;
       tile_n = tile - tile_m * a.tiles_n;
     }
+    const int tile_id = P > 1 ? tile * P + lane_n : tile;   // the tile's ticket word (and its number in slab_reduce_kernel's order)
     // every wave is done reading the previous segment's last stage (and the ticket word) before the ring is refilled
     if (it != it_begin) __syncthreads();
     DLIP_STAMP(0);
@@ -547,15 +560,16 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       constexpr int SLAB = BM * BN;   // floats
       volatile int* bcast = reinterpret_cast<volatile int*>(smem);
       const long long t0 = (long long)tile * a.nk;
-      const int gf = (int)(((t0 + 1) * sk.G - 1) / sk.iters);            // owner of the tile's first slice
-      const int gl = (int)(((t0 + a.nk) * sk.G - 1) / sk.iters);         // owner of its last slice
+      const int gf = (int)(((t0 + 1) * Gv - 1) / itv);                   // owner of the tile's first slice (index within the lane)
+      const int gl = (int)(((t0 + a.nk) * Gv - 1) / itv);                // owner of its last slice
       const int others = gl - gf;                                        // parts besides this one
       // (experiment, round 4, off in the product: VERDICT item "slab traffic") parts on one XCD -- neighbours in work order are,
       // except across the 8 XCD boundaries -- share an L2: plain stores (they stop in L2) and sc0 loads (past this CU's L1) would do
       bool l2_local = false;
       if (sk.l2_local && sk.il_tiles == 0 && q8 > 0) {
         const int big = r8 * (q8 + 1);
-        const int xf = gf < big ? gf / (q8 + 1) : r8 + (gf - big) / q8, xl = gl < big ? gl / (q8 + 1) : r8 + (gl - big) / q8;
+        const int pf = gf * P + lane_n, pl = gl * P + lane_n;
+        const int xf = pf < big ? pf / (q8 + 1) : r8 + (pf - big) / q8, xl = pl < big ? pl / (q8 + 1) : r8 + (pl - big) / q8;
         l2_local = xf == xl;
       }
       if (sk.reduce_later) {   // (workgroup-uniform) publish and leave: the kernel boundary makes the slab visible to the reduce launch
@@ -571,7 +585,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       //    part in registers (the usual case for a range's final, head-of-tile segment: the neighbour
       //    computed the rest of that tile first thing).
       __syncthreads();   // all waves are past their last fragment reads: LDS word 0 is free
-      if (tid_e == 0) bcast[0] = __hip_atomic_load(sk.counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid_e == 0) bcast[0] = __hip_atomic_load(sk.counters + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       finish = bcast[0] == others;
       if (!finish) {
@@ -592,14 +606,14 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid_e == 0) bcast[0] = __hip_atomic_fetch_add(sk.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid_e == 0) bcast[0] = __hip_atomic_fetch_add(sk.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         finish = bcast[0] == others;   // the other parts arrived between the peek and the ticket
       }
       if (finish) {
         // 3. acquire on this CU (one lane, then the wait, then the barrier every loading wave passes)
         if (tid_e == 0) {
-          __hip_atomic_store(sk.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+          __hip_atomic_store(sk.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -612,13 +626,13 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
         for (int mi = 0; mi < MI; ++mi) {
           f32x4 t[NI];
           for (int p = gf; p <= gl; ++p) {
-            const long long pb = (long long)p * sk.iters / sk.G;
-            const __amdgpu_buffer_rsrc_t pr = dlip_make_rsrc(sk.slabs + (size_t)(2 * p + (pb < t0 ? 1 : 0)) * SLAB, SLAB * 4);
+            const long long pb = (long long)p * itv / Gv;
+            const __amdgpu_buffer_rsrc_t pr = dlip_make_rsrc(sk.slabs + (size_t)(2 * (p * P + lane_n) + (pb < t0 ? 1 : 0)) * SLAB, SLAB * 4);
             f32x4 v[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
               v[ni] = acc[mi][ni];
-              if (p != g) {
+              if (p != gv) {
                 if (l2_local) v[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 1));
                 else v[ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, ((mi * NI + ni) * NT + tid_e) * 16, 0, 16));
               }
@@ -1017,7 +1031,15 @@ int launch_one(const ConvArgs& a, hipStream_t st) {
   // tdnn k=1 50 -> 48, layer 3 -1..5 %).  Larger banks (layer 4: 9.4 MB) keep the column block OUTER -- there each XCD
   // stays on one 128-channel weight block and re-streams the (L2-sized) activations instead (+4 % if forced inner).
   b.n_inner = (b.tiles_n > 1 && (size_t)a.K * a.rsc * 4 <= (size_t)3407872) ? 1 : 0;
-  if (dlip_dbg_value[DLIP_DBG_NINNER] >= 0) b.n_inner = dlip_dbg_value[DLIP_DBG_NINNER] > 0 ? 1 : 0;
+  // ... and PAIRED (kernel comment at `P`) where the launch has exactly two column blocks of the 256-row tile and enough row tiles
+  // to split -- layer 3 (K = 256): the two blocks of a row range run side by side on one XCD instead of back to back on one CU
+  // (the dominant kernel's FETCH_SIZE per launch 372 -> see profiles/r5/pmc_summary.json; dlip_debug_set(5, 2 | 1 | 0) forces a mode)
+  if (b.n_inner == 1 && b.tiles_n == 2 && BM == 256 && sk.il_tiles == 0 && !sk.reduce_later && (G & 1) == 0 && tiles > 64) b.n_inner = 2;
+  if (dlip_dbg_value[DLIP_DBG_NINNER] >= 0) {
+    const int v = dlip_dbg_value[DLIP_DBG_NINNER];
+    if (v == 2) b.n_inner = (b.tiles_n > 1 && sk.il_tiles == 0 && !sk.reduce_later && G % b.tiles_n == 0) ? 2 : (b.tiles_n > 1 ? 1 : 0);
+    else b.n_inner = v > 0 ? 1 : 0;
+  }
   DLIP_LAB_LAUNCH_HOOK();   // (lab build: DLIP_STAMP_PRINT -> stamped launch + printed medians)
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(threads), lds, st, b, sk);
   if (sk.reduce_later) {

@@ -673,7 +673,8 @@ int dlip_range_scope_end(dlip_stream_t stream);
 /* Diagnostic overrides for tests and A/B runs (the launch path reads no environment variable):
  * key 0 tile of dlip_conv_nhwc_f32 / the register-staged f16x3 kernel, 1 tile of the LDS-DMA kernel,
  * 2 LDS-DMA kernel on/off (0 = off), 3 balanced split (0 never, 2 always), 4 window kernel on/off (0 = off),
- * 5 tile order of the LDS-DMA kernel (0 column block outer, 1 inner), 6 rows kernel (conv_rows_f16x3.hip: 0 = off, 1 = on for
+ * 5 tile order of the LDS-DMA kernel (0 column block outer, 1 inner, 2 the column blocks as lanes of the balanced split: the blocks
+ * of a row range on neighbouring workgroups at the same time -- built in for layer 3's two-block launches), 6 rows kernel (conv_rows_f16x3.hip: 0 = off, 1 = on for
  * every launch of its shape class whatever the size, 3 | 4 | 5 = on with that tile height in units of 32 rows),
  * 7 the rows kernel's general mode for 2-D filters / residual / second source (1 = on for every eligible launch; anything else:
  * off -- measured slower than the ring kernel on the trunk, so since ABI 43 it is compiled into the LAB library only

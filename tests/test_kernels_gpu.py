@@ -965,6 +965,59 @@ def test_wgrad_as_conv_both_layouts(ops, slice_major, N, H, C, K, R, stride, pad
     assert rel_err(got.cpu().numpy(), w.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(1856, 6, 6, 256, 256, 3, 1, True), (1856, 11, 11, 128, 256, 3, 2, False), (300, 6, 6, 256, 384, 3, 1, False),
+                                   (40, 11, 11, 128, 256, 3, 1, True)],
+                         ids=["layer3-res", "layer3.0.conv1-stride2", "three-lanes-forced", "small-128-row-tile"])
+def test_conv_dma_paired_column_blocks(ops, shape):
+    """Round 5: the column blocks of a launch as LANES of the balanced split (a.n_inner == 2): workgroup g works on column block
+    g % P, the P workgroups of a row range run side by side on one XCD.  Layer 3's launches (two 128-column blocks of the 256-row
+    tile) take it by themselves; dlip_debug_set(5, 2) forces it elsewhere (three lanes, a 128-row tile).  Against Conv2d in fp64,
+    against the column-block-INNER order (mode 1: other part boundaries, so fp32 sums in another order: 1e-6), and bit-repeatable
+    under a second stream's load (parts are added in part order whoever finishes)."""
+    from deeplip_amd import _lib, packing
+    N, H, W, C, K, S, stride, use_res = shape
+    R = 1 if H == 1 else S
+    pad = (0 if H == 1 else S // 2, S // 2)
+    x = ops.split_pack((rnd(N, H, W, C, seed=41) * 2.0).cuda())
+    w = rnd(K, R, S, C, seed=42, scale=1.0 / np.sqrt(C * R * S))
+    ws, sc = packing.split_weights(w.double())
+    ws, sc = ws.cuda(), sc.cuda()
+    b = rnd(K, seed=43, scale=0.1).cuda()
+    kw = dict(stride=(stride, stride) if H > 1 else (1, 1), pad=pad, w_scale=sc, x_split=True, out_split=True)
+    probe = ops.conv_nhwc(x, ws, b, **kw)
+    res = ops.split_pack((rnd(*probe.shape, seed=44)).cuda()) if use_res else None
+    outs = {}
+    side = torch.cuda.Stream()
+    junk = torch.empty(32 << 20, device="cuda")
+    try:
+        for mode in (1, 2):
+            _lib.debug_set(_lib.DBG_NINNER, mode)
+            first = ops.conv_nhwc(x, ws, b, residual=res, **kw).clone()
+            y = torch.empty_like(first)
+            bad = 0
+            for i in range(20):
+                if i % 3 == 0:
+                    with torch.cuda.stream(side):
+                        junk.add_(1.0)
+                ops.conv_nhwc(x, ws, b, residual=res, out=y, **kw)
+                bad += int(not torch.equal(y.view(torch.int32), first.view(torch.int32)))
+            torch.cuda.synchronize()
+            assert bad == 0, (mode, bad)
+            outs[mode] = ops.split_unpack(first).cpu()
+        _lib.debug_set(_lib.DBG_NINNER, -1)
+        builtin = ops.split_unpack(ops.conv_nhwc(x, ws, b, residual=res, **kw)).cpu()
+    finally:
+        _lib.debug_set(_lib.DBG_NINNER, -1)
+    ref = F.conv2d(ops.split_unpack(x).cpu().permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.cpu().double(),
+                   stride=kw["stride"], padding=pad)
+    if use_res:
+        ref = ref + ops.split_unpack(res).cpu().permute(0, 3, 1, 2).double()
+    for mode in (1, 2):
+        assert rel_err(outs[mode].permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL, mode
+    assert rel_err(outs[2].numpy(), outs[1].numpy()) < 1e-6
+    assert rel_err(builtin.numpy(), outs[1].numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("N,H,C,K,stride", [(64, 22, 64, 64, 1), (40, 11, 128, 128, 1), (33, 22, 64, 128, 2), (70, 3, 512, 512, 1)])
 def test_split_reduce_launch_is_bit_identical_to_the_in_kernel_finisher(ops, N, H, C, K, stride):
     """Few tiles cut many ways (weight gradients run as convolutions: 1 - 36 tiles, 14 - 100 parts each): the parts are only
