@@ -151,11 +151,17 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
   // workgroups of a range are neighbours in work order (one XCD), walk the SAME activation rows at the same time, and so fetch them
   // into that XCD's L2 once; with the column block merely INNER (n_inner == 1) one workgroup ran a row block's column tiles one after
   // the other, ~80 us apart, and the rows had left L2 in between (rocprofv3 FETCH_SIZE: the activations of layer 3 read twice).
-  // gv / Gv / itv = workgroup index, grid and slice space of ONE lane (== g, sk.G, sk.iters when P == 1).
-  const int P = a.n_inner == 2 ? a.tiles_n : 1;
-  const int gv = P > 1 ? g / P : g, lane_n = P > 1 ? g - gv * P : 0, Gv = P > 1 ? sk.G / P : sk.G;
-  const long long itv = P > 1 ? sk.iters / P : sk.iters;
-  const long long it_begin = (long long)gv * itv / Gv, it_end = (long long)(gv + 1) * itv / Gv;
+  // gv / Gv / itv = workgroup index, grid and slice space of ONE lane (== g, sk.G, sk.iters when P == 1).  They are formed where
+  // they are needed -- here, at a segment's tile decode and in the (rare) hand-off -- from an opaque copy of g, so that none of them
+  // lives across the main loop: carried through it (the first version) they cost every 256 x 128 launch 4 - 10 % in scalar spills.
+  long long it_begin, it_end;
+  {
+    const int P = a.n_inner == 2 ? a.tiles_n : 1;
+    const int gv = P > 1 ? g / P : g, Gv = P > 1 ? sk.G / P : sk.G;
+    const long long itv = P > 1 ? sk.iters / P : sk.iters;
+    it_begin = (long long)gv * itv / Gv;
+    it_end = (long long)(gv + 1) * itv / Gv;
+  }
   // In-kernel span of this launch (measurement only, off unless a span scope is open: one scalar test; dlip_common.h): what a
   // replayed step plan cannot give the host (no event can be read back from a graph) the kernel notes itself.
   dlip_span_enter(sk.span, g);
@@ -170,14 +176,15 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
     const int tiles_m = (a.M + BM - 1) / BM;
     int tile_n = tile / tiles_m;
     int tile_m = tile - tile_n * tiles_m;
-    if (a.n_inner == 2) {   // paired lanes: `tile` counts the row tiles of this workgroup's column block
+    if (a.n_inner == 2) {   // paired lanes: `tile` counts the row tiles of this workgroup's column block g % P
+      int g_o = g;
+      asm volatile("" : "+s"(g_o));   // (opaque: the division below is redone per segment instead of living across the loop)
       tile_m = tile;
-      tile_n = lane_n;
+      tile_n = g_o - (g_o / a.tiles_n) * a.tiles_n;
     } else if (a.n_inner) {   // column block INNER: consecutive tiles (one workgroup's range, one XCD's eighth) share their activation rows
       tile_m = tile / a.tiles_n;
       tile_n = tile - tile_m * a.tiles_n;
     }
-    const int tile_id = P > 1 ? tile * P + lane_n : tile;   // the tile's ticket word (and its number in slab_reduce_kernel's order)
     // every wave is done reading the previous segment's last stage (and the ticket word) before the ring is refilled
     if (it != it_begin) __syncthreads();
     DLIP_STAMP(0);
@@ -560,6 +567,11 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
       constexpr int SLAB = BM * BN;   // floats
       volatile int* bcast = reinterpret_cast<volatile int*>(smem);
       const long long t0 = (long long)tile * a.nk;
+      // (paired lanes) this lane's workgroup index / grid / slice space, and the tile's ticket word = its number in tile_m-major order
+      const int P = a.n_inner == 2 ? a.tiles_n : 1, lane_n = P > 1 ? tile_n : 0;
+      const int gv = P > 1 ? g / P : g, Gv = P > 1 ? sk.G / P : sk.G;
+      const long long itv = P > 1 ? sk.iters / P : sk.iters;
+      const int tile_id = P > 1 ? tile * P + lane_n : tile;
       const int gf = (int)(((t0 + 1) * Gv - 1) / itv);                   // owner of the tile's first slice (index within the lane)
       const int gl = (int)(((t0 + a.nk) * Gv - 1) / itv);                // owner of its last slice
       const int others = gl - gf;                                        // parts besides this one

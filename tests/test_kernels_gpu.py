@@ -1014,8 +1014,8 @@ def test_conv_dma_paired_column_blocks(ops, shape):
         ref = ref + ops.split_unpack(res).cpu().permute(0, 3, 1, 2).double()
     for mode in (1, 2):
         assert rel_err(outs[mode].permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL, mode
-    assert rel_err(outs[2].numpy(), outs[1].numpy()) < 1e-6
-    assert rel_err(builtin.numpy(), outs[1].numpy()) < 1e-6
+    assert rel_err(outs[2].numpy(), outs[1].numpy()) < 3e-6       # other part boundaries: fp32 sums in another order
+    assert rel_err(builtin.numpy(), outs[1].numpy()) < 3e-6
 
 
 @pytest.mark.parametrize("N,H,C,K,stride", [(64, 22, 64, 64, 1), (40, 11, 128, 128, 1), (33, 22, 64, 128, 2), (70, 3, 512, 512, 1)])
