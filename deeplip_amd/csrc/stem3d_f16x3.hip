@@ -452,7 +452,14 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
     dma_piece(xr, off, lds0 + WBYTES + (kt * plane + wave * 256) * 4);
   };
 
-  int tile = blockIdx.x * a.row_tiles;                // a workgroup walks whole frames, row tile after row tile
+  // Which frames: workgroup number wg_f takes frames wg_f, wg_f + G, ...  Round 5: wg_f is NOT blockIdx.x -- consecutive workgroups
+  // sit on consecutive XCDs, and a frame's window is the five input planes f - 2 .. f + 2, so with frames dealt out in blockIdx
+  // order every plane was pulled into FIVE different XCDs' L2 (each 4 MiB, not shared): rocprofv3 FETCH_SIZE 302 MB per launch for a
+  // 62 MB split clip (profiles/r4/pmc_summary.json).  Here an XCD's workgroups take a CONTIGUOUS block of G / 8 frames of every round,
+  // so a plane is fetched by one L2 (two at a block's edge): the ring kernel's remap of its work order, for the same reason.
+  const int q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7;
+  const int wg_f = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  int tile = wg_f * a.row_tiles;                      // a workgroup walks whole frames, row tile after row tile
   if (tile >= ntiles) return;
   if (wave < np) {
 #pragma unroll
