@@ -71,7 +71,7 @@ SIGNATURES = {
     "dlip_wgrad_operand_split_f32": [c_f, c_f, c_i64, c_i64, c_i32, c_f, c_f, c_stream],
     "dlip_wgrad_operand_f32": [c_f, c_f, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_stream],
     "dlip_stem_wgrad_chwn_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
-    "dlip_wgrad_conv_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f] + [c_i32] * 13 + [c_stream],
+    "dlip_wgrad_conv_f16x3": [c_f, c_f, c_f, c_f, c_f, c_f] + [c_i32] * 15 + [c_stream],
     "dlip_wgrad_chwn_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_i32, c_f, c_stream],
     "dlip_tap_gather_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_upsample_zero_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],

@@ -386,15 +386,21 @@ WGRAD = "conv"
 # walks are adjacent 128-byte lines, dlip_wgrad_conv_f16x3) or pixel-major ([image][H][W][N32] through dlip_conv_nhwc_f16x3: every
 # piece a DRAM page of its own -- kept for A/B runs and as the second implementation the tests compare).
 WGRAD_SLICE_MAJOR = True
+# Round 5: the weight-gradient convolution's epilogue stores dW in the reference layout [K, C, R, S] itself (dlip_wgrad_conv_f16x3's
+# R, S): no [C, R', S', K] tensor, slice copy and permute launch behind every one of them.  False: round 4's path (tests compare the two).
+WGRAD_DIRECT_LAYOUT = __import__("os").environ.get("DLIP_WGRAD_DIRECT", "1") != "0"      # (the environment switch: same-box A/B runs)
 
 
-def _wgrad_conv_launch(xT, gT, inv, C_, H, W, K, Ho, Wo, N32, stride, pad, dil):
+def _wgrad_conv_launch(xT, gT, inv, C_, H, W, K, Ho, Wo, N32, stride, pad, dil, RS=None):
+    """``RS`` = (R, S): the result straight in the reference layout [K, C, R, S] (the kernel's epilogue stores it transposed and
+    drops the positions beyond the layer's filter); None: [C, R', S', K]."""
     dev = xT.device
     Ro = (H + 2 * pad[0] - stride[0] * (Ho - 1) - 1) // dil[0] + 1
     So = (W + 2 * pad[1] - stride[1] * (Wo - 1) - 1) // dil[1] + 1
-    out = torch.empty((C_, Ro, So, K), device=dev, dtype=torch.float32)
+    out = torch.empty((K, C_, RS[0], RS[1]) if RS is not None else (C_, Ro, So, K), device=dev, dtype=torch.float32)
     check(lib().dlip_wgrad_conv_f16x3(ptr(xT), ptr(gT), ptr(inv), ptr(const_vec(K, 0.0, dev)), ptr(const_vec(K, 1.0, dev)), ptr(out), C_, H, W, K,
-                                      Ho, Wo, N32, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], stream_handle()), "dlip_wgrad_conv_f16x3")
+                                      Ho, Wo, N32, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], RS[0] if RS else 0, RS[1] if RS else 0,
+                                      stream_handle()), "dlip_wgrad_conv_f16x3")
     return out
 
 
@@ -433,6 +439,8 @@ def wgrad_as_conv(x, dy, R, S, stride, pad, dil, scale2=None, xT=None, gT=None):
     dev = xT.device
     sm = 1 if WGRAD_SLICE_MAJOR else 0
     inv = lift_inv(scale2, K)
+    if sm and WGRAD_DIRECT_LAYOUT:
+        return _wgrad_conv_launch(xT, gT, inv, Cx, H, W, K, Ho, Wo, N32, stride, pad, dil, RS=(R, S))   # [K, Cx, R, S] from the epilogue
     if sm:
         out = _wgrad_conv_launch(xT, gT, inv, Cx, H, W, K, Ho, Wo, N32, stride, pad, dil)   # [Cx, R', S', K]
     else:

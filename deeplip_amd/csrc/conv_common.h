@@ -70,6 +70,9 @@ struct ConvArgs {
   // ---- the window kernel (conv_win_f16x3.hip): NULL, or this launch's {first start, last end} pair in 100 MHz ticks (dlip_span_scope_*;
   // the ring and rows kernels carry theirs in their schedule blocks)
   unsigned long long* span;
+  // ---- a weight gradient run as a convolution (dlip_wgrad_conv_f16x3 with R, S given): the output element (m = (c, r', s'), k) goes
+  // to dw[k][c][r'][s'] -- the REFERENCE layout [K, C, R, S] -- for r' < wg_R, s' < wg_S and nowhere otherwise; wg_R == 0: plain rows
+  int wg_R, wg_S;
 };
 
 
@@ -124,6 +127,7 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
   a.n_inner = 0;
   a.Hs = d->H; a.cs_x = 128; a.wt = Cw * 4; a.cs_w = 128;
   a.span = nullptr;
+  a.wg_R = a.wg_S = 0;
   return DLIP_OK;
 }
 

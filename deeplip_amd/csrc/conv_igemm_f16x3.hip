@@ -400,7 +400,7 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
 extern "C" int dlip_wgrad_conv_f16x3(const float* x_img, const float* g_img, const float* post_scale, const float* post_shift,
                                      const float* unit_scale, float* dw, int32_t C, int32_t H, int32_t W, int32_t K, int32_t Ho,
                                      int32_t Wo, int32_t N32, int32_t stride_h, int32_t stride_w, int32_t pad_h, int32_t pad_w,
-                                     int32_t dil_h, int32_t dil_w, dlip_stream_t stream) {
+                                     int32_t dil_h, int32_t dil_w, int32_t R, int32_t S, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x_img && g_img && dw && unit_scale && C > 0 && H > 0 && W > 0 && K > 0 && Ho > 0 && Wo > 0 && N32 > 0 && (N32 & 31) == 0);
   DLIP_CHECK_ARG((K & 3) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 && dlip_conv_dma_enabled());
   // the LAYER computes y[n, ho, wo] from x[n, ho * stride + r * dil - pad, ...]; its weight gradient is the convolution of x' with the
@@ -423,6 +423,11 @@ extern "C" int dlip_wgrad_conv_f16x3(const float* x_img, const float* g_img, con
   a.wt = 128;
   a.cs_w = Ho * Wo * 128;
   DLIP_CHECK_ARG((long long)C * NS * H * W * 128 < (1ll << 31) && (long long)NS * Ho * Wo * 128 < (1ll << 31));
+  if (R > 0 || S > 0) {   // dw = the reference layout [K, C, R, S]: the layer's own filter extent out of the R' x S' the convolution computes
+    DLIP_CHECK_ARG(R > 0 && S > 0 && R <= d.Ho && S <= d.Wo && (long long)K * C * R * S * 4 <= DLIP_MAX_BUFFER_BYTES);
+    a.wg_R = R; a.wg_S = S;
+    a.y_bytes = (uint32_t)((long long)K * C * R * S * 4);
+  }
   return dlip_conv_f16x3_dma_launch(&a, stream, 0);
 }
 

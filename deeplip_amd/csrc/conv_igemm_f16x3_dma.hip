@@ -827,6 +827,20 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_igemm_f16x3_d
             const int m = tile_m * BM + band0 + r;
             const int kfirst = OSPLIT ? kcol0 + (c >> 3) * 32 : kcol0 + c * 4;
             const u32x4 v = *reinterpret_cast<const u32x4*>(img + r * PITCH + pp * 16);
+            if constexpr (BIGTAPS && !OSPLIT) {
+              if (a.wg_R > 0) {   // (launch-uniform) a weight gradient straight into the reference layout [K, C, R, S]: four 4-byte stores
+                if (m < a.M && kfirst < a.K) {
+                  const int ci = dlip_div(m, a.div_howo), rem = m - ci * a.HoWo, rr = dlip_div(rem, a.div_wo), ss = rem - rr * a.Wo;
+                  if (rr < a.wg_R && ss < a.wg_S) {
+                    const int RS = a.wg_R * a.wg_S, crs = (a.M / a.HoWo) * RS;
+                    float* dst = a.y + (size_t)kfirst * crs + ci * RS + rr * a.wg_S + ss;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dst[(size_t)j * crs] = __uint_as_float(v[j]);
+                  }
+                }
+                continue;
+              }
+            }
             const uint32_t off = (m < a.M && kfirst < a.K) ? (uint32_t)((m * a.ldy + kcol0) * 4 + c * 16) : DLIP_OOB_OFFSET;
             __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)off, 0, 0);
           }
@@ -880,6 +894,15 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const ConvArgs a, cons
     v = v >= 0.f ? v : v * (a.slope ? a.slope[k + c] : 1.f);
     if (a.pscale) v = v * a.pscale[k + c] + a.pshift[k + c];
     y[c] = v;
+  }
+  if (a.wg_R > 0) {   // a weight gradient straight into the reference layout [K, C, R, S] (kernel comment at the band store)
+    const int ci = m / a.HoWo, rem = m - ci * a.HoWo, rr = rem / a.Wo, ss = rem - rr * a.Wo;
+    if (rr >= a.wg_R || ss >= a.wg_S) return;
+    const int RS = a.wg_R * a.wg_S, crs = (a.M / a.HoWo) * RS;
+    float* dst = a.y + (size_t)k * crs + ci * RS + rr * a.wg_S + ss;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[(size_t)c * crs] = y[c];
+    return;
   }
   *reinterpret_cast<f32x4*>(a.y + (size_t)m * a.ldy + k) = y;
 }

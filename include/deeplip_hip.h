@@ -578,7 +578,10 @@ int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_t H, int32_
 int dlip_wgrad_conv_f16x3(const float* x_img, const float* g_img, const float* post_scale, const float* post_shift,
                           const float* unit_scale, float* dw, int32_t C, int32_t H, int32_t W, int32_t K, int32_t Ho, int32_t Wo,
                           int32_t N32, int32_t stride_h, int32_t stride_w, int32_t pad_h, int32_t pad_w, int32_t dil_h, int32_t dil_w,
-                          dlip_stream_t stream);
+                          int32_t R, int32_t S, dlip_stream_t stream);
+/* R, S (ABI 43; 0, 0 = dw [C, R', S', K] as above): the LAYER's filter extent -- dw is then written in the REFERENCE layout
+ * [K, C, R, S] (what Conv2d.weight.grad is: models/video_models/resnet.py:9-16), the positions r' >= R / s' >= S dropped, by the
+ * epilogue itself: no [C, R', S', K] tensor, no slice copy and no permute launch behind it (48 launches of a training step). */
 /* The stem's input for its weight gradient run as a convolution: the clip x [B,T,H,W] -> out [5][H][W][N32] split format, n = b*T + t,
  * out[dt][h][w][n] = x[b, t + dt - 2, h, w] (zero outside the clip; N32 >= B*T, a multiple of 32): the five temporal taps of
  * Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) (model.py:82) as five "images" of ONE 2-D convolution whose filter is the output gradient

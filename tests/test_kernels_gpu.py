@@ -1018,6 +1018,33 @@ def test_conv_dma_paired_column_blocks(ops, shape):
     assert rel_err(builtin.numpy(), outs[1].numpy()) < 3e-6
 
 
+@pytest.mark.parametrize("N,H,C,K,stride", [(64, 22, 64, 64, 1), (40, 11, 128, 128, 1), (33, 22, 64, 128, 2), (70, 3, 512, 512, 1), (928, 6, 256, 256, 1),
+                                            (35, 12, 96, 160, 2)])
+def test_wgrad_reference_layout_from_the_epilogue(ops, N, H, C, K, stride):
+    """Round 5: dlip_wgrad_conv_f16x3 with the layer's (R, S) stores dW as [K, C, R, S] from its epilogue -- the in-kernel finisher's
+    band store, the plain launch's, and slab_reduce_kernel's -- dropping the positions r' >= R the convolution computes beside them
+    (stride 2 leaves a remainder row).  Bit for bit what round 4's [C, R', S', K] result gives after its slice copy and permute."""
+    from deeplip_amd import _lib, autograd_video as av
+    x = rnd(N, H, H, C, seed=61).cuda()
+    Ho = (H + 2 - 3) // stride + 1
+    dy = (rnd(N, Ho, Ho, K, seed=62) * 1e-3).cuda()
+    outs = {}
+    try:
+        for direct in (True, False):
+            for sk in (-1, 4):                       # the reduce launch / the in-kernel finisher
+                av.WGRAD_DIRECT_LAYOUT = direct
+                _lib.debug_set(_lib.DBG_STREAMK, sk)
+                outs[(direct, sk)] = av.wgrad_as_conv(x, dy, 3, 3, (stride, stride), (1, 1), (1, 1)).clone()
+        torch.cuda.synchronize()
+    finally:
+        av.WGRAD_DIRECT_LAYOUT = True
+        _lib.debug_set(_lib.DBG_STREAMK, -1)
+    for sk in (-1, 4):
+        assert tuple(outs[(True, sk)].shape) == (K, C, 3, 3)
+        assert torch.equal(outs[(True, sk)].view(torch.int32), outs[(False, sk)].view(torch.int32)), sk
+    assert float(outs[(True, -1)].abs().max()) > 0
+
+
 @pytest.mark.parametrize("N,H,C,K,stride", [(64, 22, 64, 64, 1), (40, 11, 128, 128, 1), (33, 22, 64, 128, 2), (70, 3, 512, 512, 1)])
 def test_split_reduce_launch_is_bit_identical_to_the_in_kernel_finisher(ops, N, H, C, K, stride):
     """Few tiles cut many ways (weight gradients run as convolutions: 1 - 36 tiles, 14 - 100 parts each): the parts are only
