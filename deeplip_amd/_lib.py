@@ -52,7 +52,9 @@ SIGNATURES = {
     "dlip_range_scope_end": [c_stream],
     "dlip_debug_set": [c_i32, c_i32],
     "dlip_bn_rows_chunks": [c_i32],
-    "dlip_bn_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_i32, c_stream],
+    "dlip_bn_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_i32, c_i32, c_stream],
+    "dlip_conv_stats_chunks": [C.POINTER(ConvDesc)],
+    "dlip_conv_nhwc_stats_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_stream],
     "dlip_bn_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_f, c_stream],
     "dlip_bn_prelu_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_stream],
     "dlip_bn_prelu_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_f, c_stream],

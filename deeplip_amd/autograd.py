@@ -178,6 +178,11 @@ def margin_ce_loss(logits, labels, scale=1.0, margin=0.0):
 # SpeakerEmbNet.forward under model.train() (train_audio.py:167-183), as dlip_* launches.
 # Channels-last [B,T,C] activations throughout; parameters keep the reference layouts.
 # ==========================================================================================
+# Round 5 (both measured on the speech encoder's training step, tools/bench_train_audio.py; False restores round 4's passes):
+BN_STATS_FROM_CONV = __import__("os").environ.get("DLIP_BN_STATS_FROM_CONV", "1") != "0"
+ZERO_BIAS_GRAD_BEFORE_BN = __import__("os").environ.get("DLIP_ZERO_BIAS_GRAD", "1") != "0"
+
+
 def _ws(M: int, C_: int, device):
     """fp64 workspace of the chunked column reductions (encoder_train_ops.hip)."""
     return torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 2,), device=device, dtype=torch.float64)
@@ -217,13 +222,16 @@ def _permute3(x, perm, flip_axis=-1):
     return y
 
 
-def _bn_rows_fwd(x2, gamma, beta, rm, rv, momentum, eps, slope, act_first):
+def _bn_rows_fwd(x2, gamma, beta, rm, rv, momentum, eps, slope, act_first, ready=None):
+    """``ready`` = (ws, chunks): the partial column sums of x2 already written by the convolution that produced it
+    (conv_train(..., stats=...)): the statistics pass over x2 is skipped."""
     M, C_ = x2.shape
     y = torch.empty_like(x2)
     mean = torch.empty((C_,), device=x2.device, dtype=torch.float32)
     invstd = torch.empty_like(mean)
+    ws, chunks = ready if ready is not None else (_ws(M, C_, x2.device), 0)
     check(lib().dlip_bn_rows_train_fwd_f32(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(invstd), ptr(rm), ptr(rv),
-                                           ptr(_ws(M, C_, x2.device)), M, C_, momentum, eps, slope, int(act_first),
+                                           ptr(ws), M, C_, momentum, eps, slope, int(act_first), int(chunks),
                                            stream_handle()), "dlip_bn_rows_train_fwd_f32")
     return y, mean, invstd
 
@@ -295,11 +303,19 @@ class TDNNBlockTrainFn(Function):
             elif S > 1 and Cx % 32 == 0 and av.WGRAD == "conv":
                 xT, xs = av.wgrad_image(x.view(B_, 1, T_, C_in), None, also_nhwc_split=True)
                 mode = 2
+        # (round 5) conv -> BN: the batch statistics come out of the convolution's epilogue (per half tile the column sums of what it
+        # writes) instead of a pass of their own over z -- 155 MB read per layer at B = 256
+        stats = None
+        if not act_first and BN_STATS_FROM_CONV and av.TRAIN_CONV == "f16x3":
+            n_ch = ops.conv_stats_chunks(B_, 1, T_, C_in, K, 1, S, dil=(1, dilation))
+            if n_ch > 0:
+                stats = {"chunks": n_ch, "ws": torch.empty((n_ch * K * 2,), device=x.device, dtype=torch.float64)}
         z = av.conv_train(x.view(B_, 1, T_, C_in), None, bias.contiguous() if bias is not None else None, (1, 1), (0, 0), (1, dilation),
-                          w_ref=weight.view(K, Cw, 1, S), xs_ready=xs)         # reference [K,C,S]: split image written straight from it
+                          w_ref=weight.view(K, Cw, 1, S), xs_ready=xs, stats=stats)   # reference [K,C,S]: split image written straight from it
         z = z.view(B_, z.shape[2], z.shape[3])
         Tp = z.shape[1]
-        y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first)
+        ready = (stats["ws"], stats["chunks"]) if stats is not None and stats.get("done") else None
+        y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first, ready)
         ctx.save_for_backward(xT if mode else x, weight, z, gamma, beta, mean, invstd)
         ctx.cfg = (dilation, slope, act_first, bias is not None)
         ctx.x_shape, ctx.mode = (B, T, Cx), mode
@@ -318,9 +334,16 @@ class TDNNBlockTrainFn(Function):
                                           slope, act_first)
         dbias = None
         if has_bias and ctx.needs_input_grad[2]:
-            dbias = torch.empty((K,), device=dev, dtype=torch.float32)
-            check(lib().dlip_colsum_rows_f32(ptr(dz2), ptr(dbias), ptr(_ws(B * Tp, K, dev)), B * Tp, K, stream_handle()),
-                  "dlip_colsum_rows_f32")
+            if not act_first and ZERO_BIAS_GRAD_BEFORE_BN:
+                # conv -> batch-statistics BN: the bias gradient is the column sum of the BatchNorm's input gradient, and that is
+                # IDENTICALLY zero: dz = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)) sums to -gamma invstd mean(g xhat)
+                # sum(xhat) = 0.  torch's autograd (the reference) returns that sum's rounding noise (~1e-9 |dy|); summing 155 MB per
+                # layer to reproduce noise is a pass this engine does not make.
+                dbias = torch.zeros((K,), device=dev, dtype=torch.float32)
+            else:
+                dbias = torch.empty((K,), device=dev, dtype=torch.float32)
+                check(lib().dlip_colsum_rows_f32(ptr(dz2), ptr(dbias), ptr(_ws(B * Tp, K, dev)), B * Tp, K, stream_handle()),
+                      "dlip_colsum_rows_f32")
         dz = dz2.view(B, Tp, K)
         dx = None
         from . import autograd_video as av

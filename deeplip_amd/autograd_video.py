@@ -252,13 +252,16 @@ def prepare_weights(owner=None):
 
 
 def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=False, scale2=None, w_ref=None, transposed=False,
-               xs_ready=None):
+               xs_ready=None, stats=None):
     """One convolution of a training step on NHWC fp32 ``x`` with CURRENT weights -> fp32 NHWC.  Weights: ``w_krsc`` [K,R,S,C]
     (kernel layout), or ``w_ref`` = the parameter itself in the reference layout [Ko,Ci,R,S] -- then ``transposed`` False means
     the forward filter bank and True the data gradient's (flipped taps, in / out channels swapped): the split-fp16 image is
     written straight from the parameter by dlip_split_weights_perm_f32, no permuted fp32 copy in between.
     ``lift``: x is a gradient (tiny magnitudes): multiply by a power of two into fp16's normal range before the split and
-    divide the result by it (the conv epilogue's post_scale) -- exact."""
+    divide the result by it (the conv epilogue's post_scale) -- exact.
+    ``stats`` (a dict {"chunks": n > 0 from ops.conv_stats_chunks, "ws": float64 [n * K * 2]}): if this call ends on the split-fp16
+    kernel, its epilogue also writes the column sums of the output into ws (the BatchNorm behind it then skips its statistics pass) and
+    stats["done"] is set; otherwise the dict is left alone."""
     N, H, W, Cx = x.shape
     if w_ref is not None:
         Ko, Ci, R_, S_ = w_ref.shape
@@ -307,8 +310,12 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
         wsc = torch.empty((K,), device=dev, dtype=torch.float32)
         check(lib().dlip_split_weights_rows_f32(ptr(w_krsc), ptr(ws), ptr(wsc), K, L, stream_handle()), "dlip_split_weights_rows_f32")
     if not lift:
+        st = None
+        if stats is not None and stats.get("chunks", 0) > 0:
+            st = stats["ws"]
+            stats["done"] = True
         return ops.conv_nhwc(xs_ready if xs_ready is not None else ops.split_pack(x), ws, bias, stride=stride, pad=pad, dil=dil, w_scale=wsc,
-                             x_split=True)
+                             x_split=True, stats=st)
     if scale2 is None:
         scale2 = pow2_lift(x)
     if xs_ready is not None:        # (x in the split format, lifted by scale2, written by the pass that formed the weight gradient's image)

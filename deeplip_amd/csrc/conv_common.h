@@ -73,6 +73,10 @@ struct ConvArgs {
   // ---- a weight gradient run as a convolution (dlip_wgrad_conv_f16x3 with R, S given): the output element (m = (c, r', s'), k) goes
   // to dw[k][c][r'][s'] -- the REFERENCE layout [K, C, R, S] -- for r' < wg_R, s' < wg_S and nowhere otherwise; wg_R == 0: plain rows
   int wg_R, wg_S;
+  // ---- dlip_conv_nhwc_stats_f16x3 (the rows kernel's fp32 epilogue): NULL, or [chunks][K][2] fp64 -- per half tile (a wave row:
+  // chunk 2 tile_m + wm) the column sums {sum y, sum y^2} of the rows it wrote: the train-mode BatchNorm's statistics without a pass
+  // of their own over y
+  double* stats;
 };
 
 
@@ -128,6 +132,7 @@ inline int dlip_fill_conv_args(const dlip_conv_desc* d, const float* x, const fl
   a.Hs = d->H; a.cs_x = 128; a.wt = Cw * 4; a.cs_w = 128;
   a.span = nullptr;
   a.wg_R = a.wg_S = 0;
+  a.stats = nullptr;
   return DLIP_OK;
 }
 

@@ -396,6 +396,30 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
   }
 }
 
+// dlip_conv_nhwc_f16x3 (split input, fp32 output, no residual) that also leaves the column sums of its output (include/deeplip_hip.h).
+extern "C" int32_t dlip_conv_stats_chunks(const dlip_conv_desc* d) {
+  if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || (d->C & 31) != 0 || (d->K & 3) != 0 || (d->ldy & 3) != 0 || !dlip_conv_dma_enabled()) return 0;
+  int bm = 0;
+  if (!dlip_conv_rows_plan(d, &bm) || bm <= 0) return 0;        // (the window kernel is asked first by the launch: not a rows shape then)
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  const long long chunks = 2 * ((M + bm - 1) / bm);
+  return chunks <= 0x7FFFFFFF ? (int32_t)chunks : 0;
+}
+
+extern "C" int dlip_conv_nhwc_stats_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, const float* w_scale,
+                                          const float* bias, const float* slope, float* y, double* stats, int64_t stats_bytes,
+                                          dlip_stream_t stream) {
+  DLIP_CHECK_ARG(d && stats && (reinterpret_cast<uintptr_t>(stats) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  const int32_t chunks = dlip_conv_stats_chunks(d);
+  DLIP_CHECK_ARG(chunks > 0 && stats_bytes >= (int64_t)chunks * d->K * 2 * 8);
+  ConvArgs a;
+  const int rc = fill_f16x3(d, x, w_split, w_scale, bias, nullptr, slope, nullptr, nullptr, y, DLIP_SPLIT_IN, &a);
+  if (rc != DLIP_OK) return rc;
+  DLIP_CHECK_ARG(!dlip_conv_win_ok(&a) && dlip_conv_rows_ok(&a));
+  a.stats = stats;
+  return dlip_conv_f16x3_rows_launch(&a, stream, 0);
+}
+
 // A convolution's weight gradient run as a convolution over SLICE-major operand images (include/deeplip_hip.h).
 extern "C" int dlip_wgrad_conv_f16x3(const float* x_img, const float* g_img, const float* post_scale, const float* post_shift,
                                      const float* unit_scale, float* dw, int32_t C, int32_t H, int32_t W, int32_t K, int32_t Ho,

@@ -479,6 +479,17 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
         f32x4 inv4;
 #pragma unroll
         for (int c = 0; c < 4; ++c) inv4[c] = k0 + c < eK ? 1.f / s4[c] : 0.f;
+        // (MODE 0, a.stats: launch-uniform) column sums of what this wave writes -- the batch statistics of the BatchNorm behind a
+        // TDNN convolution under model.train() (tdnn.py:35-43) -- taken here instead of by a pass over y: a lane adds its MI pixels
+        // (fp32: 5 values), the 16 lanes of a channel quad meet by four DPP row steps (fp32, a fixed tree: deterministic), lane 0 of
+        // the quad converts to fp64 and stores {sum, sum of squares} of its 4 channels for chunk 2 tile_m + wm; the finalize kernel
+        // adds the chunks in fp64 as it adds col_partial_kernel's.  80 values per fp32 sum: 5e-7 relative per chunk, random over
+        // ~10^3 chunks.
+        float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
+        // (the pointer is re-read from the kernel arguments HERE: held in scalar registers across the main loop it cost the fp32
+        // instances 30 extra SGPR spills -- the paired-lanes lesson of conv_igemm_f16x3_dma.hip)
+        double* const stats_p = MODE == 0 ? *reinterpret_cast<double* const volatile*>(&a.stats) : nullptr;
+        const bool want_stats = stats_p != nullptr;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           f32x4 v;
@@ -503,8 +514,28 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
             if (post) t = t * p4[c] + t4[c];
             v[c] = t;
           }
+          if (want_stats && m < eM) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { st_s[c] += v[c]; st_q[c] += v[c] * v[c]; }
+          }
           const uint32_t off = (m < eM && k0 < eK) ? (uint32_t)((m * eldy + k0) * 4) : DLIP_OOB_OFFSET;   // K % 4 == 0
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, (int)off, 0, 0);
+        }
+        if (want_stats) {
+          auto row_sum = [](float x) {   // the sum over the 16 lanes of a DPP row, in every lane: xor 1, xor 2, half mirror, mirror
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));
+            return x;
+          };
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { st_s[c] = row_sum(st_s[c]); st_q[c] = row_sum(st_q[c]); }
+          if (lrow == 0 && k0 < eK) {
+            double* dst = stats_p + ((size_t)(2 * tile_m + wm) * eK + k0) * 2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { dst[2 * c] = (double)st_s[c]; dst[2 * c + 1] = (double)st_q[c]; }
+          }
         }
         DLIP_FENCE();
       }

@@ -567,14 +567,18 @@ extern "C" int32_t dlip_bn_rows_chunks(int32_t M) { return M > 0 ? (M + CHUNK_RO
 extern "C" int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                                           float* save_mean, float* save_invstd, float* running_mean,
                                           float* running_var, double* workspace, int32_t M, int32_t C, float momentum,
-                                          float eps, float slope, int32_t act_first, dlip_stream_t stream) {
+                                          float eps, float slope, int32_t act_first, int32_t ready_chunks, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);
   DLIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+  DLIP_CHECK_ARG(ready_chunks >= 0 && !(ready_chunks > 0 && act_first));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int chunks = dlip_bn_rows_chunks(M);
-  hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, workspace, M, C, slope, act_first);
+  // ready_chunks > 0: `workspace` already holds that many partial rows {sum x, sum x^2} [chunk][C][2] -- written by the convolution
+  // that produced x (dlip_conv_nhwc_stats_f16x3) -- and the statistics pass over x is not launched
+  const int chunks = ready_chunks > 0 ? ready_chunks : dlip_bn_rows_chunks(M);
+  if (ready_chunks == 0)
+    hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, workspace, M, C, slope, act_first);
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_invstd,
                      running_mean, running_var, M, C, chunks, momentum, eps);
   const long long n4 = (long long)M * (C / 4);

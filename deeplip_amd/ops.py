@@ -52,7 +52,8 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
               post_scale: Optional[Tensor] = None, post_shift: Optional[Tensor] = None,
               out: Optional[Tensor] = None, out_channel_offset: int = 0,
               in_channels: Optional[int] = None, in_channel_offset: int = 0,
-              w_scale: Optional[Tensor] = None, x_split: bool = False, out_split: bool = False) -> Tensor:
+              w_scale: Optional[Tensor] = None, x_split: bool = False, out_split: bool = False,
+              stats: Optional[Tensor] = None) -> Tensor:
     """x [N,H,W,Cx] (NHWC), w [K,R,S,C] -> y [N,Ho,Wo,Ky].
 
     ``out`` / ``out_channel_offset`` write the K result channels into a slice of a wider tensor
@@ -111,7 +112,15 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
         elif kind == 2:      # the rows kernel (its speech-encoder mode, or the general mode: 2-D filters / residual)
             kname = "conv_rows_f16x3_kernel"
         tok = hook.begin(f"{kname}<{bm.value},{bn.value}>", 2.0 * N * Ho * Wo * K * R * S * Cin)
-    if w_scale is not None:
+    if stats is not None:
+        # the convolution's epilogue also leaves the column sums of y (dlip_conv_nhwc_stats_f16x3): conv_stats_chunks(...) said it can
+        _req(stats, "stats", torch.float64)
+        if not (x_split and w_scale is not None) or out_split or residual is not None or post_scale is not None or in_channel_offset or out_channel_offset:
+            raise ValueError("conv_nhwc(stats=...): split input, fp32 output, no residual / post-affine / channel slices")
+        _lib.ensure_conv_workspace()
+        check(lib().dlip_conv_nhwc_stats_f16x3(C.byref(d), xp, ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(slope), yp, ptr(stats),
+                                               stats.numel() * 8, stream_handle()), "dlip_conv_nhwc_stats_f16x3")
+    elif w_scale is not None:
         if x_split:
             _lib.ensure_conv_workspace()
         check(lib().dlip_conv_nhwc_f16x3(C.byref(d), xp, ptr(w_krsc), ptr(w_scale), ptr(bias), ptr(residual),
@@ -124,6 +133,15 @@ def conv_nhwc(x: Tensor, w_krsc: Tensor, bias: Optional[Tensor] = None, *, strid
     if hook is not None:
         hook.end(tok)
     return out
+
+
+def conv_stats_chunks(N, H, W, Cin, K, R, S, stride=(1, 1), pad=(0, 0), dil=(1, 1)) -> int:
+    """How many partial rows conv_nhwc(..., stats=...) writes for this split-input, fp32-output launch (0: no statistics epilogue
+    for the shape -- launch the plain convolution and let the BatchNorm make its own pass)."""
+    Ho = conv_out_size(H, R, stride[0], pad[0], dil[0])
+    Wo = conv_out_size(W, S, stride[1], pad[1], dil[1])
+    d = ConvDesc(N, H, W, Cin, K, R, S, stride[0], stride[1], pad[0], pad[1], dil[0], dil[1], Ho, Wo, Cin, K, 0)
+    return int(lib().dlip_conv_stats_chunks(C.byref(d)))
 
 
 def conv2_nhwc(x: Tensor, x2: Tensor, w_split: Tensor, bias: Tensor, w_scale: Tensor, *, stride=(1, 1), pad=(0, 0),

@@ -106,6 +106,17 @@ int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const void* w_
  * under one power-of-two scale w_scale[k]); bias = the sum of the two folded biases.  x2 is [N,H2,W2,C2] in the
  * split activation format (DLIP_SPLIT_IN is mandatory), read at pixel (ho*stride2_h, wo*stride2_w) for output pixel
  * (ho, wo); C2, ldx2 multiples of 32.  residual may still be given (added after both).  Split-format kernel only. */
+/* (ABI 43) dlip_conv_nhwc_f16x3 with DLIP_SPLIT_IN, fp32 y, no residual / post-affine, whose epilogue ALSO leaves the column sums of
+ * the y it writes: stats [chunks][K][2] fp64 = per chunk of output rows {sum y, sum y^2} -- the batch statistics of the BatchNorm
+ * behind a convolution under model.train() (models/audio_models/tdnn.py:35-43: Conv1d -> BatchNorm1d), without the pass over y that
+ * dlip_bn_rows_train_fwd_f32 would otherwise make (hand it `stats` as its workspace and `chunks` as ready_chunks).
+ * dlip_conv_stats_chunks(d): how many chunks such a launch of `d` writes, or 0 when this shape has no statistics epilogue (today:
+ * the rows kernel's shapes -- 1-D valid convolutions and k = 1 GEMMs; the caller then launches the plain convolution).  Within a
+ * chunk (half a tile: <= 80 rows) the sums are fp32 in a fixed order; across chunks the finalize kernel adds in fp64. */
+int32_t dlip_conv_stats_chunks(const dlip_conv_desc* d);
+int dlip_conv_nhwc_stats_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, const float* w_scale,
+                               const float* bias, const float* slope, float* y, double* stats, int64_t stats_bytes,
+                               dlip_stream_t stream);
 int dlip_conv2_nhwc_f16x3(const dlip_conv_desc* d, const float* x, const float* x2, int32_t H2, int32_t W2,
                           int32_t C2, int32_t ldx2, int32_t stride2_h, int32_t stride2_w, const void* w_split,
                           const float* w_scale, const float* bias, const float* residual, const float* slope,
@@ -442,10 +453,12 @@ int32_t dlip_bn_rows_chunks(int32_t M);
  * act_first = 1: y = bn(lrelu(x))  (bn_first=False, tdnn.py:40-42,96-97,109-110).
  * Batch statistics: biased variance for the normalisation, unbiased for running_var (momentum update,
  * nullable pair), as nn.BatchNorm1d.  save_mean / save_invstd [C] feed the backward. */
+/* (ABI 43) ready_chunks > 0 (act_first == 0 only): `workspace` already holds that many partial rows [chunk][C][2] fp64 = {sum x,
+ * sum x^2} of x, written by the convolution that produced x (dlip_conv_nhwc_stats_f16x3): the statistics pass over x is skipped. */
 int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                                float* save_mean, float* save_invstd, float* running_mean,
                                float* running_var, double* workspace, int32_t M, int32_t C, float momentum,
-                               float eps, float slope, int32_t act_first, dlip_stream_t stream);
+                               float eps, float slope, int32_t act_first, int32_t ready_chunks, dlip_stream_t stream);
 /* Backward of the above: dy = dL/dy -> dx = dL/dx [M,C], dgamma, dbeta [C].  dx_lift2 (nullable, DLIP_LIFT_WORDS floats: the pair, then per-workgroup scratch): the power-of-two
  * lift of dx, (2^e, 2^-e) with max|dx| * 2^e in [512, 1024] -- what dlip_pow2_scale_f32(dx, ., 1024) would return, formed by the
  * pass that writes dx: the convolution backward that consumes dx needs it and would otherwise read dx once more. */

@@ -1354,3 +1354,42 @@ def test_wgrad_reduction_major_operand(ops, N, H, W, C, R, S, stride, pad, dil):
                 win = xp[:, r * dh[0]: r * dh[0] + (Ho - 1) * sh[0] + 1: sh[0], s_ * dh[1]: s_ * dh[1] + (Wo - 1) * sh[1] + 1: sh[1]]   # [N,Ho,Wo,C]
                 ref[r * S + s_, :, :J] = win.reshape(J, C).t()
         assert torch.equal(out.cpu().view(torch.int32), _split_ref(ref.view(R * S * C, J32)).view(torch.int32))
+
+
+@pytest.mark.parametrize("case", [(64, 296, 512, 512, 1, 1), (64, 300, 512, 512, 3, 2), (256, 120, 64, 1500, 1, 1), (64, 300, 96, 512, 5, 1)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_stats_epilogue_gives_the_batchnorm_statistics(ops, case):
+    """Round 5: dlip_conv_nhwc_stats_f16x3 -- the rows kernel's fp32 epilogue also leaves, per half tile, the column sums {sum y, sum y^2}
+    of what it writes (the train-mode BatchNorm behind a TDNN convolution then makes no statistics pass over y).  (1) y is bit for bit
+    the plain launch's; (2) the chunks add up to the fp64 column sums of y (fp32 within a chunk of <= 80 rows: 2e-6); (3) rows past M
+    and channels past K contribute nothing; (4) repeatable bits; (5) dlip_bn_rows_train_fwd_f32 fed with them == its own pass."""
+    from deeplip_amd import autograd as ag, packing
+    from deeplip_amd._lib import check, lib, ptr, stream_handle
+    B, T, Cc, K, S, dil = case
+    x = ops.split_pack((rnd(B, 1, T, Cc, seed=31) * 2.0).cuda())
+    w = rnd(K, 1, S, Cc, seed=32, scale=1.0 / np.sqrt(Cc * S))
+    ws, sc = packing.split_weights(w.double())
+    ws, sc = ws.cuda(), sc.cuda()
+    b = (rnd(K, seed=33) * 0.5).cuda()
+    kw = dict(dil=(1, dil), w_scale=sc, x_split=True)
+    n = ops.conv_stats_chunks(B, 1, T, Cc, K, 1, S, dil=(1, dil))
+    assert n > 0
+    plain = ops.conv_nhwc(x, ws, b, **kw)
+    st = torch.full((n * K * 2,), float("nan"), device="cuda", dtype=torch.float64)
+    y = ops.conv_nhwc(x, ws, b, stats=st, **kw)
+    st2 = torch.empty_like(st)
+    ops.conv_nhwc(x, ws, b, stats=st2, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y, plain) and torch.equal(st, st2) and bool(torch.isfinite(st).all())
+    rows = y.reshape(-1, K).double().cpu()
+    tot = st.view(n, K, 2).sum(0).cpu()
+    assert rel_err(tot[:, 0].numpy(), rows.sum(0).numpy()) < 2e-6
+    assert rel_err(tot[:, 1].numpy(), (rows * rows).sum(0).numpy()) < 2e-6
+    if K % 4 == 0:
+        M = rows.shape[0]
+        g, be = (1.0 + 0.1 * rnd(K, seed=34)).cuda(), (0.1 * rnd(K, seed=35)).cuda()
+        a0 = ag._bn_rows_fwd(y.view(M, K), g, be, None, None, 0.1, 1e-5, 0.2, False)
+        a1 = ag._bn_rows_fwd(y.view(M, K), g, be, None, None, 0.1, 1e-5, 0.2, False, ready=(st, n))
+        torch.cuda.synchronize()
+        for u, v in zip(a0, a1):
+            assert rel_err(v.cpu().numpy(), u.cpu().numpy()) < 2e-6
