@@ -54,3 +54,30 @@ ms = e0.elapsed_time(e1) / a.steps
 fwd_gflop = 2.563 * a.batch
 print(f"full-encoder E-TDNN training step: batch {a.batch} x 300 frames x {a.dim} dims: {ms:.2f} ms/step = {a.batch / ms * 1e3:.0f} utt/s "
       f"(~{3 * fwd_gflop / ms:.1f} TFLOP/s at 3x forward FLOPs); loss {float(loss.detach()):.4f}")
+if os.environ.get("DLIP_AUDIO_GRAPH", "1") != "0":
+    import gc
+    import time
+    from deeplip_amd.train_plan import TrainStepGraph
+    del loss
+    opt.zero_grad(set_to_none=True)
+    gc.collect()
+    torch.cuda.synchronize()
+
+    def one(xb, lb):
+        opt.zero_grad(set_to_none=True)
+        l, _ = crit(net(xb), lb)
+        l.backward()
+        opt.step()
+        return l
+
+    plan = TrainStepGraph(one, eager_steps=1)
+    for _ in range(3):
+        l = plan.step(x, lab)
+    plan.finish()
+    n = max(a.steps, 10)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        l = plan.step(x, lab)
+    plan.finish()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    print(f"the same step recorded once and replayed as one HIP graph: {ms:.2f} ms/step = {a.batch / ms * 1e3:.0f} utt/s; loss {float(l.detach()):.4f}")
