@@ -335,3 +335,70 @@ def test_ragged_extractor_equals_one_at_a_time(video_net):
             assert rel_err(xv[j:j + 1].cpu().numpy(), want_v.cpu().numpy()) < 2e-6, i
     finally:
         packing.set_precision("f32")
+
+
+# ------------------------------------------------------------------------------------------ BASELINE's full sizes, through properties
+def test_ragged_full_size_batches_properties(video_net):
+    """BASELINE.json's batch sizes with RAGGED contents -- 64 clips of 11 .. 75 frames, 256 utterances of 137 .. 412 frames, f16x3 -- where
+    the oracle would need minutes: (1) sampled rows equal the engine run on that item alone at its own length (1e-6: the balanced split's
+    sum order moves with the batch); (2) what sits in the padding does not matter, bit for bit; (3) two rows with equal content and
+    DIFFERENT neighbours / positions agree; (4) a row's result does not depend on the other rows' lengths."""
+    from deeplip_amd import packing
+    from models.audio_models.tdnn import SpeakerEmbNet
+    packing.set_precision("f16x3")
+    try:
+        vnet, _ = video_net
+        r = np.random.Generator(np.random.PCG64(21))
+        lv = r.integers(11, 76, size=64).tolist()
+        lv[0], lv[63] = 75, 33
+        lv[40] = lv[7]
+        base = torch.from_numpy(wg.video_input(8, 75, 88, key="ragged.full.v", speakers=list(range(8))))     # 8 distinct clips, cut to length
+        xv = torch.zeros(64, 1, 75, 88, 88)
+        for b in range(64):
+            xv[b, :, :lv[b]] = base[b % 8, :, :lv[b]]
+        xv[40, :, :lv[40]] = xv[7, :, :lv[7]]                      # the same clip at two places of the batch
+        em = vnet.embed(xv.to(DEV), lengths=lv)
+        junk = xv.clone()
+        for b in range(64):
+            junk[b, :, lv[b]:] = 9.0
+        em_j = vnet.embed(junk.to(DEV), lengths=lv)
+        lv2 = list(lv)
+        for b in range(64):
+            if b not in (7, 40, 63):
+                lv2[b] = max(11, lv[b] - 5)
+        em_l = vnet.embed(xv.to(DEV), lengths=lv2)
+        torch.cuda.synchronize()
+        assert em.shape == (64, 512) and bool(torch.isfinite(em).all())
+        assert torch.equal(em, em_j)
+        assert rel_err(em[40:41].cpu().numpy(), em[7:8].cpu().numpy()) < 1e-6
+        for b in (7, 40, 63):
+            assert rel_err(em_l[b:b + 1].cpu().numpy(), em[b:b + 1].cpu().numpy()) < 1e-6, b
+        for b in (0, 7, 63):
+            one = vnet.embed(xv[b:b + 1, :, :lv[b]].contiguous().to(DEV))
+            torch.cuda.synchronize()
+            assert rel_err(em[b:b + 1].cpu().numpy(), one.cpu().numpy()) < 1e-6, b
+
+        anet, _ = load(SpeakerEmbNet(etdnn_opts(80)), "audio80.")
+        la = r.integers(137, 413, size=256).tolist()
+        la[0], la[255] = 412, 137
+        basea = torch.from_numpy(wg.audio_input(8, 80, 412, key="ragged.full.a", speakers=list(range(8))))
+        xa = torch.zeros(256, 80, 412)
+        for b in range(256):
+            xa[b, :, :la[b]] = basea[b % 8, :, :la[b]]
+        la[200] = la[9]
+        xa[200] = 0.0
+        xa[200, :, :la[200]] = xa[9, :, :la[9]]
+        ea, _ = anet.extract_embedding(xa.to(DEV), lengths=la)
+        ja = xa.clone()
+        for b in range(256):
+            ja[b, :, la[b]:] = -4.0
+        ea_j, _ = anet.extract_embedding(ja.to(DEV), lengths=la)
+        torch.cuda.synchronize()
+        assert ea.shape == (256, 512) and torch.equal(ea, ea_j)
+        assert rel_err(ea[200:201].cpu().numpy(), ea[9:10].cpu().numpy()) < 1e-6
+        for b in (0, 9, 255):
+            one, _ = anet.extract_embedding(xa[b:b + 1, :, :la[b]].contiguous().to(DEV))
+            torch.cuda.synchronize()
+            assert rel_err(ea[b:b + 1].cpu().numpy(), one.cpu().numpy()) < 1e-6, b
+    finally:
+        packing.set_precision("f32")
