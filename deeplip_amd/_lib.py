@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 43
+ABI_VERSION = 44
 LIFT_WORDS = 4098
 LIFT_BCAST = 2048
 
@@ -52,11 +52,11 @@ SIGNATURES = {
     "dlip_range_scope_end": [c_stream],
     "dlip_debug_set": [c_i32, c_i32],
     "dlip_bn_rows_chunks": [c_i32],
-    "dlip_bn_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_i32, c_i32, c_stream],
+    "dlip_bn_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, C.c_float, c_i32, c_i32, c_f, c_stream],
     "dlip_conv_stats_chunks": [C.POINTER(ConvDesc)],
     "dlip_conv_nhwc_stats_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_stream],
     "dlip_bn_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_f, c_stream],
-    "dlip_bn_prelu_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_stream],
+    "dlip_bn_prelu_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_f, c_stream],
     "dlip_bn_prelu_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_f, c_stream],
     "dlip_colsum_rows_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_meanstd_pool_bwd_f32": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_stream],
@@ -224,7 +224,7 @@ def ensure_conv_workspace() -> None:
 
 
 # ---- diagnostic overrides (tests, tools): dlip_debug_set ----
-DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK, DBG_WIN, DBG_NINNER, DBG_ROWS, DBG_ROWS2D = 0, 1, 2, 3, 4, 5, 6, 7
+DBG_CONV_TILE, DBG_DMA_TILE, DBG_DMA_ENABLE, DBG_STREAMK, DBG_WIN, DBG_NINNER, DBG_ROWS, DBG_ROWS2D, DBG_BN_FUSED, DBG_ROWS_TAIL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 DEBUG = {}          # what this process set through debug_set (key -> value; -1 / absent = the built-in choice)

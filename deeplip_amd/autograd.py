@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 from torch.autograd import Function
 
-from . import ops
+from . import _lib, ops
 from ._lib import LIFT_WORDS, check, lib, ptr, stream_handle
 
 
@@ -222,22 +222,25 @@ def _permute3(x, perm, flip_axis=-1):
     return y
 
 
-def _bn_rows_fwd(x2, gamma, beta, rm, rv, momentum, eps, slope, act_first, ready=None):
+def _bn_rows_fwd(x2, gamma, beta, rm, rv, momentum, eps, slope, act_first, ready=None, nbt=None):
     """``ready`` = (ws, chunks): the partial column sums of x2 already written by the convolution that produced it
-    (conv_train(..., stats=...)): the statistics pass over x2 is skipped."""
+    (conv_train(..., stats=...)): the statistics pass over x2 is skipped.  ``nbt``: the module's num_batches_tracked, incremented by the
+    launch that finishes the statistics."""
     M, C_ = x2.shape
+    _lib.ensure_conv_workspace()          # (its ticket words: the finalize step runs in the statistics pass's last workgroup)
     y = torch.empty_like(x2)
     mean = torch.empty((C_,), device=x2.device, dtype=torch.float32)
     invstd = torch.empty_like(mean)
     ws, chunks = ready if ready is not None else (_ws(M, C_, x2.device), 0)
     check(lib().dlip_bn_rows_train_fwd_f32(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(invstd), ptr(rm), ptr(rv),
-                                           ptr(ws), M, C_, momentum, eps, slope, int(act_first), int(chunks),
+                                           ptr(ws), M, C_, momentum, eps, slope, int(act_first), int(chunks), ptr(nbt),
                                            stream_handle()), "dlip_bn_rows_train_fwd_f32")
     return y, mean, invstd
 
 
 def _bn_rows_bwd(dy2, x2, gamma, beta, mean, invstd, slope, act_first):
     M, C_ = x2.shape
+    _lib.ensure_conv_workspace()
     dx = torch.empty_like(x2)
     dg = torch.empty_like(mean)
     db = torch.empty_like(mean)
@@ -254,10 +257,10 @@ class BNRowsActFn(Function):
     (bn1 / bn2 of SpeakerEmbNet, tdnn.py:92-97,105-110)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, act_first):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, act_first, nbt=None):
         shape = tuple(x.shape)                                 # any channels-last shape [..., C]: rows = all leading axes
         x = x.contiguous().view(-1, shape[-1])
-        y, mean, invstd = _bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, act_first)
+        y, mean, invstd = _bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, act_first, nbt=nbt)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.slope, ctx.act_first, ctx.shape = slope, act_first, shape
         return y.view(shape)
@@ -268,7 +271,7 @@ class BNRowsActFn(Function):
         dx, dg, db = _bn_rows_bwd(dy.contiguous().view(x.shape), x, gamma, beta, mean, invstd, ctx.slope, ctx.act_first)
         out = dx.view(ctx.shape)
         out._dlip_lift = dx._dlip_lift                        # travels with the tensor object the next backward receives
-        return out, dg, db, None, None, None, None, None, None
+        return out, dg, db, None, None, None, None, None, None, None
 
 
 class TDNNBlockTrainFn(Function):
@@ -283,7 +286,7 @@ class TDNNBlockTrainFn(Function):
     LDS-DMA kernel, whose balanced work split is what makes a 512 x 512 x 19 200 product fill the chip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, slope, dilation, act_first):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, slope, dilation, act_first, nbt=None):
         x = x.contiguous()
         B, T, Cx = x.shape
         K, Cw, S = weight.shape
@@ -315,7 +318,7 @@ class TDNNBlockTrainFn(Function):
         z = z.view(B_, z.shape[2], z.shape[3])
         Tp = z.shape[1]
         ready = (stats["ws"], stats["chunks"]) if stats is not None and stats.get("done") else None
-        y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first, ready)
+        y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first, ready, nbt)
         ctx.save_for_backward(xT if mode else x, weight, z, gamma, beta, mean, invstd)
         ctx.cfg = (dilation, slope, act_first, bias is not None)
         ctx.x_shape, ctx.mode = (B, T, Cx), mode
@@ -376,7 +379,7 @@ class TDNNBlockTrainFn(Function):
                 dweight = _conv1d_wgrad(x, dz, S, dilation, lift)
             if dweight.shape[1] != weight.shape[1]:          # zero-padded input channels: their gradient columns are not parameters
                 dweight = dweight[:, :weight.shape[1]].contiguous()
-        return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def _conv1d_wgrad(x, dz, S, dilation, lift=None):
@@ -440,15 +443,13 @@ def tdnn_block_train(x, blk):
     """blk: deeplip_amd.audio.TDNN_Block in train mode; x [B,T,C] channels-last."""
     bn = blk.bn
     y = TDNNBlockTrainFn.apply(x, blk.context_layer.weight, blk.context_layer.bias, bn.weight, bn.bias, bn.running_mean,
-                               bn.running_var, bn.momentum, bn.eps, 0.2, blk.dilation, not blk.bn_first)
-    bn.num_batches_tracked += 1
-    return y
+                               bn.running_var, bn.momentum, bn.eps, 0.2, blk.dilation, not blk.bn_first, bn.num_batches_tracked)
+    return y                              # (num_batches_tracked += 1: done by the launch that finishes the batch statistics)
 
 
 def bn_rows_act_train(x, bn, slope, act_first):
-    y = BNRowsActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, slope, act_first)
-    bn.num_batches_tracked += 1
-    return y
+    return BNRowsActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, slope, act_first,
+                             bn.num_batches_tracked)
 
 
 def meanstd_pool(x):

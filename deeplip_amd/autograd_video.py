@@ -16,7 +16,7 @@ import weakref
 import torch
 from torch.autograd import Function
 
-from . import ops
+from . import _lib, ops
 from ._lib import LIFT_BCAST, LIFT_WORDS, check, lib, ptr, stream_handle
 from .autograd import BNRowsActFn, _permute3, _ws
 
@@ -43,6 +43,7 @@ def const_vec(n: int, value: float, device):
 
 def _colsum_rows(x2):
     M, C_ = x2.shape
+    _lib.ensure_conv_workspace()
     y = torch.empty((C_,), device=x2.device, dtype=torch.float32)
     check(lib().dlip_colsum_rows_f32(ptr(x2), ptr(y), ptr(_ws(M, C_, x2.device)), M, C_, stream_handle()), "dlip_colsum_rows_f32")
     return y
@@ -655,16 +656,17 @@ class BNPReLUFn(Function):
     (dlip_bn_prelu_rows_train_fwd/bwd_f32): no separate PReLU forward / backward pass and no column sum of slope terms."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, momentum, eps, nbt=None):
         shape = tuple(x.shape)                                 # any channels-last shape [..., C]
         x = x.contiguous().view(-1, shape[-1])
         M, C_ = x.shape
+        _lib.ensure_conv_workspace()      # (its ticket words: the finalize steps run in the passes' last workgroups)
         y = torch.empty_like(x)
         mean = torch.empty((C_,), device=x.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         ws = torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 4,), device=x.device, dtype=torch.float64)
         check(lib().dlip_bn_prelu_rows_train_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(y), ptr(mean), ptr(invstd),
-                                                     ptr(running_mean), ptr(running_var), ptr(ws), M, C_, momentum, eps, stream_handle()),
+                                                     ptr(running_mean), ptr(running_var), ptr(ws), M, C_, momentum, eps, ptr(nbt), stream_handle()),
               "dlip_bn_prelu_rows_train_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, slope, mean, invstd)
         ctx.shape = shape
@@ -674,6 +676,7 @@ class BNPReLUFn(Function):
     def backward(ctx, dy):
         x, gamma, beta, slope, mean, invstd = ctx.saved_tensors
         M, C_ = x.shape
+        _lib.ensure_conv_workspace()
         dy = dy.contiguous().view(M, C_)
         dx = torch.empty_like(x)
         dg, db, ds = (torch.empty_like(mean) for _ in range(3))
@@ -684,7 +687,7 @@ class BNPReLUFn(Function):
               "dlip_bn_prelu_rows_train_bwd_f32")
         dx = dx.view(ctx.shape)
         dx._dlip_lift = lift      # see autograd._bn_rows_bwd: travels with the tensor object the convolution backward receives
-        return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None
+        return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None, None
 
 
 class AddPReLUFn(Function):
@@ -815,9 +818,8 @@ def batchnorm(x, bn):
     """Train-mode BatchNorm over all leading axes of a channels-last tensor; running stats updated in place
     (nn.BatchNorm1d/2d/3d: resnet.py:51,64,16; model.py:83; tcn.py:42)."""
     C_ = x.shape[-1]
-    y = BNRowsActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, 1.0, False)
-    bn.num_batches_tracked += 1
-    return y
+    return BNRowsActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, 1.0, False,
+                             bn.num_batches_tracked)       # (the counter is incremented by the launch that finishes the statistics)
 
 
 def batchnorm_prelu(x, bn, act):
@@ -830,8 +832,7 @@ def batchnorm_prelu(x, bn, act):
     if w is None:
         w = const_vec(C_, 0.0, x.device)
     y = BNPReLUFn.apply(x, bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(),
-                        bn.running_mean, bn.running_var, bn.momentum, bn.eps)
-    bn.num_batches_tracked += 1
+                        bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.num_batches_tracked)
     return y
 
 

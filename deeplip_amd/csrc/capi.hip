@@ -12,7 +12,7 @@ extern "C" const char* dlip_error_string(int code) {
 }
 
 // ---- diagnostic overrides and range status (include/deeplip_hip.h) ----
-int dlip_dbg_value[DLIP_DBG_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
+int dlip_dbg_value[DLIP_DBG_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 
 extern "C" int dlip_debug_set(int32_t key, int32_t value) {
   DLIP_CHECK_ARG(key >= 0 && key < DLIP_DBG_COUNT);

@@ -334,6 +334,7 @@ extern "C" int dlip_conv_f16x3_win_launch(const void* args, void* stream, int ou
 extern "C" int dlip_conv_rows_ok(const void* args);                                         // conv_rows_f16x3.hip
 extern "C" int dlip_conv_f16x3_rows_launch(const void* args, void* stream, int epi);
 extern "C" int dlip_conv_rows_plan(const dlip_conv_desc* d, int* bm);
+extern "C" long long dlip_conv_rows_tiles(const dlip_conv_desc* d);
 extern "C" int dlip_conv_rows_pool_plan(const dlip_conv_desc* d, int* bm);
 
 // Diagnostic switch (dlip_debug_set DLIP_DBG_DMA_ENABLE = 0): keeps split-format launches on the register-staged kernel.
@@ -399,11 +400,8 @@ extern "C" int dlip_conv_nhwc_f16x3(const dlip_conv_desc* d, const float* x, con
 // dlip_conv_nhwc_f16x3 (split input, fp32 output, no residual) that also leaves the column sums of its output (include/deeplip_hip.h).
 extern "C" int32_t dlip_conv_stats_chunks(const dlip_conv_desc* d) {
   if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || (d->C & 31) != 0 || (d->K & 3) != 0 || (d->ldy & 3) != 0 || !dlip_conv_dma_enabled()) return 0;
-  int bm = 0;
-  if (!dlip_conv_rows_plan(d, &bm) || bm <= 0) return 0;        // (the window kernel is asked first by the launch: not a rows shape then)
-  const long long M = (long long)d->N * d->Ho * d->Wo;
-  const long long chunks = 2 * ((M + bm - 1) / bm);
-  return chunks <= 0x7FFFFFFF ? (int32_t)chunks : 0;
+  const long long chunks = 2 * dlip_conv_rows_tiles(d);        // (the window kernel is asked first by the launch: not a rows shape then)
+  return chunks > 0 && chunks <= 0x7FFFFFFF ? (int32_t)chunks : 0;
 }
 
 extern "C" int dlip_conv_nhwc_stats_f16x3(const dlip_conv_desc* d, const float* x, const void* w_split, const float* w_scale,

@@ -51,6 +51,13 @@ struct RowsSched {
   FastDiv div_G, div_iters, div_nk;
   float* slabs;
   int* counters;
+  // MODE 0 (round 5), the SHORT LAST ROUND: row tiles t_full.. (items item_short0..) are 32 * nmi_short rows high instead of 32 MI, so
+  // that the rows left over after the launch's full rounds of tiles spread over ALL workgroups as one round of shorter tiles (B = 256:
+  // 948 tiles of 160 rows on 256 CUs = 3 full rounds + a fourth that is 70 % full -> 3 rounds + one of 128-row tiles: 3.8 tile
+  // times instead of 4).  A short tile keeps the LDS image of a full one: its wave row w holds rows w * 16 nmi_short .. of the tile
+  // in LDS rows w * 16 MI ..; the rest of the image is not fetched (out-of-range offsets), not multiplied and not stored.
+  // No short tiles: item_short0 = t_full = INT_MAX.
+  int item_short0, t_full, nmi_short, row_short0;
 #ifdef DLIP_LAB
   unsigned long long* stamps;
 #endif
@@ -69,6 +76,15 @@ __device__ __forceinline__ RowsKArgs* rows_kargs() {
   return p;
 }
 
+// ... and the RowsSched behind it (second explicit argument: at the next 8-byte boundary)
+typedef const RowsSched __attribute__((address_space(4))) RowsKSched;
+__device__ __forceinline__ RowsKSched* rows_ksched() {
+  typedef const char __attribute__((address_space(4))) KChar;
+  KChar* p = (KChar*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return (RowsKSched*)(p + ((sizeof(ConvArgs) + 7) & ~(size_t)7));
+}
+
 // EPI: 0 fp32 rows of y; 1 split-format rows of y (reports range); 2 no y: per HALF tile (the 16 MI rows of a wave row) and
 // row-group segment the fp64 column sums of v and v^2 (a.pool, the ring kernel's pooled epilogue with tile rows = 16 MI)
 // MODE: 0 the speech encoder's form (file comment): every tap a plain row offset, whole tiles per workgroup, tiles g, g + G, ...
@@ -80,9 +96,15 @@ __device__ __forceinline__ RowsKArgs* rows_kargs() {
 //         accumulators of wave w of the other parts -- so each wave publishes its own quads (sc1 stores, vmcnt(0), one relaxed
 //         ticket on the tile's word for its position) and the wave that finds its position complete adds the others' in part
 //         order and runs the epilogue; different waves of a tile may finish in different workgroups, the bits do not depend on it.
-template <int MI, int EPI, int MODE = 0, bool DUAL = false>
+// TAIL: the launch has a short last round (RowsSched); instances without it carry none of its code.
+template <int MI, int EPI, int MODE = 0, bool DUAL = false, bool TAIL = false>
 __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs a, const RowsSched sc) {
   static_assert(MODE == 1 || !DUAL, "the second source exists in the general mode only");
+  static_assert(!TAIL || (MODE == 0 && EPI != 2), "short tiles: the speech encoder's form, fp32 or split output");
+  // (TAIL) the four schedule words are re-read from the kernel-argument segment (scalar loads) where a tile begins or ends: held in
+  // scalar registers across the main loop they cost the split-output instances 40 SGPR spills and the B = 64 step 1 % (the
+  // paired-lanes lesson again)
+#define ROWS_SC(f) (rows_ksched()->f)
   static_assert(MODE == 0 || EPI != 2, "no pooled epilogue in the general mode");
   constexpr int NW = 8, BN = ROWS_BN, BM = 32 * MI, NI = 4;
   constexpr int WM = BM / 2;                       // rows of a wave's tile (16 MI); WN = 64
@@ -163,6 +185,10 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
     const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
     [[maybe_unused]] RowsKArgs* ap = nullptr;
     if constexpr (MODE == 1) ap = rows_kargs();
+    [[maybe_unused]] int t_base = tile_m * BM, t_half = WM;   // (MODE 0) the tile's first row, rows per wave row (RowsSched: short last round)
+    if constexpr (TAIL) {
+      if (item >= ROWS_SC(item_short0)) { t_half = 16 * ROWS_SC(nmi_short); t_base = ROWS_SC(row_short0) + (tile_m - ROWS_SC(t_full)) * 2 * t_half; }
+    }
 #pragma unroll
     for (int j = 0; j < NA_A; ++j) {
       const int m = tile_m * BM + 8 * (wave + 8 * j) + prow;
@@ -180,10 +206,14 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
         for (int r = 0; r < ap->R; ++r) ok |= ((unsigned)(hi0 + r * ap->dh) < (unsigned)ap->H ? colbits : 0u) << (r * ap->S);
         a_mask[j] = m < ap->M ? ~ok : ~0u;
       } else {
-        const int mc = m < a.M ? m : 0;
+        const int lr = 8 * (wave + 8 * j) + prow;            // row of the LDS image; hr: within its wave row
+        const int hr = lr >= WM ? lr - WM : lr;
+        const int ms = t_base + (lr >= WM ? t_half : 0) + hr;
+        const bool in = hr < t_half && ms < a.M;
+        const int mc = in ? ms : 0;
         const int n = dlip_div(mc, a.div_howo);
         const int t = mc - n * a.HoWo;                       // H = 1: the row's first input pixel is n * W + t
-        a_off[j] = m < a.M ? (uint32_t)(((n * a.W + t) * a.ldx + csrc) * 4) : DLIP_OOB_OFFSET;
+        a_off[j] = in ? (uint32_t)(((n * a.W + t) * a.ldx + csrc) * 4) : DLIP_OOB_OFFSET;
       }
     }
 #pragma unroll
@@ -278,15 +308,18 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) fbl[ni] = *reinterpret_cast<const f16x8*>(Bw + ni * 16 * LDK + klo);
   };
-  auto mfma_all = [&]() __attribute__((always_inline)) {
+  auto mfma_all = [&](int nmi) __attribute__((always_inline)) {   // nmi (wave-uniform): 16-row blocks of this wave's rows that exist
     __builtin_amdgcn_s_setprio(2);   // the matrix phase outranks its SIMD partner's load phase
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+      // (TAIL) a tile of the short last round skips the blocks it does not have: one scalar compare-and-branch per block
+      if (!TAIL || mi < nmi) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {   // accumulator-major: the three products of one accumulator back to back (ring kernel)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[ni], fal[mi], acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[ni], fah[mi], acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[ni], fah[mi], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) {   // accumulator-major: the three products of one accumulator back to back (ring kernel)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[ni], fal[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[ni], fah[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[ni], fah[mi], acc[mi][ni], 0, 0, 0);
+        }
       }
       DLIP_FENCE();
     }
@@ -329,7 +362,11 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       eM = ap->M; eK = ap->K; eldy = ap->ldy; eldr = ap->ldr;
     }
     const int tile_m = item / sc.tiles_n, tile_n = item - tile_m * sc.tiles_n;
-    const int row0 = tile_m * BM + wm * WM + lrow;
+    int row0 = tile_m * BM + wm * WM + lrow;
+    [[maybe_unused]] int e_nmi = MI;                  // (TAIL) 16-row blocks of this wave's rows that exist (short last round)
+    if constexpr (TAIL) {
+      if (item >= ROWS_SC(item_short0)) { e_nmi = ROWS_SC(nmi_short); row0 = ROWS_SC(row_short0) + ((tile_m - ROWS_SC(t_full)) * 2 + wm) * 16 * e_nmi + lrow; }
+    }
     const int col0 = tile_n * BN + wn * 64;
     if constexpr (EPI == 1) {
       // after the swap, 16-lane row hq of the pair (2 p, 2 p + 1) holds channels 32 p + {0, 16, 8, 24}[hq] + 0..7 of its pixel
@@ -395,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
             amax = fmaxf(amax, fabsf(t));
           }
           const int m = row0 + mi * 16;
-          const bool ok = m < eM && k0 < eK;           // K % 32 == 0 for a split output: a block is whole or absent
+          const bool ok = m < eM && k0 < eK && (!TAIL || mi < e_nmi);   // K % 32 == 0 for a split output: a block is whole or absent
           const uint32_t off = ok ? (uint32_t)((m * eldy + kb) * 4 + cs * 2) : DLIP_OOB_OFFSET;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), yr, (int)off, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), yr, (int)(ok ? off + 64u : DLIP_OOB_OFFSET), 0, 0);
@@ -514,11 +551,11 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
             if (post) t = t * p4[c] + t4[c];
             v[c] = t;
           }
-          if (want_stats && m < eM) {
+          if (want_stats && m < eM && (!TAIL || mi < e_nmi)) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) { st_s[c] += v[c]; st_q[c] += v[c] * v[c]; }
           }
-          const uint32_t off = (m < eM && k0 < eK) ? (uint32_t)((m * eldy + k0) * 4) : DLIP_OOB_OFFSET;   // K % 4 == 0
+          const uint32_t off = (m < eM && k0 < eK && (!TAIL || mi < e_nmi)) ? (uint32_t)((m * eldy + k0) * 4) : DLIP_OOB_OFFSET;   // K % 4 == 0
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, (int)off, 0, 0);
         }
         if (want_stats) {
@@ -644,6 +681,8 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
     int st_iss = total > 1 ? 2 : 1;                        // stage the next issue goes to (the prologue issued slices 0, 1)
     // consumer side: the segment being multiplied (MODE 0: always a whole tile)
     int kleft = nk, e_item = item0, done_item = -1;
+    [[maybe_unused]] int cur_nmi = MI;                     // (TAIL) the height of the tile being multiplied, in 16-row blocks per wave
+    if constexpr (TAIL) { if (e_item >= ROWS_SC(item_short0)) cur_nmi = ROWS_SC(nmi_short); }
     [[maybe_unused]] int rem = 0;
     [[maybe_unused]] bool e_part = false, e_first = true, done_part = false, done_first = false;   // (wave-uniform; MODE 1)
     if constexpr (MODE == 1) {
@@ -693,7 +732,7 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
       ROWS_SSTAMP(2);
       __builtin_amdgcn_s_barrier();                        // A: b(2s)      B: b(2s+1)
       ROWS_SSTAMP(3);
-      mfma_all();
+      mfma_all(cur_nmi);
       ROWS_SSTAMP(4);
       if constexpr (MODE == 1) {
         if (--kleft == 0) {
@@ -705,7 +744,10 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
           e_first = false;
         }
       } else {
-        if (--kleft == 0) { kleft = nk; done_item = e_item; e_item += nwg; }
+        if (--kleft == 0) {
+          kleft = nk; done_item = e_item; e_item += nwg;
+          if constexpr (TAIL) { if (e_item >= ROWS_SC(item_short0)) cur_nmi = ROWS_SC(nmi_short); }
+        }
       }
       if (FIRST) {
         __builtin_amdgcn_s_barrier();                      // b(2s+1)
@@ -732,17 +774,41 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 
 constexpr int kRowsDeclined = -1000;   // (internal) a MODE 1 launch that found no split workspace: the caller takes the ring kernel
 
-template <int MI, int EPI, int MODE = 0, bool DUAL = false>
+int rows_cus() {
+  static int cus = 0;                                  // (one device kind per process: every MI355X has the same count)
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+  }
+  return cus > 0 ? cus : 256;
+}
+
+// The short last round (RowsSched): M rows on tiles of 32 mi x 256, `slots` resident workgroups (one per CU).  full = row tiles of the
+// full height (whole rounds of the chip), nmi = height of the rest in units of 32 rows (== mi: no short tiles), tiles_m = all row tiles.
+struct RowsTail { long long tiles_m, full; int nmi; };
+RowsTail rows_tail(long long M, int tiles_n, int mi, int slots) {
+  const int bm = 32 * mi;
+  RowsTail t{(M + bm - 1) / bm, 0, mi};
+  if (dlip_dbg_value[DLIP_DBG_ROWS_TAIL] == 0 || slots <= 0 || tiles_n <= 0 || slots % tiles_n != 0) return t;
+  const long long slots_m = slots / tiles_n, per_round = (long long)bm * slots_m;
+  const long long rounds = M / per_round, rem = M - rounds * per_round;
+  if (rounds == 0 || rem == 0) return t;              // (one round: rows_pick_mi has picked the height; whole rounds: nothing left over)
+  const int nmi = (int)((rem + 32 * slots_m - 1) / (32 * slots_m));
+  if (nmi >= mi) return t;
+  t.full = rounds * slots_m;
+  t.nmi = nmi;
+  t.tiles_m = t.full + (rem + 32 * nmi - 1) / (32 * nmi);
+  return t;
+}
+
+template <int MI, int EPI, int MODE = 0, bool DUAL = false, bool TAIL = false>
 int launch_rows(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = 32 * MI;
   constexpr size_t lds = (size_t)3 * (BM + ROWS_BN) * ROWB;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds a CU");
   ConvArgs b = a;
   b.tiles_n = (a.K + ROWS_BN - 1) / ROWS_BN;
-  const long long tiles_m = ((long long)a.M + BM - 1) / BM;
-  const long long items = tiles_m * b.tiles_n;
-  if (items <= 0 || items > 0x3FFFFFFFll) return DLIP_EINVAL;
-  auto kern = conv_rows_f16x3_kernel<MI, EPI, MODE, DUAL>;
+  auto kern = conv_rows_f16x3_kernel<MI, EPI, MODE, DUAL, TAIL>;
   static DlipKernelState ks;
   int e = ks.ensure_lds(reinterpret_cast<const void*>(kern), lds);
   if (e != DLIP_OK) return e;
@@ -750,6 +816,19 @@ int launch_rows(const ConvArgs& a, hipStream_t st) {
   e = ks.resident(reinterpret_cast<const void*>(kern), 512, lds, &slots);   // one workgroup per CU
   if (e != DLIP_OK) return e;
   RowsSched sc;
+  long long tiles_m = ((long long)a.M + BM - 1) / BM;
+  sc.item_short0 = sc.t_full = 0x7FFFFFFF; sc.nmi_short = MI; sc.row_short0 = 0;
+  if constexpr (TAIL) {
+    // the short last round is laid out for the CUs of the chip -- what dlip_conv_stats_chunks can know without a launch; `slots` is that
+    // number whenever the kernel is resident once per CU (if it ever were not, the layout would still be correct, only less even)
+    const RowsTail t = rows_tail(a.M, b.tiles_n, MI, rows_cus());
+    if (t.nmi < MI) {
+      tiles_m = t.tiles_m;
+      sc.t_full = (int)t.full; sc.item_short0 = (int)(t.full * b.tiles_n); sc.nmi_short = t.nmi; sc.row_short0 = (int)(t.full * BM);
+    }
+  }
+  const long long items = tiles_m * b.tiles_n;
+  if (items <= 0 || items > 0x3FFFFFFFll) return DLIP_EINVAL;
   sc.items = (int)items;
   sc.tiles_n = b.tiles_n;
   sc.iters = 0; sc.G = 0; sc.slabs = nullptr; sc.counters = nullptr;
@@ -809,14 +888,23 @@ int launch_rows(const ConvArgs& a, hipStream_t st) {
 // Tile height.  A launch takes ceil(items / CUs) rounds of one tile-time ~ MI (+ a fixed part per round: first fill and the
 // exposed half of the last epilogue, about a slice and a half of a 16-slice tile); the fewest "row units" wins, the taller
 // tile on a tie (fewer bytes per MFMA).
-int rows_pick_mi(long long M, int K, int nk, int cus) {
+// (round 5) ... and a launch whose last round is SHORT (rows_tail) pays that round at its own height.
+int rows_pick_mi(long long M, int K, int nk, int cus, bool tail = true) {   // tail = false: a pooled launch (tiles of one height)
   const int tiles_n = (K + ROWS_BN - 1) / ROWS_BN;
   int best = 5;
   double best_cost = 1e300;
   for (int mi = 5; mi >= 3; --mi) {
-    const long long items = ((M + 32 * mi - 1) / (32 * mi)) * tiles_n;
-    const long long rounds = (items + cus - 1) / cus;
-    const double cost = (double)rounds * (mi * (double)nk + 1.5 * 5.0) * (mi == 5 ? 1.0 : mi == 4 ? 1.04 : 1.10);
+    const RowsTail t = tail ? rows_tail(M, tiles_n, mi, cus) : RowsTail{(M + 32 * mi - 1) / (32 * mi), 0, mi};
+    const double eff = mi == 5 ? 1.0 : mi == 4 ? 1.04 : 1.10;
+    double cost;
+    if (t.nmi < mi) {
+      const long long rounds = t.full * tiles_n / cus;
+      cost = ((double)rounds * (mi * (double)nk + 1.5 * 5.0) + (t.nmi * (double)nk + 1.5 * 5.0)) * eff;
+    } else {
+      const long long items = t.tiles_m * tiles_n;
+      const long long rounds = (items + cus - 1) / cus;
+      cost = (double)rounds * (mi * (double)nk + 1.5 * 5.0) * eff;
+    }
     if (cost < best_cost * 0.999) { best_cost = cost; best = mi; }
   }
   return best;
@@ -845,15 +933,24 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_ok(const voi
 
 // The same decision from a descriptor (dlip_conv_kernel_kind / dlip_conv_plan: which kernel and tile a profiler will show for a
 // split-format launch of `d` without a residual); *bm = the tile height the launch will use.
-extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_plan(const dlip_conv_desc* d, int* bm) {
+static int rows_plan(const dlip_conv_desc* d, int* bm, bool tail) {
   const long long M = (long long)d->N * d->Ho * d->Wo;
   if (d->ldr != 0 || !rows_shape_ok(d->H, d->R, d->S, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->C, d->K, M)) return 0;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  int mi = rows_pick_mi(M, d->K, d->S * (d->C / 32), cus > 0 ? cus : 256);
+  int mi = rows_pick_mi(M, d->K, d->S * (d->C / 32), rows_cus(), tail);
   if (const int v = dlip_dbg_value[DLIP_DBG_ROWS]; v >= 3 && v <= 5) mi = v;
   if (bm) *bm = 32 * mi;
   return 1;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_plan(const dlip_conv_desc* d, int* bm) { return rows_plan(d, bm, true); }
+
+// Row tiles of the fp32 / split-output launch dlip_conv_rows_plan describes (with its short last round, if any): the statistics
+// epilogue writes two partial rows per row tile (dlip_conv_stats_chunks).
+extern "C" __attribute__((visibility("hidden"))) long long dlip_conv_rows_tiles(const dlip_conv_desc* d) {
+  int bm = 0;
+  if (!dlip_conv_rows_plan(d, &bm) || bm <= 0) return 0;
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  return rows_tail(M, (d->K + ROWS_BN - 1) / ROWS_BN, bm / 32, rows_cus()).tiles_m;
 }
 
 // MODE 1: which launches of the LDS-DMA path (split input; dlip_conv_f16x3_dma_launch asks first) CAN take the rows kernel's general
@@ -923,16 +1020,14 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_declined(voi
 // pooled launch comes here only when the rows kernel is FORCED (dlip_debug_set(6, 1 | 3 | 4 | 5): tests, A/B runs).
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_rows_pool_plan(const dlip_conv_desc* d, int* bm) {
   if (dlip_dbg_value[DLIP_DBG_ROWS] <= 0) return 0;
-  return dlip_conv_rows_plan(d, bm);
+  return rows_plan(d, bm, false);
 }
 
 extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_rows_launch(const void* args, void* stream, int epi) {
   const ConvArgs& a = *static_cast<const ConvArgs*>(args);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return DLIP_EINVAL;
-  int mi = rows_pick_mi(a.M, a.K, a.nk, cus);
+  const int cus = rows_cus();
+  int mi = rows_pick_mi(a.M, a.K, a.nk, cus, epi != 2);
   if (const int v = dlip_dbg_value[DLIP_DBG_ROWS]; v >= 3 && v <= 5) mi = v;   // dlip_debug_set: a forced tile height (tests, A/B)
   if (epi == 2) {   // pooled: a half tile (16 mi rows) may contain at most one row-group boundary
     if (a.pool == nullptr || a.pool_group < 16 * mi) return DLIP_EINVAL;
@@ -940,6 +1035,14 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_rows_launch
       case 3: return launch_rows<3, 2>(a, st);
       case 4: return launch_rows<4, 2>(a, st);
       default: return launch_rows<5, 2>(a, st);
+    }
+  }
+  // a launch with a short last round (rows_tail) runs the TAIL instance; everything else the instance without that code
+  if (rows_tail(a.M, (a.K + ROWS_BN - 1) / ROWS_BN, mi, cus).nmi < mi) {
+    switch (mi) {
+      case 3: return epi ? launch_rows<3, 1, 0, false, true>(a, st) : launch_rows<3, 0, 0, false, true>(a, st);
+      case 4: return epi ? launch_rows<4, 1, 0, false, true>(a, st) : launch_rows<4, 0, 0, false, true>(a, st);
+      default: return epi ? launch_rows<5, 1, 0, false, true>(a, st) : launch_rows<5, 0, 0, false, true>(a, st);
     }
   }
   switch (mi) {

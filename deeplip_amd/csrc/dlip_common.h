@@ -20,7 +20,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic overrides (dlip_debug_set, include/deeplip_hip.h): -1 = the built-in choice.  Plain ints read on
 // the launch path -- the library itself reads no environment variable there.
-enum { DLIP_DBG_CONV_TILE = 0, DLIP_DBG_DMA_TILE = 1, DLIP_DBG_DMA_ENABLE = 2, DLIP_DBG_STREAMK = 3, DLIP_DBG_WIN = 4, DLIP_DBG_NINNER = 5, DLIP_DBG_ROWS = 6, DLIP_DBG_ROWS2D = 7, DLIP_DBG_COUNT = 8 };
+enum { DLIP_DBG_CONV_TILE = 0, DLIP_DBG_DMA_TILE = 1, DLIP_DBG_DMA_ENABLE = 2, DLIP_DBG_STREAMK = 3, DLIP_DBG_WIN = 4, DLIP_DBG_NINNER = 5, DLIP_DBG_ROWS = 6, DLIP_DBG_ROWS2D = 7, DLIP_DBG_BN_FUSED = 8, DLIP_DBG_ROWS_TAIL = 9, DLIP_DBG_COUNT = 10 };
 extern "C" __attribute__((visibility("hidden"))) int dlip_dbg_value[DLIP_DBG_COUNT];
 
 // Range-status words (dlip_set_status_words): where the f16x3 kernels report an activation the split format

@@ -24,18 +24,74 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ?
 // MODE 2: s0 = sum x, s1 unused                                                   (bias gradient)
 // MODE 3: MODE 1 for y = prelu(bn(x)) with the per-channel slopes `slope_vec` (act_first = 0), plus
 //         s2 = sum (bn(x) < 0 ? dy * bn(x) : 0) = the slope gradient, written as {s2, 0} pairs to a SECOND partial
-//         region behind the first (part + chunks * C * 2): BatchNorm + PReLU backward sums in one pass over dy and x
+//         region behind the first (part + parts * C * 2): BatchNorm + PReLU backward sums in one pass over dy and x
+//
+// (round 5) What follows the partial sums -- adding them per channel and forming mean / 1/std (MODE 0) or the parameter gradients
+// (MODE 1 / 3) or the bias gradient (MODE 2) -- used to be a launch of its own (bn_fwd_finalize / col_finalize / col_finalize3:
+// 128 launches of a lip-clip training step, 5 - 90 us each, 0.7 ms on the critical path: on the MS-TCN head's 1 MB tensors they
+// cost more than the passes they finish).  With `fin.ticket` (this stream's self-resetting ticket words: the convolution split's
+// workspace) the workgroup that finishes LAST for a 64-column block -- its ticket says so -- adds that block's partials in part
+// order (4 lane groups x parts / 4, then the groups in order: a fixed association whichever workgroup it is) and writes the results.
+// Rows per part grow beyond 512 so that a launch has at most 512 parts: the finisher reads them through ONE CU.
+struct ColFin {
+  int* ticket;                       // nullptr: the caller launches the finalize kernel
+  float* out0;                       // MODE 0 save_mean   | MODE 1 / 3 dbeta  | MODE 2 the column sums
+  float* out1;                       // MODE 0 save_invstd | MODE 1 / 3 dgamma
+  float* out2;                       // MODE 3 dslope
+  float* running_mean;               // MODE 0 (nullable pair)
+  float* running_var;
+  long long* nbt;                    // MODE 0 (nullable): num_batches_tracked += 1
+  float momentum, eps;
+};
+
+__device__ __forceinline__ void bn_stats_finish(double s, double q, int M, int c, float* save_mean, float* save_invstd,
+                                                float* running_mean, float* running_var, float momentum, float eps) {
+  const double mean = s / M;
+  double var = q / M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(M > 1 ? var * M / (M - 1) : var);
+  }
+}
+
+// The calling workgroup has written its share of a result other workgroups' shares complete -- with publish() below: write-through
+// stores, visible to the whole device once acknowledged -- and now takes a ticket on `word`; returns whether this workgroup took the
+// LAST of `n` (it then re-zeroes the word for the next launch on this stream and drops its caches' stale lines: the others' shares
+// are read with plain loads).  Every thread of the workgroup calls it; no workgroup waits for another.
+// (NOT __threadfence(): an agent-scope release writes back the whole L2 -- issued by each of a pass's ~1 000 workgroups it doubled
+// the training steps' time; the convolution kernels' split hand-off publishes the same way as this.)
+template <typename T>
+__device__ __forceinline__ void publish(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool last_arrival(int* word, int n) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == n - 1;
+    if (s_last) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const bool last = s_last != 0;
+  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return last;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          double* __restrict__ part, int M, int C, float slope, int act_first,
-                                                          const float* __restrict__ slope_vec = nullptr) {
+                                                          double* part, int M, int C, float slope, int act_first,
+                                                          const float* __restrict__ slope_vec, int rows_per_part, const ColFin fin) {
   __shared__ double red[16][64][MODE == 3 ? 3 : 2];
   const int c0 = blockIdx.x * 64, chunk = blockIdx.y;
   const int lx = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = c0 + lx * 4;
-  const int r0 = chunk * CHUNK_ROWS, r1 = min(M, r0 + CHUNK_ROWS);
+  const int r0 = chunk * rows_per_part, r1 = min(M, r0 + rows_per_part);
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   if (c < C) {   // C % 4 == 0
     f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, ga = {0, 0, 0, 0}, be = {0, 0, 0, 0}, sl = {0, 0, 0, 0};
@@ -44,8 +100,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
       ga = *reinterpret_cast<const f32x4*>(gamma + c); be = *reinterpret_cast<const f32x4*>(beta + c);
     }
     if (MODE == 3) sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
-    for (int r = r0 + rg; r < r1; r += 16) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long long)r * C + c);
+    auto add_row = [&](const f32x4 xv, const f32x4 gv) __attribute__((always_inline)) {
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -53,7 +108,6 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
           s0[k] += a; s1[k] += a * a;
         }
       } else if (MODE == 1) {
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + (long long)r * C + c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float a = act_first ? lrelu(xv[k], slope) : xv[k];
@@ -63,7 +117,6 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
           s0[k] += (double)g; s1[k] += (double)g * (double)xh;
         }
       } else if (MODE == 3) {
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + (long long)r * C + c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float xh = (xv[k] - mu[k]) * is[k];
@@ -76,6 +129,25 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) s0[k] += (double)xv[k];
       }
+    };
+    // four rows of a lane group per trip, their loads issued together (one load in flight per lane held a pass at half of what
+    // the memory system gives once a part is longer than a few trips)
+    constexpr bool TWO = MODE == 1 || MODE == 3;
+    int r = r0 + rg;
+    for (; r + 48 < r1; r += 64) {
+      f32x4 xv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *reinterpret_cast<const f32x4*>(x + (long long)(r + 16 * u) * C + c);
+        gv[u] = TWO ? *reinterpret_cast<const f32x4*>(dy + (long long)(r + 16 * u) * C + c) : xv[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add_row(xv[u], gv[u]);
+    }
+    for (; r < r1; r += 16) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long long)r * C + c);
+      const f32x4 gv = TWO ? *reinterpret_cast<const f32x4*>(dy + (long long)r * C + c) : xv;
+      add_row(xv, gv);
     }
   }
 #pragma unroll
@@ -84,6 +156,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     if (MODE == 3) red[rg][lx * 4 + k][2] = s2[k];
   }
   __syncthreads();
+  const int parts = gridDim.y;
   if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
@@ -92,11 +165,54 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
       if (MODE == 3) a2 += red[i][threadIdx.x][2];
     }
     double* p = part + ((long long)chunk * C + c0 + threadIdx.x) * 2;
-    p[0] = a0; p[1] = a1;
+    publish(p, a0); publish(p + 1, a1);
     if (MODE == 3) {
-      double* p2 = p + (long long)gridDim.y * C * 2;
-      p2[0] = a2; p2[1] = 0.0;
+      double* p2 = p + (long long)parts * C * 2;
+      publish(p2, a2); publish(p2 + 1, 0.0);
     }
+  }
+  if (fin.ticket == nullptr) return;
+  if (!last_arrival(fin.ticket + blockIdx.x, parts)) return;
+  // ---- this workgroup finishes the block's 64 columns: lane group g adds parts g, g + 4, ... (four loads in flight), then the groups ----
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int cc = c0 + col;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (cc < C) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double* pa = part + (long long)cc * 2;
+    const double* pb = pa + (long long)parts * C * 2;
+    const long long step = (long long)C * 2;
+    int i = grp;
+    for (; i + 12 < parts; i += 16) {
+      d2 v[4], w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const d2*>(pa + (i + 4 * u) * step);
+        if (MODE == 3) w[u] = *reinterpret_cast<const d2*>(pb + (i + 4 * u) * step);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a0 += v[u][0]; a1 += v[u][1]; if (MODE == 3) a2 += w[u][0]; }
+    }
+    for (; i < parts; i += 4) {
+      a0 += pa[i * step]; a1 += pa[i * step + 1];
+      if (MODE == 3) a2 += pb[i * step];
+    }
+  }
+  __syncthreads();                                   // (red is free: every thread passed last_arrival's barriers)
+  red[grp][col][0] = a0; red[grp][col][1] = a1;
+  if (MODE == 3) red[grp][col][2] = a2;
+  __syncthreads();
+  if (grp != 0 || cc >= C) return;
+  double s = 0.0, q = 0.0, t = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s += red[i][col][0]; q += red[i][col][1]; if (MODE == 3) t += red[i][col][2]; }
+  if (MODE == 0) {
+    bn_stats_finish(s, q, M, cc, fin.out0, fin.out1, fin.running_mean, fin.running_var, fin.momentum, fin.eps);
+    if (fin.nbt && cc == 0) fin.nbt[0] += 1;
+  } else {
+    if (fin.out0) fin.out0[cc] = (float)s;
+    if (MODE != 2 && fin.out1) fin.out1[cc] = (float)q;
+    if (MODE == 3) fin.out2[cc] = (float)t;
   }
 }
 
@@ -124,19 +240,12 @@ __device__ __forceinline__ bool col_reduce16(const double* __restrict__ part, in
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ save_mean,
                                                               float* __restrict__ save_invstd, float* __restrict__ running_mean,
                                                               float* __restrict__ running_var, int M, int C, int chunks,
-                                                              float momentum, float eps) {
+                                                              float momentum, float eps, long long* __restrict__ nbt) {
   double s, q;
   if (!col_reduce16(part, C, chunks, s, q)) return;
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-  const double mean = s / M;
-  double var = q / M - mean * mean;
-  if (var < 0.0) var = 0.0;
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(M > 1 ? var * M / (M - 1) : var);
-  }
+  bn_stats_finish(s, q, M, c, save_mean, save_invstd, running_mean, running_var, momentum, eps);
+  if (nbt && c == 0) nbt[0] += 1;
 }
 
 // FIXED: the launch's stride (gridDim.x * 256) is a multiple of C4, so a thread meets ONE channel group in every iteration and
@@ -199,6 +308,27 @@ __global__ __launch_bounds__(256) void col_finalize3_kernel(const double* __rest
   out0[c] = (float)s; out1[c] = (float)q; out2[c] = (float)r;
 }
 
+// out[0] = 2^floor(log2(target / max(parts))), out[1] = 1 / out[0]: the per-workgroup maxima of a producer pass (non-negative floats
+// as bit patterns) reduced by ONE workgroup (every thread of it calls): the kernel of that name, or the last workgroup of the
+// producer itself.  `parts` may be out + 2 (the maxima live where the broadcast copies go: all read before the first is written).
+__device__ __forceinline__ void pow2_finalize_parts(const unsigned* parts, int n, float* out, float target) {
+  __shared__ unsigned red[4];
+  unsigned m = 0u;
+  for (int i = threadIdx.x; i < n; i += 256) m = max(m, parts[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const float mx = __uint_as_float(max(max(red[0], red[1]), max(red[2], red[3])));
+  float s = 1.f;
+  if (mx > 0.f && mx < 3.0e38f) s = exp2f(floorf(log2f(target / mx)));
+  if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
+  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; }
+  // words 2 .. 2 + DLIP_LIFT_BCAST: 1 / s repeated -- the per-output-channel post_scale vector of the convolution that consumes the
+  // lifted gradient (its epilogue takes a vector), without a fill launch per convolution.  (The maxima lived there: all read above.)
+  for (int i = threadIdx.x; i < DLIP_LIFT_BCAST; i += 256) out[2 + i] = 1.f / s;
+}
+
 // dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M), times lrelu'(x) when the activation came first
 template <bool FIXED>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
@@ -207,7 +337,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                            f32x4* __restrict__ dx, long long n4, int C4, int M, float slope,
                                                            int act_first, const float* __restrict__ slope_vec = nullptr,
-                                                           unsigned* __restrict__ amax_acc = nullptr) {
+                                                           unsigned* amax_acc = nullptr, int* ticket = nullptr) {
   const float invM = 1.f / (float)M;
   float amax = 0.f;     // max |dx| of the launch -> amax_acc (the next convolution backward's power-of-two lift, without its own pass)
   const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -245,8 +375,204 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
     if (threadIdx.x == 0) {
       float m = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
       if (!(m == m)) m = 3.4e38f;
-      amax_acc[blockIdx.x] = __float_as_uint(m);    // one word per workgroup, reduced by pow2_finalize_parts_kernel: thousands of
-    }                                               // workgroups meeting in ONE atomic cost 14 us per launch (the hot-line effect)
+      publish(amax_acc + blockIdx.x, __float_as_uint(m));   // one word per workgroup, reduced by pow2_finalize_parts: thousands of
+    }                                                       // workgroups meeting in ONE atomic cost 14 us per launch (the hot-line effect)
+    // (round 5) ... by the workgroup that arrives last (`ticket`), not by a launch of its own
+    if (ticket && last_arrival(ticket, (int)gridDim.x))
+      pow2_finalize_parts(amax_acc, (int)gridDim.x, reinterpret_cast<float*>(amax_acc) - 2, 1024.0f);
+  }
+}
+
+// ---- (round 5) BatchNorm over FEW rows in one launch -------------------------------------------------------------------------------
+// The MS-TCN head's 24 BatchNorm layers work on [B (T + pad), 256] ~ 1 - 2.5 MB (tcn.py:42-43 under model.train()): their statistics
+// pass, finalize, apply pass (forward) and sums, finalize, apply, lift (backward) were 3 + 4 launches of 5 - 15 us each -- launch
+// latency, not bytes: ~1 ms of an 18 ms lip-clip training step.  For M <= BN_SMALL_ROWS one workgroup owns FOUR channels: a lane
+// takes rows lane, lane + 256, ... (at most 16: R of them, a template parameter) and issues ALL its loads at once -- one memory
+// latency for the whole tensor, the values stay in registers --, the sums (fp64) meet by wave butterflies and a four-wave LDS step in
+// a fixed order, and y / dx are formed from the registers: one read, one write, one launch.  Same formulas per value as the
+// three-launch path; the association of the fp64 column sums differs (fixed here too: deterministic).
+constexpr int BN_SMALL_ROWS = 4096;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// sums over the workgroup of NQ quantities x 4 channels held per lane: butterflies within a wave, then the four waves in wave order
+template <int NQ>
+__device__ __forceinline__ void block_sums(double (&s)[NQ][4], double (*red)[NQ][4]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[q][k] = wave_sum(s[q][k]);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[wave][q][k] = s[q][k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[q][k] = ((red[0][q][k] + red[1][q][k]) + red[2][q][k]) + red[3][q][k];
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ slope_vec,
+                                                           float* __restrict__ y, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, long long* __restrict__ nbt, int M, int C,
+                                                           float momentum, float eps, float slope, int act_first) {
+  __shared__ double red[4][2][4];
+  const int c = blockIdx.x * 4;                              // C % 4 == 0: every workgroup has four live channels
+  f32x4 v[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int r = threadIdx.x + 256 * u;
+    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r < M) v[u] = *reinterpret_cast<const f32x4*>(x + (long long)r * C + c);
+  }
+  double s[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    if (threadIdx.x + 256 * u < M) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const double a = act_first ? lrelu(v[u][k], slope) : v[u][k]; s[0][k] += a; s[1][k] += a * a; }
+    }
+  }
+  block_sums<2>(s, red);
+  f32x4 mu, is;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                              // every lane forms the same mean / 1/std; lane k writes channel k's
+    const double mean = s[0][k] / M;
+    double var = s[1][k] / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mu[k] = (float)mean;
+    is[k] = (float)(1.0 / sqrt(var + (double)eps));
+    if ((int)threadIdx.x == k) {
+      save_mean[c + k] = mu[k]; save_invstd[c + k] = is[k];
+      if (running_mean) {
+        running_mean[c + k] = (1.f - momentum) * running_mean[c + k] + momentum * (float)mean;
+        running_var[c + k] = (1.f - momentum) * running_var[c + k] + momentum * (float)(M > 1 ? var * M / (M - 1) : var);
+      }
+    }
+  }
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+  f32x4 sl = {slope, slope, slope, slope};
+  if (slope_vec) sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int r = threadIdx.x + 256 * u;
+    if (r < M) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (act_first) o[k] = (lrelu(v[u][k], slope) - mu[k]) * is[k] * ga[k] + be[k];
+        else o[k] = lrelu((v[u][k] - mu[k]) * is[k] * ga[k] + be[k], sl[k]);
+      }
+      *reinterpret_cast<f32x4*>(y + (long long)r * C + c) = o;
+    }
+  }
+}
+
+// Backward of the above in one launch: slope_vec != NULL = y = prelu(bn(x)) with per-channel slopes (dslope written), else the
+// LeakyReLU forms of dlip_bn_rows_train_bwd_f32.  amax_acc / ticket: the lift of dx (one word per workgroup; the workgroup that
+// arrives last -- at most C / 4 arrivals on the word -- forms the pair); amax_acc without a ticket leaves the words for
+// pow2_finalize_parts_kernel.
+template <int R>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ slope_vec, float* __restrict__ dx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
+                                                           int M, int C, float slope, int act_first, unsigned* amax_acc, int* ticket) {
+  __shared__ double red[4][3][4];
+  const int c = blockIdx.x * 4;
+  const bool vec = slope_vec != nullptr;                     // (launch-uniform)
+  f32x4 xv[R], gv[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int r = threadIdx.x + 256 * u;
+    xv[u] = gv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r < M) {
+      xv[u] = *reinterpret_cast<const f32x4*>(x + (long long)r * C + c);
+      gv[u] = *reinterpret_cast<const f32x4*>(dy + (long long)r * C + c);
+    }
+  }
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+  f32x4 sl = {slope, slope, slope, slope};
+  if (vec) sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
+  double s[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  // pass 1 (registers): g = dy through the activation, xhat; the three column sums.  g replaces dy and xhat replaces x in place.
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    if (threadIdx.x + 256 * u < M) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float g = gv[u][k], xh;
+        if (vec) {                                           // col_partial_kernel<3>
+          xh = (xv[u][k] - mu[k]) * is[k];
+          const float bn = xh * ga[k] + be[k];
+          if (bn < 0.f) { s[2][k] += (double)g * (double)bn; g *= sl[k]; }
+        } else {                                             // col_partial_kernel<1>
+          const float a = act_first ? lrelu(xv[u][k], slope) : xv[u][k];
+          xh = (a - mu[k]) * is[k];
+          if (!act_first) g *= (xh * ga[k] + be[k]) >= 0.f ? 1.f : slope;
+        }
+        s[0][k] += (double)g; s[1][k] += (double)g * (double)xh;
+        gv[u][k] = g;
+        if (!act_first) xv[u][k] = xh;                       // (act_first keeps x: its sign gates the result below)
+      }
+    }
+  }
+  block_sums<3>(s, red);
+  f32x4 db, dg;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    db[k] = (float)s[0][k]; dg[k] = (float)s[1][k];
+    if ((int)threadIdx.x == k) {
+      dbeta[c + k] = db[k]; dgamma[c + k] = dg[k];
+      if (vec) dslope[c + k] = (float)s[2][k];
+    }
+  }
+  const float invM = 1.f / (float)M;
+  float amax = 0.f;
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int r = threadIdx.x + 256 * u;
+    if (r < M) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                          // bn_bwd_apply_kernel
+        float xh = xv[u][k];
+        if (act_first) xh = (lrelu(xv[u][k], slope) - mu[k]) * is[k];
+        float d = ga[k] * is[k] * (gv[u][k] - db[k] * invM - xh * dg[k] * invM);
+        if (act_first) d *= xv[u][k] >= 0.f ? 1.f : slope;
+        o[k] = d;
+        amax = fmaxf(amax, fabsf(d));
+      }
+      *reinterpret_cast<f32x4*>(dx + (long long)r * C + c) = o;
+    }
+  }
+  if (amax_acc) {
+    __shared__ float amax_red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
+      if (!(m == m)) m = 3.4e38f;
+      publish(amax_acc + blockIdx.x, __float_as_uint(m));
+    }
+    if (ticket && last_arrival(ticket, (int)gridDim.x))
+      pow2_finalize_parts(amax_acc, (int)gridDim.x, reinterpret_cast<float*>(amax_acc) - 2, 1024.0f);
   }
 }
 
@@ -333,24 +659,8 @@ __global__ void pow2_finalize_kernel(float* __restrict__ out, float target) {
   out[1] = 1.f / s;
 }
 
-// out[0] = 2^floor(log2(target / max(parts))), out[1] = 1 / out[0]: the per-workgroup maxima of a producer pass (non-negative floats
-// as bit patterns) reduced by one workgroup
-__global__ __launch_bounds__(256) void pow2_finalize_parts_kernel(const unsigned* __restrict__ parts, int n, float* __restrict__ out, float target) {
-  __shared__ unsigned red[4];
-  unsigned m = 0u;
-  for (int i = threadIdx.x; i < n; i += 256) m = max(m, parts[i]);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  const float mx = __uint_as_float(max(max(red[0], red[1]), max(red[2], red[3])));
-  float s = 1.f;
-  if (mx > 0.f && mx < 3.0e38f) s = exp2f(floorf(log2f(target / mx)));
-  if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
-  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; }
-  // words 2 .. 2 + DLIP_LIFT_BCAST: 1 / s repeated -- the per-output-channel post_scale vector of the convolution that consumes the
-  // lifted gradient (its epilogue takes a vector), without a fill launch per convolution.  (The maxima lived there: all read above.)
-  for (int i = threadIdx.x; i < DLIP_LIFT_BCAST; i += 256) out[2 + i] = 1.f / s;
+__global__ __launch_bounds__(256) void pow2_finalize_parts_kernel(const unsigned* parts, int n, float* out, float target) {
+  pow2_finalize_parts(parts, n, out, target);
 }
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -560,35 +870,137 @@ inline unsigned grid_fixed(long long n4, int C4) {
   return (unsigned)g;
 }
 
+// Parts of a column reduction over M rows: 512-row parts up to 512 of them, longer parts beyond (a multiple of the 16 row groups).
+inline int bn_rows_per_part(int M) {
+  long long rpp = ((long long)M + 511) / 512;
+  rpp = (rpp + 15) / 16 * 16;
+  return rpp < CHUNK_ROWS ? CHUNK_ROWS : (int)rpp;
+}
+
 }  // namespace
 
-extern "C" int32_t dlip_bn_rows_chunks(int32_t M) { return M > 0 ? (M + CHUNK_ROWS - 1) / CHUNK_ROWS : 0; }
+extern "C" int32_t dlip_bn_rows_chunks(int32_t M) {
+  if (M <= 0) return 0;
+  const int rpp = bn_rows_per_part(M);
+  return (M + rpp - 1) / rpp;
+}
+
+// conv_igemm_f16x3_dma.hip: this stream's self-resetting ticket words (the balanced split's workspace); 0 = none (a capture on a
+// stream that never launched eagerly): the finalize steps then run as launches of their own
+extern "C" int dlip_conv_split_workspace(void* stream, size_t slab_floats, float** slabs, int** counters, int* counter_words);
+
+namespace {
+
+int* stream_tickets(hipStream_t st, int need) {
+  if (dlip_dbg_value[DLIP_DBG_BN_FUSED] == 0) return nullptr;       // dlip_debug_set(8, 0): the round-4 launch sequence (tests, A/B runs)
+  float* slabs = nullptr;
+  int* ctr = nullptr;
+  int words = 0;
+  if (!dlip_conv_split_workspace(st, 0, &slabs, &ctr, &words) || words < need) return nullptr;
+  return ctr;
+}
+
+bool bn_small(int M) { return M <= BN_SMALL_ROWS && dlip_dbg_value[DLIP_DBG_BN_FUSED] != 0; }
+
+// Shared forward: statistics (a pass over x, or `ready_chunks` partial rows from the producing convolution), finalize, apply.
+int bn_fwd_launch(const float* x, const float* gamma, const float* beta, const float* slope_vec, float* y, float* save_mean,
+                  float* save_invstd, float* running_mean, float* running_var, double* workspace, int M, int C, float momentum,
+                  float eps, float slope, int act_first, int ready_chunks, long long* nbt, hipStream_t st) {
+  if (ready_chunks == 0 && bn_small(M)) {
+    const dim3 grid(C / 4), block(256);
+    if (M <= 1024) hipLaunchKernelGGL(bn_small_fwd_kernel<4>, grid, block, 0, st, x, gamma, beta, slope_vec, y, save_mean, save_invstd,
+                                      running_mean, running_var, nbt, M, C, momentum, eps, slope, act_first);
+    else if (M <= 2048) hipLaunchKernelGGL(bn_small_fwd_kernel<8>, grid, block, 0, st, x, gamma, beta, slope_vec, y, save_mean, save_invstd,
+                                           running_mean, running_var, nbt, M, C, momentum, eps, slope, act_first);
+    else hipLaunchKernelGGL(bn_small_fwd_kernel<16>, grid, block, 0, st, x, gamma, beta, slope_vec, y, save_mean, save_invstd,
+                            running_mean, running_var, nbt, M, C, momentum, eps, slope, act_first);
+    return dlip_launch_status();
+  }
+  // ready_chunks > 0: `workspace` already holds that many partial rows {sum x, sum x^2} [chunk][C][2] -- written by the convolution
+  // that produced x (dlip_conv_nhwc_stats_f16x3) -- and the statistics pass over x is not launched
+  const int chunks = ready_chunks > 0 ? ready_chunks : dlip_bn_rows_chunks(M);
+  bool finalized = false;
+  if (ready_chunks == 0) {
+    ColFin fin = {stream_tickets(st, (C + 63) / 64), save_mean, save_invstd, nullptr, running_mean, running_var, nbt, momentum, eps};
+    finalized = fin.ticket != nullptr;
+    hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, workspace, M, C, slope, act_first, nullptr, bn_rows_per_part(M), fin);
+  }
+  if (!finalized)
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_invstd,
+                       running_mean, running_var, M, C, chunks, momentum, eps, nbt);
+  const long long n4 = (long long)M * (C / 4);
+  if (const unsigned gf = grid_fixed(n4, C / 4))
+    hipLaunchKernelGGL(bn_fwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
+                       save_invstd, gamma, beta, reinterpret_cast<f32x4*>(y), n4, C / 4, slope, act_first, slope_vec);
+  else
+    hipLaunchKernelGGL(bn_fwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
+                       save_invstd, gamma, beta, reinterpret_cast<f32x4*>(y), n4, C / 4, slope, act_first, slope_vec);
+  return dlip_launch_status();
+}
+
+// Shared backward: slope_vec != NULL = the PReLU form (dslope written; act_first = 0), else the LeakyReLU forms.
+int bn_bwd_launch(const float* dy, const float* x, const float* gamma, const float* beta, const float* slope_vec,
+                  const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* dslope,
+                  double* workspace, int M, int C, float slope, int act_first, float* dx_lift2, hipStream_t st) {
+  unsigned* acc = dx_lift2 ? reinterpret_cast<unsigned*>(dx_lift2) + 2 : nullptr;   // per-workgroup maxima behind the pair
+  int* tickets = stream_tickets(st, (C + 63) / 64);
+  if (bn_small(M) && C / 4 <= 4096) {
+    const unsigned grid = (unsigned)(C / 4);
+    if (M <= 1024) hipLaunchKernelGGL(bn_small_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, dy, x, save_mean, save_invstd, gamma, beta, slope_vec,
+                                      dx, dgamma, dbeta, dslope, M, C, slope, act_first, acc, tickets);
+    else if (M <= 2048) hipLaunchKernelGGL(bn_small_bwd_kernel<8>, dim3(grid), dim3(256), 0, st, dy, x, save_mean, save_invstd, gamma, beta,
+                                           slope_vec, dx, dgamma, dbeta, dslope, M, C, slope, act_first, acc, tickets);
+    else hipLaunchKernelGGL(bn_small_bwd_kernel<16>, dim3(grid), dim3(256), 0, st, dy, x, save_mean, save_invstd, gamma, beta, slope_vec, dx,
+                            dgamma, dbeta, dslope, M, C, slope, act_first, acc, tickets);
+    if (acc && !tickets) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
+    return dlip_launch_status();
+  }
+  const int chunks = dlip_bn_rows_chunks(M);
+  const int rpp = bn_rows_per_part(M);
+  ColFin fin = {tickets, dbeta, dgamma, dslope, nullptr, nullptr, nullptr, 0.f, 0.f};
+  if (slope_vec) {
+    hipLaunchKernelGGL(col_partial_kernel<3>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd,
+                       gamma, beta, workspace, M, C, 1.f, 0, slope_vec, rpp, fin);
+    if (!tickets)
+      hipLaunchKernelGGL(col_finalize3_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, workspace + (long long)chunks * C * 2,
+                         dbeta, dgamma, dslope, C, chunks);
+  } else {
+    hipLaunchKernelGGL(col_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd,
+                       gamma, beta, workspace, M, C, slope, act_first, nullptr, rpp, fin);
+    if (!tickets) hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
+  }
+  const long long n4 = (long long)M * (C / 4);
+  const unsigned gf = grid_fixed(n4, C / 4);
+  const unsigned grid = gf ? gf : grid1d(n4);
+  // (the lift of a LARGE dx stays a launch of its own: a ticket word taking thousands of arrivals, and every workgroup waiting for its
+  // stores' acknowledgements in front of it, cost bn_bwd_apply 0.6 ms per lip-clip step -- more than the 20 launches it saved)
+  int* lift_ticket = nullptr;
+  if (gf)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
+                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, slope_vec, acc, lift_ticket);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
+                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, slope_vec, acc, lift_ticket);
+  if (acc && !lift_ticket) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
+  return dlip_launch_status();
+}
+
+}  // namespace
 
 extern "C" int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                                           float* save_mean, float* save_invstd, float* running_mean,
                                           float* running_var, double* workspace, int32_t M, int32_t C, float momentum,
-                                          float eps, float slope, int32_t act_first, int32_t ready_chunks, dlip_stream_t stream) {
+                                          float eps, float slope, int32_t act_first, int32_t ready_chunks,
+                                          int64_t* num_batches_tracked, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);
   DLIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
   DLIP_CHECK_ARG(ready_chunks >= 0 && !(ready_chunks > 0 && act_first));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  // ready_chunks > 0: `workspace` already holds that many partial rows {sum x, sum x^2} [chunk][C][2] -- written by the convolution
-  // that produced x (dlip_conv_nhwc_stats_f16x3) -- and the statistics pass over x is not launched
-  const int chunks = ready_chunks > 0 ? ready_chunks : dlip_bn_rows_chunks(M);
-  if (ready_chunks == 0)
-    hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, workspace, M, C, slope, act_first);
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_invstd,
-                     running_mean, running_var, M, C, chunks, momentum, eps);
-  const long long n4 = (long long)M * (C / 4);
-  if (const unsigned gf = grid_fixed(n4, C / 4))
-    hipLaunchKernelGGL(bn_fwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
-                       save_invstd, gamma, beta, reinterpret_cast<f32x4*>(y), n4, C / 4, slope, act_first);
-  else
-    hipLaunchKernelGGL(bn_fwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
-                       save_invstd, gamma, beta, reinterpret_cast<f32x4*>(y), n4, C / 4, slope, act_first);
-  return dlip_launch_status();
+  return bn_fwd_launch(x, gamma, beta, nullptr, y, save_mean, save_invstd, running_mean, running_var, workspace, M, C, momentum, eps,
+                       slope, act_first, ready_chunks, reinterpret_cast<long long*>(num_batches_tracked), static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
@@ -598,48 +1010,19 @@ extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const
   DLIP_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace);
   DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0);
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int chunks = dlip_bn_rows_chunks(M);
-  hipLaunchKernelGGL(col_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd,
-                     gamma, beta, workspace, M, C, slope, act_first);
-  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
-  const long long n4 = (long long)M * (C / 4);
-  unsigned* acc = dx_lift2 ? reinterpret_cast<unsigned*>(dx_lift2) + 2 : nullptr;   // per-workgroup maxima behind the pair
-  const unsigned gf = grid_fixed(n4, C / 4);
-  const unsigned grid = gf ? gf : grid1d(n4);
-  if (gf)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
-                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, nullptr, acc);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
-                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, nullptr, acc);
-  if (acc) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
-  return dlip_launch_status();
+  return bn_bwd_launch(dy, x, gamma, beta, nullptr, save_mean, save_invstd, dx, dgamma, dbeta, nullptr, workspace, M, C, slope, act_first,
+                       dx_lift2, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dlip_bn_prelu_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, const float* slope, float* y,
                                                 float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                                                 double* workspace, int32_t M, int32_t C, float momentum, float eps,
-                                                dlip_stream_t stream) {
+                                                int64_t* num_batches_tracked, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && gamma && beta && slope && y && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);
   DLIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int chunks = dlip_bn_rows_chunks(M);
-  hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, workspace, M, C, 1.f, 0, nullptr);
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_invstd,
-                     running_mean, running_var, M, C, chunks, momentum, eps);
-  const long long n4 = (long long)M * (C / 4);
-  if (const unsigned gf = grid_fixed(n4, C / 4))
-    hipLaunchKernelGGL(bn_fwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
-                       save_invstd, gamma, beta, reinterpret_cast<f32x4*>(y), n4, C / 4, 1.f, 0, slope);
-  else
-    hipLaunchKernelGGL(bn_fwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
-                       save_invstd, gamma, beta, reinterpret_cast<f32x4*>(y), n4, C / 4, 1.f, 0, slope);
-  return dlip_launch_status();
+  return bn_fwd_launch(x, gamma, beta, slope, y, save_mean, save_invstd, running_mean, running_var, workspace, M, C, momentum, eps, 1.f, 0,
+                       0, reinterpret_cast<long long*>(num_batches_tracked), static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
@@ -649,26 +1032,8 @@ extern "C" int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x,
   DLIP_CHECK_ARG(dy && x && gamma && beta && slope && save_mean && save_invstd && dx && dgamma && dbeta && dslope && workspace);
   DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0);
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int chunks = dlip_bn_rows_chunks(M);
-  hipLaunchKernelGGL(col_partial_kernel<3>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd,
-                     gamma, beta, workspace, M, C, 1.f, 0, slope);
-  hipLaunchKernelGGL(col_finalize3_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, workspace + (long long)chunks * C * 2, dbeta,
-                     dgamma, dslope, C, chunks);
-  const long long n4 = (long long)M * (C / 4);
-  unsigned* acc = dx_lift2 ? reinterpret_cast<unsigned*>(dx_lift2) + 2 : nullptr;   // per-workgroup maxima behind the pair
-  const unsigned gf = grid_fixed(n4, C / 4);
-  const unsigned grid = gf ? gf : grid1d(n4);
-  if (gf)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
-                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope, acc);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
-                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope, acc);
-  if (acc) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
-  return dlip_launch_status();
+  return bn_bwd_launch(dy, x, gamma, beta, slope, save_mean, save_invstd, dx, dgamma, dbeta, dslope, workspace, M, C, 1.f, 0, dx_lift2,
+                       static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dlip_colsum_rows_f32(const float* x, float* y, double* workspace, int32_t M, int32_t C,
@@ -676,9 +1041,10 @@ extern "C" int dlip_colsum_rows_f32(const float* x, float* y, double* workspace,
   DLIP_CHECK_ARG(x && y && workspace && M > 0 && C > 0 && (C & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int chunks = dlip_bn_rows_chunks(M);
+  ColFin fin = {stream_tickets(st, (C + 63) / 64), y, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
   hipLaunchKernelGGL(col_partial_kernel<2>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, workspace, M, C, 1.f, 0);
-  hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, y, nullptr, C, chunks);
+                     nullptr, nullptr, workspace, M, C, 1.f, 0, nullptr, bn_rows_per_part(M), fin);
+  if (!fin.ticket) hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, y, nullptr, C, chunks);
   return dlip_launch_status();
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 43
+#define DLIP_ABI_VERSION 44
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -453,12 +453,20 @@ int32_t dlip_bn_rows_chunks(int32_t M);
  * act_first = 1: y = bn(lrelu(x))  (bn_first=False, tdnn.py:40-42,96-97,109-110).
  * Batch statistics: biased variance for the normalisation, unbiased for running_var (momentum update,
  * nullable pair), as nn.BatchNorm1d.  save_mean / save_invstd [C] feed the backward. */
-/* (ABI 43) ready_chunks > 0 (act_first == 0 only): `workspace` already holds that many partial rows [chunk][C][2] fp64 = {sum x,
+/* (ABI 44) num_batches_tracked (nullable): the module's int64 counter, incremented by the launch that finishes the statistics
+ * (nn.BatchNorm*.forward under model.train(): `self.num_batches_tracked += 1` -- 44 one-element torch launches per lip-clip step).
+ * Launch sequence since ABI 44: the finalize steps (partials -> mean / 1/std, -> dgamma / dbeta / dslope, -> the lift of dx) run in
+ * the LAST workgroup of the pass before them (a ticket word of the stream's dlip_conv_set_workspace block, when the stream has one)
+ * instead of in launches of their own, the parts of a column reduction grow beyond 512 rows so that there are at most 512 of them,
+ * and tensors of M <= 4096 rows (the MS-TCN head's, tcn.py:42-43) take ONE launch per direction.  dlip_debug_set(8, 0) restores
+ * the ABI 43 sequence.  Results are deterministic either way; the association of the fp64 column sums differs between the two.
+ * (ABI 43) ready_chunks > 0 (act_first == 0 only): `workspace` already holds that many partial rows [chunk][C][2] fp64 = {sum x,
  * sum x^2} of x, written by the convolution that produced x (dlip_conv_nhwc_stats_f16x3): the statistics pass over x is skipped. */
 int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                                float* save_mean, float* save_invstd, float* running_mean,
                                float* running_var, double* workspace, int32_t M, int32_t C, float momentum,
-                               float eps, float slope, int32_t act_first, int32_t ready_chunks, dlip_stream_t stream);
+                               float eps, float slope, int32_t act_first, int32_t ready_chunks, int64_t* num_batches_tracked,
+                               dlip_stream_t stream);
 /* Backward of the above: dy = dL/dy -> dx = dL/dx [M,C], dgamma, dbeta [C].  dx_lift2 (nullable, DLIP_LIFT_WORDS floats: the pair, then per-workgroup scratch): the power-of-two
  * lift of dx, (2^e, 2^-e) with max|dx| * 2^e in [512, 1024] -- what dlip_pow2_scale_f32(dx, ., 1024) would return, formed by the
  * pass that writes dx: the convolution backward that consumes dx needs it and would otherwise read dx once more. */
@@ -473,7 +481,8 @@ int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const float* gam
  * forward / backward passes and the column sum of its slope terms. */
 int dlip_bn_prelu_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, const float* slope, float* y,
                                      float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                                     double* workspace, int32_t M, int32_t C, float momentum, float eps, dlip_stream_t stream);
+                                     double* workspace, int32_t M, int32_t C, float momentum, float eps,
+                                     int64_t* num_batches_tracked, dlip_stream_t stream);
 int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* slope,
                                      const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
                                      float* dslope, double* workspace, int32_t M, int32_t C, float* dx_lift2, dlip_stream_t stream);
@@ -696,6 +705,9 @@ int dlip_range_scope_end(dlip_stream_t stream);
  * off -- measured slower than the ring kernel on the trunk, so since ABI 43 it is compiled into the LAB library only
  * (deeplip_amd.build --lab): the product library returns DLIP_EINVAL for a value > 0); key 3 also takes 3 (experiment: slabs of same-XCD tiles through
  * that XCD's L2) and 4 (the in-kernel finisher where the built-in choice is the reduce launch);
+ * 8 the train-mode BatchNorm / column-sum entry points' launch sequence (0 = ABI 43's: statistics, finalize, apply [, lift] as separate
+ * launches; otherwise the finalize steps run in the last workgroup of the pass before them and few-row tensors take one launch);
+ * 9 the rows kernel's short last round (0 = off: every tile the full height);
  * value -1 restores the built-in choice. */
 int dlip_debug_set(int32_t key, int32_t value);
 

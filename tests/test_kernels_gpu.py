@@ -1249,6 +1249,45 @@ def test_conv_rows_persistent_stream_across_tiles(ops, force_rows):
     assert rel_err(ops.split_unpack(got[0]).cpu().numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("case,mi", [((100, 300, 64, 512, 1, 1, False), 5), ((70, 300, 64, 512, 3, 2, False), 4), ((120, 290, 96, 256, 2, 1, True), 3),
+                                     ((256, 300, 32, 512, 1, 1, False), 5)], ids=lambda c: "x".join(str(int(v)) for v in c) if isinstance(c, tuple) else str(c))
+def test_conv_rows_short_last_round(ops, case, mi, force_rows):
+    """Round 5: the rows left over after a launch's full rounds of tiles run as ONE round of shorter tiles spread over all CUs (a short
+    tile keeps a full tile's LDS image; the blocks it does not have are neither fetched nor multiplied nor stored).  Bit for bit the
+    launch with every tile at full height (dlip_debug_set(9, 0)) and the ring kernel's plain launch, split and fp32 output; the
+    statistics epilogue's chunks (two per row tile of either height) add up to the same column sums; repeatable."""
+    from deeplip_amd import _lib
+    B, T, C, K, S, dil, post = case
+    x, ws, b, kw, ref = _rows_inputs(case, seed=9)
+    xs = ops.split_pack(x.cuda())
+    outs = {}
+    try:
+        for which in ("ring", "full", "short", "short2"):
+            force_rows(0 if which == "ring" else mi)
+            _lib.debug_set(_lib.DBG_STREAMK, 0)
+            _lib.debug_set(_lib.DBG_ROWS_TAIL, 0 if which == "full" else -1)
+            for out_split in (True, False):
+                outs[which, out_split] = ops.conv1d_ntc(xs, ws.cuda(), b.cuda(), out_split=out_split, **kw).clone()
+            if which in ("full", "short") and not post:
+                n = ops.conv_stats_chunks(B, 1, T, C, K, 1, S, dil=(1, dil))
+                st = torch.full((n * K * 2,), float("nan"), device="cuda", dtype=torch.float64)
+                y = ops.conv_nhwc(xs.view(B, 1, T, C), ws.cuda().view(K, 1, S, C), b.cuda(), dil=(1, dil), w_scale=kw["w_scale"], x_split=True,
+                                  slope=kw["slope"], stats=st)
+                outs[which, "stats"] = (n, st.view(n, K, 2).sum(0), y.clone())
+    finally:
+        _lib.debug_set(_lib.DBG_ROWS_TAIL, -1)
+    torch.cuda.synchronize()
+    for out_split in (True, False):
+        for which in ("full", "short", "short2"):
+            assert torch.equal(outs[which, out_split].view(torch.int32), outs["ring", out_split].view(torch.int32)), (which, out_split)
+    assert rel_err(outs["short", False].cpu().numpy(), ref.numpy()) < TOL
+    if not post:
+        (n0, s0, y0), (n1, s1, y1) = outs["full", "stats"], outs["short", "stats"]
+        assert n1 > n0                                        # the short round really is in use: more (shorter) row tiles
+        assert bool(torch.isfinite(s1).all()) and rel_err(s1.cpu().numpy(), s0.cpu().numpy()) < 2e-6
+        assert torch.equal(y0, y1) and torch.equal(y1.view(-1, K), outs["ring", False].view(-1, K))
+
+
 @pytest.mark.parametrize("mi", [3, 5])
 @pytest.mark.parametrize("case", [c for c in POOL_CASES if c[1] == 1], ids=lambda c: "x".join(str(v) for v in c))
 def test_conv_rows_pooled_epilogue(ops, case, mi, force_rows):

@@ -149,6 +149,62 @@ def test_fused_batchnorm_prelu_vs_torch_autograd(M, C):
     assert rel_err(rm.cpu().numpy(), bn.running_mean.numpy()) < 1e-5 and rel_err(rv.cpu().numpy(), bn.running_var.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M,C", [(70, 768), (1300, 256), (4096, 12), (5000, 64), (300000, 8)])
+def test_batchnorm_launch_sequences_agree(M, C):
+    """ABI 44: the finalize steps of the train-mode BatchNorm / column-sum entry points run in the LAST workgroup of the pass before
+    them (ticket words of the stream's workspace) and tensors of <= 4096 rows take one launch per direction; dlip_debug_set(8, 0)
+    restores ABI 43's separate launches.  Both sequences: same results (the fp64 column sums are associated differently: 2e-6), the
+    same power-of-two lift of dx, num_batches_tracked incremented once per forward, and repeatable bits.  300 000 rows: parts longer
+    than 512 rows (at most 512 parts per launch)."""
+    from deeplip_amd import _lib, autograd as ag, autograd_video as av
+    x = (rnd(M, C, seed=31) * 1.7 + 0.3).to(DEV)
+    ga = (1.0 + 0.3 * rnd(C, seed=32)).to(DEV)
+    be = (0.2 * rnd(C, seed=33)).to(DEV)
+    sl = (torch.rand(C, generator=torch.Generator().manual_seed(34)) * 0.5 - 0.05).to(DEV)
+    dy = (rnd(M, C, seed=35) * 1e-3).to(DEV)
+
+    def run():
+        out = {}
+        for name in ("prelu", "lrelu", "act_first"):
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            nbt = torch.zeros((), dtype=torch.long, device=DEV)
+            xg, gg, bg, sg = (t.clone().requires_grad_() for t in (x, ga, be, sl))
+            if name == "prelu":
+                y = av.BNPReLUFn.apply(xg, gg, bg, sg, rm, rv, 0.1, 1e-5, nbt)
+            else:
+                y = ag.BNRowsActFn.apply(xg, gg, bg, rm, rv, 0.1, 1e-5, 0.2, name == "act_first", nbt)
+            y.backward(dy)
+            out[name] = [t.detach().clone() for t in (y, xg.grad, gg.grad, bg.grad, rm, rv, nbt.float())]
+            if name == "prelu":
+                out[name].append(sg.grad.clone())
+        # the power-of-two lift of dx, formed by the backward's last pass (it travels on the tensor object the helper returns)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        _, mean, invstd = ag._bn_rows_fwd(x, ga, be, rm, rv, 0.1, 1e-5, 0.2, False)
+        dx, _, _ = ag._bn_rows_bwd(dy, x, ga, be, mean, invstd, 0.2, False)
+        out["lift"] = [dx._dlip_lift[:6].clone(), dx.abs().max().view(1)]
+        out["colsum"] = [av._colsum_rows(x)]
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        a = run()
+        a2 = run()
+        _lib.debug_set(_lib.DBG_BN_FUSED, 0)
+        b = run()
+    finally:
+        _lib.debug_set(_lib.DBG_BN_FUSED, -1)
+    for k in a:
+        for u, v, w in zip(a[k], a2[k], b[k]):
+            assert torch.equal(u, v), k                                       # repeatable bits
+            assert rel_err(u.cpu().numpy(), w.cpu().numpy()) < 2e-6, k        # the two sequences
+    for k in ("prelu", "lrelu", "act_first"):
+        assert float(a[k][6]) == 1.0 and float(b[k][6]) == 1.0               # num_batches_tracked: one forward
+    for r in (a, b):
+        e, inv, amax = float(r["lift"][0][0]), float(r["lift"][0][1]), float(r["lift"][1][0])
+        assert e * inv == 1.0 and 512.0 <= amax * e <= 1024.0 and bool((r["lift"][0][2:] == inv).all())
+    assert torch.equal(a["lift"][0], b["lift"][0])
+
+
 def test_prelu_maxpool_avgpool_timemean_dropout():
     from deeplip_amd import autograd_video as av
     # PReLU with per-channel slope
