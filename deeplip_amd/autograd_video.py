@@ -690,6 +690,45 @@ class BNPReLUFn(Function):
         return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None, None
 
 
+class BNPReLUMaxPoolFn(Function):
+    """maxpool(prelu(bn_train(x))) of the stem (model.py:83-85) on [N,H,W,C] WITHOUT the full-resolution tensors between the three
+    (dlip_bn_prelu_maxpool_train_fwd/bwd_f32): the forward's one pass behind the statistics writes the pooled output and the argmax
+    codes, the backward's two passes take the gradient behind the pooling per pixel from the codes and the pooled gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, momentum, eps, nbt=None):
+        x = x.contiguous()
+        N, H, W, C_ = x.shape
+        _lib.ensure_conv_workspace()
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, Ho, Wo, C_), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, Ho, Wo, C_ // 4), device=x.device, dtype=torch.int32)
+        mean = torch.empty((C_,), device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        ws = torch.empty((int(lib().dlip_bn_rows_chunks(N * H * W)) * C_ * 2,), device=x.device, dtype=torch.float64)
+        check(lib().dlip_bn_prelu_maxpool_train_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(y), idx.data_ptr(), ptr(mean), ptr(invstd),
+                                                        ptr(running_mean), ptr(running_var), ptr(ws), N, H, W, C_, momentum, eps, ptr(nbt),
+                                                        stream_handle()), "dlip_bn_prelu_maxpool_train_fwd_f32")
+        ctx.save_for_backward(x, gamma, beta, slope, mean, invstd, idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, slope, mean, invstd, idx = ctx.saved_tensors
+        N, H, W, C_ = x.shape
+        _lib.ensure_conv_workspace()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg, db, ds = (torch.empty_like(mean) for _ in range(3))
+        ws = torch.empty((int(lib().dlip_bn_rows_chunks(N * H * W)) * C_ * 4,), device=x.device, dtype=torch.float64)
+        lift = torch.empty((LIFT_WORDS,), device=x.device, dtype=torch.float32)
+        check(lib().dlip_bn_prelu_maxpool_train_bwd_f32(ptr(dy), idx.data_ptr(), ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(mean), ptr(invstd),
+                                                        ptr(dx), ptr(dg), ptr(db), ptr(ds), ptr(ws), N, H, W, C_, ptr(lift), stream_handle()),
+              "dlip_bn_prelu_maxpool_train_bwd_f32")
+        dx._dlip_lift = lift
+        return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None, None
+
+
 class AddPReLUFn(Function):
     """prelu(a + b) with per-channel slopes in one launch (the end of a residual block); the sum is kept for the backward, which is
     PReLU's (the same gradient flows to a and to b)."""
@@ -834,6 +873,22 @@ def batchnorm_prelu(x, bn, act):
     y = BNPReLUFn.apply(x, bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(),
                         bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.num_batches_tracked)
     return y
+
+
+# (round 5) the stem's BatchNorm + PReLU + max-pool as one Function (False: round 4's three: BNPReLUFn, then MaxPoolFn)
+STEM_BN_POOL_FUSED = __import__("os").environ.get("DLIP_STEM_BN_POOL", "1") != "0"
+
+
+def batchnorm_prelu_maxpool(x, bn, act):
+    """maxpool(prelu(batchnorm(x))) of a channels-last [N,H,W,C] tensor in train mode (model.py:83-85)."""
+    w = getattr(act, "weight", None)
+    C_ = x.shape[-1]
+    if not STEM_BN_POOL_FUSED or x.dim() != 4 or (w is not None and w.numel() != C_):
+        return maxpool(batchnorm_prelu(x, bn, act))
+    if w is None:
+        w = const_vec(C_, 0.0, x.device)
+    return BNPReLUMaxPoolFn.apply(x, bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(), bn.running_mean, bn.running_var,
+                                  bn.momentum, bn.eps, bn.num_batches_tracked)
 
 
 def prelu(x, act):

@@ -10,6 +10,7 @@
 // reduces one (chunk, 64-column block) in fp64 (16 row groups x 16 lanes x float4, LDS tree), partials go
 // to a caller-provided workspace and a second kernel adds them in chunk order: deterministic, no atomics.
 #include "dlip_common.h"
+#include "conv_common.h"   // FastDiv: exact division by launch constants
 
 namespace {
 
@@ -33,6 +34,38 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ?
 // workspace) the workgroup that finishes LAST for a 64-column block -- its ticket says so -- adds that block's partials in part
 // order (4 lane groups x parts / 4, then the groups in order: a fixed association whichever workgroup it is) and writes the results.
 // Rows per part grow beyond 512 so that a launch has at most 512 parts: the finisher reads them through ONE CU.
+// (round 5) The gradient behind a MaxPool3d((1,3,3),(1,2,2),(0,1,1)) WITHOUT the full-resolution tensor: the BatchNorm + PReLU in
+// front of the pooling (the stem: model.py:83-85) reads, per input pixel, the at most four windows that cover it -- their argmax bytes
+// (dlip_maxpool3x3s2_idx_f32's codes) and pooled gradients -- instead of a 460 MB (B = 32) scatter that one launch writes and two
+// passes read back.  idx == nullptr: `dy` is an ordinary dense gradient.
+struct PoolSrc {
+  const uint32_t* idx;               // [N, Ho, Wo, C / 4] argmax codes, one byte per channel
+  int H, W, Ho, Wo;
+  FastDiv div_W, div_H, div_Wo, div_Ho;   // (rows < 2^31: 32-bit index arithmetic, divisions by multiplication)
+};
+
+// g[row, c4 * 4 ..] for pixel row = (n H + h) W + w: the sum of the pooled gradients whose argmax is this pixel (maxpool_idx_bwd_kernel)
+__device__ __forceinline__ f32x4 pooled_grad(const PoolSrc& ps, const float* __restrict__ dyp, int row, int c, int C) {
+  const int t = dlip_div(row, ps.div_W), w = row - t * ps.W;
+  const int n = dlip_div(t, ps.div_H), h = t - n * ps.H;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
+    if (ho >= ps.Ho) continue;
+    const int r = h - (2 * ho - 1);
+    for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
+      if (wo >= ps.Wo) continue;
+      const uint32_t me = (uint32_t)(r * 3 + (w - (2 * wo - 1)));
+      const long long o = ((long long)(n * ps.Ho + ho) * ps.Wo + wo) * C + c;
+      const uint32_t code = ps.idx[o >> 2];
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dyp + o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (((code >> (8 * k)) & 0xFFu) == me) acc[k] += g[k];
+    }
+  }
+  return acc;
+}
+
 struct ColFin {
   int* ticket;                       // nullptr: the caller launches the finalize kernel
   float* out0;                       // MODE 0 save_mean   | MODE 1 / 3 dbeta  | MODE 2 the column sums
@@ -79,6 +112,56 @@ __device__ __forceinline__ bool last_arrival(int* word, int n) {
   const bool last = s_last != 0;
   if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return last;
+}
+
+// The tail of a column-reduction pass (col_partial_kernel, pool_bn_partial_kernel): with a ticket word, the workgroup that arrives
+// LAST for its 64-column block adds the block's partials -- lane group g parts g, g + 4, ... (four loads in flight), then the groups in
+// order -- and writes the results (MODE as in col_partial_kernel).  red: the caller's [16][64][2 | 3] LDS block, free by now.
+template <int MODE>
+__device__ __forceinline__ void col_finish(double* part, int parts, int M, int C, int c0, const ColFin& fin,
+                                           double (*red)[64][MODE == 3 ? 3 : 2]) {
+  if (fin.ticket == nullptr) return;
+  if (!last_arrival(fin.ticket + blockIdx.x, parts)) return;
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int cc = c0 + col;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (cc < C) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double* pa = part + (long long)cc * 2;
+    const double* pb = pa + (long long)parts * C * 2;
+    const long long step = (long long)C * 2;
+    int i = grp;
+    for (; i + 12 < parts; i += 16) {
+      d2 v[4], w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const d2*>(pa + (i + 4 * u) * step);
+        if (MODE == 3) w[u] = *reinterpret_cast<const d2*>(pb + (i + 4 * u) * step);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a0 += v[u][0]; a1 += v[u][1]; if (MODE == 3) a2 += w[u][0]; }
+    }
+    for (; i < parts; i += 4) {
+      a0 += pa[i * step]; a1 += pa[i * step + 1];
+      if (MODE == 3) a2 += pb[i * step];
+    }
+  }
+  __syncthreads();                                   // (red is free: every thread passed last_arrival's barriers)
+  red[grp][col][0] = a0; red[grp][col][1] = a1;
+  if (MODE == 3) red[grp][col][2] = a2;
+  __syncthreads();
+  if (grp != 0 || cc >= C) return;
+  double s = 0.0, q = 0.0, t = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s += red[i][col][0]; q += red[i][col][1]; if (MODE == 3) t += red[i][col][2]; }
+  if (MODE == 0) {
+    bn_stats_finish(s, q, M, cc, fin.out0, fin.out1, fin.running_mean, fin.running_var, fin.momentum, fin.eps);
+    if (fin.nbt && cc == 0) fin.nbt[0] += 1;
+  } else {
+    if (fin.out0) fin.out0[cc] = (float)s;
+    if (MODE != 2 && fin.out1) fin.out1[cc] = (float)q;
+    if (MODE == 3) fin.out2[cc] = (float)t;
+  }
 }
 
 template <int MODE>
@@ -171,49 +254,84 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
       publish(p2, a2); publish(p2 + 1, 0.0);
     }
   }
-  if (fin.ticket == nullptr) return;
-  if (!last_arrival(fin.ticket + blockIdx.x, parts)) return;
-  // ---- this workgroup finishes the block's 64 columns: lane group g adds parts g, g + 4, ... (four loads in flight), then the groups ----
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int cc = c0 + col;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  if (cc < C) {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const double* pa = part + (long long)cc * 2;
-    const double* pb = pa + (long long)parts * C * 2;
-    const long long step = (long long)C * 2;
-    int i = grp;
-    for (; i + 12 < parts; i += 16) {
-      d2 v[4], w[4];
+  col_finish<MODE>(part, parts, M, C, c0, fin, red);
+}
+
+// The BatchNorm + PReLU backward sums (col_partial_kernel<3>) BEHIND A MAX-POOL, taken over the POOLED rows: the gradient behind
+// the pooling is zero except at each window's argmax, so the three sums have one term per pooled element -- its gradient g, and x at
+// the pixel its argmax code names (a 4-byte gather per channel) -- instead of one per input element whose g is mostly an exact zero:
+// a quarter of the rows, and the full-resolution gradient tensor never exists.  Partials, parts and the finisher as col_partial_kernel
+// (rows = pooled pixels n Ho Wo).  (A pixel that is the argmax of two windows contributes g1 xhat + g2 xhat here and (g1 + g2) xhat
+// in the dense form: the same to fp64 rounding.)
+__global__ __launch_bounds__(256) void pool_bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dyp, const PoolSrc ps,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ slope_vec, double* part, int Mp, int M, int C,
+                                                              int rows_per_part, const ColFin fin) {
+  __shared__ double red[16][64][3];
+  const int c0 = blockIdx.x * 64, chunk = blockIdx.y;
+  const int lx = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = c0 + lx * 4;
+  const int r0 = chunk * rows_per_part, r1 = min(Mp, r0 + rows_per_part);
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (c < C) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    const f32x4 sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
+    for (int rb = r0 + rg; rb < r1; rb += 32) {           // two pooled rows of this lane group per trip: their gathers overlap
+      f32x4 g[2];
+      float xv[2][4];
+      bool on[2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v[u] = *reinterpret_cast<const d2*>(pa + (i + 4 * u) * step);
-        if (MODE == 3) w[u] = *reinterpret_cast<const d2*>(pb + (i + 4 * u) * step);
+      for (int u = 0; u < 2; ++u) {
+        const int r = rb + 16 * u;
+        on[u] = r < r1;
+        g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[u][k] = 0.f;
+        if (on[u]) {
+          const int t = dlip_div(r, ps.div_Wo), wo = r - t * ps.Wo;
+          const int n = dlip_div(t, ps.div_Ho), ho = t - n * ps.Ho;
+          const long long o = (long long)r * C + c;
+          const uint32_t code = ps.idx[o >> 2];
+          g[u] = *reinterpret_cast<const f32x4*>(dyp + o);
+          const float* xn = x + ((long long)n * ps.H * ps.W) * C + c;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int tap = (int)((code >> (8 * k)) & 0xFFu);          // r * 3 + s of the window (2 ho - 1 .., 2 wo - 1 ..)
+            const int tr = tap / 3, ts = tap - 3 * tr;
+            xv[u][k] = xn[((long long)(2 * ho - 1 + tr) * ps.W + (2 * wo - 1 + ts)) * C + k];
+          }
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { a0 += v[u][0]; a1 += v[u][1]; if (MODE == 3) a2 += w[u][0]; }
-    }
-    for (; i < parts; i += 4) {
-      a0 += pa[i * step]; a1 += pa[i * step + 1];
-      if (MODE == 3) a2 += pb[i * step];
-    }
-  }
-  __syncthreads();                                   // (red is free: every thread passed last_arrival's barriers)
-  red[grp][col][0] = a0; red[grp][col][1] = a1;
-  if (MODE == 3) red[grp][col][2] = a2;
-  __syncthreads();
-  if (grp != 0 || cc >= C) return;
-  double s = 0.0, q = 0.0, t = 0.0;
+      for (int u = 0; u < 2; ++u) {
+        if (!on[u]) continue;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { s += red[i][col][0]; q += red[i][col][1]; if (MODE == 3) t += red[i][col][2]; }
-  if (MODE == 0) {
-    bn_stats_finish(s, q, M, cc, fin.out0, fin.out1, fin.running_mean, fin.running_var, fin.momentum, fin.eps);
-    if (fin.nbt && cc == 0) fin.nbt[0] += 1;
-  } else {
-    if (fin.out0) fin.out0[cc] = (float)s;
-    if (MODE != 2 && fin.out1) fin.out1[cc] = (float)q;
-    if (MODE == 3) fin.out2[cc] = (float)t;
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (xv[u][k] - mu[k]) * is[k];
+          const float bn = xh * ga[k] + be[k];
+          float gg = g[u][k];
+          if (bn < 0.f) { s2[k] += (double)gg * (double)bn; gg *= sl[k]; }
+          s0[k] += (double)gg; s1[k] += (double)gg * (double)xh;
+        }
+      }
+    }
   }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[rg][lx * 4 + k][0] = s0[k]; red[rg][lx * 4 + k][1] = s1[k]; red[rg][lx * 4 + k][2] = s2[k]; }
+  __syncthreads();
+  const int parts = gridDim.y;
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a0 += red[i][threadIdx.x][0]; a1 += red[i][threadIdx.x][1]; a2 += red[i][threadIdx.x][2]; }
+    double* p = part + ((long long)chunk * C + c0 + threadIdx.x) * 2;
+    publish(p, a0); publish(p + 1, a1);
+    double* p2 = p + (long long)parts * C * 2;
+    publish(p2, a2); publish(p2 + 1, 0.0);
+  }
+  col_finish<3>(part, parts, M, C, c0, fin, red);
 }
 
 // forward statistics: mean, biased variance -> invstd; running stats with the unbiased variance (torch)
@@ -278,6 +396,52 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const f32x4* __restri
   }
 }
 
+// y = maxpool3x3s2(prelu(bn(x))) with the argmax codes of dlip_maxpool3x3s2_idx_f32, from the batch statistics mean / invstd: the stem's
+// BatchNorm3d + PReLU + MaxPool3d (model.py:83-85) under model.train() in ONE pass over the convolution's output -- the normalised
+// full-resolution tensor (460 MB at B = 32) is never written (was: written by the apply pass, read back by the pooling).
+__global__ __launch_bounds__(256) void bn_prelu_maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, const float* __restrict__ slope_vec,
+                                                                   f32x4* __restrict__ y, uint32_t* __restrict__ idx, int H, int W,
+                                                                   int Ho, int Wo, int C4, long long n4) {
+  const int C = C4 * 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const long long p = i / C4;
+    const int wo = (int)(p % Wo);
+    const long long t = p / Wo;
+    const int ho = (int)(t % Ho);
+    const long long n = t / Ho;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    const f32x4 sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
+    const float* xn = x + n * H * W * C + c;
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    uint32_t code = 0xFFFFFFFFu;                      // 0xFF per channel: nothing seen yet
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hh = 2 * ho - 1 + r;
+      if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const int ww = 2 * wo - 1 + s_;
+        if ((unsigned)ww >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xn + ((long long)hh * W + ww) * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a = lrelu((v[k] - mu[k]) * is[k] * ga[k] + be[k], sl[k]);   // bn_fwd_apply_kernel's expression
+          if (a > best[k] || ((code >> (8 * k)) & 0xFFu) == 0xFFu) {
+            best[k] = a;
+            code = (code & ~(0xFFu << (8 * k))) | ((uint32_t)(r * 3 + s_) << (8 * k));
+          }
+        }
+      }
+    }
+    y[i] = best;
+    idx[i] = code;
+  }
+}
+
 __global__ __launch_bounds__(256) void col_finalize_kernel(const double* __restrict__ part, float* __restrict__ out0,
                                                            float* __restrict__ out1, int C, int chunks) {
   double s, q;
@@ -330,14 +494,15 @@ __device__ __forceinline__ void pow2_finalize_parts(const unsigned* parts, int n
 }
 
 // dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M), times lrelu'(x) when the activation came first
-template <bool FIXED>
+template <bool FIXED, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                            f32x4* __restrict__ dx, long long n4, int C4, int M, float slope,
                                                            int act_first, const float* __restrict__ slope_vec = nullptr,
-                                                           unsigned* amax_acc = nullptr, int* ticket = nullptr) {
+                                                           unsigned* amax_acc = nullptr, int* ticket = nullptr,
+                                                           const PoolSrc ps = PoolSrc{}) {
   const float invM = 1.f / (float)M;
   float amax = 0.f;     // max |dx| of the launch -> amax_acc (the next convolution backward's power-of-two lift, without its own pass)
   const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -351,7 +516,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
   if (FIXED) load((int)(i0 % C4) * 4);
   for (long long i = i0; i < n4; i += (long long)gridDim.x * 256) {
     if (!FIXED) load((int)(i % C4) * 4);
-    const f32x4 xv = x[i], gv = dy[i];
+    const f32x4 xv = x[i];
+    f32x4 gv;
+    if constexpr (POOL) { const int row = (int)(i / C4); gv = pooled_grad(ps, reinterpret_cast<const float*>(dy), row, (int)(i - (long long)row * C4) * 4, C4 * 4); }
+    else gv = dy[i];
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1034,6 +1202,66 @@ extern "C" int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x,
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
   return bn_bwd_launch(dy, x, gamma, beta, slope, save_mean, save_invstd, dx, dgamma, dbeta, dslope, workspace, M, C, 1.f, 0, dx_lift2,
                        static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dlip_bn_prelu_maxpool_train_fwd_f32(const float* x, const float* gamma, const float* beta, const float* slope, float* y,
+                                                  uint32_t* idx, float* save_mean, float* save_invstd, float* running_mean,
+                                                  float* running_var, double* workspace, int64_t N, int32_t H, int32_t W, int32_t C,
+                                                  float momentum, float eps, int64_t* num_batches_tracked, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && gamma && beta && slope && y && idx && save_mean && save_invstd && workspace && N > 0 && H > 0 && W > 0 && C > 0);
+  DLIP_CHECK_ARG((C & 3) == 0 && (running_mean == nullptr) == (running_var == nullptr) && N * H * W < 0x7FFFFFFFll);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int M = (int)(N * H * W);
+  const int chunks = dlip_bn_rows_chunks(M);
+  long long* nbt = reinterpret_cast<long long*>(num_batches_tracked);
+  ColFin fin = {stream_tickets(st, (C + 63) / 64), save_mean, save_invstd, nullptr, running_mean, running_var, nbt, momentum, eps};
+  hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, workspace, M, C, 1.f, 0, nullptr, bn_rows_per_part(M), fin);
+  if (!fin.ticket)
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_invstd,
+                       running_mean, running_var, M, C, chunks, momentum, eps, nbt);
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long n4 = N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(bn_prelu_maxpool_fwd_kernel, dim3(grid1d(n4)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, slope,
+                     reinterpret_cast<f32x4*>(y), idx, H, W, Ho, Wo, C / 4, n4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_bn_prelu_maxpool_train_bwd_f32(const float* dy_pooled, const uint32_t* idx, const float* x, const float* gamma,
+                                                  const float* beta, const float* slope, const float* save_mean,
+                                                  const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* dslope,
+                                                  double* workspace, int64_t N, int32_t H, int32_t W, int32_t C, float* dx_lift2,
+                                                  dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dy_pooled && idx && x && gamma && beta && slope && save_mean && save_invstd && dx && dgamma && dbeta && dslope && workspace);
+  DLIP_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && N * H * W < 0x7FFFFFFFll);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy_pooled) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int M = (int)(N * H * W);
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const PoolSrc ps = {idx, H, W, Ho, Wo, dlip_fastdiv((uint32_t)W), dlip_fastdiv((uint32_t)H), dlip_fastdiv((uint32_t)Wo), dlip_fastdiv((uint32_t)Ho)};
+  const int Mp = (int)(N * Ho * Wo);
+  const int chunks = dlip_bn_rows_chunks(Mp);           // (the sums run over the POOLED rows; workspace sized for M >= Mp)
+  ColFin fin = {stream_tickets(st, (C + 63) / 64), dbeta, dgamma, dslope, nullptr, nullptr, nullptr, 0.f, 0.f};
+  hipLaunchKernelGGL(pool_bn_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy_pooled, ps, save_mean, save_invstd,
+                     gamma, beta, slope, workspace, Mp, M, C, bn_rows_per_part(Mp), fin);
+  if (!fin.ticket)
+    hipLaunchKernelGGL(col_finalize3_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, workspace + (long long)chunks * C * 2,
+                       dbeta, dgamma, dslope, C, chunks);
+  unsigned* acc = dx_lift2 ? reinterpret_cast<unsigned*>(dx_lift2) + 2 : nullptr;
+  const long long n4 = (long long)M * (C / 4);
+  const unsigned gf = grid_fixed(n4, C / 4);
+  const unsigned grid = gf ? gf : grid1d(n4);
+  if (gf)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy_pooled),
+                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope, acc, nullptr, ps);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy_pooled),
+                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope, acc, nullptr, ps);
+  if (acc) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
+  return dlip_launch_status();
 }
 
 extern "C" int dlip_colsum_rows_f32(const float* x, float* y, double* workspace, int32_t M, int32_t C,

@@ -205,6 +205,61 @@ def test_batchnorm_launch_sequences_agree(M, C):
     assert torch.equal(a["lift"][0], b["lift"][0])
 
 
+@pytest.mark.parametrize("N,H,W,C", [(6, 44, 44, 64), (3, 9, 11, 8), (2, 5, 7, 64), (700, 8, 8, 12)])
+def test_stem_batchnorm_prelu_maxpool_as_one_function(N, H, W, C):
+    """Round 5: maxpool(prelu(bn_train(x))) of the stem (model.py:83-85) without the full-resolution tensors between the three --
+    (1) against torch autograd (fp64) of BatchNorm + PReLU + max_pool2d: output, dx, dgamma, dbeta, dslope, running statistics;
+    (2) against the three-Function path (BNPReLUFn + MaxPoolFn): the SAME pooled output bit for bit (hence the same argmax codes)
+    and gradients to 2e-6; (3) the lift of dx; repeatable bits."""
+    from deeplip_amd import autograd_video as av
+    x = (rnd(N, H, W, C, seed=41) * 1.7 + 0.3)
+    ga = (1.0 + 0.3 * rnd(C, seed=42)); be = 0.2 * rnd(C, seed=43)
+    sl = torch.rand(C, generator=torch.Generator().manual_seed(44)) * 0.5 - 0.05
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = rnd(N, Ho, Wo, C, seed=45) * 1e-2
+    bn = torch.nn.BatchNorm2d(C, momentum=0.1).double()
+    with torch.no_grad():
+        bn.weight.copy_(ga); bn.bias.copy_(be)
+    bn.train()
+    xd = x.double().permute(0, 3, 1, 2).contiguous().requires_grad_()
+    sld = sl.double().requires_grad_()
+    ref = F.max_pool2d(F.prelu(bn(xd), sld), 3, 2, 1)
+    ref.backward(dy.double().permute(0, 3, 1, 2))
+
+    def run(fused):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        nbt = torch.zeros((), dtype=torch.long, device=DEV)
+        xg, gg, bg, sg = (t.clone().to(DEV).requires_grad_() for t in (x, ga, be, sl))
+        if fused:
+            y = av.BNPReLUMaxPoolFn.apply(xg, gg, bg, sg, rm, rv, 0.1, 1e-5, nbt)
+        else:
+            y = av.MaxPoolFn.apply(av.BNPReLUFn.apply(xg, gg, bg, sg, rm, rv, 0.1, 1e-5, nbt))
+        y.backward(dy.to(DEV))
+        torch.cuda.synchronize()
+        return [t.detach().clone() for t in (y, xg.grad, gg.grad, bg.grad, sg.grad, rm, rv, nbt.float())]
+
+    a, a2, b = run(True), run(True), run(False)
+    assert rel_err(a[0].cpu().permute(0, 3, 1, 2).numpy(), ref.detach().numpy()) < 1e-5
+    assert rel_err(a[1].cpu().permute(0, 3, 1, 2).numpy(), xd.grad.numpy()) < 1e-4
+    assert rel_err(a[2].cpu().numpy(), bn.weight.grad.numpy()) < 1e-4 and rel_err(a[3].cpu().numpy(), bn.bias.grad.numpy()) < 1e-4
+    assert rel_err(a[4].cpu().numpy(), sld.grad.numpy()) < 1e-4
+    assert rel_err(a[5].cpu().numpy(), bn.running_mean.numpy()) < 1e-5 and rel_err(a[6].cpu().numpy(), bn.running_var.numpy()) < 1e-5
+    assert float(a[7]) == 1.0
+    assert torch.equal(a[0], b[0])                             # the pooled output: the same bits as apply pass + pooling
+    for u, v, w in zip(a, a2, b):
+        assert torch.equal(u, v) and rel_err(u.cpu().numpy(), w.cpu().numpy()) < 2e-6
+    # the lift pair the backward leaves on dx
+    xg = x.to(DEV).requires_grad_()
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y = av.BNPReLUMaxPoolFn.apply(xg, ga.to(DEV), be.to(DEV), sl.to(DEV), rm, rv, 0.1, 1e-5, None)
+    fn = y.grad_fn
+    dx = av.BNPReLUMaxPoolFn.backward(fn, dy.to(DEV))[0]
+    lift = dx._dlip_lift
+    torch.cuda.synchronize()
+    e, inv, amax = float(lift[0]), float(lift[1]), float(dx.abs().max())
+    assert e * inv == 1.0 and 512.0 <= amax * e <= 1024.0 and bool((lift[2:8] == inv).all())
+
+
 def test_prelu_maxpool_avgpool_timemean_dropout():
     from deeplip_amd import autograd_video as av
     # PReLU with per-channel slope
