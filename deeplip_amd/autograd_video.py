@@ -757,6 +757,57 @@ class AddPReLUFn(Function):
         return dx, dx, dslope
 
 
+class BNAddPReLUFn(Function):
+    """The end of a BasicBlock under model.train(): prelu(bn2(x) + residual) (resnet.py:62-69) as dlip_bn_add_prelu_rows_train_fwd/bwd_f32
+    -- bn2's output is never stored, the backward's first pass replaces four.  ``fork``: return the output TWICE (two tensor objects
+    over one storage) -- the next block's first convolution takes one, its shortcut the other -- so that the two gradients arrive here
+    separately and are added inside the backward's first pass instead of by a launch of autograd's."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, slope, running_mean, running_var, momentum, eps, nbt, fork):
+        shape = tuple(x.shape)
+        x = x.contiguous().view(-1, shape[-1])
+        res = res.contiguous().view(-1, shape[-1])
+        M, C_ = x.shape
+        _lib.ensure_conv_workspace()
+        s_ = torch.empty_like(x)
+        y = torch.empty_like(x)
+        mean = torch.empty((C_,), device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        ws = torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 2,), device=x.device, dtype=torch.float64)
+        check(lib().dlip_bn_add_prelu_rows_train_fwd_f32(ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(slope), ptr(s_), ptr(y), ptr(mean), ptr(invstd),
+                                                         ptr(running_mean), ptr(running_var), ptr(ws), M, C_, momentum, eps, ptr(nbt),
+                                                         stream_handle()), "dlip_bn_add_prelu_rows_train_fwd_f32")
+        ctx.save_for_backward(x, s_, gamma, beta, slope, mean, invstd)
+        ctx.shape = shape
+        ctx.set_materialize_grads(False)
+        y = y.view(shape)
+        return (y, y.detach()) if fork else y
+
+    @staticmethod
+    def backward(ctx, dy, dy2=None):
+        x, s_, gamma, beta, slope, mean, invstd = ctx.saved_tensors
+        M, C_ = x.shape
+        _lib.ensure_conv_workspace()
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            dy = torch.zeros_like(x)
+        dy = dy.contiguous()
+        dy2 = dy2.contiguous() if dy2 is not None else None
+        dres = torch.empty_like(x)
+        dx = torch.empty_like(x)
+        dg, db, ds = (torch.empty_like(mean) for _ in range(3))
+        ws = torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 4,), device=x.device, dtype=torch.float64)
+        lift = torch.empty((LIFT_WORDS,), device=x.device, dtype=torch.float32)
+        check(lib().dlip_bn_add_prelu_rows_train_bwd_f32(ptr(dy), ptr(dy2), ptr(s_), ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(mean), ptr(invstd),
+                                                         ptr(dres), ptr(dx), ptr(dg), ptr(db), ptr(ds), ptr(ws), M, C_, ptr(lift), stream_handle()),
+              "dlip_bn_add_prelu_rows_train_bwd_f32")
+        dx = dx.view(ctx.shape)
+        dx._dlip_lift = lift
+        return dx, dres.view(ctx.shape), dg, db, (ds if ctx.needs_input_grad[4] else None), None, None, None, None, None, None
+
+
 class MaxPoolFn(Function):
     """MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on [(B T),H,W,C] (model.py:85).  The forward records each maximum's tap as one byte, the
     backward reads those instead of re-scanning the windows of x (and x itself is not kept alive for it)."""
@@ -889,6 +940,23 @@ def batchnorm_prelu_maxpool(x, bn, act):
         w = const_vec(C_, 0.0, x.device)
     return BNPReLUMaxPoolFn.apply(x, bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(), bn.running_mean, bn.running_var,
                                   bn.momentum, bn.eps, bn.num_batches_tracked)
+
+
+# (round 5) the end of a BasicBlock as one Function (False: round 4's BNRowsActFn + AddPReLUFn)
+BLOCK_TAIL_FUSED = __import__("os").environ.get("DLIP_BLOCK_TAIL", "1") != "0"
+
+
+def batchnorm_add_prelu(x, bn, res, act, fork=False):
+    """prelu(batchnorm(x) + res) in train mode (resnet.py:62-69).  ``fork``: a pair of tensors over the one output (BNAddPReLUFn)."""
+    w = getattr(act, "weight", None)
+    C_ = x.shape[-1]
+    if not BLOCK_TAIL_FUSED or x.shape != res.shape or (w is not None and w.numel() != C_):
+        y = add_prelu(batchnorm(x, bn), res, act)
+        return (y, y) if fork else y
+    if w is None:
+        w = const_vec(C_, 0.0, x.device)
+    return BNAddPReLUFn.apply(x, res, bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(), bn.running_mean, bn.running_var,
+                              bn.momentum, bn.eps, bn.num_batches_tracked, bool(fork))
 
 
 def prelu(x, act):

@@ -334,6 +334,110 @@ __global__ __launch_bounds__(256) void pool_bn_partial_kernel(const float* __res
   col_finish<3>(part, parts, M, C, c0, fin, red);
 }
 
+// ---- (round 5) the END of a BasicBlock under model.train(): out = prelu(bn2(conv2) + residual) (resnet.py:62-69) ------------------
+// Forward (after the statistics of x = conv2's output): one pass reads x and the residual and writes the sum (kept for the backward)
+// and the output -- bn2's output is never stored (was: written by the BatchNorm apply pass, read back by the add + PReLU pass).
+template <bool FIXED>
+__global__ __launch_bounds__(256) void bn_add_prelu_fwd_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ res,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ slope_vec, f32x4* __restrict__ s_out,
+                                                               f32x4* __restrict__ y, long long n4, int C4) {
+  const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  f32x4 mu, is, ga, be, sl;
+  auto load = [&](int c) {
+    mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c);
+    ga = *reinterpret_cast<const f32x4*>(gamma + c); be = *reinterpret_cast<const f32x4*>(beta + c);
+    sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
+  };
+  if (FIXED) load((int)(i0 % C4) * 4);
+  for (long long i = i0; i < n4; i += (long long)gridDim.x * 256) {
+    if (!FIXED) load((int)(i % C4) * 4);
+    const f32x4 v = x[i], r = res[i];
+    f32x4 sv, o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float h = (v[k] - mu[k]) * is[k] * ga[k] + be[k];     // bn_fwd_apply_kernel's expression (slope 1)
+      sv[k] = h + r[k];                                            // add_prelu_fwd_kernel's
+      o[k] = sv[k] >= 0.f ? sv[k] : sv[k] * sl[k];
+    }
+    s_out[i] = sv;
+    y[i] = o;
+  }
+}
+
+// Backward, first pass: the PReLU's backward, its slope-gradient terms AND the sums of bn2's backward from one read of the incoming
+// gradient(s), the kept sum and x -- was four passes (prelu_bwd writing the gradient and a tensor of slope terms, a column sum of the
+// terms, the BatchNorm's sums).  dy2 (nullable): a second gradient of the same output, added on the fly (the block's output feeds the
+// next block's first convolution AND its shortcut: autograd's own addition of the two was a 345 MB launch per layer-1 block).
+// g = the gradient behind the PReLU = the shortcut's gradient AND bn2's incoming one: written once (g_out).  Partials {sum g,
+// sum g xhat | sum slope terms}, parts and finisher as col_partial_kernel<3> (dbeta, dgamma, dslope).
+__global__ __launch_bounds__(256) void add_prelu_bn_partial_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                                   const float* __restrict__ sum, const float* __restrict__ x,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   const float* __restrict__ slope_vec, float* __restrict__ g_out,
+                                                                   double* part, int M, int C, int rows_per_part, const ColFin fin) {
+  __shared__ double red[16][64][3];
+  const int c0 = blockIdx.x * 64, chunk = blockIdx.y;
+  const int lx = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = c0 + lx * 4;
+  const int r0 = chunk * rows_per_part, r1 = min(M, r0 + rows_per_part);
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (c < C) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
+    const bool two = dy2 != nullptr;                         // (launch-uniform)
+    auto one = [&](long long o, const f32x4 d, const f32x4 sv, const f32x4 xv) __attribute__((always_inline)) {
+      f32x4 g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool neg = !(sv[k] >= 0.f);
+        g[k] = neg ? d[k] * sl[k] : d[k];                    // prelu_bwd_kernel
+        const float t = neg ? d[k] * sv[k] : 0.f;
+        const float xh = (xv[k] - mu[k]) * is[k];            // col_partial_kernel<1> at slope 1
+        s0[k] += (double)g[k]; s1[k] += (double)g[k] * (double)xh; s2[k] += (double)t;
+      }
+      *reinterpret_cast<f32x4*>(g_out + o) = g;
+    };
+    int r = r0 + rg;
+    for (; r + 16 < r1; r += 32) {                           // two rows of a lane group per trip, their loads issued together
+      const long long o0 = (long long)r * C + c, o1 = o0 + (long long)16 * C;
+      f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + o0), d1 = *reinterpret_cast<const f32x4*>(dy + o1);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sum + o0), v1 = *reinterpret_cast<const f32x4*>(sum + o1);
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + o0), x1 = *reinterpret_cast<const f32x4*>(x + o1);
+      if (two) {
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(dy2 + o0), e1 = *reinterpret_cast<const f32x4*>(dy2 + o1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { d0[k] += e0[k]; d1[k] += e1[k]; }
+      }
+      one(o0, d0, v0, x0);
+      one(o1, d1, v1, x1);
+    }
+    for (; r < r1; r += 16) {
+      const long long o = (long long)r * C + c;
+      f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+      if (two) { const f32x4 e = *reinterpret_cast<const f32x4*>(dy2 + o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] += e[k]; }
+      one(o, d, *reinterpret_cast<const f32x4*>(sum + o), *reinterpret_cast<const f32x4*>(x + o));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[rg][lx * 4 + k][0] = s0[k]; red[rg][lx * 4 + k][1] = s1[k]; red[rg][lx * 4 + k][2] = s2[k]; }
+  __syncthreads();
+  const int parts = gridDim.y;
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < C) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a0 += red[i][threadIdx.x][0]; a1 += red[i][threadIdx.x][1]; a2 += red[i][threadIdx.x][2]; }
+    double* p = part + ((long long)chunk * C + c0 + threadIdx.x) * 2;
+    publish(p, a0); publish(p + 1, a1);
+    double* p2 = p + (long long)parts * C * 2;
+    publish(p2, a2); publish(p2 + 1, 0.0);
+  }
+  col_finish<3>(part, parts, M, C, c0, fin, red);
+}
+
 // forward statistics: mean, biased variance -> invstd; running stats with the unbiased variance (torch)
 // Sum of the per-chunk partials {s, q} of 16 channels by one 256-thread workgroup: thread (channel cl = tid & 15, lane group
 // g = tid >> 4) adds chunks g, g + 16, ... in order, the 16 groups meet in LDS and are added in group order -- a fixed
@@ -1260,6 +1364,69 @@ extern "C" int dlip_bn_prelu_maxpool_train_bwd_f32(const float* dy_pooled, const
     hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy_pooled),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
                        reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, slope, acc, nullptr, ps);
+  if (acc) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_bn_add_prelu_rows_train_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                                   const float* slope, float* sum, float* y, float* save_mean, float* save_invstd,
+                                                   float* running_mean, float* running_var, double* workspace, int32_t M, int32_t C,
+                                                   float momentum, float eps, int64_t* num_batches_tracked, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && residual && gamma && beta && slope && sum && y && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(sum) |
+                   reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = dlip_bn_rows_chunks(M);
+  long long* nbt = reinterpret_cast<long long*>(num_batches_tracked);
+  ColFin fin = {stream_tickets(st, (C + 63) / 64), save_mean, save_invstd, nullptr, running_mean, running_var, nbt, momentum, eps};
+  hipLaunchKernelGGL(col_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, workspace, M, C, 1.f, 0, nullptr, bn_rows_per_part(M), fin);
+  if (!fin.ticket)
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_invstd,
+                       running_mean, running_var, M, C, chunks, momentum, eps, nbt);
+  const long long n4 = (long long)M * (C / 4);
+  if (const unsigned gf = grid_fixed(n4, C / 4))
+    hipLaunchKernelGGL(bn_add_prelu_fwd_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x),
+                       reinterpret_cast<const f32x4*>(residual), save_mean, save_invstd, gamma, beta, slope,
+                       reinterpret_cast<f32x4*>(sum), reinterpret_cast<f32x4*>(y), n4, C / 4);
+  else
+    hipLaunchKernelGGL(bn_add_prelu_fwd_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x),
+                       reinterpret_cast<const f32x4*>(residual), save_mean, save_invstd, gamma, beta, slope,
+                       reinterpret_cast<f32x4*>(sum), reinterpret_cast<f32x4*>(y), n4, C / 4);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_bn_add_prelu_rows_train_bwd_f32(const float* dy, const float* dy2, const float* sum, const float* x,
+                                                   const float* gamma, const float* beta, const float* slope, const float* save_mean,
+                                                   const float* save_invstd, float* dresidual, float* dx, float* dgamma, float* dbeta,
+                                                   float* dslope, double* workspace, int32_t M, int32_t C, float* dx_lift2,
+                                                   dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dy && sum && x && gamma && beta && slope && save_mean && save_invstd && dresidual && dx && dgamma && dbeta && dslope && workspace);
+  DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dy2) | reinterpret_cast<uintptr_t>(sum) | reinterpret_cast<uintptr_t>(x) |
+                   reinterpret_cast<uintptr_t>(dresidual) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = dlip_bn_rows_chunks(M);
+  ColFin fin = {stream_tickets(st, (C + 63) / 64), dbeta, dgamma, dslope, nullptr, nullptr, nullptr, 0.f, 0.f};
+  hipLaunchKernelGGL(add_prelu_bn_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, dy, dy2, sum, x, save_mean, save_invstd,
+                     slope, dresidual, workspace, M, C, bn_rows_per_part(M), fin);
+  if (!fin.ticket)
+    hipLaunchKernelGGL(col_finalize3_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, workspace + (long long)chunks * C * 2,
+                       dbeta, dgamma, dslope, C, chunks);
+  // second pass: bn2's input gradient from g (= dresidual) and x -- the BatchNorm backward's apply pass at slope 1
+  unsigned* acc = dx_lift2 ? reinterpret_cast<unsigned*>(dx_lift2) + 2 : nullptr;
+  const long long n4 = (long long)M * (C / 4);
+  const unsigned gf = grid_fixed(n4, C / 4);
+  const unsigned grid = gf ? gf : grid1d(n4);
+  if (gf)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dresidual),
+                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, nullptr, acc, nullptr);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dresidual),
+                       reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, nullptr, acc, nullptr);
   if (acc) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
   return dlip_launch_status();
 }

@@ -124,26 +124,29 @@ class BasicBlock(nn.Module):
                              w_scale=p["conv2"].wscale, x_split=split, out_split=out_split)
 
 
-def _basic_block_train(b: "BasicBlock", x: Tensor) -> Tensor:
+def _basic_block_train(b: "BasicBlock", x, fork: bool = False):
     """BasicBlock.forward under model.train() (resnet.py:55-69): batch-statistics BN, learnable PReLU slopes,
-    every step a differentiable dlip_* launch (deeplip_amd/autograd_video.py).  x NHWC."""
+    every step a differentiable dlip_* launch (deeplip_amd/autograd_video.py).  x NHWC -- or a PAIR of tensors over the same
+    values (the previous block's forked output: the convolutions take the first, the shortcut the second, and their two
+    gradients meet inside that block's backward instead of in an addition launch of autograd's).  ``fork``: return such a pair."""
     from . import autograd_video as av
     s = (b.stride, b.stride)
-    res, side = x, None
+    xa, xb = x if isinstance(x, tuple) else (x, x)
+    res, side = xb, None
     if b.downsample is not None:
         # the shortcut (1x1 strided convolution + BatchNorm) is independent of the main path: its own stream, forward and -- by
         # autograd's stream rule -- backward (see _tcn_block_train)
-        main = _fork_stream(x)
-        side = _branch_streams(x.device, 1)[0] if main is not None else None
+        main = _fork_stream(xb)
+        side = _branch_streams(xb.device, 1)[0] if main is not None else None
         if side is not None:
             side.wait_stream(main)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            res = av.batchnorm(av.conv(x, b.downsample[0].weight, None, stride=s), b.downsample[1])
-    h = av.batchnorm_prelu(av.conv(x, b.conv1.weight, None, stride=s, pad=(1, 1)), b.bn1, b.relu1)
-    h = av.batchnorm(av.conv(h, b.conv2.weight, None, pad=(1, 1)), b.bn2)
+            res = av.batchnorm(av.conv(xb, b.downsample[0].weight, None, stride=s), b.downsample[1])
+    h = av.batchnorm_prelu(av.conv(xa, b.conv1.weight, None, stride=s, pad=(1, 1)), b.bn1, b.relu1)
+    h = av.conv(h, b.conv2.weight, None, pad=(1, 1))
     if side is not None:
         main.wait_stream(side)
-    return av.add_prelu(h, res, b.relu2)
+    return av.batchnorm_add_prelu(h, b.bn2, res, b.relu2, fork=fork)      # bn2 + shortcut + relu2: one Function
 
 
 class ResNet(nn.Module):
@@ -494,8 +497,9 @@ class Lipreading(nn.Module):
         av.prepare_weights(self)                           # the step's split weight images (forward and data-gradient banks): one launch
         y = av.stem_conv(x.contiguous().float().view(B, T, H, W), stem.weight)       # [(B T),H/2,W/2,64]
         y = av.batchnorm_prelu_maxpool(y, bn, act)          # (one Function: no full-resolution tensor between the three)
-        for blk in self.trunk.blocks():
-            y = _basic_block_train(blk, y)
+        blocks = list(self.trunk.blocks())
+        for i, blk in enumerate(blocks):
+            y = _basic_block_train(blk, y, fork=i + 1 < len(blocks))     # (a block's output feeds the next block twice)
         y = av.avgpool(y).view(B, T, self.backend_out)
         if self.extract_feats:
             return y

@@ -502,6 +502,22 @@ int dlip_bn_prelu_maxpool_train_bwd_f32(const float* dy_pooled, const uint32_t* 
                                         const float* beta, const float* slope, const float* save_mean, const float* save_invstd,
                                         float* dx, float* dgamma, float* dbeta, float* dslope, double* workspace, int64_t N, int32_t H,
                                         int32_t W, int32_t C, float* dx_lift2, dlip_stream_t stream);
+/* (ABI 44) The END of a BasicBlock under model.train(): y = prelu(bn2(x) + residual), x = conv2's output
+ * (models/video_models/resnet.py:62-69: `out = self.bn2(out); out += residual; out = self.relu2(out)`), rows x [M,C].
+ * Forward: statistics of x, then ONE pass writes sum = bn2(x) + residual (kept for the backward) and y; bn2's output is never stored.
+ * Backward: dy [M,C] (+ dy2, nullable: a second gradient of y -- the next block's first convolution AND its shortcut both consume y --
+ * added on the fly) -> dresidual [M,C] = the gradient behind the PReLU (the shortcut's gradient and bn2's incoming one), dx [M,C],
+ * dgamma, dbeta (bn2), dslope (relu2): the first pass forms dresidual, the slope gradient's terms and bn2's two sums from one read of
+ * dy, sum and x (was: PReLU backward writing two tensors, a column sum, the BatchNorm's sums pass); the second is the BatchNorm
+ * backward's apply pass.  workspace: 2 * dlip_bn_rows_chunks(M) * C * 2 doubles; dx_lift2 as above. */
+int dlip_bn_add_prelu_rows_train_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                         const float* slope, float* sum, float* y, float* save_mean, float* save_invstd,
+                                         float* running_mean, float* running_var, double* workspace, int32_t M, int32_t C,
+                                         float momentum, float eps, int64_t* num_batches_tracked, dlip_stream_t stream);
+int dlip_bn_add_prelu_rows_train_bwd_f32(const float* dy, const float* dy2, const float* sum, const float* x, const float* gamma,
+                                         const float* beta, const float* slope, const float* save_mean, const float* save_invstd,
+                                         float* dresidual, float* dx, float* dgamma, float* dbeta, float* dslope, double* workspace,
+                                         int32_t M, int32_t C, float* dx_lift2, dlip_stream_t stream);
 /* y[c] = sum_m x[m,c] (bias gradients), same chunked reduction and workspace. */
 int dlip_colsum_rows_f32(const float* x, float* y, double* workspace, int32_t M, int32_t C, dlip_stream_t stream);
 

@@ -260,6 +260,53 @@ def test_stem_batchnorm_prelu_maxpool_as_one_function(N, H, W, C):
     assert e * inv == 1.0 and 512.0 <= amax * e <= 1024.0 and bool((lift[2:8] == inv).all())
 
 
+@pytest.mark.parametrize("M,C", [(2 * 22 * 22, 64), (9000, 128), (70, 512), (300000, 8)])
+def test_block_tail_batchnorm_add_prelu_as_one_function(M, C):
+    """Round 5: prelu(bn2(x) + residual) -- the end of a BasicBlock (resnet.py:62-69) under model.train() -- as one Function:
+    (1) against torch autograd (fp64); (2) the SAME output bits as BNRowsActFn + AddPReLUFn and gradients to 2e-6; (3) the forked
+    output: two gradients arriving separately == their sum arriving once; (4) repeatable bits, num_batches_tracked, the lift."""
+    from deeplip_amd import autograd as ag, autograd_video as av
+    x = (rnd(M, C, seed=51) * 1.7 + 0.3)
+    res = rnd(M, C, seed=52)
+    ga = (1.0 + 0.3 * rnd(C, seed=53)); be = 0.2 * rnd(C, seed=54)
+    sl = torch.rand(C, generator=torch.Generator().manual_seed(55)) * 0.5 - 0.05
+    d1, d2 = rnd(M, C, seed=56) * 1e-2, rnd(M, C, seed=57) * 1e-2
+    bn = torch.nn.BatchNorm1d(C, momentum=0.1).double()
+    with torch.no_grad():
+        bn.weight.copy_(ga); bn.bias.copy_(be)
+    bn.train()
+    xd, rd, sld = x.double().requires_grad_(), res.double().requires_grad_(), sl.double().requires_grad_()
+    ref = F.prelu(bn(xd) + rd, sld)
+    ref.backward((d1 + d2).double())
+
+    def run(mode):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        nbt = torch.zeros((), dtype=torch.long, device=DEV)
+        xg, rg, gg, bg, sg = (t.clone().to(DEV).requires_grad_() for t in (x, res, ga, be, sl))
+        if mode == "two":
+            y = av.AddPReLUFn.apply(ag.BNRowsActFn.apply(xg, gg, bg, rm, rv, 0.1, 1e-5, 1.0, False, nbt), rg, sg)
+            y.backward((d1 + d2).to(DEV))
+        elif mode == "one":
+            y = av.BNAddPReLUFn.apply(xg, rg, gg, bg, sg, rm, rv, 0.1, 1e-5, nbt, False)
+            y.backward((d1 + d2).to(DEV))
+        else:
+            y, y2 = av.BNAddPReLUFn.apply(xg, rg, gg, bg, sg, rm, rv, 0.1, 1e-5, nbt, True)
+            assert y.data_ptr() == y2.data_ptr()
+            torch.autograd.backward([y, y2], [d1.to(DEV), d2.to(DEV)])
+        torch.cuda.synchronize()
+        return [t.detach().clone() for t in (y, xg.grad, rg.grad, gg.grad, bg.grad, sg.grad, rm, rv, nbt.float())]
+
+    two, one, one2, fork = run("two"), run("one"), run("one"), run("fork")
+    assert rel_err(one[0].cpu().numpy(), ref.detach().numpy()) < 1e-5
+    for got, want in zip(one[1:6], (xd.grad, rd.grad, bn.weight.grad, bn.bias.grad, sld.grad)):
+        assert rel_err(got.cpu().numpy(), want.numpy()) < 1e-4
+    assert rel_err(one[6].cpu().numpy(), bn.running_mean.numpy()) < 1e-5 and rel_err(one[7].cpu().numpy(), bn.running_var.numpy()) < 1e-5
+    assert float(one[8]) == 1.0 and torch.equal(one[0], two[0]) and torch.equal(one[0], fork[0])
+    for a, a2, b, f in zip(one, one2, two, fork):
+        assert torch.equal(a, a2)
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-6 and rel_err(f.cpu().numpy(), a.cpu().numpy()) < 2e-6
+
+
 def test_prelu_maxpool_avgpool_timemean_dropout():
     from deeplip_amd import autograd_video as av
     # PReLU with per-channel slope
