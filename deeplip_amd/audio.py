@@ -204,8 +204,9 @@ class SpeakerEmbNet(nn.Module):
         h = self._to_ntc_padded(x)
         from . import autograd_video as av
         av.prepare_weights(self)                           # the step's split weight images (forward and data-gradient banks): one launch
-        for blk in self.tdnn:
-            h = ag.tdnn_block_train(h, blk)
+        pend = None                                        # (a block's activated output is not stored when the next block takes it on load)
+        for i, blk in enumerate(self.tdnn):
+            h, pend = ag.tdnn_block_train(h, blk, pending=pend, defer=i + 1 < len(self.tdnn))
         h = ag.meanstd_pool(h)
         x_a = ag.linear(h, self.fc1.weight, self.fc1.bias)
         h = ag.bn_rows_act_train(x_a, self.bn1, LRELU, act_first=not self.bn_first)

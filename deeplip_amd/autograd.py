@@ -180,6 +180,8 @@ def margin_ce_loss(logits, labels, scale=1.0, margin=0.0):
 # ==========================================================================================
 # Round 5 (both measured on the speech encoder's training step, tools/bench_train_audio.py; False restores round 4's passes):
 BN_STATS_FROM_CONV = __import__("os").environ.get("DLIP_BN_STATS_FROM_CONV", "1") != "0"
+# Round 5: a TDNN block's activated output is not stored when the next block can take it on load (TDNNBlockTrainFn: defer / pending)
+BN_ON_LOAD = __import__("os").environ.get("DLIP_BN_ON_LOAD", "1") != "0"
 ZERO_BIAS_GRAD_BEFORE_BN = __import__("os").environ.get("DLIP_ZERO_BIAS_GRAD", "1") != "0"
 
 
@@ -222,13 +224,13 @@ def _permute3(x, perm, flip_axis=-1):
     return y
 
 
-def _bn_rows_fwd(x2, gamma, beta, rm, rv, momentum, eps, slope, act_first, ready=None, nbt=None):
+def _bn_rows_fwd(x2, gamma, beta, rm, rv, momentum, eps, slope, act_first, ready=None, nbt=None, stats_only=False):
     """``ready`` = (ws, chunks): the partial column sums of x2 already written by the convolution that produced it
     (conv_train(..., stats=...)): the statistics pass over x2 is skipped.  ``nbt``: the module's num_batches_tracked, incremented by the
     launch that finishes the statistics."""
     M, C_ = x2.shape
     _lib.ensure_conv_workspace()          # (its ticket words: the finalize step runs in the statistics pass's last workgroup)
-    y = torch.empty_like(x2)
+    y = None if stats_only else torch.empty_like(x2)      # (stats_only: the consumer applies the BatchNorm on load)
     mean = torch.empty((C_,), device=x2.device, dtype=torch.float32)
     invstd = torch.empty_like(mean)
     ws, chunks = ready if ready is not None else (_ws(M, C_, x2.device), 0)
@@ -286,7 +288,13 @@ class TDNNBlockTrainFn(Function):
     LDS-DMA kernel, whose balanced work split is what makes a 512 x 512 x 19 200 product fill the chip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, slope, dilation, act_first, nbt=None):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, slope, dilation, act_first, nbt=None,
+                defer=False, pending=None):
+        """``pending`` = (z, mean, invstd, gamma, beta, slope) of the PREVIOUS block: x then is that block's output tensor whose
+        VALUES WERE NEVER WRITTEN (defer) -- this block's operand producers read the previous convolution's raw output z and apply
+        its BatchNorm + LeakyReLU on load (dlip_wgrad_*_bn_f32); a block that cannot (channel counts, arithmetic mode) writes the
+        values first.  ``defer``: do the same for THIS block's output: returns (y [values not written], z, mean, invstd); the
+        backward is the same either way (it needs z, never y)."""
         x = x.contiguous()
         B, T, Cx = x.shape
         K, Cw, S = weight.shape
@@ -299,12 +307,16 @@ class TDNNBlockTrainFn(Function):
         # for the backward instead of x): the reduction-major GEMM operand of a k = 1 layer (mode 1), the [C][T][B32] image of the
         # weight gradient run as a convolution otherwise (mode 2) -- what ConvTrainFn does for the lip-clip encoder
         mode, xT, xs = 0, None, None
-        if ctx.needs_input_grad[1] and av.TRAIN_CONV == "f16x3" and K % 4 == 0 and (Cw == Cx or (Cw + 31) // 32 * 32 == Cx):
+        images = ctx.needs_input_grad[1] and av.TRAIN_CONV == "f16x3" and K % 4 == 0 and (Cw == Cx or (Cw + 31) // 32 * 32 == Cx)
+        on_load = pending is not None and images and Cx % 64 == 0 and (S == 1 or av.WGRAD == "conv") and av.WGRAD_SLICE_MAJOR
+        if pending is not None and not on_load:
+            materialize_pending(x, pending)               # this block reads x itself: write the values the previous block left out
+        if images:
             if S == 1 and Cx % 64 == 0:
-                xT, xs = av.operand_and_split(x.view(B_ * T_, C_in))
+                xT, xs = av.operand_and_split(x.view(B_ * T_, C_in), bn=pending if on_load else None)
                 mode, xs = 1, xs.view(B_, 1, T_, C_in)
             elif S > 1 and Cx % 32 == 0 and av.WGRAD == "conv":
-                xT, xs = av.wgrad_image(x.view(B_, 1, T_, C_in), None, also_nhwc_split=True)
+                xT, xs = av.wgrad_image(x.view(B_, 1, T_, C_in), None, also_nhwc_split=True, bn=pending if on_load else None)
                 mode = 2
         # (round 5) conv -> BN: the batch statistics come out of the convolution's epilogue (per half tile the column sums of what it
         # writes) instead of a pass of their own over z -- 155 MB read per layer at B = 256
@@ -318,14 +330,21 @@ class TDNNBlockTrainFn(Function):
         z = z.view(B_, z.shape[2], z.shape[3])
         Tp = z.shape[1]
         ready = (stats["ws"], stats["chunks"]) if stats is not None and stats.get("done") else None
-        y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first, ready, nbt)
+        defer = bool(defer) and not act_first
+        y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first, ready, nbt,
+                                        stats_only=defer)
         ctx.save_for_backward(xT if mode else x, weight, z, gamma, beta, mean, invstd)
         ctx.cfg = (dilation, slope, act_first, bias is not None)
         ctx.x_shape, ctx.mode = (B, T, Cx), mode
+        if defer:
+            y2 = torch.empty((B, Tp, K), device=x.device, dtype=torch.float32)   # (address and shape only: nobody reads its values)
+            ctx.mark_non_differentiable(z, mean, invstd)
+            ctx.set_materialize_grads(False)      # (or autograd hands the backward ZERO-FILLED gradients for the three: a 155 MB fill per block)
+            return y2, z, mean, invstd
         return y2.view(B, Tp, K)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x, weight, z, gamma, beta, mean, invstd = ctx.saved_tensors
         dilation, slope, act_first, has_bias = ctx.cfg
         B, T, Cx = ctx.x_shape
@@ -379,7 +398,7 @@ class TDNNBlockTrainFn(Function):
                 dweight = _conv1d_wgrad(x, dz, S, dilation, lift)
             if dweight.shape[1] != weight.shape[1]:          # zero-padded input channels: their gradient columns are not parameters
                 dweight = dweight[:, :weight.shape[1]].contiguous()
-        return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def _conv1d_wgrad(x, dz, S, dilation, lift=None):
@@ -439,12 +458,27 @@ class MeanStdPoolFn(Function):
         return dx
 
 
-def tdnn_block_train(x, blk):
-    """blk: deeplip_amd.audio.TDNN_Block in train mode; x [B,T,C] channels-last."""
+def materialize_pending(y, pending):
+    """Write the values of a deferred block output ``y`` (TDNNBlockTrainFn defer): lrelu(bn(z)) from the statistics already formed."""
+    z, mean, invstd, gamma, beta, slope = pending
+    M, C_ = z.numel() // z.shape[-1], z.shape[-1]
+    sv, sc = (slope, 0.0) if isinstance(slope, torch.Tensor) else (None, float(slope))
+    check(lib().dlip_bn_apply_rows_f32(ptr(z), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sv), sc, ptr(y), M, C_, stream_handle()),
+          "dlip_bn_apply_rows_f32")
+
+
+def tdnn_block_train(x, blk, pending=None, defer=False):
+    """blk: deeplip_amd.audio.TDNN_Block in train mode; x [B,T,C] channels-last.  ``pending`` / ``defer``: TDNNBlockTrainFn --
+    returns (y, pending for the next block or None)."""
     bn = blk.bn
-    y = TDNNBlockTrainFn.apply(x, blk.context_layer.weight, blk.context_layer.bias, bn.weight, bn.bias, bn.running_mean,
-                               bn.running_var, bn.momentum, bn.eps, 0.2, blk.dilation, not blk.bn_first, bn.num_batches_tracked)
-    return y                              # (num_batches_tracked += 1: done by the launch that finishes the batch statistics)
+    defer = bool(defer) and BN_ON_LOAD and blk.bn_first
+    out = TDNNBlockTrainFn.apply(x, blk.context_layer.weight, blk.context_layer.bias, bn.weight, bn.bias, bn.running_mean,
+                                 bn.running_var, bn.momentum, bn.eps, 0.2, blk.dilation, not blk.bn_first, bn.num_batches_tracked,
+                                 defer, pending)
+    if defer:                             # (num_batches_tracked += 1: done by the launch that finishes the batch statistics)
+        y, z, mean, invstd = out
+        return y, (z, mean, invstd, bn.weight.detach(), bn.bias.detach(), 0.2)
+    return out, None
 
 
 def bn_rows_act_train(x, bn, slope, act_first):

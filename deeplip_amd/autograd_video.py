@@ -359,7 +359,7 @@ def wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2=None):
     return out.view(taps, Cx, K)
 
 
-def operand_and_split(t2, scale2=None):
+def operand_and_split(t2, scale2=None, bn=None):
     """A [J, C] row matrix (C % 64 == 0) -> (its reduction-major weight-gradient GEMM operand [C, J32], its split NHWC copy [J, C]) from
     ONE read (dlip_wgrad_operand_split_f32): the forward convolution's operand of a k = 1 layer's input beside its weight-gradient
     image, or -- with the lift ``scale2`` -- the data gradient's operand of dy beside dy's."""
@@ -369,6 +369,12 @@ def operand_and_split(t2, scale2=None):
         J32 += 32
     opT = torch.empty((C_, J32), device=t2.device, dtype=torch.float32)
     spl = torch.empty((J, C_), device=t2.device, dtype=torch.float32)
+    if bn is not None:      # t2's values were never written: read the raw convolution output and apply its BatchNorm + activation on load
+        z, mean, invstd, gamma, beta, slope = bn
+        sv, sc = (slope, 0.0) if isinstance(slope, torch.Tensor) else (None, float(slope))
+        check(lib().dlip_wgrad_operand_split_bn_f32(ptr(z), ptr(opT), J32, J, C_, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sv), sc,
+                                                    ptr(spl), stream_handle()), "dlip_wgrad_operand_split_bn_f32")
+        return opT, spl
     check(lib().dlip_wgrad_operand_split_f32(ptr(t2), ptr(opT), J32, J, C_, ptr(scale2) if scale2 is not None else None, ptr(spl), stream_handle()),
           "dlip_wgrad_operand_split_f32")
     return opT, spl
@@ -412,7 +418,7 @@ def _wgrad_conv_launch(xT, gT, inv, C_, H, W, K, Ho, Wo, N32, stride, pad, dil, 
     return out
 
 
-def wgrad_image(t, scale2=None, also_nhwc_split=False):
+def wgrad_image(t, scale2=None, also_nhwc_split=False, bn=None):
     """The weight gradient's operand image of an NHWC tensor ``t`` [N,H,W,C] (dlip_wgrad_chwn_f32; layout per
     WGRAD_SLICE_MAJOR; times scale2[0] when given).  ``also_nhwc_split``: the convolution kernels' split activation format of the
     same (scaled) tensor from the same read -- the forward convolution's operand (t = x) or the data gradient's (t = dy).
@@ -421,6 +427,12 @@ def wgrad_image(t, scale2=None, also_nhwc_split=False):
     N32 = (N + 31) // 32 * 32
     img = torch.empty((C_, H, W, N32), device=t.device, dtype=torch.float32)    # slice-major: [C][N32/32][H][W][32]
     spl = torch.empty_like(t) if also_nhwc_split else None
+    if bn is not None:      # (see operand_and_split)
+        z, mean, invstd, gamma, beta, slope = bn
+        sv, sc = (slope, 0.0) if isinstance(slope, torch.Tensor) else (None, float(slope))
+        check(lib().dlip_wgrad_chwn_bn_f32(ptr(z), ptr(img), N, H, W, C_, N32, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sv), sc, ptr(spl),
+                                           stream_handle()), "dlip_wgrad_chwn_bn_f32")
+        return img, spl
     check(lib().dlip_wgrad_chwn_f32(ptr(t), ptr(img), N, H, W, C_, t.stride(2), N32, ptr(scale2) if scale2 is not None else None,
                                     1 if WGRAD_SLICE_MAJOR else 0, ptr(spl) if spl is not None else None, stream_handle()), "dlip_wgrad_chwn_f32")
     return img, spl
@@ -476,7 +488,10 @@ class ConvTrainFn(Function):
     GEMM over the rows of all taps gathered side by side (resnet.py:9-16,55-69; tcn.py:39-41,94,101)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil):
+    def forward(ctx, x, weight, bias, stride, pad, dil, pending=None):
+        """``pending`` = (z, mean, invstd, gamma, beta, slopes) of the BatchNorm + PReLU in front (BNPReLUFn defer): x's values were never
+        written -- the operand producer applies the normalisation and the slopes to z on load; a convolution that cannot take them
+        on load writes them first."""
         x = x.contiguous()
         N, H, W, Cx = x.shape
         K, Cw, R, S = weight.shape
@@ -486,8 +501,12 @@ class ConvTrainFn(Function):
         # backward instead of x itself -- the data gradient does not need x).
         fused = WGRAD == "conv" and TRAIN_CONV == "f16x3" and R * S > 1 and Cx % 32 == 0 and K % 4 == 0 and ctx.needs_input_grad[1]
         xT = xs = None
+        on_load = pending is not None and fused and Cx % 64 == 0 and WGRAD_SLICE_MAJOR
+        if pending is not None and not on_load:
+            from .autograd import materialize_pending
+            materialize_pending(x, pending)
         if fused:
-            xT, xs = wgrad_image(x, None, also_nhwc_split=True)
+            xT, xs = wgrad_image(x, None, also_nhwc_split=True, bn=pending if on_load else None)
         y = conv_train(x, None, bias.contiguous() if bias is not None else None, stride, pad, dil, w_ref=weight, xs_ready=xs)
         ctx.save_for_backward(xT if fused else x, weight)
         ctx.cfg = (stride, pad, dil, bias is not None)
@@ -525,7 +544,7 @@ class ConvTrainFn(Function):
                 dx = conv_train(src, None, None, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), lift=True, scale2=lift,
                                 w_ref=weight, transposed=True, xs_ready=dys)
             dweight = wgrad_as_conv(None, None, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift, xT=x, gT=gT) if want_w else None
-            return dx, dweight, dbias, None, None, None
+            return dx, dweight, dbias, None, None, None, None
         if ctx.needs_input_grad[0]:
             src = dy
             if sh != 1 or sw != 1:
@@ -541,7 +560,7 @@ class ConvTrainFn(Function):
             # tiles of a per-tap GEMM: a 64-channel layer would otherwise be a single 64x64 tile)
             taps = R * S
             if Cx % 4 == 0 and K % 4 == 0:
-                return dx, wgrad_conv(x, dy, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift), dbias, None, None, None
+                return dx, wgrad_conv(x, dy, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift), dbias, None, None, None, None
             rows = torch.empty((J, taps * Cx), device=dev, dtype=torch.float32)
             for t in range(taps):
                 r, s = divmod(t, S)
@@ -549,7 +568,7 @@ class ConvTrainFn(Function):
                                                 r * dh - ph, s * dw - pw, taps * Cx, stream_handle()), "dlip_tap_gather_f32")
             dwt = wgrad_gemm(dz_rows, lambda _: rows, 1).view(taps, Cx, K)  # [RS, C, K]
             dweight = _permute3(dwt, (2, 1, 0)).view(K, Cx, R, S)
-        return dx, dweight, dbias, None, None, None
+        return dx, dweight, dbias, None, None, None, None
 
 
 class StemConvTrainFn(Function):
@@ -656,12 +675,14 @@ class BNPReLUFn(Function):
     (dlip_bn_prelu_rows_train_fwd/bwd_f32): no separate PReLU forward / backward pass and no column sum of slope terms."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, momentum, eps, nbt=None):
+    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, momentum, eps, nbt=None, defer=False):
+        """``defer``: statistics only -- returns (y [values NOT written], mean, invstd): the convolution behind applies the
+        normalisation and the slopes on load (ConvTrainFn ``pending``; autograd.TDNNBlockTrainFn does the same for the speech encoder)."""
         shape = tuple(x.shape)                                 # any channels-last shape [..., C]
         x = x.contiguous().view(-1, shape[-1])
         M, C_ = x.shape
         _lib.ensure_conv_workspace()      # (its ticket words: the finalize steps run in the passes' last workgroups)
-        y = torch.empty_like(x)
+        y = None if defer else torch.empty_like(x)
         mean = torch.empty((C_,), device=x.device, dtype=torch.float32)
         invstd = torch.empty_like(mean)
         ws = torch.empty((int(lib().dlip_bn_rows_chunks(M)) * C_ * 4,), device=x.device, dtype=torch.float64)
@@ -670,10 +691,15 @@ class BNPReLUFn(Function):
               "dlip_bn_prelu_rows_train_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, slope, mean, invstd)
         ctx.shape = shape
+        if defer:
+            y = torch.empty(shape, device=x.device, dtype=torch.float32)      # (address and shape only)
+            ctx.mark_non_differentiable(mean, invstd)
+            ctx.set_materialize_grads(False)
+            return y, mean, invstd
         return y.view(shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         x, gamma, beta, slope, mean, invstd = ctx.saved_tensors
         M, C_ = x.shape
         _lib.ensure_conv_workspace()
@@ -687,7 +713,7 @@ class BNPReLUFn(Function):
               "dlip_bn_prelu_rows_train_bwd_f32")
         dx = dx.view(ctx.shape)
         dx._dlip_lift = lift      # see autograd._bn_rows_bwd: travels with the tensor object the convolution backward receives
-        return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None, None
+        return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None, None, None
 
 
 class BNPReLUMaxPoolFn(Function):
@@ -897,11 +923,11 @@ class MulMaskFn(Function):
 # ------------------------------------------------------------------------------------------------------
 # functional helpers used by deeplip_amd.video in train mode
 # ------------------------------------------------------------------------------------------------------
-def conv(x, weight, bias=None, stride=(1, 1), pad=(0, 0), dil=(1, 1)):
-    """x NHWC, weight [K,C,R,S] (reference Conv2d layout) or [K,C,S] (Conv1d: R = 1)."""
+def conv(x, weight, bias=None, stride=(1, 1), pad=(0, 0), dil=(1, 1), pending=None):
+    """x NHWC, weight [K,C,R,S] (reference Conv2d layout) or [K,C,S] (Conv1d: R = 1).  ``pending``: batchnorm_prelu(..., defer=True)."""
     if weight.dim() == 3:
         weight = weight.unsqueeze(2)
-    return ConvTrainFn.apply(x, weight, bias, tuple(stride), tuple(pad), tuple(dil))
+    return ConvTrainFn.apply(x, weight, bias, tuple(stride), tuple(pad), tuple(dil), pending)
 
 
 def batchnorm(x, bn):
@@ -912,18 +938,27 @@ def batchnorm(x, bn):
                              bn.num_batches_tracked)       # (the counter is incremented by the launch that finishes the statistics)
 
 
-def batchnorm_prelu(x, bn, act):
+# (round 5) conv1 -> bn1 + relu1 -> conv2: relu1's output is not stored, conv2's operand producer applies bn1 + relu1 on load
+BN_ON_LOAD = __import__("os").environ.get("DLIP_BN_ON_LOAD", "1") != "0"
+
+
+def batchnorm_prelu(x, bn, act, defer=False):
     """prelu(batchnorm(x)) of a channels-last tensor in train mode, fused when the activation has one slope per channel (or is a
-    ReLU marker: slope 0, no parameter); a single shared slope keeps the two-step path (its gradient is a sum over channels)."""
+    ReLU marker: slope 0, no parameter); a single shared slope keeps the two-step path (its gradient is a sum over channels).
+    ``defer``: returns (y, pending) -- y's values are NOT written when pending is not None: hand both to conv(..., pending=pending)."""
     w = getattr(act, "weight", None)
     C_ = x.shape[-1]
     if w is not None and w.numel() != C_:
-        return prelu(batchnorm(x, bn), act)
+        y = prelu(batchnorm(x, bn), act)
+        return (y, None) if defer else y
     if w is None:
         w = const_vec(C_, 0.0, x.device)
-    y = BNPReLUFn.apply(x, bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(),
-                        bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.num_batches_tracked)
-    return y
+    w = w if w.is_contiguous() else w.contiguous()
+    if defer and BN_ON_LOAD:
+        y, mean, invstd = BNPReLUFn.apply(x, bn.weight, bn.bias, w, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.num_batches_tracked, True)
+        return y, (x.detach(), mean, invstd, bn.weight.detach(), bn.bias.detach(), w.detach())
+    y = BNPReLUFn.apply(x, bn.weight, bn.bias, w, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.num_batches_tracked)
+    return (y, None) if defer else y
 
 
 # (round 5) the stem's BatchNorm + PReLU + max-pool as one Function (False: round 4's three: BNPReLUFn, then MaxPoolFn)

@@ -448,8 +448,22 @@ __device__ __forceinline__ bool col_reduce16(const double* __restrict__ part, in
   const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int i = g; i < chunks; i += 16) { a += part[((long long)i * C + c) * 2]; b += part[((long long)i * C + c) * 2 + 1]; }
+  if (c < C) {
+    // (four loads in flight, added in the same order as one at a time: the ~1 000 half-tile rows a convolution's statistics
+    // epilogue leaves took 25 us per TDNN layer as a chain of dependent loads)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const long long step = (long long)C * 2;
+    const double* p = part + (long long)c * 2;
+    int i = g;
+    for (; i + 48 < chunks; i += 64) {
+      d2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const d2*>(p + (i + 16 * u) * step);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a += v[u][0]; b += v[u][1]; }
+    }
+    for (; i < chunks; i += 16) { a += p[i * step]; b += p[i * step + 1]; }
+  }
   red[g][cl][0] = a; red[g][cl][1] = b;
   __syncthreads();
   if (g != 0 || c >= C) return false;
@@ -1178,7 +1192,7 @@ bool bn_small(int M) { return M <= BN_SMALL_ROWS && dlip_dbg_value[DLIP_DBG_BN_F
 int bn_fwd_launch(const float* x, const float* gamma, const float* beta, const float* slope_vec, float* y, float* save_mean,
                   float* save_invstd, float* running_mean, float* running_var, double* workspace, int M, int C, float momentum,
                   float eps, float slope, int act_first, int ready_chunks, long long* nbt, hipStream_t st) {
-  if (ready_chunks == 0 && bn_small(M)) {
+  if (ready_chunks == 0 && bn_small(M) && y != nullptr) {
     const dim3 grid(C / 4), block(256);
     if (M <= 1024) hipLaunchKernelGGL(bn_small_fwd_kernel<4>, grid, block, 0, st, x, gamma, beta, slope_vec, y, save_mean, save_invstd,
                                       running_mean, running_var, nbt, M, C, momentum, eps, slope, act_first);
@@ -1201,6 +1215,7 @@ int bn_fwd_launch(const float* x, const float* gamma, const float* beta, const f
   if (!finalized)
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, save_mean, save_invstd,
                        running_mean, running_var, M, C, chunks, momentum, eps, nbt);
+  if (y == nullptr) return dlip_launch_status();   // statistics only: the consumer applies the BatchNorm on load (dlip_wgrad_*_bn_f32)
   const long long n4 = (long long)M * (C / 4);
   if (const unsigned gf = grid_fixed(n4, C / 4))
     hipLaunchKernelGGL(bn_fwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), save_mean,
@@ -1267,7 +1282,7 @@ extern "C" int dlip_bn_rows_train_fwd_f32(const float* x, const float* gamma, co
                                           float* running_var, double* workspace, int32_t M, int32_t C, float momentum,
                                           float eps, float slope, int32_t act_first, int32_t ready_chunks,
                                           int64_t* num_batches_tracked, dlip_stream_t stream) {
-  DLIP_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG(x && gamma && beta && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);   // (y NULL: statistics only)
   DLIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
   DLIP_CHECK_ARG(ready_chunks >= 0 && !(ready_chunks > 0 && act_first));
@@ -1290,7 +1305,7 @@ extern "C" int dlip_bn_prelu_rows_train_fwd_f32(const float* x, const float* gam
                                                 float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                                                 double* workspace, int32_t M, int32_t C, float momentum, float eps,
                                                 int64_t* num_batches_tracked, dlip_stream_t stream) {
-  DLIP_CHECK_ARG(x && gamma && beta && slope && y && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG(x && gamma && beta && slope && save_mean && save_invstd && workspace && M > 0 && C > 0 && (C & 3) == 0);   // (y NULL: statistics only)
   DLIP_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
   return bn_fwd_launch(x, gamma, beta, slope, y, save_mean, save_invstd, running_mean, running_var, workspace, M, C, momentum, eps, 1.f, 0,
@@ -1428,6 +1443,21 @@ extern "C" int dlip_bn_add_prelu_rows_train_bwd_f32(const float* dy, const float
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
                        reinterpret_cast<f32x4*>(dx), n4, C / 4, M, 1.f, 0, nullptr, acc, nullptr);
   if (acc) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_bn_apply_rows_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                      const float* slope_vec, float slope, float* y, int32_t M, int32_t C, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && mean && invstd && gamma && beta && y && M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long n4 = (long long)M * (C / 4);
+  if (const unsigned gf = grid_fixed(n4, C / 4))
+    hipLaunchKernelGGL(bn_fwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), mean, invstd, gamma, beta,
+                       reinterpret_cast<f32x4*>(y), n4, C / 4, slope, 0, slope_vec);
+  else
+    hipLaunchKernelGGL(bn_fwd_apply_kernel<false>, dim3(grid1d(n4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), mean, invstd, gamma,
+                       beta, reinterpret_cast<f32x4*>(y), n4, C / 4, slope, 0, slope_vec);
   return dlip_launch_status();
 }
 

@@ -99,17 +99,58 @@ __global__ __launch_bounds__(256) void wgrad_operand_kernel(const float* __restr
   dlip_report_range(amax, status);
 }
 
+// (round 5) A train-mode BatchNorm + (Leaky | P)ReLU applied ON LOAD by the operand producers below: the convolution that FOLLOWS a
+// conv -> BatchNorm -> activation (tdnn.py:35-43, resnet.py:51-53) needs its input only as split images, so the activated tensor is
+// never stored -- the producer reads the previous convolution's raw output z and forms lrelu((z - mean) invstd gamma + beta, slope)
+// per value (bn_fwd_apply_kernel's expression: the same bits).  Positions outside the image / beyond N stay exact zeros.
+struct BnOnLoad {
+  const float* mean;        // nullptr: plain load
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  const float* slope_vec;   // nullptr: the scalar `slope` for every channel
+  float slope;
+};
+// The workgroup's CT channels of the five parameter vectors, staged in LDS once (tab [5][CT]): read from memory per loaded value
+// they were five vector-memory instructions beside every 16-B data load (the producers went from 80 to 95 - 104 us per TDNN layer).
+template <int CT>
+__device__ __forceinline__ void bn_on_load_stage(const BnOnLoad& b, int c0, float* tab) {
+  for (int i = threadIdx.x; i < 5 * (CT / 4); i += 256) {
+    const int w = i / (CT / 4), c = (i - w * (CT / 4)) * 4;
+    const float* src = w == 0 ? b.mean : w == 1 ? b.invstd : w == 2 ? b.gamma : w == 3 ? b.beta : b.slope_vec;
+    f32x4 v = {b.slope, b.slope, b.slope, b.slope};
+    if (src) v = *reinterpret_cast<const f32x4*>(src + c0 + c);
+    *reinterpret_cast<f32x4*>(tab + w * CT + c) = v;
+  }
+  __syncthreads();
+}
+template <int CT>
+__device__ __forceinline__ f32x4 bn_on_load(const float* tab, f32x4 v, int c) {   // c: channel within the workgroup's CT
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + c), is = *reinterpret_cast<const f32x4*>(tab + CT + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + 2 * CT + c), be = *reinterpret_cast<const f32x4*>(tab + 3 * CT + c);
+  const f32x4 sl = *reinterpret_cast<const f32x4*>(tab + 4 * CT + c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t = (v[k] - mu[k]) * is[k] * ga[k] + be[k];
+    v[k] = t >= 0.f ? t : t * sl[k];
+  }
+  return v;
+}
+
 // The same operand from WIDER tiles (round 4; see wgrad_chwn_wide_kernel): 32 positions x CT channels (64 | 128) of one tap, read
 // as 16-B quads and written as CT / 32 sixteen-byte pieces per thread.  C % CT == 0, ldx % 4 == 0, x 16-byte aligned.
-template <int CT>
+template <int CT, bool AFF = false>
 __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int ldx,
                                                                  int C, int Ho, int Wo, int sh, int sw, int R, int S, int dh, int dw, int ph,
                                                                  int pw, int J, long long ldo, const float* __restrict__ scale,
-                                                                 DlipRange status, float* __restrict__ nhwc_out = nullptr) {
+                                                                 DlipRange status, float* __restrict__ nhwc_out = nullptr,
+                                                                 const BnOnLoad bn = BnOnLoad{}) {
   constexpr int PITCH = CT + 4, Q = CT / 32;
   __shared__ __attribute__((aligned(16))) float tile[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) float bn_tab[AFF ? 5 * CT : 4];
   const int j0 = blockIdx.x * 32, c0 = blockIdx.y * CT;
   const float sc = scale ? scale[0] : 1.f;
+  if constexpr (AFF) bn_on_load_stage<CT>(bn, c0, bn_tab);
   // this thread's Q quads: position row (i / (CT / 4)) -- pixel origin of tap (0, 0), once for all taps -- and channel quad
   int base[Q], hi0[Q], wi0[Q], col[Q], row_[Q];
 #pragma unroll
@@ -132,8 +173,10 @@ __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __
     for (int q = 0; q < Q; ++q) {
       const int hi = hi0[q] + r * dh, wi = wi0[q] + s_ * dw;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
         v = *reinterpret_cast<const f32x4*>(x + ((long long)(base[q] + hi) * W + wi) * ldx + c0 + col[q]);
+        if constexpr (AFF) v = bn_on_load<CT>(bn_tab, v, col[q]);
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] *= sc;
       *reinterpret_cast<f32x4*>(tile + row_[q] * PITCH + col[q]) = v;
@@ -237,20 +280,25 @@ __global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict
 // The same images from WIDER tiles (round 4): one workgroup = 32 images x CT channels (64 | 128) of one pixel, read as 16-B
 // quads (CT / 32 per thread in flight instead of four 4-B loads) and written as CT / 32 sixteen-byte pieces per thread -- the
 // 32 x 32 version moved 4 KB per workgroup between two barriers and held 2.8 TB/s.  group = 0, layouts 0 / 1, C % CT == 0.
-template <int CT>
+template <int CT, bool AFF = false>
 __global__ __launch_bounds__(256) void wgrad_chwn_wide_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int ldx, int C,
                                                               int N32, const float* __restrict__ scale, DlipRange status, int layout,
-                                                              float* __restrict__ nhwc_out) {
+                                                              float* __restrict__ nhwc_out, const BnOnLoad bn = BnOnLoad{}) {
   constexpr int PITCH = CT + 4, Q = CT / 32;              // floats per LDS row (16-B aligned rows); quads / pieces per thread
   __shared__ __attribute__((aligned(16))) float tile[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) float bn_tab[AFF ? 5 * CT : 4];
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * CT, p = blockIdx.z;
   const float sc = scale ? scale[0] : 1.f;
+  if constexpr (AFF) bn_on_load_stage<CT>(bn, c0, bn_tab);
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int i = threadIdx.x + 256 * q, row = i / (CT / 4), col4 = i - row * (CT / 4);
     const int n = n0 + row;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n < N) v = *reinterpret_cast<const f32x4*>(x + ((long long)n * HW + p) * ldx + c0 + col4 * 4);
+    if (n < N) {
+      v = *reinterpret_cast<const f32x4*>(x + ((long long)n * HW + p) * ldx + c0 + col4 * 4);
+      if constexpr (AFF) v = bn_on_load<CT>(bn_tab, v, col4 * 4);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] *= sc;
     *reinterpret_cast<f32x4*>(tile + row * PITCH + col4 * 4) = v;
@@ -663,6 +711,41 @@ extern "C" int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_
   else
     hipLaunchKernelGGL(wgrad_chwn_kernel, dim3((unsigned)(N32 / 32), (unsigned)((C + 31) / 32), (unsigned)(H * W)), dim3(256), 0, ST(stream), x,
                        out, (int)N, H * W, ldx, C, N32, scale, dlip_range_for(DLIP_ST_PACK), 0, 0, slice_major ? 1 : 0, nhwc_split_out);
+  return dlip_launch_status();
+}
+
+// (ABI 44) dlip_wgrad_operand_split_f32 / dlip_wgrad_chwn_f32 (with its split NHWC copy) of act(bn(x)) instead of x: BnOnLoad above.
+extern "C" int dlip_wgrad_operand_split_bn_f32(const float* x, float* out, int64_t ld_out, int64_t J, int32_t C, const float* mean,
+                                               const float* invstd, const float* gamma, const float* beta, const float* slope_vec,
+                                               float slope, float* nhwc_split_out, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && out && nhwc_split_out && mean && invstd && gamma && beta && J > 0 && J < (1ll << 28) && C > 0 && (C & 63) == 0 &&
+                 ld_out >= J && (ld_out & 31) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(nhwc_split_out)) & 127) == 0 &&
+                 (reinterpret_cast<uintptr_t>(x) & 15) == 0 && C / 64 <= 65535);
+  const BnOnLoad bn = {mean, invstd, gamma, beta, slope_vec, slope};
+  if (C % 128 == 0)
+    hipLaunchKernelGGL((wgrad_operand_wide_kernel<128, true>), dim3((unsigned)(ld_out / 32), (unsigned)(C / 128)), dim3(256), 0, ST(stream), x, out,
+                       1, 1, C, C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, nullptr, dlip_range_for(DLIP_ST_PACK), nhwc_split_out, bn);
+  else
+    hipLaunchKernelGGL((wgrad_operand_wide_kernel<64, true>), dim3((unsigned)(ld_out / 32), (unsigned)(C / 64)), dim3(256), 0, ST(stream), x, out,
+                       1, 1, C, C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, nullptr, dlip_range_for(DLIP_ST_PACK), nhwc_split_out, bn);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_wgrad_chwn_bn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t N32,
+                                      const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                      const float* slope_vec, float slope, float* nhwc_split_out, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && out && nhwc_split_out && mean && invstd && gamma && beta && N > 0 && H > 0 && W > 0 && C > 0 && (C & 63) == 0 &&
+                 N32 >= N && (N32 & 31) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(nhwc_split_out)) & 127) == 0 &&
+                 (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (long long)H * W <= 65535 && C / 64 <= 65535 && N < (1ll << 31));
+  const BnOnLoad bn = {mean, invstd, gamma, beta, slope_vec, slope};
+  if (C % 128 == 0)
+    hipLaunchKernelGGL((wgrad_chwn_wide_kernel<128, true>), dim3((unsigned)(N32 / 32), (unsigned)(C / 128), (unsigned)(H * W)), dim3(256), 0,
+                       ST(stream), x, out, (int)N, H * W, C, C, N32, nullptr, dlip_range_for(DLIP_ST_PACK), 1, nhwc_split_out, bn);
+  else
+    hipLaunchKernelGGL((wgrad_chwn_wide_kernel<64, true>), dim3((unsigned)(N32 / 32), (unsigned)(C / 64), (unsigned)(H * W)), dim3(256), 0,
+                       ST(stream), x, out, (int)N, H * W, C, C, N32, nullptr, dlip_range_for(DLIP_ST_PACK), 1, nhwc_split_out, bn);
   return dlip_launch_status();
 }
 

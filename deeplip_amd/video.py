@@ -142,8 +142,9 @@ def _basic_block_train(b: "BasicBlock", x, fork: bool = False):
             side.wait_stream(main)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             res = av.batchnorm(av.conv(xb, b.downsample[0].weight, None, stride=s), b.downsample[1])
-    h = av.batchnorm_prelu(av.conv(xa, b.conv1.weight, None, stride=s, pad=(1, 1)), b.bn1, b.relu1)
-    h = av.conv(h, b.conv2.weight, None, pad=(1, 1))
+    # bn1 + relu1's output is not stored: conv2's operand producer applies them on load to conv1's raw output
+    h, pend = av.batchnorm_prelu(av.conv(xa, b.conv1.weight, None, stride=s, pad=(1, 1)), b.bn1, b.relu1, defer=True)
+    h = av.conv(h, b.conv2.weight, None, pad=(1, 1), pending=pend)
     if side is not None:
         main.wait_stream(side)
     return av.batchnorm_add_prelu(h, b.bn2, res, b.relu2, fork=fork)      # bn2 + shortcut + relu2: one Function

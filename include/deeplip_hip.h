@@ -453,7 +453,10 @@ int32_t dlip_bn_rows_chunks(int32_t M);
  * act_first = 1: y = bn(lrelu(x))  (bn_first=False, tdnn.py:40-42,96-97,109-110).
  * Batch statistics: biased variance for the normalisation, unbiased for running_var (momentum update,
  * nullable pair), as nn.BatchNorm1d.  save_mean / save_invstd [C] feed the backward. */
-/* (ABI 44) num_batches_tracked (nullable): the module's int64 counter, incremented by the launch that finishes the statistics
+/* (ABI 44) y == NULL: statistics only (save_mean, save_invstd, running statistics, the counter) -- the consumer applies the
+ * normalisation and the activation on load (dlip_wgrad_operand_split_bn_f32 / dlip_wgrad_chwn_bn_f32) and the activated tensor is
+ * never stored.
+ * (ABI 44) num_batches_tracked (nullable): the module's int64 counter, incremented by the launch that finishes the statistics
  * (nn.BatchNorm*.forward under model.train(): `self.num_batches_tracked += 1` -- 44 one-element torch launches per lip-clip step).
  * Launch sequence since ABI 44: the finalize steps (partials -> mean / 1/std, -> dgamma / dbeta / dslope, -> the lift of dx) run in
  * the LAST workgroup of the pass before them (a ticket word of the stream's dlip_conv_set_workspace block, when the stream has one)
@@ -518,6 +521,10 @@ int dlip_bn_add_prelu_rows_train_bwd_f32(const float* dy, const float* dy2, cons
                                          const float* beta, const float* slope, const float* save_mean, const float* save_invstd,
                                          float* dresidual, float* dx, float* dgamma, float* dbeta, float* dslope, double* workspace,
                                          int32_t M, int32_t C, float* dx_lift2, dlip_stream_t stream);
+/* (ABI 44) The apply pass alone: y = act((x - mean) invstd gamma + beta) on [M,C] rows from statistics already formed (a deferred
+ * activation -- dlip_bn_rows_train_fwd_f32 with y == NULL -- whose consumer turns out to need the values after all). */
+int dlip_bn_apply_rows_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* slope_vec, float slope, float* y, int32_t M, int32_t C, dlip_stream_t stream);
 /* y[c] = sum_m x[m,c] (bias gradients), same chunked reduction and workspace. */
 int dlip_colsum_rows_f32(const float* x, float* y, double* workspace, int32_t M, int32_t C, dlip_stream_t stream);
 
@@ -619,6 +626,18 @@ int dlip_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int64_t N
  * more than 32 taps for this (split input, fp32 output, no residual).  train_video.py:129-147 (loss.backward()). */
 int dlip_wgrad_chwn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t N32,
                         const float* scale, int32_t slice_major, float* nhwc_split_out, dlip_stream_t stream);
+/* (ABI 44) The two producers above with a train-mode BatchNorm + (Leaky | P)ReLU applied ON LOAD: x is the RAW output z of the
+ * previous convolution and every loaded value becomes act((z - mean) invstd gamma + beta) (slope_vec [C] per-channel slopes, or NULL:
+ * the scalar `slope`) before it is split -- the convolution behind a conv -> BatchNorm -> activation (tdnn.py:35-43: the next
+ * TDNN_Block; resnet.py:51-57: conv2 behind bn1 + relu1) needs its input only as these images, so the activated tensor is never
+ * stored (one write and one read of an activation-sized tensor per layer).  Slice-major image layout; C % 64 == 0; the split NHWC
+ * copy is mandatory (it is the forward convolution's operand). */
+int dlip_wgrad_operand_split_bn_f32(const float* x, float* out, int64_t ld_out, int64_t J, int32_t C, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, const float* slope_vec, float slope,
+                                    float* nhwc_split_out, dlip_stream_t stream);
+int dlip_wgrad_chwn_bn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t N32, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, const float* slope_vec, float slope,
+                           float* nhwc_split_out, dlip_stream_t stream);
 /* nhwc_split_out (nullable; C % 32 == 0): the same tensor (scaled alike) ALSO in the convolution kernels' split activation format
  * [N,H,W,C] -- what dlip_split_pack_f32 / dlip_split_pack_scaled_f32 would write -- from the one read: the forward convolution's
  * operand together with the weight gradient's (x), the data gradient's together with the weight gradient's (dy). */

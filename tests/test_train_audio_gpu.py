@@ -104,6 +104,43 @@ def test_tdnn_block_train_fn_gradients(B, T, C, K, S, dil, act_first):
         assert float(bg.grad.abs().max()) < 1e-4 * float(dy.abs().sum() / K) + 1e-5
 
 
+@pytest.mark.parametrize("B,T,C,K1,K2,S2,dil2", [(9, 60, 64, 128, 64, 1, 1), (7, 70, 64, 512, 128, 3, 2), (5, 44, 32, 64, 96, 3, 1), (6, 50, 64, 100, 64, 1, 1)])
+def test_tdnn_blocks_with_the_activation_applied_on_load(B, T, C, K1, K2, S2, dil2):
+    """Round 5: a TDNN block's activated output is not stored when the next block can take it on load -- the next block's operand
+    producers read the raw convolution output and apply BatchNorm + LeakyReLU per loaded value (dlip_wgrad_*_bn_f32).  Two blocks in a
+    row, deferred against stored: outputs, every gradient and the running statistics bit for bit; a second block that cannot take the
+    values on load (K1 = 100: no multiple of 64) has them written first."""
+    from deeplip_amd import autograd as ag
+    x = rnd(B, T, C, seed=61)
+    w1 = rnd(K1, C, 3, seed=62, scale=1.0 / np.sqrt(C * 3)); b1 = rnd(K1, seed=63, scale=0.1)
+    w2 = rnd(K2, K1, S2, seed=64, scale=1.0 / np.sqrt(K1 * S2)); b2 = rnd(K2, seed=65, scale=0.1)
+    g1 = torch.rand(K1, generator=torch.Generator().manual_seed(66)) + 0.5; be1 = rnd(K1, seed=67, scale=0.2)
+    g2 = torch.rand(K2, generator=torch.Generator().manual_seed(68)) + 0.5; be2 = rnd(K2, seed=69, scale=0.2)
+    dy = rnd(B, T - 2 - dil2 * (S2 - 1), K2, seed=70)
+
+    def run(defer):
+        ts = [t.clone().to(DEV).requires_grad_() for t in (x, w1, b1, g1, be1, w2, b2, g2, be2)]
+        xg, a1, c1, d1, e1, a2, c2, d2, e2 = ts
+        rm1, rv1, rm2, rv2 = torch.zeros(K1, device=DEV), torch.ones(K1, device=DEV), torch.zeros(K2, device=DEV), torch.ones(K2, device=DEV)
+        n1 = torch.zeros((), dtype=torch.long, device=DEV)
+        out = ag.TDNNBlockTrainFn.apply(xg, a1, c1, d1, e1, rm1, rv1, 0.1, 1e-5, 0.2, 1, False, n1, defer, None)
+        pend = None
+        if defer:
+            h, z, mean, invstd = out
+            pend = (z, mean, invstd, d1.detach(), e1.detach(), 0.2)
+        else:
+            h = out
+        y = ag.TDNNBlockTrainFn.apply(h, a2, c2, d2, e2, rm2, rv2, 0.1, 1e-5, 0.2, dil2, False, None, False, pend)
+        y.backward(dy.to(DEV))
+        torch.cuda.synchronize()
+        return [y.detach().clone()] + [t.grad.clone() for t in ts] + [rm1, rv1, rm2, rv2, n1.float()]
+
+    a, b = run(True), run(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), i
+    assert float(a[-1]) == 1.0
+
+
 def load(module, prefix):
     shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
     sd = wg.fill_state_dict(shapes, prefix=prefix)

@@ -307,6 +307,38 @@ def test_block_tail_batchnorm_add_prelu_as_one_function(M, C):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-6 and rel_err(f.cpu().numpy(), a.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("N,HW,Cin,planes,stride", [(5, 8, 64, 64, 1), (4, 8, 64, 128, 2), (40, 3, 256, 512, 2)])
+def test_basic_block_with_bn1_relu1_applied_on_load(N, HW, Cin, planes, stride):
+    """Round 5: conv1 -> bn1 + relu1 -> conv2 under model.train(): relu1's output is not stored, conv2's operand producer applies the
+    normalisation and the slopes to conv1's raw output on load (dlip_wgrad_chwn_bn_f32).  A whole BasicBlock (with and without the
+    down-sampling shortcut), on load against stored: output, input gradient, every parameter gradient and the running statistics
+    bit for bit."""
+    from deeplip_amd import autograd_video as av, video
+    from deeplip_amd.video import BasicBlock, downsample_basic_block
+    x = rnd(N, HW, HW, Cin, seed=81)
+    Ho = (HW - 1) // stride + 1
+    dy = rnd(N, Ho, Ho, planes, seed=82) * 1e-2
+
+    def run(on_load):
+        torch.manual_seed(3)
+        ds = downsample_basic_block(Cin, planes, stride) if (stride != 1 or Cin != planes) else None
+        blk = BasicBlock(Cin, planes, stride, ds, relu_type="prelu").to(DEV).train()
+        prev, av.BN_ON_LOAD = av.BN_ON_LOAD, on_load
+        try:
+            xg = x.clone().to(DEV).requires_grad_()
+            y = video._basic_block_train(blk, xg)
+            y.backward(dy.to(DEV))
+            torch.cuda.synchronize()
+        finally:
+            av.BN_ON_LOAD = prev
+        return [y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in blk.parameters()] + [b.clone().float() for b in blk.buffers()]
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) > 8
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), i
+
+
 def test_prelu_maxpool_avgpool_timemean_dropout():
     from deeplip_amd import autograd_video as av
     # PReLU with per-channel slope
