@@ -898,6 +898,29 @@ class TimeMeanFn(Function):
         return dx, None
 
 
+class DropoutFn(Function):
+    """nn.Dropout (tcn.py:80,85) from the uniform draws u themselves: y = u >= p ? x / (1 - p) : 0 (dlip_dropout_keep_f32), the backward
+    the same launch on dy.  torch's generator makes the draws (graph-safe Philox offsets); the keep test, the cast and the product
+    were three more launches per dropout."""
+
+    @staticmethod
+    def forward(ctx, x, u, p):
+        x = x.contiguous()
+        ctx.save_for_backward(u)
+        ctx.p = float(p)
+        y = torch.empty_like(x)
+        check(lib().dlip_dropout_keep_f32(ptr(x), ptr(u), ptr(y), x.numel(), ctx.p, 1.0 / (1.0 - ctx.p), stream_handle()), "dlip_dropout_keep_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (u,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib().dlip_dropout_keep_f32(ptr(dy), ptr(u), ptr(dx), dy.numel(), ctx.p, 1.0 / (1.0 - ctx.p), stream_handle()), "dlip_dropout_keep_f32")
+        return dx, None, None
+
+
 class MulMaskFn(Function):
     """y = x * mask * scale: nn.Dropout with an explicit keep-mask (tcn.py:80,85) and, with mask = 1 and two
     calls, nothing else -- the add of the residual branches is torch's own tensor add."""
@@ -1085,12 +1108,15 @@ class ChompConcatFn(Function):
         lens = [z.shape[2] for z in zs]                       # T + pad_j
         Ct = sum(widths)
         out = torch.empty((B, T, Ct), device=zs[0].device, dtype=torch.float32)
+        ctx.cfg = (T, widths, lens)
+        if TCN_FEWER_LAUNCHES and len(zs) <= 4 and all((L - T) % 2 == 0 for L in lens):
+            _chomp_concat_launch(zs, lens, widths, out, B, T, 0)      # (round 5) every branch in one launch
+            return out
         off = 0
         for z, Cb, L in zip(zs, widths, lens):
             check(lib().dlip_tap_gather_f32(ptr(z), out.data_ptr() + 4 * off, B, 1, L, Cb, Cb, 1, T, 1, 1, 0, (L - T) // 2, Ct, stream_handle()),
                   "dlip_tap_gather_f32")
             off += Cb
-        ctx.cfg = (T, widths, lens)
         return out
 
     @staticmethod
@@ -1098,6 +1124,10 @@ class ChompConcatFn(Function):
         T, widths, lens = ctx.cfg
         dy = dy.contiguous()
         B, _, Ct = dy.shape
+        if TCN_FEWER_LAUNCHES and len(widths) <= 4 and all((L - T) % 2 == 0 for L in lens):
+            outs = [torch.empty((B, 1, L, Cb), device=dy.device, dtype=torch.float32) for Cb, L in zip(widths, lens)]
+            _chomp_concat_launch(outs, lens, widths, dy, B, T, 1)
+            return (None,) + tuple(outs)
         outs, off = [], 0
         for Cb, L in zip(widths, lens):
             g = torch.empty((B, 1, L, Cb), device=dy.device, dtype=torch.float32)
@@ -1108,6 +1138,19 @@ class ChompConcatFn(Function):
         return (None,) + tuple(outs)
 
 
+# (round 5) the MS-TCN stage's chomp + concatenation in one launch, its dropout in two (False: round 4's 3 + 4 launches; A/B runs)
+TCN_FEWER_LAUNCHES = __import__("os").environ.get("DLIP_TCN_FEWER_LAUNCHES", "1") != "0"
+
+
+def _chomp_concat_launch(branches, lens, widths, cat, B, T, backward):
+    import ctypes as C
+    n = len(branches)
+    pa = (C.c_void_p * n)(*[b.data_ptr() for b in branches])
+    la = (C.c_int32 * n)(*[int(v) for v in lens])
+    wa = (C.c_int32 * n)(*[int(v) for v in widths])
+    check(lib().dlip_chomp_concat_f32(pa, la, wa, n, ptr(cat), B, T, backward, stream_handle()), "dlip_chomp_concat_f32")
+
+
 def chomp_concat(zs, T):
     return ChompConcatFn.apply(T, *zs)
 
@@ -1115,8 +1158,10 @@ def chomp_concat(zs, T):
 def dropout(x, p: float, training: bool = True):
     if not training or p <= 0.0:
         return x
-    mask = (torch.rand(x.shape, device=x.device) >= p).float()   # torch's generator: the mask stream is build-owned
-    return MulMaskFn.apply(x, mask, 1.0 / (1.0 - p))
+    u = torch.rand(x.shape, device=x.device)                     # torch's generator: the mask stream is build-owned; kept iff u >= p
+    if not TCN_FEWER_LAUNCHES:
+        return MulMaskFn.apply(x, (u >= p).float(), 1.0 / (1.0 - p))
+    return DropoutFn.apply(x, u, p)
 
 
 def stem_conv(x_bthw, weight):

@@ -642,6 +642,49 @@ __global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * mask[i] * scale;
 }
 
+// nn.Dropout with the keep test in the kernel: y = u >= p ? x * scale : 0 from the uniform draws u themselves (was: a compare, a
+// cast and the multiplication as three launches behind the generator's; u is what the backward keeps).
+__global__ __launch_bounds__(256) void dropout_keep_kernel(const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ y,
+                                                           float p, float scale, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = u[i] >= p ? x[i] * scale : 0.f;
+}
+
+// The end of a multibranch TCN stage in ONE launch (was one strided row copy per branch): out[b, t, off_j + c] = z_j[b, t + (L_j - T) / 2, c]
+// -- the symmetric chomp (tcn.py:52-59) and the concatenation along channels (tcn.py:96-108) of up to four branches [B, L_j, C_j].
+// BWD: the reverse -- g_j[b, l, c] = dy[b, l - (L_j - T) / 2, off_j + c] inside the kept rows, 0 in the chomped ones.
+struct ChompCat {
+  float* z[4];            // branch tensors (forward: sources; backward: destinations)
+  int L[4], C4[4], off4[4];
+  long long start[5];     // prefix sums of the branches' float4 counts (forward: B T C4_j; backward: B L_j C4_j)
+  int nb, T, Ct4;
+};
+template <bool BWD>
+__global__ __launch_bounds__(256) void chomp_concat_kernel(const ChompCat cc, float* __restrict__ cat) {
+  const long long n4 = cc.start[cc.nb];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) j += (q < cc.nb && i >= cc.start[q]) ? 1 : 0;
+    const long long k = i - cc.start[j];
+    const int C4 = cc.C4[j], L = cc.L[j], sh = (L - cc.T) / 2;
+    const int c4 = (int)(k % C4);
+    const long long row = k / C4;
+    if (!BWD) {
+      const int t = (int)(row % cc.T);
+      const long long b = row / cc.T;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(cc.z[j] + ((b * L + t + sh) * C4 + c4) * 4);
+      *reinterpret_cast<f32x4*>(cat + ((b * cc.T + t) * cc.Ct4 + cc.off4[j] + c4) * 4) = v;
+    } else {
+      const int l = (int)(row % L);
+      const long long b = row / L;
+      const int t = l - sh;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)t < (unsigned)cc.T) v = *reinterpret_cast<const f32x4*>(cat + ((b * cc.T + t) * cc.Ct4 + cc.off4[j] + c4) * 4);
+      *reinterpret_cast<f32x4*>(cc.z[j] + ((b * L + l) * C4 + c4) * 4) = v;
+    }
+  }
+}
+
 }  // namespace
 
 #define ST(s) static_cast<hipStream_t>(s)
@@ -862,6 +905,37 @@ extern "C" int dlip_stem_wgrad_operand_f32(const float* x, float* out, int64_t l
 extern "C" int dlip_split_stem_weights_f32(const float* w, float* w_img, float* w_scale, int32_t K, dlip_stream_t stream) {
   DLIP_CHECK_ARG(w && w_img && w_scale && K > 0);
   hipLaunchKernelGGL(split_stem_weights_kernel, dim3((unsigned)K), dim3(64), 0, ST(stream), w, w_img, w_scale);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_dropout_keep_f32(const float* x, const float* u, float* y, int64_t n, float p, float scale, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && u && y && n > 0 && p >= 0.f && p < 1.f);
+  hipLaunchKernelGGL(dropout_keep_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, u, y, p, scale, (long long)n);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_chomp_concat_f32(const float* const* branches, const int32_t* lengths, const int32_t* widths, int32_t n_branches,
+                                     float* cat, int32_t B, int32_t T, int32_t backward, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(branches && lengths && widths && cat && n_branches >= 1 && n_branches <= 4 && B > 0 && T > 0);
+  ChompCat cc;
+  cc.nb = n_branches; cc.T = T;
+  int off = 0;
+  cc.start[0] = 0;
+  for (int j = 0; j < 4; ++j) {
+    if (j < n_branches) {
+      DLIP_CHECK_ARG(branches[j] && widths[j] > 0 && (widths[j] & 3) == 0 && lengths[j] >= T && ((lengths[j] - T) & 1) == 0 &&
+                     (reinterpret_cast<uintptr_t>(branches[j]) & 15) == 0);
+      cc.z[j] = const_cast<float*>(branches[j]); cc.L[j] = lengths[j]; cc.C4[j] = widths[j] / 4; cc.off4[j] = off / 4;
+      off += widths[j];
+      cc.start[j + 1] = cc.start[j] + (long long)B * (backward ? lengths[j] : T) * cc.C4[j];
+    } else {
+      cc.z[j] = nullptr; cc.L[j] = T; cc.C4[j] = 1; cc.off4[j] = 0; cc.start[j + 1] = cc.start[j];
+    }
+  }
+  cc.Ct4 = off / 4;
+  DLIP_CHECK_ARG((reinterpret_cast<uintptr_t>(cat) & 15) == 0);
+  if (backward) hipLaunchKernelGGL(chomp_concat_kernel<true>, dim3(grid_for(cc.start[n_branches])), dim3(256), 0, ST(stream), cc, cat);
+  else hipLaunchKernelGGL(chomp_concat_kernel<false>, dim3(grid_for(cc.start[n_branches])), dim3(256), 0, ST(stream), cc, cat);
   return dlip_launch_status();
 }
 

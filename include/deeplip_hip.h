@@ -702,6 +702,15 @@ int dlip_stem_wgrad_operand_f32(const float* x, float* out, int64_t ld_out, int3
  * dlip_stem3d_pool_f16x3 (K x 1184 B) and its per-channel power-of-two scale [K], on the device: what a training step needs
  * every iteration (the extraction path packs once on the host). */
 int dlip_split_stem_weights_f32(const float* w, float* w_img, float* w_scale, int32_t K, dlip_stream_t stream);
+/* (ABI 44) nn.Dropout (tcn.py:80,85) with the keep test in the kernel: y = u >= p ? x * scale : 0, u = the uniform draws (the
+ * backward applies the same launch to dy with the kept u).  Replaces compare + cast + dlip_mul_mask_f32 behind the generator. */
+int dlip_dropout_keep_f32(const float* x, const float* u, float* y, int64_t n, float p, float scale, dlip_stream_t stream);
+/* (ABI 44) The end of a multibranch TCN stage in one launch: symmetric chomp (tcn.py:52-59) + concatenation along channels
+ * (tcn.py:96-108) of n_branches <= 4 tensors z_j [B, lengths[j], widths[j]] (HOST arrays of pointers / sizes; lengths[j] - T even,
+ * widths multiples of 4): cat[b, t, off_j + c] = z_j[b, t + (lengths[j] - T) / 2, c].  backward != 0: the reverse -- `branches` are
+ * written from cat (= the gradient of the concatenation), zeros in the chomped rows. */
+int dlip_chomp_concat_f32(const float* const* branches, const int32_t* lengths, const int32_t* widths, int32_t n_branches, float* cat,
+                          int32_t B, int32_t T, int32_t backward, dlip_stream_t stream);
 /* y = x * mask * scale (nn.Dropout forward / backward, tcn.py:80,85). */
 int dlip_mul_mask_f32(const float* x, const float* mask, float* y, int64_t n, float scale, dlip_stream_t stream);
 
