@@ -66,6 +66,7 @@ SIGNATURES = {
     "dlip_bn_apply_rows_f32": [c_f, c_f, c_f, c_f, c_f, c_f, C.c_float, c_f, c_i32, c_i32, c_stream],
     "dlip_dropout_keep_f32": [c_f, c_f, c_f, c_i64, C.c_float, C.c_float, c_stream],
     "dlip_chomp_concat_f32": [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_i32, c_f, c_i32, c_i32, c_i32, c_stream],
+    "dlip_upsample_zero_split_f32": [c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_bn_prelu_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_f, c_stream],
     "dlip_colsum_rows_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_meanstd_pool_bwd_f32": [c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_stream],

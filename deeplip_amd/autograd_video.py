@@ -481,6 +481,25 @@ def wgrad_conv(x, dy, R, S, stride, pad, dil, scale2=None):
     return _permute3(dwt, (2, 1, 0)).view(dy.shape[3], x.shape[3], R, S)
 
 
+def _upsample_zero(dy, Hu, Wu, sh, sw, lift, Ci=4):
+    """Zero insertion of a strided layer's output gradient dy [N,Ho,Wo,K] -> [N,Hu,Wu,K] for its data-gradient convolution.  Returns
+    (tensor, split): with the split-fp16 arithmetic and K % 32 == 0 the lifted split operand is written directly (round 5:
+    dlip_upsample_zero_split_f32) and the fp32 tensor is an UNWRITTEN placeholder that only carries the shape; otherwise the fp32 tensor
+    and None."""
+    N, Ho, Wo, K = dy.shape
+    src = torch.empty((N, Hu, Wu, K), device=dy.device, dtype=torch.float32)
+    if TRAIN_CONV == "f16x3" and K % 32 == 0 and Ci % 4 == 0 and lift is not None and UPSAMPLE_SPLIT_FUSED:   # (conv_train's split-kernel conditions)
+        xs = torch.empty_like(src)
+        check(lib().dlip_upsample_zero_split_f32(ptr(dy), ptr(xs), ptr(lift), N, Ho, Wo, Hu, Wu, K, sh, sw, stream_handle()),
+              "dlip_upsample_zero_split_f32")
+        return src, xs
+    check(lib().dlip_upsample_zero_f32(ptr(dy), ptr(src), N, Ho, Wo, Hu, Wu, K, sh, sw, stream_handle()), "dlip_upsample_zero_f32")
+    return src, None
+
+
+UPSAMPLE_SPLIT_FUSED = __import__("os").environ.get("DLIP_UPSAMPLE_SPLIT", "1") != "0"
+
+
 class ConvTrainFn(Function):
     """nn.Conv2d / nn.Conv1d (H = 1) on NHWC activations, raw (unfolded) weights in the reference layout
     [K,C,R,S]: forward = the fp32 implicit-GEMM kernel; backward = bias column sum, DATA gradient = the same
@@ -538,22 +557,17 @@ class ConvTrainFn(Function):
             if want_x:
                 src = dy
                 if not dense:
-                    Hu, Wu = H + 2 * ph - dh * (R - 1), W + 2 * pw - dw * (S - 1)
-                    src = torch.empty((N, Hu, Wu, K), device=dev, dtype=torch.float32)
-                    check(lib().dlip_upsample_zero_f32(ptr(dy), ptr(src), N, Ho, Wo, Hu, Wu, K, sh, sw, stream_handle()), "dlip_upsample_zero_f32")
+                    src, dys = _upsample_zero(dy, H + 2 * ph - dh * (R - 1), W + 2 * pw - dw * (S - 1), sh, sw, lift, weight.shape[1])
                 dx = conv_train(src, None, None, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), lift=True, scale2=lift,
                                 w_ref=weight, transposed=True, xs_ready=dys)
             dweight = wgrad_as_conv(None, None, R, S, (sh, sw), (ph, pw), (dh, dw), scale2=lift, xT=x, gT=gT) if want_w else None
             return dx, dweight, dbias, None, None, None, None
         if ctx.needs_input_grad[0]:
-            src = dy
+            src, dys = dy, None
             if sh != 1 or sw != 1:
-                Hu, Wu = H + 2 * ph - dh * (R - 1), W + 2 * pw - dw * (S - 1)
-                src = torch.empty((N, Hu, Wu, K), device=dev, dtype=torch.float32)
-                check(lib().dlip_upsample_zero_f32(ptr(dy), ptr(src), N, Ho, Wo, Hu, Wu, K, sh, sw, stream_handle()),
-                      "dlip_upsample_zero_f32")
+                src, dys = _upsample_zero(dy, H + 2 * ph - dh * (R - 1), W + 2 * pw - dw * (S - 1), sh, sw, lift, weight.shape[1])
             dx = conv_train(src, None, None, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), lift=True, scale2=lift,
-                            w_ref=weight, transposed=True)
+                            w_ref=weight, transposed=True, xs_ready=dys)
         dweight = None
         if ctx.needs_input_grad[1]:
             # all taps side by side in ONE [J, RS*C] matrix -> one GEMM with RS*C output rows (RS times the

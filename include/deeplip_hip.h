@@ -665,6 +665,10 @@ int dlip_stem_wgrad_chwn_f32(const float* x, float* out, int32_t B, int32_t T, i
  * gradient of a strided convolution as a stride-1 convolution (resnet.py:9-16 with stride 2). */
 int dlip_upsample_zero_f32(const float* dz, float* out, int64_t N, int32_t Ho, int32_t Wo, int32_t Hu, int32_t Wu,
                            int32_t C, int32_t stride_h, int32_t stride_w, dlip_stream_t stream);
+/* (ABI 44) The same zero insertion written straight as the lifted split operand of the data-gradient convolution: out_split =
+ * dlip_split_pack_scaled_f32(dlip_upsample_zero_f32(dz), scale) without the fp32 tensor in between (C % 32 == 0). */
+int dlip_upsample_zero_split_f32(const float* dz, float* out_split, const float* scale, int64_t N, int32_t Ho, int32_t Wo, int32_t Hu,
+                                 int32_t Wu, int32_t C, int32_t stride_h, int32_t stride_w, dlip_stream_t stream);
 /* nn.PReLU(C) on rows [M,C] (resnet.py:52,66; model.py:84; tcn.py:47,105): y = x >= 0 ? x : slope[c] * x. */
 int dlip_prelu_rows_fwd_f32(const float* x, const float* slope, float* y, int64_t M, int32_t C, dlip_stream_t stream);
 /* Backward: dx, and dslope_terms [M,C] = (x < 0 ? dy * x : 0) whose column sums (dlip_colsum_rows_f32) are
