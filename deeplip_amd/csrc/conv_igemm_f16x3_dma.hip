@@ -1140,7 +1140,9 @@ static int dma_pick(long long M, int K, int nk, int epi) {
   // rows, 512 | 768 -> 256 channels, 48-168 slices -- are a handful of row tiles split many ways: on 64-row tiles there are twice as
   // many tiles to split and half as many parts per tile for the finisher to add (tools/bench_tcn.py, same box: 41.8 -> 27.9 us,
   // 45.9 -> 32.7, 60.7 -> 45.6 against 128 x 128; 128 x 64 and 256 x 128 in between)
-  if (M <= 2048 && nk >= 16 && nk < 256) return K <= 64 ? 3 : 2;
+  // (round 5) ... and up to 3 072 rows: the head's k = 7, dilation 8 branch is 32 x (29 + 48) = 2 464 rows x 168 slices and had fallen
+  // to 128 x 128: 64.7 us against 44.6 on 64 x 128 (tools/bench_tcn.py, same box) -- the longest branch of its stage, four launches a step
+  if (M <= 3072 && nk >= 16 && nk < 256) return K <= 64 ? 3 : 2;
   if (K <= 64) return 1;
   if (nk <= 8) return 4;
   if (nk >= 32 && M >= 8192) return 5;
