@@ -79,7 +79,7 @@ SIGNATURES = {
     "dlip_split_weights_perm_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_fill_from_scalar_f32": [c_f, c_f, c_i32, c_stream],
     "dlip_aam_margin_f32": [c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_i32, c_stream],
-    "dlip_split_weights_multi_f32": [c_f, c_f, c_i32, c_stream],
+    "dlip_split_weights_multi_f32": [c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_wgrad_operand_split_f32": [c_f, c_f, c_i64, c_i64, c_i32, c_f, c_f, c_stream],
     "dlip_wgrad_operand_f32": [c_f, c_f, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_stream],
     "dlip_stem_wgrad_chwn_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],

@@ -183,7 +183,8 @@ class _WeightPrep:
         blocks = np.concatenate(blocks)
         d_dev = torch.from_numpy(descs.view(np.uint8).copy()).to(device)
         b_dev = torch.from_numpy(blocks).to(device)
-        self.table, self.table_len = (d_dev, b_dev, int(blocks.size)), len(self.order)
+        max_row = max(self.entries[k]["T"] * self.entries[k]["Cw"] for k in self.order)    # floats of the longest output row
+        self.table, self.table_len = (d_dev, b_dev, int(blocks.size), int(max_row)), len(self.order)
 
     def prepare(self):
         if not self.order:
@@ -218,13 +219,13 @@ class _WeightPrep:
                 self.stats["skipped"] += 1
                 return                                   # (no host-to-device copy inside a capture: this step splits per convolution)
             self._build(self.entries[self.order[0]]["ws"].device)
-        d_dev, b_dev, n = self.table
+        d_dev, b_dev, n, max_row = self.table
         cur = torch.cuda.current_stream()
         if self.side is None:
             self.side = torch.cuda.Stream(device=d_dev.device)
         self.side.wait_stream(cur)                       # the previous step's last readers of the images are behind us
         with torch.cuda.stream(self.side):
-            check(lib().dlip_split_weights_multi_f32(ptr(d_dev), ptr(b_dev), n, stream_handle()), "dlip_split_weights_multi_f32")
+            check(lib().dlip_split_weights_multi_f32(ptr(d_dev), ptr(b_dev), n, max_row, stream_handle()), "dlip_split_weights_multi_f32")
             self.event = torch.cuda.Event()
             self.event.record(self.side)
         self.joined = set()

@@ -1086,15 +1086,21 @@ struct WSplitDesc {
   int32_t K, C, T, Cp, mode, row0;
 };
 
-__global__ __launch_bounds__(256) void split_weights_multi_kernel(const WSplitDesc* __restrict__ descs, const int32_t* __restrict__ blk2desc) {
+// (round 5) The launch held the chip for 340 us of an 15.3 ms lip-clip step -- 38 k workgroups of one row each, four per CU (a
+// static 32 KB staging buffer), every element written by two 2-byte stores.  Now: the staging buffer is dynamic LDS sized to the
+// launch's longest row (stage_floats; rows beyond it take the unstaged path as before), the row maximum is taken from 16-byte LDS
+// reads, and a thread writes eight consecutive values as one 16-byte piece of hi halves and one of lo halves.  Same value per
+// element, same scale per row: same bits.
+__global__ __launch_bounds__(256) void split_weights_multi_kernel(const WSplitDesc* __restrict__ descs, const int32_t* __restrict__ blk2desc,
+                                                                  int stage_floats) {
   __shared__ float red[4];
-  __shared__ float stage[8192];
+  extern __shared__ __attribute__((aligned(16))) float stage[];
   const WSplitDesc d = descs[blk2desc[blockIdx.x]];
   const int row = (int)blockIdx.x - d.row0;
   const int K = d.K, C = d.C, T = d.T, mode = d.mode;
   const int inner = d.Cp, real = mode == 0 ? C : K;
-  const int L = T * inner;
-  const bool staged = L <= 8192;
+  const int L = T * inner;                          // a multiple of 32 (Cp is)
+  const bool staged = L <= stage_floats;
   const float* __restrict__ w = d.w;
   if (staged) {
     if (inner != real) {
@@ -1115,7 +1121,14 @@ __global__ __launch_bounds__(256) void split_weights_multi_kernel(const WSplitDe
     return mode == 0 ? w[((long long)row * C + j) * T + t] : w[((long long)j * C + row) * T + (T - 1 - t)];
   };
   float m = 0.f;
-  for (int i = threadIdx.x; i < L; i += 256) m = fmaxf(m, fabsf(src(i)));
+  if (staged) {
+    for (int i = threadIdx.x; i < L / 4; i += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+  } else {
+    for (int i = threadIdx.x; i < L; i += 256) m = fmaxf(m, fabsf(src(i)));
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -1124,13 +1137,24 @@ __global__ __launch_bounds__(256) void split_weights_multi_kernel(const WSplitDe
   float sc = 1.f;
   if (m > 0.f && m < 3.0e38f) sc = exp2f(floorf(log2f(1023.0f / m)));
   if (threadIdx.x == 0) d.scale[row] = sc;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   _Float16* out = reinterpret_cast<_Float16*>(d.ws + (long long)row * L);
-  for (int i = threadIdx.x; i < L; i += 256) {
-    const float t = src(i) * sc;
-    const _Float16 hi = (_Float16)t, lo = (_Float16)(t - (float)hi);
-    const int b = i >> 5, q = i & 31;
-    out[b * 64 + q] = hi;
-    out[b * 64 + 32 + q] = lo;
+  for (int i8 = threadIdx.x; i8 < L / 8; i8 += 256) {       // eight consecutive values: a quarter of a 32-value block
+    float v[8];
+    if (staged) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(stage + 8 * i8), a1 = *reinterpret_cast<const f32x4*>(stage + 8 * i8 + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] = a0[k]; v[4 + k] = a1[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = src(8 * i8 + k);
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float t = v[k] * sc; hi[k] = (_Float16)t; lo[k] = (_Float16)(t - (float)hi[k]); }
+    const int blk = i8 >> 2, q = (i8 & 3) * 8;
+    *reinterpret_cast<h8*>(out + blk * 64 + q) = hi;
+    *reinterpret_cast<h8*>(out + blk * 64 + 32 + q) = lo;
   }
 }
 
@@ -1563,10 +1587,14 @@ extern "C" int dlip_split_weights_perm_f32(const float* w_kct, float* w_split, f
 }
 
 static_assert(sizeof(WSplitDesc) == 48, "include/deeplip_hip.h: struct dlip_wsplit_desc");
-extern "C" int dlip_split_weights_multi_f32(const void* descs, const int32_t* block_desc, int32_t n_blocks, dlip_stream_t stream) {
-  DLIP_CHECK_ARG(descs && block_desc && n_blocks > 0 && (reinterpret_cast<uintptr_t>(descs) & 7) == 0);
-  hipLaunchKernelGGL(split_weights_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const WSplitDesc*>(descs), block_desc);
+extern "C" int dlip_split_weights_multi_f32(const void* descs, const int32_t* block_desc, int32_t n_blocks, int32_t max_row_floats,
+                                            dlip_stream_t stream) {
+  DLIP_CHECK_ARG(descs && block_desc && n_blocks > 0 && (reinterpret_cast<uintptr_t>(descs) & 7) == 0 && max_row_floats >= 0);
+  // the staging buffer: the launch's longest row (T * C_pad floats), at most 32 KB (longer rows are read from memory twice); dynamic
+  // LDS, so that a launch of short rows keeps more workgroups on a CU
+  int stage_floats = max_row_floats <= 0 || max_row_floats > 8192 ? 8192 : (max_row_floats + 31) / 32 * 32;
+  hipLaunchKernelGGL(split_weights_multi_kernel, dim3((unsigned)n_blocks), dim3(256), (size_t)stage_floats * 4, static_cast<hipStream_t>(stream),
+                     static_cast<const WSplitDesc*>(descs), block_desc, stage_floats);
   return dlip_launch_status();
 }
 

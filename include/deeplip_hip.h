@@ -573,7 +573,10 @@ typedef struct dlip_wsplit_desc {
   float* w_scale;       /* one per output row */
   int32_t K, C, T, C_pad, mode, row0;
 } dlip_wsplit_desc;
-int dlip_split_weights_multi_f32(const void* descs, const int32_t* block_desc, int32_t n_blocks, dlip_stream_t stream);
+/* (ABI 44) max_row_floats: the longest output row of the launch, T * C_pad floats (0: unknown) -- sizes the kernel's staging buffer
+ * (dynamic LDS), so that a launch of short rows keeps more workgroups on a CU. */
+int dlip_split_weights_multi_f32(const void* descs, const int32_t* block_desc, int32_t n_blocks, int32_t max_row_floats,
+                                 dlip_stream_t stream);
 /* y[0:n] = src[0] (device scalar broadcast: the per-channel 1/scale vector of the weight-gradient GEMM). */
 int dlip_fill_from_scalar_f32(const float* src, float* y, int32_t n, dlip_stream_t stream);
 
