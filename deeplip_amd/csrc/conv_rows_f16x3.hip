@@ -341,6 +341,29 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
   const bool has_slope0 = a.slope != nullptr;
   const bool has_post0 = a.pscale != nullptr;
   float amax = 0.f;
+  // (round 5) MODE 0, fp32 / split output: the epilogue's per-channel parameters {1 / wscale, bias, slope} of this workgroup's column
+  // block, 3 KB of LDS behind the ring, written once.  A workgroup's tiles g, g + G, ... share their column block whenever the column
+  // blocks divide G (K = 512: two blocks on 256 workgroups), and the epilogue took them from memory per tile: two dependent L2 round
+  // trips (~2.4 k cycles) at the head of the interval in which its SIMD partner multiplies for 1.1 k -- in-kernel stamps at B = 256:
+  // 16 x 2 632 cycles of slices per k = 1 tile, but 60.6 k per tile, the difference being the two halves' epilogues each stalling the
+  // other.  A tile of another column block (tab_n differs) takes the parameters from memory as before.
+  constexpr bool TAB = MODE == 0 && EPI != 2;
+  float* const ptab = smem + NSTAGE * (STAGE_B / 4);
+  [[maybe_unused]] int tab_n = -1;
+  if constexpr (TAB) {
+    tab_n = __builtin_amdgcn_readfirstlane(item0 - (item0 / sc.tiles_n) * sc.tiles_n);
+    if (tid < BN) {
+      const int k = tab_n * BN + tid;
+      float iv = 0.f, bv = 0.f, sv = 1.f;
+      if (k < a.K) {
+        iv = 1.f / a.wscale[k];                       // power of two: exact
+        if (a.bias) bv = a.bias[k];
+        if (a.slope) sv = a.slope[k];
+      }
+      ptab[tid] = iv; ptab[BN + tid] = bv; ptab[2 * BN + tid] = sv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // landed before this wave reaches the first barrier of the loop
+    }
+  }
   auto epilogue_p = [&](int item, auto post_c) __attribute__((always_inline)) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     constexpr bool post = decltype(post_c)::value;   // (compile-time inside: the runtime flag selected and computed both forms per value)
@@ -395,17 +418,30 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
           }
         }
         float inv[8], bi[8], sl[8], ps[8], pt[8];
+        bool from_tab = false;
+        if constexpr (TAB && !post) from_tab = tile_n == tab_n;      // (wave-uniform)
+        if (from_tab) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const f32x4 s4 = dlip_buffer_load_f4(scr, (uint32_t)(k0 + 4 * q) * 4u);
-          const f32x4 b4 = dlip_buffer_load_f4(bir, (uint32_t)(k0 + 4 * q) * 4u);
-          f32x4 l4 = {1.f, 1.f, 1.f, 1.f}, p4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
-          if (has_slope) l4 = dlip_buffer_load_f4(slr, (uint32_t)(k0 + 4 * q) * 4u);
-          if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)(k0 + 4 * q) * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)(k0 + 4 * q) * 4u); }
+          for (int q = 0; q < 2; ++q) {
+            const float* tp = ptab + wn * 64 + 32 * p + cs + 4 * q;
+            const f32x4 i4 = *reinterpret_cast<const f32x4*>(tp), b4 = *reinterpret_cast<const f32x4*>(tp + BN);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(tp + 2 * BN);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            inv[4 * q + c] = k0 + 4 * q + c < eK ? 1.f / s4[c] : 0.f;   // power of two: exact
-            bi[4 * q + c] = b4[c]; sl[4 * q + c] = l4[c]; ps[4 * q + c] = p4[c]; pt[4 * q + c] = t4[c];
+            for (int c = 0; c < 4; ++c) { inv[4 * q + c] = i4[c]; bi[4 * q + c] = b4[c]; sl[4 * q + c] = l4[c]; ps[4 * q + c] = 1.f; pt[4 * q + c] = 0.f; }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x4 s4 = dlip_buffer_load_f4(scr, (uint32_t)(k0 + 4 * q) * 4u);
+            const f32x4 b4 = dlip_buffer_load_f4(bir, (uint32_t)(k0 + 4 * q) * 4u);
+            f32x4 l4 = {1.f, 1.f, 1.f, 1.f}, p4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+            if (has_slope) l4 = dlip_buffer_load_f4(slr, (uint32_t)(k0 + 4 * q) * 4u);
+            if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)(k0 + 4 * q) * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)(k0 + 4 * q) * 4u); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              inv[4 * q + c] = k0 + 4 * q + c < eK ? 1.f / s4[c] : 0.f;   // power of two: exact
+              bi[4 * q + c] = b4[c]; sl[4 * q + c] = l4[c]; ps[4 * q + c] = p4[c]; pt[4 * q + c] = t4[c];
+            }
           }
         }
 #pragma unroll
@@ -508,14 +544,20 @@ __global__ __launch_bounds__(512, 2) void conv_rows_f16x3_kernel(const ConvArgs 
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int k0 = col0 + 16 * ni + 4 * hq;
-        const f32x4 s4 = dlip_buffer_load_f4(scr, (uint32_t)k0 * 4u);
-        const f32x4 b4 = dlip_buffer_load_f4(bir, (uint32_t)k0 * 4u);
-        f32x4 l4 = {1.f, 1.f, 1.f, 1.f}, p4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
-        if (has_slope) l4 = dlip_buffer_load_f4(slr, (uint32_t)k0 * 4u);
-        if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)k0 * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)k0 * 4u); }
-        f32x4 inv4;
+        f32x4 b4, inv4, l4 = {1.f, 1.f, 1.f, 1.f}, p4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+        bool from_tab = false;
+        if constexpr (TAB && !post) from_tab = tile_n == tab_n;      // (wave-uniform: the parameter table in LDS, see ptab)
+        if (from_tab) {
+          const float* tp = ptab + wn * 64 + 16 * ni + 4 * hq;
+          inv4 = *reinterpret_cast<const f32x4*>(tp); b4 = *reinterpret_cast<const f32x4*>(tp + BN); l4 = *reinterpret_cast<const f32x4*>(tp + 2 * BN);
+        } else {
+          const f32x4 s4 = dlip_buffer_load_f4(scr, (uint32_t)k0 * 4u);
+          b4 = dlip_buffer_load_f4(bir, (uint32_t)k0 * 4u);
+          if (has_slope) l4 = dlip_buffer_load_f4(slr, (uint32_t)k0 * 4u);
+          if (post) { p4 = dlip_buffer_load_f4(psr, (uint32_t)k0 * 4u); t4 = dlip_buffer_load_f4(ptr_, (uint32_t)k0 * 4u); }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) inv4[c] = k0 + c < eK ? 1.f / s4[c] : 0.f;
+          for (int c = 0; c < 4; ++c) inv4[c] = k0 + c < eK ? 1.f / s4[c] : 0.f;
+        }
         // (MODE 0, a.stats: launch-uniform) column sums of what this wave writes -- the batch statistics of the BatchNorm behind a
         // TDNN convolution under model.train() (tdnn.py:35-43) -- taken here instead of by a pass over y: a lane adds its MI pixels
         // (fp32: 5 values), the 16 lanes of a channel quad meet by four DPP row steps (fp32, a fixed tree: deterministic), lane 0 of
@@ -804,7 +846,7 @@ RowsTail rows_tail(long long M, int tiles_n, int mi, int slots) {
 template <int MI, int EPI, int MODE = 0, bool DUAL = false, bool TAIL = false>
 int launch_rows(const ConvArgs& a, hipStream_t st) {
   constexpr int BM = 32 * MI;
-  constexpr size_t lds = (size_t)3 * (BM + ROWS_BN) * ROWB;
+  constexpr size_t lds = (size_t)3 * (BM + ROWS_BN) * ROWB + (MODE == 0 && EPI != 2 ? 3 * ROWS_BN * sizeof(float) : 0);   // ring + the epilogue's parameter table
   static_assert(lds <= 160 * 1024, "LDS ring exceeds a CU");
   ConvArgs b = a;
   b.tiles_n = (a.K + ROWS_BN - 1) / ROWS_BN;
