@@ -1,6 +1,7 @@
 """Model-level parity (-m gpu): the drop-in ``models.*`` modules running on the HIP engine against
 (a) the committed golden vectors captured from the reference classes and (b) the CPU oracle on the
-same seeded inputs, up to the BASELINE.json parity sizes ([32,1,29,88,88] clips, [32,80,300] mels).
+same seeded inputs, at the BASELINE.json parity sizes ([32,1,29,88,88] clips, [32,80,300] mels) and at the FULL sizes of configs[1] /
+configs[2] ([64,1,29,88,88], [256,1,80,300]: every row against the oracle, ~10 s of host time, shared by both arithmetic modes).
 
 Tolerances (BASELINE.json north_star): embeddings / features / trial scores within 1e-4 relative
 (measured as max|a-b| / max|b| per tensor; scores: absolute, they live in [-1,1]); speaker-label
@@ -186,7 +187,7 @@ def test_audio_parity_size_b32_f80_vs_oracle():
 
 def test_full_size_configs_batch_invariance_and_fusion_properties(video_net):
     """BASELINE.json full sizes -- configs[1] video [64,1,29,88,88], configs[2] audio [256,1,80,300] -- through
-    size-independent properties (the oracle would need minutes here): a clip / an utterance embeds to the same
+    size-independent properties (beside the direct comparison of test_full_size_configs_against_the_oracle below): a clip / an utterance embeds to the same
     vector inside the full batch and inside a batch of 4 (bit-exact in f32 mode, 1e-6 in f16x3: the balanced work
     split moves the summation tree with the batch), duplicated inputs give the same rows, the fused [64,1024]
     rows are z-normalised per modality, and a trial of a row with itself scores exactly 1."""
@@ -222,6 +223,46 @@ def test_full_size_configs_batch_invariance_and_fusion_properties(video_net):
     assert float((s_self - 1).abs().max()) < 1e-6
     s_dup = scoring.cosine_scores(fused, torch.tensor([5], dtype=torch.int32, device=DEV), torch.tensor([63], dtype=torch.int32, device=DEV))
     assert abs(float(s_dup.cpu()[0]) - 1.0) < 1e-6
+
+
+_FULL_REF = {}
+
+
+def _full_size_reference(sd_video, sd_audio):
+    """The oracle on BASELINE.json's FULL configurations -- 64 clips [64,1,29,88,88] and 256 utterances [256,1,80,300] -- computed once
+    per test process (about a minute of the box's host cores) and shared by both arithmetic modes."""
+    if not _FULL_REF:
+        xv = torch.from_numpy(wg.video_input(64, speakers=np.arange(64) % 16, key="full.video"))
+        xa = torch.from_numpy(wg.audio_input(256, 80, 300, speakers=np.arange(256) % 16, key="full.audio"))
+        with torch.no_grad():
+            _FULL_REF["video"] = torch.cat([O.video_time_mean(O.lipreading_features(sd_video, xv[i:i + 8])) for i in range(0, 64, 8)])
+            _FULL_REF["audio"] = torch.cat([O.speaker_extract_embedding(sd_audio, xa[i:i + 32], O.ETDNN_CONTEXT)[0] for i in range(0, 256, 32)])
+        _FULL_REF["xv"], _FULL_REF["xa"] = xv, xa
+    return _FULL_REF
+
+
+def test_full_size_configs_against_the_oracle(video_net):
+    """BASELINE.json configs[1] and configs[2] at their FULL sizes, every row against the CPU oracle (round 5: until now the direct
+    comparison stopped at the parity size B = 32 and the full sizes were held by properties only): 64 clip embeddings and 256
+    utterance embeddings, 1e-4 element-wise; then the fused [64,1024] rows and 2 016 cosine trials among them against the oracle's
+    fusion and scoring of ITS embeddings."""
+    from deeplip_amd import fusion, scoring
+    from models.audio_models.tdnn import SpeakerEmbNet
+    net, sdv = video_net
+    anet, sda = load(SpeakerEmbNet(etdnn_opts(80)), "audio80.")
+    ref = _full_size_reference(sdv, sda)
+    em = net.embed(ref["xv"].to(DEV))
+    ea, _ = anet.extract_embedding(ref["xa"].unsqueeze(1).to(DEV))
+    fused = fusion.fuse_av(ea[:64].contiguous(), em)
+    ia, ib = np.triu_indices(64, 1)
+    sc = scoring.cosine_scores(fused, torch.from_numpy(ia.astype(np.int32)).to(DEV), torch.from_numpy(ib.astype(np.int32)).to(DEV))
+    torch.cuda.synchronize()
+    close(em.cpu().numpy(), ref["video"].numpy(), what="64 clip embeddings (configs[1])")
+    close(ea.cpu().numpy(), ref["audio"].numpy(), what="256 utterance embeddings (configs[2])")
+    rfused = O.fuse_av(ref["audio"][:64], ref["video"]).numpy()
+    close(fused.cpu().numpy(), rfused, what="fused [64,1024]")
+    rsc = O.cosine_trial_scores(rfused, ia, ib)
+    assert float(np.abs(sc.cpu().numpy() - rsc).max()) < TOL
 
 
 def test_pooling_module(golden):
