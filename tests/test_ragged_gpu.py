@@ -339,15 +339,16 @@ def test_ragged_extractor_equals_one_at_a_time(video_net):
 
 # ------------------------------------------------------------------------------------------ BASELINE's full sizes, through properties
 def test_ragged_full_size_batches_properties(video_net):
-    """BASELINE.json's batch sizes with RAGGED contents -- 64 clips of 11 .. 75 frames, 256 utterances of 137 .. 412 frames, f16x3 -- where
-    the oracle would need minutes: (1) sampled rows equal the engine run on that item alone at its own length (1e-6: the balanced split's
+    """BASELINE.json's batch sizes with RAGGED contents -- 64 clips of 11 .. 75 frames, 256 utterances of 137 .. 412 frames, f16x3:
+    (1) sampled rows equal the engine run on that item alone at its own length (1e-6: the balanced split's
     sum order moves with the batch); (2) what sits in the padding does not matter, bit for bit; (3) two rows with equal content and
-    DIFFERENT neighbours / positions agree; (4) a row's result does not depend on the other rows' lengths."""
+    DIFFERENT neighbours / positions agree; (4) a row's result does not depend on the other rows' lengths; (5) every row
+    against the oracle run on that item alone at its own length (1e-4 element-wise)."""
     from deeplip_amd import packing
     from models.audio_models.tdnn import SpeakerEmbNet
     packing.set_precision("f16x3")
     try:
-        vnet, _ = video_net
+        vnet, sdv = video_net
         r = np.random.Generator(np.random.PCG64(21))
         lv = r.integers(11, 76, size=64).tolist()
         lv[0], lv[63] = 75, 33
@@ -377,8 +378,14 @@ def test_ragged_full_size_batches_properties(video_net):
             one = vnet.embed(xv[b:b + 1, :, :lv[b]].contiguous().to(DEV))
             torch.cuda.synchronize()
             assert rel_err(em[b:b + 1].cpu().numpy(), one.cpu().numpy()) < 1e-6, b
+        # (5, round 5) ... and EVERY row against the oracle run on that clip alone at its own length -- the reference's loop
+        # (train_fusion.py:346-348); the host cores of the box take ~10 s for the 64 clips
+        with torch.no_grad():
+            for b in range(64):
+                ref = O.video_time_mean(O.lipreading_features(sdv, xv[b:b + 1, :, :lv[b]].contiguous()))
+                close(em[b:b + 1].cpu().numpy(), ref.numpy(), what=f"clip {b} of 64 (T={lv[b]})")
 
-        anet, _ = load(SpeakerEmbNet(etdnn_opts(80)), "audio80.")
+        anet, sda = load(SpeakerEmbNet(etdnn_opts(80)), "audio80.")
         la = r.integers(137, 413, size=256).tolist()
         la[0], la[255] = 412, 137
         basea = torch.from_numpy(wg.audio_input(8, 80, 412, key="ragged.full.a", speakers=list(range(8))))
@@ -400,5 +407,9 @@ def test_ragged_full_size_batches_properties(video_net):
             one, _ = anet.extract_embedding(xa[b:b + 1, :, :la[b]].contiguous().to(DEV))
             torch.cuda.synchronize()
             assert rel_err(ea[b:b + 1].cpu().numpy(), one.cpu().numpy()) < 1e-6, b
+        with torch.no_grad():                                 # every one of the 256 utterances against the oracle, one at a time
+            for b in range(256):
+                ref, _ = O.speaker_extract_embedding(sda, xa[b:b + 1, :, :la[b]].contiguous(), O.ETDNN_CONTEXT)
+                close(ea[b:b + 1].cpu().numpy(), ref.numpy(), what=f"utterance {b} of 256 (T={la[b]})")
     finally:
         packing.set_precision("f32")
