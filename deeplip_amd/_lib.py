@@ -58,7 +58,7 @@ SIGNATURES = {
     "dlip_bn_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_f, c_stream],
     "dlip_bn_prelu_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_f, c_stream],
     "dlip_bn_prelu_maxpool_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, C.c_float, C.c_float, c_f, c_stream],
-    "dlip_bn_prelu_maxpool_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f, c_stream],
+    "dlip_bn_prelu_maxpool_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_f, c_stream],
     "dlip_bn_add_prelu_rows_train_fwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, C.c_float, c_f, c_stream],
     "dlip_bn_add_prelu_rows_train_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, c_f, c_stream],
     "dlip_wgrad_operand_split_bn_f32": [c_f, c_f, c_i64, c_i64, c_i32, c_f, c_f, c_f, c_f, c_f, C.c_float, c_f, c_stream],

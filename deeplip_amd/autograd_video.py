@@ -737,7 +737,9 @@ class BNPReLUMaxPoolFn(Function):
     codes, the backward's two passes take the gradient behind the pooling per pixel from the codes and the pooled gradient."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, momentum, eps, nbt=None):
+    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, momentum, eps, nbt=None, fork=False):
+        """``fork``: the pooled output TWICE (two tensor objects over one storage, as BNAddPReLUFn): the first block's convolution takes
+        one, its shortcut the other, and their two gradients are added inside the backward's passes."""
         x = x.contiguous()
         N, H, W, C_ = x.shape
         _lib.ensure_conv_workspace()
@@ -751,23 +753,27 @@ class BNPReLUMaxPoolFn(Function):
                                                         ptr(running_mean), ptr(running_var), ptr(ws), N, H, W, C_, momentum, eps, ptr(nbt),
                                                         stream_handle()), "dlip_bn_prelu_maxpool_train_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, slope, mean, invstd, idx)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, y.detach()) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         x, gamma, beta, slope, mean, invstd, idx = ctx.saved_tensors
         N, H, W, C_ = x.shape
         _lib.ensure_conv_workspace()
+        if dy is None:
+            dy, dy2 = dy2, None
         dy = dy.contiguous()
+        dy2 = dy2.contiguous() if dy2 is not None else None
         dx = torch.empty_like(x)
         dg, db, ds = (torch.empty_like(mean) for _ in range(3))
         ws = torch.empty((int(lib().dlip_bn_rows_chunks(N * H * W)) * C_ * 4,), device=x.device, dtype=torch.float64)
         lift = torch.empty((LIFT_WORDS,), device=x.device, dtype=torch.float32)
-        check(lib().dlip_bn_prelu_maxpool_train_bwd_f32(ptr(dy), idx.data_ptr(), ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(mean), ptr(invstd),
+        check(lib().dlip_bn_prelu_maxpool_train_bwd_f32(ptr(dy), ptr(dy2), idx.data_ptr(), ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(mean), ptr(invstd),
                                                         ptr(dx), ptr(dg), ptr(db), ptr(ds), ptr(ws), N, H, W, C_, ptr(lift), stream_handle()),
               "dlip_bn_prelu_maxpool_train_bwd_f32")
         dx._dlip_lift = lift
-        return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None, None
+        return dx, dg, db, (ds if ctx.needs_input_grad[3] else None), None, None, None, None, None, None
 
 
 class AddPReLUFn(Function):
@@ -1003,16 +1009,18 @@ def batchnorm_prelu(x, bn, act, defer=False):
 STEM_BN_POOL_FUSED = __import__("os").environ.get("DLIP_STEM_BN_POOL", "1") != "0"
 
 
-def batchnorm_prelu_maxpool(x, bn, act):
-    """maxpool(prelu(batchnorm(x))) of a channels-last [N,H,W,C] tensor in train mode (model.py:83-85)."""
+def batchnorm_prelu_maxpool(x, bn, act, fork=False):
+    """maxpool(prelu(batchnorm(x))) of a channels-last [N,H,W,C] tensor in train mode (model.py:83-85).  ``fork``: a pair of tensors
+    over the one output (see BNPReLUMaxPoolFn)."""
     w = getattr(act, "weight", None)
     C_ = x.shape[-1]
     if not STEM_BN_POOL_FUSED or x.dim() != 4 or (w is not None and w.numel() != C_):
-        return maxpool(batchnorm_prelu(x, bn, act))
+        y = maxpool(batchnorm_prelu(x, bn, act))
+        return (y, y) if fork else y
     if w is None:
         w = const_vec(C_, 0.0, x.device)
     return BNPReLUMaxPoolFn.apply(x, bn.weight, bn.bias, w if w.is_contiguous() else w.contiguous(), bn.running_mean, bn.running_var,
-                                  bn.momentum, bn.eps, bn.num_batches_tracked)
+                                  bn.momentum, bn.eps, bn.num_batches_tracked, bool(fork))
 
 
 # (round 5) the end of a BasicBlock as one Function (False: round 4's BNRowsActFn + AddPReLUFn)

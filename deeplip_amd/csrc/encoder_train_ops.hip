@@ -40,6 +40,8 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ?
 // passes read back.  idx == nullptr: `dy` is an ordinary dense gradient.
 struct PoolSrc {
   const uint32_t* idx;               // [N, Ho, Wo, C / 4] argmax codes, one byte per channel
+  const float* dy2;                  // nullptr, or a SECOND pooled gradient of the same output, added on the fly (the pooled tensor feeds the
+                                     // first block's convolution AND its shortcut: autograd's own addition was one more 115 MB launch)
   int H, W, Ho, Wo;
   FastDiv div_W, div_H, div_Wo, div_Ho;   // (rows < 2^31: 32-bit index arithmetic, divisions by multiplication)
 };
@@ -57,7 +59,12 @@ __device__ __forceinline__ f32x4 pooled_grad(const PoolSrc& ps, const float* __r
       const uint32_t me = (uint32_t)(r * 3 + (w - (2 * wo - 1)));
       const long long o = ((long long)(n * ps.Ho + ho) * ps.Wo + wo) * C + c;
       const uint32_t code = ps.idx[o >> 2];
-      const f32x4 g = *reinterpret_cast<const f32x4*>(dyp + o);
+      f32x4 g = *reinterpret_cast<const f32x4*>(dyp + o);
+      if (ps.dy2) {
+        const f32x4 g2 = *reinterpret_cast<const f32x4*>(ps.dy2 + o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] += g2[k];
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (((code >> (8 * k)) & 0xFFu) == me) acc[k] += g[k];
@@ -295,6 +302,11 @@ __global__ __launch_bounds__(256) void pool_bn_partial_kernel(const float* __res
           const long long o = (long long)r * C + c;
           const uint32_t code = ps.idx[o >> 2];
           g[u] = *reinterpret_cast<const f32x4*>(dyp + o);
+          if (ps.dy2) {
+            const f32x4 g2 = *reinterpret_cast<const f32x4*>(ps.dy2 + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[u][k] += g2[k];
+          }
           const float* xn = x + ((long long)n * ps.H * ps.W) * C + c;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -1371,18 +1383,19 @@ extern "C" int dlip_bn_prelu_maxpool_train_fwd_f32(const float* x, const float* 
   return dlip_launch_status();
 }
 
-extern "C" int dlip_bn_prelu_maxpool_train_bwd_f32(const float* dy_pooled, const uint32_t* idx, const float* x, const float* gamma,
+extern "C" int dlip_bn_prelu_maxpool_train_bwd_f32(const float* dy_pooled, const float* dy_pooled2, const uint32_t* idx, const float* x, const float* gamma,
                                                   const float* beta, const float* slope, const float* save_mean,
                                                   const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* dslope,
                                                   double* workspace, int64_t N, int32_t H, int32_t W, int32_t C, float* dx_lift2,
                                                   dlip_stream_t stream) {
   DLIP_CHECK_ARG(dy_pooled && idx && x && gamma && beta && slope && save_mean && save_invstd && dx && dgamma && dbeta && dslope && workspace);
   DLIP_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && N * H * W < 0x7FFFFFFFll);
-  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy_pooled) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy_pooled) | reinterpret_cast<uintptr_t>(dy_pooled2) |
+                   reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int M = (int)(N * H * W);
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const PoolSrc ps = {idx, H, W, Ho, Wo, dlip_fastdiv((uint32_t)W), dlip_fastdiv((uint32_t)H), dlip_fastdiv((uint32_t)Wo), dlip_fastdiv((uint32_t)Ho)};
+  const PoolSrc ps = {idx, dy_pooled2, H, W, Ho, Wo, dlip_fastdiv((uint32_t)W), dlip_fastdiv((uint32_t)H), dlip_fastdiv((uint32_t)Wo), dlip_fastdiv((uint32_t)Ho)};
   const int Mp = (int)(N * Ho * Wo);
   const int chunks = dlip_bn_rows_chunks(Mp);           // (the sums run over the POOLED rows; workspace sized for M >= Mp)
   ColFin fin = {stream_tickets(st, (C + 63) / 64), dbeta, dgamma, dslope, nullptr, nullptr, nullptr, 0.f, 0.f};

@@ -497,7 +497,7 @@ class Lipreading(nn.Module):
         stem, bn, act = self.frontend3D[0], self.frontend3D[1], self.frontend3D[2]
         av.prepare_weights(self)                           # the step's split weight images (forward and data-gradient banks): one launch
         y = av.stem_conv(x.contiguous().float().view(B, T, H, W), stem.weight)       # [(B T),H/2,W/2,64]
-        y = av.batchnorm_prelu_maxpool(y, bn, act)          # (one Function: no full-resolution tensor between the three)
+        y = av.batchnorm_prelu_maxpool(y, bn, act, fork=True)   # (one Function: no full-resolution tensor between the three; a pair: see BNAddPReLUFn)
         blocks = list(self.trunk.blocks())
         for i, blk in enumerate(blocks):
             y = _basic_block_train(blk, y, fork=i + 1 < len(blocks))     # (a block's output feeds the next block twice)

@@ -491,6 +491,8 @@ int dlip_bn_prelu_rows_train_bwd_f32(const float* dy, const float* x, const floa
                                      float* dslope, double* workspace, int32_t M, int32_t C, float* dx_lift2, dlip_stream_t stream);
 /* (ABI 44) BatchNorm3d (batch statistics) + PReLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the stem under model.train()
  * (models/video_models/model.py:83-85) WITHOUT the full-resolution tensors between them: x [N,H,W,C] = the stem convolution's output.
+ * (dy_pooled2, nullable: a second gradient of the pooled output, added on the fly -- the first BasicBlock's convolution and its
+ * shortcut both consume it.)
  * Forward: statistics of x (workspace as dlip_bn_rows_train_fwd_f32 with M = N H W), then ONE pass writes the pooled y
  * [N,Ho,Wo,C] and the argmax codes idx [N,Ho,Wo,C/4] (dlip_maxpool3x3s2_idx_f32's: tap r*3+s of the first maximum, one byte per
  * channel); prelu(bn(x)) is never stored.  Backward: dy_pooled [N,Ho,Wo,C] -> dx [N,H,W,C], dgamma, dbeta, dslope: both passes form
@@ -501,7 +503,7 @@ int dlip_bn_prelu_maxpool_train_fwd_f32(const float* x, const float* gamma, cons
                                         uint32_t* idx, float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                                         double* workspace, int64_t N, int32_t H, int32_t W, int32_t C, float momentum, float eps,
                                         int64_t* num_batches_tracked, dlip_stream_t stream);
-int dlip_bn_prelu_maxpool_train_bwd_f32(const float* dy_pooled, const uint32_t* idx, const float* x, const float* gamma,
+int dlip_bn_prelu_maxpool_train_bwd_f32(const float* dy_pooled, const float* dy_pooled2, const uint32_t* idx, const float* x, const float* gamma,
                                         const float* beta, const float* slope, const float* save_mean, const float* save_invstd,
                                         float* dx, float* dgamma, float* dbeta, float* dslope, double* workspace, int64_t N, int32_t H,
                                         int32_t W, int32_t C, float* dx_lift2, dlip_stream_t stream);

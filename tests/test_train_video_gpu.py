@@ -239,6 +239,14 @@ def test_stem_batchnorm_prelu_maxpool_as_one_function(N, H, W, C):
         return [t.detach().clone() for t in (y, xg.grad, gg.grad, bg.grad, sg.grad, rm, rv, nbt.float())]
 
     a, a2, b = run(True), run(True), run(False)
+    # the forked output: two gradients arriving separately == their sum arriving once
+    xg, gg, bg, sg = (t.clone().to(DEV).requires_grad_() for t in (x, ga, be, sl))
+    y1, y2 = av.BNPReLUMaxPoolFn.apply(xg, gg, bg, sg, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), 0.1, 1e-5, None, True)
+    assert y1.data_ptr() == y2.data_ptr()
+    torch.autograd.backward([y1, y2], [(0.25 * dy).to(DEV), (0.75 * dy).to(DEV)])
+    torch.cuda.synchronize()
+    for got, want in zip((xg.grad, gg.grad, bg.grad, sg.grad), a[1:5]):
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 2e-6
     assert rel_err(a[0].cpu().permute(0, 3, 1, 2).numpy(), ref.detach().numpy()) < 1e-5
     assert rel_err(a[1].cpu().permute(0, 3, 1, 2).numpy(), xd.grad.numpy()) < 1e-4
     assert rel_err(a[2].cpu().numpy(), bn.weight.grad.numpy()) < 1e-4 and rel_err(a[3].cpu().numpy(), bn.bias.grad.numpy()) < 1e-4
