@@ -83,7 +83,19 @@ class TrainStepGraph:
                     # permitted when stream is capturing" -- seen in one run of two).  "thread_local" confines the check to this
                     # thread; the launches of the autograd worker threads are captured either way (they go to the capturing stream).
                     import torch.distributed as _dist
-                    mode = "thread_local" if (_dist.is_available() and _dist.is_initialized()) else "global"
+                    in_job = _dist.is_available() and _dist.is_initialized()
+                    mode = "thread_local" if in_job else "global"
+                    if in_job:
+                        # ... and it must hold NO work of the eager steps when the capture begins: a recorded DP step captures its
+                        # bucket all-reduces, which pulls the process group's own stream into the capture, and HIP refuses the
+                        # watchdog's query of an EARLIER collective's end event (recorded on that stream before the capture, long
+                        # complete) while the stream is capturing -- "operation not permitted on an event last recorded in a
+                        # capturing stream", the job aborts (seen once in seven runs of tests/test_rccl_gpu.py, round 5).  The
+                        # watchdog retires completed work at its next poll (every 100 ms): everything is complete after the
+                        # synchronize, five polls later its list is empty; captured collectives are never enqueued to it.
+                        import time
+                        torch.cuda.synchronize(self.device)
+                        time.sleep(0.5)
                     with torch.cuda.graph(g, stream=self.stream, capture_error_mode=mode):
                         self.outputs = self.fn(*self.static)
                     self.graph = g
