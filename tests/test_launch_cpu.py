@@ -76,15 +76,22 @@ def test_sigterm_to_the_launcher_ends_the_job():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     code = ("import sys; sys.path.insert(0, %r); from deeplip_amd import launch; "
-            "sys.exit(launch.self_launch(%r, ['300'], 2))" % (ROOT, os.path.join(ROOT, "tests", "launch_sleeper.py")))
+            "sys.exit(launch.self_launch(%r, ['90'], 2))" % (ROOT, os.path.join(ROOT, "tests", "launch_sleeper.py")))
     p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)
-    pids = []
+    import re
+    pids, seen = [], []
     t0 = time.time()
     while len(pids) < 2 and time.time() - t0 < 120:
         line = p.stdout.readline()
-        if line.startswith("rank-pid"):
-            pids.append(int(line.split()[1]))
-    assert len(pids) == 2, "the two ranks never started"
+        if not line:
+            break                                         # the job ended before both ranks reported
+        seen.append(line)
+        # (anywhere in the line: two ranks write to one pipe, and a line of the launcher's children may arrive glued to another --
+        # one run of the suite in ~20 sat here for the sleepers' whole 300 s with one pid read)
+        pids += [int(v) for v in re.findall(r"rank-pid (\d+)", line)]
+    if len(pids) != 2:
+        p.kill()
+    assert len(pids) == 2, "the two ranks never started: " + repr(seen[-10:])
     p.send_signal(signal.SIGTERM)
     assert p.wait(timeout=60) == 128 + signal.SIGTERM
     for _ in range(50):                                   # the ranks are gone (reaped by their own parent, which is gone too)
