@@ -236,7 +236,7 @@ def _timed_replay(run, steps, warmup, sync):
     return e0.elapsed_time(e1) / steps
 
 
-def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan):
+def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan, c5_all=None):
     """The other BASELINE.json configurations, measured beside the headline: every entry is
     plan replay over inputs resident in HBM, HIP-event timed; failures are recorded, never fatal to the headline.
       C2 video-only clip embed [B,1,29,88,88]; C3 speech-encoder embed [256,1,F,300] (configs[2]);
@@ -375,44 +375,97 @@ def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan):
                 "valid_gflop_per_s": round(valid_gf / el, 1), "rectangular_gflop_per_s": round(rect_gf_per_s, 1),
                 "valid_work_rate_vs_rectangular": round(valid_gf / el / rect_gf_per_s, 4), **stats}
 
-    def c5():
-        from models.audio_models.loss import LMCL
-        from models.fusion_models import model_fusion
-        bs = 60                                      # conf/fusion_config.yaml:91
-        vb = xv[:bs].contiguous() if B >= bs else xv
-        ab = xa[:vb.shape[0]].contiguous()
-        nb = vb.shape[0]
-        plan = StepPlan(lambda v, a_: (audio.extract_embedding(a_)[0], video.embed(v)), vb, ab)
-        enc_ms = _timed_replay(plan.run, st, wu, sync)
-        xa_e, xv_e = (t.clone() for t in plan.run())
-        plan.close()
-        head = model_fusion.model_fusion(1024, 512, 57, extract_feats=False).to(device)
-        crit = LMCL(512, 57, 30.0, 0.2).to(device)
-        head.train()
-        opt = torch.optim.SGD([{"params": head.parameters()}, {"params": crit.parameters()}], 0.5, momentum=0.9, weight_decay=1e-5)
-        labels = (torch.arange(nb, device=device) % 57).long()
-        feats = torch.cat([fusion.feature_normalize(xa_e), fusion.feature_normalize(xv_e)], 1)
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(10)]
-        for i in range(12):
-            e = ev[max(i - 2, 0)]
-            opt.zero_grad()
-            e[0].record()
-            loss, logits = crit(head(feats), labels)
-            e[1].record()
-            loss.backward()
-            e[2].record()
-            opt.step()
-            e[3].record()
-        sync()
-        f = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)
-        b = sum(e[1].elapsed_time(e[2]) for e in ev) / len(ev)
-        o = sum(e[2].elapsed_time(e[3]) for e in ev) / len(ev)
-        tot = enc_ms + f + b + o
-        return {"workload": f"one rank's DP step of the fusion head: {nb} A+V pairs, frozen encoders, Linearfusion + LMCL, SGD "
-                            "(conf/fusion_config.yaml:87-99); gradients of the 3.4 MB head are one flat all-reduce at N > 1",
-                "pairs_per_s": round(1e3 * nb / tot, 1), "ms": {"encoders_frozen_extract": round(enc_ms, 4), "head_forward": round(f, 4),
-                                                                   "head_backward": round(b, 4), "optimizer": round(o, 4)},
-                "loss": round(float(loss.detach()), 4)}
+    def e1_av_test(ragged):
+        """The product surface, measured as a user drives it: train_fusion.Trainer('av_test') on a ragged synthetic list -> the
+        reference's on-disk store -> models.fusion_models.utils.eer_cos_lomgrid(run) (train_fusion.py:317-420,423-451).  Extraction is
+        the second pass over the list (plans recorded, host batches pinned: test.cache_host_batches), in VALID work per second like
+        C4_ragged_extraction, whose rate it is held against."""
+        import train_fusion
+        from models.fusion_models import utils
+        ov = {"data.test_speakers": 32, "data.test_utt_per_spk": 32, "data.test_clips_per_utt": 3, "data.utt_per_spk": 2,
+              "model.audio_config.etdnn.input_dim": args.audio_dim, "test.batch": B, "test.frames": "u8", "test.cache_host_batches": True,
+              "test.max_arena_gb": 176, "test.eval_grid": False}
+
+        def run():
+            from deeplip_amd import scoring_entry as se
+            tr = train_fusion.Trainer("av_test", overrides=ov)
+            try:
+                ds = tr.lomgridtestset
+                pool_a = [wg.audio_input(1, args.audio_dim, 412, key=f"bench.e1.a{i}", speakers=[i])[0] for i in range(8)]
+                pool_v = [wg.video_input(1, 75, 88, key=f"bench.e1.v{i}", speakers=[i])[0, 0] for i in range(4)]
+                ds.audio_item = lambda i: pool_a[i % 8][:, :int(ds.audio_len[i])]       # (the timing does not care what the pixels are)
+                ds.clip_item = lambda c: pool_v[c % 4][:int(ds.clip_len[c])]
+                tr._extract(ds)                                                          # records the plans, pins the host batches
+                sync()
+                t0 = time.perf_counter()
+                tables = tr._extract(ds)
+                sync()
+                t_ex = time.perf_counter() - t0
+                tr.lomgrid_tables = tables
+                t0 = time.perf_counter()
+                tr._write_store("lomgrid", ds, tables)
+                t_store = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                eer, thr = utils.eer_cos_lomgrid(tr.log_time)
+                t_score = time.perf_counter() - t0
+                stats = dict(tr.extract_stats)
+                n = len(ds)
+                gf_v, gf_a = 18.337 / 29.0, (2.563 + (0.085 if args.audio_dim == 80 else 0.0)) / 300.0
+                valid_gf = stats["valid_video_frames"] * gf_v + stats["valid_audio_frames"] * gf_a
+                return {"workload": f"train_fusion.Trainer('av_test'): {n} utterances / {len(ds.clip_len)} lip clips of differing length "
+                                    f"(batches of {B}, uint8 RGB frames + mel from pinned host memory) -> fused [N,1024] table -> the reference's "
+                                    ".npy store -> utils.eer_cos_lomgrid(run) over 20000 trials",
+                        "extract_utt_per_s": round(n / t_ex, 1), "clips_per_s": round(len(ds.clip_len) / t_ex, 1),
+                        "valid_gflop_per_s": round(valid_gf / t_ex, 1),
+                        "vs_C4_ragged_extraction": round(valid_gf / t_ex / ragged["valid_gflop_per_s"], 4) if ragged and "valid_gflop_per_s" in ragged else None,
+                        "store_write_s": round(t_store, 3), "score_from_store_s": round(t_score, 3), "eer": round(float(eer), 6),
+                        "arith": tr.arith, "f32_reruns": stats.get("f32_reruns", 0), "plans_recorded": stats.get("plans_recorded")}
+            finally:
+                tr.close()
+                se._process_paths.clear()
+        return _in_tmp(run)
+
+    def e2_train_video(f2):
+        """train_video.py as a user runs it: main() with the reference's flags, full-model training at B = 32 x 29 frames -- the loop's
+        own clips/s (from its 4th step on: recorded steps replayed, the next batch's copies behind the running step)."""
+        import train_video
+
+        def run():
+            train_video.main(["--batch-size", "32", "--frames", "29", "--steps", "14", "--maxepoch", "1", "--data-cache", "2", "--display", "100",
+                              "--save-path", os.path.join(os.getcwd(), "ck")])
+            st = dict(train_video.train.last_stats)
+            st = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}
+            st["workload"] = "train_video.main(): full Lipreading training (forward + backward + Adam + per-iteration cosine LR), 32 clips x 29 frames per step"
+            if f2 and "clips_per_s" in f2:
+                st["vs_F2_train_video_step"] = round(st["clips_per_s"] / f2["clips_per_s"], 4)
+            return st
+        return _in_tmp(run)
+
+    def e3_train_audio(f2):
+        """train_audio.Trainer._train_epoch(): full E-TDNN training (LMCL, SGD) at B = 256 x 300 frames, the second epoch (recorded
+        step replayed)."""
+        import train_audio
+        ov = {"train.bs": 256, "train.steps_per_epoch": 10, "train.crop_frames": [300, 300], "data.audio_frames": 300, "train.data_cache": 2,
+              "data.utt_per_spk": 8, "data.test_speakers": 2, "data.test_utt_per_spk": 2}
+
+        def run():
+            tr = train_audio.Trainer(overrides=ov)
+            try:
+                tr.current_epoch = 1
+                tr._train_epoch()
+                tr.current_epoch = 2
+                tr._train_epoch()
+                st = dict(tr.last_epoch_stats)
+                out_ = {"workload": "train_audio.Trainer._train_epoch(): full E-TDNN training step (forward + backward + SGD, LMCL), 256 utterances "
+                                    "x 300 frames x 24 features", "utt_per_s": round(st["utt_per_s"], 1),
+                        "ms_per_step": round(1e3 * st["bs"] / st["utt_per_s"], 3), "step_mode": st["step_mode"], "loss": round(st["loss"], 4),
+                        "arith": tr.arith}
+                if f2 and "utt_per_s" in f2:
+                    out_["vs_F2_train_audio_step"] = round(out_["utt_per_s"] / f2["utt_per_s"], 4)
+                return out_
+            finally:
+                tr.close()
+        return _in_tmp(run)
 
     def f2_video():
         """one optimisation step of the FULL lip-clip model (ResNet-18 + MS-TCN, Adam) at the reference's shapes,
@@ -502,10 +555,73 @@ def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan):
     guarded("C4_fusion_scoring", c4)
     if "error" not in out["C4_fusion_scoring"]:
         guarded("C4_ragged_extraction", lambda: c4_ragged(out["C4_fusion_scoring"]))
-    guarded("C5_fusion_train_step", c5)
+    in_job = dist.is_available() and dist.is_initialized()
+    if c5_all is not None:
+        out["C5_fusion_train_step"] = c5_all     # a job of several ranks: EVERY rank ran the trainer's epoch (main(), before this)
+    else:
+        guarded("C5_fusion_train_step", lambda: c5_entry(args))
     guarded("F2_train_video_step", f2_video)
     guarded("F2_train_audio_step", f2_audio)
+    if not args.no_entry_points and not in_job:
+        # the three entry points measured by calling them (the product surface, in the arithmetic their configs name: auto)
+        guarded("E1_train_fusion_av_test", lambda: e1_av_test(out.get("C4_ragged_extraction")))
+        guarded("E2_train_video_main", lambda: e2_train_video(out.get("F2_train_video_step")))
+        guarded("E3_train_audio_epoch", lambda: e3_train_audio(out.get("F2_train_audio_step")))
     return out
+
+
+def _in_tmp(fn):
+    """Run an entry-point leg in a scratch directory (the trainers write exp/<run>/ under the working directory)."""
+    import shutil
+    import tempfile
+    cwd, tmp = os.getcwd(), tempfile.mkdtemp(prefix="dlip_bench_")
+    from deeplip_amd import arith, packing
+    prec, mode = packing.PRECISION, arith.MODE
+    os.chdir(tmp)
+    try:
+        return fn()
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+        arith.configure(mode)                # the trainers configure the arithmetic themselves (model.arith: auto)
+        packing.set_precision(prec)
+
+def c5_entry(args):
+    """One rank's DP training step of the fusion head THROUGH THE ENTRY POINT: train_fusion.Trainer('train')._train_epoch() --
+    the frozen encoders' recorded plan (copies behind compute) + the head's recorded step (Linearfusion + LMCL forward, backward,
+    all-reduce of the 3.4 MB head at N > 1, SGD: one HIP graph), conf/fusion_config.yaml:87-99 at bs 60."""
+    import train_fusion
+    from deeplip_amd import arith
+    sync = torch.cuda.synchronize
+    st_, wu = max(5, args.steps // 2), 2
+    ov = {"train.bs": 60, "train.loss": "LMCL", "train.steps_per_epoch": 12, "train.data_cache": 2, "train.epoch": 2,
+          "model.audio_config.etdnn.input_dim": args.audio_dim, "data.utt_per_spk": 4}
+
+    def run():
+        tr = train_fusion.Trainer("train", overrides=ov)
+        try:
+            tr.current_epoch = 1
+            tr._train_epoch()                                    # eager head step, recording, first replays; the batches get pinned
+            tr.current_epoch = 2
+            tr._train_epoch()
+            st = dict(tr.last_epoch_stats)
+            # where a step's time goes: the two recorded pieces replayed alone
+            pipe, steps = tr._enc_pipe[1], tr._steps.last
+            enc_ms = _timed_replay(lambda: pipe.plans[0].run(check=False), st_, wu, sync)
+            head_ms = None
+            if steps.recorded:
+                xs = [t.clone() for t in steps.static]
+                head_ms = _timed_replay(lambda: steps.step(*xs), 20, 3, sync)
+            return {"workload": "train_fusion.Trainer('train')._train_epoch(): 60 A+V pairs per step, frozen encoders (recorded plan, copies "
+                                "behind compute), Linearfusion + LMCL head as one recorded step (forward + backward + SGD; its 3.4 MB "
+                                "gradient bucket all-reduced inside at N > 1), conf/fusion_config.yaml:87-99",
+                    "pairs_per_s": round(st["pairs_per_s"], 1), "ms_per_step": round(st["ms_per_step"], 4), "step_mode": st["step_mode"],
+                    "ms": {"encoders_frozen_extract": round(enc_ms, 4), "head_step_recorded": round(head_ms, 4) if head_ms is not None else None},
+                    "loss": round(st["loss"], 4), "arith": tr.arith, "f32_reruns": arith.STATS["f32_reruns"]}
+        finally:
+            tr.close()
+    return _in_tmp(run)
+
 
 
 def dry_launch(args, world, rank):
@@ -574,6 +690,7 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="issue the two encoders in sequence on one stream (default: the "
                     "speech encoder on a second stream, fork / join recorded into the step plan)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--no-entry-points", action="store_true", help="skip the entry-point lines (E1..E3: the trainers driven as a user drives them)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configurations (C2..C5) reported under `configs`")
     ap.add_argument("--eager", action="store_true",
                     help="issue every launch of every step from Python (round-1 behaviour) instead of replaying a recorded "
@@ -611,7 +728,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    from deeplip_amd import _lib, fusion, ops, packing, weightgen as wg
+    from deeplip_amd import _lib, arith, fusion, ops, packing, weightgen as wg
     from deeplip_amd.plan import StepPlan
     global SINGLE_STREAM
     SINGLE_STREAM = args.single_stream
@@ -670,7 +787,7 @@ def main():
         """W warm-up + K timed steps in one arithmetic mode -> (result fields, models, state dicts).
         The steady-state loop replays a recorded step plan (one dlip_plan_run per step; --eager issues the
         launches from Python instead) and runs the all-gather exchange after it when N > 1."""
-        packing.set_precision(precision)
+        arith.configure(precision)              # the headline runs the mode it names, no fallback: "f16x3" raises where "auto" would re-run
         video, audio, sds = build_models(device, args.audio_dim)
         hook = EventHook()
         ops.LAUNCH_HOOK = hook                  # events off: tallies the algorithmic FLOPs per kernel instance
@@ -860,7 +977,7 @@ def main():
         return fields, video, audio, sds
 
     def parity(precision, video, audio, ref, cxv, cxa):
-        packing.set_precision(precision)      # the pack cache is keyed by the arithmetic mode
+        arith.configure(precision)            # the pack cache is keyed by the arithmetic mode
         got = fusion.fuse_av(audio.extract_embedding(cxa.unsqueeze(1).to(device))[0], video.embed(cxv.to(device)))
         torch.cuda.synchronize()
         err = float((got.cpu() - ref).abs().max() / ref.abs().max())
@@ -871,8 +988,18 @@ def main():
 
     main_fields, video, audio, sds = measure(args.precision)
     configs = None
+    c5_all = None
+    if dist_on and not args.no_configs:
+        # BASELINE configs[4] inside a scaling run: train_fusion.Trainer's DP epoch on EVERY rank (gradient bucket all-reduced over
+        # RCCL inside the head's recorded step).  `step_mode` says whether the recorded step or eager steps ran -- at more than one
+        # rank the first replay is checked against an eager step from the same state and dropped on any doubt (train_plan.py).
+        try:
+            c5_all = c5_entry(args)
+            c5_all["ranks"] = world
+        except Exception as ex:   # noqa: BLE001
+            c5_all = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if rank == 0 and not args.no_configs:
-        configs = extra_configs(args, device, video, audio, xv, xa, main_fields["peak"], StepPlan)
+        configs = extra_configs(args, device, video, audio, xv, xa, main_fields["peak"], StepPlan, c5_all)
     if dist_on:
         dist.barrier()
     alt = None
@@ -880,7 +1007,7 @@ def main():
         alt_prec = "f32" if args.precision != "f32" else "f16x3"
         alt_fields, avideo, aaudio, _ = measure(alt_prec)
         alt = (alt_prec, alt_fields, avideo, aaudio)
-    packing.set_precision("f32")
+    arith.configure("f32")
 
     if rank == 0:
         res = {

@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 44
+ABI_VERSION = 45
 LIFT_WORDS = 4098
 LIFT_BCAST = 2048
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "dlip_conv_pool_f16x3": [C.POINTER(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i32, c_f, c_i32, c_i32, c_stream],
     "dlip_pool_finish_f32": [c_f, c_i64, c_i32, c_i32, c_i32, c_f, c_i32, c_i32, c_i32, c_i32, c_f, c_stream],
     "dlip_set_status_words": [c_f],
+    "dlip_status_scope": [c_f],
     "dlip_span_scope_begin": [c_f, c_f, c_i32],
     "dlip_span_scope_end": [c_stream, C.POINTER(C.c_int32)],
     "dlip_range_scope_begin": [c_f, c_i32],
@@ -121,7 +122,8 @@ SIGNATURES = {
     "dlip_group_mean_f32": [c_f, c_f, c_f, c_i32, c_i32, c_stream],
     "dlip_mask_frames_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_meanstd_pool_f32": [c_f, c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
-    "dlip_attentive_stat_pool_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_attentive_stat_pool_f32": [c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_attentive_stat_pool_bwd_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_f, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_nct_to_ntc_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_ntc_to_nct_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_nct_to_ntc_split_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
@@ -263,28 +265,78 @@ def status_words():
     return _status
 
 
+def _range_error(words) -> "DeepLipRangeError":
+    high = [n for n, v in zip(_STATUS_NAMES, words[:4]) if v]
+    recourse = ("results since the last check are invalid. Run that model in the exact mode -- arith 'f32' (deeplip_amd.arith / "
+                "--arith / model.arith / DLIP_ARITH), i.e. deeplip_amd.packing.set_precision('f32'): exact fp32 MFMA, same engine; "
+                "arith 'auto' does it by itself for the batch concerned.")
+    if high:
+        return DeepLipRangeError("f16x3 arithmetic: an activation with |v| >= 65520 (not representable as hi + lo fp16) was "
+                                 f"produced by {', '.join(high)}; " + recourse)
+    fam = words[_ST_LOW] - 1
+    who = _STATUS_NAMES[fam] if 0 <= fam < len(_STATUS_NAMES) else "a split-format producer"
+    return DeepLipRangeError(f"f16x3 arithmetic: {who} produced a tensor whose largest magnitude is below 2^-6 = 0.0156: its "
+                             "lo halves are fp16 subnormals and the result is no longer fp32-grade (relative error 3e-8 / max|v|); "
+                             + recourse)
+
+
+class StatusBlock:
+    """A status block of its own (dlip_status_scope): int32[8] in pinned host memory, handed to the launches a thread makes inside
+    ``scope()`` -- a recorded step plan keeps reporting to it on every replay, so the host can tell WHICH plan's batch left the
+    range.  Live blocks are also looked at by ``check_range()``: nothing reported anywhere goes unseen."""
+
+    def __init__(self):
+        self.t = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.np = self.t.numpy()
+        self.private = False        # True: the owner settles every report itself (a pipeline's per-batch f32 re-run); check_range() skips it
+        _blocks.add(self)
+
+    def take(self):
+        """The error this block holds (and clears), or None.  A host memory read: covers launches that have completed."""
+        if not self.np.any():
+            return None
+        words = self.t.tolist()
+        self.t.zero_()
+        return _range_error(words)
+
+    def scope(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            status_words()      # the process-wide block exists before any launch, scoped or not
+            check(lib().dlip_status_scope(self.t.data_ptr()), "dlip_status_scope")
+            try:
+                yield self
+            finally:
+                lib().dlip_status_scope(None)
+        return cm()
+
+
+import weakref as _weakref
+
+_blocks = _weakref.WeakSet()
+
+
 def check_range(sync: bool = False) -> None:
     """Raise DeepLipRangeError if a kernel reported an activation outside what the split format holds since the last call:
     |v| >= 65520 (infinite in fp16), or a whole produced tensor with its largest magnitude in (0, 2^-6) (lo is subnormal
     there: relative accuracy below fp32 grade; include/deeplip_hip.h).  Without ``sync`` only launches that have completed are
-    covered (the call is a host memory read); callers that are about to consume results synchronise first (or pass sync=True)."""
+    covered (the call is a host memory read); callers that are about to consume results synchronise first (or pass sync=True).
+    Covers the process-wide block and every live StatusBlock (recorded plans report to their own)."""
     t = status_words()
     if sync:
         torch.cuda.synchronize()
     if _status_np.any():
         words = t.tolist()
         t.zero_()
-        high = [n for n, v in zip(_STATUS_NAMES, words[:4]) if v]
-        recourse = ("results since the last check are invalid. Pack the model with deeplip_amd.packing.set_precision('f32') "
-                    "(exact fp32 MFMA, same engine).")
-        if high:
-            raise DeepLipRangeError("f16x3 arithmetic: an activation with |v| >= 65520 (not representable as hi + lo fp16) was "
-                                    f"produced by {', '.join(high)}; " + recourse)
-        fam = words[_ST_LOW] - 1
-        who = _STATUS_NAMES[fam] if 0 <= fam < len(_STATUS_NAMES) else "a split-format producer"
-        raise DeepLipRangeError(f"f16x3 arithmetic: {who} produced a tensor whose largest magnitude is below 2^-6 = 0.0156: its "
-                                "lo halves are fp16 subnormals and the result is no longer fp32-grade (relative error 3e-8 / max|v|); "
-                                + recourse)
+        raise _range_error(words)
+    for b in list(_blocks):
+        if b.private:
+            continue
+        err = b.take()
+        if err is not None:
+            raise err
 
 
 # ---- low-side range scopes: one evidence word per split-producing launch (dlip_range_scope_*) ----

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import _lib, ops, packing
+from . import _lib, arith, ops, packing
 from .holders import BatchNormParams, ConvParams, LinearParams, Marker
 from .video import _cached_pack, _require_eval
 
@@ -57,7 +57,7 @@ class AttentiveStatPooling(nn.Module):
         hidden = ops.linear(x_ntc.reshape(B * T, C_), self.W.detach().contiguous(), self.b.detach().reshape(-1).contiguous())
         y = ops._empty((B, 2 * C_), x_ntc.device)
         check(lib().dlip_attentive_stat_pool_f32(ptr(x_ntc), ptr(hidden), ptr(self.v.detach().contiguous()),
-                                                 ptr(self.k.detach().contiguous()), ptr(lengths), len_add, ptr(y), B, T, C_,
+                                                 ptr(self.k.detach().contiguous()), ptr(lengths), len_add, ptr(y), None, B, T, C_,
                                                  self.hidden_size, stream_handle()), "dlip_attentive_stat_pool_f32")
         return y
 
@@ -195,8 +195,8 @@ class SpeakerEmbNet(nn.Module):
         layer differentiable.  Each step is a torch.autograd Function whose forward and backward are dlip_*
         launches (deeplip_amd/autograd.py: TDNNBlockTrainFn, MeanStdPoolFn, LinearFn, BNRowsActFn)."""
         from . import autograd as ag
-        if self.pooling_type != "statistic":
-            raise NotImplementedError("train-mode encoder: only pooling='statistic' (the shipped configs)")
+        if self.pooling_type not in ("statistic", "attentive_statistic"):
+            raise NotImplementedError("train-mode encoder: pooling 'statistic' (the shipped configs) or 'attentive_statistic'")
         if self.input_dim % 4:
             raise ValueError("train-mode encoder: input_dim must be a multiple of 4")
         # [B,T,F] channels-last; F zero-padded to a multiple of 32 when the first layer can then run on the split-fp16 kernels
@@ -207,7 +207,8 @@ class SpeakerEmbNet(nn.Module):
         pend = None                                        # (a block's activated output is not stored when the next block takes it on load)
         for i, blk in enumerate(self.tdnn):
             h, pend = ag.tdnn_block_train(h, blk, pending=pend, defer=i + 1 < len(self.tdnn))
-        h = ag.meanstd_pool(h)
+        # (pooling.py:24-26 | :87-107: attention scores, softmax over frames, weighted mean and std, all differentiable)
+        h = ag.meanstd_pool(h) if self.pooling_type == "statistic" else ag.attentive_stat_pool(h, self.pooling)
         x_a = ag.linear(h, self.fc1.weight, self.fc1.bias)
         h = ag.bn_rows_act_train(x_a, self.bn1, LRELU, act_first=not self.bn_first)
         xv = ag.linear(h, self.fc2.weight, self.fc2.bias)
@@ -217,6 +218,7 @@ class SpeakerEmbNet(nn.Module):
         """Frames the stack's valid convolutions take off an utterance: T' = T - frames_consumed() (22 for the E-TDNN)."""
         return sum(b.dilation * (b.kernel_size - 1) - 2 * b.padding for b in self.tdnn)
 
+    @arith.guarded_eval
     @_lib.scoped_eval
     def extract_embedding(self, x: Tensor, lengths=None, taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
         """[B,F,T] -> (xv [B,E] = fc2 output, x_a [B,E] = fc1 output)   (tdnn.py:89-101).
@@ -271,6 +273,7 @@ class SpeakerEmbNet(nn.Module):
         xv = ops.linear(h, p["fc2"].w, p["fc2"].b, w_scale=p["fc2"].wscale)
         return xv, x_a
 
+    @arith.guarded_eval
     def forward(self, x: Tensor) -> Tensor:
         """tdnn.py:103-111: extract_embedding()[0] -> bn2 / LeakyReLU."""
         xv, _ = self.extract_embedding(x)

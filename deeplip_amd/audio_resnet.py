@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, packing
+from . import arith
 from .holders import BatchNormParams, ConvParams, LinearParams, Marker
 from .video import BasicBlock, _basic_block_train, _cached_pack, downsample_basic_block
 
@@ -96,6 +97,7 @@ class SpeakerEmbNet(nn.Module):
             h = _basic_block_train(b, h)
         return ag.linear(av.avgpool(h), self.fc.weight, self.fc.bias)
 
+    @arith.guarded_eval
     def extract_embedding(self, x: Tensor, lengths=None) -> Tuple[Tensor, Tensor]:
         """[B,1,F,T] (or [B,F,T]) -> (embedding [B,E], the same tensor): the TDNN encoder's (xv, x_a) interface with
         a single fully connected layer."""

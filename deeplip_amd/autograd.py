@@ -458,6 +458,52 @@ class MeanStdPoolFn(Function):
         return dx
 
 
+class AttnStatPoolFn(Function):
+    """The tail of AttentiveStatPooling (models/audio_models/pooling.py:87-107) behind its hidden layer: e = relu(hidden) v + k,
+    alpha = softmax over frames, y = [sum alpha x | sqrt(sum alpha x^2 - mean^2)].  x [B,T,C], hidden [B,T,H] (= x W^T + b from the
+    differentiable GEMM in front: W, b and the second path into x get their gradients there), v [H,1], k [1,1]."""
+
+    @staticmethod
+    def forward(ctx, x, hidden, v, k):
+        x, hidden = x.contiguous(), hidden.contiguous()
+        B, T, C_ = x.shape
+        H = hidden.shape[2]
+        y = torch.empty((B, 2 * C_), device=x.device, dtype=torch.float32)
+        alpha = torch.empty((B, T), device=x.device, dtype=torch.float32)
+        vv, kk = v.detach().contiguous(), k.detach().contiguous()
+        check(lib().dlip_attentive_stat_pool_f32(ptr(x), ptr(hidden), ptr(vv), ptr(kk), None, 0, ptr(y), ptr(alpha), B, T, C_, H,
+                                                 stream_handle()), "dlip_attentive_stat_pool_f32")
+        ctx.save_for_backward(x, hidden, vv, alpha, y)
+        ctx.shapes = (tuple(v.shape), tuple(k.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, hidden, vv, alpha, y = ctx.saved_tensors
+        B, T, C_ = x.shape
+        H = hidden.shape[2]
+        dx = torch.empty_like(x)
+        dh = torch.empty_like(hidden)
+        rde = torch.empty_like(hidden)
+        de = torch.empty((B, T), device=x.device, dtype=torch.float32)
+        check(lib().dlip_attentive_stat_pool_bwd_f32(ptr(x), ptr(hidden), ptr(vv), ptr(alpha), ptr(y), ptr(dy.contiguous()), None, 0, ptr(dx),
+                                                     ptr(dh), ptr(rde), ptr(de), B, T, C_, H, stream_handle()), "dlip_attentive_stat_pool_bwd_f32")
+        dv = _colsum(rde.view(B * T, H)).view(ctx.shapes[0]) if ctx.needs_input_grad[2] else None
+        dk = _colsum(de.view(B * T, 1)).view(ctx.shapes[1]) if ctx.needs_input_grad[3] else None
+        return dx, dh, dv, dk
+
+
+def attentive_stat_pool(x, pool):
+    """AttentiveStatPooling.forward under model.train() (pooling.py:99-107) on channels-last x [B,T,C] -> [B,2C]: the hidden layer
+    W x + b is the engine's differentiable 1 x 1 convolution (forward, data and weight gradient on the MFMA kernels), the rest
+    AttnStatPoolFn."""
+    from . import autograd_video as av
+    B, T, C_ = x.shape
+    H = pool.hidden_size
+    hidden = av.conv(x.reshape(B, 1, T, C_), pool.W.view(H, C_, 1, 1), pool.b.reshape(-1)).reshape(B, T, H)
+    return AttnStatPoolFn.apply(x, hidden, pool.v, pool.k)
+
+
 def materialize_pending(y, pending):
     """Write the values of a deferred block output ``y`` (TDNNBlockTrainFn defer): lrelu(bn(z)) from the statistics already formed."""
     z, mean, invstd, gamma, beta, slope = pending

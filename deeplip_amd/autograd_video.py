@@ -86,7 +86,7 @@ def wgrad_gemm(dz_rows, tap_rows, n_taps):
 # "f16x3" = the split-fp16 kernels of the extraction path -- activations split once per convolution (dlip_split_pack_f32; a
 # gradient after its power-of-two lift), the CURRENT weights split on the device (dlip_split_weights_rows_f32), fp32 out: 2.6x the
 # rate of the exact-fp32 MFMA kernel at fp32-grade accuracy -- or "f32", the exact kernel (what the training path used before).
-TRAIN_CONV = "f16x3"
+TRAIN_CONV = "f32" if __import__("os").environ.get("DLIP_ARITH", "auto").strip().lower() == "f32" else "f16x3"    # (deeplip_amd.arith.configure sets it)
 WGRAD_ODD_PITCH = True
 
 

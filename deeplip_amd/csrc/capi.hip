@@ -27,9 +27,13 @@ extern "C" int dlip_debug_set(int32_t key, int32_t value) {
 
 namespace {
 int32_t* g_status_words = nullptr;
+// dlip_status_scope: the block the launches of THIS host thread report to instead of the process-wide one (thread-local like the
+// range scope and stream capture: a step plan is recorded by one thread, and the words its launches were handed stay baked into it)
+thread_local int32_t* g_status_scope = nullptr;
+inline int32_t* status_now() { return g_status_scope != nullptr ? g_status_scope : g_status_words; }
 }
 
-extern "C" int32_t* dlip_status_words(void) { return g_status_words; }
+extern "C" int32_t* dlip_status_words(void) { return status_now(); }
 
 // ---- low-side range scope (include/deeplip_hip.h: dlip_range_scope_begin / _end) ----
 // Thread-local like stream capture: a scope belongs to the host thread that issues the launches of one forward pass.
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(64) void range_verdict_kernel(int32_t* slots, int n
 
 DlipRange dlip_range_for(int family) {
   DlipRange r;
-  if (g_status_words != nullptr) r.status = g_status_words + family;
+  if (status_now() != nullptr) r.status = status_now() + family;
   RangeScope& sc = g_scope;
   if (sc.slots != nullptr && sc.cur < sc.n) r.lo = sc.slots + (size_t)DLIP_EVID_WORDS * (sc.cur++);
   r.code = family + 1;
@@ -89,7 +93,7 @@ extern "C" int dlip_range_scope_end(dlip_stream_t stream) {
   const int used = sc.cur;
   sc = RangeScope{};
   if (used > 0) {
-    hipLaunchKernelGGL(range_verdict_kernel, dim3((unsigned)used), dim3(64), 0, static_cast<hipStream_t>(stream), slots, used, g_status_words);
+    hipLaunchKernelGGL(range_verdict_kernel, dim3((unsigned)used), dim3(64), 0, static_cast<hipStream_t>(stream), slots, used, status_now());
     return dlip_launch_status();
   }
   return DLIP_OK;
@@ -97,6 +101,11 @@ extern "C" int dlip_range_scope_end(dlip_stream_t stream) {
 
 extern "C" int dlip_set_status_words(int32_t* words) {
   g_status_words = words;
+  return DLIP_OK;
+}
+
+extern "C" int dlip_status_scope(int32_t* words) {
+  g_status_scope = words;
   return DLIP_OK;
 }
 

@@ -224,7 +224,8 @@ namespace {
 // phase 3 one thread per channel (coalesced) with fp64 accumulation.
 __global__ __launch_bounds__(256) void attentive_stat_kernel(const float* __restrict__ x, const float* __restrict__ hidden,
                                                              const float* __restrict__ v, const float* __restrict__ kk,
-                                                             float* __restrict__ y, int Tpad, int C, int Hd, const DlipLen len) {
+                                                             float* __restrict__ y, float* __restrict__ alpha_out, int Tpad, int C,
+                                                             int Hd, const DlipLen len) {
   extern __shared__ float alpha[];   // [T]
   __shared__ float red[2];
   const int b = blockIdx.x;
@@ -251,6 +252,8 @@ __global__ __launch_bounds__(256) void attentive_stat_kernel(const float* __rest
   const double se = red[1];
   for (int t = threadIdx.x; t < T; t += 256) alpha[t] = (float)(exp((double)(alpha[t] - mx)) / se);
   __syncthreads();
+  if (alpha_out != nullptr)          // the attention weights, kept for the backward pass (zeros behind a ragged utterance's end)
+    for (int t = threadIdx.x; t < Tpad; t += 256) alpha_out[(long long)b * Tpad + t] = t < T ? alpha[t] : 0.f;
   const float* xb = x + (long long)b * Tpad * C;
   for (int c = threadIdx.x; c < C; c += 256) {
     double m = 0.0, q = 0.0;
@@ -266,12 +269,99 @@ __global__ __launch_bounds__(256) void attentive_stat_kernel(const float* __rest
 }  // namespace
 
 extern "C" int dlip_attentive_stat_pool_f32(const float* x, const float* hidden, const float* v, const float* k,
-                                            const int32_t* len, int32_t len_add, float* y, int32_t B, int32_t T, int32_t C,
-                                            int32_t Hd, dlip_stream_t stream) {
+                                            const int32_t* len, int32_t len_add, float* y, float* alpha_out, int32_t B, int32_t T,
+                                            int32_t C, int32_t Hd, dlip_stream_t stream) {
   DLIP_CHECK_ARG(x && hidden && v && k && y && B > 0 && T > 0 && C > 0 && Hd > 0 && T <= 16000);
   DlipLen l; l.len = len; l.mul = 1; l.add = len_add;
   hipLaunchKernelGGL(attentive_stat_kernel, dim3(B), dim3(256), (size_t)T * sizeof(float),
-                     static_cast<hipStream_t>(stream), x, hidden, v, k, y, T, C, Hd, l);
+                     static_cast<hipStream_t>(stream), x, hidden, v, k, y, alpha_out, T, C, Hd, l);
+  return dlip_launch_status();
+}
+
+namespace {
+// Backward of the AttentiveStatPooling tail (models/audio_models/pooling.py:87-107; the forward above) for one utterance per
+// workgroup.  With u = q - m^2, s = sqrt(u):   g_q = ds / (2 s),  g_m = dm - 2 m g_q   (torch's own chain through sqrt and the square)
+//   dx[t,c]     = alpha_t (g_m[c] + 2 x[t,c] g_q[c])                     the statistics' direct path
+//   dalpha_t    = sum_c (g_m[c] x[t,c] + g_q[c] x[t,c]^2)
+//   de_t        = alpha_t (dalpha_t - sum_t' alpha_t' dalpha_t')        softmax over the utterance's valid frames
+//   dhidden[t,j]= de_t v_j [hidden[t,j] > 0]                            -> W, b and the second path into x, through the GEMM's backward
+//   rde[t,j]    = de_t relu(hidden[t,j])                                column sums = dv;  sum(de) = dk
+// fp64 accumulation wherever a sum runs over channels or frames.  LDS: g_m [C] | g_q [C] | dalpha [Tpad].
+__global__ __launch_bounds__(256) void attentive_stat_bwd_kernel(const float* __restrict__ x, const float* __restrict__ hidden,
+                                                                 const float* __restrict__ v, const float* __restrict__ alpha,
+                                                                 const float* __restrict__ y, const float* __restrict__ dy,
+                                                                 float* __restrict__ dx, float* __restrict__ dhidden,
+                                                                 float* __restrict__ rde, float* __restrict__ de_out, int Tpad, int C,
+                                                                 int Hd, const DlipLen len) {
+  extern __shared__ float sm[];
+  float* gm = sm;
+  float* gq = sm + C;
+  float* dal = sm + 2 * C;          // [Tpad]: dalpha, then de
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  const int T = dlip_valid_rows(len, b, Tpad);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* xb = x + (long long)b * Tpad * C;
+  const float* ab = alpha + (long long)b * Tpad;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double m = y[(long long)b * 2 * C + c], s = y[(long long)b * 2 * C + C + c];
+    const double dm = dy[(long long)b * 2 * C + c], ds = dy[(long long)b * 2 * C + C + c];
+    const double q = ds / (2.0 * s);
+    gq[c] = (float)q;
+    gm[c] = (float)(dm - 2.0 * m * q);
+  }
+  __syncthreads();
+  for (int t = wave; t < T; t += 4) {
+    double a = 0.0;
+    for (int c = lane; c < C; c += 64) {
+      const double xv = xb[(long long)t * C + c];
+      a += xv * ((double)gm[c] + (double)gq[c] * xv);
+    }
+    a = dlip_wave_sum_f64(a);
+    if (lane == 0) dal[t] = (float)a;
+  }
+  __syncthreads();
+  {
+    double part = 0.0;
+    for (int t = threadIdx.x; t < T; t += 256) part += (double)ab[t] * (double)dal[t];
+    part = dlip_wave_sum_f64(part);
+    if (lane == 0) red[wave] = part;
+  }
+  __syncthreads();
+  const double dot = red[0] + red[1] + red[2] + red[3];
+  for (int t = threadIdx.x; t < Tpad; t += 256) {
+    const float de = t < T ? (float)((double)ab[t] * ((double)dal[t] - dot)) : 0.f;
+    dal[t] = de;
+    de_out[(long long)b * Tpad + t] = de;
+  }
+  __syncthreads();
+  float* dxb = dx + (long long)b * Tpad * C;
+  for (long long i = threadIdx.x; i < (long long)Tpad * C; i += 256) {
+    const int t = (int)(i / C), c = (int)(i - (long long)t * C);
+    dxb[i] = t < T ? ab[t] * (gm[c] + 2.f * xb[i] * gq[c]) : 0.f;
+  }
+  const float* hb = hidden + (long long)b * Tpad * Hd;
+  float* dhb = dhidden + (long long)b * Tpad * Hd;
+  float* rb = rde + (long long)b * Tpad * Hd;
+  for (long long i = threadIdx.x; i < (long long)Tpad * Hd; i += 256) {
+    const int t = (int)(i / Hd), j = (int)(i - (long long)t * Hd);
+    const float h = hb[i], de = dal[t];
+    dhb[i] = (t < T && h > 0.f) ? de * v[j] : 0.f;
+    rb[i] = t < T ? de * fmaxf(h, 0.f) : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int dlip_attentive_stat_pool_bwd_f32(const float* x, const float* hidden, const float* v, const float* alpha, const float* y,
+                                                const float* dy, const int32_t* len, int32_t len_add, float* dx, float* dhidden,
+                                                float* rde, float* de, int32_t B, int32_t T, int32_t C, int32_t Hd,
+                                                dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && hidden && v && alpha && y && dy && dx && dhidden && rde && de && B > 0 && T > 0 && C > 0 && Hd > 0);
+  const size_t lds = ((size_t)2 * C + T) * sizeof(float);
+  DLIP_CHECK_ARG(lds <= 60 * 1024);
+  DlipLen l; l.len = len; l.mul = 1; l.add = len_add;
+  hipLaunchKernelGGL(attentive_stat_bwd_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), x, hidden, v, alpha, y, dy,
+                     dx, dhidden, rde, de, T, C, Hd, l);
   return dlip_launch_status();
 }
 

@@ -126,6 +126,30 @@ def allreduce_grads(params, world_size: Optional[int] = None) -> int:
     return n
 
 
+_CAPTURE_GROUP = [None, None]      # the group, and the default group it was made beside (a re-initialised job makes a new one)
+
+
+def capture_group(device: Optional[torch.device] = None):
+    """The process group whose collectives are CAPTURED into recorded training steps (deeplip_amd.train_plan) -- a second
+    communicator over the same ranks that never carries an eager collective after its one warm-up.  Why: every process group has
+    a watchdog thread polling the end events of its eager collectives; when a recorded step captures a collective of that group,
+    the group's own stream enters the capture and HIP refuses the watchdog's query of an earlier event on it -- the job aborts
+    ("operation not permitted on an event last recorded in a capturing stream": round 5, once in seven runs).  A group that only
+    ever sees captured collectives (which are never enqueued to a watchdog) has nothing to poll; the default group, which the eager
+    steps, broadcasts and metric reductions use, is never captured.  Collective on every rank (dist.new_group); None outside a job."""
+    if not active():
+        return None
+    default = dist.distributed_c10d._get_default_group()
+    if _CAPTURE_GROUP[0] is None or _CAPTURE_GROUP[1] is not default:
+        g = dist.new_group(backend=dist.get_backend())
+        t = torch.zeros(1, device=device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+        dist.all_reduce(t, group=g)            # communicator set-up happens HERE, eagerly, long before any capture
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+        _CAPTURE_GROUP[0], _CAPTURE_GROUP[1] = g, default
+    return _CAPTURE_GROUP[0]
+
+
 class GradBuckets:
     """Bucketed gradient all-reduce overlapped with backward (what replaces nn.DataParallel's
     gather of gradients, train_audio.py:83 / train_video.py:206-207, on one process per GPU over RCCL).
@@ -153,6 +177,8 @@ class GradBuckets:
         self.params = [p for p in params if p.requires_grad]
         self.world = world()[1]
         self.active = active()     # a process group exists (a one-rank job included): the collectives are issued
+        # all-reduces issued while the stream is being captured (a recorded step) go to the capture group (see capture_group)
+        self.capture_grp = capture_group(self.params[0].device) if (self.active and self.params and self.params[0].is_cuda) else None
         self.buckets: List[torch.Tensor] = []
         self._slot = {}            # id(param) -> bucket index
         self._pending: List[int] = []
@@ -200,7 +226,9 @@ class GradBuckets:
             return
         self._launched[bi] = True
         if self.active:
-            self._works.append(dist.all_reduce(self.buckets[bi], async_op=True))
+            b = self.buckets[bi]
+            grp = self.capture_grp if (self.capture_grp is not None and b.is_cuda and torch.cuda.is_current_stream_capturing()) else None
+            self._works.append(dist.all_reduce(b, async_op=True, group=grp))
 
     def _hook(self, p):
         bi = self._slot[id(p)]

@@ -30,11 +30,18 @@ class RaggedExtractor:
     rows [B,D]`` are launch-only step functions (deeplip_amd/plan.py)."""
 
     def __init__(self, audio_fn: Optional[Callable], video_fn: Optional[Callable], device, batch: int = 32, clip_batch: Optional[int] = None,
-                 waste: float = 0.10, audio_quantum: int = 4, video_quantum: int = 1, max_arena_bytes: int = 64 << 30):
+                 waste: float = 0.10, audio_quantum: int = 4, video_quantum: int = 1, max_arena_bytes: int = 64 << 30,
+                 audio_min_frames: int = 1, video_min_frames: int = 1, fallback="auto"):
+        """``audio_min_frames`` / ``video_min_frames``: the shortest item the encoders can embed -- for the E-TDNN
+        ``frames_consumed() + 2`` = 24 (its valid convolutions take 22 frames off an utterance and the unbiased standard deviation of
+        the statistics pooling needs two pooled frames, pooling.py:24-26), one frame for a lip clip.  Checked HERE, on the host,
+        where the lengths are: the kernels only clamp a length to [0, T] and a pooled count of 0 (or 1 under the std) would come
+        back as NaN / Inf rows in the embedding table with no error.  ``fallback``: see ExtractPipeline (per-batch f32 re-run)."""
         self.device, self.batch, self.clip_batch, self.waste = device, int(batch), int(clip_batch or batch), float(waste)
         self.aq, self.vq = audio_quantum, video_quantum
-        self.pa = BucketedExtract(audio_fn, device=device, max_arena_bytes=max_arena_bytes // 4) if audio_fn is not None else None
-        self.pv = BucketedExtract(video_fn, device=device, max_arena_bytes=max_arena_bytes) if video_fn is not None else None
+        self.audio_min_frames, self.video_min_frames = int(audio_min_frames), int(video_min_frames)
+        self.pa = BucketedExtract(audio_fn, device=device, max_arena_bytes=max_arena_bytes // 4, fallback=fallback) if audio_fn is not None else None
+        self.pv = BucketedExtract(video_fn, device=device, max_arena_bytes=max_arena_bytes, fallback=fallback) if video_fn is not None else None
         self.stats: dict = {}
 
     def close(self) -> None:
@@ -62,8 +69,23 @@ class RaggedExtractor:
         n = hi - lo
         dev = self.device
         xa = xv = None
+        if n and self.pa is not None:
+            short = np.flatnonzero(np.asarray(dataset.audio_len[lo:hi]) < self.audio_min_frames)
+            if short.size:
+                raise ValueError(f"RaggedExtractor: utterance {lo + int(short[0])} has {int(dataset.audio_len[lo + int(short[0])])} frames; the "
+                                 f"speech encoder needs >= {self.audio_min_frames} (its valid convolutions + two pooled frames for the "
+                                 f"unbiased std); {short.size} such utterance(s) in the list")
         ba = plan_batches(dataset.audio_len[lo:hi], self.batch, self.waste, self.aq) if self.pa is not None and n else []
         c0, c1 = int(dataset.clip_ptr[lo]), int(dataset.clip_ptr[hi])
+        if n and self.pv is not None:
+            short = np.flatnonzero(np.asarray(dataset.clip_len[c0:c1]) < self.video_min_frames)
+            if short.size:
+                raise ValueError(f"RaggedExtractor: lip clip {c0 + int(short[0])} has {int(dataset.clip_len[c0 + int(short[0])])} frames; "
+                                 f"needs >= {self.video_min_frames}")
+            empty = np.flatnonzero(np.diff(np.asarray(dataset.clip_ptr[lo:hi + 1])) < 1)
+            if empty.size:
+                raise ValueError(f"RaggedExtractor: utterance {lo + int(empty[0])} has no lip clip (the mean over its clip files, "
+                                 "train_fusion.py:349, would be 0 / 0)")
         bv = plan_batches(dataset.clip_len[c0:c1], self.clip_batch, self.waste, self.vq) if self.pv is not None and n else []
         ta = torch.empty((len(ba) * self.batch, D), device=dev) if ba else None           # rows in submission order
         tv = torch.empty((len(bv) * self.clip_batch, D), device=dev) if bv else None
@@ -111,6 +133,7 @@ class RaggedExtractor:
             "valid_audio_frames": int(np.sum(dataset.audio_len[lo:hi])) if ba else 0,
             "valid_video_frames": int(np.sum(dataset.clip_len[c0:c1])) if bv else 0,
             "plans_recorded": (self.pa.recorded if self.pa else 0) + (self.pv.recorded if self.pv else 0),
+            "f32_reruns": (self.pa.reruns if self.pa else 0) + (self.pv.reruns if self.pv else 0),
         }
         _lib.check_range(sync=True)
         return xa, xv

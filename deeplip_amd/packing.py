@@ -3,6 +3,7 @@ in fp64 on the host (rounded to fp32 once), weights permuted to the kernels' KRS
 Runs once per ``load_state_dict`` / device move (cached by the owning module)."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -15,9 +16,11 @@ Tensor = torch.Tensor
 
 
 # Arithmetic mode of the implicit-GEMM kernels for weights packed from now on:
-#   "f32"   exact fp32 MFMA (default; bit-reproducible fma chains)
+#   "f32"   exact fp32 MFMA (bit-reproducible fma chains)
 #   "f16x3" split (hi, lo) fp16 operands, 3 f16 MFMAs per product, fp32 accumulate (~2^-22 relative)
-PRECISION = "f32"
+# The library's default is the MEASURED configuration: "f16x3" under the arith mode "auto" (deeplip_amd/arith.py: what leaves its
+# range is computed again in f32) unless $DLIP_ARITH says f32; the entry points call arith.configure() with their flag / config key.
+PRECISION = "f32" if os.environ.get("DLIP_ARITH", "auto").strip().lower() == "f32" else "f16x3"
 
 
 def set_precision(mode: str) -> None:

@@ -23,6 +23,7 @@ from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 
+from . import arith
 from ._lib import DeepLipHipError, check_range
 from .plan import StepPlan
 
@@ -36,7 +37,10 @@ def pin(t: Tensor) -> Tensor:
 class ExtractPipeline:
     """``fn(*inputs) -> rows [B, D]`` recorded once per input set; ``run(batches, table)`` streams host batches through."""
 
-    def __init__(self, fn: Callable, *example_inputs: Tensor, depth: int = 2, device: Optional[torch.device] = None):
+    def __init__(self, fn: Callable, *example_inputs: Tensor, depth: int = 2, device: Optional[torch.device] = None, fallback="auto"):
+        """``fallback``: what happens to a batch whose replay left the range of the f16x3 arithmetic.  True: that batch -- still in its
+        input set -- is computed again eagerly on the exact f32 pack of the same models and its rows overwritten (counted in
+        deeplip_amd.arith.STATS); False: DeepLipRangeError at the next submit / finish; "auto": True under arith mode ``auto``."""
         if depth < 2:
             raise ValueError("ExtractPipeline: depth >= 2 (one set being filled while another is being read)")
         for i, t in enumerate(example_inputs):
@@ -44,6 +48,9 @@ class ExtractPipeline:
                 raise DeepLipHipError(f"ExtractPipeline: example input {i} must be a tensor (shape / dtype template)")
         self.device = device or next((t.device for t in example_inputs if t.is_cuda), torch.device("cuda", torch.cuda.current_device()))
         self.depth = depth
+        self.fn = fn
+        self.fallback = arith.fallback_enabled() if fallback == "auto" else bool(fallback)
+        self.reruns = 0
         self.run_stream = torch.cuda.Stream(device=self.device)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.sets: List[Tuple[Tensor, ...]] = []
@@ -59,11 +66,16 @@ class ExtractPipeline:
                 self.plans.append(StepPlan(fn, *ins, stream=self.run_stream))
         self.ready = [torch.cuda.Event() for _ in range(depth)]
         self.free = [torch.cuda.Event() for _ in range(depth)]
+        self._pending: list = [None] * depth # (tables, row, rows) of the replay in flight on set k: settled when the set is recycled / at finish()
+        for p in self.plans:
+            p.status.private = True          # every report of a replay is settled here, batch by batch (_settle)
         self._replayed = [False] * depth     # set k has a replay in flight (or finished) whose FREE event must be awaited before refilling it
         self._next = 0                       # batches submitted so far: batch i uses input set i % depth
         self.batch = int(example_inputs[0].shape[0])
         self.launches = self.plans[0].launches
         self.run_stream.synchronize()
+        for p in self.plans:
+            p.take_range_error()             # what the RECORDING passes reported about the example values: not an output of this pipeline
 
     def submit(self, hb: Sequence[Tensor], tables: Sequence[Tensor], row: int) -> int:
         """One batch: ``hb`` (pinned host tensors shaped like the recorded inputs; any of them may be SHORT in its leading
@@ -83,13 +95,14 @@ class ExtractPipeline:
             # host free to enqueue all 40 batches at once the replays behind the enqueue burst take 5.2-6.2 ms instead of
             # 4.2 (and the enqueue itself 2.3 ms per batch); throttled, every batch takes 4.23 ms -- the resident rate.
             self.free[k].synchronize()
+            self._settle(k)
         with torch.cuda.stream(self.copy_stream):
             for dst, src in zip(ins, hb):
                 (dst if src.shape[0] == dst.shape[0] else dst[:src.shape[0]]).copy_(src, non_blocking=True)
             self.ready[k].record(self.copy_stream)
         with torch.cuda.stream(self.run_stream):
             self.run_stream.wait_event(self.ready[k])
-            out = self.plans[k].run()
+            out = self.plans[k].run(check=False)
             outs = [out] if isinstance(out, Tensor) else list(out)
             if len(outs) != len(tables):
                 raise ValueError(f"ExtractPipeline: the step returns {len(outs)} tensors, {len(tables)} tables given")
@@ -97,7 +110,29 @@ class ExtractPipeline:
                 t[row: row + rows].copy_(o[:rows], non_blocking=True)
             self.free[k].record(self.run_stream)
         self._replayed[k] = True
+        self._pending[k] = (list(tables), row, rows)
         return rows
+
+    def _settle(self, k: int) -> None:
+        """Set k's last replay has finished: did it stay inside the f16x3 range?  If not, the batch is still in the set's buffers --
+        compute it again on the exact f32 packs (fallback) or raise.  The reference computes everything in fp32
+        (train_fusion.py:338-358), so a batch must never come back wrong because the fast arithmetic could not hold it."""
+        pend, self._pending[k] = self._pending[k], None
+        if pend is None:
+            return
+        err = self.plans[k].take_range_error()
+        if err is None:
+            return
+        if not self.fallback:
+            raise err
+        tables, row, rows = pend
+        with torch.cuda.stream(self.run_stream):
+            out = arith.rerun_exact(self.fn, *self.sets[k], what=f"ExtractPipeline batch (rows {row}..{row + rows - 1})", err=err)
+            outs = [out] if isinstance(out, Tensor) else list(out)
+            for t, o in zip(tables, outs):
+                t[row: row + rows].copy_(o[:rows], non_blocking=True)
+        self.run_stream.synchronize()
+        self.reruns += 1
 
     def run(self, batches: Iterable[Sequence[Tensor]], table, row0: int = 0) -> int:
         """Stream ``batches`` (tuples of pinned host tensors shaped like the recorded inputs; any of them may be SHORT in its
@@ -114,7 +149,9 @@ class ExtractPipeline:
     def finish(self) -> None:
         self.run_stream.synchronize()
         self._replayed = [False] * self.depth
-        check_range(sync=False)       # an f16x3 overflow of the LAST batch surfaces here, not one call late
+        for k in range(self.depth):   # an f16x3 overflow of the LAST batches surfaces (or is repaired) here, not one call late
+            self._settle(k)
+        check_range(sync=False)
 
     def close(self) -> None:
         for p in self.plans:
@@ -132,8 +169,9 @@ class BucketedExtract:
     (the bench, an epoch of evaluation) records nothing.  Rows are written in SUBMISSION order; the caller un-sorts once at the
     end (``table[order] = rows``)."""
 
-    def __init__(self, fn: Callable, depth: int = 2, device: Optional[torch.device] = None, max_arena_bytes: int = 96 << 30):
+    def __init__(self, fn: Callable, depth: int = 2, device: Optional[torch.device] = None, max_arena_bytes: int = 96 << 30, fallback="auto"):
         self.fn, self.depth, self.device, self.max_arena_bytes = fn, depth, device, max_arena_bytes
+        self.fallback = fallback
         self.pipes: dict = {}        # shape key -> ExtractPipeline, in LRU order (dicts keep insertion order)
         self.recorded = 0            # pipelines recorded so far (tests, the bench's report)
 
@@ -154,7 +192,7 @@ class BucketedExtract:
                 full.append(torch.cat([t] * reps)[:batch] if int(t.shape[0]) != batch else t)
             dev = self.device or torch.device("cuda", torch.cuda.current_device())
             with torch.no_grad():
-                p = ExtractPipeline(self.fn, *(t.to(dev) for t in full), depth=self.depth, device=dev)
+                p = ExtractPipeline(self.fn, *(t.to(dev) for t in full), depth=self.depth, device=dev, fallback=self.fallback)
             self.recorded += 1
         self.pipes[key] = p        # most recently used last
         while len(self.pipes) > 1 and self._arena_bytes() > self.max_arena_bytes:
@@ -170,6 +208,10 @@ class BucketedExtract:
     def finish(self) -> None:
         for p in self.pipes.values():
             p.finish()
+
+    @property
+    def reruns(self) -> int:
+        return sum(p.reruns for p in self.pipes.values())
 
     def close(self) -> None:
         for p in self.pipes.values():

@@ -28,7 +28,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 
 from . import holders, ops
-from ._lib import DeepLipHipError, check, check_range, lib, range_scope, scope_slots
+from ._lib import DeepLipHipError, StatusBlock, check, check_range, lib, range_scope, scope_slots
 
 Tensor = torch.Tensor
 
@@ -119,6 +119,9 @@ class StepPlan:
         self._order_with = stream
         self.arena = Arena()
         self._range_slots = scope_slots(self.device)
+        # the plan's OWN range-status block (dlip_status_scope): the recorded launches report to it on every replay, so a pipeline
+        # knows which batch left the f16x3 range (take_range_error) -- check_range() sees it as well
+        self.status = StatusBlock()
         # spans=True: every launch of the LDS-DMA convolution kernel times itself in-kernel on every replay (dlip_span_scope_*);
         # span_names = those launches in order, as ops.LAUNCH_HOOK names them (instance, algorithmic FLOPs)
         self._spans = None
@@ -170,7 +173,7 @@ class StepPlan:
             try:
                 # one low-side range scope per pass over the plan's own evidence words: the verdict kernel is the last launch of
                 # the recorded step, so every replay reports (and re-zeroes) for itself
-                with range_scope(self._range_slots):
+                with self.status.scope(), range_scope(self._range_slots):
                     out = self.fn(*self.inputs)
             finally:
                 if names is not None:
@@ -184,9 +187,9 @@ class StepPlan:
             ops.ARENA = prev
             ops.LAUNCH_HOOK = prev_hook
 
-    def run(self):
+    def run(self, check: bool = True):
         """Replay the step on the current stream (asynchronous); returns the recorded output tensor(s),
-        which the next run overwrites."""
+        which the next run overwrites.  ``check=False``: the caller settles range reports itself (pipeline.py)."""
         if self._gen != holders.PACK_GEN[0]:
             raise StalePlanError("StepPlan: model weights / placement changed since the plan was recorded; record a new plan")
         # in-place parameter updates (optimizer.step() on an eval-mode model, hand edits, `p.data = ...`) leave the generation
@@ -196,9 +199,14 @@ class StepPlan:
             if packing.state_version(module, device) != ver:
                 raise StalePlanError("StepPlan: a model's parameters were modified in place since the plan was recorded (its packed "
                                      "weights are stale); record a new plan")
-        check_range()           # f16x3 overflow reported by an earlier replay (host read, no synchronisation)
+        if check:
+            check_range()       # f16x3 overflow reported by an earlier replay (host read, no synchronisation)
         check(lib().dlip_plan_run(self._handle, torch.cuda.current_stream(self.device).cuda_stream), "dlip_plan_run")
         return self.outputs
+
+    def take_range_error(self):
+        """The range error the plan's completed replays reported since the last look (cleared), or None.  Host memory read."""
+        return self.status.take()
 
     def span_summary(self, reset: bool = True) -> dict:
         """Per kernel instance: launches per replay, replays seen, mean in-kernel span (first workgroup in -> last workgroup out,

@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn as nn
 
-from . import _lib, ops, packing
+from . import _lib, arith, ops, packing
 from .holders import BatchNormParams, ConvParams, LinearParams, Marker, PReLUParams
 
 Tensor = torch.Tensor
@@ -437,11 +437,19 @@ def _lengths_i32(lengths, device) -> Tensor:
 
 
 def _cached_pack(module: nn.Module, device, builder):
+    """The module's packed weights in the CURRENT arithmetic mode.  One slot per mode: the f16x3 pack a recorded plan addresses
+    and the f32 pack the auto mode re-runs an out-of-range batch on (deeplip_amd/arith.py) live side by side; a slot of the other
+    mode that was baked from older parameter values is dropped when this one is rebuilt."""
     ver = packing.state_version(module, device)
-    cache = module.__dict__.get("_dlip_pack")
+    caches = module.__dict__.get("_dlip_pack")
+    if caches is None:
+        caches = module.__dict__["_dlip_pack"] = {}
+    cache = caches.get(ver[2])
     if cache is None or cache[0] != ver:
+        for mode in [m for m, c in caches.items() if (c[0][0], c[0][1], c[0][3]) != (ver[0], ver[1], ver[3])]:
+            del caches[mode]
         cache = (ver, builder(device))
-        module.__dict__["_dlip_pack"] = cache
+        caches[ver[2]] = cache
     if ops.ARENA is not None:
         ops.ARENA.keep.append(cache[1])   # a recorded step addresses these weights: the plan keeps them alive
         ops.ARENA.modules[id(module)] = (module, device, ver)   # ... and checks on every replay that they still are the weights
@@ -508,6 +516,7 @@ class Lipreading(nn.Module):
             y = _tcn_block_train(blk, y, self.tcn_dropout)
         return ag.linear(av.time_mean(y, _lengths_i32(lengths, x.device)), self.tcn.tcn_output.weight, self.tcn.tcn_output.bias)
 
+    @arith.guarded_eval
     @_lib.scoped_eval
     def forward(self, x: Tensor, lengths, taps: Optional[dict] = None, pooled: bool = False, ragged: Optional[Tensor] = None,
                 clip_params: Optional[Tensor] = None):
@@ -572,6 +581,7 @@ class Lipreading(nn.Module):
         y = self.trunk.run(y, p["trunk"], None, x_split=True).view(B, T, self.backend_out)
         return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
 
+    @arith.guarded_eval
     def classifier_features(self, x: Tensor, lengths) -> Tensor:
         """[B,1,T,H,W] -> [B,768]: everything of forward() except the final tcn_output Linear (the
         input of the trainable classifier layer in train_video.py)."""
@@ -582,6 +592,7 @@ class Lipreading(nn.Module):
             self.extract_feats = ef
         return self.tcn.pooled(feats, lengths, _cached_pack(self, x.device, self._pack)["tcn"])
 
+    @arith.guarded_eval
     @_lib.scoped_eval
     def embed(self, x: Tensor, lengths=None, finish: bool = True):
         """[B,1,T,H,W] -> [B,512]: per-clip temporal mean of the features, the quantity the fusion

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 44
+#define DLIP_ABI_VERSION 45
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -287,7 +287,20 @@ int dlip_meanstd_pool_f32(const float* x, const int32_t* len, int32_t len_add, f
  * (from dlip_conv_nhwc_f32), e = relu(hidden).v + k, alpha = softmax over T, y [B,2C] = weighted mean |
  * sqrt(weighted E[x^2] - mean^2).  len / len_add: as dlip_meanstd_pool_f32 (softmax and statistics over the valid frames). */
 int dlip_attentive_stat_pool_f32(const float* x, const float* hidden, const float* v, const float* k, const int32_t* len,
-                                 int32_t len_add, float* y, int32_t B, int32_t T, int32_t C, int32_t Hd, dlip_stream_t stream);
+                                 int32_t len_add, float* y, float* alpha_out, int32_t B, int32_t T, int32_t C, int32_t Hd,
+                                 dlip_stream_t stream);
+/* (ABI 45) alpha_out (nullable, [B,T]) of the entry point above: the attention weights, kept for the backward pass (zeros behind a
+ * ragged utterance's end).  The backward of that tail for a training step (models/audio_models/pooling.py:87-107 under
+ * model.train(), selected by the config's `pooling: attentive_statistic`, tdnn.py:66-75; train_audio.py:185-200): from y [B,2C]
+ * and dy [B,2C], with g_q = ds / (2 s), g_m = dm - 2 m g_q:
+ *   dx [B,T,C]      = alpha_t (g_m + 2 x g_q)                              (the statistics' direct path; zeros in padding frames)
+ *   de [B,T]        = alpha_t (dalpha_t - sum_t' alpha_t' dalpha_t'),  dalpha_t = sum_c (g_m x + g_q x^2)
+ *   dhidden [B,T,Hd]= de_t v_j [hidden > 0]      (through the GEMM's own backward: dW, db and the second path into x)
+ *   rde [B,T,Hd]    = de_t relu(hidden)          (its column sums over B*T rows = dv; the sum of de = dk)
+ * One workgroup per utterance, fp64 wherever a sum runs over channels or frames; (2 C + T) * 4 bytes of LDS <= 60 KB. */
+int dlip_attentive_stat_pool_bwd_f32(const float* x, const float* hidden, const float* v, const float* alpha, const float* y,
+                                     const float* dy, const int32_t* len, int32_t len_add, float* dx, float* dhidden, float* rde,
+                                     float* de, int32_t B, int32_t T, int32_t C, int32_t Hd, dlip_stream_t stream);
 
 /* Layout adapters at the API boundary.
  *   dlip_nct_to_ntc_f32: x [B,C,T] (reference layout, tdnn.py:89) -> y [B,T,Cp] zero-padded to Cp>=C.
@@ -734,6 +747,13 @@ int dlip_mul_mask_f32(const float* x, const float* mask, float* y, int64_t n, fl
  * 3 reserved}, zeroed by the caller; NULL unregisters (nothing is reported).  One block per process (one process per GPU).
  * ------------------------------------------------------------------------------------------ */
 int dlip_set_status_words(int32_t* words);
+/* (ABI 45) A status block for the launches of the CALLING THREAD alone: until dlip_status_scope(NULL), every producer this thread
+ * launches (and the verdict kernel of a range scope it closes) reports to `words` (int32[8], host-pinned and device-visible, or
+ * device memory; zeroed by the caller) instead of the process-wide block.  The address is handed to the kernels per launch, so a step
+ * plan recorded inside such a scope reports to ITS block on every replay: the host can tell WHICH recorded batch left the range
+ * (deeplip_amd.pipeline: the offending batch is re-run on the exact "f32" pack of the same model, train_fusion.py:338-358 never
+ * saw it) where the process-wide block only says that one of the launches since the last look did. */
+int dlip_status_scope(int32_t* words);
 
 /* The LOW side of that range.  hi keeps 11 significant bits down to 6.1e-5, but lo = v - hi is a normal fp16 number only while
  * |v| >= 2^-3; below, lo sits on the subnormal grid 2^-24: an absolute error of up to 3e-8 per element, whatever its size.  Measured

@@ -16,6 +16,35 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: a long CPU-oracle leg (tens of seconds); runs by default")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _arith_baseline():
+    """The LIBRARY's default arithmetic is "auto" (f16x3 with an f32 re-run of what leaves its range: deeplip_amd/arith.py).  The
+    tests choose their modes explicitly -- packing.set_precision / arith.configure / $DLIP_ARITH per test or module -- and start from
+    the exact mode, as they always have: f32 packs, no fallback."""
+    os.environ.pop("DLIP_ARITH", None)
+    from deeplip_amd import arith
+    arith.configure("f32")
+    yield
+
+
+@pytest.fixture(autouse=True)
+def _arith_isolated():
+    """What a test (a Trainer, arith.configure) sets must not leak into the next one."""
+    from deeplip_amd import arith, autograd_video as av, packing
+    saved = (packing.PRECISION, arith.MODE, av.TRAIN_CONV, dict(arith.STATS))
+    yield
+    packing.set_precision(saved[0])
+    arith.MODE, av.TRAIN_CONV = saved[1], saved[2]
+    arith.STATS.update(saved[3])
+
+
+@pytest.fixture(params=["auto", "f32"])
+def arith_mode(request, monkeypatch):
+    """Entry-point tests run once per arithmetic mode: $DLIP_ARITH is what a Trainer's arith.configure() reads first."""
+    monkeypatch.setenv("DLIP_ARITH", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="session")
 def manifest():
     with open(os.path.join(GOLDEN, "manifest.json")) as f:
@@ -24,7 +53,7 @@ def manifest():
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: np.load(os.path.join(GOLDEN, f"{n}_golden.npz")) for n in ("video", "audio", "heads", "train", "audio_train", "video_train")}
+    return {n: np.load(os.path.join(GOLDEN, f"{n}_golden.npz")) for n in ("video", "audio", "heads", "train", "audio_train", "audio_attn_train", "video_train")}
 
 
 def rel_err(a, b):

@@ -332,6 +332,51 @@ def audio_train():
     print("audio_train:", {k: np.shape(v) for k, v in list(out.items())[:12]}, "...", len(out), "arrays")
 
 
+def audio_attn_train():
+    """Two optimisation steps of the speech encoder with ``pooling: attentive_statistic`` (tdnn.py:66-75; pooling.py:73-107) + LMCL,
+    composed as train_audio.py:167-183 composes them (model.train(), SGD lr 0.0001 / momentum 0.9 / wd 1e-5).  5-layer TDNN,
+    8 utterances x 120 frames x 24 MFCCs: the attention parameters W, b, v, k train with everything else."""
+    out = {}
+    opts = {"arch": "tdnn", "tdnn": {"input_dim": 24, "hidden_dim": [512] * 4 + [1500],
+                                     "context": [[-2, -1, 0, 1, 2], [-2, 0, 2], [-3, 0, 3], [0], [0]], "tdnn_layers": 5,
+                                     "embedding_dim": 512, "pooling": "attentive_statistic", "attention_hidden_size": 64, "bn_first": True}}
+    net = SpeakerEmbNet(opts)
+    crit = LMCL(512, 57, 30, 0.2)
+    fill(net, "attrain.audio."); fill(crit, "attrain.lmcl.")
+    net.train(); crit.train()
+    x = torch.from_numpy(wg.audio_input(8, 24, 120, key="attrain.x"))
+    lab = torch.from_numpy(wg.labels(8, 57))
+    # lr 0.0001, not the config's 0.01: from 0.002 up the reference's SECOND forward is NaN on these inputs -- one step at LMCL's s = 30
+    # sharpens the attention until some channel's weighted variance q - m^2 rounds below zero in fp32 and pooling.py:104 takes its
+    # square root (the reference has no floor there).  A golden must be finite to pin anything.
+    opt = torch.optim.SGD([{"params": net.parameters()}, {"params": crit.parameters()}], 0.0001, momentum=0.9, weight_decay=1e-5)
+    for step in range(2):
+        opt.zero_grad()
+        output = net(x)
+        loss, logits = crit(output, lab)
+        loss.backward()
+        if step == 0:
+            out["loss0"] = loss.detach().numpy(); out["logits0"] = logits.detach().numpy()
+            out["argmax0"] = torch.max(logits, dim=1)[1].numpy(); out["output0"] = output.detach().numpy()
+            g = {k: v.grad for k, v in net.named_parameters()}
+            for k in ("pooling.W", "pooling.b", "pooling.v", "pooling.k"):
+                out["grad_" + k] = g[k].numpy().copy()
+            out["grad_fc1_w_rows4"] = g["fc1.weight"][:4].numpy().copy()
+            out["grad_tdnn4_bn_w"] = g["tdnn.4.bn.weight"].numpy().copy()
+            for k, v in g.items():
+                out[f"gradnorm_{k}"] = np.array([float(v.double().norm()), float(v.double().sum())])
+        opt.step()
+    out["loss1"] = loss.detach().numpy()
+    for k, v in net.state_dict().items():
+        v = v.detach().double()
+        out[f"after2_{k}_sum"] = np.array([float(v.sum()), float(v.abs().sum())])
+    for k in ("pooling.W", "pooling.v", "pooling.k"):
+        out["after2_" + k] = dict(net.named_parameters())[k].detach().numpy().copy()
+    manifest["audio_attn_train"] = {k: list(np.shape(v)) for k, v in out.items()}
+    np.savez_compressed(os.path.join(HERE, "audio_attn_train_golden.npz"), **out)
+    print("audio_attn_train:", {k: np.shape(v) for k, v in list(out.items())[:10]}, "...", len(out), "arrays")
+
+
 def video_train():
     """One optimisation step of the FULL lip-clip model exactly as train_video.py:129-147 composes it
     (model.train(): batch-statistics BatchNorm in stem / trunk / TCN, learnable PReLU slopes; CrossEntropyLoss;
@@ -401,7 +446,7 @@ def video_train():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["video", "audio", "heads", "train", "audio_train", "video_train"]
+    which = sys.argv[1:] or ["video", "audio", "heads", "train", "audio_train", "audio_attn_train", "video_train"]
     mpath = os.path.join(HERE, "manifest.json")
     if os.path.exists(mpath):
         manifest.update(json.load(open(mpath)))

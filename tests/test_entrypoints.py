@@ -24,7 +24,7 @@ def test_train_video_cpu_plumbing(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["full", "full-rgb", "head-only", "c1-size"])
-def test_train_video_gpu_two_steps(tmp_path, mode):
+def test_train_video_gpu_two_steps(tmp_path, mode, arith_mode):
     """Default = full-model training as the reference does (model.train(), backward through stem / trunk / TCN on
     the engine); --head-only = classifier layer on frozen eval-mode features.  ``c1-size`` is BASELINE config C1's shape --
     conf/video_config.json, [4, (3 ->) 1, 29, 88, 88] from uint8 RGB, 54 classes, 2 optimisation steps -- whose "finite loss,
@@ -47,10 +47,11 @@ def test_train_video_graph_step(tmp_path, capsys):
     eager + recording + replays, per-iteration cosine learning rate read from a device tensor.  (That a replayed step is bit-
     identical to the eager one is tests/test_train_video_gpu.py::test_recorded_training_step_is_bit_identical_to_eager.)"""
     import train_video
-    loss, shape = train_video.main(["--save-path", str(tmp_path / "ck"), "--steps", "4", "--frames", "9", "--graph-step"])
+    loss, shape = train_video.main(["--save-path", str(tmp_path / "ck"), "--steps", "4", "--frames", "9"])      # recorded steps: the default
     assert np.isfinite(loss) and shape == (4, 54)
     out = capsys.readouterr().out
-    assert out.count("(replayed)") == 3
+    assert out.count("(replayed)") == 3 and "recorded steps: {'shapes': 1, 'recorded': 1" in out
+    assert train_video.train.last_stats["step_mode"] == "graph"
     lrs = [float(l.split(" lr ")[1].split()[0]) for l in out.splitlines() if l.startswith("epoch 0 it")]
     assert lrs == sorted(lrs, reverse=True) and lrs[0] < 3e-4 and lrs[-1] > 0           # the cosine schedule advanced every iteration
     sd = torch.load(tmp_path / "ck" / "1.pt", map_location="cpu")
@@ -60,7 +61,7 @@ def test_train_video_graph_step(tmp_path, capsys):
 
 
 @pytest.mark.gpu
-def test_train_audio_test_mode(tmp_path, monkeypatch):
+def test_train_audio_test_mode(tmp_path, monkeypatch, arith_mode):
     import train_audio
     monkeypatch.chdir(tmp_path)
     tr = train_audio.Trainer(overrides={"data.test_speakers": 4, "data.test_utt_per_spk": 3, "data.trials": 200,
@@ -71,6 +72,7 @@ def test_train_audio_test_mode(tmp_path, monkeypatch):
     assert not torch.equal(w0, tr.model.tdnn[0].context_layer.weight.detach())
     assert int(tr.model.tdnn[0].bn.num_batches_tracked) == 4 and int(tr.model.bn2.num_batches_tracked) == 4
     assert np.isfinite(tr.last_epoch_stats["loss"]) and tr.last_epoch_stats["utt_per_s"] > 0
+    assert tr.arith == arith_mode and tr.last_epoch_stats["step_mode"] == "graph"       # the recorded step is the default
     assert not tr.model.training                         # back in eval mode for extraction
     assert tr.model_average(2) == 2
     table = tr.extract_test_xv()
@@ -194,3 +196,52 @@ def test_train_audio_reference_method_names_and_av_test_flow(tmp_path, monkeypat
         assert torch.equal(w0, tr.model.tdnn[0].context_layer.weight.detach()) and not torch.equal(c0, tr.criterion.weights.detach())
     finally:
         se._process_paths.clear()
+
+
+@pytest.mark.gpu
+def test_train_video_eager_step_flag_and_ragged_shapes(tmp_path, capsys):
+    """--eager-step keeps the loop of eager launches; and a run whose batches come in two padded lengths records one step per
+    shape (pad_packed_collate pads to the batch's longest clip, dataset.py:123-139)."""
+    import train_video
+    loss, shape = train_video.main(["--save-path", str(tmp_path / "ck"), "--steps", "2", "--frames", "9", "--eager-step"])
+    assert np.isfinite(loss) and "(replayed)" not in capsys.readouterr().out
+    assert train_video.train.last_plan is None
+    orig = train_video.synthetic_batch
+
+    def two_lengths(args, it, rgb=False):
+        import copy
+        a = copy.copy(args)
+        a.frames = 9 if it % 2 == 0 else 7
+        return orig(a, it, rgb)
+
+    train_video.synthetic_batch = two_lengths
+    try:
+        loss, shape = train_video.main(["--save-path", str(tmp_path / "ck2"), "--steps", "6", "--frames", "9"])
+    finally:
+        train_video.synthetic_batch = orig
+    assert np.isfinite(loss)
+    assert train_video.train.last_plan.summary() == {"shapes": 2, "recorded": 2, "eager_only": []}
+
+
+@pytest.mark.gpu
+def test_train_audio_crop_ladder_records_one_step_per_length(tmp_path, monkeypatch):
+    """train.crop_frames: the collate's random crop (models/audio_models/datasets.py:112-115) drawn from a short ladder of
+    lengths, one recorded step per rung; the margin a recorded step bakes in is part of its key."""
+    import train_audio
+    monkeypatch.chdir(tmp_path)
+    tr = train_audio.Trainer(overrides={"data.test_speakers": 2, "data.test_utt_per_spk": 2, "data.audio_frames": 160, "data.n_spk": 6,
+                                        "data.utt_per_spk": 3, "train.bs": 8, "train.epoch": 1, "train.steps_per_epoch": 12,
+                                        "train.crop_frames": [100, 160], "train.margin": [0.2, 0.35]})
+    ladder = tr.crop_ladder()
+    assert ladder[-1] == 160 and ladder[0] >= 100 and all(b <= 1.1 * a + 4 for a, b in zip(ladder, ladder[1:])) and len(ladder) >= 4
+    tr.current_epoch = 1
+    tr._adjust_margin()
+    tr._train_epoch()
+    s1 = tr._steps.summary()
+    assert 2 <= s1["shapes"] <= len(ladder) and s1["eager_only"] == []
+    tr.current_epoch = 6                        # past epoch 5 the margin steps to its end value (train_audio.py:141-145): new recordings
+    tr._adjust_margin()
+    tr._train_epoch()
+    assert tr._steps.summary()["shapes"] > s1["shapes"]
+    assert np.isfinite(tr.last_epoch_stats["loss"]) and tr.last_epoch_stats["crop_ladder"] == [int(t) for t in ladder]
+    tr.close()

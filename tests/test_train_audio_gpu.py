@@ -198,6 +198,83 @@ def test_speaker_encoder_two_sgd_steps_vs_reference_golden(golden):
         assert abs(float(v.detach().double().abs().sum()) - ref[1]) < 1e-4 * max(ref[1], 1e-6), k
 
 
+@pytest.mark.parametrize("B,T,C,H", [(32, 278, 1500, 64), (3, 41, 64, 16)])
+def test_attentive_stat_pooling_forward_backward_vs_oracle_autograd(B, T, C, H):
+    """AttentiveStatPooling under model.train() (models/audio_models/pooling.py:87-107; `pooling: attentive_statistic`, tdnn.py:66-75)
+    at the size the E-TDNN feeds it ([32,1500,278]): output and the gradients of x, W, b, v, k against torch autograd of the oracle's
+    restatement in fp64.  (x is kept positive-ish with a real spread over frames so that no channel's weighted variance sits at
+    the fp32 cancellation floor, where the reference itself returns NaN.)"""
+    from deeplip_amd import autograd as ag
+    from models.audio_models.pooling import AttentiveStatPooling
+    from oracle import deeplip_oracle as O
+    pool = AttentiveStatPooling(C, H)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        pool.W.copy_(torch.randn(H, C, generator=g) / np.sqrt(C)); pool.b.copy_(torch.randn(1, H, generator=g) * 0.1)
+        pool.v.copy_(torch.randn(H, 1, generator=g) * 0.5); pool.k.copy_(torch.randn(1, 1, generator=g) * 0.1)
+    x = torch.randn(B, C, T, generator=g) * 0.8 + 0.3                      # reference layout [B,C,T]
+    dy = torch.randn(B, 2 * C, generator=g)
+    sd = {"pooling." + k: v.detach().double().clone().requires_grad_() for k, v in pool.named_parameters()}
+    xr = x.double().requires_grad_()
+    ref = O.attentive_stat_pooling(sd, "pooling", xr)
+    ref.backward(dy.double())
+    pool = pool.to(DEV)
+    xg = x.permute(0, 2, 1).contiguous().to(DEV).requires_grad_()          # engine layout [B,T,C]
+    y = ag.attentive_stat_pool(xg, pool)
+    y.backward(dy.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    assert rel_err(xg.grad.cpu().permute(0, 2, 1).numpy(), xr.grad.numpy()) < 1e-4
+    for k, p in pool.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), sd["pooling." + k].grad.numpy()) < 1e-4, k
+    # eval-mode forward of the same module (the golden-pinned kernel): same values
+    with torch.no_grad():
+        assert rel_err(pool.eval().run_ntc(xg.detach()).cpu().numpy(), ref.detach().numpy()) < 1e-5
+
+
+def test_attentive_speaker_encoder_two_sgd_steps_vs_reference_golden(golden):
+    """`pooling: attentive_statistic` trains: two SGD steps of SpeakerEmbNet + LMCL against values captured from the reference's own
+    classes (tests/golden/capture_golden.py: audio_attn_train; lr 1e-4 -- at the config's 0.01 the reference's second forward is NaN
+    on these inputs, see the capture script)."""
+    from models.audio_models.loss import LMCL
+    from models.audio_models.tdnn import SpeakerEmbNet
+    g = golden["audio_attn_train"]
+    opts = {"arch": "tdnn", "tdnn": {"input_dim": 24, "hidden_dim": [512] * 4 + [1500],
+                                     "context": [[-2, -1, 0, 1, 2], [-2, 0, 2], [-3, 0, 3], [0], [0]], "tdnn_layers": 5,
+                                     "embedding_dim": 512, "pooling": "attentive_statistic", "attention_hidden_size": 64, "bn_first": True}}
+    net = load(SpeakerEmbNet(opts), "attrain.audio.").train()
+    crit = load(LMCL(512, 57, 30, 0.2), "attrain.lmcl.").train()
+    x = torch.from_numpy(wg.audio_input(8, 24, 120, key="attrain.x")).to(DEV)
+    lab = torch.from_numpy(wg.labels(8, 57)).to(DEV)
+    opt = torch.optim.SGD([{"params": net.parameters()}, {"params": crit.parameters()}], 0.0001, momentum=0.9, weight_decay=1e-5)
+    for step in range(2):
+        opt.zero_grad()
+        output = net(x)
+        loss, logits = crit(output, lab)
+        loss.backward()
+        if step == 0:
+            assert abs(float(loss) - float(g["loss0"])) < 1e-4 * float(g["loss0"])
+            assert rel_err(output.detach().cpu().numpy(), g["output0"]) < 1e-4
+            assert rel_err(logits.detach().cpu().numpy(), g["logits0"]) < 1e-4
+            assert np.array_equal(torch.max(logits, 1)[1].cpu().numpy(), g["argmax0"])
+            gr = {k: v.grad for k, v in net.named_parameters()}
+            for k in ("pooling.W", "pooling.b", "pooling.v"):
+                assert rel_err(gr[k].cpu().numpy(), g["grad_" + k]) < 1e-3, k        # (through sqrt(q - m^2): fp32 cancellation on both sides)
+            assert abs(float(gr["pooling.k"])) < 1e-5                                  # softmax is shift-invariant: d/dk = 0 up to rounding
+            assert rel_err(gr["fc1.weight"][:4].cpu().numpy(), g["grad_fc1_w_rows4"]) < 1e-4
+            for k, v in gr.items():
+                ref = g[f"gradnorm_{k}"]
+                if ref[0] > 1e-5:
+                    assert abs(float(v.double().norm()) - ref[0]) < 2e-3 * ref[0], k
+        opt.step()
+    assert abs(float(loss) - float(g["loss1"])) < 1e-3 * max(1.0, float(g["loss1"]))
+    for k in ("pooling.W", "pooling.v"):
+        assert rel_err(dict(net.named_parameters())[k].detach().cpu().numpy(), g["after2_" + k]) < 1e-4, k
+    for k, v in net.state_dict().items():
+        ref = g[f"after2_{k}_sum"]
+        assert abs(float(v.detach().double().abs().sum()) - ref[1]) < 1e-4 * max(ref[1], 1e-6), k
+
+
 def test_full_size_training_step_vs_fp64_oracle():
     """The speech encoder's optimisation step at the size bench.py times it (configs.F2_train_audio_step: B = 256 utterances x 300
     frames x 24 features, E-TDNN, LMCL): loss and EVERY parameter's gradient against the oracle's train-mode restatement

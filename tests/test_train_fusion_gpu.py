@@ -10,7 +10,13 @@ pytestmark = pytest.mark.gpu
 SMALL = {"train.bs": 16, "train.epoch": 2, "train.steps_per_epoch": 3, "data.n_spk": 6, "data.utt_per_spk": 4,
          "data.test_speakers": 4, "data.test_utt_per_spk": 3, "data.trials": 300, "data.trial_targets": 60,
          "data.video_frames": 9, "data.audio_frames": 120, "data.test_audio_frames": [60, 120], "data.test_video_frames": [5, 12],
-         "data.test_clips_per_utt": 2}
+         "data.test_clips_per_utt": 2, "test.batch": 16}
+
+
+@pytest.fixture(autouse=True)
+def _modes(arith_mode):
+    """Every test of this file runs under arith ``auto`` (the shipped configuration: f16x3 + f32 re-run) and under exact ``f32``."""
+    return arith_mode
 
 
 @pytest.mark.parametrize("loss,fus", [("CrossEntropy", "linear"), ("LMCL", "concat")])
@@ -24,6 +30,7 @@ def test_train_mode_loss_falls(loss, fus, tmp_path, monkeypatch):
     tr.current_epoch = 2
     l1, a1 = tr._train_epoch()
     assert np.isfinite(l0) and np.isfinite(l1)
+    assert tr.last_epoch_stats["step_mode"] == "graph"      # the shipped config: encoders' plan + the head's recorded step
     if loss == "CrossEntropy":     # LMCL at s=30 on random-weight embeddings is too noisy over 3 batches
         assert l1 < l0
     p = tr.save()

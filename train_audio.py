@@ -32,14 +32,14 @@ import yaml
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from deeplip_amd import _lib, dist as ddist, ops, scoring, weightgen as wg  # noqa: E402
+from deeplip_amd import _lib, arith, dist as ddist, ops, scoring, weightgen as wg  # noqa: E402
 from deeplip_amd.synthetic import SyntheticAVSet, synthetic_trials  # noqa: E402
 from models.audio_models import tdnn  # noqa: E402
 from models.audio_models.loss import AAMSoftmax, LMCL, CrossEntropy  # noqa: E402
 
 
 class Trainer(object):
-    def __init__(self, config="conf/audio_config.yaml", overrides=None):
+    def __init__(self, config="conf/audio_config.yaml", overrides=None, arith_mode=None):
         with open(os.path.join(ROOT, config)) as f:
             opts = yaml.safe_load(f)
         for k, v in (overrides or {}).items():
@@ -50,6 +50,8 @@ class Trainer(object):
             d[leaf] = v
         self.train_opts, self.model_opts = opts["train"], opts["model"]
         self.data_opts, self.test_opts = opts["data"], opts["test"]
+        # the arithmetic of the engine (--arith > $DLIP_ARITH > model.arith > auto), before the first weight pack
+        self.arith = arith.configure(arith_mode, self.model_opts.get("arith"))
         if not torch.cuda.is_available():
             raise RuntimeError("train_audio.py needs a ROCm GPU: the deeplip_amd engine has no CPU path")
         self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
@@ -92,7 +94,13 @@ class Trainer(object):
         self.freeze_encoder = bool(self.train_opts.get("freeze_encoder", False))
         groups = [{"params": self.criterion.parameters()}] if self.freeze_encoder else \
                  [{"params": self.model.parameters()}, {"params": self.criterion.parameters()}]   # train_audio.py:112
-        self.optim = torch.optim.SGD(groups, o["init_lr"], momentum=o["momentum"], weight_decay=o["weight_decay"])
+        # train.graph_step (default on): the optimisation step is recorded once per crop length and replayed as one HIP graph
+        # (deeplip_amd/train_plan.py); a recorded step reads its learning rate from a device tensor, which MultiStepLR updates in
+        # place, and takes the fused SGD kernel.  train.graph_step: false keeps the loop of eager launches.
+        self.graph_step = bool(self.train_opts.get("graph_step", True)) and os.environ.get("DLIP_GRAPH_STEP", "1") != "0"
+        self.optim = self._make_sgd(groups, o)
+        self._steps = None          # ShapeKeyedSteps, built with the first recorded step
+        self._extractor = None      # one RaggedExtractor for every list and epoch of this trainer (its recorded plans are kept)
         self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optim, milestones=self.train_opts["lr_decay_step"], gamma=0.1)
         self.epoch, self.current_epoch = self.train_opts["epoch"], 0
         self.log_time = time.asctime(time.localtime(time.time())).replace(" ", "_")[4:]
@@ -102,6 +110,47 @@ class Trainer(object):
             self.log_time = name[0]
         ddist.broadcast_params(list(self.model.parameters()) + list(self.criterion.parameters()))
         self.buckets = None         # built on the first training step (gradient views need the final placement)
+
+    def _make_sgd(self, groups, o):
+        if self.graph_step:
+            return torch.optim.SGD(groups, lr=torch.tensor(float(o["init_lr"]), device=self.device), momentum=o["momentum"],
+                                   weight_decay=o["weight_decay"], fused=True)
+        return torch.optim.SGD(groups, o["init_lr"], momentum=o["momentum"], weight_decay=o["weight_decay"])
+
+    def crop_ladder(self):
+        """The crop lengths of the training batches.  The reference's collate cuts every batch to ONE random length of 200 .. 400
+        frames (models/audio_models/datasets.py:112-115); here that length is drawn from the short geometric ladder of
+        deeplip_amd.ragged.rung_tops over ``train.crop_frames`` (neighbouring lengths within ``train.crop_ladder_waste`` = 10 % of
+        each other, 8 rungs for 200 .. 400): one recorded step per rung.  No ``crop_frames``: every batch at ``data.audio_frames``."""
+        from deeplip_amd.ragged import rung_tops
+        cf = self.train_opts.get("crop_frames")
+        Ta = int(self.data_opts["audio_frames"])
+        if not cf:
+            return [Ta]
+        lo, hi = int(cf[0]), min(int(cf[1]), Ta)
+        lo = min(lo, hi)
+        need = (self.model.frames_consumed() + 2) if hasattr(self.model, "frames_consumed") else 1
+        if lo < need:
+            raise ValueError(f"train.crop_frames: the encoder needs utterances of >= {need} frames")
+        return rung_tops(lo, hi, float(self.train_opts.get("crop_ladder_waste", 0.10)), 4 if hi % 4 == 0 else 1)
+
+    def _one_step(self, x, lab):
+        """One optimisation step, launches only (what a recorded step replays): train_audio.py:185-200."""
+        if self.buckets is None:
+            self.optim.zero_grad(set_to_none=True)
+        else:
+            self.buckets.zero()
+        if self.freeze_encoder:
+            with torch.no_grad():
+                emb = self.model(x)
+        else:
+            emb = self.model(x)                       # output of bn2 / LeakyReLU (train_audio.py:187)
+        loss, logits = self.criterion(emb, lab)
+        loss.backward()                               # bucket all-reduces start as the gradients land
+        if self.buckets is not None:
+            self.buckets.finish()
+        self.optim.step()
+        return loss, logits
 
     def _adjust_margin(self):
         if isinstance(self.criterion, (LMCL, AAMSoftmax)):
@@ -116,29 +165,65 @@ class Trainer(object):
         if ddist.active() and self.buckets is None:
             params = [p for g in self.optim.param_groups for p in g["params"]]
             self.buckets = ddist.GradBuckets(params)
-        t0 = time.perf_counter()
         steps = self.train_opts.get("steps_per_epoch", 2)
-        for _ in range(steps):
-            idx = rng.integers(0, len(self.trainset), bs)
-            x = torch.from_numpy(self.trainset.audio(idx)).to(self.device)
-            lab = torch.from_numpy(self.trainset.labels(idx)).to(self.device)
-            self.optim.zero_grad(set_to_none=self.buckets is None)
-            if self.freeze_encoder:
-                with torch.no_grad():
-                    emb = self.model(x)
+        ladder = self.crop_ladder()
+        Ta = int(self.data_opts["audio_frames"])
+        recorded = self.graph_step and (self.buckets is None or os.environ.get("DLIP_GRAPH_WITH_BUCKETS", "1") != "0")
+        if recorded and self._steps is None:
+            from deeplip_amd.train_plan import ShapeKeyedSteps, grad_witness, step_state
+            mods = [self.criterion] if self.freeze_encoder else [self.model, self.criterion]
+            # (with GradBuckets the branches of a step stay on one stream: see train_video.py)
+            self._steps = ShapeKeyedSteps(self._one_step, eager_steps=1, device=self.device, branch_streams=self.buckets is None,
+                                          state=step_state(mods, [self.optim], self.buckets), witness=grad_witness(mods, self.buckets))
+        acc = torch.zeros(3, dtype=torch.float64, device=self.device)          # loss * n, correct, n: read once per epoch
+        copy_stream = torch.cuda.Stream(device=self.device)
+        cache = self.__dict__.setdefault("_batch_cache", {})
+        n_cache = int(self.train_opts.get("data_cache", 0) or 0)
+
+        def stage(i):
+            """Batch i -> the device, copies on their own stream behind the running step.  ``train.data_cache: N``: the synthetic
+            source's first N batches are generated once (pinned) and walked cyclically -- a run that measures the trainer, not numpy."""
+            k = (self.current_epoch, i) if n_cache <= 0 else i % n_cache
+            hb = cache.get(k) if n_cache > 0 else None
+            if hb is None:
+                idx = rng.integers(0, len(self.trainset), bs)
+                T = int(ladder[int(rng.integers(0, len(ladder)))])
+                t0_ = int(rng.integers(0, Ta - T + 1))
+                xb = np.ascontiguousarray(self.trainset.audio(idx)[:, :, t0_:t0_ + T])       # the batch's one crop (datasets.py:112-115)
+                hb = (torch.from_numpy(xb).pin_memory(), torch.from_numpy(self.trainset.labels(idx)).pin_memory())
+                if n_cache > 0:
+                    cache[k] = hb
+            with torch.cuda.stream(copy_stream):
+                x, lab = hb[0].to(self.device, non_blocking=True), hb[1].to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return x, lab, ev
+
+        staged = stage(0) if steps > 0 else None
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            x, lab, ev = staged
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            x.record_stream(cur); lab.record_stream(cur)
+            if recorded:
+                # keyed by the crop length (the shape) AND the margin the criterion bakes into the recorded launches
+                loss, logits = self._steps.step(x, lab, key=float(getattr(self.criterion, "margin", 0.0)))
             else:
-                emb = self.model(x)                       # output of bn2 / LeakyReLU (train_audio.py:187)
-            loss, logits = self.criterion(emb, lab)
-            loss.backward()                               # bucket all-reduces start as the gradients land
-            if self.buckets is not None:
-                self.buckets.finish()
-            self.optim.step()
-            correct += float((torch.max(logits, dim=1)[1] == lab).sum())
-            tot += float(loss.detach()) * len(idx); n += len(idx)
+                loss, logits = self._one_step(x, lab)
+            acc[0] += loss.detach().double() * x.shape[0]
+            acc[1] += (torch.max(logits.detach(), dim=1)[1] == lab).sum()
+            acc[2] += x.shape[0]
+            staged = stage(i + 1) if i + 1 < steps else None
+        if recorded:
+            self._steps.finish()
+        tot, correct, n = acc.tolist()
         _lib.check_range(sync=True)                       # f16x3 packing: an overflow in this epoch is an error, not a NaN
+        dt = time.perf_counter() - t0
         tot, correct, n = ddist.allreduce_metrics([tot, correct, n], self.device)
-        self.last_epoch_stats = {"loss": tot / n, "acc": correct / n, "utt_per_s": n / (time.perf_counter() - t0),
-                                 "steps": steps, "bs": bs * self.world}
+        self.last_epoch_stats = {"loss": tot / n, "acc": correct / n, "utt_per_s": n / dt, "steps": steps, "bs": bs * self.world,
+                                 "step_mode": (self._steps.mode if recorded else "eager"), "crop_ladder": [int(t) for t in ladder]}
         self.model.eval()
         return tot / n
 
@@ -212,15 +297,12 @@ class Trainer(object):
         with torch.no_grad():
             if dataset.ragged:
                 # utterances at their own lengths (train_audio.py:343-373 feeds them one by one): length-bucketed batches,
-                # every row equal to the one-at-a-time result (deeplip_amd/extract.py)
-                from deeplip_amd.extract import RaggedExtractor
+                # every row equal to the one-at-a-time result (deeplip_amd/extract.py).  ONE extractor per trainer: the plans it
+                # records (a dozen padded shapes x two input sets) serve every list and every epoch's evaluation.
                 D = self.model.embedding_dim
-                both = torch.empty((0, 2 * D), device=self.device)
-                ex = RaggedExtractor(lambda a, l: torch.cat(self.model.extract_embedding(a, lengths=l), dim=1), None, self.device, batch=batch)
-                try:
-                    both, _ = ex.run(dataset, 0, len(dataset), 2 * D)
-                finally:
-                    ex.close()
+                ex = self._ragged_extractor(batch)
+                both, _ = ex.run(dataset, 0, len(dataset), 2 * D)
+                self.extract_stats = dict(ex.stats)
                 xv, x_a = both[:, :D].contiguous(), both[:, D:].contiguous()
                 rows.append(x_a if ce else ops.l2_normalize(xv) if normalize else xv)
             else:
@@ -231,6 +313,29 @@ class Trainer(object):
         table = scoring.EmbeddingTable(dataset.utt_ids, torch.cat(rows))
         _lib.check_range(sync=True)       # a range report of the LAST batch must surface here, not at some later call
         return table
+
+    def _ragged_extractor(self, batch):
+        """The trainer's RaggedExtractor (built on first use, per batch size).  Its recorded plans address the model's packed
+        weights: a plan whose weights changed since (training, a checkpoint load) is stale -- the extractor is rebuilt then."""
+        from deeplip_amd import holders
+        from deeplip_amd.extract import RaggedExtractor
+        from deeplip_amd import packing
+        key = (int(batch), holders.PACK_GEN[0], packing.state_version(self.model, self.device))
+        if self._extractor is not None and self._extractor[0] != key:
+            self._extractor[1].close()
+            self._extractor = None
+        if self._extractor is None:
+            ex = RaggedExtractor(lambda a, l: torch.cat(self.model.extract_embedding(a, lengths=l), dim=1), None, self.device, batch=batch,
+                                 audio_min_frames=self.model.frames_consumed() + 2)
+            self._extractor = (key, ex)
+        return self._extractor[1]
+
+    def close(self):
+        """Release the recorded extraction plans (their arenas) and the recorded training steps."""
+        if self._extractor is not None:
+            self._extractor[1].close()
+            self._extractor = None
+        self._steps = None
 
     def _load_for_extract(self, avg_only=False):
         """train_audio.py:235-236,300-301 (net_avg.pth if the run has one) / :345-347,377-379 (``resume`` unless fine-tuning)."""
@@ -329,15 +434,19 @@ class Trainer(object):
         param_groups = [{"params": self.criterion.parameters()}]
         kind = self.train_opts.get("type", "sgd")
         if kind == "sgd":
-            o = self.train_opts["sgd"]
-            self.optim = torch.optim.SGD(param_groups, o["init_lr"], momentum=o["momentum"], weight_decay=o["weight_decay"])
+            self.optim = self._make_sgd(param_groups, self.train_opts["sgd"])
         elif kind == "adam":
             o = self.train_opts["adam"]
-            self.optim = torch.optim.Adam(param_groups, o["init_lr"], weight_decay=o["weight_decay"])
+            if self.graph_step:
+                self.optim = torch.optim.Adam(param_groups, lr=torch.tensor(float(o["init_lr"]), device=self.device),
+                                              weight_decay=o["weight_decay"], capturable=True, fused=True)
+            else:
+                self.optim = torch.optim.Adam(param_groups, o["init_lr"], weight_decay=o["weight_decay"])
         else:
             raise NotImplementedError(kind)
         self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optim, milestones=self.train_opts["lr_decay_step"], gamma=0.1)
         self.buckets = None
+        self._steps = None              # the recorded steps addressed the old optimizer's state
 
     def __call__(self):
         """train_audio.py:473-483."""
@@ -379,11 +488,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=None,
                     help="GPUs of this node, one process each (default: len(train.gpus_id), as the reference sizes nn.DataParallel: "
                          "train_audio.py:80-83)")
+    ap.add_argument("--eager-step", action="store_true",
+                    help="training: issue every launch of every step from Python instead of replaying one recorded HIP graph per crop "
+                         "length (train.graph_step: false)")
+    arith.add_argument(ap)
     a = ap.parse_args()
     rc = _self_launch(a.gpus, a.config, {k: yaml.safe_load(v) for k, v in (kv.split("=", 1) for kv in a.set)})
     if rc is not None:
         sys.exit(rc)
-    tr = Trainer(a.config, {k: yaml.safe_load(v) for k, v in (kv.split("=", 1) for kv in a.set)})
+    ov = {k: yaml.safe_load(v) for k, v in (kv.split("=", 1) for kv in a.set)}
+    if a.eager_step:
+        ov["train.graph_step"] = False
+    tr = Trainer(a.config, ov, arith_mode=a.arith)
     from models.audio_models import utils           # the scoring entry points, called as train_audio.py:499-543 calls them
 
     def report(fn):
@@ -413,6 +529,9 @@ def main():
                 report(getattr(utils, "eer_cos_" + name + ("_featurefusion" if a.mode == "av_fusion" else "")))
             if tr.test_opts.get("use_plda"):
                 report(getattr(utils, "eer_plda_" + name))
+    if tr.rank == 0 and arith.STATS["f32_reruns"]:
+        print("arith auto: {} batch(es) computed again in exact f32".format(arith.STATS["f32_reruns"]))
+    tr.close()
     if ddist.active():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

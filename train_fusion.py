@@ -39,7 +39,7 @@ from torch.optim import lr_scheduler
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from deeplip_amd import dist as ddist, fusion, ops, scoring  # noqa: E402
+from deeplip_amd import arith, dist as ddist, fusion, ops, scoring  # noqa: E402
 from deeplip_amd.synthetic import SyntheticAVSet, synthetic_trials  # noqa: E402
 from models.audio_models import tdnn  # noqa: E402
 from models.audio_models.loss import LMCL, CrossEntropy  # noqa: E402
@@ -48,7 +48,7 @@ from models.video_models.model import Lipreading  # noqa: E402
 
 
 class Trainer(object):
-    def __init__(self, mode, config="conf/fusion_config.yaml", overrides=None, dry=False):
+    def __init__(self, mode, config="conf/fusion_config.yaml", overrides=None, dry=False, arith_mode=None):
         with open(os.path.join(ROOT, config) if not os.path.isabs(config) else config) as f:
             opts = yaml.safe_load(f)
         for k, v in (overrides or {}).items():      # e.g. {"train.bs": 8}
@@ -60,6 +60,12 @@ class Trainer(object):
         self.train_opts, self.model_opts = opts["train"], opts["model"]
         self.data_opts, self.test_opts = opts["data"], opts["test"]
         self.mode = mode
+        self._extractor = None      # one RaggedExtractor for every list / epoch of this trainer (keeps its recorded plans)
+        self._host_cache = {} if self.test_opts.get("cache_host_batches", False) else None
+        self._steps = self._enc_pipe = self.buckets = None
+        self.graph_step = bool(self.train_opts.get("graph_step", True)) and os.environ.get("DLIP_GRAPH_STEP", "1") != "0" and not dry
+        if not dry:                 # the arithmetic of the engine (--arith > $DLIP_ARITH > model.arith > auto), before the first weight pack
+            self.arith = arith.configure(arith_mode, self.model_opts.get("arith"))
 
         self.rank, self.world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
         local = int(os.environ.get("LOCAL_RANK", 0))
@@ -154,7 +160,11 @@ class Trainer(object):
         param_groups = [{"params": list(self.model_fusion.parameters())}, {"params": self.criterion.parameters()}]
         if self.train_opts["optimizer"] == "sgd":
             o = self.train_opts["sgd"]
-            self.optim = optim.SGD(param_groups, o["init_lr"], momentum=o["momentum"], weight_decay=o["weight_decay"])
+            if self.graph_step:     # a recorded step reads its learning rate from a device tensor (MultiStepLR updates it in place)
+                self.optim = optim.SGD(param_groups, lr=torch.tensor(float(o["init_lr"]), device=self.device), momentum=o["momentum"],
+                                       weight_decay=o["weight_decay"], fused=True)
+            else:
+                self.optim = optim.SGD(param_groups, o["init_lr"], momentum=o["momentum"], weight_decay=o["weight_decay"])
         else:
             raise NotImplementedError(self.train_opts["optimizer"])
         self.epoch = self.train_opts["epoch"]
@@ -224,7 +234,107 @@ class Trainer(object):
             return
         ddist.allreduce_grads([p for g in self.optim.param_groups for p in g["params"]], self.world)   # one bucket (3.4 MB)
 
+    def _head_step(self, xv_audio, em_video, labels):
+        """The trainable part of a step (train_fusion.py:291-299): fusion head + criterion forward, backward, gradient all-reduce of
+        the 3.4 MB head, SGD -- launches only, so that it can be recorded once and replayed (deeplip_amd.train_plan)."""
+        if self.buckets is None:
+            self.optim.zero_grad(set_to_none=True)
+        else:
+            self.buckets.zero()
+        output = self._fuse(xv_audio, em_video)
+        loss, logits = self.criterion(output, labels)
+        loss.backward()
+        if self.buckets is not None:
+            self.buckets.finish()
+        self.optim.step()
+        return loss, logits
+
     def _train_epoch(self):
+        if self.dry or not self.graph_step:
+            return self._train_epoch_eager()
+        return self._train_epoch_recorded()
+
+    def _train_epoch_recorded(self):
+        """_train_epoch (train_fusion.py:241-315) as two replayed pieces per step: the frozen encoders' plan (deeplip_amd.pipeline:
+        the batch's host-to-device copies and the encoders run BEHIND the previous step's head; a batch that leaves the f16x3 range is
+        computed again in f32 under arith auto) and the head's recorded step (forward + backward + all-reduce + SGD, one HIP graph)."""
+        from deeplip_amd.pipeline import ExtractPipeline, pin
+        from deeplip_amd.train_plan import ShapeKeyedSteps, grad_witness, step_state
+        self.model_fusion.train()
+        self.model_audio.eval()
+        self.model_video.eval()
+        bs = self.train_opts["bs"]
+        steps = self.train_opts.get("steps_per_epoch", max(1, len(self.trainset) // (bs * self.world)))
+        rng = np.random.Generator(np.random.PCG64([self.current_epoch, 17]))
+        D = self.embedding_dim
+        heads = [m for m in (self.model_fusion, self.criterion) if isinstance(m, torch.nn.Module)]
+        if ddist.active() and self.buckets is None:
+            self.buckets = ddist.GradBuckets([p for g in self.optim.param_groups for p in g["params"]])     # one 3.4 MB bucket
+        if self._steps is None:
+            self._steps = ShapeKeyedSteps(self._head_step, eager_steps=1, device=self.device, branch_streams=False,
+                                          state=step_state(heads, [self.optim], self.buckets), witness=grad_witness(heads, self.buckets))
+        cache = self.__dict__.setdefault("_batch_cache", {})
+        n_cache = int(self.train_opts.get("data_cache", 0) or 0)
+
+        def host_batch(it):
+            # speaker-balanced sampling as the reference's sampler (datasets.py:161-164): idx % n_spk
+            glob = rng.integers(0, len(self.trainset), bs * self.world)
+            k = it % n_cache if n_cache > 0 else None
+            if k is not None and k in cache:
+                return cache[k]
+            idx = glob[self.rank * bs:(self.rank + 1) * bs]
+            clips, ptr = self.trainset.video(idx)
+            hb = (pin(torch.from_numpy(self.trainset.audio(idx))), pin(torch.from_numpy(clips)), pin(torch.from_numpy(ptr)),
+                  pin(torch.from_numpy(self.trainset.labels(idx))))
+            if k is not None:
+                cache[k] = hb
+            return hb
+
+        def encoders(audio, clips, ptr, labels):
+            xv_audio, _ = self.model_audio.extract_embedding(audio)                      # train_fusion.py:262
+            em_video = ops.group_mean(self.model_video.embed(clips), ptr)                # :267-281: mean over T, then over clip files
+            return xv_audio, em_video, labels
+
+        first = host_batch(0)
+        key = tuple(tuple(t.shape) for t in first)
+        if self._enc_pipe is not None and self._enc_pipe[0] != key:
+            self._enc_pipe[1].close()
+            self._enc_pipe = None
+        if self._enc_pipe is None:
+            with torch.no_grad():
+                self._enc_pipe = (key, ExtractPipeline(encoders, *(t.to(self.device) for t in first), device=self.device))
+        pipe = self._enc_pipe[1]
+        slots = [(torch.empty((bs, D), device=self.device), torch.empty((bs, D), device=self.device),
+                  torch.empty((bs,), dtype=torch.int64, device=self.device)) for _ in range(2)]
+        acc = torch.zeros(3, dtype=torch.float64, device=self.device)
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        cur = torch.cuda.current_stream(self.device)
+        with torch.no_grad():
+            pipe.submit(first, slots[0], 0)
+        for it in range(steps):
+            pipe.finish()                                    # batch `it` is through the encoders (and inside the arithmetic's range)
+            xv_audio, em_video, labels = slots[it % 2]
+            if it + 1 < steps:
+                pipe.run_stream.wait_stream(cur)             # the slot it overwrites was read by step it - 1, already ordered on `cur`
+                with torch.no_grad():
+                    pipe.submit(host_batch(it + 1), slots[(it + 1) % 2], 0)
+            loss, logits = self._steps.step(xv_audio, em_video, labels, key=float(getattr(self.criterion, "margin", 0.0)))
+            acc[0] += loss.detach().double() * bs
+            acc[1] += (torch.max(logits.detach(), dim=1)[1] == labels).sum()
+            acc[2] += bs
+        self._steps.finish()
+        sum_loss, correct, sum_samples = acc.tolist()
+        dt = time.perf_counter() - t0
+        tot = ddist.allreduce_metrics([sum_loss, correct, sum_samples], self.device)
+        self.last_epoch_stats = {"loss": tot[0] / tot[2], "acc": tot[1] / tot[2], "pairs_per_s": tot[2] / dt, "steps": steps,
+                                 "step_mode": self._steps.mode, "ms_per_step": 1e3 * dt / max(steps, 1)}
+        if self.rank == 0:
+            print("Epoch {} loss {:.4f} acc {:.2f}% | {:.1f} A+V pairs/s on {} GPU(s) [{}]".format(
+                self.current_epoch, tot[0] / tot[2], 100.0 * tot[1] / tot[2], tot[2] / dt, self.world, self._steps.mode), flush=True)
+        return tot[0] / tot[2], tot[1] / tot[2]
+
+    def _train_epoch_eager(self):
         self.model_fusion.train()
         if not self.dry:
             self.model_audio.eval()
@@ -253,6 +363,8 @@ class Trainer(object):
             correct += float((prediction == labels).sum())
         tot = ddist.allreduce_metrics([sum_loss, correct, sum_samples], self.device)
         dt = time.perf_counter() - t0
+        self.last_epoch_stats = {"loss": tot[0] / tot[2], "acc": tot[1] / tot[2], "pairs_per_s": tot[2] / dt, "steps": steps,
+                                 "step_mode": "eager", "ms_per_step": 1e3 * dt / max(steps, 1)}
         if self.rank == 0:
             print("Epoch {} loss {:.4f} acc {:.2f}% | {:.1f} A+V pairs/s on {} GPU(s)".format(
                 self.current_epoch, tot[0] / tot[2], 100.0 * tot[1] / tot[2], tot[2] / dt, self.world), flush=True)
@@ -313,13 +425,45 @@ class Trainer(object):
             m.eval()
 
     # ------------------------------------------------------------------ test-time extraction + scoring
-    def _extract(self, dataset, batch=32):
+    def _ragged_extractor(self, batch):
+        """The trainer's RaggedExtractor, built on first use and kept: the plans it records (a dozen padded shapes x two input sets
+        per encoder) serve both test lists and every later evaluation.  Rebuilt when the encoders' weights changed since (its plans
+        address their packed weights) or the batch size did."""
+        from deeplip_amd import holders, packing
+        from deeplip_amd.extract import RaggedExtractor
+        key = (int(batch), holders.PACK_GEN[0], packing.state_version(self.model_audio, self.device), packing.state_version(self.model_video, self.device))
+        if self._extractor is not None and self._extractor[0] != key:
+            self._extractor[1].close()
+            self._extractor = None
+        if self._extractor is None:
+            ex = RaggedExtractor(lambda a, l: self.model_audio.extract_embedding(a, lengths=l)[0],          # train_fusion.py:338
+                                 lambda v, l: self.model_video.embed(v, lengths=l),                        # :346-348 (mean over T)
+                                 self.device, batch=batch, audio_min_frames=self.model_audio.frames_consumed() + 2,
+                                 max_arena_bytes=int(self.test_opts.get("max_arena_gb", 64)) << 30)
+            self._extractor = (key, ex)
+        return self._extractor[1]
+
+    def close(self):
+        """Release the recorded plans (extraction arenas, the training pipeline) this trainer holds."""
+        if self._extractor is not None:
+            self._extractor[1].close()
+            self._extractor = None
+        if self._enc_pipe is not None:
+            self._enc_pipe[1].close()
+            self._enc_pipe = None
+        self._steps = None
+
+    def _extract(self, dataset, batch=None):
         """Sharded over ranks; returns (EmbeddingTable of fused [N,1024], audio-only table, video-only table).  The reference
         walks the list one utterance at a time with a `.to(device)` in front of every forward (train_fusion.py:338-358); here
-        the rank's shard streams through deeplip_amd.pipeline.ExtractPipeline: batches of `batch` utterances, the host-to-device
-        copies of batch i+1 behind the replay of batch i (two input sets, one recorded plan each), the embeddings left in HBM."""
+        the rank's shard streams through deeplip_amd.pipeline.ExtractPipeline: batches of `batch` utterances (``test.batch``), the
+        host-to-device copies of batch i+1 behind the replay of batch i (two input sets, one recorded plan each), the embeddings
+        left in HBM.  ``test.frames: u8``: the lip clips travel as the uint8 RGB frames a loader holds ([B,T,3,88,88], BASELINE.json's
+        input shape; a quarter of the bytes) and are normalised by the stem's pre-pass."""
         from deeplip_amd import _lib
         from deeplip_amd.pipeline import ExtractPipeline, pin
+        batch = int(batch or self.test_opts.get("batch", 64))
+        u8 = str(self.test_opts.get("frames", "f32")).lower() == "u8"
         lo, hi = ddist.shard_range(len(dataset))
         D = self.embedding_dim
         n_loc = hi - lo
@@ -328,15 +472,12 @@ class Trainer(object):
         if n_loc and dataset.ragged:
             # utterances / clips of differing length: length-bucketed batches, one recorded plan per padded shape, every row
             # equal to the reference's one-at-a-time result (deeplip_amd/extract.py, tests/test_ragged_gpu.py)
-            from deeplip_amd.extract import RaggedExtractor
-            ex = RaggedExtractor(lambda a, l: self.model_audio.extract_embedding(a, lengths=l)[0],          # train_fusion.py:338
-                                 lambda v, l: self.model_video.embed(v, lengths=l),                        # :346-348 (mean over T)
-                                 self.device, batch=batch)
-            try:
-                xa, xv = ex.run(dataset, lo, hi, D)                                                        # :349 inside (clip-group mean)
-            finally:
-                ex.close()
-            self.extract_stats = ex.stats
+            ex = self._ragged_extractor(batch)
+            hc = None
+            if self._host_cache is not None:           # test.cache_host_batches: a second pass over a list re-uses its pinned batches
+                hc = self._host_cache.setdefault(id(dataset), {})
+            xa, xv = ex.run(dataset, lo, hi, D, u8=u8, host_cache=hc)                                      # :349 inside (clip-group mean)
+            self.extract_stats = dict(ex.stats)
         elif n_loc:
             cpu = dataset.clips                        # clips per utterance (constant over a synthetic set)
 
@@ -345,6 +486,9 @@ class Trainer(object):
                 clips, ptr = dataset.video(idx)
                 ptr_full = np.full((batch + 1,), ptr[-1], dtype=np.int32)      # a short batch: empty groups behind its last one
                 ptr_full[:len(ptr)] = ptr
+                if u8:
+                    from deeplip_amd.synthetic import frames_u8_from_clips
+                    clips = frames_u8_from_clips(clips, rgb=True)
                 return (pin(torch.from_numpy(dataset.audio(idx))), pin(torch.from_numpy(clips)), pin(torch.from_numpy(ptr_full)))
 
             def step(audio, clips, ptr):
@@ -354,7 +498,7 @@ class Trainer(object):
 
             first = host_batch(lo)
             full = tuple(torch.zeros((batch,) + tuple(first[0].shape[1:])) if i == 0 else
-                         torch.zeros((batch * cpu,) + tuple(first[1].shape[1:])) if i == 1 else first[2].clone() for i in range(3))
+                         torch.zeros((batch * cpu,) + tuple(first[1].shape[1:]), dtype=first[1].dtype) if i == 1 else first[2].clone() for i in range(3))
             for dst, src in zip(full[:2], first[:2]):
                 dst[:src.shape[0]] = src                                               # the plan is recorded on representative values
             with torch.no_grad():
@@ -471,11 +615,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=None,
                     help="GPUs of this node to use, one process each (default: len(train.gpus_id) of the config, as the "
                          "reference sizes nn.DataParallel: train_fusion.py:88-93)")
+    ap.add_argument("--eager-step", action="store_true",
+                    help="--mode train: issue every launch of every step from Python instead of replaying the recorded encoder plan + "
+                         "the recorded head step (train.graph_step: false)")
+    arith.add_argument(ap)
     args = ap.parse_args()
     ov = {}
     for kv in args.set:
         k, v = kv.split("=", 1)
         ov[k] = yaml.safe_load(v)
+    if args.eager_step:
+        ov["train.graph_step"] = False
     rc = _self_launch(args.gpus, args.config, ov, "train.gpus_id")
     if rc is not None:
         sys.exit(rc)
@@ -494,7 +644,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    trainer = Trainer(args.mode, args.config, ov)
+    trainer = Trainer(args.mode, args.config, ov, arith_mode=args.arith)
     from models.fusion_models import utils          # the scoring entry points, called as train_fusion.py:430-469 calls them
 
     def report(fn):
@@ -519,6 +669,9 @@ def main():
                 report(getattr(utils, "eer_cos_" + name + ("" if args.mode == "av_test" else "_scorefusion")))
             if trainer.test_opts["use_plda"]:
                 report(getattr(utils, "eer_plda_" + name))
+    if trainer.rank == 0 and arith.STATS["f32_reruns"]:
+        print("arith auto: {} batch(es) computed again in exact f32".format(arith.STATS["f32_reruns"]))
+    trainer.close()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -76,8 +76,15 @@ def load_args(argv=None):
     p.add_argument("--frame-size", type=int, default=96, help="side of the synthetic uint8 mouth crops (LRW ROIs are 96 x 96)")
     p.add_argument("--head-only", action="store_true", help="train tcn.tcn_output on frozen eval-mode features")
     p.add_argument("--graph-step", action="store_true",
-                   help="record the optimisation step once and replay it as one HIP graph (deeplip_amd.train_plan.TrainStepGraph: "
-                        "full-model training on one GPU; batches of one shape)")
+                   help="(the default since round 6; kept for old command lines) record the optimisation step and replay it as one HIP graph")
+    p.add_argument("--eager-step", action="store_true",
+                   help="issue every launch of every step from Python instead of replaying a recorded step (deeplip_amd.train_plan: one "
+                        "recorded HIP graph per batch shape, recorded the second time a shape is met; the default for full-model training)")
+    p.add_argument("--data-cache", type=int, default=0, metavar="N",
+                   help="synthetic source: generate N batches once, keep them in pinned host memory and cycle through them (the numpy "
+                        "generator makes ~30 clips/s; a run that measures the TRAINER rather than the generator uses this)")
+    from deeplip_amd import arith
+    arith.add_argument(p)
     return p.parse_args(argv)
 
 
@@ -147,7 +154,7 @@ def train(model, args, device):
     buckets = ddist.GradBuckets(params) if (ddist.active() and device.type != "cpu") else None
     # (with GradBuckets the recorded step contains the bucket all-reduces -- RCCL collectives captured into the graph: exercised at one
     # rank by tests/test_rccl_gpu.py; DLIP_GRAPH_WITH_BUCKETS=0 keeps data-parallel runs on the eager loop)
-    graph_step = bool(getattr(args, "graph_step", False)) and full and (buckets is None or os.environ.get("DLIP_GRAPH_WITH_BUCKETS", "1") != "0")
+    graph_step = not bool(getattr(args, "eager_step", False)) and full and (buckets is None or os.environ.get("DLIP_GRAPH_WITH_BUCKETS", "1") != "0")
     if graph_step:      # a recorded step reads its learning rate from a device tensor (the scheduler updates it in place)
         optimizer = torch.optim.Adam(params, lr=torch.tensor(float(args.lr), device=device), weight_decay=1e-4, capturable=True, fused=True)
     else:
@@ -162,7 +169,7 @@ def train(model, args, device):
               "--device gpu computes them (C1-size run: tests/test_entrypoints.py::test_train_video_gpu_two_steps[c1-size]).")
     plan = None
     if graph_step:
-        from deeplip_amd.train_plan import TrainStepGraph
+        from deeplip_amd.train_plan import ShapeKeyedSteps, grad_witness, step_state
 
         def one_step(xb, lb, ln):
             if buckets is None:
@@ -177,67 +184,147 @@ def train(model, args, device):
             optimizer.step()
             return ls, lg
 
+        # One recorded step per batch shape (pad_packed_collate pads to the batch's longest clip, dataset.py:123-139: a run meets a
+        # few shapes); a shape's first step runs eagerly, its second records.  In a job of several ranks the first replay is
+        # checked against an eager step from the same state and the run falls back to eager steps on any doubt (train_plan.py).
         # (with GradBuckets the branches stay on one stream: a bucket's all-reduce is enqueued behind the CURRENT stream of the hook
         # that completes it, and would not wait for gradients another branch stream is still writing)
-        plan = TrainStepGraph(one_step, eager_steps=1, device=device, branch_streams=buckets is None)
+        plan = ShapeKeyedSteps(one_step, eager_steps=1, device=device, branch_streams=buckets is None,
+                               state=step_state([model], [optimizer], buckets), witness=grad_witness([model], buckets))
+    source = _BatchSource(args, world, rank, device)
+    copy_stream = torch.cuda.Stream(device=device) if device.type != "cpu" else None
+
+    def stage(i):
+        """Batch i on the device: host batch (generated, or from the --data-cache ring) -> asynchronous copies on the copy stream,
+        behind the step that is running.  The reference's loop does `.cuda()` in front of every forward (train_video.py:125)."""
+        nonlocal frontend
+        inputs, lengths, labels = source.get(i)
+        cur = torch.cuda.current_stream(device)
+        with torch.cuda.stream(copy_stream):
+            lab = labels.to(device, non_blocking=True)
+            ln = torch.as_tensor(lengths, dtype=torch.int32).to(device, non_blocking=True)
+            raw = inputs.to(device, non_blocking=True)
+            cp = None
+            if args.rgb and full:
+                cp = torch.from_numpy(ops.draw_clip_params(inputs.shape[0], inputs.shape[-2], inputs.shape[-1], 88, rng=aug_rng)).to(device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        return raw, lab, ln, cp, lengths, ev
+
+    total_steps = int(args.maxepoch) * args.steps
+    staged = stage(0) if device.type != "cpu" and total_steps > 0 else None
+    acc = torch.zeros(3, dtype=torch.float64, device=device) if device.type != "cpu" else None      # sum loss*n, correct, n: read at display time only
+    last_loss = last_shape = None
+    # throughput of the loop as it runs: counted from the 4th step on (a shape's first step is eager, its second records and replays)
+    import time
+    mark_at, t_mark, t_end = min(3, max(total_steps - 1, 0)), None, None
     for epoch in range(int(args.maxepoch)):
-        run_loss = run_ok = run_n = 0.0
+        if acc is not None:
+            acc.zero_()
         model.train() if full else model.eval()                                                # (:129)
         for it in range(args.steps):
-            inputs, lengths, labels = synthetic_batch(args, (epoch * args.steps + it) * world + rank, args.rgb)
+            gi = epoch * args.steps + it
             if device.type == "cpu":
+                inputs, lengths, labels = source.get(gi)
                 print(f"[plumbing] batch {tuple(inputs.shape)} lengths {lengths} labels {labels.tolist()} lr {sched.get_last_lr()}")
                 optimizer.step(); sched.step()
                 continue
-            labels = labels.to(device)
+            if gi == mark_at:
+                torch.cuda.synchronize(device)
+                t_mark = time.perf_counter()
+            raw, labels, ln, cp, lengths, ev = staged
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(ev)
+            for t in (raw, labels, ln, cp):
+                if t is not None:
+                    t.record_stream(cur)
             if args.rgb:
                 # uint8 frames -> normalised 88 x 88 gray clips on the GPU: RandomCrop + HorizontalFlip per clip while the model
                 # trains (dataloaders.py:13-17), CenterCrop otherwise (:19-24); padding frames = zeros of the normalised clip
                 from deeplip_amd.frontend import VideoFrontend
                 frontend = frontend or VideoFrontend(88)
-                cp = None
-                if full:
-                    cp = torch.from_numpy(ops.draw_clip_params(inputs.shape[0], inputs.shape[-2], inputs.shape[-1], 88, rng=aug_rng)).to(device)
-                x = frontend(inputs.to(device), clip_params=cp, lengths=torch.as_tensor(lengths, dtype=torch.int32).to(device))
+                x = frontend(raw, clip_params=cp, lengths=ln)
             else:
-                x = inputs.unsqueeze(1).to(device)                                                      # :125
+                x = raw.unsqueeze(1)                                                                    # :125
             if plan is not None:
-                loss, logits = plan.step(x.contiguous(), labels, torch.as_tensor(lengths, dtype=torch.int32).to(device))
-                sched.step()
-                plan.finish()
-                _, pred = torch.max(torch.softmax(logits.detach(), 1), 1)
-                run_loss += float(loss.detach()) * len(labels); run_ok += float((pred == labels).sum()); run_n += len(labels)
-                last = (float(loss.detach()), tuple(logits.shape))
-                if it % args.display == 0 and rank == 0:
-                    print(f"epoch {epoch} it {it} loss {run_loss / run_n:.4f} acc {run_ok / run_n:.3f} lr {float(sched.get_last_lr()[0]):.2e}"
-                          f"{' (replayed)' if plan.recorded else ''}", flush=True)
-                continue
-            optimizer.zero_grad(set_to_none=buckets is None)
-            if full:
-                logits = model(x, lengths=lengths)                          # (:140) whole graph on the engine
+                loss, logits = plan.step(x.contiguous(), labels, ln)
             else:
-                with torch.no_grad():
-                    pooled = model.classifier_features(x, lengths)         # frozen stem + trunk + MS-TCN
-                logits = ag.linear(pooled, head.weight, head.bias)          # tcn_output (model.py:27)
-            loss = ag.margin_ce_loss(logits, labels, 1.0, 0.0)              # nn.CrossEntropyLoss (:115,143)
-            loss.backward()
-            if buckets is not None:
-                buckets.finish()                                            # wait for the bucket all-reduces, average
-            optimizer.step()
-            sched.step()                                                    # per-iteration (:147)
-            _, pred = torch.max(torch.softmax(logits.detach(), 1), 1)       # (:145)
-            run_loss += float(loss.detach()) * len(labels); run_ok += float((pred == labels).sum()); run_n += len(labels)
-            last = (float(loss.detach()), tuple(logits.shape))
-            if it % args.display == 0 and rank == 0:
-                print(f"epoch {epoch} it {it} loss {run_loss / run_n:.4f} acc {run_ok / run_n:.3f} lr {sched.get_last_lr()[0]:.2e}", flush=True)
+                optimizer.zero_grad(set_to_none=buckets is None)
+                if full:
+                    logits = model(x, lengths=lengths)                          # (:140) whole graph on the engine
+                else:
+                    with torch.no_grad():
+                        pooled = model.classifier_features(x, lengths)         # frozen stem + trunk + MS-TCN
+                    logits = ag.linear(pooled, head.weight, head.bias)          # tcn_output (model.py:27)
+                loss = ag.margin_ce_loss(logits, labels, 1.0, 0.0)              # nn.CrossEntropyLoss (:115,143)
+                loss.backward()
+                if buckets is not None:
+                    buckets.finish()                                            # wait for the bucket all-reduces, average
+                optimizer.step()
+            sched.step()                                                        # per-iteration (:147)
+            # metrics stay on the device (a recorded step's outputs are rewritten by the next replay: folded in right behind it)
+            n_b = labels.shape[0]
+            _, pred = torch.max(torch.softmax(logits.detach(), 1), 1)           # (:145)
+            acc[0] += loss.detach().double() * n_b
+            acc[1] += (pred == labels).sum()
+            acc[2] += n_b
+            last_loss, last_shape = loss.detach().clone(), tuple(logits.shape)
+            staged = stage(gi + 1) if gi + 1 < total_steps else None            # the next batch's copies run behind this step
+            if it % args.display == 0 or it + 1 == args.steps:
+                if plan is not None:
+                    plan.finish()                                               # waits; a range report of the f16x3 arithmetic surfaces here
+                a0, a1, a2 = acc.tolist()
+                if rank == 0 and it % args.display == 0:
+                    print(f"epoch {epoch} it {it} loss {a0 / a2:.4f} acc {a1 / a2:.3f} lr {float(sched.get_last_lr()[0]):.2e}"
+                          f"{' (replayed)' if plan is not None and plan.last.recorded else ''}", flush=True)
+        if device.type != "cpu" and epoch + 1 == int(args.maxepoch):
+            torch.cuda.synchronize(device)
+            t_end = time.perf_counter()                                                        # (the checkpoint below is not a step)
         if rank == 0:
             os.makedirs(args.save_path, exist_ok=True)
             torch.save(model.state_dict(), os.path.join(args.save_path, f"{epoch + 1}.pt"))  # (:169)
+    last = (float(last_loss), last_shape) if last_loss is not None else None
+    train.last_stats = None
+    if t_mark is not None and total_steps > mark_at and t_end is not None:
+        dt = t_end - t_mark
+        n = (total_steps - mark_at) * args.batch_size * world
+        train.last_stats = {"clips_per_s": n / dt, "ms_per_step": 1e3 * dt / (total_steps - mark_at), "steps_timed": total_steps - mark_at,
+                            "step_mode": plan.mode if plan is not None else "eager", "global_batch": args.batch_size * world}
+        if rank == 0:
+            print("train: {:.1f} clips/s, {:.2f} ms/step over the last {} steps [{}]".format(
+                train.last_stats["clips_per_s"], train.last_stats["ms_per_step"], total_steps - mark_at, train.last_stats["step_mode"]), flush=True)
+    if rank == 0 and device.type != "cpu":
+        how = ("recorded steps: " + str(plan.summary())) if plan is not None else "eager steps"
+        print(f"train: {how}", flush=True)
+    train.last_plan = plan
     return last
+
+
+class _BatchSource:
+    """The synthetic loader behind train(): ``get(i)`` -> (inputs, lengths, labels) of iteration i as pad_packed_collate hands them
+    over (dataset.py:123-139).  ``--data-cache N``: the first N batches are generated once, pinned, and walked cyclically."""
+
+    def __init__(self, args, world, rank, device):
+        self.args, self.world, self.rank = args, world, rank
+        self.n = int(getattr(args, "data_cache", 0) or 0)
+        self.cache = {}
+        self.pin = device.type != "cpu"
+
+    def get(self, i):
+        k = i % self.n if self.n > 0 else i
+        if k in self.cache:
+            return self.cache[k]
+        b = synthetic_batch(self.args, k * self.world + self.rank, self.args.rgb)
+        if self.n > 0:
+            b = (b[0].pin_memory() if self.pin else b[0], b[1], b[2])
+            self.cache[k] = b
+        return b
 
 
 def main(argv=None):
     args = load_args(argv)
+    from deeplip_amd import arith
+    mode = arith.configure(args.arith, load_json(args.config_path).get("arith"))     # before the first weight pack
     if args.device == "gpu" and args.gpus > 1:
         from deeplip_amd import launch
         rc = launch.maybe_self_launch(os.path.abspath(__file__), list(sys.argv[1:] if argv is None else argv), args.gpus)
