@@ -557,7 +557,7 @@ def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan, c5_all=Non
         guarded("C4_ragged_extraction", lambda: c4_ragged(out["C4_fusion_scoring"]))
     in_job = dist.is_available() and dist.is_initialized()
     if c5_all is not None:
-        out["C5_fusion_train_step"] = c5_all     # a job of several ranks: EVERY rank ran the trainer's epoch (main(), before this)
+        out["C5_fusion_train_step"] = c5_all     # a job of several ranks: EVERY rank runs the trainer's epoch at the end of main()
     else:
         guarded("C5_fusion_train_step", lambda: c5_entry(args))
     guarded("F2_train_video_step", f2_video)
@@ -607,7 +607,7 @@ def c5_entry(args):
             st = dict(tr.last_epoch_stats)
             # where a step's time goes: the two recorded pieces replayed alone
             pipe, steps = tr._enc_pipe[1], tr._steps.last
-            enc_ms = _timed_replay(lambda: pipe.plans[0].run(check=False), st_, wu, sync)
+            enc_ms = _timed_replay(lambda: pipe.plans[0].run(check_reports=False), st_, wu, sync)
             head_ms = None
             if steps.recorded:
                 xs = [t.clone() for t in steps.static]
@@ -690,6 +690,8 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="issue the two encoders in sequence on one stream (default: the "
                     "speech encoder on a second stream, fork / join recorded into the step plan)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--dp-leg-timeout", type=int, default=240, help="N > 1: seconds the DP training leg (C5 on every rank) may take before the "
+                    "watchdog prints the line without it")
     ap.add_argument("--no-entry-points", action="store_true", help="skip the entry-point lines (E1..E3: the trainers driven as a user drives them)")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configurations (C2..C5) reported under `configs`")
     ap.add_argument("--eager", action="store_true",
@@ -988,18 +990,8 @@ def main():
 
     main_fields, video, audio, sds = measure(args.precision)
     configs = None
-    c5_all = None
-    if dist_on and not args.no_configs:
-        # BASELINE configs[4] inside a scaling run: train_fusion.Trainer's DP epoch on EVERY rank (gradient bucket all-reduced over
-        # RCCL inside the head's recorded step).  `step_mode` says whether the recorded step or eager steps ran -- at more than one
-        # rank the first replay is checked against an eager step from the same state and dropped on any doubt (train_plan.py).
-        try:
-            c5_all = c5_entry(args)
-            c5_all["ranks"] = world
-        except Exception as ex:   # noqa: BLE001
-            c5_all = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if rank == 0 and not args.no_configs:
-        configs = extra_configs(args, device, video, audio, xv, xa, main_fields["peak"], StepPlan, c5_all)
+        configs = extra_configs(args, device, video, audio, xv, xa, main_fields["peak"], StepPlan, {"pending": True} if dist_on else None)
     if dist_on:
         dist.barrier()
     alt = None
@@ -1009,6 +1001,7 @@ def main():
         alt = (alt_prec, alt_fields, avideo, aaudio)
     arith.configure("f32")
 
+    res = None
     if rank == 0:
         res = {
             "metric": "lip-clips/sec (fused A+V embed)", "value": main_fields["value"], "unit": "lip-clips/sec",
@@ -1059,6 +1052,36 @@ def main():
                 c4["max_abs_score_err_vs_oracle"] = float(f"{float(np.abs(osc.reshape(-1) - gpu_scores.reshape(-1)).max()):.3e}")
             if alt is not None:
                 res["alt_mode"]["parity"] = parity(alt[0], alt[2], alt[3], ref, cxv, cxa)
+
+    if dist_on and not args.no_configs:
+        # BASELINE configs[4] inside a scaling run, LAST and under a watchdog: train_fusion.Trainer's DP epoch on EVERY rank, the
+        # head's 3.4 MB gradient bucket all-reduced over RCCL INSIDE its recorded step -- a code path no multi-GPU node has run yet
+        # (a captured collective on a second communicator; first replay checked against an eager step, train_plan.py).  Everything
+        # measured above is already in `res`: if this leg hangs (one rank failing inside a collective would leave the others
+        # waiting) the watchdog prints the line as it stands, says so, and ends the process -- the scaling record survives.
+        import threading
+
+        def bail():
+            if rank == 0 and res is not None:
+                res.setdefault("configs", {})["C5_fusion_train_step"] = {"error": f"the DP training leg did not finish within {args.dp_leg_timeout} s; "
+                                                                                  "the line was printed by the watchdog"}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(float(args.dp_leg_timeout), bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            c5_all = c5_entry(args)
+            c5_all["ranks"] = world
+        except Exception as ex:   # noqa: BLE001
+            c5_all = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        # the ranks leave this leg together or not at all (a rank that failed above would otherwise run ahead into the teardown)
+        dist.barrier()
+        dog.cancel()
+        if res is not None:
+            res.setdefault("configs", {})["C5_fusion_train_step"] = c5_all
+    if rank == 0:
         print(json.dumps(res), flush=True)
 
     if dist_on:

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -65,7 +66,13 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
   constexpr int LDK = 32;
   constexpr int NSTORE = OSPLIT ? MI * NI : MI * NI;   // 16-B output stores per lane and tile (split: 2 per channel-block pair and pixel block)
   static_assert(BN % RPP == 0 && WM % 16 == 0 && 2 * WBLK % NW == 0 && NI % 2 == 0, "tile / window layout");
-  static_assert(WPER <= 7, "the last window piece of a channel slice goes out at least two slices before the slice ends");
+  // Window pieces go out PPT per slice during the first taps of the previous channel slice.  (Round 6: PPT = 2 for the geometries
+  // with few waves -- 64 x 64 WAVE tiles: two or four waves own the whole window, 10 - 11 pieces each.  Why those geometries: a wave
+  // tile of MI x NI fragments reads 2 KB of LDS per fragment row / column and slice for 3 MI NI MFMAs of 16 cycles; against the
+  // CU's 128 B / clk that is (4 / 3)(1 / MI + 1 / NI) LDS cycles per MFMA cycle -- 1.0 for the 64 x 32 wave tiles of the 2 x 2
+  // layout (the LDS port is as busy as the matrix pipes: neither can be), 0.67 for 64 x 64.)
+  constexpr int PPT = (WPER + 6) / 7;
+  static_assert(WPER <= 7 * PPT && PPT <= 2, "the last window piece of a channel slice goes out at least two slices before the slice ends");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds_c = reinterpret_cast<char*>(smem);
   auto stage_off = [](int st) { return st == 2 ? SLOT_B : HEAD_OFF + st * BSTAGE_B; };   // stages 0, 1 outside the image
@@ -276,14 +283,17 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
         // the weights come from L2) and is not needed before the next channel slice -- issued BEHIND the slice's weight pieces
         // it may stay in flight across two slice ends instead of one (in-kernel stamps: with the window piece first the wave
         // stood 1 000 - 1 300 cycles in that wait in six slices of nine).
-        const bool win_now = tap < WPER && stream_win;
-        const bool win_prev = tap >= 1 && tap - 1 < WPER && stream_win;   // a window piece went out in the previous slice
+        // pieces this slice / the previous slice sent out (fold per tap once the loop is unrolled)
+        const int n_now = stream_win ? (tap * PPT >= WPER ? 0 : (WPER - tap * PPT < PPT ? WPER - tap * PPT : PPT)) : 0;
+        const int n_prev = (stream_win && tap >= 1) ? ((tap - 1) * PPT >= WPER ? 0 : (WPER - (tap - 1) * PPT < PPT ? WPER - (tap - 1) * PPT : PPT)) : 0;
         WIN_SSTAMP(0);
         if (moreP) {
           const int wnext = last_c ? 0 : wbase + BK * 4;   // first channel slice of the next tile, or this tile's next one
           issue_b((tap + 2) % 3, tap + 2 < NTAPS ? (tap + 2) * a.Cw * 4 + wbase : (tap + 2 - NTAPS) * a.Cw * 4 + wnext);
         }
-        if (win_now) { if (last_c) issue_win(0, 0, wave + NW * tap, m0n - halo_lo); else issue_win(c + 1, c + 1, wave + NW * tap, p0); }
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+          if (i < n_now) { if (last_c) issue_win(0, 0, wave + NW * (tap * PPT + i), m0n - halo_lo); else issue_win(c + 1, c + 1, wave + NW * (tap * PPT + i), p0); }
         DLIP_FENCE();
         WIN_SSTAMP(1);
         read_rest(tap % 3); DLIP_FENCE();
@@ -302,10 +312,20 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N, OCC) void conv_win_f16x3_ker
           // weights and this slice's pieces in the queue.  Every LDS read of this slice is complete (lgkmcnt) before the
           // barrier releases its stage; the last group's MFMAs then cover the next slice's first fragment reads.
           // (younger than the next slice's weights: the previous slice's window piece, this slice's weights and window piece)
-          const int wn = (win_now ? 1 : 0) + (win_prev ? 1 : 0);
-          if (!first && c == 0 && tap == 0) { if (wn) wait_vmcnt<B_PER + 1 + NSTORE>(); else wait_vmcnt<B_PER + NSTORE>(); }
-          else if (moreP) { if (wn == 2) wait_vmcnt<B_PER + 2>(); else if (wn == 1) wait_vmcnt<B_PER + 1>(); else wait_vmcnt<B_PER>(); }
-          else            { if (wn == 2) wait_vmcnt<2>(); else if (wn == 1) wait_vmcnt<1>(); else wait_vmcnt<0>(); }
+          const int wn = n_now + n_prev;                 // 0 .. 2 PPT
+          auto wait_plus = [&](auto base) {              // s_waitcnt vmcnt(base + wn): wn folds per tap, one instruction remains
+            constexpr int BASE = decltype(base)::value;
+            if (wn == 4) wait_vmcnt<BASE + 4>(); else if (wn == 3) wait_vmcnt<BASE + 3>(); else if (wn == 2) wait_vmcnt<BASE + 2>();
+            else if (wn == 1) wait_vmcnt<BASE + 1>(); else wait_vmcnt<BASE>();
+          };
+#ifdef DLIP_LAB
+          // lab probe (DLIP_WIN_NOWAIT=1; WRONG results, timing only): what a slice costs when nobody waits for the next slice's weights --
+          // the ceiling of any deeper ring / earlier issue
+          if (a.n_inner == 77) wait_vmcnt<40>(); else
+#endif
+          if (!first && c == 0 && tap == 0) wait_plus(std::integral_constant<int, B_PER + NSTORE>{});
+          else if (moreP) wait_plus(std::integral_constant<int, B_PER>{});
+          else wait_plus(std::integral_constant<int, 0>{});
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           WIN_SSTAMP(4);
           __builtin_amdgcn_s_barrier();
@@ -477,6 +497,7 @@ int launch_win(const ConvArgs& a, hipStream_t st, bool out_split) {
   const long long grid = tiles < slots ? tiles : slots;
   b.span = dlip_span_next();
 #ifdef DLIP_LAB
+  b.n_inner = getenv("DLIP_WIN_NOWAIT") ? 77 : 0;
   if (getenv("DLIP_STAMP_PRINT")) {   // median cycles between the phase stamps of every workgroup's second tile
     static unsigned long long* dbuf = nullptr;
     if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), 2 * 4096 * 8 * 8);
@@ -578,8 +599,19 @@ extern "C" __attribute__((visibility("hidden"))) int dlip_conv_f16x3_win_launch(
   // K <= 64: four waves, two workgroups per CU (eight waves in one workgroup per CU: 258 vs 218 us on layer 1, same box).
   // 64 < K <= 128 (layer 2, 128 -> 128 channels on 11x11 maps): eight waves on a 128x128 tile, one workgroup per CU (the
   // fp32 epilogue image alone is 64 KB): 178 us vs 200-210 on the 256x128 ring kernel without a residual, 211-223 vs 241-275 with.
-  if (a.K > 64) return launch_win<128, 128, 4, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
+  // dlip_debug_set(DLIP_DBG_WIN, v) picks a geometry for same-box A/B runs: 3 = 128x64 tile, TWO waves of 64x64 (two workgroups
+  // per CU); 4 = 256x64, four waves of 64x64; 5 = (K > 64) 128x128, four waves of 64x64; 6 = (K > 64) 256x128, eight waves of 64x64;
+  // 7 = round 5's 2 x 2 waves of 64x32 on the 128x64 tile.
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int v = dlip_dbg_value[DLIP_DBG_WIN];
+  if (a.K > 64) {
+    if (v == 5) return launch_win<128, 128, 2, 2, 1>(a, st, out_split != 0);
+    if (v == 6) return launch_win<256, 128, 4, 2, 1>(a, st, out_split != 0);
+    return launch_win<128, 128, 4, 2, 2>(a, st, out_split != 0);
+  }
   // (256x64 with eight waves in ONE workgroup per CU -- the weights fetched once per 256 rows instead of per 128 -- measured
   // 9-20 % slower than the two independent 128x64 workgroups: 239-249 vs 219-225 us, with a residual 348-357 vs 292-297)
-  return launch_win<128, 64, 2, 2, 2>(a, static_cast<hipStream_t>(stream), out_split != 0);
+  if (v == 3) return launch_win<128, 64, 2, 1, 1>(a, st, out_split != 0);
+  if (v == 4) return launch_win<256, 64, 4, 1, 1>(a, st, out_split != 0);
+  return launch_win<128, 64, 2, 2, 2>(a, st, out_split != 0);
 }

@@ -69,6 +69,7 @@ class ExtractPipeline:
         self._pending: list = [None] * depth # (tables, row, rows) of the replay in flight on set k: settled when the set is recycled / at finish()
         for p in self.plans:
             p.status.private = True          # every report of a replay is settled here, batch by batch (_settle)
+        self._fifo: list = []                # sets with an unsettled replay, oldest first (wait_next)
         self._replayed = [False] * depth     # set k has a replay in flight (or finished) whose FREE event must be awaited before refilling it
         self._next = 0                       # batches submitted so far: batch i uses input set i % depth
         self.batch = int(example_inputs[0].shape[0])
@@ -87,6 +88,8 @@ class ExtractPipeline:
         rows = int(hb[0].shape[0])
         if rows > self.batch or len(hb) != len(ins) or any(int(h.shape[0]) > int(d.shape[0]) for h, d in zip(hb, ins)):
             raise ValueError("ExtractPipeline: batch does not match the recorded inputs")
+        if k in self._fifo:
+            self._fifo.remove(k)             # recycled before anybody waited for it: settled right below
         if self._replayed[k]:
             # (Also across calls: a second run() without finish() in between refills sets the previous call's last replays may
             # still be reading -- the copy stream is ordered behind nothing but this wait.)
@@ -102,7 +105,7 @@ class ExtractPipeline:
             self.ready[k].record(self.copy_stream)
         with torch.cuda.stream(self.run_stream):
             self.run_stream.wait_event(self.ready[k])
-            out = self.plans[k].run(check=False)
+            out = self.plans[k].run(check_reports=False)
             outs = [out] if isinstance(out, Tensor) else list(out)
             if len(outs) != len(tables):
                 raise ValueError(f"ExtractPipeline: the step returns {len(outs)} tensors, {len(tables)} tables given")
@@ -111,7 +114,20 @@ class ExtractPipeline:
             self.free[k].record(self.run_stream)
         self._replayed[k] = True
         self._pending[k] = (list(tables), row, rows)
+        self._fifo.append(k)
         return rows
+
+    def wait_next(self) -> bool:
+        """Wait for the OLDEST submitted batch that has not been waited for (host wait on its FREE event), settle its range report
+        (f32 re-run under the fallback) and return True; False when nothing is pending.  Lets a caller consume batch i while
+        batches i + 1 .. are in flight -- the training loop of train_fusion.py: the head's step on batch i runs while the encoders
+        work on batch i + 1 and the copies of batch i + 2 are on their way."""
+        if not self._fifo:
+            return False
+        k = self._fifo.pop(0)
+        self.free[k].synchronize()
+        self._settle(k)
+        return True
 
     def _settle(self, k: int) -> None:
         """Set k's last replay has finished: did it stay inside the f16x3 range?  If not, the batch is still in the set's buffers --
@@ -149,6 +165,7 @@ class ExtractPipeline:
     def finish(self) -> None:
         self.run_stream.synchronize()
         self._replayed = [False] * self.depth
+        self._fifo = []
         for k in range(self.depth):   # an f16x3 overflow of the LAST batches surfaces (or is repaired) here, not one call late
             self._settle(k)
         check_range(sync=False)

@@ -187,9 +187,9 @@ class StepPlan:
             ops.ARENA = prev
             ops.LAUNCH_HOOK = prev_hook
 
-    def run(self, check: bool = True):
+    def run(self, check_reports: bool = True):
         """Replay the step on the current stream (asynchronous); returns the recorded output tensor(s),
-        which the next run overwrites.  ``check=False``: the caller settles range reports itself (pipeline.py)."""
+        which the next run overwrites.  ``check_reports=False``: the caller settles range reports itself (pipeline.py)."""
         if self._gen != holders.PACK_GEN[0]:
             raise StalePlanError("StepPlan: model weights / placement changed since the plan was recorded; record a new plan")
         # in-place parameter updates (optimizer.step() on an eval-mode model, hand edits, `p.data = ...`) leave the generation
@@ -199,7 +199,7 @@ class StepPlan:
             if packing.state_version(module, device) != ver:
                 raise StalePlanError("StepPlan: a model's parameters were modified in place since the plan was recorded (its packed "
                                      "weights are stale); record a new plan")
-        if check:
+        if check_reports:
             check_range()       # f16x3 overflow reported by an earlier replay (host read, no synchronisation)
         check(lib().dlip_plan_run(self._handle, torch.cuda.current_stream(self.device).cuda_stream), "dlip_plan_run")
         return self.outputs

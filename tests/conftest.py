@@ -22,8 +22,9 @@ def _arith_baseline():
     tests choose their modes explicitly -- packing.set_precision / arith.configure / $DLIP_ARITH per test or module -- and start from
     the exact mode, as they always have: f32 packs, no fallback."""
     os.environ.pop("DLIP_ARITH", None)
-    from deeplip_amd import arith
+    from deeplip_amd import arith, autograd_video as av
     arith.configure("f32")
+    av.TRAIN_CONV = "f16x3"      # ... and the train-mode convolutions where they have always run in the tests: the split kernels
     yield
 
 

@@ -249,3 +249,33 @@ def test_grad_buckets_second_backward_before_finish_raises():
         (p * 3).sum().backward()
     b.finish()                                                      # single process: nothing in flight, state resets
     (p * 2).sum().backward()
+
+
+def _capture_group_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = ddist.capture_group()
+        assert g is not None and g is ddist.capture_group() and g is not dist.group.WORLD      # one per job, not the default group
+        t = torch.full((4,), float(rank + 1))
+        dist.all_reduce(t, group=g)                          # the group works like the default one (same ranks)
+        verdict = torch.tensor([1.0 if rank == 0 else 0.0])
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)       # TrainStepGraph._agree: one rank's doubt is everybody's
+        q.put((rank, t.tolist(), float(verdict)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capture_group_world2():
+    """The process group recorded training steps send their collectives to (deeplip_amd.dist.capture_group): created collectively,
+    once per job, over the same ranks; and the MIN all-reduce by which the ranks agree on keeping or dropping a recorded step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_capture_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(60) for p in procs]
+    for rank, t, verdict in res:
+        assert t == [3.0] * 4 and verdict == 0.0
+    assert ddist.capture_group() is None                     # outside a job

@@ -304,25 +304,30 @@ class Trainer(object):
             with torch.no_grad():
                 self._enc_pipe = (key, ExtractPipeline(encoders, *(t.to(self.device) for t in first), device=self.device))
         pipe = self._enc_pipe[1]
+        DEPTH = pipe.depth                                   # batches in flight: one in the encoders, one in its copies
         slots = [(torch.empty((bs, D), device=self.device), torch.empty((bs, D), device=self.device),
-                  torch.empty((bs,), dtype=torch.int64, device=self.device)) for _ in range(2)]
+                  torch.empty((bs,), dtype=torch.int64, device=self.device)) for _ in range(DEPTH)]
         acc = torch.zeros(3, dtype=torch.float64, device=self.device)
         torch.cuda.synchronize(self.device)
         t0 = time.perf_counter()
         cur = torch.cuda.current_stream(self.device)
         with torch.no_grad():
-            pipe.submit(first, slots[0], 0)
+            for j in range(min(DEPTH, steps)):
+                pipe.submit(first if j == 0 else host_batch(j), slots[j % DEPTH], 0)
         for it in range(steps):
-            pipe.finish()                                    # batch `it` is through the encoders (and inside the arithmetic's range)
-            xv_audio, em_video, labels = slots[it % 2]
-            if it + 1 < steps:
-                pipe.run_stream.wait_stream(cur)             # the slot it overwrites was read by step it - 1, already ordered on `cur`
-                with torch.no_grad():
-                    pipe.submit(host_batch(it + 1), slots[(it + 1) % 2], 0)
+            pipe.wait_next()                                 # batch `it` is through the encoders (and inside the arithmetic's range)
+            xv_audio, em_video, labels = slots[it % DEPTH]
             loss, logits = self._steps.step(xv_audio, em_video, labels, key=float(getattr(self.criterion, "margin", 0.0)))
             acc[0] += loss.detach().double() * bs
             acc[1] += (torch.max(logits.detach(), dim=1)[1] == labels).sum()
             acc[2] += bs
+            if it + DEPTH < steps:
+                # batch it + DEPTH takes the input set and the slot batch `it` just left: its copies start now, behind the encoders'
+                # work on batch it + 1; the slot is rewritten only after the head's step above has read it (ordered on `cur`)
+                pipe.run_stream.wait_stream(cur)
+                with torch.no_grad():
+                    pipe.submit(host_batch(it + DEPTH), slots[it % DEPTH], 0)
+        pipe.finish()
         self._steps.finish()
         sum_loss, correct, sum_samples = acc.tolist()
         dt = time.perf_counter() - t0
