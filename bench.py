@@ -617,7 +617,8 @@ def c5_entry(args):
                                 "gradient bucket all-reduced inside at N > 1), conf/fusion_config.yaml:87-99",
                     "pairs_per_s": round(st["pairs_per_s"], 1), "ms_per_step": round(st["ms_per_step"], 4), "step_mode": st["step_mode"],
                     "ms": {"encoders_frozen_extract": round(enc_ms, 4), "head_step_recorded": round(head_ms, 4) if head_ms is not None else None},
-                    "loss": round(st["loss"], 4), "arith": tr.arith, "f32_reruns": arith.STATS["f32_reruns"]}
+                    "loss": round(st["loss"], 4), "arith": tr.arith, "f32_reruns": arith.STATS["f32_reruns"],
+                    "verified": steps.verified}
         finally:
             tr.close()
     return _in_tmp(run)
@@ -690,6 +691,7 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="issue the two encoders in sequence on one stream (default: the "
                     "speech encoder on a second stream, fork / join recorded into the step plan)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--dp-leg", action="store_true", help="inside a torch.distributed job: run the DP training leg even with --no-configs (tests)")
     ap.add_argument("--dp-leg-timeout", type=int, default=240, help="N > 1: seconds the DP training leg (C5 on every rank) may take before the "
                     "watchdog prints the line without it")
     ap.add_argument("--no-entry-points", action="store_true", help="skip the entry-point lines (E1..E3: the trainers driven as a user drives them)")
@@ -966,8 +968,13 @@ def main():
                 roof["traffic_source"] = "profiles/traffic_latest.json is from another build of the kernel (source sha mismatch): ignored"
             elif key in tr and "hbm_read_bytes_per_launch" in tr[key]:
                 roof["traffic"] = round(tr[key]["hbm_read_bytes_per_launch"] + tr[key]["hbm_write_bytes_per_launch"])
+                from deeplip_amd import build as _build
+                same_box = meta.get("box") == _build.box_id()
                 roof["traffic_source"] = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per "
-                                          "launch, FETCH x2 gfx950 correction; stamped with this kernel source's sha)")
+                                          "launch, FETCH x2 gfx950 correction; stamped with this kernel source's sha); collected "
+                                          f"{meta.get('collected_utc', 'at an unrecorded time')} on {'THIS box' if same_box else 'box ' + str(meta.get('box', '?'))}"
+                                          + (" by tools/collect_profiles.sh in the same call as this line" if same_box else ""))
+                roof["traffic_collected"] = {"utc": meta.get("collected_utc"), "box": meta.get("box"), "same_box_as_this_run": same_box}
         except Exception:
             pass
         fields = {"value": round(value, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -1053,7 +1060,7 @@ def main():
             if alt is not None:
                 res["alt_mode"]["parity"] = parity(alt[0], alt[2], alt[3], ref, cxv, cxa)
 
-    if dist_on and not args.no_configs:
+    if dist_on and (not args.no_configs or args.dp_leg):
         # BASELINE configs[4] inside a scaling run, LAST and under a watchdog: train_fusion.Trainer's DP epoch on EVERY rank, the
         # head's 3.4 MB gradient bucket all-reduced over RCCL INSIDE its recorded step -- a code path no multi-GPU node has run yet
         # (a captured collective on a second communicator; first replay checked against an eager step, train_plan.py).  Everything

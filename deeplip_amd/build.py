@@ -146,3 +146,17 @@ def dominant_kernel_sha() -> str:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read() + b"\0")
     return h.hexdigest()[:16]
+
+
+def box_id() -> str:
+    """What tells one GPU box of the pool from another in a record: the first GPU's unique id (sysfs), else the host name."""
+    import glob
+    import socket
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/unique_id")):
+        try:
+            v = open(f).read().strip()
+            if v:
+                return "gpu-" + v
+        except OSError:
+            pass
+    return socket.gethostname()

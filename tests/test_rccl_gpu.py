@@ -45,6 +45,19 @@ def test_bench_scaling_protocol_on_rccl_one_rank():
     assert r["n1_value_rank0_alone"] > 1000
 
 
+def test_bench_dp_training_leg_on_rccl_one_rank(monkeypatch):
+    """The leg a scaling run ends with (BASELINE configs[4] on every rank: train_fusion.Trainer's epoch, the head's gradient bucket
+    all-reduced INSIDE its recorded step on the capture group) as a one-rank job, with the first-replay verification forced on: the
+    line says the recorded step ran, was checked against an eager step from the same state, and what the check measured."""
+    monkeypatch.setenv("DLIP_VERIFY_GRAPH", "1")
+    rc, js, lines = _run("bench.py", ["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-configs", "--single-mode", "--no-h2d", "--dp-leg"])
+    assert rc == 0, "".join(lines)[-2000:]
+    c5 = js[-1]["configs"]["C5_fusion_train_step"]
+    assert "error" not in c5, c5
+    assert c5["ranks"] == 1 and c5["step_mode"] == "graph" and c5["pairs_per_s"] > 1000
+    assert c5["verified"]["outputs_rel_err"] <= 1e-6 and c5["verified"]["witness_rel_err"] <= 1e-6
+
+
 def test_train_audio_dp_on_rccl_one_rank(tmp_path):
     """BASELINE config C5's mechanism (DP training, bucketed all-reduce behind backward) as a job on the real backend."""
     over = ["data.test_speakers=4", "data.test_utt_per_spk=3", "data.trials=200", "data.trial_targets=40", "data.audio_frames=120",

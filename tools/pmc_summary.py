@@ -61,7 +61,12 @@ def main():
     sys.path.insert(0, root)
     from deeplip_amd import build
     abi = int(re.search(r"#define DLIP_ABI_VERSION (\d+)", open(os.path.join(root, "include", "deeplip_hip.h")).read()).group(1))
-    res["_meta"] = {"kernel_sha": build.dominant_kernel_sha(), "kernel_sources": list(build.DOMINANT_KERNEL_SOURCES), "abi": abi, "steps": steps}
+    import socket, time
+    # ... and WHEN / WHERE they were collected: tools/collect_profiles.sh runs these passes in the same gpurun call -- the same box,
+    # minutes apart -- as the bench line that quotes them, and the line says so (roofline.traffic_source)
+    res["_meta"] = {"kernel_sha": build.dominant_kernel_sha(), "kernel_sources": list(build.DOMINANT_KERNEL_SOURCES), "abi": abi, "steps": steps,
+                    "collected_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "box": build.box_id(),
+                    "library_sha": build.library_sha()[:16]}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
 
