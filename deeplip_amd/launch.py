@@ -90,8 +90,9 @@ def self_launch(script: str, argv: Sequence[str], nproc: int, relay=None, env=No
         # its launcher holding the GPUs.  The exact process group we started, nothing by pattern.  The teardown itself runs with
         # the stop signals BLOCKED: a second SIGTERM during the grace wait used to raise inside this handler and skip the
         # escalation to SIGKILL.
-        if main:
-            signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM, signal.SIGHUP, signal.SIGINT})
+        prev_mask = None
+        if main:     # (the caller's mask comes back afterwards as it was: a harness that keeps SIGINT blocked keeps it blocked)
+            prev_mask = signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM, signal.SIGHUP, signal.SIGINT})
         try:
             if p is not None:
                 _kill_group(p, signal.SIGTERM)
@@ -105,7 +106,7 @@ def self_launch(script: str, argv: Sequence[str], nproc: int, relay=None, env=No
                 for sig, h in old.items():          # (restored before unblocking: a pending stop signal then takes its old course)
                     signal.signal(sig, h)
                 old = {}
-                signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM, signal.SIGHUP, signal.SIGINT})
+                signal.pthread_sigmask(signal.SIG_SETMASK, prev_mask)
         if isinstance(ex, _Terminated):
             print(f"[launch] signal {ex.signum}: job stopped", file=sys.stderr, flush=True)
             return 128 + ex.signum

@@ -101,9 +101,10 @@ class PLDA:
         if allow_pickle is None:
             allow_pickle = os.environ.get("DLIP_ALLOW_PICKLED_CHECKPOINTS") == "1"
         if not allow_pickle:
-            raise RuntimeError(f"{path} is not this build's PLDA archive; if it is the reference's joblib pickle of a `plda.Classifier`, "
-                               "loading it runs code from the file: pass allow_pickle=True (or set DLIP_ALLOW_PICKLED_CHECKPOINTS=1) "
-                               "if you trust it, or re-fit with Trainer.train_plda()")
+            raise RuntimeError(f"{path} is not this build's PLDA archive (a numpy .npz of plain arrays under the reference's file name; "
+                               "INTEGRATION.md, 'Formats that differ').  Two older forms are pickles and are only loaded on request -- the "
+                               "reference's joblib pickle of a `plda.Classifier`, and the joblib dict of arrays round 4 of this build wrote: "
+                               "both run code on load; set DLIP_ALLOW_PICKLED_CHECKPOINTS=1 (or allow_pickle=True) if you trust the file.")
         import joblib
         try:
             obj = joblib.load(path)
