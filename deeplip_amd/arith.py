@@ -32,7 +32,10 @@ log = logging.getLogger("deeplip_amd.arith")
 MODES = ("auto", "f16x3", "f32")
 ENV = "DLIP_ARITH"
 
-STATS = {"f32_reruns": 0, "last": None}     # batches / calls computed again in f32 by the auto mode, and the last one's story
+# batches / calls computed again in f32 by the auto mode, the last one's story, and how many of those re-runs also CALIBRATED a
+# model's activation exponents (packing.act_exponents): from then on that model's batches stay on the f16x3 path
+STATS = {"f32_reruns": 0, "calibrations": 0, "last": None}
+CALIBRATE = True               # auto: the exact re-run of an out-of-range batch also calibrates activation exponents (False: it only repairs the batch)
 _tls = threading.local()
 
 
@@ -84,13 +87,25 @@ def note_rerun(what: str, err: Exception) -> None:
                 what, STATS["last"]["reason"], STATS["f32_reruns"])
 
 
-def rerun_exact(fn: Callable, *args, what: str = "a batch", err: Optional[Exception] = None):
-    """``fn(*args)`` eagerly on the f32 packs; the results are complete (synchronised, range-checked) on return."""
+def rerun_exact(fn: Callable, *args, what: str = "a batch", err: Optional[Exception] = None, calibrate: bool = True):
+    """``fn(*args)`` eagerly on the f32 packs; the results are complete (synchronised, range-checked) on return.  ``calibrate``: the
+    exact pass also measures every tensor the f16x3 path stores split and gives the models it ran activation exponents (powers of two
+    folded into their f16x3 packs: packing.calib_finish) -- the next batch of the same kind stays inside the fast arithmetic's range."""
     note_rerun(what, err or _lib.DeepLipRangeError("range"))
-    with exact(), torch.no_grad():
-        out = fn(*args)
+    calibrate = calibrate and CALIBRATE
+    if calibrate:
+        packing.CALIB = {}
+    try:
+        with exact(), torch.no_grad():
+            out = fn(*args)
+    finally:
+        n = packing.calib_finish() if calibrate else 0
     torch.cuda.synchronize()
     _lib.check_range()          # exact fp32 reports nothing of the split format; a stale word must not outlive the re-run
+    if n:
+        STATS["calibrations"] += n
+        log.warning("arith auto: activation exponents calibrated for %d model(s) on that batch (%d so far): their f16x3 packs are rebuilt, "
+                    "recorded plans re-recorded", n, STATS["calibrations"])
     return out
 
 

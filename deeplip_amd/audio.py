@@ -85,13 +85,16 @@ class TDNN_Block(nn.Module):
         self.activation = Marker("LeakyReLU(0.2)")
         self.bn_first = bn_first
 
-    def pack(self, device) -> packing.Packed:
+    def pack(self, device, e_in: int = 0, e_out: int = 0) -> packing.Packed:
+        """``e_in`` / ``e_out``: activation exponents of the layer's input / output in the f16x3 pack (packing.act_exponents)."""
         cp = packing.pad_channels(self.input_dim)
         slope = packing.const_slope(self.output_dim, LRELU, device)
         if self.bn_first:   # conv -> BN -> LReLU: BN folds into the conv
-            return packing.pack_conv1d(self.context_layer.weight, self.context_layer.bias, self.bn, device, slope, cp)
-        p = packing.pack_conv1d(self.context_layer.weight, self.context_layer.bias, None, device, slope, cp)
+            return packing.pack_conv1d(self.context_layer.weight, self.context_layer.bias, self.bn, device, slope, cp, e_in, e_out)
+        p = packing.pack_conv1d(self.context_layer.weight, self.context_layer.bias, None, device, slope, cp, e_in, e_out)
         sc, sh = packing.bn_scale_shift(self.bn)  # conv -> LReLU -> BN: BN is the post-affine of the epilogue
+        if packing.PRECISION == "f16x3" and e_out:
+            sh = sh * (2.0 ** int(e_out))          # (the shift lands behind the activation: scaled with the output)
         p.post_scale, p.post_shift = sc.float().to(device), sh.float().to(device)
         return p
 
@@ -163,22 +166,36 @@ class SpeakerEmbNet(nn.Module):
         self.fc2 = LinearParams(embedding_dim, embedding_dim)
         self.bn2 = BatchNormParams(embedding_dim)
 
+    def _exp(self, name: str) -> int:
+        """Activation exponent of a tensor of the f16x3 pack: "in" (the features), "t<i>" (output of TDNN layer i = input of
+        layer i + 1; the last one also scales the pooled statistics that fc1 reads).  Zero unless a calibration set it."""
+        if packing.PRECISION != "f16x3":
+            return 0
+        if name == f"t{len(self.tdnn) - 1}" and self.pooling_type == "attentive_statistic":
+            return 0            # (the attention scores are not homogeneous in their input: that tensor stays unscaled)
+        return packing.act_exponents(self).get(name, 0)
+
     def _pack(self, device):
         def ss(bn):
             sc, sh = packing.bn_scale_shift(bn)
             return sc.float().to(device), sh.float().to(device)
-        return {"tdnn": [b.pack(device) for b in self.tdnn],
-                "fc1": packing.pack_linear(self.fc1.weight, self.fc1.bias, None, device),
-                "fc2": packing.pack_linear(self.fc2.weight, self.fc2.bias, None, device),
-                "bn1": ss(self.bn1), "bn2": ss(self.bn2)}
+        n = len(self.tdnn)
+        e = [self._exp("in")] + [self._exp(f"t{i}") for i in range(n)]
+        pk = {"tdnn": [b.pack(device, e[i], e[i + 1]) for i, b in enumerate(self.tdnn)],
+              "fc1": packing.pack_linear(self.fc1.weight, self.fc1.bias, None, device, e_in=e[n], e_out=0),
+              "fc2": packing.pack_linear(self.fc2.weight, self.fc2.bias, None, device),
+              "bn1": ss(self.bn1), "bn2": ss(self.bn2), "e_in": e[0], "e_last": e[n]}
+        if e[0]:
+            pk["in_scale"] = torch.full((1,), 2.0 ** e[0], dtype=torch.float32, device=device)
+        return pk
 
-    def _to_ntc(self, x: Tensor, split: bool = False) -> Tensor:
-        """[B,F,T] -> [B,T,Fp] channels-last; ``split``: Fp = F rounded up to 32, split activation format."""
+    def _to_ntc(self, x: Tensor, split: bool = False, pad32: bool = False) -> Tensor:
+        """[B,F,T] -> [B,T,Fp] channels-last; ``split``: Fp = F rounded up to 32, split activation format (``pad32``: that width, fp32)."""
         if x.dim() == 4:            # [B,1,F,T] (the north-star / train_audio.py:183-184 resnet layout)
             x = x.squeeze(1)
         if x.dim() != 3 or x.shape[1] != self.input_dim:
             raise ValueError(f"SpeakerEmbNet expects [B,{self.input_dim},T] features, got {tuple(x.shape)}")
-        return ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim, 32 if split else 4),
+        return ops.nct_to_ntc(x.contiguous().float(), pad_to=packing.pad_channels(self.input_dim, 32 if (split or pad32) else 4),
                               out_split=split)
 
     def _to_ntc_padded(self, x: Tensor) -> Tensor:
@@ -241,7 +258,14 @@ class SpeakerEmbNet(nn.Module):
         # by the producing layer's epilogue; the last layer hands fp32 to the pooling kernel, which
         # writes the utterance statistics in that format again for fc1.
         f16x3 = p["tdnn"][0].wscale is not None
-        h = self._to_ntc(x, split=f16x3)
+        packing.calib_note(self, "in", x)                    # (a calibrating exact pass notes the tensors' magnitudes; no-op otherwise)
+        if f16x3 and p["e_in"]:
+            # an input whose gain put it outside the split format (calibrated: packing.act_exponents): 2^e x, then the split
+            h = ops.split_pack_scaled(self._to_ntc(x, split=False, pad32=True), p["in_scale"])
+        else:
+            h = self._to_ntc(x, split=f16x3)
+        if taps is not None and f16x3 and (p["e_in"] or p["e_last"] or packing.act_exponents(self)):
+            raise NotImplementedError("taps of a model with calibrated activation exponents (the intermediate tensors are scaled)")
         split, n = f16x3, len(self.tdnn)
         pooled = None
         for i, (blk, bp) in enumerate(zip(self.tdnn, p["tdnn"])):
@@ -252,6 +276,7 @@ class SpeakerEmbNet(nn.Module):
                 if pooled is not None:
                     break
             h = blk.run_ntc(h, bp, x_split=split, out_split=nxt)
+            packing.calib_note(self, f"t{i}", h)
             split = nxt
         if taps is not None:
             taps["tdnn_out"] = h

@@ -20,6 +20,7 @@ import torch.nn as nn
 # whenever a holder's tensors may have been replaced or rewritten wholesale -- load_state_dict, .to()/.cuda()/
 # .float(), train()/eval() switches (an optimizer ran in between) -- so a forward only compares one integer.
 PACK_GEN = [0]
+LOAD_GEN = [0]      # bumped by load_state_dict alone: calibrated activation exponents (packing.act_exponents) belong to the weights they were measured on
 
 
 def invalidate_packs() -> None:
@@ -33,6 +34,7 @@ class _Holder(nn.Module):
 
     def _load_from_state_dict(self, *a, **k):
         invalidate_packs()
+        LOAD_GEN[0] += 1
         return super()._load_from_state_dict(*a, **k)
 
     def train(self, mode: bool = True):

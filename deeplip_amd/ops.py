@@ -438,6 +438,23 @@ def split_pack(x: Tensor) -> Tensor:
     return y
 
 
+def split_pack_scaled(x: Tensor, scale: Tensor) -> Tensor:
+    """split_pack(x * scale[0]) -- ``scale``: a device scalar holding a power of two (the activation exponent of a model input whose
+    gain lies outside the split format, packing.act_exponents; the multiplication is exact)."""
+    _req(x, "x"); _req(scale, "scale")
+    y = _empty(x.shape, x.device)
+    Cc = x.shape[-1]
+    check(lib().dlip_split_pack_scaled_f32(ptr(x), ptr(y), ptr(scale), x.numel() // Cc, Cc, stream_handle()), "dlip_split_pack_scaled_f32")
+    return y
+
+
+def channel_scale(x: Tensor, scale_vec: Tensor, zero_vec: Tensor) -> Tensor:
+    """y[..., c] = x[..., c] * scale_vec[c] (dlip_affine_act_f32 with a unit slope): how an fp32 output leaves a model whose last
+    split tensor carries an activation exponent -- scale_vec = 2^-e, exact."""
+    C_ = x.shape[-1]
+    return affine_act(x.reshape(-1, C_), scale_vec, zero_vec, slope=1.0).view(x.shape)
+
+
 def split_unpack(x: Tensor) -> Tensor:
     """Inverse of split_pack (hi + lo in fp32)."""
     _req(x, "x")

@@ -89,9 +89,16 @@ def split_weights(w: Tensor):
     return packed, scale.to(torch.float32)
 
 
-def _finish(w64: Tensor, b64: Tensor, device, slope) -> "Packed":
-    """w64: fp64 weights already in kernel layout [K, (R, S,) C]."""
+def _finish(w64: Tensor, b64: Tensor, device, slope, e_in: int = 0, e_out: int = 0) -> "Packed":
+    """w64: fp64 weights already in kernel layout [K, (R, S,) C].  ``e_in`` / ``e_out`` (f16x3 packs only): the ACTIVATION EXPONENTS of
+    the layer's input and output tensors -- the stored split tensor is 2^e times the true one (see act_exponents below).  A layer
+    y = act(W x + b) with a positively homogeneous activation (ReLU / PReLU / LeakyReLU) maps stored input to stored output with
+    W' = 2^(e_out - e_in) W and b' = 2^e_out b: exact powers of two, folded here -- the split weight bits do not change at all (their
+    per-channel power-of-two scale absorbs the factor), no kernel knows about exponents."""
     if PRECISION == "f16x3":
+        if e_in or e_out:
+            w64 = w64 * (2.0 ** int(e_out - e_in))
+            b64 = b64 * (2.0 ** int(e_out))
         ws, sc = split_weights(w64)
         return Packed(ws.contiguous().to(device), _dev(b64, device), slope, wscale=sc.to(device))
     return Packed(_dev(w64, device), _dev(b64, device), slope)
@@ -101,13 +108,13 @@ def pad_channels(c: int, mult: int = 4) -> int:
     return (c + mult - 1) // mult * mult
 
 
-def pack_conv2d(weight, bias, bn, device, slope=None) -> Packed:
+def pack_conv2d(weight, bias, bn, device, slope=None, e_in: int = 0, e_out: int = 0) -> Packed:
     """[K,C,R,S] -> KRSC."""
     w, b = fold(weight, bias, bn)
-    return _finish(w.permute(0, 2, 3, 1).contiguous(), b, device, slope)
+    return _finish(w.permute(0, 2, 3, 1).contiguous(), b, device, slope, e_in, e_out)
 
 
-def pack_conv2d_shortcut(weight, bn, down_weight, down_bn, device, slope=None) -> Packed:
+def pack_conv2d_shortcut(weight, bn, down_weight, down_bn, device, slope=None, e_h: int = 0, e_x: int = 0, e_out: int = 0) -> Packed:
     """conv2 [K,C,3,3] + bn2 and the shortcut's 1x1 stride-2 conv [K,C2,1,1] + BatchNorm (resnet.py:13-17) as ONE
     reduction: rows [K, 9*C32 | C2] under one per-channel power-of-two scale, bias = sum of the folded biases
     (dlip_conv2_nhwc_f16x3).  f16x3 packing only."""
@@ -119,12 +126,13 @@ def pack_conv2d_shortcut(weight, bn, down_weight, down_bn, device, slope=None) -
     C2 = wd.shape[1]
     if C % 32 or C2 % 32:
         raise ValueError("pack_conv2d_shortcut: channel counts must be multiples of 32")
-    rows = torch.cat([w.permute(0, 2, 3, 1).reshape(K, -1), wd.reshape(K, C2)], dim=1)   # [K, 9C + C2], 32-blocks intact
+    # activation exponents: conv2 reads h (e_h), the shortcut reads the block's input (e_x), both land in the output's (e_out)
+    rows = torch.cat([w.permute(0, 2, 3, 1).reshape(K, -1) * (2.0 ** int(e_out - e_h)), wd.reshape(K, C2) * (2.0 ** int(e_out - e_x))], dim=1)   # [K, 9C + C2], 32-blocks intact
     ws, sc = split_weights(rows)
-    return Packed(ws.contiguous().to(device), _dev(b + bd, device), slope, wscale=sc.to(device))
+    return Packed(ws.contiguous().to(device), _dev((b + bd) * (2.0 ** int(e_out)), device), slope, wscale=sc.to(device))
 
 
-def pack_conv1d(weight, bias, bn, device, slope=None, cin_pad: Optional[int] = None) -> Packed:
+def pack_conv1d(weight, bias, bn, device, slope=None, cin_pad: Optional[int] = None, e_in: int = 0, e_out: int = 0) -> Packed:
     """[K,C,S] -> [K,S,Cp] (input channels zero-padded to Cp)."""
     w, b = fold(weight, bias, bn)
     w = w.permute(0, 2, 1)
@@ -132,12 +140,12 @@ def pack_conv1d(weight, bias, bn, device, slope=None, cin_pad: Optional[int] = N
         wp = torch.zeros(w.shape[0], w.shape[1], cin_pad, dtype=torch.float64)
         wp[:, :, :w.shape[2]] = w
         w = wp
-    return _finish(w.contiguous(), b, device, slope)
+    return _finish(w.contiguous(), b, device, slope, e_in, e_out)
 
 
-def pack_linear(weight, bias, bn, device, slope=None) -> Packed:
+def pack_linear(weight, bias, bn, device, slope=None, e_in: int = 0, e_out: int = 0) -> Packed:
     w, b = fold(weight, bias, bn)
-    return _finish(w.contiguous(), b, device, slope)
+    return _finish(w.contiguous(), b, device, slope, e_in, e_out)
 
 
 def split_stem_weights(w: Tensor):
@@ -158,11 +166,14 @@ def split_stem_weights(w: Tensor):
     return img.contiguous().view(torch.float32).reshape(-1), scale.to(torch.float32)
 
 
-def pack_stem3d(weight, bn, device, slope=None) -> Packed:
+def pack_stem3d(weight, bn, device, slope=None, e_in: int = 0, e_out: int = 0) -> Packed:
     """[64,1,5,7,7] -> k-major [248,64] (245 taps + 3 zero rows); f16x3: the split LDS image."""
     w, b = fold(weight, None, bn)
     K = w.shape[0]
     if PRECISION == "f16x3":
+        if e_in or e_out:
+            w = w * (2.0 ** int(e_out - e_in))
+            b = b * (2.0 ** int(e_out))
         img, sc = split_stem_weights(w)
         return Packed(img.to(device), _dev(b, device), slope, wscale=sc.to(device))
     wp = torch.zeros(248, K, dtype=torch.float64)
@@ -191,7 +202,85 @@ def state_version(module: torch.nn.Module, device) -> tuple:
     if c is None or c[0] != gen:
         c = (gen, list(module.parameters()) + list(module.buffers()))
         module.__dict__["_dlip_tensors"] = c
-    v = 0
+    v = 7919 * module.__dict__.get("_dlip_exp_ver", 0)     # the activation exponents folded into the f16x3 pack (set_act_exponents)
     for t in c[1]:
         v += t._version + (t.data_ptr() & 0xFFFFFFFF)     # in-place updates bump _version; `p.data = other` moves data_ptr
     return (gen, device, PRECISION, v)
+
+
+# ---- activation exponents of the f16x3 packs -------------------------------------------------------------------------------------
+# The split format holds |v| in [2^-6 .. 65520) at fp32 grade.  A checkpoint whose activations live elsewhere -- BatchNorm statistics
+# that shrink or grow a layer's output, an input with a gain of 2^+-20 -- used to RAISE (DeepLipRangeError) and, under arith "auto",
+# had every batch computed again in exact fp32.  Now the exact re-run of the FIRST such batch doubles as a calibration: it measures
+# the largest magnitude of every tensor the f16x3 path stores split (dlip_pow2_scale_f32 on the fp32 tensors of the exact path, one
+# synchronisation at the end), and each gets a power-of-two exponent e that puts its largest stored magnitude at 2^11 .. 2^12.  The
+# exponents are folded into the packed weights and biases (see _finish: exact, no kernel changes, in-range models keep e = 0 and
+# today's bits); tensors that meet in a residual addition share one exponent (the smallest of the group).  Outputs that leave the
+# engine as fp32 are brought back by one multiplication with 2^-e, or not at all where the consumer is scale invariant (z-norm).
+ACT_TARGET = 4096.0            # 2^12: a factor 16 below fp16's largest value for batches that run hotter than the calibration batch
+MAX_CALIBRATIONS = 3           # per model; afterwards an out-of-range batch is simply computed in f32 (arith auto)
+CALIB = None                   # while a calibrating exact pass runs: {id(module): (module, {tensor name: device pair from pow2_scale})}
+
+
+def act_exponents(module) -> dict:
+    """{tensor name: e} of a model's f16x3 pack ({} = all zero: nothing was ever calibrated)."""
+    if module.__dict__.get("_dlip_exp_load_gen") != holders.LOAD_GEN[0]:
+        return {}               # measured on other weights (a load_state_dict since): void, and the calibration budget starts again
+    return module.__dict__.get("_dlip_exp", {})
+
+
+def set_act_exponents(module, exps: dict) -> None:
+    if module.__dict__.get("_dlip_exp_load_gen") != holders.LOAD_GEN[0]:
+        module.__dict__["_dlip_calibrations"] = 0
+    module.__dict__["_dlip_exp_load_gen"] = holders.LOAD_GEN[0]
+    module.__dict__["_dlip_exp"] = {k: int(v) for k, v in exps.items() if int(v) != 0}
+    module.__dict__["_dlip_exp_ver"] = module.__dict__.get("_dlip_exp_ver", 0) + 1      # packs and recorded plans of the model are stale now
+
+
+def calib_note(module, name: str, t: Tensor) -> None:
+    """Inside a calibrating pass (CALIB is a dict): remember the power of two that would lift tensor ``t`` to ACT_TARGET."""
+    if CALIB is None or not t.is_cuda:
+        return
+    from . import _lib
+    ent = CALIB.setdefault(id(module), (module, {}))
+    pair = torch.empty(2, device=t.device, dtype=torch.float32)
+    tt = t if t.is_contiguous() else t.contiguous()
+    _lib.check(_lib.lib().dlip_pow2_scale_f32(tt.data_ptr(), pair.data_ptr(), tt.numel(), float(ACT_TARGET), _lib.stream_handle()), "dlip_pow2_scale_f32")
+    prev = ent[1].get(name)
+    ent[1][name] = pair if prev is None else torch.minimum(prev, pair)      # (a name noted twice in one pass: the hotter tensor rules)
+
+
+def calib_finish(groups_of=None) -> int:
+    """End of a calibrating pass: read the noted scales (one synchronisation), turn them into exponents, apply each model's
+    residual groups (``module.act_exponent_groups()``: lists of names that must share an exponent) and install them.  Returns the number
+    of models whose exponents changed."""
+    import math
+    global CALIB
+    notes, CALIB = CALIB, None
+    changed = 0
+    if not notes:
+        return 0
+    torch.cuda.synchronize()
+    for module, named in notes.values():
+        fresh = module.__dict__.get("_dlip_exp_load_gen") != holders.LOAD_GEN[0]
+        if not fresh and module.__dict__.get("_dlip_calibrations", 0) >= MAX_CALIBRATIONS:
+            continue
+        exps = {}
+        for name, pair in named.items():
+            s = float(pair[0])
+            exps[name] = int(round(math.log2(s))) if (s > 0 and math.isfinite(s)) else 0
+        for grp in (module.act_exponent_groups() if hasattr(module, "act_exponent_groups") else []):
+            have = [exps[n] for n in grp if n in exps]
+            if have:
+                for n in grp:
+                    exps[n] = min(have)
+        exps = {k: max(-100, min(100, v)) for k, v in exps.items()}
+        # Tensors that sit comfortably inside the format keep e = 0 (and with it the bits they have always had): a largest magnitude
+        # of 2^-2 .. 2^14 gives e in [-2, 14] -- overflow is a factor 4 away at least and the low-side guard (largest magnitude
+        # below 2^-6) a factor 16.  Only what the calibration found outside that window is moved.
+        exps = {k: (0 if -2 <= v <= 14 else v) for k, v in exps.items()}
+        if {k: v for k, v in exps.items() if v} != act_exponents(module):
+            set_act_exponents(module, exps)            # (resets the budget when the weights are new)
+            module.__dict__["_dlip_calibrations"] = module.__dict__.get("_dlip_calibrations", 0) + 1
+            changed += 1
+    return changed

@@ -25,7 +25,7 @@ import torch
 
 from . import arith
 from ._lib import DeepLipHipError, check_range
-from .plan import StepPlan
+from .plan import StalePlanError, StepPlan
 
 Tensor = torch.Tensor
 
@@ -51,6 +51,7 @@ class ExtractPipeline:
         self.fn = fn
         self.fallback = arith.fallback_enabled() if fallback == "auto" else bool(fallback)
         self.reruns = 0
+        self.rerecorded = 0
         self.run_stream = torch.cuda.Stream(device=self.device)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.sets: List[Tuple[Tensor, ...]] = []
@@ -63,12 +64,11 @@ class ExtractPipeline:
                 for dst, src in zip(ins, example_inputs):      # a recorded pass must see representative values (range guard)
                     dst.copy_(src, non_blocking=True)
                 self.sets.append(ins)
-                self.plans.append(StepPlan(fn, *ins, stream=self.run_stream))
+                self.plans.append(StepPlan(fn, *ins, stream=self.run_stream, private_status=True))
         self.ready = [torch.cuda.Event() for _ in range(depth)]
         self.free = [torch.cuda.Event() for _ in range(depth)]
         self._pending: list = [None] * depth # (tables, row, rows) of the replay in flight on set k: settled when the set is recycled / at finish()
-        for p in self.plans:
-            p.status.private = True          # every report of a replay is settled here, batch by batch (_settle)
+        # (every report of a replay is settled here, batch by batch: _settle; the plans' status blocks are private)
         self._fifo: list = []                # sets with an unsettled replay, oldest first (wait_next)
         self._replayed = [False] * depth     # set k has a replay in flight (or finished) whose FREE event must be awaited before refilling it
         self._next = 0                       # batches submitted so far: batch i uses input set i % depth
@@ -105,7 +105,16 @@ class ExtractPipeline:
             self.ready[k].record(self.copy_stream)
         with torch.cuda.stream(self.run_stream):
             self.run_stream.wait_event(self.ready[k])
-            out = self.plans[k].run(check_reports=False)
+            try:
+                out = self.plans[k].run(check_reports=False)
+            except StalePlanError:
+                # the models' packs changed under the plan.  Under the fallback that is expected once: the exact re-run of an
+                # out-of-range batch calibrated activation exponents (arith.rerun_exact), so the f16x3 packs were rebuilt -- record
+                # this set's plan again on the batch that has just been copied into it, and carry on in the fast arithmetic
+                if not self.fallback:
+                    raise
+                self._rerecord(k)
+                out = self.plans[k].run(check_reports=False)
             outs = [out] if isinstance(out, Tensor) else list(out)
             if len(outs) != len(tables):
                 raise ValueError(f"ExtractPipeline: the step returns {len(outs)} tensors, {len(tables)} tables given")
@@ -116,6 +125,16 @@ class ExtractPipeline:
         self._pending[k] = (list(tables), row, rows)
         self._fifo.append(k)
         return rows
+
+    def _rerecord(self, k: int) -> None:
+        old = self.plans[k]
+        self.plans[k] = StepPlan(self.fn, *self.sets[k], stream=self.run_stream, private_status=True)
+        self.plans[k].take_range_error()     # (the recording passes ran on this very batch; its replay right behind reports for itself)
+        self.rerecorded += 1
+        try:
+            old.close()
+        except Exception:   # noqa: BLE001 -- a stale plan's leftovers must not take the run down
+            pass
 
     def wait_next(self) -> bool:
         """Wait for the OLDEST submitted batch that has not been waited for (host wait on its FREE event), settle its range report

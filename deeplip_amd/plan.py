@@ -98,7 +98,8 @@ SPAN_KERNELS = ("conv_igemm_f16x3_dma_kernel", "conv_rows_f16x3_kernel", "conv_w
 class StepPlan:
     """``fn(*inputs)`` recorded on a private HIP stream; see the module docstring."""
 
-    def __init__(self, fn: Callable, *inputs: Tensor, stream: Optional[torch.cuda.Stream] = None, spans: bool = False):
+    def __init__(self, fn: Callable, *inputs: Tensor, stream: Optional[torch.cuda.Stream] = None, spans: bool = False,
+                 private_status: bool = False):
         for i, t in enumerate(inputs):
             if not (isinstance(t, Tensor) and t.is_cuda):
                 raise DeepLipHipError(f"StepPlan: input {i} must be a CUDA (ROCm) tensor")
@@ -122,6 +123,9 @@ class StepPlan:
         # the plan's OWN range-status block (dlip_status_scope): the recorded launches report to it on every replay, so a pipeline
         # knows which batch left the f16x3 range (take_range_error) -- check_range() sees it as well
         self.status = StatusBlock()
+        # private_status: the owner settles every report of this plan itself, the recording passes' included (a pipeline records on
+        # whatever batch comes first -- possibly the very batch that is out of range -- and repairs it after its replay)
+        self.status.private = bool(private_status)
         # spans=True: every launch of the LDS-DMA convolution kernel times itself in-kernel on every replay (dlip_span_scope_*);
         # span_names = those launches in order, as ops.LAUNCH_HOOK names them (instance, algorithmic FLOPs)
         self._spans = None

@@ -91,20 +91,25 @@ class BasicBlock(nn.Module):
         self.stride = stride
         self.planes = planes
 
-    def pack(self, device) -> Dict[str, packing.Packed]:
+    def pack(self, device, e_x: int = 0, e_h: int = 0, e_o: int = 0) -> Dict[str, packing.Packed]:
+        """``e_x`` / ``e_h`` / ``e_o``: activation exponents (f16x3 pack) of the block's input, of conv1's output and of the block's
+        output; a block without a shortcut convolution adds its input to its output, so there e_o == e_x (packing.act_exponents)."""
+        if self.downsample is None and e_o != e_x:
+            raise ValueError("BasicBlock.pack: an identity shortcut needs e_o == e_x")
         p = {
-            "conv1": packing.pack_conv2d(self.conv1.weight, None, self.bn1, device, _slope(self.relu1, self.planes, device)),
-            "conv2": packing.pack_conv2d(self.conv2.weight, None, self.bn2, device, _slope(self.relu2, self.planes, device)),
+            "conv1": packing.pack_conv2d(self.conv1.weight, None, self.bn1, device, _slope(self.relu1, self.planes, device), e_x, e_h),
+            "conv2": packing.pack_conv2d(self.conv2.weight, None, self.bn2, device, _slope(self.relu2, self.planes, device), e_h, e_o),
         }
         if self.downsample is not None:
-            p["down"] = packing.pack_conv2d(self.downsample[0].weight, None, self.downsample[1], device)
+            p["down"] = packing.pack_conv2d(self.downsample[0].weight, None, self.downsample[1], device, None, e_x, e_o)
             if packing.PRECISION == "f16x3" and self.conv2.weight.shape[1] % 32 == 0 and self.downsample[0].weight.shape[1] % 32 == 0:
                 p["conv2+down"] = packing.pack_conv2d_shortcut(self.conv2.weight, self.bn2, self.downsample[0].weight,
-                                                              self.downsample[1], device, _slope(self.relu2, self.planes, device))
+                                                              self.downsample[1], device, _slope(self.relu2, self.planes, device),
+                                                              e_h, e_x, e_o)
         return p
 
     def run(self, x: Tensor, p: Dict[str, packing.Packed], split: bool = False, out_split: bool = False,
-            pool_group: Optional[int] = None, pool_lengths: Optional[Tensor] = None, pool_len_mul: int = 1):
+            pool_group: Optional[int] = None, pool_lengths: Optional[Tensor] = None, pool_len_mul: int = 1, calib=None):
         """x NHWC.  conv1+bn1+relu1 | (1x1 s2 conv + bn) | conv2+bn2 + residual + relu2.
         ``split``: x is in the split activation format (f16x3 packing only) and so are the block's
         internal tensors; ``out_split`` keeps the result in it for the next block; ``pool_group`` (split only):
@@ -112,6 +117,8 @@ class BasicBlock(nn.Module):
         s = (self.stride, self.stride)
         h = ops.conv_nhwc(x, p["conv1"].w, p["conv1"].b, stride=s, pad=(1, 1), slope=p["conv1"].slope,
                           w_scale=p["conv1"].wscale, x_split=split, out_split=split)
+        if calib is not None and not split:      # a calibrating exact pass: (owner model, block index) -> note |h|, |out|
+            packing.calib_note(calib[0], f"h{calib[1]}", h)
         if split and FUSE_SHORTCUT and "conv2+down" in p and pool_group is None:
             q = p["conv2+down"]   # conv2 + bn2 + (1x1 s2 conv + bn)(x) + relu2 in one reduction (resnet.py:62-68)
             return ops.conv2_nhwc(h, x, q.w, q.b, q.wscale, pad=(1, 1), stride2=s, slope=q.slope, out_split=out_split)
@@ -120,8 +127,11 @@ class BasicBlock(nn.Module):
         if pool_group is not None:   # the block's output leaves as pooled partial sums only
             return ops.conv_pool(h, p["conv2"].w, p["conv2"].b, p["conv2"].wscale, pool_group, pad=(1, 1), residual=res,
                                  slope=p["conv2"].slope, lengths=pool_lengths, len_mul=pool_len_mul)
-        return ops.conv_nhwc(h, p["conv2"].w, p["conv2"].b, pad=(1, 1), residual=res, slope=p["conv2"].slope,
-                             w_scale=p["conv2"].wscale, x_split=split, out_split=out_split)
+        out = ops.conv_nhwc(h, p["conv2"].w, p["conv2"].b, pad=(1, 1), residual=res, slope=p["conv2"].slope,
+                            w_scale=p["conv2"].wscale, x_split=split, out_split=out_split)
+        if calib is not None and not split:
+            packing.calib_note(calib[0], f"o{calib[1]}", out)
+        return out
 
 
 def _basic_block_train(b: "BasicBlock", x, fork: bool = False):
@@ -188,8 +198,27 @@ class ResNet(nn.Module):
     def blocks(self) -> List[BasicBlock]:
         return [b for l in (self.layer1, self.layer2, self.layer3, self.layer4) for b in l]
 
-    def pack(self, device):
-        return [b.pack(device) for b in self.blocks()]
+    def pack(self, device, exps: Optional[dict] = None):
+        """``exps``: {"stem", "h<i>", "o<i>"} activation exponents of the owning model's f16x3 pack (None / {}: all zero)."""
+        e = exps or {}
+        out, e_x = [], e.get("stem", 0)
+        for i, b in enumerate(self.blocks()):
+            e_o = e.get(f"o{i}", 0) if b.downsample is not None else e_x
+            out.append(b.pack(device, e_x, e.get(f"h{i}", 0), e_o))
+            e_x = e_o
+        return out
+
+    def exponent_groups(self):
+        """Tensors that meet in a residual addition and therefore share an exponent: a run of identity-shortcut blocks and the
+        tensor that enters it ("stem" for layer 1, the down-sampling block's output elsewhere)."""
+        groups, cur = [], ["stem"]
+        for i, b in enumerate(self.blocks()):
+            if b.downsample is not None:
+                groups.append(cur)
+                cur = []
+            cur.append(f"o{i}")
+        groups.append(cur)
+        return groups
 
     @staticmethod
     def wants_split(packed) -> bool:
@@ -198,7 +227,7 @@ class ResNet(nn.Module):
         return packed[0]["conv1"].wscale is not None
 
     def run(self, x: Tensor, packed, taps: Optional[dict] = None, x_split: bool = False, pool_frames: Optional[int] = None,
-            pool_lengths: Optional[Tensor] = None):
+            pool_lengths: Optional[Tensor] = None, owner=None):
         """x [N,H,W,64] NHWC (in the split activation format if ``x_split``) -> [N,512]; with ``pool_frames`` = T
         (f16x3 packing): ops.Pooled sums over each clip's T*Ho*Wo output pixels of the last convolution instead
         (finish with ops.pool_finish(..., 'mean') = AdaptiveAvgPool + temporal mean); ``pool_lengths`` (int32 CUDA [B]):
@@ -216,7 +245,8 @@ class ResNet(nn.Module):
                     raise ValueError("ResNet.run: pooled output needs the f16x3 packing")
                 hw = ops.conv_out_size(x.shape[1], 3, b.stride, 1, 1) * ops.conv_out_size(x.shape[2], 3, b.stride, 1, 1)
                 return b.run(x, p, split=True, pool_group=pool_frames * hw, pool_lengths=pool_lengths, pool_len_mul=hw)
-            x = b.run(x, p, split=split, out_split=split and not last)   # avgpool reads fp32
+            x = b.run(x, p, split=split, out_split=split and not last,   # avgpool reads fp32
+                      calib=(owner, i) if (owner is not None and packing.CALIB is not None) else None)
             if taps is not None and i % 2 == 1:
                 taps[f"layer{i // 2 + 1}"] = ops.split_unpack(x) if (split and not last) else x
         return ops.avgpool(x)
@@ -486,13 +516,33 @@ class Lipreading(nn.Module):
                              num_classes=num_classes, tcn_options=tcn_options, dropout=tcn_options["dropout"],
                              relu_type=relu_type, dwpw=tcn_options["dwpw"])
 
+    def act_exponent_groups(self):
+        return self.trunk.exponent_groups()
+
     def _pack(self, device):
-        return {
+        # activation exponents of the f16x3 pack (packing.act_exponents: all zero unless a calibration set them): "in" the float
+        # clip, "stem" the pooled stem output, "h<i>" / "o<i>" the trunk's block tensors
+        e = packing.act_exponents(self) if packing.PRECISION == "f16x3" else {}
+        n_blocks = len(self.trunk.blocks())
+        pk = {
             "stem": packing.pack_stem3d(self.frontend3D[0].weight, self.frontend3D[1], device,
-                                        _slope(self.frontend3D[2], self.frontend_nout, device)),
-            "trunk": self.trunk.pack(device),
+                                        _slope(self.frontend3D[2], self.frontend_nout, device), e.get("in", 0), e.get("stem", 0)),
+            "trunk": self.trunk.pack(device, e),
             "tcn": self.tcn.pack(device),
+            "e_in": e.get("in", 0), "e_out": 0,
         }
+        if e:
+            e_x = e.get("stem", 0)       # the exponent the LAST block's output carries (identity blocks inherit their input's)
+            for i, b in enumerate(self.trunk.blocks()):
+                e_x = e.get(f"o{i}", 0) if b.downsample is not None else e_x
+            pk["e_out"] = e_x
+            if e_x:
+                pk["out_scale"] = (torch.full((self.backend_out,), 2.0 ** (-e_x), dtype=torch.float32, device=device),
+                                   torch.zeros((self.backend_out,), dtype=torch.float32, device=device))
+            if pk["e_in"]:
+                pk["in_scale"] = (torch.full((1,), 2.0 ** pk["e_in"], dtype=torch.float32, device=device),
+                                  torch.zeros((1,), dtype=torch.float32, device=device))
+        return pk
 
     def _forward_train(self, x: Tensor, lengths):
         """forward() under model.train() (train_video.py:129,140-146): the whole encoder differentiable, every
@@ -538,6 +588,14 @@ class Lipreading(nn.Module):
         p = _cached_pack(self, x.device, self._pack)
         x = x.contiguous().float()
         split = self.trunk.wants_split(p["trunk"])
+        packing.calib_note(self, "in", x)                 # (a calibrating exact pass notes the tensors' magnitudes; no-op otherwise)
+        if split and (p["e_in"] or p["e_out"] or packing.act_exponents(self)):
+            if taps is not None:
+                raise NotImplementedError("taps of a model with calibrated activation exponents (the intermediate tensors are scaled)")
+            if p["e_in"]:                                  # a float clip whose gain lies outside the split format: 2^e x first (exact)
+                sv = p.setdefault(("in_vec", W), (torch.full((W,), 2.0 ** p["e_in"], dtype=torch.float32, device=x.device),
+                                                  torch.zeros((W,), dtype=torch.float32, device=x.device)))
+                x = ops.channel_scale(x, sv[0], sv[1])
         if split and taps is None and p["stem"].wscale is not None and W <= 88 and W % 8 == 0:
             # stem + max pooling in one kernel: the pre-pool activations (4x the pooled bytes) stay on chip
             y = ops.stem3d_pool(x.view(B, T, H, W), p["stem"].w, p["stem"].b, p["stem"].slope, p["stem"].wscale, lengths=ragged)
@@ -549,12 +607,20 @@ class Lipreading(nn.Module):
             if taps is not None:
                 taps["stem_act"] = y
             y = ops.maxpool3x3s2(y, out_split=split)
+            if not split:
+                packing.calib_note(self, "stem", y)
             if taps is not None:
                 taps["stem"] = ops.split_unpack(y) if split else y
         if pooled:
             return self.trunk.run(y, p["trunk"], None, x_split=split, pool_frames=T, pool_lengths=ragged)
-        y = self.trunk.run(y, p["trunk"], taps, x_split=split).view(B, T, self.backend_out)
+        y = self._descale(self.trunk.run(y, p["trunk"], taps, x_split=split, owner=self), p).view(B, T, self.backend_out)
         return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
+
+    @staticmethod
+    def _descale(y: Tensor, p) -> Tensor:
+        """fp32 features / means of a pack whose last trunk tensor carries an activation exponent: times 2^-e (exact)."""
+        sc = p.get("out_scale")
+        return ops.channel_scale(y, sc[0], sc[1]) if sc is not None else y
 
     def _forward_u8(self, frames: Tensor, lengths, taps, pooled: bool, ragged: Optional[Tensor] = None,
                     clip_params: Optional[Tensor] = None):
@@ -568,6 +634,9 @@ class Lipreading(nn.Module):
         frames = frames.contiguous()
         p = _cached_pack(self, frames.device, self._pack)
         split = self.trunk.wants_split(p["trunk"])
+        if split and p["e_in"]:
+            raise NotImplementedError("this model's f16x3 pack was calibrated on float clips of an unusual gain (input exponent "
+                                      f"{p['e_in']}): uint8 frames always normalise into range -- re-pack (load_state_dict) to drop the calibration")
         B, T = frames.shape[0], frames.shape[1]
         if not (split and taps is None and p["stem"].wscale is not None):
             from .frontend import VideoFrontend
@@ -578,7 +647,7 @@ class Lipreading(nn.Module):
                                clip_params=clip_params)
         if pooled:
             return self.trunk.run(y, p["trunk"], None, x_split=True, pool_frames=T, pool_lengths=ragged)
-        y = self.trunk.run(y, p["trunk"], None, x_split=True).view(B, T, self.backend_out)
+        y = self._descale(self.trunk.run(y, p["trunk"], None, x_split=True), p).view(B, T, self.backend_out)
         return y if self.extract_feats else self.tcn.run(y, lengths, p["tcn"])
 
     @arith.guarded_eval
@@ -611,7 +680,8 @@ class Lipreading(nn.Module):
             lens = ops.lengths_i32(lengths, x.device, n=x.shape[0], lo=1, hi=x.shape[1] if x.dtype == torch.uint8 else x.shape[2])
         if not self.training and FUSE_POOL and self._can_pool(x):
             pooled = self.forward(x, None, pooled=True, ragged=lens)
-            return ops.pool_finish(pooled, "mean") if finish else pooled
+            # (finish=False: the sums go to fusion.fuse_av, whose z-norm is invariant under the pack's power-of-two output exponent)
+            return self._descale(ops.pool_finish(pooled, "mean"), _cached_pack(self, x.device, self._pack)) if finish else pooled
         ef, self.extract_feats = self.extract_feats, True
         try:
             return ops.time_mean(self.forward(x, lengths=None, ragged=lens), lens)

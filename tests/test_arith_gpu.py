@@ -29,10 +29,12 @@ def _oracle_rows(sd, x):
         return O.speaker_extract_embedding(O.to_torch_sd(sd), x, O.TDNN_CONTEXT)[0].numpy()
 
 
-def test_auto_eager_call_is_computed_again_in_f32():
+def test_auto_eager_call_is_computed_again_in_f32(monkeypatch):
     """An under-range input (1e-4 of what CMVN-normalised features look like) through the eager entry point: f16x3 raises,
-    auto returns oracle-grade rows and counts the re-run; an in-range call afterwards runs f16x3 again and counts nothing."""
+    auto returns oracle-grade rows and counts the re-run; an in-range call afterwards runs f16x3 again and counts nothing.
+    (Repair only, arith.CALIBRATE off: one odd batch between normal ones must not re-scale the model; the calibration has its own tests.)"""
     from deeplip_amd import _lib, arith, weightgen as wg
+    monkeypatch.setattr(arith, "CALIBRATE", False)
     net, sd = _tdnn()
     x = torch.from_numpy(wg.audio_input(3, 24, 200))
     small = x * 1.0e-4
@@ -78,13 +80,14 @@ def test_auto_video_embed_is_computed_again_in_f32():
 
 
 @pytest.mark.parametrize("mode", ["auto", "f16x3"])
-def test_pipeline_repairs_exactly_the_offending_batch(mode):
+def test_pipeline_repairs_exactly_the_offending_batch(mode, monkeypatch):
     """Five batches through an ExtractPipeline, the third one under-range.  auto: every row oracle-grade, ONE re-run, the other
     batches untouched by it (same bits as a run without the bad batch); f16x3: DeepLipRangeError by finish()."""
     from deeplip_amd import _lib, arith, weightgen as wg
     from deeplip_amd.pipeline import ExtractPipeline, pin
     net, sd = _tdnn()
     arith.configure(mode)
+    monkeypatch.setattr(arith, "CALIBRATE", False)      # (repair only: ONE odd batch among normal ones must not re-scale the model)
     B = 4
     xs = [torch.from_numpy(wg.audio_input(B, 24, 160, key=f"arith.pipe{i}")) for i in range(5)]
     xs[2] = xs[2] * 1.0e-4
@@ -137,3 +140,130 @@ def test_plan_status_block_is_its_own():
     with pytest.raises(_lib.DeepLipRangeError):
         _lib.check_range()
     pa.close(); pb.close()
+
+
+@pytest.mark.parametrize("gain_log2", [-20, -10, 14, 20])
+def test_calibration_moves_an_out_of_range_input_gain_onto_the_fast_path(gain_log2):
+    """Features with a gain of 2^-20 .. 2^+20 (a front-end without CMVN, a different scaling convention): the FIRST batch leaves the
+    f16x3 range, is computed again in exact f32 -- and that pass calibrates activation exponents (powers of two folded into the f16x3
+    pack, packing.act_exponents).  The next batches of the same kind run the fast arithmetic, no re-run, and meet the 1e-4 bar."""
+    from deeplip_amd import arith, packing, weightgen as wg
+    net, sd = _tdnn()
+    arith.configure("auto")
+    g = float(2.0 ** gain_log2)
+    xs = [torch.from_numpy(wg.audio_input(3, 24, 200, key=f"arith.gain{i}")) * g for i in range(3)]
+    n0, c0 = arith.STATS["f32_reruns"], arith.STATS["calibrations"]
+    got = net.extract_embedding(xs[0].cuda())[0]
+    assert arith.STATS["f32_reruns"] == n0 + 1 and arith.STATS["calibrations"] == c0 + 1
+    assert_close_rel(got.cpu().numpy(), _oracle_rows(sd, xs[0]), rtol=1e-4, what="first batch (exact re-run)")
+    e = packing.act_exponents(net)
+    assert e and "in" in e and (e["in"] > 0) == (gain_log2 < 0)
+    for x in xs[1:]:
+        got = net.extract_embedding(x.cuda())[0]
+        assert_close_rel(got.cpu().numpy(), _oracle_rows(sd, x), rtol=1e-4, what=f"gain 2^{gain_log2}: calibrated f16x3 path")
+    assert arith.STATS["f32_reruns"] == n0 + 1                       # ... without another exact re-run
+    # new weights void the calibration
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert packing.act_exponents(net) == {}
+
+
+def test_calibration_of_the_lip_clip_trunk_respects_the_residual_groups():
+    """A checkpoint whose trunk BatchNorms shrink the activations layer after layer: after the calibrating re-run the model embeds on
+    the f16x3 path; tensors that meet in a residual addition share their exponent (resnet.py:62-69: out += residual)."""
+    from deeplip_amd import arith, packing, weightgen as wg
+    from models.video_models.model import Lipreading
+    from oracle import deeplip_oracle as O
+    tcn = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
+    net = Lipreading(num_classes=54, relu_type="prelu", tcn_options=tcn, extract_feats=True)
+    sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="video.")
+    for k in sd:
+        if k.startswith("trunk.") and (".bn" in k or "downsample.1" in k) and k.endswith(".weight"):
+            sd[k] = np.full_like(sd[k], 0.05)
+        if k.startswith("trunk.") and (".bn" in k or "downsample.1" in k) and k.endswith(".bias"):
+            sd[k] = np.zeros_like(sd[k])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval().cuda()
+    arith.configure("auto")
+    xs = [torch.from_numpy(wg.video_input(2, frames=9, key=f"arith.vcal{i}")) for i in range(2)]
+    n0 = arith.STATS["f32_reruns"]
+    net.embed(xs[0].cuda())
+    assert arith.STATS["f32_reruns"] == n0 + 1
+    e = packing.act_exponents(net)
+    assert e and max(e.values()) > 14
+    for grp in net.act_exponent_groups():
+        assert len({e.get(n, 0) for n in grp}) == 1, (grp, e)
+    with torch.no_grad():
+        want = O.video_time_mean(O.lipreading_features(O.to_torch_sd(sd), xs[1])).numpy()
+        feats = O.lipreading_features(O.to_torch_sd(sd), xs[1]).numpy()
+    got = net.embed(xs[1].cuda())
+    assert arith.STATS["f32_reruns"] == n0 + 1                       # the second clip batch: fast path, no re-run
+    assert_close_rel(got.cpu().numpy(), want, rtol=1e-4, what="calibrated f16x3 lip-clip embed")
+    assert_close_rel(net(xs[1].cuda(), None).cpu().numpy(), feats, rtol=1e-4, what="calibrated f16x3 features [B,T,512]")
+    assert arith.STATS["f32_reruns"] == n0 + 1
+
+
+def test_pipeline_re_records_its_plans_after_a_calibration():
+    """Six batches of features with a gain of 2^-18 through an ExtractPipeline under auto: the first batches are repaired in exact f32
+    (one of those passes calibrates the model), the pipeline re-records its plans on the rebuilt f16x3 pack and the rest of the list
+    runs the fast arithmetic; every row oracle-grade."""
+    from deeplip_amd import arith, weightgen as wg
+    from deeplip_amd.pipeline import ExtractPipeline, pin
+    net, sd = _tdnn()
+    arith.configure("auto")
+    B, g = 4, float(2.0 ** -18)
+    xs = [torch.from_numpy(wg.audio_input(B, 24, 160, key=f"arith.pcal{i}")) * g for i in range(6)]
+    with torch.no_grad():
+        pipe = ExtractPipeline(lambda a: net.extract_embedding(a)[0], xs[0].cuda())
+    table = torch.zeros((6 * B, 512), device="cuda")
+    pipe.run([(pin(x),) for x in xs], table)
+    pipe.finish()
+    assert 1 <= pipe.reruns <= 3 and pipe.rerecorded >= 1
+    want = np.concatenate([_oracle_rows(sd, x) for x in xs])
+    assert_close_rel(table.cpu().numpy(), want, rtol=1e-4, what="pipeline rows across a calibration")
+    r0 = pipe.reruns
+    pipe.run([(pin(x),) for x in xs], table)                         # a second pass over the list: nothing left to repair
+    pipe.finish()
+    assert pipe.reruns == r0
+    assert_close_rel(table.cpu().numpy(), want, rtol=1e-4, what="second pass")
+    pipe.close()
+
+
+@pytest.mark.parametrize("case", ["tdnn-gamma-1e-3", "stem-var-1e3", "trunk-gamma-1e-2..10", "trunk-gamma-1e-2..1"])
+def test_checkpoint_like_statistics_meet_the_bar_under_auto(case):
+    """tests/test_range_gpu.py holds the f16x3 mode to "meets the 1e-4 bar OR raises" on checkpoints whose BatchNorm statistics push
+    activations out of the split format.  Under ``auto`` the same checkpoints simply MEET THE BAR: in range -> f16x3; out of range ->
+    the first call is computed in exact f32 and calibrates activation exponents, the second call runs f16x3 on the re-scaled pack (or
+    is repaired again if the calibration budget is spent) -- never an error, never a wrong row."""
+    from deeplip_amd import arith, weightgen as wg
+    from oracle import deeplip_oracle as O
+    import test_range_gpu as R
+    arith.configure("auto")
+    if case.startswith("tdnn"):
+        net, sd = R._tdnn()
+        for i in range(5):
+            sd[f"tdnn.{i}.bn.weight"] = np.full_like(sd[f"tdnn.{i}.bn.weight"], 1.0e-3)
+            sd[f"tdnn.{i}.bn.bias"] = np.zeros_like(sd[f"tdnn.{i}.bn.bias"])
+        xs = [torch.from_numpy(wg.audio_input(3, 24, 200, key=f"auto.r{i}")) for i in range(2)]
+        run = lambda x: net.extract_embedding(x.cuda())[0]
+        oracle = lambda x: O.speaker_extract_embedding(O.to_torch_sd(sd), x, O.TDNN_CONTEXT)[0]
+    else:
+        net, sd = R._lipreading()
+        if case == "stem-var-1e3":
+            sd["frontend3D.1.running_var"] = np.full_like(sd["frontend3D.1.running_var"], 1.0e3)
+        else:
+            lo, hi = (1e-2, 10.0) if case.endswith("10") else (1e-2, 1.0)
+            r = np.random.Generator(np.random.PCG64(100))
+            for k in sd:
+                if k.startswith("trunk.") and (".bn" in k or "downsample.1" in k) and k.endswith(".weight"):
+                    sd[k] = np.exp(r.uniform(np.log(lo), np.log(hi), sd[k].shape)).astype(np.float32)
+        xs = [torch.from_numpy(wg.video_input(2, frames=9, key=f"auto.rv{i}")) for i in range(2)]
+        run = lambda x: net(x.cuda(), None)
+        oracle = lambda x: O.lipreading_features(O.to_torch_sd(sd), x)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval().cuda()
+    n0 = arith.STATS["f32_reruns"]
+    for i, x in enumerate(xs):
+        with torch.no_grad():
+            want = oracle(x).numpy()
+        assert_close_rel(run(x).cpu().numpy(), want, rtol=1e-4, what=f"{case}, call {i}")
+    print(f"\n{case}: {arith.STATS['f32_reruns'] - n0} exact re-run(s) over 2 calls, exponents {__import__('deeplip_amd.packing', fromlist=['x']).act_exponents(net)}")
