@@ -431,7 +431,7 @@ def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan, c5_all=Non
         import train_video
 
         def run():
-            train_video.main(["--batch-size", "32", "--frames", "29", "--steps", "14", "--maxepoch", "1", "--data-cache", "2", "--display", "100",
+            train_video.main(["--batch-size", "32", "--frames", "29", "--steps", "27", "--maxepoch", "1", "--data-cache", "2", "--display", "100",
                               "--save-path", os.path.join(os.getcwd(), "ck")])
             st = dict(train_video.train.last_stats)
             st = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}
