@@ -55,6 +55,56 @@ if __name__ == "__main__" and not _launch.in_job():
     if _n > 1:
         sys.exit(_launch.self_launch(os.path.abspath(__file__), sys.argv[1:], _n, relay=_relay))
 
+LIVE_PMC = None       # {"kernels": pmc.summarise(...), "steps": n, "seconds": s} from this run's own counter passes, or {"skipped": why}
+
+
+def _live_pmc_passes(argv):
+    """`roofline.traffic` measured IN THIS RUN: two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate passes, as the guide
+    prescribes) of this very command, run as CHILD processes NOW -- before this process has touched the GPU -- on 5 + 2 replayed steps
+    each.  Single process only (N = 1 outside a job); --no-pmc skips them; any failure leaves the committed collection
+    (profiles/traffic_latest.json, sha-stamped) as the source, and the line says which it was."""
+    import shutil
+    import subprocess
+    import tempfile
+    if "--pmc-child" in argv or "--no-pmc" in argv or "--dry-launch" in argv or "--eager" in argv:
+        return {"skipped": "disabled for this invocation"}
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {"skipped": "rocprofv3 not on PATH"}
+    steps, warm = 5, 2
+    t0 = time.perf_counter()
+    dirs = []
+    passthrough = []
+    for flag in ("--batch", "--audio-dim", "--precision"):
+        if flag in argv:
+            i = argv.index(flag)
+            passthrough += argv[i:i + 2]
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="dlip_pmc_")
+            dirs.append(d)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps),
+                   "--warmup", str(warm), "--no-cpu-baseline", "--single-mode", "--no-configs", "--no-kernel-events", "--no-h2d", "--no-spans",
+                   "--pmc-child"] + passthrough
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+            if r.returncode != 0:
+                return {"skipped": f"the {counter} pass exited with {r.returncode}"}
+        from deeplip_amd import pmc
+        kernels = pmc.summarise(dirs, steps + warm)
+        if not kernels:
+            return {"skipped": "the passes wrote no counter rows"}
+        return {"kernels": kernels, "steps": steps + warm, "seconds": round(time.perf_counter() - t0, 1)}
+    except Exception as ex:   # noqa: BLE001 -- evidence gathering must never take the measurement down
+        return {"skipped": f"{type(ex).__name__}: {ex}"[:200]}
+    finally:
+        for d in dirs:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__" and not _launch.in_job() and _launch.argv_gpus(sys.argv[1:]) <= 1:
+    LIVE_PMC = _live_pmc_passes(sys.argv[1:])       # (child processes; this one has not imported torch yet)
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -691,6 +741,9 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="issue the two encoders in sequence on one stream (default: the "
                     "speech encoder on a second stream, fork / join recorded into the step plan)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic in this run "
+                    "(then profiles/traffic_latest.json is quoted, if it belongs to this kernel build)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dp-leg", action="store_true", help="inside a torch.distributed job: run the DP training leg even with --no-configs (tests)")
     ap.add_argument("--dp-leg-timeout", type=int, default=240, help="N > 1: seconds the DP training leg (C5 on every rank) may take before the "
                     "watchdog prints the line without it")
@@ -960,7 +1013,23 @@ def main():
         # inside this process, so it comes from the committed PMC passes of this same command (tools/collect_profiles.sh
         # -> profiles/traffic_latest.json) -- and only if that file was produced by THIS kernel source (sha over
         # conv_igemm_f16x3_dma.hip and the headers it includes, stamped into it); otherwise null rather than a stale number.
+        live = LIVE_PMC if (isinstance(LIVE_PMC, dict) and "kernels" in LIVE_PMC and precision == args.precision) else None
+        if live is not None:
+            k = live["kernels"].get(roof.get("kernel", ""))
+            if k and "hbm_read_bytes_per_launch" in k and "hbm_write_bytes_per_launch" in k:
+                from deeplip_amd import build as _build
+                roof["traffic"] = round(k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"])
+                roof["traffic_read_write"] = [round(k["hbm_read_bytes_per_launch"]), round(k["hbm_write_bytes_per_launch"])]
+                roof["traffic_source"] = ("measured in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate, FETCH x2 gfx950 "
+                                          f"correction) of this command over {live['steps']} replayed steps each, run as child processes before the "
+                                          f"timed regions ({live['seconds']} s); {k['launches']} launches of the kernel counted")
+                roof["traffic_collected"] = {"utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "box": _build.box_id(), "same_box_as_this_run": True,
+                                             "in_run": True}
+        elif isinstance(LIVE_PMC, dict) and precision == args.precision:
+            roof["traffic_in_run"] = LIVE_PMC.get("skipped")
         try:
+            if roof.get("traffic") is not None:
+                raise StopIteration      # (measured in this run: the committed collection is not consulted)
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
             meta = tr.get("_meta", {})
             key = roof.get("kernel", "")

@@ -158,3 +158,24 @@ def test_plda_closed_form_matches_bruteforce_density():
         closed = np.sum(np.log1p(psi) - 0.5 * np.log1p(2 * psi) + psi * (u1 + u2) ** 2 / (2 * (1 + 2 * psi))
                         - psi * (u1 ** 2 + u2 ** 2) / (2 * (1 + psi)))
         assert abs(closed - O.plda_llr_bruteforce(u1, u2, psi)) < 1e-9 * max(1.0, abs(closed))
+
+
+def test_pmc_summary_parses_counter_csvs(tmp_path):
+    """deeplip_amd.pmc (used by tools/pmc_summary.py and by bench.py's in-run counter passes): per-launch HBM bytes with the gfx950
+    FETCH_SIZE x2 correction, kernel names as the bench line spells them."""
+    from deeplip_amd import pmc
+    d = tmp_path / "pass" / "host"
+    d.mkdir(parents=True)
+    name = "void (anonymous namespace)::conv_igemm_f16x3_dma_kernel<256, 128, 4, 2, 1, 3, 1, false, 0>((anonymous namespace)::ConvArgs)"
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    for i in range(4):
+        rows.append(f'{i},"{name}",FETCH_SIZE,1000')
+        rows.append(f'{i},"{name}",WRITE_SIZE,500')
+    (d / "1_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    res = pmc.summarise([str(tmp_path / "pass")], 2)
+    k = res["conv_igemm_f16x3_dma_kernel<256,128>"]
+    assert k["launches"] == 4 and k["launches_per_step"] == 2
+    assert k["hbm_read_bytes_per_launch"] == 2 * 1000 * 1024 and k["hbm_write_bytes_per_launch"] == 500 * 1024
+    assert pmc.short("void conv_win_f16x3_kernel<128, 64, 2, 2, true, 2>(ConvArgs)") == "conv_win_f16x3_kernel<128,64>"
+    assert pmc.short("x::conv_igemm_f16x3_dma_kernel<256, 128, 4, 2, 2, 3, 1, false, 0>") == "conv_igemm_f16x3_dma_kernel<256,128,pool>"
+    assert pmc.short("x::conv_igemm_f16x3_dma_kernel<256, 128, 4, 2, 1, 3, 1, true, 0>") == "conv_igemm_f16x3_dma_kernel<256,128,dual>"
