@@ -13,6 +13,11 @@ whole encoder (conv dgrad / wgrad, BN and pooling backward as dlip_* launches --
 SGD over model + criterion parameters, MultiStepLR, margin schedule, per-epoch checkpoints and checkpoint
 averaging.  ``train.freeze_encoder: true`` keeps the older criterion-only step on frozen x-vectors.
 
+Round 6: a batch is cut to ONE crop length drawn from a short ladder over ``train.crop_frames`` (the collate's random crop,
+models/audio_models/datasets.py:112-115) and the optimisation step is recorded once per crop length (and margin) and replayed
+(``train.graph_step``, ``--eager-step``); ragged test lists go through ONE extractor per trainer; ``--arith`` / ``model.arith`` pick the
+arithmetic (deeplip_amd/arith.py: auto = f16x3 with an in-process f32 re-run -- and calibration -- of what leaves its range).
+
 Data parallelism (the reference wraps the model in nn.DataParallel over ``gpus_id``, train_audio.py:80-83): launched
 under ``torch.distributed.run`` every rank draws its own batches, replicas start from rank 0's weights, gradients are
 averaged by bucketed all-reduces over RCCL that overlap the backward pass (deeplip_amd.dist.GradBuckets), metrics are

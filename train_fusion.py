@@ -16,6 +16,11 @@ three structural changes:
   * data parallel = one process per GPU over RCCL (gradient all-reduce of the trainable tail, one
     all-gather of test embeddings), replacing nn.DataParallel (:91-93).
 
+Round 6: ``--mode train`` runs the frozen encoders as a two-deep recorded pipeline (copies of batch i + 2 behind the encoders' work on
+batch i + 1 behind the head's step on batch i) and the head's forward + backward + all-reduce + SGD as ONE recorded step
+(``train.graph_step``, ``--eager-step``); extraction keeps one RaggedExtractor per trainer (``test.batch``, ``test.frames: u8|f32``);
+``--arith`` / ``model.arith`` pick the arithmetic (auto = the benchmarked f16x3, out-of-range batches computed again in f32).
+
     python train_fusion.py --mode train            # single GPU
     python train_fusion.py --mode train --gpus 8   # starts its own 8-rank job (deeplip_amd/launch.py); so does a config
                                                    # whose train.gpus_id lists 8 devices, as in the reference

@@ -17,7 +17,10 @@ class (tests/test_train_video_gpu.py).  ``--head-only`` trains the classifier la
 frozen eval-mode features instead (the fast path on the fused inference kernels).  Under
 ``torch.distributed.run`` every rank draws its own batches and the gradients are averaged by bucketed
 all-reduce per step over RCCL (the reference uses DataParallel: train_video.py:196).
-``--device cpu`` runs the plumbing only (config -> model -> batches -> optimiser/scheduler ->
+Round 6: the optimisation step is RECORDED once per batch shape and replayed as one HIP graph by default (``--eager-step`` keeps the
+loop of eager launches; deeplip_amd/train_plan.py), the next batch's host-to-device copies run behind the step in flight, metrics stay
+on the device between ``--display`` points; ``--arith auto|f16x3|f32`` (default: $DLIP_ARITH, the config's "arith", auto) picks the
+engine's arithmetic (deeplip_amd/arith.py).  ``--device cpu`` runs the plumbing only (config -> model -> batches -> optimiser/scheduler ->
 checkpoint round trip) because the engine has no CPU arithmetic by design.
 """
 from __future__ import annotations
