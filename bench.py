@@ -469,6 +469,8 @@ def extra_configs(args, device, video, audio, xv, xa, peak, StepPlan, c5_all=Non
                         "valid_gflop_per_s": round(valid_gf / t_ex, 1),
                         "vs_C4_ragged_extraction": round(valid_gf / t_ex / ragged["valid_gflop_per_s"], 4) if ragged and "valid_gflop_per_s" in ragged else None,
                         "store_write_s": round(t_store, 3), "score_from_store_s": round(t_score, 3), "eer": round(float(eer), 6),
+                        "eer_note": "near 0.5 by construction: this leg cuts every item from a small pool of generated clips / utterances (the timing "
+                                    "does not care what the pixels are), so the list carries no speaker structure; C4_fusion_scoring is the EER check",
                         "arith": tr.arith, "f32_reruns": stats.get("f32_reruns", 0), "plans_recorded": stats.get("plans_recorded")}
             finally:
                 tr.close()

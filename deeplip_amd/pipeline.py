@@ -70,6 +70,7 @@ class ExtractPipeline:
         self._pending: list = [None] * depth # (tables, row, rows) of the replay in flight on set k: settled when the set is recycled / at finish()
         # (every report of a replay is settled here, batch by batch: _settle; the plans' status blocks are private)
         self._fifo: list = []                # sets with an unsettled replay, oldest first (wait_next)
+        self._rows = [0] * depth             # rows of the batch a set holds (prefetch -> replay)
         self._replayed = [False] * depth     # set k has a replay in flight (or finished) whose FREE event must be awaited before refilling it
         self._next = 0                       # batches submitted so far: batch i uses input set i % depth
         self.batch = int(example_inputs[0].shape[0])
@@ -81,7 +82,13 @@ class ExtractPipeline:
     def submit(self, hb: Sequence[Tensor], tables: Sequence[Tensor], row: int) -> int:
         """One batch: ``hb`` (pinned host tensors shaped like the recorded inputs; any of them may be SHORT in its leading
         dimension) -> copies on the copy stream, one plan replay on the run stream, the first ``rows = hb[0].shape[0]`` output rows
-        into ``tables[j][row : row + rows]``.  Asynchronous; returns ``rows``."""
+        into ``tables[j][row : row + rows]``.  Asynchronous; returns ``rows``.  (= prefetch + replay.)"""
+        return self.replay(self.prefetch(hb), tables, row)
+
+    def prefetch(self, hb: Sequence[Tensor]) -> int:
+        """The copy half of ``submit``: the batch goes into the next input set (copy stream; the host first waits for the replay
+        that last read the set).  Returns the set's index for ``replay``.  A caller that wants the replays in ITS order -- the
+        fusion trainer runs encoders(i), head(i), encoders(i + 1) back to back on one stream -- prefetches ahead and replays late."""
         k = self._next % self.depth
         self._next += 1
         ins = self.sets[k]
@@ -99,10 +106,18 @@ class ExtractPipeline:
             # 4.2 (and the enqueue itself 2.3 ms per batch); throttled, every batch takes 4.23 ms -- the resident rate.
             self.free[k].synchronize()
             self._settle(k)
+            self._replayed[k] = False
         with torch.cuda.stream(self.copy_stream):
             for dst, src in zip(ins, hb):
                 (dst if src.shape[0] == dst.shape[0] else dst[:src.shape[0]]).copy_(src, non_blocking=True)
             self.ready[k].record(self.copy_stream)
+        self._rows[k] = rows
+        return k
+
+    def replay(self, k: int, tables: Sequence[Tensor], row: int) -> int:
+        """The run half of ``submit`` for the set ``prefetch`` returned: the plan's replay on the run stream behind the set's copies,
+        its first rows into ``tables[j][row : ...]``."""
+        rows = self._rows[k]
         with torch.cuda.stream(self.run_stream):
             self.run_stream.wait_event(self.ready[k])
             try:
