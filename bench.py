@@ -644,6 +644,8 @@ def c5_entry(args):
     all-reduce of the 3.4 MB head at N > 1, SGD: one HIP graph), conf/fusion_config.yaml:87-99 at bs 60."""
     import train_fusion
     from deeplip_amd import arith
+    if os.environ.get("DLIP_BENCH_DP_HANG") == "1":      # test hook (tests/test_rccl_gpu.py): a rank that never comes back -> the watchdog's turn
+        time.sleep(10 ** 6)
     sync = torch.cuda.synchronize
     st_, wu = max(5, args.steps // 2), 2
     ov = {"train.bs": 60, "train.loss": "LMCL", "train.steps_per_epoch": 12, "train.data_cache": 2, "train.epoch": 2,

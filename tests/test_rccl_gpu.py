@@ -58,6 +58,17 @@ def test_bench_dp_training_leg_on_rccl_one_rank(monkeypatch):
     assert c5["verified"]["outputs_rel_err"] <= 1e-6 and c5["verified"]["witness_rel_err"] <= 1e-6
 
 
+def test_bench_watchdog_prints_the_line_when_the_dp_leg_hangs(monkeypatch):
+    """The DP training leg runs LAST and under a watchdog: a rank that hangs in it (here: by a test hook) must not cost the scaling
+    record -- after --dp-leg-timeout seconds the line is printed as it stands, with the leg marked, and the job ends with code 0."""
+    monkeypatch.setenv("DLIP_BENCH_DP_HANG", "1")
+    rc, js, lines = _run("bench.py", ["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-configs", "--single-mode", "--no-h2d", "--dp-leg",
+                                      "--dp-leg-timeout", "5"])
+    assert rc == 0, "".join(lines)[-2000:]
+    assert len(js) == 1 and js[0]["value"] > 1000
+    assert "did not finish" in js[0]["configs"]["C5_fusion_train_step"]["error"]
+
+
 def test_train_audio_dp_on_rccl_one_rank(tmp_path):
     """BASELINE config C5's mechanism (DP training, bucketed all-reduce behind backward) as a job on the real backend."""
     over = ["data.test_speakers=4", "data.test_utt_per_spk=3", "data.trials=200", "data.trial_targets=40", "data.audio_frames=120",
