@@ -67,6 +67,8 @@ struct StemArgs {
   unsigned long long* span;     // NULL, or {first start, last end} of this launch in 100 MHz ticks (dlip_span_scope_*): the pre-pass notes the start
 #ifdef DLIP_LAB
   unsigned long long* stamps;   // lab build: [grid][8] s_memtime of each workgroup's second tile
+  int lab_skip_last_step;       // lab probe (DLIP_STEM_SKIP_STEP8=1; WRONG results, timing only): the reduction without its 9th k-step --
+                                // what a K = 256 repack (8 steps instead of 9) could gain at most, before it pays for its gather
 #endif
 };
 
@@ -521,6 +523,9 @@ __global__ __launch_bounds__(PTHREADS) void stem3d_pool_f16x3_kernel(const StemA
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
+#ifdef DLIP_LAB
+      if (s == STEPS - 1 && a.lab_skip_last_step) continue;
+#endif
       const int rho16 = (4 * s + kq) * 16;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -707,6 +712,7 @@ extern "C" int dlip_stem3d_bn_act_f16x3(const float* x, const void* w_split, con
   }
 #ifdef DLIP_LAB
   a.stamps = nullptr;
+  a.lab_skip_last_step = 0;
   if (getenv("DLIP_STAMP_PRINT")) {
     static unsigned long long* dbuf = nullptr;
     if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), 256 * 8 * 8);
@@ -784,6 +790,7 @@ static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws,
   }
 #ifdef DLIP_LAB
   a.stamps = nullptr;
+  a.lab_skip_last_step = getenv("DLIP_STEM_SKIP_STEP8") ? 1 : 0;
   if (getenv("DLIP_STAMP_PRINT")) {
     static unsigned long long* dbuf = nullptr;
     constexpr size_t NS = 256 * 12 * 8;
