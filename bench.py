@@ -679,6 +679,36 @@ def c5_entry(args):
 
 
 
+def last_leg_under_watchdog(res, rank, timeout_s, key, fn):
+    """Run ``fn()`` -- a leg EVERY rank of the job takes part in -- as the last thing before the line is printed, under a watchdog.
+    Everything measured so far is in ``res`` (rank 0's line; None on the other ranks).  If the leg does not come back within
+    ``timeout_s`` (one rank failing inside a collective leaves the others waiting for it) the watchdog prints the line as it stands,
+    marks the leg, and ends THIS process with code 0; every rank has its own watchdog, so the job ends clean and the record
+    survives.  Returns what ``fn`` returned (or an error record), already stored under ``res["configs"][key]`` on rank 0."""
+    import threading
+
+    def bail():
+        if rank == 0 and res is not None:
+            res.setdefault("configs", {})[key] = {"error": f"this leg did not finish within {timeout_s} s; the line was printed by the watchdog"}
+            print(json.dumps(res), flush=True)
+        os._exit(0)
+
+    dog = threading.Timer(float(timeout_s), bail)
+    dog.daemon = True
+    dog.start()
+    try:
+        out = fn()
+    except Exception as ex:   # noqa: BLE001
+        out = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    # the ranks leave the leg together or not at all (a rank that failed above would otherwise run ahead into the teardown)
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    dog.cancel()
+    if res is not None:
+        res.setdefault("configs", {})[key] = out
+    return out
+
+
 def dry_launch(args, world, rank):
     """Rehearsal of the N-rank launch where there is no second GPU: CPU ranks, backend gloo, a stand-in for the per-rank step
     (a [B,1024] row block filled with the rank id), then the REAL protocol of a scaling run -- exchange() after every step,
@@ -715,13 +745,28 @@ def dry_launch(args, world, rank):
     if world > 1:
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
+    res = None
     if rank == 0:
-        print(json.dumps({"metric": "lip-clips/sec (fused A+V embed)", "value": None, "unit": "lip-clips/sec", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * float(tmax.item()) / max(1, args.steps), 4),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
-                          "dry_launch": True, "config": {"workload": "launcher rehearsal: CPU ranks over gloo, stand-in step, "
-                                                                      "real exchange protocol; not a measurement"},
-                          "ranks": ranks}), flush=True)
+        res = {"metric": "lip-clips/sec (fused A+V embed)", "value": None, "unit": "lip-clips/sec", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * float(tmax.item()) / max(1, args.steps), 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": None, "data": "none",
+               "dry_launch": True, "config": {"workload": "launcher rehearsal: CPU ranks over gloo, stand-in step, "
+                                                           "real exchange protocol; not a measurement"},
+               "ranks": ranks}
+    if args.dp_leg:
+        # rehearsal of the scaling run's LAST leg (the DP training epoch every rank takes part in) and of its watchdog: a stand-in
+        # collective; --dry-hang-rank R makes rank R never come back, which leaves the others waiting inside the all-reduce
+        def leg():
+            if rank == args.dry_hang_rank:
+                time.sleep(10 ** 6)
+            t = torch.tensor([float(rank + 1)])
+            if world > 1:
+                dist.all_reduce(t)
+            return {"stand_in_allreduce": float(t.item()), "ranks": world}
+
+        last_leg_under_watchdog(res, rank, args.dp_leg_timeout, "C5_fusion_train_step", leg)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -765,6 +810,8 @@ def main():
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher rehearsal on CPU ranks (gloo): stand-in step + the real exchange, one JSON line, no measurement")
     ap.add_argument("--dry-fail-rank", type=int, default=-1, help="with --dry-launch: this rank exits 3 (tests return-code propagation)")
+    ap.add_argument("--dry-hang-rank", type=int, default=-1, help="with --dry-launch --dp-leg: this rank never comes back from the last leg "
+                    "(tests the watchdog: the line is printed without the leg, every rank ends with code 0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1139,28 +1186,12 @@ def main():
         # (a captured collective on a second communicator; first replay checked against an eager step, train_plan.py).  Everything
         # measured above is already in `res`: if this leg hangs (one rank failing inside a collective would leave the others
         # waiting) the watchdog prints the line as it stands, says so, and ends the process -- the scaling record survives.
-        import threading
+        def dp_leg():
+            out = c5_entry(args)
+            out["ranks"] = world
+            return out
 
-        def bail():
-            if rank == 0 and res is not None:
-                res.setdefault("configs", {})["C5_fusion_train_step"] = {"error": f"the DP training leg did not finish within {args.dp_leg_timeout} s; "
-                                                                                  "the line was printed by the watchdog"}
-                print(json.dumps(res), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(float(args.dp_leg_timeout), bail)
-        dog.daemon = True
-        dog.start()
-        try:
-            c5_all = c5_entry(args)
-            c5_all["ranks"] = world
-        except Exception as ex:   # noqa: BLE001
-            c5_all = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-        # the ranks leave this leg together or not at all (a rank that failed above would otherwise run ahead into the teardown)
-        dist.barrier()
-        dog.cancel()
-        if res is not None:
-            res.setdefault("configs", {})["C5_fusion_train_step"] = c5_all
+        last_leg_under_watchdog(res, rank, args.dp_leg_timeout, "C5_fusion_train_step", dp_leg)
     if rank == 0:
         print(json.dumps(res), flush=True)
 

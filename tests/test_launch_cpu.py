@@ -102,6 +102,22 @@ def test_sigterm_to_the_launcher_ends_the_job():
     assert not alive, alive
 
 
+def test_bench_last_leg_watchdog_two_ranks():
+    """The scaling run's LAST leg (the DP training epoch every rank takes part in) runs under a watchdog: rehearsed on two CPU ranks --
+    the leg completes -> its result is in the line; rank 1 never comes back (rank 0 then waits inside the all-reduce) -> after
+    --dp-leg-timeout seconds rank 0's watchdog prints the line without the leg, both ranks end with code 0, the launcher returns 0."""
+    r = _run("--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "0", "--dp-leg")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["configs"]["C5_fusion_train_step"] == {"stand_in_allreduce": 3.0, "ranks": 2}
+    r = _run("--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "0", "--dp-leg", "--dry-hang-rank", "1", "--dp-leg-timeout", "4")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "did not finish within 4 s" in d["configs"]["C5_fusion_train_step"]["error"]
+
+
 def test_train_fusion_dry_two_ranks_end_to_end(tmp_path):
     """`python train_fusion.py --mode train --dry --gpus 2`: the trainer launches its own 2-rank job (CPU ranks, gloo) and runs the
     data-parallel protocol of BASELINE config C5 around stand-in arithmetic (train_fusion.py:88-93,241-315): one job name for all
