@@ -109,6 +109,21 @@ def rerun_exact(fn: Callable, *args, what: str = "a batch", err: Optional[Except
     return out
 
 
+def calibrate(fn: Callable, *args):
+    """Explicit calibration (any mode): run ``fn(*args)`` -- eval-mode forwards of the models to calibrate, on a representative batch --
+    in exact fp32 and give those models activation exponents for their f16x3 packs (packing.calib_finish).  Returns fn's (exact)
+    result.  Under ``auto`` this happens by itself on the first out-of-range batch; under ``f16x3`` it is how a checkpoint whose
+    activations live outside the split format is made to run there without an exception."""
+    packing.CALIB = {}
+    try:
+        with exact(), torch.no_grad():
+            out = fn(*args)
+    finally:
+        n = packing.calib_finish()
+    STATS["calibrations"] += n
+    return out
+
+
 def guarded_eval(fn):
     """Method decorator of the encoders' eval-mode entry points.  Under ``auto`` an EAGER call (not one being recorded into a step
     plan, not one nested in another guarded call) is followed by a synchronise + range check, and a range error turns into a second

@@ -267,3 +267,52 @@ def test_checkpoint_like_statistics_meet_the_bar_under_auto(case):
             want = oracle(x).numpy()
         assert_close_rel(run(x).cpu().numpy(), want, rtol=1e-4, what=f"{case}, call {i}")
     print(f"\n{case}: {arith.STATS['f32_reruns'] - n0} exact re-run(s) over 2 calls, exponents {__import__('deeplip_amd.packing', fromlist=['x']).act_exponents(net)}")
+
+
+def test_explicit_calibration_lets_plain_f16x3_run_an_out_of_range_input():
+    """arith.calibrate(fn, batch): under plain ``f16x3`` (which raises on a range report, it never re-runs) a model calibrated on one
+    representative batch takes the same kind of input without an exception, at the bar."""
+    from deeplip_amd import _lib, arith, packing, weightgen as wg
+    net, sd = _tdnn()
+    arith.configure("f16x3")
+    g = float(2.0 ** -16)
+    xs = [torch.from_numpy(wg.audio_input(3, 24, 200, key=f"arith.ecal{i}")) * g for i in range(2)]
+    with pytest.raises(_lib.DeepLipRangeError):
+        net.extract_embedding(xs[0].cuda())
+        _lib.check_range(sync=True)
+    exact = arith.calibrate(lambda x: net.extract_embedding(x)[0], xs[0].cuda())
+    assert_close_rel(exact.cpu().numpy(), _oracle_rows(sd, xs[0]), rtol=1e-4, what="the calibrating pass itself (exact f32)")
+    assert packing.act_exponents(net).get("in", 0) > 14
+    got = net.extract_embedding(xs[1].cuda())[0]
+    _lib.check_range(sync=True)                                      # nothing reported
+    assert_close_rel(got.cpu().numpy(), _oracle_rows(sd, xs[1]), rtol=1e-4, what="plain f16x3 after an explicit calibration")
+
+
+def test_trainer_extraction_of_an_out_of_range_list_repairs_calibrates_and_reports(tmp_path, monkeypatch):
+    """The entry point: train_audio.Trainer (arith auto, the shipped default) extracting a ragged test list whose features carry a
+    gain of 2^-18.  The first batch is computed again in exact f32 and calibrates the encoder; the extractor's plans are re-recorded;
+    the table is oracle-grade row by row; the trainer's extract_stats and arith.STATS say what happened."""
+    import train_audio
+    from deeplip_amd import arith, weightgen as wg
+    from oracle import deeplip_oracle as O
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("DLIP_ARITH", "auto")
+    tr = train_audio.Trainer(overrides={"data.test_speakers": 4, "data.test_utt_per_spk": 4, "data.trials": 100, "data.trial_targets": 20,
+                                        "data.n_spk": 6, "data.utt_per_spk": 2, "data.test_audio_frames": [60, 140], "test.write_store": False})
+    ds = tr.voxtestset
+    item = ds.audio_item
+    g = np.float32(2.0 ** -18)
+    ds.audio_item = lambda i: item(i) * g
+    n0, c0 = arith.STATS["f32_reruns"], arith.STATS["calibrations"]
+    table = tr._xvectors(ds, batch=8, normalize=False)
+    assert arith.STATS["f32_reruns"] > n0 and arith.STATS["calibrations"] > c0 and tr.extract_stats["f32_reruns"] >= 1
+    sd = O.to_torch_sd(wg.fill_state_dict({k: tuple(v.shape) for k, v in tr.model.state_dict().items()}, prefix="audio."))
+    rows = []
+    with torch.no_grad():
+        for i in range(len(ds)):
+            rows.append(O.speaker_extract_embedding(sd, torch.from_numpy(ds.audio_item(i)[None]), O.ETDNN_CONTEXT)[0])
+    assert_close_rel(table.emb.cpu().numpy(), torch.cat(rows).numpy(), rtol=1e-4, what="x-vectors of an out-of-range list")
+    n1 = arith.STATS["f32_reruns"]
+    tr._xvectors(ds, batch=8, normalize=False)                       # a second pass over the list: the calibrated fast path
+    assert arith.STATS["f32_reruns"] == n1
+    tr.close()
