@@ -68,6 +68,10 @@ def _live_pmc_passes(argv):
     import tempfile
     if "--pmc-child" in argv or "--no-pmc" in argv or "--dry-launch" in argv or "--eager" in argv:
         return {"skipped": "disabled for this invocation"}
+    # Never from inside a profiler: under `rocprofv3 ... -- python3 bench.py` the tool's preloaded library may already have initialised
+    # the GPU in THIS process, and a process that holds the GPU must not start (fork + exec) another program on this pool.
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return {"skipped": "this process runs under a profiler"}
     exe = shutil.which("rocprofv3")
     if exe is None:
         return {"skipped": "rocprofv3 not on PATH"}

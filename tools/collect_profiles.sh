@@ -9,8 +9,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 STEPS=5
 SSTEPS=40   # the kernel-trace runs: long enough to sit at the chip's steady (power-capped) clocks like bench.py's own timed region
-ARGS="$R/bench.py --steps $SSTEPS --warmup 5 --no-cpu-baseline --single-mode"
-PARGS="$R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --single-mode --no-configs --no-kernel-events"
+ARGS="$R/bench.py --steps $SSTEPS --warmup 5 --no-cpu-baseline --single-mode --no-pmc"     # (--no-pmc: a profiled bench must not start its own counter passes)
+PARGS="$R/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --single-mode --no-configs --no-kernel-events --no-pmc"
 # kernel durations: single-stream run (what bench.py's HIP events time; with the two encoders overlapped on two streams a
 # trace charges each kernel the time it shared the chip) -> kernel_stats.csv; the default two-stream command -> kernel_stats_two_stream.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $ARGS --no-configs --single-stream > $O/stats.log 2>&1
@@ -27,6 +27,8 @@ rm -rf $O/stats/*/*kernel_trace.csv   # large; the stats csv is what gets commit
 # the judged bench line LAST, with this very collection's counters as `roofline.traffic` (bench.py reads profiles/traffic_latest.json
 # and ignores it unless its kernel_sha matches the library's dominant-kernel sources)
 cp $O/pmc_summary.json $R/profiles/traffic_latest.json
+# (un-profiled: this run makes its own two --pmc passes before it touches the GPU and quotes THEM as roofline.traffic; the passes above
+# stay in pmc_summary.json / profiles/traffic_latest.json as the cross-check and for the other counters)
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -c 2500 $O/bench.json
 ls $O
