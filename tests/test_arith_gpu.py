@@ -184,7 +184,7 @@ def test_calibration_of_the_lip_clip_trunk_respects_the_residual_groups():
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net.eval().cuda()
     arith.configure("auto")
-    xs = [torch.from_numpy(wg.video_input(2, frames=9, key=f"arith.vcal{i}")) for i in range(2)]
+    xs = [torch.from_numpy(wg.video_input(2, frames=29, key=f"arith.vcal{i}")) for i in range(2)]      # (29 frames: the pooled epilogue serves embed())
     n0 = arith.STATS["f32_reruns"]
     net.embed(xs[0].cuda())
     assert arith.STATS["f32_reruns"] == n0 + 1
@@ -199,6 +199,12 @@ def test_calibration_of_the_lip_clip_trunk_respects_the_residual_groups():
     assert arith.STATS["f32_reruns"] == n0 + 1                       # the second clip batch: fast path, no re-run
     assert_close_rel(got.cpu().numpy(), want, rtol=1e-4, what="calibrated f16x3 lip-clip embed")
     assert_close_rel(net(xs[1].cuda(), None).cpu().numpy(), feats, rtol=1e-4, what="calibrated f16x3 features [B,T,512]")
+    # the fused row: the pooled sums reach the z-norm still carrying the pack's output exponent -- invariant under it, bit for bit
+    from deeplip_amd import fusion, ops
+    xa = torch.randn(2, 512, generator=torch.Generator().manual_seed(1)).cuda()
+    pooled = net.embed(xs[1].cuda(), finish=False)
+    assert isinstance(pooled, ops.Pooled)
+    assert torch.equal(fusion.fuse_av(xa, pooled), fusion.fuse_av(xa, net.embed(xs[1].cuda())))
     assert arith.STATS["f32_reruns"] == n0 + 1
 
 
