@@ -262,7 +262,8 @@ def test_attentive_speaker_encoder_two_sgd_steps_vs_reference_golden(golden):
             assert np.array_equal(torch.max(logits, 1)[1].cpu().numpy(), g["argmax0"])
             gr = {k: v.grad for k, v in net.named_parameters()}
             for k in ("pooling.W", "pooling.b", "pooling.v"):
-                assert rel_err(gr[k].cpu().numpy(), g["grad_" + k]) < 1e-3, k        # (through sqrt(q - m^2): fp32 cancellation on both sides)
+                got = gr[k][:6] if k == "pooling.W" else gr[k]                        # (the fixture keeps six rows of W's gradient)
+                assert rel_err(got.cpu().numpy(), g["grad_" + k]) < 1e-3, k           # (through sqrt(q - m^2): fp32 cancellation on both sides)
             assert abs(float(gr["pooling.k"])) < 1e-5                                  # softmax is shift-invariant: d/dk = 0 up to rounding
             assert rel_err(gr["fc1.weight"][:4].cpu().numpy(), g["grad_fc1_w_rows4"]) < 1e-4
             for k, v in gr.items():
@@ -272,7 +273,8 @@ def test_attentive_speaker_encoder_two_sgd_steps_vs_reference_golden(golden):
         opt.step()
     assert abs(float(loss) - float(g["loss1"])) < 1e-3 * max(1.0, float(g["loss1"]))
     for k in ("pooling.W", "pooling.v"):
-        assert rel_err(dict(net.named_parameters())[k].detach().cpu().numpy(), g["after2_" + k]) < 1e-4, k
+        got = dict(net.named_parameters())[k].detach()
+        assert rel_err((got[:6] if k == "pooling.W" else got).cpu().numpy(), g["after2_" + k]) < 1e-4, k
     for k, v in net.state_dict().items():
         ref = g[f"after2_{k}_sum"]
         assert abs(float(v.detach().double().abs().sum()) - ref[1]) < 1e-4 * max(ref[1], 1e-6), k
