@@ -275,7 +275,7 @@ def _range_error(words) -> "DeepLipRangeError":
                                  f"produced by {', '.join(high)}; " + recourse)
     fam = words[_ST_LOW] - 1
     who = _STATUS_NAMES[fam] if 0 <= fam < len(_STATUS_NAMES) else "a split-format producer"
-    return DeepLipRangeError(f"f16x3 arithmetic: {who} produced a tensor whose largest magnitude is below 2^-6 = 0.0156: its "
+    return DeepLipRangeError(f"f16x3 arithmetic: {who} produced a tensor whose largest magnitude is below 2^-2 = 0.25: its "
                              "lo halves are fp16 subnormals and the result is no longer fp32-grade (relative error 3e-8 / max|v|); "
                              + recourse)
 
@@ -320,7 +320,7 @@ _blocks = _weakref.WeakSet()
 
 def check_range(sync: bool = False) -> None:
     """Raise DeepLipRangeError if a kernel reported an activation outside what the split format holds since the last call:
-    |v| >= 65520 (infinite in fp16), or a whole produced tensor with its largest magnitude in (0, 2^-6) (lo is subnormal
+    |v| >= 65520 (infinite in fp16), or a whole produced tensor with its largest magnitude in (0, 2^-2) (lo is subnormal
     there: relative accuracy below fp32 grade; include/deeplip_hip.h).  Without ``sync`` only launches that have completed are
     covered (the call is a host memory read); callers that are about to consume results synchronise first (or pass sync=True).
     Covers the process-wide block and every live StatusBlock (recorded plans report to their own)."""

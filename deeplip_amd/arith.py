@@ -2,7 +2,7 @@
 
     f16x3   every product of fp32 values as hi*hi + hi*lo + lo*hi on the f16 matrix core, fp32 accumulate (fp32-grade: 5e-7 against
             the CPU reference where the bar is 1e-4; three times the exact mode's speed).  A value the split format cannot hold
-            (|v| >= 65520, or a whole tensor below 2^-6) RAISES DeepLipRangeError at the next check.
+            (|v| >= 65520, or a whole tensor below 2^-2) RAISES DeepLipRangeError at the next check.
     f32     exact fp32 MFMA: the reference's arithmetic (models/video_models/model.py:82-85 computes in fp32 end to end).
     auto    f16x3, and what leaves its range is computed again -- the same batch, the same process, the same model object -- on
             the exact f32 pack, logged and counted (``STATS``).  The default: the measured configuration IS the product's.

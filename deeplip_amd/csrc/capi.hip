@@ -44,8 +44,8 @@ struct RangeScope {
 };
 thread_local RangeScope g_scope;
 
-// One thread per launch of the scope, over its DLIP_EVID_LINES lines: flag 1 ("something, all below 2^-6") anywhere without flag 0
-// ("something >= 2^-6") anywhere = the launch's whole tensor lay in (0, 2^-6) -> its kernel family + 1 into the host-pinned
+// One thread per launch of the scope, over its DLIP_EVID_LINES lines: flag 1 ("something, all below 2^-2") anywhere without flag 0
+// ("something >= 2^-2") anywhere = the launch's whole tensor lay in (0, 2^-2) -> its kernel family + 1 into the host-pinned
 // word DLIP_ST_LOW (sticky until the host clears it); raised flags are re-zeroed for the scope's next use.
 __global__ __launch_bounds__(64) void range_verdict_kernel(int32_t* slots, int n, int32_t* status) {
   // one WAVE per launch: lane 2 l + f looks at flag f of line l (a single thread walking the 64 words took 20 us)

@@ -209,7 +209,7 @@ def state_version(module: torch.nn.Module, device) -> tuple:
 
 
 # ---- activation exponents of the f16x3 packs -------------------------------------------------------------------------------------
-# The split format holds |v| in [2^-6 .. 65520) at fp32 grade.  A checkpoint whose activations live elsewhere -- BatchNorm statistics
+# The split format holds tensors whose largest |v| lies in [2^-2 .. 65520) at fp32 grade.  A checkpoint whose activations live elsewhere -- BatchNorm statistics
 # that shrink or grow a layer's output, an input with a gain of 2^+-20 -- used to RAISE (DeepLipRangeError) and, under arith "auto",
 # had every batch computed again in exact fp32.  Now the exact re-run of the FIRST such batch doubles as a calibration: it measures
 # the largest magnitude of every tensor the f16x3 path stores split (dlip_pow2_scale_f32 on the fp32 tensors of the exact path, one
@@ -276,8 +276,9 @@ def calib_finish(groups_of=None) -> int:
                     exps[n] = min(have)
         exps = {k: max(-100, min(100, v)) for k, v in exps.items()}
         # Tensors that sit comfortably inside the format keep e = 0 (and with it the bits they have always had): a largest magnitude
-        # of 2^-2 .. 2^14 gives e in [-2, 14] -- overflow is a factor 4 away at least and the low-side guard (largest magnitude
-        # below 2^-6) a factor 16.  Only what the calibration found outside that window is moved.
+        # of 2^-2 .. 2^14 gives e in [-2, 14] -- overflow is a factor 4 away at least, and the low-side guard (largest magnitude
+        # below 2^-2) is where the window ends: a batch that runs colder than the calibration batch is reported and computed in f32,
+        # never silently less exact.  Only what the calibration found outside that window is moved (to 2^12: a factor 2^14 above the guard).
         exps = {k: (0 if -2 <= v <= 14 else v) for k, v in exps.items()}
         if {k: v for k, v in exps.items() if v} != act_exponents(module):
             set_act_exponents(module, exps)            # (resets the budget when the weights are new)

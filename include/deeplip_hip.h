@@ -759,7 +759,7 @@ int dlip_status_scope(int32_t* words);
  * |v| >= 2^-3; below, lo sits on the subnormal grid 2^-24: an absolute error of up to 3e-8 per element, whatever its size.  Measured
  * on a 3-layer chain of Gaussian activations the result is 5.9e-7 off at sigma 1, 2.8e-5 at sigma 1e-3 (largest element 4.5e-3),
  * 3.1e-2 at sigma 1e-6.  A checkpoint whose BatchNorm statistics put a whole layer's activations down there would lose
- * fp32-grade accuracy silently, so a produced tensor whose largest magnitude lies in (0, 2^-6) is reported -- word 4 of the
+ * fp32-grade accuracy silently, so a produced tensor whose largest magnitude lies in (0, 2^-2) is reported -- word 4 of the
  * status block (int32[8]: {conv, stem, split_pack, pooling, LOW, 3 reserved}) receives the kernel family + 1 -- and the host
  * raises exactly as for an overflow (same recourse: "f32" packing).
  * Per-launch evidence needs a word per launch: between dlip_range_scope_begin and dlip_range_scope_end (thread-local, may
