@@ -69,7 +69,10 @@ DlipRange dlip_range_for(int family) {
   DlipRange r;
   if (status_now() != nullptr) r.status = status_now() + family;
   RangeScope& sc = g_scope;
-  if (sc.slots != nullptr && sc.cur < sc.n) r.lo = sc.slots + (size_t)DLIP_EVID_WORDS * (sc.cur++);
+  if (sc.slots != nullptr) {
+    if (sc.cur < sc.n) r.lo = sc.slots + (size_t)DLIP_EVID_WORDS * sc.cur;
+    ++sc.cur;            // (counted beyond n as well: a scope that ran out of slots must not end quietly, dlip_range_scope_end)
+  }
   r.code = family + 1;
   return r;
 }
@@ -90,13 +93,15 @@ extern "C" int dlip_range_scope_end(dlip_stream_t stream) {
   DLIP_CHECK_ARG(sc.depth > 0);
   if (--sc.depth > 0) return DLIP_OK;          // an inner scope: the outermost one owns the verdict
   int32_t* slots = sc.slots;
-  const int used = sc.cur;
+  const int used = sc.cur < sc.n ? sc.cur : sc.n;
+  const bool over = sc.cur > sc.n;     // more split-producing launches than the scope has slots: the later ones went unguarded
   sc = RangeScope{};
   if (used > 0) {
     hipLaunchKernelGGL(range_verdict_kernel, dim3((unsigned)used), dim3(64), 0, static_cast<hipStream_t>(stream), slots, used, status_now());
-    return dlip_launch_status();
+    const int e = dlip_launch_status();
+    if (e != DLIP_OK) return e;
   }
-  return DLIP_OK;
+  return over ? DLIP_ERANGE : DLIP_OK;
 }
 
 extern "C" int dlip_set_status_words(int32_t* words) {

@@ -765,6 +765,10 @@ static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws,
   const long long xb = frames * H * a.pwp * 4, yb = frames * a.Hp * a.Wp * 64 * 4;
   if (xb > DLIP_MAX_BUFFER_BYTES || yb > DLIP_MAX_BUFFER_BYTES) return DLIP_ERANGE;
   a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
+  // TWO evidence slots: the pre-pass reports the largest magnitude of the CLIP it splits, the kernel that of the pooled output it
+  // stores.  (One slot for both until round 6: an output of ordinary size then vouched for a clip far below the line -- a float clip
+  // with a gain of 2^-14 went unreported, tests/test_arith_gpu.py's clip soak.)
+  const DlipRange in_status = dlip_range_for(DLIP_ST_STEM);
   a.status = dlip_range_for(DLIP_ST_STEM);
   a.span = dlip_span_next();
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -774,10 +778,10 @@ static int stem_pool_launch(const void* x, int src_kind, int CH, int Hs, int Ws,
     if (frames * H > 0x7FFFFFFFll) return DLIP_ERANGE;
     if (src_kind == 0)
       hipLaunchKernelGGL(stem_split_input_kernel<0>, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), H, W, a.pwp,
-                         1, H, W, 0, 0, (int)T, lengths, static_cast<const int32_t*>(nullptr), a.status, a.span);
+                         1, H, W, 0, 0, (int)T, lengths, static_cast<const int32_t*>(nullptr), in_status, a.span);
     else
       hipLaunchKernelGGL(stem_split_input_kernel<1>, dim3(pgrid), dim3(256), 0, st, x, static_cast<uint32_t*>(x_split), (int)(frames * H), H, W, a.pwp,
-                         CH, Hs, Ws, oy, ox, (int)T, lengths, clip_params, a.status, a.span);
+                         CH, Hs, Ws, oy, ox, (int)T, lengths, clip_params, in_status, a.span);
   }
   const long long grid = frames < 256 ? frames : 256;   // persistent: a workgroup walks whole frames
   const size_t ldsb = (size_t)WBYTES + (size_t)KT * (np * 256 + 32) * 4 + (size_t)CARRY_SLOTS * CARRY_B + 3 * 64 * 4 + 128;

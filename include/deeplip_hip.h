@@ -767,7 +767,9 @@ int dlip_status_scope(int32_t* words);
  * spread over them, so that thousands finishing together do not queue at one line) of `slots` (device int32[1024 n], zeroed once
  * by the caller; flags, not counters: plain stores, no read-modify-write); _end launches a one-block verdict kernel on `stream` -- which must be ordered behind every launch
  * of the scope (join side streams first) -- that reports and re-zeroes the words.  Recorded into a step plan the verdict is
- * part of every replay.  Outside a scope the low side is not guarded (the high side always is). */
+ * part of every replay.  Outside a scope the low side is not guarded (the high side always is).  A scope with more producers than
+ * slots ends with DLIP_ERANGE (the launches beyond n ran unguarded: never quietly).  Launches that split TWO tensors take two slots
+ * (the stem + pool entry point: one for the clip its pre-pass splits, one for the pooled output). */
 /* Span scope (measurement): what a replayed step plan cannot give the host -- no event recorded into a graph can be read back --
  * the kernel notes itself.  Between _begin and _end (thread-local, not nestable) every launch of an MFMA kernel on split-format
  * input (the LDS-DMA ring kernel behind dlip_conv_nhwc_f16x3 / dlip_conv2_nhwc_f16x3 / dlip_conv_pool_f16x3, the window kernel, the

@@ -358,3 +358,44 @@ def test_pipeline_survives_a_list_whose_gains_jump_between_extremes():
     print(f"\nsoak: {n} batches, {pipe.reruns} repaired in f32, {cal} calibration(s), {pipe.rerecorded} re-recording(s), exponents {packing.act_exponents(net)}")
     pipe.close()
     _lib.check_range(sync=True)
+
+
+def test_lip_clip_pipeline_survives_a_list_whose_gains_jump_between_extremes():
+    """The same soak for the lip-clip encoder (float clips; the residual groups of the trunk share exponents, the stem's input carries one,
+    the pooled output is de-scaled): 18 batches of two 29-frame clips with gains from {1, 2^-14, 2^+10} through ONE ExtractPipeline
+    under auto, against the engine's exact mode; two of the exact batches against the oracle."""
+    from deeplip_amd import _lib, arith, packing, weightgen as wg
+    from deeplip_amd.pipeline import ExtractPipeline, pin
+    from models.video_models.model import Lipreading
+    from oracle import deeplip_oracle as O
+    tcn = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
+    net = Lipreading(num_classes=54, relu_type="prelu", tcn_options=tcn, extract_feats=True)
+    sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="video.")
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval().cuda()
+    B, n = 2, 18
+    r = np.random.Generator(np.random.PCG64(707))
+    gains = r.choice(np.array([1.0, 2.0 ** -14, 2.0 ** 10], dtype=np.float32), size=n)
+    gains[0] = 1.0
+    xs = [torch.from_numpy(wg.video_input(B, frames=29, key=f"arith.vsoak{i}")) * float(gains[i]) for i in range(n)]
+    arith.configure("f32")
+    want = torch.cat([net.embed(x.cuda()) for x in xs]).cpu().numpy()
+    with torch.no_grad():
+        for i in (1, n - 1):
+            ref = O.video_time_mean(O.lipreading_features(O.to_torch_sd(sd), xs[i])).numpy()
+            assert_close_rel(want[i * B:(i + 1) * B], ref, rtol=1e-4, what=f"exact mode, clip batch {i}")
+    arith.configure("auto")
+    c0 = arith.STATS["calibrations"]
+    with torch.no_grad():
+        pipe = ExtractPipeline(lambda a: net.embed(a), xs[0].cuda())
+    table = torch.zeros((n * B, want.shape[1]), device="cuda")
+    pipe.run([(pin(x),) for x in xs], table)
+    pipe.finish()
+    got = table.cpu().numpy()
+    for i in range(n):
+        assert_close_rel(got[i * B:(i + 1) * B], want[i * B:(i + 1) * B], rtol=1e-4, what=f"clip soak batch {i} (gain {gains[i]:g})")
+    cal = arith.STATS["calibrations"] - c0
+    assert cal <= packing.MAX_CALIBRATIONS and pipe.reruns >= 1
+    print(f"\nclip soak: {n} batches, {pipe.reruns} repaired in f32, {cal} calibration(s), {pipe.rerecorded} re-recording(s), exponents {packing.act_exponents(net)}")
+    pipe.close()
+    _lib.check_range(sync=True)

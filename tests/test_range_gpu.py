@@ -327,3 +327,38 @@ def test_plan_replay_reports_an_under_range_batch():
         plan.close()                                # clean again
     finally:
         packing.set_precision("f32")
+
+
+def test_a_scope_that_runs_out_of_slots_ends_with_an_error():
+    """dlip_range_scope_end: more split-producing launches than slots -> DLIP_ERANGE (the later launches ran unguarded; never quietly)."""
+    from deeplip_amd import _lib, ops
+    x = rnd(4, 8, 64, seed=3).cuda()
+    slots = torch.zeros(_lib._EVID_WORDS * 2, dtype=torch.int32, device="cuda")          # a scope of two slots
+    with pytest.raises(_lib.DeepLipHipError):
+        with _lib.range_scope(slots):
+            for _ in range(3):
+                ops.split_pack(x)
+    with _lib.range_scope(slots):                                                          # two launches fit
+        ops.split_pack(x)
+        ops.split_pack(x)
+    _lib.check_range(sync=True)
+
+
+def test_stem_reports_a_clip_below_the_line_even_when_its_output_is_ordinary():
+    """The fused stem + pool entry point splits TWO tensors (the clip in its pre-pass, the pooled output in its epilogue): each has its
+    evidence slot.  A float clip with a gain of 2^-14 behind an ordinary BatchNorm gives an ordinary output (the BatchNorm's shift) --
+    and is reported for its input (until round 6 the output's evidence vouched for it)."""
+    from deeplip_amd import _lib, arith, weightgen as wg
+    net, sd = _lipreading()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval().cuda()
+    x = torch.from_numpy(wg.video_input(2, frames=9, key="range.stem.low"))
+    arith.configure("f16x3")
+    try:
+        net(x.cuda(), None)
+        _lib.check_range(sync=True)                                                        # an ordinary clip: nothing
+        with pytest.raises(_lib.DeepLipRangeError, match="below 2\\^-2"):
+            net((x * float(2.0 ** -14)).cuda(), None)
+            _lib.check_range(sync=True)
+    finally:
+        arith.configure("f32")
