@@ -399,3 +399,36 @@ def test_lip_clip_pipeline_survives_a_list_whose_gains_jump_between_extremes():
     print(f"\nclip soak: {n} batches, {pipe.reruns} repaired in f32, {cal} calibration(s), {pipe.rerecorded} re-recording(s), exponents {packing.act_exponents(net)}")
     pipe.close()
     _lib.check_range(sync=True)
+
+
+def test_new_weights_void_a_calibration_and_in_place_updates_keep_it():
+    """Activation exponents belong to the weights they were measured on: ``load_state_dict`` voids them (and the calibration budget starts
+    again), an in-place update of the same parameters (an optimizer step, a fine-tune) re-packs WITH them.  Both ways every row is at
+    the bar."""
+    from deeplip_amd import arith, packing, weightgen as wg
+    net, sd = _tdnn()
+    arith.configure("auto")
+    g = float(2.0 ** -18)
+    xs = [torch.from_numpy(wg.audio_input(3, 24, 200, key=f"arith.void{i}")) for i in range(3)]
+    net.extract_embedding((xs[0] * g).cuda())                        # repaired in f32, calibrates
+    e1 = dict(packing.act_exponents(net))
+    assert e1.get("in", 0) > 14
+    # an in-place update of one layer's weights (what an optimizer step does): same exponents, new pack, right rows
+    with torch.no_grad():
+        net.tdnn[1].context_layer.weight.mul_(1.01)
+    sd2 = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    n0 = arith.STATS["f32_reruns"]
+    got = net.extract_embedding((xs[1] * g).cuda())[0]
+    assert packing.act_exponents(net) == e1 and arith.STATS["f32_reruns"] == n0      # the fast arithmetic on the calibrated, re-packed model
+    assert_close_rel(got.cpu().numpy(), _oracle_rows(sd2, xs[1] * g), rtol=1e-4, what="after an in-place weight update")
+    # new weights: the exponents are void, an ordinary input runs the ordinary pack ...
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert packing.act_exponents(net) == {}
+    got = net.extract_embedding(xs[2].cuda())[0]
+    assert arith.STATS["f32_reruns"] == n0
+    assert_close_rel(got.cpu().numpy(), _oracle_rows(sd, xs[2]), rtol=1e-4, what="ordinary input on reloaded weights")
+    # ... and the out-of-range one is repaired and calibrates again (a fresh budget)
+    c0 = arith.STATS["calibrations"]
+    got = net.extract_embedding((xs[2] * g).cuda())[0]
+    assert arith.STATS["f32_reruns"] == n0 + 1 and arith.STATS["calibrations"] == c0 + 1
+    assert_close_rel(got.cpu().numpy(), _oracle_rows(sd, xs[2] * g), rtol=1e-4, what="out-of-range input on reloaded weights")
