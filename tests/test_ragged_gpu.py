@@ -413,3 +413,61 @@ def test_ragged_full_size_batches_properties(video_net):
                 close(ea[b:b + 1].cpu().numpy(), ref.numpy(), what=f"utterance {b} of 256 (T={la[b]})")
     finally:
         packing.set_precision("f32")
+
+
+def test_random_shapes_f16x3_against_the_exact_mode():
+    """Shape fuzz (tools/probes/shape_fuzz.py: 340 random shapes over three seeds, worst 1.2e-6 of a row's scale for the speech encoder,
+    5.5e-7 for the lip-clip encoder): 12 seeded random (B, T) per encoder, every second one ragged, the f16x3 arithmetic against the
+    engine's exact mode -- which the fixed-shape tests pin to the oracle.  A tile-edge or padding bug of the window / ring / rows / pooled
+    kernels is an O(1) error on some shape; the arithmetic's own tail is ~1e-6, so the bar here is rel_err < 5e-6 (max error over max
+    magnitude per tensor; the fixed shapes keep the element-wise 1e-4 bar)."""
+    from conftest import rel_err
+    from deeplip_amd import _lib, arith, weightgen as wg
+    from models.audio_models.tdnn import SpeakerEmbNet
+    from models.video_models.model import Lipreading
+    from oracle import deeplip_oracle as O
+    opts = {"arch": "tdnn", "tdnn": {"input_dim": 24, "hidden_dim": [512] * 4 + [1500], "context": O.TDNN_CONTEXT, "tdnn_layers": 5,
+                                      "embedding_dim": 512, "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}}
+    anet = SpeakerEmbNet(opts)
+    sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in anet.state_dict().items()}, prefix="audio_tdnn.")
+    anet.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    anet.eval().cuda()
+    tcn = {"num_layers": 4, "kernel_size": [3, 5, 7], "dropout": 0.2, "dwpw": False, "width_mult": 1}
+    vnet = Lipreading(num_classes=54, relu_type="prelu", tcn_options=tcn, extract_feats=True)
+    sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in vnet.state_dict().items()}, prefix="video.")
+    vnet.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    vnet.eval().cuda()
+    amin = anet.frames_consumed() + 2
+    r = np.random.Generator(np.random.PCG64(2026))
+    worst = 0.0
+    for i in range(12):
+        B, T = int(r.integers(1, 21)), int(r.integers(amin, 520))
+        x = torch.from_numpy(wg.audio_input(B, 24, T, key=f"fuzz.t.a{i}")).cuda()
+        L = None
+        if i % 2:
+            L = torch.from_numpy(r.integers(amin, T + 1, size=B).astype(np.int32))
+            L[int(r.integers(0, B))] = T
+            L = L.cuda()
+        out = {}
+        for mode in ("f32", "f16x3"):
+            arith.configure(mode)
+            out[mode] = anet.extract_embedding(x, lengths=L)[0].cpu().numpy()
+            _lib.check_range(sync=True)
+        e = rel_err(out["f16x3"], out["f32"])
+        assert e < 5e-6, f"speech encoder B={B} T={T} ragged={L is not None}: {e:.3e}"
+        worst = max(worst, e)
+        B, T = int(r.integers(1, 7)), int(r.integers(1, 41))
+        x = torch.from_numpy(wg.video_input(B, frames=T, key=f"fuzz.t.v{i}")).cuda()
+        L = None
+        if i % 2:
+            L = [int(v) for v in r.integers(1, T + 1, size=B)]
+            L[int(r.integers(0, B))] = T
+        for mode in ("f32", "f16x3"):
+            arith.configure(mode)
+            out[mode] = vnet.embed(x, L).cpu().numpy()
+            out[mode + "f"] = vnet(x, L).cpu().numpy()
+            _lib.check_range(sync=True)
+        e = max(rel_err(out["f16x3"], out["f32"]), rel_err(out["f16x3f"], out["f32f"]))
+        assert e < 5e-6, f"lip-clip encoder B={B} T={T} ragged={L is not None}: {e:.3e}"
+        worst = max(worst, e)
+    print(f"\nshape fuzz, 24 shapes: worst f16x3 vs exact {worst:.2e}")
