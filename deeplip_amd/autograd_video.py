@@ -330,6 +330,13 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
     return ops.conv_nhwc(xs, ws, None, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True, post_scale=inv, post_shift=zeros)
 
 
+def _pixel_pitch(t):
+    """Floats between two pixels of an NHWC tensor.  NOT simply ``t.stride(2)``: torch ignores the strides of size-1 dimensions when it calls
+    a tensor contiguous, so a [N,1,1,C] gradient that arrives as a permuted view ([N,C,1,1] -> NHWC) keeps stride(2) == 1 through
+    ``.contiguous()`` -- and the operand producers rejected it (tools/probes/grad_fuzz.py: a Conv1d whose output is one frame wide)."""
+    return t.shape[3] if t.is_contiguous() else t.stride(2)
+
+
 def wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2=None):
     """dW[(tap, c), k] of a Conv2d / Conv1d on NHWC tensors with BOTH operands written by dlip_wgrad_operand_f32: one pass over
     x (all R*S taps, reduction-major, split) and one over dy (power-of-two lift, reduction-major, split), then the one GEMM.
@@ -349,7 +356,7 @@ def wgrad_conv_fused(x, dy, R, S, stride, pad, dil, scale2=None):
     check(lib().dlip_wgrad_operand_f32(ptr(dy), ptr(dzT_s), J32, N, Ho, Wo, K, K, Ho, Wo, 1, 1, 1, 1, 1, 1, 0, 0, ptr(scale2), stream_handle()),
           "dlip_wgrad_operand_f32")
     xT_s = torch.empty((taps * Cx, J32), device=dev, dtype=torch.float32)
-    check(lib().dlip_wgrad_operand_f32(ptr(x), ptr(xT_s), J32, N, H, W, Cx, x.stride(2), Ho, Wo, stride[0], stride[1], R, S, dil[0], dil[1],
+    check(lib().dlip_wgrad_operand_f32(ptr(x), ptr(xT_s), J32, N, H, W, Cx, _pixel_pitch(x), Ho, Wo, stride[0], stride[1], R, S, dil[0], dil[1],
                                        pad[0], pad[1], None, stream_handle()), "dlip_wgrad_operand_f32")
     inv = lift_inv(scale2, K)
     ones = const_vec(K, 1.0, dev)
@@ -434,7 +441,7 @@ def wgrad_image(t, scale2=None, also_nhwc_split=False, bn=None):
         check(lib().dlip_wgrad_chwn_bn_f32(ptr(z), ptr(img), N, H, W, C_, N32, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(sv), sc, ptr(spl),
                                            stream_handle()), "dlip_wgrad_chwn_bn_f32")
         return img, spl
-    check(lib().dlip_wgrad_chwn_f32(ptr(t), ptr(img), N, H, W, C_, t.stride(2), N32, ptr(scale2) if scale2 is not None else None,
+    check(lib().dlip_wgrad_chwn_f32(ptr(t), ptr(img), N, H, W, C_, _pixel_pitch(t), N32, ptr(scale2) if scale2 is not None else None,
                                     1 if WGRAD_SLICE_MAJOR else 0, ptr(spl) if spl is not None else None, stream_handle()), "dlip_wgrad_chwn_f32")
     return img, spl
 

@@ -743,3 +743,30 @@ def test_weight_registry_drops_entries_whose_owner_moved_or_died():
         av.prepare_weights()
     assert len(av.WEIGHT_PREP.order) == 0
     av.WEIGHT_PREP.__init__()
+
+
+def test_conv_train_fn_one_frame_wide_output_from_a_permuted_gradient():
+    """A Conv1d whose output is ONE frame wide, its gradient arriving as a permuted view [N,K,1,1] -> NHWC: torch calls that view contiguous
+    with stride(2) == 1 (size-1 dimensions' strides do not count), and the operand producers took stride(2) for the pixel pitch
+    (dlip_wgrad_chwn_f32: invalid argument; found by tools/probes/grad_fuzz.py -- 590 random shapes of this function and of the TDNN block
+    against fp64 autograd, nothing else outside the bars, worst 2.3e-6)."""
+    from deeplip_amd import autograd_video as av
+    N, W, C, K, S, dil = 2, 9, 768, 100, 3, 4
+    x = rnd(N, C, 1, W, seed=41).requires_grad_()
+    w = rnd(K, C, 1, S, seed=42, scale=1.0 / np.sqrt(C * S)).requires_grad_()
+    b = rnd(K, seed=43, scale=0.1).requires_grad_()
+    ref = F.conv2d(x.double(), w.double(), b.double(), dilation=(1, dil))
+    assert ref.shape == (N, K, 1, 1)
+    dy = rnd(*ref.shape, seed=44)
+    ref.backward(dy.double())
+    xg = nhwc(x.detach()).to(DEV).requires_grad_()
+    wgp, bg = w.detach().to(DEV).requires_grad_(), b.detach().to(DEV).requires_grad_()
+    y = av.conv(xg, wgp, bg, dil=(1, dil))
+    g = dy.to(DEV).permute(0, 2, 3, 1)                    # NOT copied by .contiguous(): strides (K, 1, 1, 1)
+    assert g.is_contiguous() and g.stride(2) == 1
+    y.backward(g)
+    torch.cuda.synchronize()
+    assert rel_err(y.detach().cpu().numpy(), nhwc(ref.detach()).numpy()) < 2e-5
+    assert rel_err(xg.grad.cpu().numpy(), nhwc(x.grad).numpy()) < 1e-4
+    assert rel_err(wgp.grad.cpu().numpy(), w.grad.numpy()) < 1e-4
+    assert rel_err(bg.grad.cpu().numpy(), b.grad.numpy()) < 1e-4
