@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 45
+ABI_VERSION = 46
 LIFT_WORDS = 4098
 LIFT_BCAST = 2048
 
@@ -140,6 +140,7 @@ SIGNATURES = {
     "dlip_frame_preemph_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, C.c_float, c_stream],
     "dlip_powspec_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_powspec_dft64_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],
+    "dlip_powspec_wave_fft64_f32": [c_f, c_f, c_f, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, C.c_double, c_i32, c_i32, c_stream],
     "dlip_log_floor_f32": [c_f, c_f, c_i64, c_stream],
     "dlip_cmvn_nct_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_i32, c_stream],
     "dlip_delta_nct_f32": [c_f, c_f, c_i32, c_i32, c_i32, c_i32, c_stream],

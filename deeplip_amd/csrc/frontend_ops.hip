@@ -101,6 +101,73 @@ __global__ __launch_bounds__(256) void powspec_dft64_kernel(const float* __restr
   }
 }
 
+// Power spectrum STRAIGHT FROM THE WAVEFORM, in the reference's own precision: python_speech_features pre-emphasises, frames and
+// transforms in fp64 (numpy), so a band that holds 1e-12 of a frame's energy -- the lowest one-bin mel filter next to DC in a frame where
+// pre-emphasis leaves nothing -- is still resolved there, while fp32 pre-emphasis alone puts rounding noise at -143 dB of the frame under
+// it (tools/probes/frontend_fuzz.py: such elements came out 0.3 .. 1 % off in energy).  One workgroup per frame: the frame's samples are
+// pre-emphasised in fp64 (coefficient a double: 0.97, not 0.97f) into LDS in bit-reversed order, a radix-2 decimation-in-time FFT of
+// nfft points runs there (log2(nfft) stages of nfft / 2 butterflies, one per thread and stage; twiddles from an LDS table of
+// sincospi), and the first NB bins leave as |.|^2 / nfft in fp32 together with the frame's energy (summed in fp64).
+__global__ __launch_bounds__(512) void powspec_wave_fft64_kernel(const float* __restrict__ x, float* __restrict__ pw, float* __restrict__ energy,
+                                                                 long long S, int NF, int L, int step, int nfft, int lg, double coef, int NB,
+                                                                 int NBp) {
+  extern __shared__ double sh[];          // [nfft] re | [nfft] im | [nfft / 2] cos | [nfft / 2] sin | [8] wave sums
+  double* re = sh;
+  double* im = sh + nfft;
+  double* cs = sh + 2 * nfft;
+  double* sn = cs + nfft / 2;
+  double* part = sn + nfft / 2;
+  const long long r = blockIdx.x;
+  const int f = (int)(r % NF);
+  const float* xb = x + (r / NF) * S;
+  const int half = nfft >> 1;
+  for (int j = threadIdx.x; j < nfft; j += blockDim.x) {
+    const long long n = (long long)f * step + j;
+    double v = 0.0;
+    if (j < L && n < S) v = n == 0 ? (double)xb[0] : (double)xb[n] - coef * (double)xb[n - 1];
+    const int br = (int)(__brev((unsigned)j) >> (32 - lg));
+    re[br] = v;
+    im[br] = 0.0;
+    if (j < half) {
+      double s, c;
+      sincospi(-2.0 * (double)j / (double)nfft, &s, &c);       // exp(-2 pi i j / nfft)
+      cs[j] = c;
+      sn[j] = s;
+    }
+  }
+  __syncthreads();
+  for (int st = 1; st <= lg; ++st) {
+    const int len = 1 << st, hl = len >> 1, tw = nfft >> st;
+    for (int t = threadIdx.x; t < half; t += blockDim.x) {
+      const int pos = t & (hl - 1), i0 = ((t >> (st - 1)) << st) + pos, i1 = i0 + hl;
+      const double wr = cs[pos * tw], wi = sn[pos * tw];
+      const double br_ = re[i1] * wr - im[i1] * wi, bi_ = re[i1] * wi + im[i1] * wr;
+      const double ar = re[i0], ai = im[i0];
+      re[i0] = ar + br_; im[i0] = ai + bi_;
+      re[i1] = ar - br_; im[i1] = ai - bi_;
+    }
+    __syncthreads();
+  }
+  double e = 0.0;
+  for (int k = threadIdx.x; k < NBp; k += blockDim.x) {
+    float p = 0.f;
+    if (k < NB) {
+      const double pp = (re[k] * re[k] + im[k] * im[k]) / (double)nfft;
+      p = (float)pp;
+      e += pp;
+    }
+    pw[r * NBp + k] = p;
+  }
+  e = dlip_wave_sum_f64(e);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x + 63) / 64; ++w) t += part[w];
+    energy[r] = t == 0.0 ? 2.220446049250313e-16f : (float)t;
+  }
+}
+
 // y = log(x == 0 ? eps : x) elementwise (base.logfbank / base.mfcc)
 __global__ __launch_bounds__(256) void log_floor_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -216,6 +283,20 @@ extern "C" int dlip_powspec_dft64_f32(const float* frames, float* pw, float* ene
   DLIP_CHECK_ARG(NB <= nfft / 2 + 1);
   hipLaunchKernelGGL(powspec_dft64_kernel, dim3(R), dim3(256), (size_t)(3 * nfft + 4) * sizeof(double),
                      static_cast<hipStream_t>(stream), frames, pw, energy, NB, NBp, nfft);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_powspec_wave_fft64_f32(const float* x, float* pw, float* energy, int64_t B, int64_t S, int32_t NF, int32_t frame_len,
+                                           int32_t frame_step, int32_t nfft, double preemph, int32_t NB, int32_t NBp, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(x && pw && energy && B > 0 && S > 0 && NF > 0 && frame_len > 0 && frame_step > 0 && nfft >= frame_len);
+  DLIP_CHECK_ARG(nfft >= 128 && nfft <= 1024 && (nfft & (nfft - 1)) == 0 && NB > 0 && NB <= nfft / 2 + 1 && NBp >= NB);
+  DLIP_CHECK_ARG(B * (long long)NF < (1ll << 31));
+  int lg = 0;
+  while ((1 << lg) < nfft) ++lg;
+  const int threads = nfft / 2;            // 64 .. 512: one butterfly per thread and stage
+  const size_t lds = (size_t)(3 * nfft + 8) * sizeof(double);
+  hipLaunchKernelGGL(powspec_wave_fft64_kernel, dim3((unsigned)(B * NF)), dim3((unsigned)threads), lds, static_cast<hipStream_t>(stream), x, pw,
+                     energy, (long long)S, NF, frame_len, frame_step, nfft, lg, preemph, NB, NBp);
   return dlip_launch_status();
 }
 

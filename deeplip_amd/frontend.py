@@ -54,7 +54,8 @@ def num_frames(n_samples: int, frame_len: int, frame_step: int) -> int:
 class AudioFrontend:
     def __init__(self, feat_type: str = "mfcc", rate: int = 16000, win_len: float = 0.025, win_shift: float = 0.01,
                  nfft: int = 512, num_bin: int = 26, num_cep: int = 24, preemph: float = 0.97, ceplifter: int = 22,
-                 energy: bool = True, normalize: bool = True, delta: bool = False, dft64: Optional[bool] = None, device="cuda"):
+                 energy: bool = True, normalize: bool = True, delta: bool = False, dft64: Optional[bool] = None, device="cuda",
+                 dft: Optional[str] = None):
         if feat_type not in ("mfcc", "fbank", "logfbank"):
             raise NotImplementedError("Other features are not implemented!")   # datasets.py:75-76
         self.feat_type, self.rate, self.nfft = feat_type, rate, nfft
@@ -62,9 +63,21 @@ class AudioFrontend:
         self.frame_step = int(round(win_shift * rate))
         self.num_bin, self.num_cep, self.preemph, self.normalize, self.energy = num_bin, num_cep, preemph, normalize, energy
         self.delta = delta            # datasets.py:81-82: [feat | delta(N=1) | delta(N=2)] after the normalisation
-        # fp64 DFT (one direct-DFT kernel) instead of the fp32 MFMA GEMM: needed where the lowest filters sit on bins at the
-        # fp32 noise floor of a 512-point DFT -- banks denser than the shipped 24 / 26 / 60 bands (default: > 60 bands)
-        self.dft64 = (num_bin > 60) if dft64 is None else bool(dft64)
+        # How the power spectrum is formed (``dft``):
+        #   "fft64"    (default since ABI 46) pre-emphasis, framing and a radix-2 FFT in fp64, one launch from the waveform
+        #              (dlip_powspec_wave_fft64_f32) -- the reference's own precision (numpy on doubles), every band of every frame at 1e-4;
+        #   "gemm32"   fp32 pre-emphasis + the DFT as an fp32 MFMA GEMM (rounds 1 - 5's default): elements holding ~1e-12 of a frame's
+        #              energy come out 0.3 .. 1 % off (tools/probes/frontend_fuzz.py); kept for A/B runs and as a second implementation;
+        #   "direct64" fp32 pre-emphasis + a direct fp64 DFT (round 2's route for banks denser than 60 bands).
+        # ``dft64`` (rounds 2 - 5's switch): True -> "direct64", False -> "gemm32".
+        if dft is None:
+            dft = "fft64" if dft64 is None else ("direct64" if dft64 else "gemm32")
+        if dft not in ("fft64", "gemm32", "direct64"):
+            raise ValueError(f"AudioFrontend: dft must be 'fft64', 'gemm32' or 'direct64', got {dft!r}")
+        if dft == "fft64" and (nfft < 128 or nfft > 1024 or nfft & (nfft - 1)):
+            dft = "gemm32"            # (the FFT kernel takes powers of two 128 .. 1024; any other nfft keeps the GEMM route)
+        self.dft = dft
+        self.dft64 = dft == "direct64"
         self.device = torch.device(device)
         nb = nfft // 2 + 1
         self.nb, self.nbp = nb, (nb + 3) // 4 * 4
@@ -92,18 +105,22 @@ class AudioFrontend:
         B, S = wave.shape
         NF = num_frames(S, self.frame_len, self.frame_step)
         R = B * NF
-        frames = ops._empty((R, self.nfft), wave.device)
-        check(lib().dlip_frame_preemph_f32(ptr(wave), ptr(frames), B, S, NF, self.frame_len, self.frame_step, self.nfft,
-                                           self.preemph, stream_handle()), "dlip_frame_preemph_f32")
         pw = ops._empty((R, self.nbp), wave.device)
         energy = ops._empty((R,), wave.device)
-        if self.dft64:
-            check(lib().dlip_powspec_dft64_f32(ptr(frames), ptr(pw), ptr(energy), R, self.nb, self.nbp, self.nfft, stream_handle()),
-                  "dlip_powspec_dft64_f32")
+        if self.dft == "fft64":
+            check(lib().dlip_powspec_wave_fft64_f32(ptr(wave), ptr(pw), ptr(energy), B, S, NF, self.frame_len, self.frame_step, self.nfft,
+                                                    float(self.preemph), self.nb, self.nbp, stream_handle()), "dlip_powspec_wave_fft64_f32")
         else:
-            spec = ops.linear(frames, self.w_dft)                              # [R, 2*nb]  (DFT as GEMM)
-            check(lib().dlip_powspec_f32(ptr(spec), ptr(pw), ptr(energy), R, self.nb, self.nbp, self.nfft, stream_handle()),
-                  "dlip_powspec_f32")
+            frames = ops._empty((R, self.nfft), wave.device)
+            check(lib().dlip_frame_preemph_f32(ptr(wave), ptr(frames), B, S, NF, self.frame_len, self.frame_step, self.nfft,
+                                               self.preemph, stream_handle()), "dlip_frame_preemph_f32")
+            if self.dft == "direct64":
+                check(lib().dlip_powspec_dft64_f32(ptr(frames), ptr(pw), ptr(energy), R, self.nb, self.nbp, self.nfft, stream_handle()),
+                      "dlip_powspec_dft64_f32")
+            else:
+                spec = ops.linear(frames, self.w_dft)                          # [R, 2*nb]  (DFT as GEMM)
+                check(lib().dlip_powspec_f32(ptr(spec), ptr(pw), ptr(energy), R, self.nb, self.nbp, self.nfft, stream_handle()),
+                      "dlip_powspec_f32")
         mel = torch.zeros((R, self.nfp), device=wave.device, dtype=torch.float32)
         ops.conv_nhwc(pw.view(1, 1, R, self.nbp), self.w_mel.view(self.num_bin, 1, 1, self.nbp),
                       out=mel.view(1, 1, R, self.nfp))                         # [R, num_bin] (+ zero pad)

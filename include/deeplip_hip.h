@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 45
+#define DLIP_ABI_VERSION 46
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -394,6 +394,13 @@ int dlip_powspec_f32(const float* spec, float* pw, float* energy, int32_t R, int
  * nfft 512) the fp32-GEMM DFT's rounding noise is larger than the signal.  nfft a power of two <= 1024. */
 int dlip_powspec_dft64_f32(const float* frames, float* pw, float* energy, int32_t R, int32_t NB, int32_t NBp,
                            int32_t nfft, dlip_stream_t stream);
+/* (ABI 46) x [B,S] waveform -> pw [B*NF, NBp] / energy [B*NF] as above, with pre-emphasis, framing and the DFT (a radix-2 FFT in LDS, one
+ * workgroup per frame) ALL in fp64, as python_speech_features computes them (sigproc.preemphasis / framesig / numpy rfft on doubles;
+ * features/audio front-end of models/audio_models/datasets.py:60-82).  `preemph` is a double: the reference's 0.97 is.  What the fp32 routes
+ * lose: elements holding ~1e-12 of a frame's energy (the lowest mel band of a frame that pre-emphasis empties), 0.3 .. 1 % there.  The
+ * default route of deeplip_amd.frontend.AudioFrontend since ABI 46.  nfft a power of two, 128 .. 1024. */
+int dlip_powspec_wave_fft64_f32(const float* x, float* pw, float* energy, int64_t B, int64_t S, int32_t NF, int32_t frame_len,
+                                int32_t frame_step, int32_t nfft, double preemph, int32_t NB, int32_t NBp, dlip_stream_t stream);
 /* y = log(x == 0 ? eps : x). */
 int dlip_log_floor_f32(const float* x, float* y, int64_t n, dlip_stream_t stream);
 /* feat [B,NF,C] (row stride ldf; channel 0 := log(energy) when energy != NULL) -> per-utterance

@@ -151,3 +151,37 @@ def test_delta_features_vs_oracle():
         ref = O.audio_features(sig[b].astype(np.float64), "mfcc", delta=True)
         assert y[b].shape == ref.shape == (72, ref.shape[1])
         assert rel_err(y[b].cpu().numpy(), ref) < 1e-4
+
+
+@pytest.mark.gpu
+def test_default_route_resolves_the_bands_that_pre_emphasis_empties():
+    """tools/probes/frontend_fuzz.py's find: a sine + white noise, logfbank-60 (a shipped bank), a length with a remainder against the shift.
+    Band 0 -- a one-bin filter next to DC -- holds ~1e-12 of a frame's energy in some frames (log energy -24 .. -27).  The reference
+    pre-emphasises, frames and transforms in fp64; so does the default route since ABI 46 (dlip_powspec_wave_fft64_f32), and EVERY element
+    of the un-normalised features is inside 1e-4 of the feature scale.  The fp32 routes are not (0.3 .. 1 % in those elements' energy):
+    kept as second implementations, they agree with the default on everything above the floor."""
+    from deeplip_amd.frontend import AudioFrontend
+    S, B = 56146, 6
+    t = np.arange(S) / 16000.0
+    r = np.random.Generator(np.random.PCG64(11))
+    sig = np.stack([0.3 * np.sin(2 * np.pi * (150 + 170 * b) * t) + 0.05 * r.standard_normal(S) for b in range(B)]).astype(np.float32)
+    x = torch.from_numpy(sig).cuda()
+    out = {d: AudioFrontend("logfbank", num_bin=60, normalize=False, dft=d)(x).cpu().numpy() for d in ("fft64", "gemm32", "direct64")}
+    assert AudioFrontend("logfbank", num_bin=60).dft == "fft64"
+    n_floor = 0
+    for b in range(B):
+        ref = O.audio_features(sig[b].astype(np.float64), "logfbank", nfilt=60, normalize=False)
+        assert out["fft64"][b].shape == ref.shape
+        scale = np.abs(ref).max()
+        assert np.abs(out["fft64"][b] - ref).max() < 1e-4 * scale, b                      # every element, floor included
+        floor = ref < -20.0
+        n_floor += int(floor.sum())
+        for d in ("gemm32", "direct64"):
+            assert (np.abs(out[d][b] - ref) * ~floor).max() < 1e-4 * scale, (d, b)
+    assert n_floor >= 8                                                                  # (the case really has such elements: 11 of 126 000)
+    # CMVN-ed MFCCs + deltas through the default route, against the oracle
+    fe = AudioFrontend("mfcc", delta=True)
+    y = fe(x).cpu().numpy()
+    for b in range(B):
+        ref = O.audio_features(sig[b].astype(np.float64), "mfcc", delta=True)
+        assert rel_err(y[b], ref) < 1e-4, b

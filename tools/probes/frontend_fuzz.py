@@ -4,7 +4,7 @@ Un-normalised features are compared outright; CMVN-ed ones on the bands that are
 Elements whose un-normalised LOG energy is below -20 (2e-9 of a unit-energy frame: the lowest one-bin filter next to DC in a frame where
 pre-emphasis leaves nothing) are counted separately: they sit below what fp32 framing resolves -- the reference frames and transforms in
 fp64 -- and come out 0.3 ... 1 % off in energy (1e-4 ... 3e-4 of the feature scale, band 0, one frame in a few hundred).
-   python tools/probes/frontend_fuzz.py [n] [seed]"""
+   python tools/probes/frontend_fuzz.py [n] [seed] [fft64 | gemm32 | direct64]"""
 import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -17,6 +17,7 @@ from oracle import deeplip_oracle as O
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+dft = sys.argv[3] if len(sys.argv) > 3 else None        # fft64 (the default) | gemm32 | direct64
 r = np.random.Generator(np.random.PCG64(seed))
 bad, worst = 0, 0.0
 floor_elems, floor_worst = 0, 0.0
@@ -36,7 +37,7 @@ for i in range(n):
     tag = f"{feat_type}-{num_bin} delta={delta} B={B} S={S}"
     try:
         for normalize in (False, True):
-            fe = AudioFrontend(feat_type, num_bin=num_bin, normalize=normalize, delta=delta)
+            fe = AudioFrontend(feat_type, num_bin=num_bin, normalize=normalize, delta=delta, dft=dft)
             y = fe(torch.from_numpy(sig).cuda()).cpu().numpy()
             for b in range(B):
                 ref = O.audio_features(sig[b].astype(np.float64), feat_type, nfilt=num_bin, normalize=normalize, delta=delta)
