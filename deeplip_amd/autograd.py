@@ -254,6 +254,27 @@ def _bn_rows_bwd(dy2, x2, gamma, beta, mean, invstd, slope, act_first):
     return dx, dg, db
 
 
+# (round 6, ABI 47) conv -> BatchNorm -> activation under backward(): the BatchNorm's input gradient dz is needed only as the operand
+# images of the convolution in front (weight gradient, data gradient), so it is formed PER LOADED VALUE by their producers from dy and z
+# (dlip_wgrad_*_bnbwd_f32) and never stored: the apply pass's write and the producers' read of an activation-sized tensor per layer.
+BN_BWD_ON_LOAD = __import__("os").environ.get("DLIP_BN_BWD_ON_LOAD", "1") != "0"      # (the environment switch: same-box A/B runs)
+BN_SMALL_ROWS = 4096          # (encoder_train_ops.hip: at most this many rows go through the one-launch BatchNorm, which writes dz)
+
+
+def _bn_rows_bwd_sums(dy2, x2, gamma, beta, mean, invstd, slope, act_first):
+    """dgamma, dbeta and the lift of the dz that the producers will form on load (a DLIP_LIFT_WORDS buffer, as pow2_lift returns it)."""
+    M, C_ = x2.shape
+    _lib.ensure_conv_workspace()
+    dg = torch.empty_like(mean)
+    db = torch.empty_like(mean)
+    lift = torch.empty((LIFT_WORDS,), device=x2.device, dtype=torch.float32)
+    parts = torch.empty((2 * ((C_ + 63) // 64) * int(lib().dlip_bn_rows_chunks(M)),), device=x2.device, dtype=torch.float32)
+    check(lib().dlip_bn_rows_train_bwd_sums_f32(ptr(dy2), ptr(x2), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dg), ptr(db),
+                                                ptr(_ws(M, C_, x2.device)), ptr(parts), M, C_, slope, int(act_first), ptr(lift), stream_handle()),
+          "dlip_bn_rows_train_bwd_sums_f32")
+    return dg, db, lift
+
+
 class BNRowsActFn(Function):
     """[M,C]: lrelu(bn_train(x)) (act_first=False) or bn_train(lrelu(x)) (True); running stats updated in place
     (bn1 / bn2 of SpeakerEmbNet, tdnn.py:92-97,105-110)."""
@@ -352,6 +373,44 @@ class TDNNBlockTrainFn(Function):
         K, _, S = weight.shape
         Tp = z.shape[1]
         dev = x.device
+        from . import autograd_video as av
+        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        no_dbias_pass = not (has_bias and ctx.needs_input_grad[2]) or (not act_first and ZERO_BIAS_GRAD_BEFORE_BN)
+        if (BN_BWD_ON_LOAD and av.TRAIN_CONV == "f16x3" and mode in (1, 2) and want_w and K % 64 == 0 and B * Tp > BN_SMALL_ROWS and no_dbias_pass
+                and av.WGRAD_SLICE_MAJOR and (mode == 1 or av.WGRAD == "conv")):
+            # dz is never stored: sums + lift, then the producers form it on load (see BN_BWD_ON_LOAD)
+            dy2, z2 = dy.contiguous().view(B * Tp, K), z.view(B * Tp, K)
+            dgamma, dbeta, lift = _bn_rows_bwd_sums(dy2, z2, gamma, beta, mean, invstd, slope, act_first)
+            dbias = torch.zeros((K,), device=dev, dtype=torch.float32) if has_bias and ctx.needs_input_grad[2] else None
+            M = B * Tp
+            sl = float(slope)
+            if mode == 1:
+                J32 = x.shape[1]
+                gT = torch.empty((K, J32), device=dev, dtype=torch.float32)
+                dzs = torch.empty((B, 1, Tp, K), device=dev, dtype=torch.float32) if want_x else None
+                check(lib().dlip_wgrad_operand_split_bnbwd_f32(ptr(dy2), ptr(z2), ptr(gT), J32, M, K, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+                                                               ptr(dgamma), ptr(dbeta), M, sl, int(act_first), ptr(lift), ptr(dzs), stream_handle()),
+                      "dlip_wgrad_operand_split_bnbwd_f32")
+            else:
+                N32 = (B + 31) // 32 * 32
+                gT = torch.empty((K, 1, Tp, N32), device=dev, dtype=torch.float32)
+                dzs = torch.empty((B, 1, Tp, K), device=dev, dtype=torch.float32) if want_x else None
+                check(lib().dlip_wgrad_chwn_bnbwd_f32(ptr(dy2), ptr(z2), ptr(gT), B, 1, Tp, K, N32, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+                                                      ptr(dgamma), ptr(dbeta), M, sl, int(act_first), ptr(lift), ptr(dzs), stream_handle()),
+                      "dlip_wgrad_chwn_bnbwd_f32")
+            dx = None
+            if want_x:
+                shape_only = torch.empty((B, 1, Tp, K), device=dev, dtype=torch.float32)      # (address and shape: conv_train reads dzs)
+                dx = av.conv_train(shape_only, None, None, (1, 1), (0, (S - 1) * dilation), (1, dilation), lift=True, scale2=lift,
+                                   w_ref=weight.view(K, Cx, 1, S), transposed=True, xs_ready=dzs)
+                dx = dx.view(B, dx.shape[2], Cx)
+            if mode == 1:
+                dweight = _permute3(av.wgrad_gemm_operands(x, gT, lift).view(1, Cx, K), (2, 1, 0)).view(K, Cx, 1)
+            else:
+                dweight = av.wgrad_as_conv(None, None, 1, S, (1, 1), (0, 0), (1, dilation), scale2=lift, xT=x, gT=gT).view(K, Cx, S)
+            if dweight.shape[1] != weight.shape[1]:
+                dweight = dweight[:, :weight.shape[1]].contiguous()
+            return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         dz2, dgamma, dbeta = _bn_rows_bwd(dy.contiguous().view(B * Tp, K), z.view(B * Tp, K), gamma, beta, mean, invstd,
                                           slope, act_first)
         dbias = None

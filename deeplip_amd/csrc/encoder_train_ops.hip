@@ -82,6 +82,7 @@ struct ColFin {
   float* running_var;
   long long* nbt;                    // MODE 0 (nullable): num_batches_tracked += 1
   float momentum, eps;
+  unsigned* amax_parts = nullptr;    // MODE 1 (nullable): per workgroup (max |g|, max |xhat|) as bit patterns, 2 words each (dlip_bn_rows_train_bwd_sums_f32)
 };
 
 __device__ __forceinline__ void bn_stats_finish(double s, double q, int M, int c, float* save_mean, float* save_invstd,
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   const int c = c0 + lx * 4;
   const int r0 = chunk * rows_per_part, r1 = min(M, r0 + rows_per_part);
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  float gmax = 0.f, hmax = 0.f;      // MODE 1: the largest |g| and |xhat| this lane saw (fin.amax_parts: the bound behind the fused backward's lift)
   if (c < C) {   // C % 4 == 0
     f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, ga = {0, 0, 0, 0}, be = {0, 0, 0, 0}, sl = {0, 0, 0, 0};
     if (MODE == 1 || MODE == 3) {
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
           float g = gv[k];
           if (!act_first) g *= (xh * ga[k] + be[k]) >= 0.f ? 1.f : slope;
           s0[k] += (double)g; s1[k] += (double)g * (double)xh;
+          gmax = fmaxf(gmax, fabsf(g)); hmax = fmaxf(hmax, fabsf(xh));
         }
       } else if (MODE == 3) {
 #pragma unroll
@@ -261,7 +264,45 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
       publish(p2, a2); publish(p2 + 1, 0.0);
     }
   }
+  if (MODE == 1 && fin.amax_parts != nullptr) {       // (workgroup-uniform)
+    __shared__ float mx[4][2];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { gmax = fmaxf(gmax, __shfl_xor(gmax, off)); hmax = fmaxf(hmax, __shfl_xor(hmax, off)); }
+    if ((threadIdx.x & 63) == 0) { mx[threadIdx.x >> 6][0] = gmax; mx[threadIdx.x >> 6][1] = hmax; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      float m = fmaxf(fmaxf(mx[0][threadIdx.x], mx[1][threadIdx.x]), fmaxf(mx[2][threadIdx.x], mx[3][threadIdx.x]));
+      if (!(m == m)) m = 3.4e38f;
+      publish(fin.amax_parts + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + threadIdx.x, __float_as_uint(m));
+    }
+  }
   col_finish<MODE>(part, parts, M, C, c0, fin, red);
+}
+
+// The lift of a BatchNorm backward's dx WITHOUT dx: |dx| = |gamma invstd (g - mean(g) - xhat mean(g xhat))| <= gamma invstd max|g| (2 + max|xhat|)
+// (|mean(g xhat)| <= sqrt(mean g^2) sqrt(mean xhat^2) <= max|g|: the batch statistics make mean xhat^2 = 1).  parts: n pairs
+// (max |g|, max |xhat|) from col_partial_kernel<1>.  out: a DLIP_LIFT_WORDS buffer as pow2_finalize_parts writes it, the exponent chosen
+// so that the BOUND sits at `target`: the true maximum then lies up to (2 + max|xhat|) -- an order of magnitude -- below it, well inside
+// the split format (a power-of-two lift is exact: another exponent, the same gradients).
+__global__ __launch_bounds__(256) void bn_bwd_lift_bound_kernel(const unsigned* __restrict__ parts, int n, const float* __restrict__ gamma,
+                                                                const float* __restrict__ invstd, int C, float* __restrict__ out, float target) {
+  __shared__ float red[4][3];
+  float g = 0.f, h = 0.f, gi = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { g = fmaxf(g, __uint_as_float(parts[2 * i])); h = fmaxf(h, __uint_as_float(parts[2 * i + 1])); }
+  for (int c = threadIdx.x; c < C; c += 256) gi = fmaxf(gi, fabsf(gamma[c] * invstd[c]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { g = fmaxf(g, __shfl_xor(g, off)); h = fmaxf(h, __shfl_xor(h, off)); gi = fmaxf(gi, __shfl_xor(gi, off)); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = g; red[threadIdx.x >> 6][1] = h; red[threadIdx.x >> 6][2] = gi; }
+  __syncthreads();
+  g = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+  h = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+  gi = fmaxf(fmaxf(red[0][2], red[1][2]), fmaxf(red[2][2], red[3][2]));
+  const float bound = gi * g * (2.f + h);
+  float s = 1.f;
+  if (bound > 0.f && bound < 3.0e38f) s = exp2f(floorf(log2f(target / bound)));
+  if (!(s > 0.f) || s > 1.0e30f) s = 1.0e30f;
+  if (threadIdx.x == 0) { out[0] = s; out[1] = 1.f / s; }
+  for (int i = threadIdx.x; i < DLIP_LIFT_BCAST; i += 256) out[2 + i] = 1.f / s;
 }
 
 // The BatchNorm + PReLU backward sums (col_partial_kernel<3>) BEHIND A MAX-POOL, taken over the POOLED rows: the gradient behind
@@ -1335,6 +1376,28 @@ extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
   return bn_bwd_launch(dy, x, gamma, beta, nullptr, save_mean, save_invstd, dx, dgamma, dbeta, nullptr, workspace, M, C, slope, act_first,
                        dx_lift2, static_cast<hipStream_t>(stream));
+}
+
+// (ABI 47) The first half of dlip_bn_rows_train_bwd_f32 alone: dgamma, dbeta and the lift of a dx that is never written -- the operand
+// producers of the convolution in front form dx per loaded value (dlip_wgrad_operand_split_bnbwd_f32 / dlip_wgrad_chwn_bnbwd_f32).
+extern "C" int dlip_bn_rows_train_bwd_sums_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                                               const float* save_invstd, float* dgamma, float* dbeta, double* workspace, float* amax_parts,
+                                               int32_t M, int32_t C, float slope, int32_t act_first, float* dx_lift2, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dgamma && dbeta && workspace && amax_parts && dx_lift2);
+  DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int* tickets = stream_tickets(st, (C + 63) / 64);
+  const int chunks = dlip_bn_rows_chunks(M);
+  const int rpp = bn_rows_per_part(M);
+  ColFin fin = {tickets, dbeta, dgamma, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
+  fin.amax_parts = reinterpret_cast<unsigned*>(amax_parts);
+  hipLaunchKernelGGL(col_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd, gamma, beta, workspace, M,
+                     C, slope, act_first, nullptr, rpp, fin);
+  if (!tickets) hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
+  hipLaunchKernelGGL(bn_bwd_lift_bound_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const unsigned*>(amax_parts), ((C + 63) / 64) * chunks,
+                     gamma, save_invstd, C, dx_lift2, 1024.0f);
+  return dlip_launch_status();
 }
 
 extern "C" int dlip_bn_prelu_rows_train_fwd_f32(const float* x, const float* gamma, const float* beta, const float* slope, float* y,

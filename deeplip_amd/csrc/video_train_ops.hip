@@ -110,7 +110,42 @@ struct BnOnLoad {
   const float* beta;
   const float* slope_vec;   // nullptr: the scalar `slope` for every channel
   float slope;
+  // (ABI 47) the BACKWARD on load: the producer reads dy (its first source) and z (`z`) and forms the BatchNorm's input gradient
+  // dz = gamma invstd (g - dbeta / M - xhat dgamma / M) per value -- bn_bwd_apply_kernel's expression, the same bits -- so dz is never stored
+  const float* z = nullptr;
+  const float* dgamma = nullptr;
+  const float* dbeta = nullptr;
+  float invM = 0.f;
+  int act_first = 0;
 };
+__device__ __forceinline__ float bnl_lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+template <int CT>
+__device__ __forceinline__ void bn_bwd_on_load_stage(const BnOnLoad& b, int c0, float* tab) {      // tab [6][CT]: mean invstd gamma beta dgamma dbeta
+  for (int i = threadIdx.x; i < 6 * (CT / 4); i += 256) {
+    const int w = i / (CT / 4), c = (i - w * (CT / 4)) * 4;
+    const float* src = w == 0 ? b.mean : w == 1 ? b.invstd : w == 2 ? b.gamma : w == 3 ? b.beta : w == 4 ? b.dgamma : b.dbeta;
+    *reinterpret_cast<f32x4*>(tab + w * CT + c) = *reinterpret_cast<const f32x4*>(src + c0 + c);
+  }
+  __syncthreads();
+}
+template <int CT>
+__device__ __forceinline__ f32x4 bn_bwd_on_load(const float* tab, const BnOnLoad& b, f32x4 gv, f32x4 xv, int c) {
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + c), is = *reinterpret_cast<const f32x4*>(tab + CT + c);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + 2 * CT + c), be = *reinterpret_cast<const f32x4*>(tab + 3 * CT + c);
+  const f32x4 dg = *reinterpret_cast<const f32x4*>(tab + 4 * CT + c), db = *reinterpret_cast<const f32x4*>(tab + 5 * CT + c);
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a = b.act_first ? bnl_lrelu(xv[k], b.slope) : xv[k];
+    const float xh = (a - mu[k]) * is[k];
+    float g = gv[k];
+    if (!b.act_first) g *= (xh * ga[k] + be[k]) >= 0.f ? 1.f : b.slope;
+    float d = ga[k] * is[k] * (g - db[k] * b.invM - xh * dg[k] * b.invM);
+    if (b.act_first) d *= xv[k] >= 0.f ? 1.f : b.slope;
+    o[k] = d;
+  }
+  return o;
+}
 // The workgroup's CT channels of the five parameter vectors, staged in LDS once (tab [5][CT]): read from memory per loaded value
 // they were five vector-memory instructions beside every 16-B data load (the producers went from 80 to 95 - 104 us per TDNN layer).
 template <int CT>
@@ -139,7 +174,7 @@ __device__ __forceinline__ f32x4 bn_on_load(const float* tab, f32x4 v, int c) { 
 
 // The same operand from WIDER tiles (round 4; see wgrad_chwn_wide_kernel): 32 positions x CT channels (64 | 128) of one tap, read
 // as 16-B quads and written as CT / 32 sixteen-byte pieces per thread.  C % CT == 0, ldx % 4 == 0, x 16-byte aligned.
-template <int CT, bool AFF = false>
+template <int CT, int AFF = 0>      // AFF: 0 plain, 1 BatchNorm + activation on load, 2 BatchNorm BACKWARD on load (x = dy, bn.z = z)
 __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int ldx,
                                                                  int C, int Ho, int Wo, int sh, int sw, int R, int S, int dh, int dw, int ph,
                                                                  int pw, int J, long long ldo, const float* __restrict__ scale,
@@ -147,10 +182,11 @@ __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __
                                                                  const BnOnLoad bn = BnOnLoad{}) {
   constexpr int PITCH = CT + 4, Q = CT / 32;
   __shared__ __attribute__((aligned(16))) float tile[32 * PITCH];
-  __shared__ __attribute__((aligned(16))) float bn_tab[AFF ? 5 * CT : 4];
+  __shared__ __attribute__((aligned(16))) float bn_tab[AFF == 2 ? 6 * CT : AFF == 1 ? 5 * CT : 4];
   const int j0 = blockIdx.x * 32, c0 = blockIdx.y * CT;
   const float sc = scale ? scale[0] : 1.f;
-  if constexpr (AFF) bn_on_load_stage<CT>(bn, c0, bn_tab);
+  if constexpr (AFF == 1) bn_on_load_stage<CT>(bn, c0, bn_tab);
+  if constexpr (AFF == 2) bn_bwd_on_load_stage<CT>(bn, c0, bn_tab);
   // this thread's Q quads: position row (i / (CT / 4)) -- pixel origin of tap (0, 0), once for all taps -- and channel quad
   int base[Q], hi0[Q], wi0[Q], col[Q], row_[Q];
 #pragma unroll
@@ -174,8 +210,10 @@ __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __
       const int hi = hi0[q] + r * dh, wi = wi0[q] + s_ * dw;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
-        v = *reinterpret_cast<const f32x4*>(x + ((long long)(base[q] + hi) * W + wi) * ldx + c0 + col[q]);
-        if constexpr (AFF) v = bn_on_load<CT>(bn_tab, v, col[q]);
+        const long long off = ((long long)(base[q] + hi) * W + wi) * ldx + c0 + col[q];
+        v = *reinterpret_cast<const f32x4*>(x + off);
+        if constexpr (AFF == 1) v = bn_on_load<CT>(bn_tab, v, col[q]);
+        if constexpr (AFF == 2) v = bn_bwd_on_load<CT>(bn_tab, bn, v, *reinterpret_cast<const f32x4*>(bn.z + off), col[q]);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] *= sc;
@@ -280,24 +318,27 @@ __global__ __launch_bounds__(256) void wgrad_chwn_kernel(const float* __restrict
 // The same images from WIDER tiles (round 4): one workgroup = 32 images x CT channels (64 | 128) of one pixel, read as 16-B
 // quads (CT / 32 per thread in flight instead of four 4-B loads) and written as CT / 32 sixteen-byte pieces per thread -- the
 // 32 x 32 version moved 4 KB per workgroup between two barriers and held 2.8 TB/s.  group = 0, layouts 0 / 1, C % CT == 0.
-template <int CT, bool AFF = false>
+template <int CT, int AFF = 0>      // AFF as in wgrad_operand_wide_kernel
 __global__ __launch_bounds__(256) void wgrad_chwn_wide_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int ldx, int C,
                                                               int N32, const float* __restrict__ scale, DlipRange status, int layout,
                                                               float* __restrict__ nhwc_out, const BnOnLoad bn = BnOnLoad{}) {
   constexpr int PITCH = CT + 4, Q = CT / 32;              // floats per LDS row (16-B aligned rows); quads / pieces per thread
   __shared__ __attribute__((aligned(16))) float tile[32 * PITCH];
-  __shared__ __attribute__((aligned(16))) float bn_tab[AFF ? 5 * CT : 4];
+  __shared__ __attribute__((aligned(16))) float bn_tab[AFF == 2 ? 6 * CT : AFF == 1 ? 5 * CT : 4];
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * CT, p = blockIdx.z;
   const float sc = scale ? scale[0] : 1.f;
-  if constexpr (AFF) bn_on_load_stage<CT>(bn, c0, bn_tab);
+  if constexpr (AFF == 1) bn_on_load_stage<CT>(bn, c0, bn_tab);
+  if constexpr (AFF == 2) bn_bwd_on_load_stage<CT>(bn, c0, bn_tab);
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int i = threadIdx.x + 256 * q, row = i / (CT / 4), col4 = i - row * (CT / 4);
     const int n = n0 + row;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (n < N) {
-      v = *reinterpret_cast<const f32x4*>(x + ((long long)n * HW + p) * ldx + c0 + col4 * 4);
-      if constexpr (AFF) v = bn_on_load<CT>(bn_tab, v, col4 * 4);
+      const long long off = ((long long)n * HW + p) * ldx + c0 + col4 * 4;
+      v = *reinterpret_cast<const f32x4*>(x + off);
+      if constexpr (AFF == 1) v = bn_on_load<CT>(bn_tab, v, col4 * 4);
+      if constexpr (AFF == 2) v = bn_bwd_on_load<CT>(bn_tab, bn, v, *reinterpret_cast<const f32x4*>(bn.z + off), col4 * 4);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] *= sc;
@@ -819,6 +860,49 @@ extern "C" int dlip_wgrad_chwn_bn_f32(const float* x, float* out, int64_t N, int
   else
     hipLaunchKernelGGL((wgrad_chwn_wide_kernel<64, true>), dim3((unsigned)(N32 / 32), (unsigned)(C / 64), (unsigned)(H * W)), dim3(256), 0,
                        ST(stream), x, out, (int)N, H * W, C, C, N32, nullptr, dlip_range_for(DLIP_ST_PACK), 1, nhwc_split_out, bn);
+  return dlip_launch_status();
+}
+
+// (ABI 47) The two producers with a train-mode BatchNorm's BACKWARD applied on load: sources dy and z (the BatchNorm's input: the raw
+// convolution output), per-channel mean / invstd / gamma / beta and the two backward sums dgamma / dbeta (dlip_bn_rows_train_bwd_sums_f32),
+// M = rows of the statistics; the value split is lift[0] * dz with dz = bn_bwd_apply_kernel's expression (same bits).  dz itself -- an
+// activation-sized fp32 tensor written by the apply pass and read back here -- never exists.  nhwc_split_out nullable.
+extern "C" int dlip_wgrad_operand_split_bnbwd_f32(const float* dy, const float* z, float* out, int64_t ld_out, int64_t J, int32_t C,
+                                                  const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                                  const float* dgamma, const float* dbeta, int64_t M, float slope, int32_t act_first,
+                                                  const float* lift, float* nhwc_split_out, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dy && z && out && mean && invstd && gamma && beta && dgamma && dbeta && lift && J > 0 && J < (1ll << 28) && M > 0 && C > 0 &&
+                 (C & 63) == 0 && ld_out >= J && (ld_out & 31) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(nhwc_split_out)) & 127) == 0 &&
+                 ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(z)) & 15) == 0 && C / 64 <= 65535);
+  BnOnLoad bn = {mean, invstd, gamma, beta, nullptr, slope};
+  bn.z = z; bn.dgamma = dgamma; bn.dbeta = dbeta; bn.invM = 1.f / (float)M; bn.act_first = act_first;
+  if (C % 128 == 0)
+    hipLaunchKernelGGL((wgrad_operand_wide_kernel<128, 2>), dim3((unsigned)(ld_out / 32), (unsigned)(C / 128)), dim3(256), 0, ST(stream), dy, out,
+                       1, 1, C, C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, lift, dlip_range_for(DLIP_ST_PACK), nhwc_split_out, bn);
+  else
+    hipLaunchKernelGGL((wgrad_operand_wide_kernel<64, 2>), dim3((unsigned)(ld_out / 32), (unsigned)(C / 64)), dim3(256), 0, ST(stream), dy, out,
+                       1, 1, C, C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, lift, dlip_range_for(DLIP_ST_PACK), nhwc_split_out, bn);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_wgrad_chwn_bnbwd_f32(const float* dy, const float* z, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t N32,
+                                         const float* mean, const float* invstd, const float* gamma, const float* beta, const float* dgamma,
+                                         const float* dbeta, int64_t M, float slope, int32_t act_first, const float* lift,
+                                         float* nhwc_split_out, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(dy && z && out && mean && invstd && gamma && beta && dgamma && dbeta && lift && N > 0 && H > 0 && W > 0 && M > 0 && C > 0 &&
+                 (C & 63) == 0 && N32 >= N && (N32 & 31) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(nhwc_split_out)) & 127) == 0 &&
+                 ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(z)) & 15) == 0 && (long long)H * W <= 65535 && C / 64 <= 65535 &&
+                 N < (1ll << 31));
+  BnOnLoad bn = {mean, invstd, gamma, beta, nullptr, slope};
+  bn.z = z; bn.dgamma = dgamma; bn.dbeta = dbeta; bn.invM = 1.f / (float)M; bn.act_first = act_first;
+  if (C % 128 == 0)
+    hipLaunchKernelGGL((wgrad_chwn_wide_kernel<128, 2>), dim3((unsigned)(N32 / 32), (unsigned)(C / 128), (unsigned)(H * W)), dim3(256), 0,
+                       ST(stream), dy, out, (int)N, H * W, C, C, N32, lift, dlip_range_for(DLIP_ST_PACK), 1, nhwc_split_out, bn);
+  else
+    hipLaunchKernelGGL((wgrad_chwn_wide_kernel<64, 2>), dim3((unsigned)(N32 / 32), (unsigned)(C / 64), (unsigned)(H * W)), dim3(256), 0,
+                       ST(stream), dy, out, (int)N, H * W, C, C, N32, lift, dlip_range_for(DLIP_ST_PACK), 1, nhwc_split_out, bn);
   return dlip_launch_status();
 }
 

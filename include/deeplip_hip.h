@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 46
+#define DLIP_ABI_VERSION 47
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -663,6 +663,25 @@ int dlip_wgrad_operand_split_bn_f32(const float* x, float* out, int64_t ld_out, 
 int dlip_wgrad_chwn_bn_f32(const float* x, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t N32, const float* mean,
                            const float* invstd, const float* gamma, const float* beta, const float* slope_vec, float slope,
                            float* nhwc_split_out, dlip_stream_t stream);
+/* (ABI 47) The BACKWARD of a train-mode BatchNorm (+ LeakyReLU) applied ON LOAD, in two parts: (1) dlip_bn_rows_train_bwd_sums_f32 = the first
+ * half of dlip_bn_rows_train_bwd_f32 -- dgamma, dbeta -- plus the power-of-two lift of a dx that is never written: from the largest |g| and
+ * |xhat| the sums pass sees (amax_parts: 2 * ceil(C / 64) * dlip_bn_rows_chunks(M) floats of scratch) and max gamma invstd, the bound
+ * |dx| <= gamma invstd max|g| (2 + max|xhat|) is put at 1024 (a lift is exact: another exponent, the same gradients); (2) the two operand
+ * producers read dy and z and form dx = gamma invstd (g - dbeta / M - xhat dgamma / M) per loaded value (the apply pass's expression, the
+ * same bits), times lift[0], straight into the weight gradient's image and the data gradient's split operand (nhwc_split_out, nullable).
+ * The convolution in front of a BatchNorm (tdnn.py:35-43 under loss.backward(), train_audio.py:189-191) needs the BatchNorm's input
+ * gradient only as these images: one write and one read of an activation-sized fp32 tensor per layer less.  C % 64 == 0. */
+int dlip_bn_rows_train_bwd_sums_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                                    const float* save_invstd, float* dgamma, float* dbeta, double* workspace, float* amax_parts, int32_t M,
+                                    int32_t C, float slope, int32_t act_first, float* dx_lift2, dlip_stream_t stream);
+int dlip_wgrad_operand_split_bnbwd_f32(const float* dy, const float* z, float* out, int64_t ld_out, int64_t J, int32_t C, const float* mean,
+                                       const float* invstd, const float* gamma, const float* beta, const float* dgamma, const float* dbeta,
+                                       int64_t M, float slope, int32_t act_first, const float* lift, float* nhwc_split_out,
+                                       dlip_stream_t stream);
+int dlip_wgrad_chwn_bnbwd_f32(const float* dy, const float* z, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t N32,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta, const float* dgamma,
+                              const float* dbeta, int64_t M, float slope, int32_t act_first, const float* lift, float* nhwc_split_out,
+                              dlip_stream_t stream);
 /* nhwc_split_out (nullable; C % 32 == 0): the same tensor (scaled alike) ALSO in the convolution kernels' split activation format
  * [N,H,W,C] -- what dlip_split_pack_f32 / dlip_split_pack_scaled_f32 would write -- from the one read: the forward convolution's
  * operand together with the weight gradient's (x), the data gradient's together with the weight gradient's (dy). */

@@ -333,3 +333,45 @@ def test_full_size_training_step_vs_fp64_oracle():
     worst, who = max(ours)
     assert worst < max(1e-4, 2.0 * max(floor)), (who, worst, max(floor))
     assert np.mean([e for e, _ in ours]) < max(1e-4, 2.0 * np.mean(floor))
+
+
+@pytest.mark.parametrize("B,T,C,K,S,dil,act_first", [(40, 120, 64, 128, 1, 1, False), (40, 120, 64, 128, 3, 2, False), (24, 200, 128, 64, 5, 1, False),
+                                                     (40, 120, 64, 128, 1, 1, True), (36, 130, 64, 192, 3, 1, False)])
+def test_tdnn_block_backward_with_the_batchnorm_gradient_formed_on_load(B, T, C, K, S, dil, act_first, monkeypatch):
+    """ABI 47: conv -> BatchNorm -> LeakyReLU under backward() at more than 4 096 rows -- the BatchNorm's input gradient dz is formed per loaded
+    value by the operand producers of the convolution in front (dlip_wgrad_*_bnbwd_f32) behind a sums pass that also bounds its lift
+    (dlip_bn_rows_train_bwd_sums_f32), and never stored.  Against fp64 autograd (1e-4), and against the path that stores dz (the same
+    expression per value; the lift's exponent differs, which moves nothing but the last bit of a split: 2e-6)."""
+    from deeplip_amd import autograd as ag
+    x = rnd(B, C, T, seed=21).requires_grad_()
+    w = rnd(K, C, S, seed=22, scale=1.0 / np.sqrt(C * S)).requires_grad_()
+    b = rnd(K, seed=23, scale=0.1).requires_grad_()
+    gamma = (torch.rand(K, generator=torch.Generator().manual_seed(24)) + 0.5).requires_grad_()
+    beta = rnd(K, seed=25, scale=0.2).requires_grad_()
+    z = F.conv1d(x.double(), w.double(), b.double(), dilation=dil)
+    if act_first:
+        ref = F.batch_norm(F.leaky_relu(z, 0.2), None, None, gamma.double(), beta.double(), training=True, eps=1e-5)
+    else:
+        ref = F.leaky_relu(F.batch_norm(z, None, None, gamma.double(), beta.double(), training=True, eps=1e-5), 0.2)
+    dy = rnd(*ref.shape, seed=26) * 1e-4                     # (gradient-sized values: the lift matters)
+    ref.backward(dy.double())
+    assert B * (T - dil * (S - 1)) > ag.BN_SMALL_ROWS
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ag, "BN_BWD_ON_LOAD", fused)
+        xg = x.detach().permute(0, 2, 1).contiguous().to(DEV).requires_grad_()
+        wg_, bg, gg, beg = (t.detach().to(DEV).requires_grad_() for t in (w, b, gamma, beta))
+        rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+        y = ag.TDNNBlockTrainFn.apply(xg, wg_, bg, gg, beg, rm, rv, 0.1, 1e-5, 0.2, dil, act_first)
+        y.backward(dy.permute(0, 2, 1).contiguous().to(DEV))
+        torch.cuda.synchronize()
+        out[fused] = (xg.grad.cpu().permute(0, 2, 1).numpy(), wg_.grad.cpu().numpy(), gg.grad.cpu().numpy(), beg.grad.cpu().numpy(), bg.grad.cpu().numpy())
+    for got in out.values():
+        assert rel_err(got[0], x.grad.numpy()) < 1e-4
+        assert rel_err(got[1], w.grad.numpy()) < 1e-4
+        assert rel_err(got[2], gamma.grad.numpy()) < 1e-4
+        assert rel_err(got[3], beta.grad.numpy()) < 1e-4
+    for a, c in zip(out[True][:4], out[False][:4]):
+        assert rel_err(a, c) < 2e-6
+    from deeplip_amd import _lib
+    _lib.check_range(sync=True)
