@@ -222,10 +222,19 @@ class SpeakerEmbNet(nn.Module):
         from . import autograd_video as av
         av.prepare_weights(self)                           # the step's split weight images (forward and data-gradient banks): one launch
         pend = None                                        # (a block's activated output is not stored when the next block takes it on load)
+        # (round 6) the LAST block's activated output is not stored either when the statistics pooling takes it on load (ABI 48)
+        # ... and the pooling's BACKWARD writes nothing: the last block's BatchNorm backward forms that gradient per loaded value (hand_over)
+        last_on_load = self.pooling_type == "statistic" and ag.POOL_BN_ON_LOAD
+        n = len(self.tdnn)
+        hand_over = False
         for i, blk in enumerate(self.tdnn):
-            h, pend = ag.tdnn_block_train(h, blk, pending=pend, defer=i + 1 < len(self.tdnn))
+            if i + 1 == n and last_on_load:
+                T_out = h.shape[1] - blk.dilation * (blk.kernel_size - 1) + 2 * blk.padding
+                hand_over = ag.POOL_BWD_ON_LOAD and h.shape[0] * T_out > ag.BN_SMALL_ROWS and T_out > 1 and blk.bn_first and ag.BN_ON_LOAD
+            h, pend = ag.tdnn_block_train(h, blk, pending=pend, defer=(2 if hand_over else True) if (i + 1 < n or last_on_load) else False)
         # (pooling.py:24-26 | :87-107: attention scores, softmax over frames, weighted mean and std, all differentiable)
-        h = ag.meanstd_pool(h) if self.pooling_type == "statistic" else ag.attentive_stat_pool(h, self.pooling)
+        h = (ag.meanstd_pool(h, pending=pend, hand_over=hand_over and pend is not None) if self.pooling_type == "statistic"
+             else ag.attentive_stat_pool(h, self.pooling))
         x_a = ag.linear(h, self.fc1.weight, self.fc1.bias)
         h = ag.bn_rows_act_train(x_a, self.bn1, LRELU, act_first=not self.bn_first)
         xv = ag.linear(h, self.fc2.weight, self.fc2.bias)

@@ -351,6 +351,7 @@ class TDNNBlockTrainFn(Function):
         z = z.view(B_, z.shape[2], z.shape[3])
         Tp = z.shape[1]
         ready = (stats["ws"], stats["chunks"]) if stats is not None and stats.get("done") else None
+        ctx.expect_ms = defer == 2 and not act_first      # (defer == 2: deferred to a statistics pooling that hands its backward over)
         defer = bool(defer) and not act_first
         y2, mean, invstd = _bn_rows_fwd(z.view(B * Tp, K), gamma, beta, running_mean, running_var, momentum, eps, slope, act_first, ready, nbt,
                                         stats_only=defer)
@@ -374,6 +375,23 @@ class TDNNBlockTrainFn(Function):
         Tp = z.shape[1]
         dev = x.device
         from . import autograd_video as av
+        ms = getattr(dy, "_dlip_ms", None)
+        if ctx.expect_ms and ms is None:
+            raise RuntimeError("TDNNBlockTrainFn.backward: the gradient handed over by the statistics pooling (MeanStdPoolFn, hand_over) arrived "
+                               "without its source -- autograd copied or accumulated the tensor; set DLIP_POOL_BWD_ON_LOAD=0")
+        if ms is not None:
+            # dy was never written: formed per loaded value inside the BatchNorm backward from the pooled statistics and their gradient
+            y_pool, g_pool, T_ms = ms
+            M = B * Tp
+            _lib.ensure_conv_workspace()
+            dz2 = torch.empty((M, K), device=dev, dtype=torch.float32)
+            dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
+            lift = torch.empty((LIFT_WORDS,), device=dev, dtype=torch.float32)
+            check(lib().dlip_bn_rows_train_bwd_ms_f32(ptr(y_pool), ptr(g_pool), int(T_ms), ptr(z), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd),
+                                                      ptr(dz2), ptr(dgamma), ptr(dbeta), ptr(_ws(M, K, dev)), M, K, float(slope), ptr(lift),
+                                                      stream_handle()), "dlip_bn_rows_train_bwd_ms_f32")
+            dz2._dlip_lift = lift
+            return TDNNBlockTrainFn._backward_from_dz(ctx, dz2, dgamma, dbeta)
         want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         no_dbias_pass = not (has_bias and ctx.needs_input_grad[2]) or (not act_first and ZERO_BIAS_GRAD_BEFORE_BN)
         if (BN_BWD_ON_LOAD and av.TRAIN_CONV == "f16x3" and mode in (1, 2) and want_w and K % 64 == 0 and B * Tp > BN_SMALL_ROWS and no_dbias_pass
@@ -413,6 +431,18 @@ class TDNNBlockTrainFn(Function):
             return dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         dz2, dgamma, dbeta = _bn_rows_bwd(dy.contiguous().view(B * Tp, K), z.view(B * Tp, K), gamma, beta, mean, invstd,
                                           slope, act_first)
+        return TDNNBlockTrainFn._backward_from_dz(ctx, dz2, dgamma, dbeta)
+
+    @staticmethod
+    def _backward_from_dz(ctx, dz2, dgamma, dbeta):
+        """The convolution's part of the backward, given the BatchNorm's input gradient dz2 [B T', K] (and its lift, as an attribute)."""
+        x, weight, z, gamma, beta, mean, invstd = ctx.saved_tensors
+        dilation, slope, act_first, has_bias = ctx.cfg
+        B, T, Cx = ctx.x_shape
+        mode = ctx.mode
+        K, _, S = weight.shape
+        Tp = z.shape[1]
+        dev = x.device
         dbias = None
         if has_bias and ctx.needs_input_grad[2]:
             if not act_first and ZERO_BIAS_GRAD_BEFORE_BN:
@@ -498,23 +528,50 @@ def _conv1d_wgrad(x, dz, S, dilation, lift=None):
 
 
 class MeanStdPoolFn(Function):
-    """MeanStdPooling on [B,T,C] -> [B,2C] (pooling.py:24-26) and its backward."""
+    """MeanStdPooling on [B,T,C] -> [B,2C] (pooling.py:24-26) and its backward.  ``pending`` = (z, mean, invstd, gamma, beta, slope) of the
+    block in front (TDNNBlockTrainFn defer): x's values were never written -- both kernels read the raw convolution output z and apply
+    that block's BatchNorm + LeakyReLU per loaded value (dlip_meanstd_pool_bn_f32 / _bwd_bn_f32, ABI 48)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, pending=None, hand_over=False):
+        """``hand_over`` (with ``pending``): the backward writes nothing -- see backward."""
         x = x.contiguous()
+        ctx.hand_over = bool(hand_over) and pending is not None
+        if pending is not None:
+            z, mean, invstd, gamma, beta, slope = pending
+            B, T, C_ = x.shape
+            y = torch.empty((B, 2 * C_), device=x.device, dtype=torch.float32)
+            check(lib().dlip_meanstd_pool_bn_f32(ptr(z), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), float(slope), ptr(y), B, T, C_, stream_handle()),
+                  "dlip_meanstd_pool_bn_f32")
+            ctx.save_for_backward(z, y, mean, invstd, gamma, beta)
+            ctx.slope, ctx.on_load = float(slope), True
+            return y
         y = ops.meanstd_pool(x)
         ctx.save_for_backward(x, y)
+        ctx.on_load = False
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.on_load:
+            z, y, mean, invstd, gamma, beta = ctx.saved_tensors
+            B, T, C_ = z.shape
+            dx = torch.empty_like(z)
+            if ctx.hand_over:
+                # The block in front forms this gradient itself, per loaded value, inside its BatchNorm backward (MsSrc,
+                # dlip_bn_rows_train_bwd_ms_f32): dx stays UNWRITTEN and carries what that takes.  TDNNBlockTrainFn.backward raises if the
+                # tensor it receives has lost the attribute (it was told at forward time to expect it).
+                dx._dlip_ms = (y, dy.contiguous(), T)
+                return dx, None, None
+            check(lib().dlip_meanstd_pool_bwd_bn_f32(ptr(z), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ctx.slope, ptr(y), ptr(dy.contiguous()),
+                                                     ptr(dx), B, T, C_, stream_handle()), "dlip_meanstd_pool_bwd_bn_f32")
+            return dx, None, None
         x, y = ctx.saved_tensors
         B, T, C_ = x.shape
         dx = torch.empty_like(x)
         check(lib().dlip_meanstd_pool_bwd_f32(ptr(x), ptr(y), ptr(dy.contiguous()), ptr(dx), B, T, C_, stream_handle()),
               "dlip_meanstd_pool_bwd_f32")
-        return dx
+        return dx, None, None
 
 
 class AttnStatPoolFn(Function):
@@ -576,7 +633,7 @@ def tdnn_block_train(x, blk, pending=None, defer=False):
     """blk: deeplip_amd.audio.TDNN_Block in train mode; x [B,T,C] channels-last.  ``pending`` / ``defer``: TDNNBlockTrainFn --
     returns (y, pending for the next block or None)."""
     bn = blk.bn
-    defer = bool(defer) and BN_ON_LOAD and blk.bn_first
+    defer = (2 if defer == 2 else 1) if (bool(defer) and BN_ON_LOAD and blk.bn_first) else False     # (2: deferred to a pooling that hands its backward over)
     out = TDNNBlockTrainFn.apply(x, blk.context_layer.weight, blk.context_layer.bias, bn.weight, bn.bias, bn.running_mean,
                                  bn.running_var, bn.momentum, bn.eps, 0.2, blk.dilation, not blk.bn_first, bn.num_batches_tracked,
                                  defer, pending)
@@ -591,5 +648,12 @@ def bn_rows_act_train(x, bn, slope, act_first):
                              bn.num_batches_tracked)
 
 
-def meanstd_pool(x):
-    return MeanStdPoolFn.apply(x)
+POOL_BN_ON_LOAD = __import__("os").environ.get("DLIP_POOL_BN_ON_LOAD", "1") != "0"      # (the environment switch: same-box A/B runs)
+
+
+POOL_BWD_ON_LOAD = __import__("os").environ.get("DLIP_POOL_BWD_ON_LOAD", "1") != "0"     # (the environment switch: same-box A/B runs)
+
+
+def meanstd_pool(x, pending=None, hand_over=False):
+    """``pending`` / ``hand_over``: see MeanStdPoolFn (the last TDNN block's output taken on load; its gradient formed by that block)."""
+    return MeanStdPoolFn.apply(x, pending, hand_over)

@@ -73,6 +73,32 @@ __device__ __forceinline__ f32x4 pooled_grad(const PoolSrc& ps, const float* __r
   return acc;
 }
 
+// (ABI 48) The gradient of a MeanStdPooling's INPUT formed on load: dy[b, t, c] = dmean[b, c] / T + dstd[b, c] (y[b, t, c] - mean[b, c]) / ((T - 1) std[b, c])
+// (meanstd_bwd_kernel's expression) with y the ACTIVATED value the BatchNorm backward recomputes anyway -- the pooling's backward then
+// writes nothing: its [B,T,C] gradient (460 MB for the E-TDNN's last layer at B = 256) was one write and two reads.
+struct MsSrc {
+  const float* y = nullptr;          // [B, 2 C] pooled (mean | std); nullptr: the gradient is read from memory
+  const float* g = nullptr;          // [B, 2 C] its gradient
+  int T = 1;                         // frames per utterance: row r belongs to utterance r / T
+  FastDiv div_T;
+};
+__device__ __forceinline__ f32x4 ms_grad(const MsSrc& ms, int row, int c, int C, const f32x4 yact) {
+  const int b = dlip_div(row, ms.div_T);
+  const float* yb = ms.y + (long long)b * 2 * C + c;
+  const float* gb = ms.g + (long long)b * 2 * C + c;
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(yb), sd = *reinterpret_cast<const f32x4*>(yb + C);
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gb), gsd = *reinterpret_cast<const f32x4*>(gb + C);
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a = gm[k] / (float)ms.T;
+    const float gs = sd[k] > 0.f ? gsd[k] : 0.f;
+    const float den = sd[k] > 0.f ? (float)(ms.T - 1) * sd[k] : 1.f;
+    o[k] = a + gs * (yact[k] - mean[k]) / den;
+  }
+  return o;
+}
+
 struct ColFin {
   int* ticket;                       // nullptr: the caller launches the finalize kernel
   float* out0;                       // MODE 0 save_mean   | MODE 1 / 3 dbeta  | MODE 2 the column sums
@@ -83,6 +109,7 @@ struct ColFin {
   long long* nbt;                    // MODE 0 (nullable): num_batches_tracked += 1
   float momentum, eps;
   unsigned* amax_parts = nullptr;    // MODE 1 (nullable): per workgroup (max |g|, max |xhat|) as bit patterns, 2 words each (dlip_bn_rows_train_bwd_sums_f32)
+  MsSrc ms;                          // MODE 1, act_first == 0: dy formed on load from a pooled gradient (dlip_bn_rows_train_bwd_ms_f32)
 };
 
 __device__ __forceinline__ void bn_stats_finish(double s, double q, int M, int c, float* save_mean, float* save_invstd,
@@ -192,7 +219,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
       ga = *reinterpret_cast<const f32x4*>(gamma + c); be = *reinterpret_cast<const f32x4*>(beta + c);
     }
     if (MODE == 3) sl = *reinterpret_cast<const f32x4*>(slope_vec + c);
-    auto add_row = [&](const f32x4 xv, const f32x4 gv) __attribute__((always_inline)) {
+    auto add_row = [&](const f32x4 xv, f32x4 gv, const int row) __attribute__((always_inline)) {
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -200,6 +227,12 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
           s0[k] += a; s1[k] += a * a;
         }
       } else if (MODE == 1) {
+        if (fin.ms.y != nullptr) {      // (workgroup-uniform; act_first == 0) the gradient from the pooled one, at the activated value
+          f32x4 ya;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ya[k] = lrelu((xv[k] - mu[k]) * is[k] * ga[k] + be[k], slope);
+          gv = ms_grad(fin.ms, row, c, C, ya);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float a = act_first ? lrelu(xv[k], slope) : xv[k];
@@ -225,7 +258,8 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     };
     // four rows of a lane group per trip, their loads issued together (one load in flight per lane held a pass at half of what
     // the memory system gives once a part is longer than a few trips)
-    constexpr bool TWO = MODE == 1 || MODE == 3;
+    constexpr bool TWO_ = MODE == 1 || MODE == 3;
+    const bool TWO = TWO_ && !(MODE == 1 && fin.ms.y != nullptr);      // (a gradient formed on load is not read)
     int r = r0 + rg;
     for (; r + 48 < r1; r += 64) {
       f32x4 xv[4], gv[4];
@@ -235,12 +269,12 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
         gv[u] = TWO ? *reinterpret_cast<const f32x4*>(dy + (long long)(r + 16 * u) * C + c) : xv[u];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) add_row(xv[u], gv[u]);
+      for (int u = 0; u < 4; ++u) add_row(xv[u], gv[u], r + 16 * u);
     }
     for (; r < r1; r += 16) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long long)r * C + c);
       const f32x4 gv = TWO ? *reinterpret_cast<const f32x4*>(dy + (long long)r * C + c) : xv;
-      add_row(xv, gv);
+      add_row(xv, gv, r);
     }
   }
 #pragma unroll
@@ -673,7 +707,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
                                                            f32x4* __restrict__ dx, long long n4, int C4, int M, float slope,
                                                            int act_first, const float* __restrict__ slope_vec = nullptr,
                                                            unsigned* amax_acc = nullptr, int* ticket = nullptr,
-                                                           const PoolSrc ps = PoolSrc{}) {
+                                                           const PoolSrc ps = PoolSrc{}, const MsSrc ms = MsSrc{}) {
   const float invM = 1.f / (float)M;
   float amax = 0.f;     // max |dx| of the launch -> amax_acc (the next convolution backward's power-of-two lift, without its own pass)
   const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -690,6 +724,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
     const f32x4 xv = x[i];
     f32x4 gv;
     if constexpr (POOL) { const int row = (int)(i / C4); gv = pooled_grad(ps, reinterpret_cast<const float*>(dy), row, (int)(i - (long long)row * C4) * 4, C4 * 4); }
+    else if (ms.y != nullptr) {       // (launch-uniform; act_first == 0) see MsSrc
+      const int row = (int)(i / C4);
+      f32x4 ya;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ya[k] = lrelu((xv[k] - mu[k]) * is[k] * ga[k] + be[k], slope);
+      gv = ms_grad(ms, row, (int)(i - (long long)row * C4) * 4, C4 * 4, ya);
+    }
     else gv = dy[i];
     f32x4 o;
 #pragma unroll
@@ -919,9 +960,19 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 // A thread keeps ONE channel quad (its mean, std and the two gradients in registers) and walks a chunk of frames: no index
 // arithmetic per element (the first version divided a 64-bit element index twice per element and re-read its four parameters per
 // channel: 529 us for the 854 MB of an E-TDNN step at B = 256 -- 1.6 TB/s; round 4).  Same operations per value, same bits.
+// (ABI 48) BN: x is the raw convolution output z in front of a train-mode BatchNorm + LeakyReLU whose activated values were never stored
+// (dlip_meanstd_pool_bn_f32): they are formed per loaded value again (the same expression, the same bits).
+struct PoolBnB {
+  const float* mean = nullptr;
+  const float* invstd = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float slope = 1.f;
+};
+template <bool BN = false>
 __global__ __launch_bounds__(256) void meanstd_bwd_kernel(const f32x4* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ dy, f32x4* __restrict__ dx, int T, int C4,
-                                                          int tchunk) {
+                                                          int tchunk, const PoolBnB bn = PoolBnB{}) {
   const int c4 = blockIdx.x * blockDim.x + threadIdx.x;   // (64, 128 or 256 threads: whichever wastes the fewest lanes on C4)
   if (c4 >= C4) return;
   const int b = blockIdx.z, t0 = blockIdx.y * tchunk, t1 = min(T, t0 + tchunk);
@@ -938,8 +989,20 @@ __global__ __launch_bounds__(256) void meanstd_bwd_kernel(const f32x4* __restric
     den[k] = sd > 0.f ? (float)(T - 1) * sd : 1.f;
   }
   const long long base = (long long)b * T * C4 + c4;
+  f32x4 mu = {0, 0, 0, 0}, is = mu, ga = mu, be = mu;
+  if constexpr (BN) {
+    mu = *reinterpret_cast<const f32x4*>(bn.mean + c); is = *reinterpret_cast<const f32x4*>(bn.invstd + c);
+    ga = *reinterpret_cast<const f32x4*>(bn.gamma + c); be = *reinterpret_cast<const f32x4*>(bn.beta + c);
+  }
   for (int t = t0; t < t1; ++t) {
-    const f32x4 v = x[base + (long long)t * C4];
+    f32x4 v = x[base + (long long)t * C4];
+    if constexpr (BN) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float u = (v[k] - mu[k]) * is[k] * ga[k] + be[k];
+        v[k] = u >= 0.f ? u : u * bn.slope;
+      }
+    }
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = a[k] + gs[k] * (v[k] - mean[k]) / den[k];
@@ -1306,7 +1369,7 @@ int bn_fwd_launch(const float* x, const float* gamma, const float* beta, const f
 // Shared backward: slope_vec != NULL = the PReLU form (dslope written; act_first = 0), else the LeakyReLU forms.
 int bn_bwd_launch(const float* dy, const float* x, const float* gamma, const float* beta, const float* slope_vec,
                   const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* dslope,
-                  double* workspace, int M, int C, float slope, int act_first, float* dx_lift2, hipStream_t st) {
+                  double* workspace, int M, int C, float slope, int act_first, float* dx_lift2, hipStream_t st, const MsSrc ms = MsSrc{}) {
   unsigned* acc = dx_lift2 ? reinterpret_cast<unsigned*>(dx_lift2) + 2 : nullptr;   // per-workgroup maxima behind the pair
   int* tickets = stream_tickets(st, (C + 63) / 64);
   if (bn_small(M) && C / 4 <= 4096) {
@@ -1330,6 +1393,7 @@ int bn_bwd_launch(const float* dy, const float* x, const float* gamma, const flo
       hipLaunchKernelGGL(col_finalize3_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, workspace + (long long)chunks * C * 2,
                          dbeta, dgamma, dslope, C, chunks);
   } else {
+    fin.ms = ms;
     hipLaunchKernelGGL(col_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd,
                        gamma, beta, workspace, M, C, slope, act_first, nullptr, rpp, fin);
     if (!tickets) hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);
@@ -1343,11 +1407,11 @@ int bn_bwd_launch(const float* dy, const float* x, const float* gamma, const flo
   if (gf)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gf), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, slope_vec, acc, lift_ticket);
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, slope_vec, acc, lift_ticket, PoolSrc{}, ms);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(dy),
                        reinterpret_cast<const f32x4*>(x), save_mean, save_invstd, gamma, beta, dgamma, dbeta,
-                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, slope_vec, acc, lift_ticket);
+                       reinterpret_cast<f32x4*>(dx), n4, C / 4, M, slope, act_first, slope_vec, acc, lift_ticket, PoolSrc{}, ms);
   if (acc && !lift_ticket) hipLaunchKernelGGL(pow2_finalize_parts_kernel, dim3(1), dim3(256), 0, st, acc, (int)grid, dx_lift2, 1024.0f);
   return dlip_launch_status();
 }
@@ -1376,6 +1440,23 @@ extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
   return bn_bwd_launch(dy, x, gamma, beta, nullptr, save_mean, save_invstd, dx, dgamma, dbeta, nullptr, workspace, M, C, slope, act_first,
                        dx_lift2, static_cast<hipStream_t>(stream));
+}
+
+// (ABI 48) dlip_bn_rows_train_bwd_f32 behind a MeanStdPooling whose backward writes nothing: dy is formed per loaded value from the pooled
+// statistics y_pool [B,2C] and their gradient g_pool [B,2C] (MsSrc; M = B T rows, conv -> BatchNorm -> LeakyReLU order, more than
+// BN_SMALL_ROWS rows).
+extern "C" int dlip_bn_rows_train_bwd_ms_f32(const float* y_pool, const float* g_pool, int32_t T, const float* x, const float* gamma,
+                                             const float* beta, const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                                             float* dbeta, double* workspace, int32_t M, int32_t C, float slope, float* dx_lift2,
+                                             dlip_stream_t stream) {
+  DLIP_CHECK_ARG(y_pool && g_pool && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace);
+  DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0 && T > 1 && M % T == 0 && !bn_small(M));
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(y_pool) |
+                   reinterpret_cast<uintptr_t>(g_pool)) & 15) == 0);
+  MsSrc ms;
+  ms.y = y_pool; ms.g = g_pool; ms.T = T; ms.div_T = dlip_fastdiv((uint32_t)T);
+  return bn_bwd_launch(x /* never read as dy */, x, gamma, beta, nullptr, save_mean, save_invstd, dx, dgamma, dbeta, nullptr, workspace, M, C, slope, 0,
+                       dx_lift2, static_cast<hipStream_t>(stream), ms);
 }
 
 // (ABI 47) The first half of dlip_bn_rows_train_bwd_f32 alone: dgamma, dbeta and the lift of a dx that is never written -- the operand
@@ -1588,8 +1669,29 @@ extern "C" int dlip_meanstd_pool_bwd_f32(const float* x, const float* y, const f
   if (tsplit < 1) tsplit = 1;
   if (tsplit > T) tsplit = T;
   const int tchunk = (T + tsplit - 1) / tsplit;
-  hipLaunchKernelGGL(meanstd_bwd_kernel, dim3(cb, (T + tchunk - 1) / tchunk, B), dim3(bs), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const f32x4*>(x), y, dy, reinterpret_cast<f32x4*>(dx), T, C4, tchunk);
+  hipLaunchKernelGGL(meanstd_bwd_kernel<false>, dim3(cb, (T + tchunk - 1) / tchunk, B), dim3(bs), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(x), y, dy, reinterpret_cast<f32x4*>(dx), T, C4, tchunk, PoolBnB{});
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_meanstd_pool_bwd_bn_f32(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                            float slope, const float* y, const float* dy, float* dx, int32_t B, int32_t T, int32_t C,
+                                            dlip_stream_t stream) {
+  DLIP_CHECK_ARG(z && mean && invstd && gamma && beta && y && dy && dx && B > 0 && T > 1 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  DLIP_CHECK_ARG(B <= 65535);
+  const int C4 = C / 4;
+  int bs = 256;
+  for (int cand : {128, 64})
+    if ((C4 + cand - 1) / cand * cand < (C4 + bs - 1) / bs * bs) bs = cand;
+  const int cb = (C4 + bs - 1) / bs;
+  int tsplit = (int)((4096 + (long long)cb * B - 1) / ((long long)cb * B));
+  if (tsplit < 1) tsplit = 1;
+  if (tsplit > T) tsplit = T;
+  const int tchunk = (T + tsplit - 1) / tsplit;
+  PoolBnB bn; bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma; bn.beta = beta; bn.slope = slope;
+  hipLaunchKernelGGL(meanstd_bwd_kernel<true>, dim3(cb, (T + tchunk - 1) / tchunk, B), dim3(bs), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f32x4*>(z), y, dy, reinterpret_cast<f32x4*>(dx), T, C4, tchunk, bn);
   return dlip_launch_status();
 }
 

@@ -97,9 +97,19 @@ __global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict
 // split activation format; ldy = 2C rounded up to 32, padding zeroed) for the LDS-DMA GEMM behind it.
 // `len` (ragged batches: utterance b is valid for its first len[b] + len_add of the T frames, the rest is padding): the
 // statistics cover the valid frames only, as the reference's one-utterance-at-a-time loop computes them (train_fusion.py:334-338).
-template <bool SPLIT>
+// (ABI 48) BN: x is the RAW output z of the last TDNN convolution and every loaded value becomes lrelu((z - mean) invstd gamma + beta, slope)
+// first (bn_fwd_apply_kernel's expression: the same bits) -- the train-mode BatchNorm + LeakyReLU in front of the pooling, whose activated
+// tensor ([B,T,1500]: 460 MB at B = 256) is then never stored.
+struct PoolBn {
+  const float* mean = nullptr;
+  const float* invstd = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float slope = 1.f;
+};
+template <bool SPLIT, bool BN = false>
 __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                      int Tpad, int C, int ldy, const DlipLen len, DlipRange status) {
+                                                      int Tpad, int C, int ldy, const DlipLen len, DlipRange status, const PoolBn bn = PoolBn{}) {
   __shared__ double part[16][64][2];
   const int b = blockIdx.y, c0 = blockIdx.x * 64;
   const int T = dlip_valid_rows(len, b, Tpad);
@@ -109,8 +119,20 @@ __global__ __launch_bounds__(256) void meanstd_kernel(const float* __restrict__ 
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (c < C) {   // C % 4 == 0: a float4 is all inside or all outside
     const float* p = x + (long long)b * Tpad * C + c;
+    f32x4 mu = {0, 0, 0, 0}, is = mu, ga = mu, be = mu;
+    if constexpr (BN) {
+      mu = *reinterpret_cast<const f32x4*>(bn.mean + c); is = *reinterpret_cast<const f32x4*>(bn.invstd + c);
+      ga = *reinterpret_cast<const f32x4*>(bn.gamma + c); be = *reinterpret_cast<const f32x4*>(bn.beta + c);
+    }
     for (int t = g; t < T; t += 16) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + (long long)t * C);
+      f32x4 v = *reinterpret_cast<const f32x4*>(p + (long long)t * C);
+      if constexpr (BN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float u = (v[k] - mu[k]) * is[k] * ga[k] + be[k];
+          v[k] = u >= 0.f ? u : u * bn.slope;
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) { s[k] += (double)v[k]; q[k] += (double)v[k] * (double)v[k]; }
     }
@@ -212,6 +234,17 @@ extern "C" int dlip_meanstd_pool_f32(const float* x, const int32_t* len, int32_t
   else
     hipLaunchKernelGGL(meanstd_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, T, C, 2 * C, l,
                        DlipRange{});
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_meanstd_pool_bn_f32(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                        float slope, float* y, int32_t B, int32_t T, int32_t C, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(z && mean && invstd && gamma && beta && y && B > 0 && B <= 65535 && T > 0 && C > 0 && (C & 3) == 0);
+  DLIP_CHECK_ARG((reinterpret_cast<uintptr_t>(z) & 15) == 0);
+  DlipLen l; l.len = nullptr; l.mul = 1; l.add = 0;
+  PoolBn bn; bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma; bn.beta = beta; bn.slope = slope;
+  hipLaunchKernelGGL((meanstd_kernel<false, true>), dim3((C + 63) / 64, B), dim3(256), 0, static_cast<hipStream_t>(stream), z, y, T, C, 2 * C, l,
+                     DlipRange{}, bn);
   return dlip_launch_status();
 }
 

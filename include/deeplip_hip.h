@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 47
+#define DLIP_ABI_VERSION 48
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -671,6 +671,20 @@ int dlip_wgrad_chwn_bn_f32(const float* x, float* out, int64_t N, int32_t H, int
  * same bits), times lift[0], straight into the weight gradient's image and the data gradient's split operand (nhwc_split_out, nullable).
  * The convolution in front of a BatchNorm (tdnn.py:35-43 under loss.backward(), train_audio.py:189-191) needs the BatchNorm's input
  * gradient only as these images: one write and one read of an activation-sized fp32 tensor per layer less.  C % 64 == 0. */
+/* (ABI 48) MeanStdPooling (pooling.py:24-26) and its backward on the RAW output z of the last TDNN convolution, the train-mode BatchNorm +
+ * LeakyReLU in front applied per loaded value (tdnn.py:35-43 -> :96 under model.train()): the activated [B,T,1500] tensor -- 460 MB at
+ * B = 256 -- is never stored.  dx of the backward is the gradient with respect to the ACTIVATED values (the BatchNorm's backward follows). */
+int dlip_meanstd_pool_bn_f32(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                             float* y, int32_t B, int32_t T, int32_t C, dlip_stream_t stream);
+int dlip_meanstd_pool_bwd_bn_f32(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                                 const float* y, const float* dy, float* dx, int32_t B, int32_t T, int32_t C, dlip_stream_t stream);
+/* (ABI 48) ... and the BatchNorm backward BEHIND that pooling with the pooling's backward formed on load: dy[b,t,c] = dmean / T + dstd (y - mean) /
+ * ((T - 1) std) per loaded value from the pooled statistics y_pool [B,2C] and their gradient g_pool [B,2C] (y = the activated value the
+ * BatchNorm backward recomputes anyway) -- the pooling's backward writes nothing (its [B,T,C] gradient was one write and two reads).  Otherwise
+ * dlip_bn_rows_train_bwd_f32 (conv -> BatchNorm -> LeakyReLU order; M = B T > 4096 rows). */
+int dlip_bn_rows_train_bwd_ms_f32(const float* y_pool, const float* g_pool, int32_t T, const float* x, const float* gamma, const float* beta,
+                                  const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, double* workspace,
+                                  int32_t M, int32_t C, float slope, float* dx_lift2, dlip_stream_t stream);
 int dlip_bn_rows_train_bwd_sums_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                                     const float* save_invstd, float* dgamma, float* dbeta, double* workspace, float* amax_parts, int32_t M,
                                     int32_t C, float slope, int32_t act_first, float* dx_lift2, dlip_stream_t stream);

@@ -375,3 +375,40 @@ def test_tdnn_block_backward_with_the_batchnorm_gradient_formed_on_load(B, T, C,
         assert rel_err(a, c) < 2e-6
     from deeplip_amd import _lib
     _lib.check_range(sync=True)
+
+
+@pytest.mark.parametrize("B,switch", [(12, "POOL_BN_ON_LOAD"), (64, "POOL_BN_ON_LOAD"), (64, "POOL_BWD_ON_LOAD")])
+def test_meanstd_pooling_with_the_batchnorm_in_front_applied_on_load(B, switch, monkeypatch):
+    """ABI 48: the last TDNN block's BatchNorm + LeakyReLU output is not stored when the statistics pooling behind it reads the raw
+    convolution output and applies them per loaded value (forward AND backward; POOL_BN_ON_LOAD) -- and with more than 4 096 rows (B = 64)
+    the pooling's backward writes nothing either: the block's BatchNorm backward forms that gradient per loaded value from the pooled
+    statistics and their gradient (POOL_BWD_ON_LOAD, dlip_bn_rows_train_bwd_ms_f32).  The whole encoder's forward + backward with the switch
+    on and off: same loss, same running statistics, gradients to 1e-6 (the same expressions per value)."""
+    from deeplip_amd import autograd as ag, weightgen as wg
+    from models.audio_models.loss import LMCL
+    from models.audio_models.tdnn import SpeakerEmbNet
+    from oracle import deeplip_oracle as O
+    opts = {"arch": "tdnn", "tdnn": {"input_dim": 24, "hidden_dim": [512] * 4 + [1500], "context": O.TDNN_CONTEXT, "tdnn_layers": 5,
+                                      "embedding_dim": 512, "pooling": "statistic", "attention_hidden_size": 64, "bn_first": True}}
+    x = torch.from_numpy(wg.audio_input(B, 24, 90, key="pool.onload")).to(DEV)
+    lab = torch.from_numpy(wg.labels(B, 19)).to(DEV)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ag, switch, on)
+        net = SpeakerEmbNet(opts)
+        sd = wg.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, prefix="audio_tdnn.")
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.to(DEV).train()
+        crit = LMCL(512, 19, 30, 0.2).to(DEV)
+        with torch.no_grad():
+            crit.weights.copy_(torch.from_numpy(wg.fill_state_dict({"w": tuple(crit.weights.shape)}, prefix="pool.onload.crit.")["w"]))
+        loss, _ = crit(net(x), lab)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[on] = (float(loss.detach()), {k: v.grad.detach().cpu().numpy() for k, v in net.named_parameters()},
+                   {k: v.detach().cpu().numpy() for k, v in net.named_buffers()})
+    assert res[True][0] == res[False][0]
+    for k in res[True][1]:
+        assert rel_err(res[True][1][k], res[False][1][k]) < 1e-6, k
+    for k in res[True][2]:
+        assert np.array_equal(res[True][2][k], res[False][2][k]), k            # running statistics: the same sums
