@@ -27,6 +27,31 @@ def _colsum(x):
     return y
 
 
+# (round 6) nn.Linear products of 2^27 multiply-adds or more (the speech encoder's fc1: 256 x 3000 -> 512) on the split-fp16 matrix kernels with
+# their balanced work split, like every convolution of the step: the exact-fp32 kernels ran them on 32 - 188 tiles with no split of the
+# reduction -- forward 63 us, dx 69 us, dW 44 us (tools/probes: E§R6.17).  An input width that is no multiple of 32 is zero-padded by
+# the pass that splits it (3 000 -> 3 008).
+LINEAR_ON_MATRIX_KERNELS = __import__("os").environ.get("DLIP_LINEAR_F16X3", "1") != "0"      # (the environment switch: same-box A/B runs)
+_ONE_PAIR = {}
+
+
+def _one_pair(device):
+    key = (device.type, device.index)
+    if key not in _ONE_PAIR:
+        _ONE_PAIR[key] = torch.ones((2,), device=device, dtype=torch.float32)
+    return _ONE_PAIR[key]
+
+
+def _linear_big(x, w) -> bool:
+    from . import autograd_video as av
+    M, Cin = x.shape
+    N = w.shape[0]
+    if not (LINEAR_ON_MATRIX_KERNELS and av.TRAIN_CONV == "f16x3" and x.is_cuda and M * N * Cin >= (1 << 27) and Cin % 4 == 0 and N % 32 == 0):
+        return False
+    # (the (1, 1) scale pair is made by the first eager call: a recorded step's first call is eager -- nothing is allocated under a capture)
+    return (x.device.type, x.device.index) in _ONE_PAIR or not torch.cuda.is_current_stream_capturing()
+
+
 class LinearFn(Function):
     """y = x W^T + b   (nn.Linear; model_fusion.py:19,23, loss.py:14)."""
 
@@ -36,6 +61,16 @@ class LinearFn(Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         M, Cin = x.shape
+        ctx.big = _linear_big(x, w)
+        if ctx.big:
+            from . import autograd_video as av
+            N = w.shape[0]
+            Cp = (Cin + 31) // 32 * 32
+            xs = torch.empty((M, 1, 1, Cp), device=x.device, dtype=torch.float32)
+            check(lib().dlip_split_pack_scaled_pad_f32(ptr(x), ptr(xs), ptr(_one_pair(x.device)), M, Cin, Cp, stream_handle()),
+                  "dlip_split_pack_scaled_pad_f32")
+            y = av.conv_train(xs, None, b.contiguous() if b is not None else None, w_ref=w.view(N, Cin, 1, 1), xs_ready=xs)   # (xs doubles as the shape holder)
+            return y.view(M, N)
         if Cin % 4 == 0:
             return ops.linear(x, w, b.contiguous() if b is not None else None)
         y = _gemm(x, w, M, w.shape[0], Cin, tb=True)
@@ -47,6 +82,16 @@ class LinearFn(Function):
         dy = dy.contiguous()
         M, K = dy.shape
         Cin = x.shape[1]
+        if ctx.big:
+            from . import autograd_video as av
+            lift = av.pow2_lift(dy)
+            dy4 = dy.view(M, 1, 1, K)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = av.conv_train(dy4, None, None, lift=True, scale2=lift, w_ref=w.view(K, Cin, 1, 1), transposed=True).view(M, Cin)
+            dw = av.wgrad_conv(x.view(M, 1, 1, Cin), dy4, 1, 1, (1, 1), (0, 0), (1, 1), scale2=lift).view(K, Cin) if ctx.needs_input_grad[1] else None
+            db = _colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            return dx, dw, db
         dx = _gemm(dy, w, M, Cin, K) if ctx.needs_input_grad[0] else None          # dY [M,K] @ W [K,C]
         dw = _gemm(dy, x, K, Cin, M, ta=True) if ctx.needs_input_grad[1] else None  # dY^T [K,M] @ X [M,C]
         db = _colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None

@@ -79,3 +79,31 @@ def test_autograd_functions_vs_torch():
     assert abs(float(loss) - float(lc)) < 1e-5 * abs(float(lc))
     for a, c in ((x, xc), (w, wc), (b, bc)):
         assert rel_err(a.grad.cpu().numpy(), c.grad.numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_large_linear_products_run_on_the_matrix_kernels(monkeypatch):
+    """nn.Linear of 2^27 multiply-adds or more under autograd (the speech encoder's fc1: 256 x 3000 -> 512): forward, dx, dW through the
+    split-fp16 convolution kernels (the input's 3 000 columns zero-padded to 3 008 by the pass that splits it) against fp64, and against the
+    exact-fp32 route it replaces."""
+    from deeplip_amd import autograd as ag
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(256, 3000, generator=g)
+    w = torch.randn(512, 3000, generator=g) * 0.02
+    b = torch.randn(512, generator=g) * 0.1
+    dy = torch.randn(256, 512, generator=g) * 1e-3
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    (xr @ wr.t() + br).backward(dy.double())
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(ag, "LINEAR_ON_MATRIX_KERNELS", on)
+        xg, wg_, bg = (t.clone().cuda().requires_grad_() for t in (x, w, b))
+        y = ag.linear(xg, wg_, bg)
+        y.backward(dy.cuda())
+        torch.cuda.synchronize()
+        out[on] = (y.detach().cpu(), xg.grad.cpu(), wg_.grad.cpu(), bg.grad.cpu())
+        ref = (xr.detach() @ wr.detach().t() + br.detach())
+        for got, want, tol in ((out[on][0], ref, 2e-5), (out[on][1], xr.grad, 1e-4), (out[on][2], wr.grad, 1e-4), (out[on][3], br.grad, 1e-4)):
+            assert float((got.double() - want).abs().max() / want.abs().max()) < tol, on
+    for a, c in zip(out[True], out[False]):
+        assert float((a.double() - c.double()).abs().max() / c.double().abs().max()) < 5e-6
