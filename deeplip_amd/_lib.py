@@ -13,7 +13,7 @@ import torch  # must be imported first: the library binds to the HIP runtime tor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLIP_LIB_PATH") or os.path.join(_PKG, "lib", "libdeeplip_hip.so")  # env override: A/B builds
-ABI_VERSION = 48
+ABI_VERSION = 49
 LIFT_WORDS = 4098
 LIFT_BCAST = 2048
 
@@ -66,10 +66,12 @@ SIGNATURES = {
     "dlip_wgrad_chwn_bn_f32": [c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f, C.c_float, c_f, c_stream],
     "dlip_meanstd_pool_bn_f32": [c_f, c_f, c_f, c_f, c_f, C.c_float, c_f, c_i32, c_i32, c_i32, c_stream],
     "dlip_meanstd_pool_bwd_bn_f32": [c_f, c_f, c_f, c_f, c_f, C.c_float, c_f, c_f, c_f, c_i32, c_i32, c_i32, c_stream],
-    "dlip_bn_rows_train_bwd_ms_f32": [c_f, c_f, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_f, c_stream],
-    "dlip_bn_rows_train_bwd_sums_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_f, c_stream],
+    "dlip_meanstd_bwd_coef_f32": [c_f, c_f, c_f, c_i32, c_i32, c_i32, c_stream],
+    "dlip_bn_rows_train_bwd_ms_f32": [c_f, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_f, c_stream],
+    "dlip_bn_rows_train_bwd_sums_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i32, c_i32, C.c_float, c_i32, c_f, c_f, c_i32,
+                                        c_stream],
     "dlip_wgrad_operand_split_bnbwd_f32": [c_f, c_f, c_f, c_i64, c_i64, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, C.c_float, c_i32, c_f, c_f,
-                                           c_stream],
+                                           c_i32, c_f, c_i32, c_stream],
     "dlip_wgrad_chwn_bnbwd_f32": [c_f, c_f, c_f, c_i64, c_i32, c_i32, c_i32, c_i32, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, C.c_float, c_i32, c_f,
                                   c_f, c_stream],
     "dlip_bn_apply_rows_f32": [c_f, c_f, c_f, c_f, c_f, c_f, C.c_float, c_f, c_i32, c_i32, c_stream],

@@ -306,17 +306,19 @@ BN_BWD_ON_LOAD = __import__("os").environ.get("DLIP_BN_BWD_ON_LOAD", "1") != "0"
 BN_SMALL_ROWS = 4096          # (encoder_train_ops.hip: at most this many rows go through the one-launch BatchNorm, which writes dz)
 
 
-def _bn_rows_bwd_sums(dy2, x2, gamma, beta, mean, invstd, slope, act_first):
-    """dgamma, dbeta and the lift of the dz that the producers will form on load (a DLIP_LIFT_WORDS buffer, as pow2_lift returns it)."""
+def _bn_rows_bwd_sums(dy2, x2, gamma, beta, mean, invstd, slope, act_first, ms=None):
+    """dgamma, dbeta and the lift of the dz that the producers will form on load (a DLIP_LIFT_WORDS buffer, as pow2_lift returns it).
+    ``ms`` = (coef, T): dy2 itself is formed on load from a statistics pooling's coefficients (MeanStdPoolFn hand_over; dy2 may be None)."""
     M, C_ = x2.shape
+    ms_c, ms_T = ms if ms is not None else (None, 0)
     _lib.ensure_conv_workspace()
     dg = torch.empty_like(mean)
     db = torch.empty_like(mean)
     lift = torch.empty((LIFT_WORDS,), device=x2.device, dtype=torch.float32)
     parts = torch.empty((2 * ((C_ + 63) // 64) * int(lib().dlip_bn_rows_chunks(M)),), device=x2.device, dtype=torch.float32)
     check(lib().dlip_bn_rows_train_bwd_sums_f32(ptr(dy2), ptr(x2), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dg), ptr(db),
-                                                ptr(_ws(M, C_, x2.device)), ptr(parts), M, C_, slope, int(act_first), ptr(lift), stream_handle()),
-          "dlip_bn_rows_train_bwd_sums_f32")
+                                                ptr(_ws(M, C_, x2.device)), ptr(parts), M, C_, slope, int(act_first), ptr(lift), ptr(ms_c),
+                                                int(ms_T), stream_handle()), "dlip_bn_rows_train_bwd_sums_f32")
     return dg, db, lift
 
 
@@ -424,35 +426,41 @@ class TDNNBlockTrainFn(Function):
         if ctx.expect_ms and ms is None:
             raise RuntimeError("TDNNBlockTrainFn.backward: the gradient handed over by the statistics pooling (MeanStdPoolFn, hand_over) arrived "
                                "without its source -- autograd copied or accumulated the tensor; set DLIP_POOL_BWD_ON_LOAD=0")
-        if ms is not None:
+        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        no_dbias_pass = not (has_bias and ctx.needs_input_grad[2]) or (not act_first and ZERO_BIAS_GRAD_BEFORE_BN)
+        # (ABI 49) the k = 1 producer takes any K % 4 == 0 (tdnn.9's 1 500): a ragged last channel block, the split copy at a padded row pitch
+        fused = (BN_BWD_ON_LOAD and av.TRAIN_CONV == "f16x3" and mode in (1, 2) and want_w and (K % 64 == 0 or (mode == 1 and K % 4 == 0))
+                 and B * Tp > BN_SMALL_ROWS and no_dbias_pass and av.WGRAD_SLICE_MAJOR and (mode == 1 or av.WGRAD == "conv")
+                 and (ms is None or mode == 1))
+        if ms is not None and not fused:
             # dy was never written: formed per loaded value inside the BatchNorm backward from the pooled statistics and their gradient
-            y_pool, g_pool, T_ms = ms
+            coef_ms, T_ms = ms
             M = B * Tp
             _lib.ensure_conv_workspace()
             dz2 = torch.empty((M, K), device=dev, dtype=torch.float32)
             dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
             lift = torch.empty((LIFT_WORDS,), device=dev, dtype=torch.float32)
-            check(lib().dlip_bn_rows_train_bwd_ms_f32(ptr(y_pool), ptr(g_pool), int(T_ms), ptr(z), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd),
+            check(lib().dlip_bn_rows_train_bwd_ms_f32(ptr(coef_ms), int(T_ms), ptr(z), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd),
                                                       ptr(dz2), ptr(dgamma), ptr(dbeta), ptr(_ws(M, K, dev)), M, K, float(slope), ptr(lift),
                                                       stream_handle()), "dlip_bn_rows_train_bwd_ms_f32")
             dz2._dlip_lift = lift
             return TDNNBlockTrainFn._backward_from_dz(ctx, dz2, dgamma, dbeta)
-        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        no_dbias_pass = not (has_bias and ctx.needs_input_grad[2]) or (not act_first and ZERO_BIAS_GRAD_BEFORE_BN)
-        if (BN_BWD_ON_LOAD and av.TRAIN_CONV == "f16x3" and mode in (1, 2) and want_w and K % 64 == 0 and B * Tp > BN_SMALL_ROWS and no_dbias_pass
-                and av.WGRAD_SLICE_MAJOR and (mode == 1 or av.WGRAD == "conv")):
-            # dz is never stored: sums + lift, then the producers form it on load (see BN_BWD_ON_LOAD)
-            dy2, z2 = dy.contiguous().view(B * Tp, K), z.view(B * Tp, K)
-            dgamma, dbeta, lift = _bn_rows_bwd_sums(dy2, z2, gamma, beta, mean, invstd, slope, act_first)
+        if fused:
+            # dz is never stored: sums + lift, then the producers form it on load (see BN_BWD_ON_LOAD); with ``ms`` dy is not stored either
+            dy2, z2 = (dy.contiguous().view(B * Tp, K) if ms is None else None), z.view(B * Tp, K)
+            dgamma, dbeta, lift = _bn_rows_bwd_sums(dy2, z2, gamma, beta, mean, invstd, slope, act_first, ms)
+            ms_c, ms_T = ms if ms is not None else (None, 0)
             dbias = torch.zeros((K,), device=dev, dtype=torch.float32) if has_bias and ctx.needs_input_grad[2] else None
             M = B * Tp
             sl = float(slope)
+            Kp = (K + 31) // 32 * 32                     # row pitch of the data gradient's split operand (K % 32 != 0: zero-padded channels)
             if mode == 1:
                 J32 = x.shape[1]
                 gT = torch.empty((K, J32), device=dev, dtype=torch.float32)
-                dzs = torch.empty((B, 1, Tp, K), device=dev, dtype=torch.float32) if want_x else None
+                dzs = torch.empty((B, 1, Tp, Kp), device=dev, dtype=torch.float32) if want_x else None
                 check(lib().dlip_wgrad_operand_split_bnbwd_f32(ptr(dy2), ptr(z2), ptr(gT), J32, M, K, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
-                                                               ptr(dgamma), ptr(dbeta), M, sl, int(act_first), ptr(lift), ptr(dzs), stream_handle()),
+                                                               ptr(dgamma), ptr(dbeta), M, sl, int(act_first), ptr(lift), ptr(dzs),
+                                                               Kp if Kp != K else 0, ptr(ms_c), int(ms_T), stream_handle()),
                       "dlip_wgrad_operand_split_bnbwd_f32")
             else:
                 N32 = (B + 31) // 32 * 32
@@ -606,7 +614,9 @@ class MeanStdPoolFn(Function):
                 # The block in front forms this gradient itself, per loaded value, inside its BatchNorm backward (MsSrc,
                 # dlip_bn_rows_train_bwd_ms_f32): dx stays UNWRITTEN and carries what that takes.  TDNNBlockTrainFn.backward raises if the
                 # tensor it receives has lost the attribute (it was told at forward time to expect it).
-                dx._dlip_ms = (y, dy.contiguous(), T)
+                coef = torch.empty_like(y)            # [B, 2C] = (A | K): dy[b,t,c] = A + K y, one launch over the pooled tensors
+                check(lib().dlip_meanstd_bwd_coef_f32(ptr(y), ptr(dy.contiguous()), ptr(coef), B, C_, T, stream_handle()), "dlip_meanstd_bwd_coef_f32")
+                dx._dlip_ms = (coef, T)
                 return dx, None, None
             check(lib().dlip_meanstd_pool_bwd_bn_f32(ptr(z), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ctx.slope, ptr(y), ptr(dy.contiguous()),
                                                      ptr(dx), B, T, C_, stream_handle()), "dlip_meanstd_pool_bwd_bn_f32")

@@ -273,7 +273,7 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
             Cw = Cx
         # a lifted gradient whose channel count is a multiple of 4 but not of 32 (1500): split with its rows zero-padded to the next 32
         pad_x = Cx
-        if transposed and lift and TRAIN_CONV == "f16x3" and Cx % 32 and Cx % 4 == 0 and K % 4 == 0 and Cw == Cx and xs_ready is None:
+        if transposed and lift and TRAIN_CONV == "f16x3" and Cx % 32 and Cx % 4 == 0 and K % 4 == 0 and Cw == Cx and (xs_ready is None or scale2 is not None):
             pad_x = (Cx + 31) // 32 * 32
             dev = x.device
             if scale2 is None:
@@ -282,8 +282,11 @@ def conv_train(x, w_krsc, bias, stride=(1, 1), pad=(0, 0), dil=(1, 1), lift=Fals
             wsc = torch.empty((K,), device=dev, dtype=torch.float32)
             check(lib().dlip_split_weights_perm_f32(ptr(w_ref.contiguous()), ptr(ws), ptr(wsc), Ko, Ci, R_ * S_, 1, pad_x, stream_handle()),
                   "dlip_split_weights_perm_f32")
-            xs = torch.empty((N, H, W, pad_x), device=dev, dtype=torch.float32)
-            check(lib().dlip_split_pack_scaled_pad_f32(ptr(x), ptr(xs), ptr(scale2), N * H * W, Cx, pad_x, stream_handle()), "dlip_split_pack_scaled_pad_f32")
+            if xs_ready is not None:       # (round 6) the padded split operand [N,H,W,pad_x], lifted by scale2, written by the pass that formed the gradient
+                xs = xs_ready
+            else:
+                xs = torch.empty((N, H, W, pad_x), device=dev, dtype=torch.float32)
+                check(lib().dlip_split_pack_scaled_pad_f32(ptr(x), ptr(xs), ptr(scale2), N * H * W, Cx, pad_x, stream_handle()), "dlip_split_pack_scaled_pad_f32")
             return ops.conv_nhwc(xs, ws, None, stride=stride, pad=pad, dil=dil, w_scale=wsc, x_split=True, post_scale=lift_inv(scale2, K),
                                  post_shift=const_vec(K, 0.0, dev))
         if TRAIN_CONV != "f16x3" or Cx % 32 or K % 4 or Cw != Cx:

@@ -73,30 +73,38 @@ __device__ __forceinline__ f32x4 pooled_grad(const PoolSrc& ps, const float* __r
   return acc;
 }
 
-// (ABI 48) The gradient of a MeanStdPooling's INPUT formed on load: dy[b, t, c] = dmean[b, c] / T + dstd[b, c] (y[b, t, c] - mean[b, c]) / ((T - 1) std[b, c])
-// (meanstd_bwd_kernel's expression) with y the ACTIVATED value the BatchNorm backward recomputes anyway -- the pooling's backward then
-// writes nothing: its [B,T,C] gradient (460 MB for the E-TDNN's last layer at B = 256) was one write and two reads.
+// (ABI 48 / 49) The gradient of a MeanStdPooling's INPUT formed on load: dy[b, t, c] = dmean[b, c] / T + dstd[b, c] (y[b, t, c] - mean[b, c]) / ((T - 1) std[b, c])
+// (meanstd_bwd_kernel's expression) is A[b, c] + K[b, c] y with y the ACTIVATED value the BatchNorm backward recomputes anyway -- the pooling's
+// backward then writes nothing: its [B,T,C] gradient (460 MB for the E-TDNN's last layer at B = 256) was one write and two reads.  The two
+// coefficients per (utterance, channel) come from ms_coef_kernel (one FMA per value: with the divisions per value the passes were ALU-bound,
+// 461 us for a producer launch that moves 1.4 GB).
 struct MsSrc {
-  const float* y = nullptr;          // [B, 2 C] pooled (mean | std); nullptr: the gradient is read from memory
-  const float* g = nullptr;          // [B, 2 C] its gradient
+  const float* coef = nullptr;       // [B, 2 C] (A | K); nullptr: the gradient is read from memory
   int T = 1;                         // frames per utterance: row r belongs to utterance r / T
   FastDiv div_T;
 };
 __device__ __forceinline__ f32x4 ms_grad(const MsSrc& ms, int row, int c, int C, const f32x4 yact) {
   const int b = dlip_div(row, ms.div_T);
-  const float* yb = ms.y + (long long)b * 2 * C + c;
-  const float* gb = ms.g + (long long)b * 2 * C + c;
-  const f32x4 mean = *reinterpret_cast<const f32x4*>(yb), sd = *reinterpret_cast<const f32x4*>(yb + C);
-  const f32x4 gm = *reinterpret_cast<const f32x4*>(gb), gsd = *reinterpret_cast<const f32x4*>(gb + C);
+  const float* cb = ms.coef + (long long)b * 2 * C + c;
+  const f32x4 A = *reinterpret_cast<const f32x4*>(cb), K = *reinterpret_cast<const f32x4*>(cb + C);
   f32x4 o;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float a = gm[k] / (float)ms.T;
-    const float gs = sd[k] > 0.f ? gsd[k] : 0.f;
-    const float den = sd[k] > 0.f ? (float)(ms.T - 1) * sd[k] : 1.f;
-    o[k] = a + gs * (yact[k] - mean[k]) / den;
-  }
+  for (int k = 0; k < 4; ++k) o[k] = fmaf(K[k], yact[k], A[k]);
   return o;
+}
+// coef[b, c] = A = dmean / T - K mean, coef[b, C + c] = K = dstd / ((T - 1) std) (0 where std == 0: no gradient through it)
+__global__ __launch_bounds__(256) void ms_coef_kernel(const float* __restrict__ y, const float* __restrict__ g, float* __restrict__ coef, int B,
+                                                      int C, int T) {
+  const long long n = (long long)B * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long b = i / C;
+    const int c = (int)(i - b * C);
+    const float mean = y[b * 2 * C + c], sd = y[b * 2 * C + C + c];
+    const float gm = g[b * 2 * C + c], gsd = g[b * 2 * C + C + c];
+    const float K = sd > 0.f ? gsd / ((float)(T - 1) * sd) : 0.f;
+    coef[b * 2 * C + c] = gm / (float)T - K * mean;
+    coef[b * 2 * C + C + c] = K;
+  }
 }
 
 struct ColFin {
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
           s0[k] += a; s1[k] += a * a;
         }
       } else if (MODE == 1) {
-        if (fin.ms.y != nullptr) {      // (workgroup-uniform; act_first == 0) the gradient from the pooled one, at the activated value
+        if (fin.ms.coef != nullptr) {      // (workgroup-uniform; act_first == 0) the gradient from the pooled one, at the activated value
           f32x4 ya;
 #pragma unroll
           for (int k = 0; k < 4; ++k) ya[k] = lrelu((xv[k] - mu[k]) * is[k] * ga[k] + be[k], slope);
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     // four rows of a lane group per trip, their loads issued together (one load in flight per lane held a pass at half of what
     // the memory system gives once a part is longer than a few trips)
     constexpr bool TWO_ = MODE == 1 || MODE == 3;
-    const bool TWO = TWO_ && !(MODE == 1 && fin.ms.y != nullptr);      // (a gradient formed on load is not read)
+    const bool TWO = TWO_ && !(MODE == 1 && fin.ms.coef != nullptr);      // (a gradient formed on load is not read)
     int r = r0 + rg;
     for (; r + 48 < r1; r += 64) {
       f32x4 xv[4], gv[4];
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const f32x4* __restri
     const f32x4 xv = x[i];
     f32x4 gv;
     if constexpr (POOL) { const int row = (int)(i / C4); gv = pooled_grad(ps, reinterpret_cast<const float*>(dy), row, (int)(i - (long long)row * C4) * 4, C4 * 4); }
-    else if (ms.y != nullptr) {       // (launch-uniform; act_first == 0) see MsSrc
+    else if (ms.coef != nullptr) {       // (launch-uniform; act_first == 0) see MsSrc
       const int row = (int)(i / C4);
       f32x4 ya;
 #pragma unroll
@@ -1445,16 +1453,23 @@ extern "C" int dlip_bn_rows_train_bwd_f32(const float* dy, const float* x, const
 // (ABI 48) dlip_bn_rows_train_bwd_f32 behind a MeanStdPooling whose backward writes nothing: dy is formed per loaded value from the pooled
 // statistics y_pool [B,2C] and their gradient g_pool [B,2C] (MsSrc; M = B T rows, conv -> BatchNorm -> LeakyReLU order, more than
 // BN_SMALL_ROWS rows).
-extern "C" int dlip_bn_rows_train_bwd_ms_f32(const float* y_pool, const float* g_pool, int32_t T, const float* x, const float* gamma,
-                                             const float* beta, const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
-                                             float* dbeta, double* workspace, int32_t M, int32_t C, float slope, float* dx_lift2,
-                                             dlip_stream_t stream) {
-  DLIP_CHECK_ARG(y_pool && g_pool && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace);
+extern "C" int dlip_meanstd_bwd_coef_f32(const float* y_pool, const float* g_pool, float* coef, int32_t B, int32_t C, int32_t T,
+                                         dlip_stream_t stream) {
+  DLIP_CHECK_ARG(y_pool && g_pool && coef && B > 0 && C > 0 && T > 1);
+  const long long n = (long long)B * C;
+  hipLaunchKernelGGL(ms_coef_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     y_pool, g_pool, coef, B, C, T);
+  return dlip_launch_status();
+}
+
+extern "C" int dlip_bn_rows_train_bwd_ms_f32(const float* ms_coef, int32_t T, const float* x, const float* gamma, const float* beta,
+                                             const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                                             double* workspace, int32_t M, int32_t C, float slope, float* dx_lift2, dlip_stream_t stream) {
+  DLIP_CHECK_ARG(ms_coef && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace);
   DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0 && T > 1 && M % T == 0 && !bn_small(M));
-  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(y_pool) |
-                   reinterpret_cast<uintptr_t>(g_pool)) & 15) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(ms_coef)) & 15) == 0);
   MsSrc ms;
-  ms.y = y_pool; ms.g = g_pool; ms.T = T; ms.div_T = dlip_fastdiv((uint32_t)T);
+  ms.coef = ms_coef; ms.T = T; ms.div_T = dlip_fastdiv((uint32_t)T);
   return bn_bwd_launch(x /* never read as dy */, x, gamma, beta, nullptr, save_mean, save_invstd, dx, dgamma, dbeta, nullptr, workspace, M, C, slope, 0,
                        dx_lift2, static_cast<hipStream_t>(stream), ms);
 }
@@ -1463,16 +1478,21 @@ extern "C" int dlip_bn_rows_train_bwd_ms_f32(const float* y_pool, const float* g
 // producers of the convolution in front form dx per loaded value (dlip_wgrad_operand_split_bnbwd_f32 / dlip_wgrad_chwn_bnbwd_f32).
 extern "C" int dlip_bn_rows_train_bwd_sums_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                                                const float* save_invstd, float* dgamma, float* dbeta, double* workspace, float* amax_parts,
-                                               int32_t M, int32_t C, float slope, int32_t act_first, float* dx_lift2, dlip_stream_t stream) {
-  DLIP_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dgamma && dbeta && workspace && amax_parts && dx_lift2);
+                                               int32_t M, int32_t C, float slope, int32_t act_first, float* dx_lift2, const float* ms_coef,
+                                               int32_t ms_T, dlip_stream_t stream) {
+  // (ABI 49) ms_coef / ms_T (nullable): dy formed on load from a MeanStdPooling's coefficients (dlip_meanstd_bwd_coef_f32; MsSrc); dy may then be NULL
+  DLIP_CHECK_ARG(x && gamma && beta && save_mean && save_invstd && dgamma && dbeta && workspace && amax_parts && dx_lift2);
+  DLIP_CHECK_ARG((dy != nullptr || ms_coef != nullptr) && (ms_coef == nullptr || (ms_T > 1 && !act_first && M % ms_T == 0)));
   DLIP_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0);
-  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0);
+  DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ms_coef)) & 15) == 0);
+  if (dy == nullptr) dy = x;           // (never read)
   hipStream_t st = static_cast<hipStream_t>(stream);
   int* tickets = stream_tickets(st, (C + 63) / 64);
   const int chunks = dlip_bn_rows_chunks(M);
   const int rpp = bn_rows_per_part(M);
   ColFin fin = {tickets, dbeta, dgamma, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
   fin.amax_parts = reinterpret_cast<unsigned*>(amax_parts);
+  if (ms_coef != nullptr) { fin.ms.coef = ms_coef; fin.ms.T = ms_T; fin.ms.div_T = dlip_fastdiv((uint32_t)ms_T); }
   hipLaunchKernelGGL(col_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, save_mean, save_invstd, gamma, beta, workspace, M,
                      C, slope, act_first, nullptr, rpp, fin);
   if (!tickets) hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, dbeta, dgamma, C, chunks);

@@ -117,6 +117,11 @@ struct BnOnLoad {
   const float* dbeta = nullptr;
   float invM = 0.f;
   int act_first = 0;
+  // (ABI 49) ... with dy itself formed on load from a MeanStdPooling's pooled statistics and their gradient (encoder_train_ops.hip: MsSrc): then
+  // the first source is not read at all
+  const float* ms_coef = nullptr;    // [B, 2 C] (A | K): dy = A + K y (dlip_meanstd_bwd_coef_f32)
+  int ms_T = 1;
+  int C = 0;                         // channels of the tensor (the last CT-wide block of a launch may be ragged)
 };
 __device__ __forceinline__ float bnl_lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
 template <int CT>
@@ -124,15 +129,33 @@ __device__ __forceinline__ void bn_bwd_on_load_stage(const BnOnLoad& b, int c0, 
   for (int i = threadIdx.x; i < 6 * (CT / 4); i += 256) {
     const int w = i / (CT / 4), c = (i - w * (CT / 4)) * 4;
     const float* src = w == 0 ? b.mean : w == 1 ? b.invstd : w == 2 ? b.gamma : w == 3 ? b.beta : w == 4 ? b.dgamma : b.dbeta;
-    *reinterpret_cast<f32x4*>(tab + w * CT + c) = *reinterpret_cast<const f32x4*>(src + c0 + c);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c0 + c < b.C) v = *reinterpret_cast<const f32x4*>(src + c0 + c);      // (C % 4 == 0: a quad is all inside or all outside)
+    *reinterpret_cast<f32x4*>(tab + w * CT + c) = v;
   }
   __syncthreads();
 }
+// dy[row, c ..] = A + K ya from the pooling's coefficients (encoder_train_ops.hip: ms_grad) at the activated values ya
+__device__ __forceinline__ f32x4 bnl_ms_grad(const BnOnLoad& b, int row, int c, const f32x4 ya) {
+  const int u = row / b.ms_T;
+  const float* cb = b.ms_coef + (long long)u * 2 * b.C + c;
+  const f32x4 A = *reinterpret_cast<const f32x4*>(cb), K = *reinterpret_cast<const f32x4*>(cb + b.C);
+  f32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = fmaf(K[k], ya[k], A[k]);
+  return o;
+}
 template <int CT>
-__device__ __forceinline__ f32x4 bn_bwd_on_load(const float* tab, const BnOnLoad& b, f32x4 gv, f32x4 xv, int c) {
+__device__ __forceinline__ f32x4 bn_bwd_on_load(const float* tab, const BnOnLoad& b, f32x4 gv, f32x4 xv, int c, int row = 0, int cabs = 0) {
   const f32x4 mu = *reinterpret_cast<const f32x4*>(tab + c), is = *reinterpret_cast<const f32x4*>(tab + CT + c);
   const f32x4 ga = *reinterpret_cast<const f32x4*>(tab + 2 * CT + c), be = *reinterpret_cast<const f32x4*>(tab + 3 * CT + c);
   const f32x4 dg = *reinterpret_cast<const f32x4*>(tab + 4 * CT + c), db = *reinterpret_cast<const f32x4*>(tab + 5 * CT + c);
+  if (b.ms_coef != nullptr) {          // (launch-uniform; act_first == 0)
+    f32x4 ya;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ya[k] = bnl_lrelu((xv[k] - mu[k]) * is[k] * ga[k] + be[k], b.slope);
+    gv = bnl_ms_grad(b, row, cabs, ya);
+  }
   f32x4 o;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -179,11 +202,14 @@ __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __
                                                                  int C, int Ho, int Wo, int sh, int sw, int R, int S, int dh, int dw, int ph,
                                                                  int pw, int J, long long ldo, const float* __restrict__ scale,
                                                                  DlipRange status, float* __restrict__ nhwc_out = nullptr,
-                                                                 const BnOnLoad bn = BnOnLoad{}) {
+                                                                 const BnOnLoad bn = BnOnLoad{}, int ld_nhwc = 0) {
+  // (ABI 49, AFF == 2 only) C need not be a multiple of CT: the last channel block is ragged -- quads beyond C load as zeros, rows beyond C
+  // of the image are not written, and the split NHWC copy has the row pitch ld_nhwc >= C (a multiple of 32: its padding channels are zeros)
   constexpr int PITCH = CT + 4, Q = CT / 32;
   __shared__ __attribute__((aligned(16))) float tile[32 * PITCH];
   __shared__ __attribute__((aligned(16))) float bn_tab[AFF == 2 ? 6 * CT : AFF == 1 ? 5 * CT : 4];
   const int j0 = blockIdx.x * 32, c0 = blockIdx.y * CT;
+  const int ldn = ld_nhwc > 0 ? ld_nhwc : C;
   const float sc = scale ? scale[0] : 1.f;
   if constexpr (AFF == 1) bn_on_load_stage<CT>(bn, c0, bn_tab);
   if constexpr (AFF == 2) bn_bwd_on_load_stage<CT>(bn, c0, bn_tab);
@@ -209,11 +235,12 @@ __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __
     for (int q = 0; q < Q; ++q) {
       const int hi = hi0[q] + r * dh, wi = wi0[q] + s_ * dw;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W && (AFF != 2 || c0 + col[q] < C)) {
         const long long off = ((long long)(base[q] + hi) * W + wi) * ldx + c0 + col[q];
-        v = *reinterpret_cast<const f32x4*>(x + off);
+        if (AFF != 2 || bn.ms_coef == nullptr) v = *reinterpret_cast<const f32x4*>(x + off);
         if constexpr (AFF == 1) v = bn_on_load<CT>(bn_tab, v, col[q]);
-        if constexpr (AFF == 2) v = bn_bwd_on_load<CT>(bn_tab, bn, v, *reinterpret_cast<const f32x4*>(bn.z + off), col[q]);
+        if constexpr (AFF == 2)      // (one tap, stride 1: position j IS row j of the tensor)
+          v = bn_bwd_on_load<CT>(bn_tab, bn, v, *reinterpret_cast<const f32x4*>(bn.z + off), col[q], j0 + row_[q], c0 + col[q]);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] *= sc;
@@ -231,7 +258,8 @@ __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __
         o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
         amax = fmaxf(amax, fabsf(v));
       }
-      *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + ((long long)tap * C + c0 + cr) * ldo + j0) + (pq < 4 ? 0 : 32) + jb) = o;
+      if (AFF != 2 || c0 + cr < C)
+        *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out + ((long long)tap * C + c0 + cr) * ldo + j0) + (pq < 4 ? 0 : 32) + jb) = o;
     }
     if (nhwc_out) {   // (one tap, stride 1, no padding: position j IS row j of x) the same tile as split NHWC rows, from the one read
 #pragma unroll
@@ -244,8 +272,8 @@ __global__ __launch_bounds__(256) void wgrad_operand_wide_kernel(const float* __
           const _Float16 hi = (_Float16)v;
           o[e] = pq < 4 ? hi : (_Float16)(v - (float)hi);
         }
-        if (j0 + nl < J)
-          *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(nhwc_out + (long long)(j0 + nl) * C + c0 + cb * 32) + (pq < 4 ? 0 : 32) + jb) = o;
+        if (j0 + nl < J && c0 + cb * 32 < ldn)
+          *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(nhwc_out + (long long)(j0 + nl) * ldn + c0 + cb * 32) + (pq < 4 ? 0 : 32) + jb) = o;
       }
     }
     __syncthreads();
@@ -870,19 +898,29 @@ extern "C" int dlip_wgrad_chwn_bn_f32(const float* x, float* out, int64_t N, int
 extern "C" int dlip_wgrad_operand_split_bnbwd_f32(const float* dy, const float* z, float* out, int64_t ld_out, int64_t J, int32_t C,
                                                   const float* mean, const float* invstd, const float* gamma, const float* beta,
                                                   const float* dgamma, const float* dbeta, int64_t M, float slope, int32_t act_first,
-                                                  const float* lift, float* nhwc_split_out, dlip_stream_t stream) {
-  DLIP_CHECK_ARG(dy && z && out && mean && invstd && gamma && beta && dgamma && dbeta && lift && J > 0 && J < (1ll << 28) && M > 0 && C > 0 &&
-                 (C & 63) == 0 && ld_out >= J && (ld_out & 31) == 0);
+                                                  const float* lift, float* nhwc_split_out, int32_t ld_nhwc, const float* ms_coef,
+                                                  int32_t ms_T, dlip_stream_t stream) {
+  // (ABI 49) C % 4 == 0 is enough (a ragged last channel block); ld_nhwc: row pitch of nhwc_split_out (0 = C; else >= C, a multiple of 32);
+  // ms_coef / ms_T: dy formed on load from a MeanStdPooling's coefficients (dlip_meanstd_bwd_coef_f32; then dy may be NULL)
+  DLIP_CHECK_ARG(z && out && mean && invstd && gamma && beta && dgamma && dbeta && lift && J > 0 && J < (1ll << 28) && M > 0 && C > 0 &&
+                 (C & 3) == 0 && ld_out >= J && (ld_out & 31) == 0);
+  DLIP_CHECK_ARG((dy != nullptr || ms_coef != nullptr) && (ms_coef == nullptr || (ms_T > 1 && !act_first && J % ms_T == 0)));
+  DLIP_CHECK_ARG(ld_nhwc == 0 ? (C & 31) == 0 || nhwc_split_out == nullptr : (ld_nhwc >= C && (ld_nhwc & 31) == 0));
   DLIP_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(nhwc_split_out)) & 127) == 0 &&
-                 ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(z)) & 15) == 0 && C / 64 <= 65535);
+                 ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(ms_coef)) & 15) == 0 &&
+                 (C + 63) / 64 <= 65535);
   BnOnLoad bn = {mean, invstd, gamma, beta, nullptr, slope};
   bn.z = z; bn.dgamma = dgamma; bn.dbeta = dbeta; bn.invM = 1.f / (float)M; bn.act_first = act_first;
-  if (C % 128 == 0)
-    hipLaunchKernelGGL((wgrad_operand_wide_kernel<128, 2>), dim3((unsigned)(ld_out / 32), (unsigned)(C / 128)), dim3(256), 0, ST(stream), dy, out,
-                       1, 1, C, C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, lift, dlip_range_for(DLIP_ST_PACK), nhwc_split_out, bn);
+  bn.ms_coef = ms_coef; bn.ms_T = ms_T > 0 ? ms_T : 1; bn.C = C;
+  const float* src = dy ? dy : z;      // (never read when the gradient is formed on load)
+  if (C % 128 == 0 || C > 512)      // (a ragged last block of 128 wastes less than the 64-wide tile costs: 461 -> us on the E-TDNN's 1 500 channels)
+    hipLaunchKernelGGL((wgrad_operand_wide_kernel<128, 2>), dim3((unsigned)(ld_out / 32), (unsigned)((C + 127) / 128)), dim3(256), 0, ST(stream), src, out,
+                       1, 1, C, C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, lift, dlip_range_for(DLIP_ST_PACK), nhwc_split_out, bn,
+                       ld_nhwc);
   else
-    hipLaunchKernelGGL((wgrad_operand_wide_kernel<64, 2>), dim3((unsigned)(ld_out / 32), (unsigned)(C / 64)), dim3(256), 0, ST(stream), dy, out,
-                       1, 1, C, C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, lift, dlip_range_for(DLIP_ST_PACK), nhwc_split_out, bn);
+    hipLaunchKernelGGL((wgrad_operand_wide_kernel<64, 2>), dim3((unsigned)(ld_out / 32), (unsigned)((C + 63) / 64)), dim3(256), 0, ST(stream), src,
+                       out, 1, 1, C, C, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, (int)J, (long long)ld_out, lift, dlip_range_for(DLIP_ST_PACK), nhwc_split_out,
+                       bn, ld_nhwc);
   return dlip_launch_status();
 }
 
@@ -896,7 +934,7 @@ extern "C" int dlip_wgrad_chwn_bnbwd_f32(const float* dy, const float* z, float*
                  ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(z)) & 15) == 0 && (long long)H * W <= 65535 && C / 64 <= 65535 &&
                  N < (1ll << 31));
   BnOnLoad bn = {mean, invstd, gamma, beta, nullptr, slope};
-  bn.z = z; bn.dgamma = dgamma; bn.dbeta = dbeta; bn.invM = 1.f / (float)M; bn.act_first = act_first;
+  bn.z = z; bn.dgamma = dgamma; bn.dbeta = dbeta; bn.invM = 1.f / (float)M; bn.act_first = act_first; bn.C = C;
   if (C % 128 == 0)
     hipLaunchKernelGGL((wgrad_chwn_wide_kernel<128, 2>), dim3((unsigned)(N32 / 32), (unsigned)(C / 128), (unsigned)(H * W)), dim3(256), 0,
                        ST(stream), dy, out, (int)N, H * W, C, C, N32, lift, dlip_range_for(DLIP_ST_PACK), 1, nhwc_split_out, bn);

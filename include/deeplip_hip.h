@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DLIP_ABI_VERSION 48
+#define DLIP_ABI_VERSION 49
 #define DLIP_LIFT_WORDS 4098   /* a gradient's power-of-two lift: (2^e, 2^-e), then 2^-e repeated 2048 times (the post_scale vector of
                                   the convolution that consumes the lifted gradient); while it is formed the words behind the pair
                                   hold one maximum per workgroup of the producing pass */
@@ -681,17 +681,24 @@ int dlip_meanstd_pool_bwd_bn_f32(const float* z, const float* mean, const float*
 /* (ABI 48) ... and the BatchNorm backward BEHIND that pooling with the pooling's backward formed on load: dy[b,t,c] = dmean / T + dstd (y - mean) /
  * ((T - 1) std) per loaded value from the pooled statistics y_pool [B,2C] and their gradient g_pool [B,2C] (y = the activated value the
  * BatchNorm backward recomputes anyway) -- the pooling's backward writes nothing (its [B,T,C] gradient was one write and two reads).  Otherwise
- * dlip_bn_rows_train_bwd_f32 (conv -> BatchNorm -> LeakyReLU order; M = B T > 4096 rows). */
-int dlip_bn_rows_train_bwd_ms_f32(const float* y_pool, const float* g_pool, int32_t T, const float* x, const float* gamma, const float* beta,
-                                  const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, double* workspace,
-                                  int32_t M, int32_t C, float slope, float* dx_lift2, dlip_stream_t stream);
+ * dlip_bn_rows_train_bwd_f32 (conv -> BatchNorm -> LeakyReLU order; M = B T > 4096 rows).  The gradient is A[b,c] + K[b,c] y: the two
+ * coefficients per (utterance, channel) -- coef [B,2C] = (A | K) -- come from dlip_meanstd_bwd_coef_f32 (ABI 49), one launch over [B,2C]. */
+int dlip_meanstd_bwd_coef_f32(const float* y_pool, const float* g_pool, float* coef, int32_t B, int32_t C, int32_t T, dlip_stream_t stream);
+int dlip_bn_rows_train_bwd_ms_f32(const float* ms_coef, int32_t T, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                                  const float* save_invstd, float* dx, float* dgamma, float* dbeta, double* workspace, int32_t M, int32_t C,
+                                  float slope, float* dx_lift2, dlip_stream_t stream);
 int dlip_bn_rows_train_bwd_sums_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
                                     const float* save_invstd, float* dgamma, float* dbeta, double* workspace, float* amax_parts, int32_t M,
-                                    int32_t C, float slope, int32_t act_first, float* dx_lift2, dlip_stream_t stream);
+                                    int32_t C, float slope, int32_t act_first, float* dx_lift2, const float* ms_coef, int32_t ms_T,
+                                    dlip_stream_t stream);
+/* (ABI 49) both take ms_coef [B,2C] + ms_T (nullable: then as ABI 47): dy is itself formed on load from a MeanStdPooling's coefficients
+ * (dlip_bn_rows_train_bwd_ms_f32's rule; dy may be NULL) -- the last TDNN layer's whole backward then reads z alone.  The operand
+ * producer also takes a channel count that is no multiple of 64 (C % 4 == 0: the E-TDNN's 1 500) and the row pitch ld_nhwc of its split copy
+ * (0 = C; else >= C, a multiple of 32, the padding channels written as zeros). */
 int dlip_wgrad_operand_split_bnbwd_f32(const float* dy, const float* z, float* out, int64_t ld_out, int64_t J, int32_t C, const float* mean,
                                        const float* invstd, const float* gamma, const float* beta, const float* dgamma, const float* dbeta,
-                                       int64_t M, float slope, int32_t act_first, const float* lift, float* nhwc_split_out,
-                                       dlip_stream_t stream);
+                                       int64_t M, float slope, int32_t act_first, const float* lift, float* nhwc_split_out, int32_t ld_nhwc,
+                                       const float* ms_coef, int32_t ms_T, dlip_stream_t stream);
 int dlip_wgrad_chwn_bnbwd_f32(const float* dy, const float* z, float* out, int64_t N, int32_t H, int32_t W, int32_t C, int32_t N32,
                               const float* mean, const float* invstd, const float* gamma, const float* beta, const float* dgamma,
                               const float* dbeta, int64_t M, float slope, int32_t act_first, const float* lift, float* nhwc_split_out,

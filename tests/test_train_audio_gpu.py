@@ -336,7 +336,9 @@ def test_full_size_training_step_vs_fp64_oracle():
 
 
 @pytest.mark.parametrize("B,T,C,K,S,dil,act_first", [(40, 120, 64, 128, 1, 1, False), (40, 120, 64, 128, 3, 2, False), (24, 200, 128, 64, 5, 1, False),
-                                                     (40, 120, 64, 128, 1, 1, True), (36, 130, 64, 192, 3, 1, False)])
+                                                     (40, 120, 64, 128, 1, 1, True), (36, 130, 64, 192, 3, 1, False),
+                                                     # (ABI 49) a k = 1 layer whose width is no multiple of 64 / of 32: the ragged last channel block
+                                                     (40, 120, 64, 100, 1, 1, False), (20, 250, 128, 1500, 1, 1, False)])
 def test_tdnn_block_backward_with_the_batchnorm_gradient_formed_on_load(B, T, C, K, S, dil, act_first, monkeypatch):
     """ABI 47: conv -> BatchNorm -> LeakyReLU under backward() at more than 4 096 rows -- the BatchNorm's input gradient dz is formed per loaded
     value by the operand producers of the convolution in front (dlip_wgrad_*_bnbwd_f32) behind a sums pass that also bounds its lift
