@@ -1,4 +1,9 @@
-import sys; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+"""Does the f16x3 range guard see a float lip clip whose gain puts it below the line?  The clip at gains 1, 2^-14, 2^10, 2^16 through embed() and
+forward() under plain f16x3, against the exact mode.  (How the stem's shared evidence slot was found: 2^-14 went unreported, EXPERIMENTS R6.12.)
+   python tools/probes/video_gain_range.py"""
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 from deeplip_amd import _lib, arith, packing, weightgen as wg
 from models.video_models.model import Lipreading
